@@ -1,0 +1,202 @@
+/*
+ * openmatch_hip.h — C ABI of the MI355X (gfx950) dense-retrieval hot path.
+ *
+ * The reference (thunlp/OpenMatch v2) has no native boundary of its own: every
+ * FLOP of its hot path runs inside un-vendored third-party libraries
+ * (HF transformers, torch ATen, faiss, NCCL).  This header is the boundary a
+ * maintainer would bind instead of those libraries; each entry point names the
+ * reference call site it replaces (paths relative to the reference tree,
+ * `src/openmatch/...`; `HF:` = installed transformers 5.15).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *     pointers are borrowed, never owned or freed by the library;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
+ *     nothing synchronises the device unless the entry point says so;
+ *   - no hidden allocation on the hot loop: scratch is a caller-provided
+ *     workspace whose size comes from the matching *_workspace_bytes();
+ *   - return value: 0 = OK, non-zero = error, message via om_last_error()
+ *     (thread-local, valid until the next failing call on that thread);
+ *   - matrices are row-major, leading dimensions in ELEMENTS.
+ */
+#ifndef OPENMATCH_HIP_H
+#define OPENMATCH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OM_ABI_VERSION 1
+
+/* element types */
+#define OM_F32 0
+#define OM_BF16 1
+
+/* GEMM epilogue activation */
+#define OM_ACT_NONE 0
+#define OM_ACT_GELU_ERF 1  /* HF "gelu"      (HF:activations.py GELUActivation)   */
+#define OM_ACT_RELU 2      /* HF "relu"      (T5 DenseReluDense)                  */
+#define OM_ACT_GELU_TANH 3 /* HF "gelu_new"  (T5 v1.1 gated act)                  */
+#define OM_ACT_MUL_RESID 0x100 /* flag: multiply by `resid` instead of adding it (gated FFN) */
+
+/* encoder architecture */
+#define OM_ARCH_BERT 0 /* HF:models/bert/modeling_bert.py  BertModel       */
+#define OM_ARCH_T5 1   /* HF:models/t5/modeling_t5.py      T5EncoderModel  */
+
+/* pooling — modeling/dense_retrieval_model.py:145-150 */
+#define OM_POOL_NONE 0
+#define OM_POOL_FIRST 1
+#define OM_POOL_MEAN 2 /* utils.py:233-235 mean_pooling */
+
+/* search precision */
+#define OM_SEARCH_F32 0           /* exact f32 MFMA scan                                   */
+#define OM_SEARCH_BF16_RESCORE 1  /* bf16 MFMA candidate scan + exact f32 re-score (same ids) */
+
+const char* om_last_error(void);
+int om_abi_version(void);
+
+/* Number of HIP devices visible, or -1 with om_last_error() set. */
+int om_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * Dense contraction  C[M,N] = act(A[M,K] · B[N,K]^T + bias[N]) + resid[M,N]
+ * (torch.nn.Linear layout: B is the [out,in] weight).  Replaces the ATen/BLAS
+ * GEMMs under every nn.Linear of HF BertLayer / T5Block and linear.py:22-23.
+ * in_dtype: OM_F32 (exact f32 MFMA, k-ordered fmaf chain) or OM_BF16
+ * (bf16 MFMA, f32 accumulate).  bias (f32) and resid (out_dtype) may be NULL.
+ * Requires K * sizeof(in) % 128 == 0.
+ * ------------------------------------------------------------------------ */
+int om_gemm_nt(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb,
+               int out_dtype, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+               const float* bias, const void* resid, int64_t ldr, int act, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Encoder forward:  ids -> hidden [B,L,H] -> pooled/head/normalised reps [B,D]
+ * Replaces  lm(**items) + pooling + head + F.normalize  in
+ * modeling/dense_retrieval_model.py:133-155 (DRModel.encode), i.e. the whole
+ * HF BertModel.forward (HF:models/bert/modeling_bert.py:623-684) or
+ * T5Stack.forward (HF:models/t5/modeling_t5.py) in eval mode.
+ * ------------------------------------------------------------------------ */
+typedef struct OmLayerWeights {
+  /* matrices: compute dtype (OM_F32 / OM_BF16), [out,in] row-major */
+  const void* qkv_w;   /* [3H,H]  rows: query | key | value                       */
+  const float* qkv_b;  /* [3H] or NULL (T5)                                       */
+  const void* o_w;     /* [H,H]                                                   */
+  const float* o_b;    /* [H] or NULL                                             */
+  const float* ln1_g;  /* BERT: attention.output.LayerNorm ; T5: layer[0].layer_norm */
+  const float* ln1_b;  /* NULL for T5 (RMSNorm)                                   */
+  const void* ffn1_w;  /* [F,H]   BERT intermediate.dense / T5 wi (wi_0 if gated) */
+  const float* ffn1_b; /* [F] or NULL                                             */
+  const void* ffn1g_w; /* [F,H]   T5 v1.1 wi_1 (linear gate) or NULL              */
+  const void* ffn2_w;  /* [H,F]                                                   */
+  const float* ffn2_b; /* [H] or NULL                                             */
+  const float* ln2_g;  /* BERT: output.LayerNorm ; T5: layer[1].layer_norm        */
+  const float* ln2_b;
+} OmLayerWeights;
+
+typedef struct OmEncoderConfig {
+  int arch;          /* OM_ARCH_*                                                 */
+  int dtype;         /* compute dtype of matrices/activations: OM_F32 | OM_BF16   */
+  int hidden;        /* H                                                         */
+  int n_layers;
+  int n_heads;
+  int head_dim;      /* 64                                                        */
+  int ffn;           /* F                                                         */
+  int vocab;
+  int max_pos;       /* BERT position table rows                                  */
+  int type_vocab;    /* BERT token-type table rows                                */
+  int act;           /* OM_ACT_*                                                  */
+  float ln_eps;      /* 1e-12 BERT, 1e-6 T5                                       */
+  int rel_buckets;   /* T5 relative_attention_num_buckets (32)                    */
+  int rel_max_dist;  /* T5 relative_attention_max_distance (128)                  */
+  int pooling;       /* OM_POOL_*                                                 */
+  int head_in;       /* LinearHead input dim  (0 = no head)                       */
+  int head_out;      /* LinearHead output dim                                     */
+  int normalize;     /* F.normalize(reps, dim=1)                                  */
+} OmEncoderConfig;
+
+typedef struct OmEncoderWeights {
+  const float* word_emb;  /* [vocab,H] f32                                        */
+  const float* pos_emb;   /* [max_pos,H] f32 (BERT)                               */
+  const float* type_emb;  /* [type_vocab,H] f32 (BERT)                            */
+  const float* emb_ln_g;  /* BERT embeddings.LayerNorm                            */
+  const float* emb_ln_b;
+  const OmLayerWeights* layers_host; /* HOST array [n_layers] of device pointers  */
+  const float* final_ln_g; /* T5 final_layer_norm.weight                          */
+  const float* rel_bias;   /* T5 block[0] relative_attention_bias [buckets,heads] f32 */
+  const float* head_w;     /* LinearHead weight [head_out,head_in] f32, or NULL   */
+} OmEncoderWeights;
+
+size_t om_encoder_workspace_bytes(const OmEncoderConfig* cfg, int64_t B, int64_t L);
+
+/* T5 relative-position bucket of `relative_position` = key_pos - query_pos, bidirectional
+ * (HF:models/t5/modeling_t5.py T5Attention._relative_position_bucket).  Host function. */
+int om_t5_relative_bucket(int relative_position, int num_buckets, int max_distance);
+
+/* input_ids / attention_mask / token_type_ids: int64 [B,L] as the reference's
+ * collators produce them (dataset/data_collator.py:27-38,78-83); token_type_ids
+ * may be NULL (treated as 0; always ignored for T5).
+ * out_hidden: [B,L,H] in cfg->dtype, or NULL.  out_reps: f32 [B,D]
+ * (D = head_out if head else H), or NULL when pooling == OM_POOL_NONE. */
+int om_encoder_forward(const OmEncoderConfig* cfg, const OmEncoderWeights* w,
+                       const int64_t* input_ids, const int64_t* attention_mask,
+                       const int64_t* token_type_ids, int64_t B, int64_t L,
+                       void* out_hidden, float* out_reps, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Exact inner-product search.  Replaces faiss.IndexFlatIP.add / .search
+ * (retriever/dense_retriever.py:38-41,105,180) and faiss-GPU sharding (:43-58).
+ * ------------------------------------------------------------------------ */
+
+/* index.add(): make the bf16 shadow copy of rows [0,N) and accumulate the
+ * rounding statistics the certified candidate margin needs.
+ * stats: device float[2] = {max_i ||p_i - bf16(p_i)||_2 , max_i ||bf16(p_i)||_2},
+ * updated with max (initialise to 0 before the first add). */
+int om_index_to_bf16(const float* rows_f32, int64_t N, int d, void* rows_bf16, float* stats,
+                     void* stream);
+
+size_t om_sim_topk_workspace_bytes(int64_t n_queries, int d, int k);
+
+/* D,I = index.search(x, k):  scores[Q,k] f32 sorted descending, ids[Q,k] int64 =
+ * id_offset + row, padded with (-3.4028235e38, -1) when N < k (faiss semantics).
+ * Ties are ordered by ascending row.  mode OM_SEARCH_BF16_RESCORE needs
+ * index_bf16 + stats from om_index_to_bf16; returned scores are always the
+ * exact f32 inner products.  Synchronises `stream` internally (reads back
+ * overflow flags between scan rounds).  k <= 2048. */
+int om_sim_topk(int mode, const float* queries, int64_t n_queries, const float* index_f32,
+                const void* index_bf16, const float* stats, int64_t N, int d, int k,
+                int64_t id_offset, float* out_scores, int64_t* out_ids, void* workspace,
+                size_t workspace_bytes, void* stream);
+
+/* Merge W partial results (utils.py:215-229 merge_retrieval_results_by_score /
+ * faiss shard merge): parts are [W][Q,k_in] row-major, each row descending;
+ * entries with id < 0 are padding.  Output [Q,k_out] descending; ties keep
+ * (part, position) order (python's stable sorted(reverse=True)). */
+int om_topk_merge(const float* part_scores, const int64_t* part_ids, int W, int64_t n_queries,
+                  int k_in, int k_out, float* out_scores, int64_t* out_ids, void* stream);
+
+/* ------------------------------------------------------------------------
+ * In-batch-negatives contrastive loss, forward + backward in one call.
+ * Replaces  scores = q @ p.T ; CrossEntropyLoss(mean)(scores, arange(Q)*n_psg)
+ * (modeling/dense_retrieval_model.py:113-122, loss.py:9-15) and its autograd.
+ *   q [Qg,d], p [Pg,d] f32 (already all-gathered when negatives_x_device);
+ *   loss = loss_scale * mean_i CE(scores[i,:], i*n_psg);
+ *   d_q [q_rows,d], d_p [p_rows,d]: gradient of loss w.r.t. the LOCAL slices
+ *   q[q_row0 : q_row0+q_rows], p[p_row0 : p_row0+p_rows] (the reference's
+ *   all_gather re-inserts only the local tensor: :247-258).
+ * scores (f32 [Qg,Pg]) may be NULL; d_q / d_p may be NULL (forward only).
+ * workspace: (2*Qg*Pg + Qg) floats.
+ * ------------------------------------------------------------------------ */
+int om_contrastive_fwd_bwd(const float* q, const float* p, int Qg, int Pg, int d, int n_psg,
+                           float loss_scale, int q_row0, int q_rows, int p_row0, int p_rows,
+                           float* loss, float* scores, float* d_q, float* d_p, float* workspace,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENMATCH_HIP_H */

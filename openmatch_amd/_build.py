@@ -1,0 +1,69 @@
+"""Builds libopenmatch_hip.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+No torch involvement: the library is plain HIP + a C ABI (include/openmatch_hip.h); the
+Python side binds it with ctypes.  `python -m openmatch_amd._build` rebuilds it.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+REPO = os.path.dirname(HERE)
+OBJ_DIR = os.path.join(REPO, "build", "obj")
+LIB_PATH = os.path.join(CSRC, "libopenmatch_hip.so")
+ARCH = "gfx950"
+SOURCES = ["abi.cpp", "gemm.hip", "elementwise.hip", "attention.hip", "encoder.hip",
+           "search.hip", "contrastive.hip", "train.hip"]
+HEADERS = ["common.h", "gemm_core.h", "kernels.h", os.path.join("..", "..", "include", "openmatch_hip.h")]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the MI355X build needs ROCm's hipcc on PATH")
+    return exe
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths if os.path.exists(p))
+
+
+def build_native(force=False, verbose=False):
+    """Compile every translation unit for gfx950 and link the shared library. Returns its path."""
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-x", "hip", "-Wno-unused-result"]
+    hdr_time = _newest(hdrs)
+
+    def compile_one(src):
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
+        if (not force and os.path.exists(obj)
+                and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time)):
+            return obj, False
+        cmd = [hipcc] + flags + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        return obj, True
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(compile_one, srcs))
+    objs = [o for o, _ in results]
+    if force or any(ch for _, ch in results) or not os.path.exists(LIB_PATH):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_native(force="--force" in sys.argv, verbose=True))

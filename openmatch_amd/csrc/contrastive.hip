@@ -1,0 +1,101 @@
+// In-batch-negatives contrastive loss, forward + backward (K10 + K11).
+// Replaces  scores = q @ p.T ; CrossEntropyLoss(mean)(scores, arange(Q) * n_psg)  and its
+// autograd (modeling/dense_retrieval_model.py:113-122; loss.py:9-15).  Sizes are tiny
+// ([64,768] x [768,512] at the reference's 8-GPU config), so this is latency-bound: the
+// score GEMM runs on the exact-f32 MFMA path, the softmax is one wavefront per row, and the
+// two gradient contractions are plain coalesced f32 loops over the LOCAL rows only.
+#include "kernels.h"
+
+// row-wise: loss_i = logsumexp(S[i,:]) - S[i,target_i];  dS = (softmax - onehot) * coef
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ S,
+                                                      float* __restrict__ dS, int Qg, int Pg,
+                                                      int n_psg, float coef,
+                                                      float* __restrict__ row_loss) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= Qg) return;
+  const float* s = S + (int64_t)i * Pg;
+  float mx = -INFINITY;
+  for (int j = lane; j < Pg; j += 64) mx = fmaxf(mx, s[j]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < Pg; j += 64) sum += expf(s[j] - mx);
+  sum = wave_sum(sum);
+  const int tgt = i * n_psg;
+  const float lse = mx + logf(sum);
+  if (lane == 0) row_loss[i] = lse - s[tgt];
+  if (dS) {
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < Pg; j += 64) {
+      const float p = expf(s[j] - mx) * inv;
+      dS[(int64_t)i * Pg + j] = (p - (j == tgt ? 1.f : 0.f)) * coef;
+    }
+  }
+}
+
+// loss = scale * mean(row_loss)   (deterministic single-wave reduction)
+__global__ void ce_reduce_kernel(const float* __restrict__ row_loss, int Qg, float scale,
+                                 float* __restrict__ loss) {
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < Qg; i += 64) acc += row_loss[i];
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) *loss = acc / (float)Qg * scale;
+}
+
+// d_q[i,c] = sum_j dS[q_row0+i, j] * p[j,c]
+__global__ void dq_kernel(const float* __restrict__ dS, const float* __restrict__ p,
+                          float* __restrict__ dq, int Pg, int d, int q_row0) {
+  const int i = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  const float* ds = dS + (int64_t)(q_row0 + i) * Pg;
+  float acc = 0.f;
+  for (int j = 0; j < Pg; ++j) acc = fmaf(ds[j], p[(int64_t)j * d + c], acc);
+  dq[(int64_t)i * d + c] = acc;
+}
+// d_p[j,c] = sum_i dS[i, p_row0+j] * q[i,c]
+__global__ void dp_kernel(const float* __restrict__ dS, const float* __restrict__ q,
+                          float* __restrict__ dp, int Qg, int Pg, int d, int p_row0) {
+  const int j = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  float acc = 0.f;
+  for (int i = 0; i < Qg; ++i)
+    acc = fmaf(dS[(int64_t)i * Pg + p_row0 + j], q[(int64_t)i * d + c], acc);
+  dp[(int64_t)j * d + c] = acc;
+}
+
+extern "C" int om_contrastive_fwd_bwd(const float* q, const float* p, int Qg, int Pg, int d,
+                                      int n_psg, float loss_scale, int q_row0, int q_rows,
+                                      int p_row0, int p_rows, float* loss, float* scores,
+                                      float* d_q, float* d_p, float* workspace, void* stream) {
+  if (Qg <= 0 || Pg <= 0) OM_FAIL("empty batch");
+  if ((int64_t)(Qg - 1) * n_psg >= Pg) OM_FAIL("target index out of range (Pg < Qg * n_psg)");
+  if (!workspace || !loss) OM_FAIL("null argument");
+  if (q_row0 < 0 || q_row0 + q_rows > Qg || p_row0 < 0 || p_row0 + p_rows > Pg)
+    OM_FAIL("local slice out of range");
+  hipStream_t s = (hipStream_t)stream;
+  // workspace: S [Qg,Pg] (if scores == NULL) | dS [Qg,Pg] | row_loss [Qg]
+  float* S = scores ? scores : workspace;
+  float* dS = workspace + (scores ? 0 : (size_t)Qg * Pg);
+  float* row_loss = dS + (size_t)Qg * Pg;
+  const bool bwd = d_q || d_p;
+  if (om_gemm_nt(OM_F32, q, d, p, d, OM_F32, S, Pg, Qg, Pg, d, nullptr, nullptr, 0, OM_ACT_NONE, s))
+    return 1;
+  hipLaunchKernelGGL(ce_rows_kernel, dim3((Qg + 3) / 4), dim3(256), 0, s, S, bwd ? dS : nullptr, Qg,
+                     Pg, n_psg, loss_scale / (float)Qg, row_loss);
+  OM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(64), 0, s, row_loss, Qg, loss_scale, loss);
+  OM_LAUNCH_CHECK();
+  if (d_q && q_rows > 0) {
+    hipLaunchKernelGGL(dq_kernel, dim3((d + 255) / 256, q_rows), dim3(256), 0, s, dS, p, d_q, Pg, d,
+                       q_row0);
+    OM_LAUNCH_CHECK();
+  }
+  if (d_p && p_rows > 0) {
+    hipLaunchKernelGGL(dp_kernel, dim3((d + 255) / 256, p_rows), dim3(256), 0, s, dS, q, d_p, Qg, Pg,
+                       d, p_row0);
+    OM_LAUNCH_CHECK();
+  }
+  return 0;
+}

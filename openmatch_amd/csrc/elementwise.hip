@@ -1,0 +1,294 @@
+// HBM-bound helpers of the encoder: embedding gather + LayerNorm (K1), LayerNorm / RMSNorm
+// (tails of K4/K6), pooling (K7), L2 normalise (K9), T5 relative-position bias, and the
+// f32 -> bf16 index shadow copy.  One wavefront (64 lanes) owns one row; 4 rows per block.
+#include "common.h"
+#include "kernels.h"
+
+#define ROWS_PER_BLOCK 4
+#define MAX_VEC_LIMIT 8  // 4-element vectors per lane -> H <= 2048 (NV = 4 covers H <= 1024)
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+  __device__ static inline void load(const float* p, float (&v)[4]) {
+    const float4 t = *(const float4*)p;
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  __device__ static inline void store(float* p, const float (&v)[4]) {
+    *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct Vec4<bf16_t> {
+  __device__ static inline void load(const bf16_t* p, float (&v)[4]) {
+    const uint2 t = *(const uint2*)p;
+    v[0] = bf16_to_f32((bf16_t)(t.x & 0xffff)); v[1] = bf16_to_f32((bf16_t)(t.x >> 16));
+    v[2] = bf16_to_f32((bf16_t)(t.y & 0xffff)); v[3] = bf16_to_f32((bf16_t)(t.y >> 16));
+  }
+  __device__ static inline void store(bf16_t* p, const float (&v)[4]) {
+    uint2 t;
+    t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    *(uint2*)p = t;
+  }
+};
+
+// Normalise the row held in x[][] (nv vectors per lane) and write it out.
+// LayerNorm: two-pass mean / biased variance in f32 (torch.nn.LayerNorm);
+// RMSNorm (T5LayerNorm, HF:models/t5/modeling_t5.py:59-72): x * rsqrt(mean(x^2)+eps) * g.
+template <typename TOut, int MAX_VEC>
+__device__ inline void norm_and_store(float (&x)[MAX_VEC][4], int nvec, int lane, int H,
+                                      const float* __restrict__ g, const float* __restrict__ b,
+                                      float eps, int rms, TOut* __restrict__ out) {
+  float mean = 0.f;
+  if (!rms) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAX_VEC; ++j)
+      if (j < nvec && (lane + 64 * j) * 4 < H) s += (x[j][0] + x[j][1]) + (x[j][2] + x[j][3]);
+    mean = wave_sum(s) / (float)H;
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAX_VEC; ++j)
+    if (j < nvec && (lane + 64 * j) * 4 < H) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = x[j][e] - mean; ss += d * d; }
+    }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)H + eps);
+#pragma unroll
+  for (int j = 0; j < MAX_VEC; ++j) {
+    const int c = (lane + 64 * j) * 4;
+    if (j < nvec && c < H) {
+      float gv[4], y[4];
+      Vec4<float>::load(g + c, gv);
+      if (b) {
+        float bv[4];
+        Vec4<float>::load(b + c, bv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (x[j][e] - mean) * rstd * gv[e] + bv[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (x[j][e] - mean) * rstd * gv[e];
+      }
+      Vec4<TOut>::store(out + c, y);
+    }
+  }
+}
+
+template <typename TIn, typename TOut, int MAX_VEC>
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_kernel(
+    const TIn* __restrict__ x, int64_t ldx, TOut* __restrict__ y, int64_t ldy,
+    const float* __restrict__ g, const float* __restrict__ b, int64_t M, int H, float eps, int rms) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nvec = (H / 4 + 63) / 64;
+  float v[MAX_VEC][4];
+#pragma unroll
+  for (int j = 0; j < MAX_VEC; ++j) {
+    const int c = (lane + 64 * j) * 4;
+    if (j < nvec && c < H) Vec4<TIn>::load(x + row * ldx + c, v[j]);
+  }
+  norm_and_store<TOut, MAX_VEC>(v, nvec, lane, H, g, b, eps, rms, y + row * ldy);
+}
+
+// BERT: LN(word[id] + type[tt] + pos[t])  (HF:models/bert/modeling_bert.py:68-108).
+// T5  : word[id]                          (shared embedding, no norm).
+template <typename TOut, int MAX_VEC>
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void embed_kernel(
+    const int64_t* __restrict__ ids, const int64_t* __restrict__ type_ids,
+    const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
+    const float* __restrict__ g, const float* __restrict__ b, TOut* __restrict__ out, int64_t M,
+    int L, int H, int vocab, int type_vocab, float eps, int bert) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= M) return;
+  int64_t id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const int nvec = (H / 4 + 63) / 64;
+  float v[MAX_VEC][4];
+  if (bert) {
+    int64_t tt = type_ids ? type_ids[row] : 0;
+    tt = tt < 0 ? 0 : (tt >= type_vocab ? type_vocab - 1 : tt);
+    const int t = (int)(row % L);
+#pragma unroll
+    for (int j = 0; j < MAX_VEC; ++j) {
+      const int c = (lane + 64 * j) * 4;
+      if (j < nvec && c < H) {
+        float w[4], ty[4], p[4];
+        Vec4<float>::load(word + id * H + c, w);
+        Vec4<float>::load(type + tt * H + c, ty);
+        Vec4<float>::load(pos + (int64_t)t * H + c, p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[j][e] = (w[e] + ty[e]) + p[e];
+      }
+    }
+    norm_and_store<TOut, MAX_VEC>(v, nvec, lane, H, g, b, eps, 0, out + row * H);
+  } else {
+#pragma unroll
+    for (int j = 0; j < MAX_VEC; ++j) {
+      const int c = (lane + 64 * j) * 4;
+      if (j < nvec && c < H) {
+        Vec4<float>::load(word + id * H + c, v[j]);
+        Vec4<TOut>::store(out + row * H + c, v[j]);
+      }
+    }
+  }
+}
+
+// pooling == FIRST: hidden[:,0,:] ; MEAN: sum(h*m)/clamp(sum(m),1e-9)  (utils.py:233-235)
+template <typename T>
+__global__ void pool_kernel(const T* __restrict__ x, const int64_t* __restrict__ mask,
+                            float* __restrict__ out, int L, int H, int mode) {
+  const int64_t b = blockIdx.x;
+  const T* xb = x + b * (int64_t)L * H;
+  for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (mode == OM_POOL_FIRST) {
+      Vec4<T>::load(xb + c, acc);
+    } else {
+      float cnt = 0.f;
+      for (int t = 0; t < L; ++t) {
+        const float m = (float)mask[b * L + t];
+        float v[4];
+        Vec4<T>::load(xb + (int64_t)t * H + c, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[e] * m;
+        cnt += m;
+      }
+      cnt = fmaxf(cnt, 1e-9f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = acc[e] / cnt;
+    }
+    Vec4<float>::store(out + b * H + c, acc);
+  }
+}
+
+// F.normalize(x, dim=1): x / max(||x||_2, 1e-12)   (modeling/dense_retrieval_model.py:153-154)
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void l2norm_kernel(const float* __restrict__ x,
+                                                                     float* __restrict__ y,
+                                                                     int64_t M, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float ss = 0.f;
+  for (int c = lane; c < D; c += 64) { const float v = x[row * D + c]; ss += v * v; }
+  const float denom = fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+  for (int c = lane; c < D; c += 64) y[row * D + c] = x[row * D + c] / denom;
+}
+
+// T5 additive attention bias  bias[h][q][k] = table[bucket(k - q)][h]
+// (HF:models/t5/modeling_t5.py compute_bias; the bucket LUT is built on the host).
+__global__ void t5_bias_kernel(const float* __restrict__ table, const int* __restrict__ lut,
+                               float* __restrict__ out, int L, int heads) {
+  const int64_t n = (int64_t)heads * L * L;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % L), q = (int)((i / L) % L), h = (int)(i / ((int64_t)L * L));
+    out[i] = table[lut[k - q + (L - 1)] * heads + h];
+  }
+}
+
+// index.add(): bf16 shadow rows + rounding statistics for the certified search margin.
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void index_to_bf16_kernel(
+    const float* __restrict__ x, bf16_t* __restrict__ y, int64_t N, int d,
+    unsigned* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= N) return;
+  float e2 = 0.f, n2 = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    const float v = x[row * d + c];
+    const bf16_t r = f32_to_bf16(v);
+    const float rv = bf16_to_f32(r);
+    y[row * d + c] = r;
+    e2 += (v - rv) * (v - rv);
+    n2 += rv * rv;
+  }
+  e2 = wave_sum(e2); n2 = wave_sum(n2);
+  if (lane == 0) {
+    // non-negative floats order like their bit patterns; round the norms UP a little
+    atomicMax(stats + 0, __float_as_uint(sqrtf(e2) * 1.0001f));
+    atomicMax(stats + 1, __float_as_uint(sqrtf(n2) * 1.0001f));
+  }
+}
+
+// ---- host launchers ---------------------------------------------------------
+template <typename TIn, typename TOut>
+static int launch_ln(const void* x, int64_t ldx, void* y, int64_t ldy, const float* g,
+                     const float* b, int64_t M, int H, float eps, int rms, hipStream_t s) {
+  const unsigned grid = (unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  if (H <= 1024)
+    hipLaunchKernelGGL((layernorm_kernel<TIn, TOut, 4>), dim3(grid), dim3(64 * ROWS_PER_BLOCK), 0, s,
+                       (const TIn*)x, ldx, (TOut*)y, ldy, g, b, M, H, eps, rms);
+  else
+    hipLaunchKernelGGL((layernorm_kernel<TIn, TOut, 8>), dim3(grid), dim3(64 * ROWS_PER_BLOCK), 0, s,
+                       (const TIn*)x, ldx, (TOut*)y, ldy, g, b, M, H, eps, rms);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int omk_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* g,
+                  const float* b, int64_t M, int H, float eps, int rms, hipStream_t s) {
+  if (H % 4 != 0 || H > 64 * 4 * MAX_VEC_LIMIT) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
+  if (M <= 0) return 0;
+  if (dtype == OM_BF16) return launch_ln<bf16_t, bf16_t>(x, ldx, y, ldy, g, b, M, H, eps, rms, s);
+  return launch_ln<float, float>(x, ldx, y, ldy, g, b, M, H, eps, rms, s);
+}
+
+int omk_embed(int dtype, const int64_t* ids, const int64_t* type_ids, const float* word,
+              const float* pos, const float* type, const float* g, const float* b, void* out,
+              int64_t M, int L, int H, int vocab, int type_vocab, float eps, int bert,
+              hipStream_t s) {
+  if (H % 4 != 0 || H > 64 * 4 * MAX_VEC_LIMIT) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
+  if (M <= 0) return 0;
+  const unsigned grid = (unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+#define EMBED_LAUNCH(TT, NV)                                                                   \
+  hipLaunchKernelGGL((embed_kernel<TT, NV>), dim3(grid), dim3(64 * ROWS_PER_BLOCK), 0, s, ids, \
+                     type_ids, word, pos, type, g, b, (TT*)out, M, L, H, vocab, type_vocab, eps, bert)
+  if (dtype == OM_BF16) {
+    if (H <= 1024) EMBED_LAUNCH(bf16_t, 4); else EMBED_LAUNCH(bf16_t, 8);
+  } else {
+    if (H <= 1024) EMBED_LAUNCH(float, 4); else EMBED_LAUNCH(float, 8);
+  }
+#undef EMBED_LAUNCH
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int omk_pool(int dtype, const void* x, const int64_t* mask, float* out, int64_t B, int L, int H,
+             int mode, hipStream_t s) {
+  if (B <= 0) return 0;
+  if (H % 4 != 0) OM_FAIL("hidden size must be a multiple of 4");
+  if (dtype == OM_BF16)
+    hipLaunchKernelGGL((pool_kernel<bf16_t>), dim3((unsigned)B), dim3(256), 0, s, (const bf16_t*)x,
+                       mask, out, L, H, mode);
+  else
+    hipLaunchKernelGGL((pool_kernel<float>), dim3((unsigned)B), dim3(256), 0, s, (const float*)x,
+                       mask, out, L, H, mode);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int omk_l2norm(const float* x, float* y, int64_t M, int D, hipStream_t s) {
+  if (M <= 0) return 0;
+  const unsigned grid = (unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  hipLaunchKernelGGL(l2norm_kernel, dim3(grid), dim3(64 * ROWS_PER_BLOCK), 0, s, x, y, M, D);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int omk_t5_bias(const float* table, const int* lut, float* out, int L, int heads, hipStream_t s) {
+  hipLaunchKernelGGL(t5_bias_kernel, dim3(256), dim3(256), 0, s, table, lut, out, L, heads);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int om_index_to_bf16(const float* rows_f32, int64_t N, int d, void* rows_bf16,
+                                float* stats, void* stream) {
+  if (N <= 0) return 0;
+  const unsigned grid = (unsigned)((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  hipLaunchKernelGGL(index_to_bf16_kernel, dim3(grid), dim3(64 * ROWS_PER_BLOCK), 0,
+                     (hipStream_t)stream, rows_f32, (bf16_t*)rows_bf16, N, d, (unsigned*)stats);
+  OM_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,168 @@
+// om_encoder_forward: the whole eval-mode encoder (BERT post-LN or T5 pre-RMSNorm stack)
+// + pooling + LinearHead + normalise, as a fixed sequence of launches on ONE stream.
+// Stands in for DRModel.encode (modeling/dense_retrieval_model.py:133-155) and the HF model
+// it calls (HF:models/bert/modeling_bert.py:623-684 / HF:models/t5/modeling_t5.py T5Stack).
+//
+// Activation buffers live in the caller's workspace ([M = B*L tokens] x width, compute dtype):
+//   x   [M,H]   hidden state entering a layer (LN output; T5: residual stream)
+//   y   [M,H]   pre-LayerNorm sum (BERT) / normed input (T5)
+//   x1  [M,H]   post-attention hidden (BERT)
+//   qkv [M,3H]  fused projection      ctx [M,H] attention output
+//   ff  [M,F]   FFN inner activation  ff2 [M,F] gate (T5 v1.1 only)
+#include <math.h>
+
+#include <vector>
+
+#include "kernels.h"
+
+struct EncWs {
+  char *x, *y, *x1, *qkv, *ctx, *ff, *ff2;
+  float *pooled, *headout, *posbias;
+  int* lut;
+  size_t total;
+};
+
+static EncWs carve(const OmEncoderConfig* c, int64_t B, int64_t L, char* base) {
+  const size_t es = c->dtype == OM_BF16 ? 2 : 4;
+  const size_t M = (size_t)B * L, H = c->hidden, F = c->ffn;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return base + o; };
+  EncWs w;
+  w.x = take(M * H * es);
+  w.y = take(M * H * es);
+  w.x1 = take(M * H * es);
+  w.qkv = take(M * 3 * H * es);
+  w.ctx = take(M * H * es);
+  w.ff = take(M * F * es);
+  w.ff2 = take(c->arch == OM_ARCH_T5 ? M * F * es : 0);
+  w.pooled = (float*)take((size_t)B * H * 4);
+  w.headout = (float*)take((size_t)B * (c->head_out > 0 ? c->head_out : 1) * 4);
+  w.posbias = (float*)take(c->arch == OM_ARCH_T5 ? (size_t)c->n_heads * L * L * 4 : 0);
+  w.lut = (int*)take(c->arch == OM_ARCH_T5 ? (size_t)(2 * L) * 4 : 0);
+  w.total = off;
+  return w;
+}
+
+extern "C" size_t om_encoder_workspace_bytes(const OmEncoderConfig* cfg, int64_t B, int64_t L) {
+  if (!cfg || B <= 0 || L <= 0) return 0;
+  return carve(cfg, B, L, nullptr).total;
+}
+
+extern "C" int om_t5_relative_bucket(int relative_position, int num_buckets, int max_distance) {
+  // bidirectional: half the buckets for each sign; exact below max_exact, log-spaced above
+  int nb = num_buckets / 2;
+  int bucket = relative_position > 0 ? nb : 0;
+  const int n = relative_position < 0 ? -relative_position : relative_position;
+  const int max_exact = nb / 2;
+  if (n < max_exact) return bucket + n;
+  const double v = log((double)n / max_exact) / log((double)max_distance / max_exact) * (nb - max_exact);
+  int large = max_exact + (int)v;
+  if (large > nb - 1) large = nb - 1;
+  return bucket + large;
+}
+
+static int check_cfg(const OmEncoderConfig* c) {
+  if (c->dtype != OM_F32 && c->dtype != OM_BF16) OM_FAIL("dtype must be OM_F32 or OM_BF16");
+  if (c->arch != OM_ARCH_BERT && c->arch != OM_ARCH_T5) OM_FAIL("unknown arch");
+  if (c->head_dim != 64 || c->n_heads * 64 != c->hidden)
+    OM_FAIL("only head_dim 64 with n_heads*64 == hidden is supported");
+  const int es = c->dtype == OM_BF16 ? 2 : 4;
+  if ((c->hidden * es) % 128 || (c->ffn * es) % 128) OM_FAIL("hidden/ffn rows must be multiples of 128 bytes");
+  if (c->head_in > 0 && ((c->head_in * 4) % 128 || c->head_in != c->hidden)) OM_FAIL("head_in must equal hidden");
+  return 0;
+}
+
+extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeights* w,
+                                  const int64_t* input_ids, const int64_t* attention_mask,
+                                  const int64_t* token_type_ids, int64_t B, int64_t L,
+                                  void* out_hidden, float* out_reps, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  if (!c || !w || !input_ids || !attention_mask) OM_FAIL("null argument");
+  if (check_cfg(c)) return 1;
+  if (B <= 0) return 0;
+  if (L < 1 || L > 256) OM_FAIL("sequence length must be in [1,256]");
+  if (!workspace || ((uintptr_t)workspace & 255)) OM_FAIL("workspace must be 256-byte aligned");
+  EncWs ws = carve(c, B, L, (char*)workspace);
+  if (ws.total > workspace_bytes) OM_FAIL("workspace too small");
+  if (c->pooling != OM_POOL_NONE && !out_reps) OM_FAIL("out_reps required when pooling is set");
+  hipStream_t s = (hipStream_t)stream;
+  const int dt = c->dtype, H = c->hidden, F = c->ffn, nh = c->n_heads;
+  const int64_t M = B * L;
+  const bool bert = c->arch == OM_ARCH_BERT;
+  const OmLayerWeights* Ls = w->layers_host;
+  if (!Ls) OM_FAIL("layers_host is null");
+
+#define GEMM(A_, lda_, W_, ldw_, C_, ldc_, N_, K_, bias_, res_, ldr_, act_)                      \
+  do {                                                                                           \
+    if (om_gemm_nt(dt, A_, lda_, W_, ldw_, dt, C_, ldc_, M, N_, K_, bias_, res_, ldr_, act_, s)) \
+      return 1;                                                                                  \
+  } while (0)
+#define RUN(expr) do { if (expr) return 1; } while (0)
+
+  char* final_hidden = nullptr;
+  if (bert) {
+    if (L > c->max_pos) OM_FAIL("sequence longer than the position table");
+    RUN(omk_embed(dt, input_ids, token_type_ids, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g,
+                  w->emb_ln_b, ws.x, M, (int)L, H, c->vocab, c->type_vocab, c->ln_eps, 1, s));
+    const float scale = 1.0f / sqrtf((float)c->head_dim);
+    for (int l = 0; l < c->n_layers; ++l) {
+      const OmLayerWeights& lw = Ls[l];
+      GEMM(ws.x, H, lw.qkv_w, H, ws.qkv, 3 * H, 3 * H, H, lw.qkv_b, nullptr, 0, OM_ACT_NONE);
+      RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, nullptr, B, (int)L, H, nh, scale, s));
+      GEMM(ws.ctx, H, lw.o_w, H, ws.y, H, H, H, lw.o_b, ws.x, H, OM_ACT_NONE);
+      RUN(omk_layernorm(dt, ws.y, H, ws.x1, H, lw.ln1_g, lw.ln1_b, M, H, c->ln_eps, 0, s));
+      GEMM(ws.x1, H, lw.ffn1_w, H, ws.ff, F, F, H, lw.ffn1_b, nullptr, 0, c->act);
+      GEMM(ws.ff, F, lw.ffn2_w, F, ws.y, H, H, F, lw.ffn2_b, ws.x1, H, OM_ACT_NONE);
+      void* dst = (l == c->n_layers - 1 && out_hidden) ? out_hidden : (void*)ws.x;
+      RUN(omk_layernorm(dt, ws.y, H, dst, H, lw.ln2_g, lw.ln2_b, M, H, c->ln_eps, 0, s));
+      final_hidden = (char*)dst;
+    }
+    if (c->n_layers == 0) final_hidden = ws.x;
+  } else {
+    // relative-position bias, shared by all layers (table lives in block 0)
+    if (!w->rel_bias || !w->final_ln_g) OM_FAIL("T5 needs rel_bias and final_ln_g");
+    std::vector<int> lut(2 * L);
+    for (int rel = -(int)(L - 1); rel <= (int)(L - 1); ++rel)
+      lut[rel + (L - 1)] = om_t5_relative_bucket(rel, c->rel_buckets, c->rel_max_dist);
+    OM_HIP(hipMemcpyAsync(ws.lut, lut.data(), (2 * L - 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    OM_HIP(hipStreamSynchronize(s));  // `lut` is a pageable host temporary
+    RUN(omk_t5_bias(w->rel_bias, ws.lut, ws.posbias, (int)L, nh, s));
+    RUN(omk_embed(dt, input_ids, nullptr, w->word_emb, nullptr, nullptr, nullptr, nullptr, ws.x, M,
+                  (int)L, H, c->vocab, 1, c->ln_eps, 0, s));
+    for (int l = 0; l < c->n_layers; ++l) {
+      const OmLayerWeights& lw = Ls[l];
+      RUN(omk_layernorm(dt, ws.x, H, ws.y, H, lw.ln1_g, nullptr, M, H, c->ln_eps, 1, s));
+      GEMM(ws.y, H, lw.qkv_w, H, ws.qkv, 3 * H, 3 * H, H, nullptr, nullptr, 0, OM_ACT_NONE);
+      RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, ws.posbias, B, (int)L, H, nh, 1.0f, s));
+      GEMM(ws.ctx, H, lw.o_w, H, ws.x, H, H, H, nullptr, ws.x, H, OM_ACT_NONE);  // x += o(ctx)
+      RUN(omk_layernorm(dt, ws.x, H, ws.y, H, lw.ln2_g, nullptr, M, H, c->ln_eps, 1, s));
+      if (lw.ffn1g_w) {
+        GEMM(ws.y, H, lw.ffn1g_w, H, ws.ff2, F, F, H, nullptr, nullptr, 0, OM_ACT_NONE);
+        GEMM(ws.y, H, lw.ffn1_w, H, ws.ff, F, F, H, nullptr, ws.ff2, F, c->act | OM_ACT_MUL_RESID);
+      } else {
+        GEMM(ws.y, H, lw.ffn1_w, H, ws.ff, F, F, H, nullptr, nullptr, 0, c->act);
+      }
+      GEMM(ws.ff, F, lw.ffn2_w, F, ws.x, H, H, F, nullptr, ws.x, H, OM_ACT_NONE);  // x += wo(ff)
+    }
+    void* dst = out_hidden ? out_hidden : (void*)ws.y;
+    RUN(omk_layernorm(dt, ws.x, H, dst, H, w->final_ln_g, nullptr, M, H, c->ln_eps, 1, s));
+    final_hidden = (char*)dst;
+  }
+
+  if (c->pooling != OM_POOL_NONE) {
+    const bool head = c->head_in > 0 && w->head_w;
+    float* pooled = head ? ws.pooled : out_reps;
+    RUN(omk_pool(dt, final_hidden, attention_mask, pooled, B, (int)L, H, c->pooling, s));
+    int D = H;
+    if (head) {
+      D = c->head_out;
+      if (om_gemm_nt(OM_F32, pooled, H, w->head_w, c->head_in, OM_F32, out_reps, D, B, D, c->head_in,
+                     nullptr, nullptr, 0, OM_ACT_NONE, s))
+        return 1;
+    }
+    if (c->normalize) RUN(omk_l2norm(out_reps, out_reps, B, D, s));
+  }
+#undef GEMM
+#undef RUN
+  return 0;
+}

@@ -1,0 +1,99 @@
+// om_gemm_nt: C = act(A · B^T + bias) + resid  on MFMA (bf16 or exact-f32), gfx950.
+// Stands in for the ATen/BLAS GEMM under every nn.Linear on the hot path
+// (HF:models/bert/modeling_bert.py:175-177,289-293,334-351; linear.py:22-23).
+#include "gemm_core.h"
+
+__device__ inline float act_apply(float x, int act) {
+  if (act == OM_ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  if (act == OM_ACT_RELU) return fmaxf(x, 0.0f);
+  if (act == OM_ACT_GELU_TANH) {
+    // HF NewGELUActivation: 0.5x(1+tanh(sqrt(2/pi)(x+0.044715x^3)))
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+  }
+  return x;
+}
+
+template <typename T, typename OutT>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(
+    const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, OutT* C,
+    int64_t ldc, int64_t M, int64_t N, int64_t K, const float* __restrict__ bias,
+    const OutT* resid, int64_t ldr, int act, int group_m) {  // resid may alias C (in-place +=)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int64_t ntm = (M + GEMM_BM - 1) / GEMM_BM, ntn = (N + GEMM_BN - 1) / GEMM_BN;
+  int64_t tm, tn;
+  gemm_tile_coords(ntm, ntn, group_m, tm, tn);
+  const int64_t m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+
+  f32x16_t acc[2][2];
+  gemm_mainloop<T>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int64_t n = n0 + wn * 64 + ni * 32 + (lane & 31);
+    if (n >= N) continue;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int64_t mbase = m0 + wm * 64 + mi * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = mbase + (r & 3) + 8 * (r >> 2);
+        if (m >= M) continue;
+        float v = act_apply(acc[mi][ni][r] + bv, act & 0xff);
+        if (resid) {
+          const float rv = ElemOps<OutT>::load(resid + m * ldr + n);
+          v = (act & OM_ACT_MUL_RESID) ? v * rv : v + rv;
+        }
+        ElemOps<OutT>::store(C + m * ldc + n, v);
+      }
+    }
+  }
+}
+
+template <typename T, typename OutT>
+static int launch_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                       int64_t M, int64_t N, int64_t K, const float* bias, const void* resid,
+                       int64_t ldr, int act, hipStream_t s) {
+  const int64_t ntm = (M + GEMM_BM - 1) / GEMM_BM, ntn = (N + GEMM_BN - 1) / GEMM_BN;
+  const int64_t nwg = ntm * ntn;
+  if (nwg > 0x7fffffffLL) OM_FAIL("grid too large");
+  static bool attr_set = false;
+  if (!attr_set) {
+    OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    attr_set = true;
+  }
+  // sweep order: keep `group_m` activation row-tiles resident while walking the weight tiles
+  const int group_m = 8;
+  hipLaunchKernelGGL((gemm_nt_kernel<T, OutT>), dim3((unsigned)nwg), dim3(GEMM_THREADS),
+                     GEMM_LDS_BYTES, s, (const T*)A, lda, (const T*)B, ldb, (OutT*)C, ldc, M, N, K,
+                     bias, (const OutT*)resid, ldr, act, group_m);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int om_gemm_nt(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb,
+                          int out_dtype, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                          const float* bias, const void* resid, int64_t ldr, int act,
+                          void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if (K <= 0) OM_FAIL("K must be positive");
+  const int64_t es = in_dtype == OM_BF16 ? 2 : 4;
+  if ((K * es) % GEMM_ROW_BYTES != 0) OM_FAIL("K*sizeof(elem) must be a multiple of 128 bytes");
+  if ((lda * es) % 16 != 0 || (ldb * es) % 16 != 0) OM_FAIL("lda/ldb must keep rows 16-byte aligned");
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) OM_FAIL("A/B must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (in_dtype == OM_BF16 && out_dtype == OM_BF16)
+    return launch_gemm<bf16_t, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, act, s);
+  if (in_dtype == OM_BF16 && out_dtype == OM_F32)
+    return launch_gemm<bf16_t, float>(A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, act, s);
+  if (in_dtype == OM_F32 && out_dtype == OM_F32)
+    return launch_gemm<float, float>(A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, act, s);
+  if (in_dtype == OM_F32 && out_dtype == OM_BF16)
+    return launch_gemm<float, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, act, s);
+  OM_FAIL("unsupported dtype combination");
+}

@@ -1,0 +1,482 @@
+// Exact inner-product top-k over a resident index shard (K12 + K13 + K14), gfx950.
+// Replaces faiss.IndexFlatIP.search and the faiss-GPU shard merge
+// (retriever/dense_retriever.py:38-58,180; utils.py:215-229).
+//
+// The [Q x N] score matrix is never materialised.  The scan is a threshold-filtered GEMM:
+//   1. bootstrap: score the first few thousand rows densely, sort, theta_q = k-th best so far
+//      (the k-th best of ANY subset is a lower bound of the final k-th best);
+//   2. scan the remaining rows in geometrically growing chunks with the MFMA main loop of
+//      gemm_core.h (A = index rows, B = queries -> every lane owns one query column); the
+//      epilogue appends (score,row) to the query's candidate list only if score >= theta_q
+//      -- the expected number of survivors per chunk is k * chunk / rows_seen;
+//   3. after each chunk a per-query bitonic sort (LDS, 8192 keys) keeps the best k and
+//      raises theta_q.  If a list overflows (adversarial row order) the chunk is redone
+//      through the dense path, which is always exact.
+// Scores in OM_SEARCH_F32 mode come from the exact-f32 MFMA (k-ordered fmaf chain).
+// In OM_SEARCH_BF16_RESCORE mode the scan runs on the bf16 shadow index with a CERTIFIED
+// margin: |s_bf16 - s_f32| <= E_q = ||q||*max||p-bf16(p)|| + ||q-bf16(q)||*max||bf16(p)|| (+ f32
+// accumulation slop), the list keeps everything within 2*E_q of the running k-th best, and
+// the survivors are re-scored with exact f32 dot products before the final top-k -- so the
+// returned ids are those of the f32 scan.
+#include <algorithm>
+
+#include "gemm_core.h"
+#include "kernels.h"
+
+#define SORT_CAP 8192      // keys one workgroup sorts in LDS (64 KiB)
+#define DENSE_CHUNK 4096   // rows scored densely per bootstrap / fallback step
+#define LIST_MAX (SORT_CAP - DENSE_CHUNK)
+#define K_MAX 2048
+#define SORT_THREADS 512
+
+typedef unsigned long long u64;
+
+__host__ __device__ inline u64 pack_key(float score, uint32_t payload) {
+  return ((u64)f32_orderable(score) << 32) | (u64)(uint32_t)~payload;
+}
+__host__ __device__ inline float key_score(u64 k) { return orderable_f32((uint32_t)(k >> 32)); }
+__host__ __device__ inline uint32_t key_payload(u64 k) { return ~(uint32_t)k; }
+
+// ---- filtered scan: A = index rows [row0, row0+nrows), B = queries ----------------------
+template <typename T>
+__global__ __launch_bounds__(GEMM_THREADS) void sim_filter_kernel(
+    const T* __restrict__ rows, int64_t nrows, uint32_t row_base, const T* __restrict__ queries,
+    int64_t nq, int64_t d, const float* __restrict__ thr, u64* __restrict__ keys,
+    unsigned* __restrict__ cnt, int group_m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int64_t ntm = (nrows + GEMM_BM - 1) / GEMM_BM, ntn = (nq + GEMM_BN - 1) / GEMM_BN;
+  int64_t tm, tn;
+  gemm_tile_coords(ntm, ntn, group_m, tm, tn);
+  const int64_t m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+  f32x16_t acc[2][2];
+  gemm_mainloop<T>(rows, d, queries, d, nrows, nq, d, m0, n0, smem, acc);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int64_t q = n0 + wn * 64 + ni * 32 + (lane & 31);
+    if (q >= nq) continue;
+    const float th = thr[q];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int64_t mbase = m0 + wm * 64 + mi * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = mbase + (r & 3) + 8 * (r >> 2);
+        const float v = acc[mi][ni][r];
+        if (m < nrows && v >= th) {
+          const unsigned pos = atomicAdd(cnt + q, 1u);
+          if (pos < SORT_CAP) keys[q * SORT_CAP + pos] = pack_key(v, row_base + (uint32_t)m);
+        }
+      }
+    }
+  }
+}
+
+// append a dense score block S[q, 0:n] (rows row_base..) to every list
+__global__ void append_dense_kernel(const float* __restrict__ S, int64_t ldS, int n,
+                                    uint32_t row_base, u64* __restrict__ keys,
+                                    unsigned* __restrict__ cnt) {
+  const int64_t q = blockIdx.x;
+  const unsigned base = cnt[q];
+  for (int j = threadIdx.x; j < n; j += blockDim.x)
+    if (base + j < SORT_CAP) keys[q * SORT_CAP + base + j] = pack_key(S[q * ldS + j], row_base + j);
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[q] = base + n;
+}
+
+// flag[0] |= any list overflowed
+__global__ void check_overflow_kernel(const unsigned* __restrict__ cnt, int64_t nq,
+                                      unsigned* __restrict__ flag) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < nq && cnt[q] > SORT_CAP) atomicOr(flag, 1u);
+}
+__global__ void restore_cnt_kernel(unsigned* __restrict__ cnt, const unsigned* __restrict__ prev,
+                                   int64_t nq) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < nq) cnt[q] = prev[q];
+}
+
+// descending bitonic sort of P (power of two) keys in LDS
+__device__ inline void bitonic_sort_desc(u64* s, int P, int tid, int nthr) {
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < P; i += nthr) {
+        const int x = i ^ j;
+        if (x > i) {
+          const u64 a = s[i], b = s[x];
+          const bool desc = (i & k) == 0;
+          if (desc ? (a < b) : (a > b)) { s[i] = b; s[x] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Sort one list, keep the best k (exact mode) or everything within margin[q] of the k-th
+// best (certified bf16 mode), publish the new threshold.  flag[1] = max list length,
+// flag[2] |= a certified list outgrew LIST_MAX.
+__global__ __launch_bounds__(SORT_THREADS) void select_kernel(
+    u64* __restrict__ keys, unsigned* __restrict__ cnt, unsigned* __restrict__ cnt_prev,
+    float* __restrict__ thr, const float* __restrict__ margin, int k, unsigned* __restrict__ flag) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u64* s = (u64*)smem;
+  const int64_t q = blockIdx.x;
+  const int tid = threadIdx.x;
+  unsigned n = cnt[q];
+  if (n > SORT_CAP) n = SORT_CAP;
+  int P = 2;
+  while (P < (int)n) P <<= 1;
+  u64* list = keys + q * SORT_CAP;
+  for (int i = tid; i < P; i += SORT_THREADS) s[i] = i < (int)n ? list[i] : 0ull;
+  __syncthreads();
+  bitonic_sort_desc(s, P, tid, SORT_THREADS);
+
+  unsigned& keep_s = *(unsigned*)(smem + SORT_CAP * 8);  // all LDS in the one dynamic array
+  if (tid == 0) keep_s = 0;
+  __syncthreads();
+  float th = -INFINITY;
+  unsigned keep;
+  if (!margin) {
+    keep = n < (unsigned)k ? n : (unsigned)k;
+    if (n >= (unsigned)k) th = key_score(s[k - 1]);
+  } else {
+    if (n >= (unsigned)k) {
+      th = key_score(s[k - 1]) - 2.0f * margin[q];
+      unsigned local = 0;
+      for (int i = tid; i < (int)n; i += SORT_THREADS) local += key_score(s[i]) >= th ? 1u : 0u;
+      atomicAdd(&keep_s, local);
+      __syncthreads();
+      keep = keep_s;
+    } else {
+      keep = n;
+    }
+  }
+  for (int i = tid; i < (int)keep; i += SORT_THREADS) list[i] = s[i];
+  if (tid == 0) {
+    cnt[q] = keep;
+    cnt_prev[q] = keep;
+    thr[q] = th;
+    atomicMax(flag + 1, keep);
+    if (keep > LIST_MAX) atomicOr(flag + 2, 1u);
+  }
+}
+
+// per-query certified margin and bf16 copy of the queries
+__global__ __launch_bounds__(256) void query_prep_kernel(const float* __restrict__ q,
+                                                         bf16_t* __restrict__ qb,
+                                                         float* __restrict__ margin,
+                                                         const float* __restrict__ stats,
+                                                         int64_t nq, int d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nq) return;
+  float n2 = 0.f, e2 = 0.f, b2 = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    const float v = q[row * d + c];
+    const bf16_t r = f32_to_bf16(v);
+    const float rv = bf16_to_f32(r);
+    qb[row * d + c] = r;
+    n2 += v * v; e2 += (v - rv) * (v - rv); b2 += rv * rv;
+  }
+  n2 = wave_sum(n2); e2 = wave_sum(e2); b2 = wave_sum(b2);
+  if (lane == 0) {
+    const float qn = sqrtf(n2), qe = sqrtf(e2), qbn = sqrtf(b2);
+    const float Ep = stats[0], Pn = stats[1];
+    const float slop = 8.0f * (float)d * 5.9604645e-8f * (qn + qbn) * (Pn + Ep);
+    margin[row] = 1.01f * (qn * Ep + qe * Pn) + slop;
+  }
+}
+
+// exact f32 re-score of every surviving candidate: one wavefront per (query, slot)
+__global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ q,
+                                                      const float* __restrict__ index,
+                                                      u64* __restrict__ keys,
+                                                      const unsigned* __restrict__ cnt, int d) {
+  const int64_t qi = blockIdx.y;
+  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (slot >= (int)cnt[qi]) return;
+  u64* kp = keys + qi * SORT_CAP + slot;
+  const uint32_t row = key_payload(*kp);
+  const float* qv = q + qi * d;
+  const float* pv = index + (int64_t)row * d;
+  float acc = 0.f;
+  for (int c = lane * 4; c < d; c += 256) {
+    const float4 a = *(const float4*)(qv + c);
+    const float4 b = *(const float4*)(pv + c);
+    acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc);
+    acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) *kp = pack_key(acc, row);
+}
+
+__global__ void emit_kernel(const u64* __restrict__ keys, const unsigned* __restrict__ cnt, int k,
+                            int64_t id_offset, float* __restrict__ out_scores,
+                            int64_t* __restrict__ out_ids) {
+  const int64_t q = blockIdx.x;
+  const unsigned n = cnt[q];
+  for (int j = threadIdx.x; j < k; j += blockDim.x) {
+    if (j < (int)n) {
+      const u64 key = keys[q * SORT_CAP + j];
+      out_scores[q * k + j] = key_score(key);
+      out_ids[q * k + j] = id_offset + (int64_t)key_payload(key);
+    } else {
+      out_scores[q * k + j] = -3.4028235e38f;  // faiss pads (D,I) with (-FLT_MAX, -1)
+      out_ids[q * k + j] = -1;
+    }
+  }
+}
+
+__global__ void init_lists_kernel(unsigned* cnt, unsigned* cnt_prev, float* thr, int64_t nq) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < nq) { cnt[q] = 0; cnt_prev[q] = 0; thr[q] = -INFINITY; }
+}
+
+// ---- K14: merge W sorted partial lists per query ------------------------------------------
+__global__ __launch_bounds__(SORT_THREADS) void merge_kernel(
+    const float* __restrict__ ps, const int64_t* __restrict__ pi, int W, int64_t nq, int k_in,
+    int k_out, float* __restrict__ out_scores, int64_t* __restrict__ out_ids) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u64* s = (u64*)smem;
+  const int64_t q = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int n = W * k_in;
+  int P = 2;
+  while (P < n) P <<= 1;
+  for (int i = tid; i < P; i += SORT_THREADS) {
+    u64 key = 0ull;
+    if (i < n) {
+      const int w = i / k_in, j = i % k_in;
+      const int64_t src = ((int64_t)w * nq + q) * k_in + j;
+      if (pi[src] >= 0) key = pack_key(ps[src], (uint32_t)i);  // ties: (part, position) order
+    }
+    s[i] = key;
+  }
+  __syncthreads();
+  bitonic_sort_desc(s, P, tid, SORT_THREADS);
+  for (int j = tid; j < k_out; j += SORT_THREADS) {
+    const u64 key = j < P ? s[j] : 0ull;
+    if (key != 0ull) {
+      const int i = (int)key_payload(key);
+      const int w = i / k_in, jj = i % k_in;
+      const int64_t src = ((int64_t)w * nq + q) * k_in + jj;
+      out_scores[q * k_out + j] = ps[src];
+      out_ids[q * k_out + j] = pi[src];
+    } else {
+      out_scores[q * k_out + j] = -3.4028235e38f;
+      out_ids[q * k_out + j] = -1;
+    }
+  }
+}
+
+extern "C" int om_topk_merge(const float* part_scores, const int64_t* part_ids, int W,
+                             int64_t n_queries, int k_in, int k_out, float* out_scores,
+                             int64_t* out_ids, void* stream) {
+  if (n_queries <= 0 || k_out <= 0) return 0;
+  if (W <= 0 || k_in <= 0) OM_FAIL("W and k_in must be positive");
+  if ((int64_t)W * k_in > SORT_CAP) OM_FAIL("W*k_in exceeds the 8192-key merge capacity");
+  static bool attr_set = false;
+  if (!attr_set) {
+    OM_HIP(hipFuncSetAttribute((const void*)merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               SORT_CAP * 8));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(merge_kernel, dim3((unsigned)n_queries), dim3(SORT_THREADS), SORT_CAP * 8,
+                     (hipStream_t)stream, part_scores, part_ids, W, n_queries, k_in, k_out,
+                     out_scores, out_ids);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- host orchestration -------------------------------------------------------------------
+struct SearchWs {
+  u64* keys; unsigned *cnt, *cnt_prev, *flag; float *thr, *margin, *dense; bf16_t* qb;
+  size_t total;
+};
+static SearchWs carve_search(int64_t nq, int d, char* base) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return base + o; };
+  SearchWs w;
+  w.keys = (u64*)take((size_t)nq * SORT_CAP * 8);
+  w.cnt = (unsigned*)take((size_t)nq * 4);
+  w.cnt_prev = (unsigned*)take((size_t)nq * 4);
+  w.flag = (unsigned*)take(64);
+  w.thr = (float*)take((size_t)nq * 4);
+  w.margin = (float*)take((size_t)nq * 4);
+  w.dense = (float*)take((size_t)nq * DENSE_CHUNK * 4);
+  w.qb = (bf16_t*)take((size_t)nq * d * 2);
+  w.total = off;
+  return w;
+}
+
+extern "C" size_t om_sim_topk_workspace_bytes(int64_t n_queries, int d, int k) {
+  (void)k;
+  if (n_queries <= 0 || d <= 0) return 0;
+  return carve_search(n_queries, d, nullptr).total;
+}
+
+namespace {
+struct Scan {
+  int mode; const float* q32; const float* idx32; const bf16_t* idx16; int64_t nq, N; int d, k;
+  SearchWs ws; hipStream_t s;
+
+  int select(bool certified) {
+    hipLaunchKernelGGL(select_kernel, dim3((unsigned)nq), dim3(SORT_THREADS), SORT_CAP * 8 + 16, s,
+                       ws.keys, ws.cnt, ws.cnt_prev, ws.thr, certified ? ws.margin : nullptr, k,
+                       ws.flag);
+    OM_LAUNCH_CHECK();
+    return 0;
+  }
+  int read_flags(unsigned (&f)[4]) {
+    OM_HIP(hipMemcpyAsync(f, ws.flag, sizeof(f), hipMemcpyDeviceToHost, s));
+    OM_HIP(hipStreamSynchronize(s));
+    return 0;
+  }
+  // dense-score rows [r0, r0+n) and merge them into the lists (always exact, HBM heavy)
+  int dense_step(int64_t r0, int n, bool bf16) {
+    if (bf16) {
+      if (om_gemm_nt(OM_BF16, ws.qb, d, idx16 + r0 * d, d, OM_F32, ws.dense, DENSE_CHUNK, nq, n, d,
+                     nullptr, nullptr, 0, OM_ACT_NONE, s)) return 1;
+    } else {
+      if (om_gemm_nt(OM_F32, q32, d, idx32 + r0 * d, d, OM_F32, ws.dense, DENSE_CHUNK, nq, n, d,
+                     nullptr, nullptr, 0, OM_ACT_NONE, s)) return 1;
+    }
+    hipLaunchKernelGGL(append_dense_kernel, dim3((unsigned)nq), dim3(256), 0, s, ws.dense,
+                       (int64_t)DENSE_CHUNK, n, (uint32_t)r0, ws.keys, ws.cnt);
+    OM_LAUNCH_CHECK();
+    return select(bf16);
+  }
+  int filter_step(int64_t r0, int64_t n, bool bf16) {
+    const int64_t ntm = (n + GEMM_BM - 1) / GEMM_BM, ntn = (nq + GEMM_BN - 1) / GEMM_BN;
+    if (ntm * ntn > 0x7fffffffLL) OM_FAIL("scan grid too large");
+    if (bf16)
+      hipLaunchKernelGGL((sim_filter_kernel<bf16_t>), dim3((unsigned)(ntm * ntn)), dim3(GEMM_THREADS),
+                         GEMM_LDS_BYTES, s, idx16 + r0 * d, n, (uint32_t)r0, ws.qb, nq, (int64_t)d,
+                         ws.thr, ws.keys, ws.cnt, 8);
+    else
+      hipLaunchKernelGGL((sim_filter_kernel<float>), dim3((unsigned)(ntm * ntn)), dim3(GEMM_THREADS),
+                         GEMM_LDS_BYTES, s, idx32 + r0 * d, n, (uint32_t)r0, q32, nq, (int64_t)d,
+                         ws.thr, ws.keys, ws.cnt, 8);
+    OM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(check_overflow_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s,
+                       ws.cnt, nq, ws.flag);
+    OM_LAUNCH_CHECK();
+    return 0;
+  }
+
+  // returns 0 ok, 1 error, 2 certified margin too wide (caller retries in f32)
+  int run(bool bf16) {
+    OM_HIP(hipMemsetAsync(ws.flag, 0, 64, s));
+    hipLaunchKernelGGL(init_lists_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s,
+                       ws.cnt, ws.cnt_prev, ws.thr, nq);
+    OM_LAUNCH_CHECK();
+    if (bf16) {
+      hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, q32,
+                         ws.qb, ws.margin, stats, nq, d);
+      OM_LAUNCH_CHECK();
+    }
+    int64_t done = 0;
+    unsigned f[4];
+    // bootstrap
+    {
+      const int n = (int)std::min<int64_t>(N, DENSE_CHUNK);
+      if (dense_step(0, n, bf16)) return 1;
+      done = n;
+      if (read_flags(f)) return 1;
+      if (f[2]) return 2;
+    }
+    while (done < N) {
+      const int64_t list = std::max<unsigned>(f[1], 1u);
+      // expected survivors of a chunk ~ list * chunk / done ; aim at half the free slots
+      int64_t chunk = (int64_t)((double)done * (double)(SORT_CAP - list) / (2.0 * (double)list));
+      chunk = std::max<int64_t>(chunk, DENSE_CHUNK);
+      chunk = std::min<int64_t>(chunk, N - done);
+      OM_HIP(hipMemsetAsync(ws.flag, 0, 64, s));
+      if (filter_step(done, chunk, bf16)) return 1;
+      if (read_flags(f)) return 1;
+      if (!f[0]) {
+        if (select(bf16)) return 1;
+      } else {
+        // a list overflowed: rewind to the pre-chunk lists and redo the chunk densely
+        hipLaunchKernelGGL(restore_cnt_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s,
+                           ws.cnt, ws.cnt_prev, nq);
+        OM_LAUNCH_CHECK();
+        for (int64_t r = done; r < done + chunk; r += DENSE_CHUNK) {
+          OM_HIP(hipMemsetAsync(ws.flag, 0, 64, s));
+          if (dense_step(r, (int)std::min<int64_t>(DENSE_CHUNK, done + chunk - r), bf16)) return 1;
+          if (bf16) {
+            if (read_flags(f)) return 1;
+            if (f[2]) return 2;
+          }
+        }
+      }
+      if (read_flags(f)) return 1;
+      if (f[2]) return 2;
+      done += chunk;
+    }
+    if (bf16) {
+      // exact f32 re-score of the certified candidate set, then the true top-k
+      const unsigned maxlist = std::max<unsigned>(f[1], 1u);
+      hipLaunchKernelGGL(rescore_kernel, dim3((maxlist + 3) / 4, (unsigned)nq), dim3(256), 0, s, q32,
+                         idx32, ws.keys, ws.cnt, d);
+      OM_LAUNCH_CHECK();
+      if (select(false)) return 1;
+    }
+    return 0;
+  }
+  const float* stats;
+};
+}  // namespace
+
+extern "C" int om_sim_topk(int mode, const float* queries, int64_t n_queries,
+                           const float* index_f32, const void* index_bf16, const float* stats,
+                           int64_t N, int d, int k, int64_t id_offset, float* out_scores,
+                           int64_t* out_ids, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+  if (n_queries <= 0) return 0;
+  if (k < 1 || k > K_MAX) OM_FAIL("k must be in [1,2048]");
+  if (N < 0 || N > 0xffffffffLL) OM_FAIL("shard rows must fit in 32 bits");
+  if (d <= 0 || (d * 2) % GEMM_ROW_BYTES != 0) OM_FAIL("d must be a multiple of 64 (pad with zeros)");
+  if (n_queries > 65535) OM_FAIL("at most 65535 queries per call");
+  if (!queries || !out_scores || !out_ids) OM_FAIL("null argument");
+  if (!workspace || ((uintptr_t)workspace & 255)) OM_FAIL("workspace must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  Scan sc;
+  sc.ws = carve_search(n_queries, d, (char*)workspace);
+  if (sc.ws.total > workspace_bytes) OM_FAIL("workspace too small");
+  sc.mode = mode; sc.q32 = queries; sc.idx32 = index_f32; sc.idx16 = (const bf16_t*)index_bf16;
+  sc.nq = n_queries; sc.N = N; sc.d = d; sc.k = k; sc.s = s; sc.stats = stats;
+
+  static bool attr_set = false;
+  if (!attr_set) {
+    OM_HIP(hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               SORT_CAP * 8 + 16));
+    OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel<float>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel<bf16_t>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    attr_set = true;
+  }
+  if (N > 0) {
+    if (!index_f32) OM_FAIL("index_f32 is null");
+    int rc = 2;
+    if (mode == OM_SEARCH_BF16_RESCORE) {
+      if (!index_bf16 || !stats) OM_FAIL("bf16 mode needs index_bf16 and stats");
+      rc = sc.run(true);
+      if (rc == 1) return 1;
+    }
+    if (rc == 2 && sc.run(false)) return 1;  // f32 scan (requested, or margin too wide)
+  } else {
+    hipLaunchKernelGGL(init_lists_kernel, dim3((unsigned)((n_queries + 255) / 256)), dim3(256), 0, s,
+                       sc.ws.cnt, sc.ws.cnt_prev, sc.ws.thr, n_queries);
+    OM_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(emit_kernel, dim3((unsigned)n_queries), dim3(256), 0, s, sc.ws.keys, sc.ws.cnt, k,
+                     id_offset, out_scores, out_ids);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
