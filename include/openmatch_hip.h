@@ -61,6 +61,17 @@ int om_abi_version(void);
 /* Number of HIP devices visible, or -1 with om_last_error() set. */
 int om_device_count(void);
 
+/* Measurement aid (bench.py's `roofline` object): while enabled, every launch of the dense
+ * contraction kernel (class 0: bf16 encoder/scan GEMM, class 1: f32 GEMM, class 2: filtered
+ * index scan) is bracketed by hipEvents on the launch stream.  om_kernel_timing_read()
+ * synchronises those events, returns the summed kernel time / launch count / algorithmic
+ * FLOPs (2*M*N*K) of the class since the last reset, and resets it. */
+#define OM_TIMING_GEMM_BF16 0
+#define OM_TIMING_GEMM_F32 1
+#define OM_TIMING_SCAN 2
+int om_kernel_timing_enable(int enable);
+int om_kernel_timing_read(int kernel_class, double* total_ms, int64_t* launches, double* flops);
+
 /* ------------------------------------------------------------------------
  * Dense contraction  C[M,N] = act(A[M,K] · B[N,K]^T + bias[N]) + resid[M,N]
  * (torch.nn.Linear layout: B is the [out,in] weight).  Replaces the ATen/BLAS

@@ -92,5 +92,10 @@ __device__ inline unsigned xcd_remap(unsigned bid, unsigned nwg) {
   return base + bid / nx;
 }
 
+// ---- optional per-launch timing (abi.cpp) ------------------------------------
+bool om_timing_on();
+void om_timing_begin(int kernel_class, hipStream_t s);
+void om_timing_end(int kernel_class, hipStream_t s, double flops);
+
 static inline int64_t ceil_div_i64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -69,9 +69,13 @@ static int launch_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, v
   }
   // sweep order: keep `group_m` activation row-tiles resident while walking the weight tiles
   const int group_m = 8;
+  const int tclass = sizeof(T) == 2 ? OM_TIMING_GEMM_BF16 : OM_TIMING_GEMM_F32;
+  const bool timing = om_timing_on();
+  if (timing) om_timing_begin(tclass, s);
   hipLaunchKernelGGL((gemm_nt_kernel<T, OutT>), dim3((unsigned)nwg), dim3(GEMM_THREADS),
                      GEMM_LDS_BYTES, s, (const T*)A, lda, (const T*)B, ldb, (OutT*)C, ldc, M, N, K,
                      bias, (const OutT*)resid, ldr, act, group_m);
+  if (timing) om_timing_end(tclass, s, 2.0 * (double)M * (double)N * (double)K);
   OM_LAUNCH_CHECK();
   return 0;
 }

@@ -353,6 +353,8 @@ struct Scan {
   int filter_step(int64_t r0, int64_t n, bool bf16) {
     const int64_t ntm = (n + GEMM_BM - 1) / GEMM_BM, ntn = (nq + GEMM_BN - 1) / GEMM_BN;
     if (ntm * ntn > 0x7fffffffLL) OM_FAIL("scan grid too large");
+    const bool timing = om_timing_on();
+    if (timing) om_timing_begin(OM_TIMING_SCAN, s);
     if (bf16)
       hipLaunchKernelGGL((sim_filter_kernel<bf16_t>), dim3((unsigned)(ntm * ntn)), dim3(GEMM_THREADS),
                          GEMM_LDS_BYTES, s, idx16 + r0 * d, n, (uint32_t)r0, ws.qb, nq, (int64_t)d,
@@ -361,6 +363,7 @@ struct Scan {
       hipLaunchKernelGGL((sim_filter_kernel<float>), dim3((unsigned)(ntm * ntn)), dim3(GEMM_THREADS),
                          GEMM_LDS_BYTES, s, idx32 + r0 * d, n, (uint32_t)r0, q32, nq, (int64_t)d,
                          ws.thr, ws.keys, ws.cnt, 8);
+    if (timing) om_timing_end(OM_TIMING_SCAN, s, 2.0 * (double)n * (double)nq * (double)d);
     OM_LAUNCH_CHECK();
     hipLaunchKernelGGL(check_overflow_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s,
                        ws.cnt, nq, ws.flag);

@@ -1,0 +1,1 @@
+from .data_collator import DRInferenceCollator, QPCollator

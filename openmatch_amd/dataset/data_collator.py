@@ -1,0 +1,32 @@
+"""Batch collators with the reference's names and outputs (src/openmatch/dataset/data_collator.py)."""
+from dataclasses import dataclass
+
+from transformers import DataCollatorWithPadding, DefaultDataCollator
+
+
+def _flatten(groups):
+    return [x for g in groups for x in g] if groups and isinstance(groups[0], list) else groups
+
+
+@dataclass
+class QPCollator(DataCollatorWithPadding):
+    """List of {"query": enc, "passages": [enc, ...]} -> (queries, passages), each padded to its
+    fixed maximum length, so every batch has the static [B,32] / [B*n,128] shapes the HIP encoder
+    is tuned for (reference :8-40)."""
+    max_q_len: int = 32
+    max_p_len: int = 128
+
+    def __call__(self, features):
+        queries = _flatten([f["query"] for f in features])
+        passages = _flatten([f["passages"] for f in features])
+        pad = lambda items, n: self.tokenizer.pad(items, padding="max_length", max_length=n, return_tensors="pt")
+        return pad(queries, self.max_q_len), pad(passages, self.max_p_len)
+
+
+@dataclass
+class DRInferenceCollator(DefaultDataCollator):
+    """(text ids, tensor batch) for the encoding loops (reference :78-83)."""
+
+    def __call__(self, features):
+        text_ids = [f["text_id"] for f in features]
+        return text_ids, super().__call__(features)

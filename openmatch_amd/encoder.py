@@ -1,0 +1,202 @@
+"""Host side of the HIP encoder: turns a HF `BertModel` / `T5EncoderModel` (the parameter
+container the reference keeps in `DRModel.lm_q / lm_p`) into the packed device weights that
+`om_encoder_forward` consumes, and launches it.
+
+The HF module's own `forward` is never called on this path; it stays the owner of the
+parameters so `state_dict()` / `save_pretrained()` keep the reference's checkpoint layout
+(modeling/dense_retrieval_model.py:230-245).
+"""
+import ctypes as C
+
+import torch
+
+from . import native as N
+
+_ACT = {"gelu": N.ACT_GELU_ERF, "relu": N.ACT_RELU, "gelu_new": N.ACT_GELU_TANH,
+        "gelu_pytorch_tanh": N.ACT_GELU_TANH}
+
+
+def compute_dtype_code(model_args=None):
+    """bf16 MFMA when the caller asked for 16-bit compute the way the reference does
+    (`--fp16` -> torch autocast in retriever/dense_retriever.py:76, or ModelArguments.dtype),
+    exact f32 MFMA otherwise."""
+    if torch.is_autocast_enabled():
+        return N.OM_BF16
+    dt = getattr(model_args, "dtype", None) if model_args is not None else None
+    if dt in ("bfloat16", "float16", "bf16", "fp16"):
+        return N.OM_BF16
+    return N.OM_F32
+
+
+class _Packed:
+    """Device copies of one encoder's weights in one compute dtype + the ctypes views of them."""
+
+    def __init__(self):
+        self.keep = []       # tensors that must outlive the ctypes pointers
+        self.cfg = {}
+        self.weights = N.OmEncoderWeights()
+        self.layers = None
+
+    def dev(self, t, dtype, device):
+        t = t.detach().to(device=device, dtype=dtype).contiguous()
+        self.keep.append(t)
+        return t.data_ptr()
+
+
+def _arch_of(model):
+    name = type(model).__name__
+    if "T5" in name:
+        return "t5"
+    if name.startswith("Bert") or "Bert" in name and "Roberta" not in name:
+        return "bert"
+    raise NotImplementedError(
+        f"openmatch_amd has HIP encoders for BERT and T5-encoder backbones; got {name}")
+
+
+def _pack_bert(model, code, device):
+    cfg = model.config
+    if getattr(cfg, "position_embedding_type", "absolute") != "absolute":
+        raise NotImplementedError("only absolute position embeddings are supported")
+    wd = torch.bfloat16 if code == N.OM_BF16 else torch.float32
+    f32 = torch.float32
+    pk = _Packed()
+    emb = model.embeddings
+    w = pk.weights
+    w.word_emb = pk.dev(emb.word_embeddings.weight, f32, device)
+    w.pos_emb = pk.dev(emb.position_embeddings.weight, f32, device)
+    w.type_emb = pk.dev(emb.token_type_embeddings.weight, f32, device)
+    w.emb_ln_g = pk.dev(emb.LayerNorm.weight, f32, device)
+    w.emb_ln_b = pk.dev(emb.LayerNorm.bias, f32, device)
+    layers = (N.OmLayerWeights * cfg.num_hidden_layers)()
+    for i, layer in enumerate(model.encoder.layer):
+        at, lw = layer.attention, layers[i]
+        qkv_w = torch.cat([at.self.query.weight, at.self.key.weight, at.self.value.weight], 0)
+        qkv_b = torch.cat([at.self.query.bias, at.self.key.bias, at.self.value.bias], 0)
+        lw.qkv_w = pk.dev(qkv_w, wd, device)
+        lw.qkv_b = pk.dev(qkv_b, f32, device)
+        lw.o_w = pk.dev(at.output.dense.weight, wd, device)
+        lw.o_b = pk.dev(at.output.dense.bias, f32, device)
+        lw.ln1_g = pk.dev(at.output.LayerNorm.weight, f32, device)
+        lw.ln1_b = pk.dev(at.output.LayerNorm.bias, f32, device)
+        lw.ffn1_w = pk.dev(layer.intermediate.dense.weight, wd, device)
+        lw.ffn1_b = pk.dev(layer.intermediate.dense.bias, f32, device)
+        lw.ffn2_w = pk.dev(layer.output.dense.weight, wd, device)
+        lw.ffn2_b = pk.dev(layer.output.dense.bias, f32, device)
+        lw.ln2_g = pk.dev(layer.output.LayerNorm.weight, f32, device)
+        lw.ln2_b = pk.dev(layer.output.LayerNorm.bias, f32, device)
+    pk.layers = layers
+    w.layers_host = C.cast(layers, C.POINTER(N.OmLayerWeights))
+    act = cfg.hidden_act if isinstance(cfg.hidden_act, str) else "gelu"
+    if act not in _ACT:
+        raise NotImplementedError(f"activation {act!r} has no HIP epilogue")
+    pk.cfg = dict(arch=N.ARCH_BERT, dtype=code, hidden=cfg.hidden_size, n_layers=cfg.num_hidden_layers,
+                  n_heads=cfg.num_attention_heads, head_dim=cfg.hidden_size // cfg.num_attention_heads,
+                  ffn=cfg.intermediate_size, vocab=cfg.vocab_size, max_pos=cfg.max_position_embeddings,
+                  type_vocab=cfg.type_vocab_size, act=_ACT[act], ln_eps=float(cfg.layer_norm_eps),
+                  rel_buckets=0, rel_max_dist=0)
+    return pk
+
+
+def _pack_t5(model, code, device):
+    cfg = model.config
+    if cfg.num_heads * cfg.d_kv != cfg.d_model:
+        raise NotImplementedError("T5 with inner_dim != d_model is not supported")
+    wd = torch.bfloat16 if code == N.OM_BF16 else torch.float32
+    f32 = torch.float32
+    pk = _Packed()
+    enc = model.encoder
+    w = pk.weights
+    w.word_emb = pk.dev(enc.embed_tokens.weight, f32, device)
+    w.final_ln_g = pk.dev(enc.final_layer_norm.weight, f32, device)
+    w.rel_bias = pk.dev(enc.block[0].layer[0].SelfAttention.relative_attention_bias.weight, f32, device)
+    layers = (N.OmLayerWeights * cfg.num_layers)()
+    gated = bool(getattr(cfg, "is_gated_act", False))
+    for i, block in enumerate(enc.block):
+        sa, ff, lw = block.layer[0].SelfAttention, block.layer[1].DenseReluDense, layers[i]
+        lw.qkv_w = pk.dev(torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], 0), wd, device)
+        lw.o_w = pk.dev(sa.o.weight, wd, device)
+        lw.ln1_g = pk.dev(block.layer[0].layer_norm.weight, f32, device)
+        lw.ln2_g = pk.dev(block.layer[1].layer_norm.weight, f32, device)
+        if gated:
+            lw.ffn1_w = pk.dev(ff.wi_0.weight, wd, device)
+            lw.ffn1g_w = pk.dev(ff.wi_1.weight, wd, device)
+        else:
+            lw.ffn1_w = pk.dev(ff.wi.weight, wd, device)
+        lw.ffn2_w = pk.dev(ff.wo.weight, wd, device)
+    pk.layers = layers
+    w.layers_host = C.cast(layers, C.POINTER(N.OmLayerWeights))
+    act = cfg.dense_act_fn
+    if act not in _ACT:
+        raise NotImplementedError(f"activation {act!r} has no HIP epilogue")
+    pk.cfg = dict(arch=N.ARCH_T5, dtype=code, hidden=cfg.d_model, n_layers=cfg.num_layers,
+                  n_heads=cfg.num_heads, head_dim=cfg.d_kv, ffn=cfg.d_ff, vocab=cfg.vocab_size,
+                  max_pos=0, type_vocab=0, act=_ACT[act], ln_eps=float(cfg.layer_norm_epsilon),
+                  rel_buckets=cfg.relative_attention_num_buckets,
+                  rel_max_dist=cfg.relative_attention_max_distance)
+    return pk
+
+
+_PACK_CACHE_ATTR = "_openmatch_amd_packed"
+
+
+def _version_key(model, head):
+    mods = [model] + ([head] if head is not None else [])
+    return tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters())
+
+
+def packed_weights(model, head, code, device):
+    """Packed weights for (model, head, dtype, device), rebuilt only when a parameter changed."""
+    cache = model.__dict__.setdefault(_PACK_CACHE_ATTR, {})
+    key = (code, str(device), id(head))
+    ver = _version_key(model, head)
+    hit = cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    pk = _pack_bert(model, code, device) if _arch_of(model) == "bert" else _pack_t5(model, code, device)
+    if head is not None:
+        lin = head.linear
+        pk.weights.head_w = pk.dev(lin.weight, torch.float32, device)
+        pk.cfg.update(head_in=lin.in_features, head_out=lin.out_features)
+    else:
+        pk.cfg.update(head_in=0, head_out=0)
+    cache[key] = (ver, pk)
+    return pk
+
+
+_POOL = {None: N.POOL_NONE, "first": N.POOL_FIRST, "mean": N.POOL_MEAN}
+
+
+def hip_encode(model, items, pooling, head, normalize, code, want_hidden=True):
+    """(hidden [B,L,H], reps [B,D] f32) through om_encoder_forward.  `items` holds
+    input_ids / attention_mask / optional token_type_ids as int64 device tensors."""
+    if pooling not in _POOL:
+        raise ValueError("Unknown pooling type: {}".format(pooling))
+    ids = items["input_ids"]
+    mask = items["attention_mask"]
+    tti = items.get("token_type_ids") if hasattr(items, "get") else None
+    if ids.dim() != 2:
+        raise ValueError("input_ids must be [batch, length]")
+    ids = ids.to(torch.int64).contiguous()
+    mask = mask.to(device=ids.device, dtype=torch.int64).contiguous()
+    if tti is not None:
+        tti = tti.to(device=ids.device, dtype=torch.int64).contiguous()
+    N.require_device(ids, mask, tti)
+    device = ids.device
+    pk = packed_weights(model, head, code, device)
+    cfg = N.OmEncoderConfig(pooling=_POOL[pooling], normalize=int(bool(normalize)), **pk.cfg)
+    B, L = ids.shape
+    H = cfg.hidden
+    D = cfg.head_out if cfg.head_in > 0 else H
+    lib = N.lib()
+    with torch.cuda.device(device):
+        nbytes = lib.om_encoder_workspace_bytes(C.byref(cfg), B, L)
+        ws_buf, ws_ptr = N.Workspace.get(device, nbytes, "encoder")
+        hidden = None
+        if want_hidden:
+            hidden = torch.empty(B, L, H, device=device,
+                                 dtype=torch.bfloat16 if code == N.OM_BF16 else torch.float32)
+        reps = torch.empty(B, D, device=device, dtype=torch.float32) if pooling is not None else None
+        N.check(lib.om_encoder_forward(C.byref(cfg), C.byref(pk.weights), N.ptr(ids), N.ptr(mask),
+                                       N.ptr(tti), B, L, N.ptr(hidden), N.ptr(reps),
+                                       C.c_void_p(ws_ptr), nbytes, N.stream_ptr(device)))
+    return hidden, reps

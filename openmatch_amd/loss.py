@@ -1,0 +1,39 @@
+"""Loss callables of the reference's GradCache path (src/openmatch/loss.py:7-38) on top of the
+HIP contrastive kernel.  Same call signatures."""
+import torch
+from torch import Tensor
+from torch import distributed as dist
+
+from .ops import contrastive_loss
+
+
+class SimpleContrastiveLoss:
+    def __call__(self, x: Tensor, y: Tensor, target: Tensor = None, reduction: str = "mean"):
+        if target is not None or reduction != "mean":
+            raise NotImplementedError("only the default in-batch target with mean reduction has a HIP path")
+        n_psg = y.size(0) // x.size(0)
+        loss, _ = contrastive_loss(x, y, n_psg, 1.0, x, 0, y, 0)
+        return loss
+
+
+class DistributedContrastiveLoss(SimpleContrastiveLoss):
+    def __init__(self, n_target: int = 0, scale_loss: bool = True):
+        assert dist.is_initialized(), "Distributed training has not been properly initialized."
+        super().__init__()
+        self.word_size = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.scale_loss = scale_loss
+
+    def __call__(self, x: Tensor, y: Tensor, **kwargs):
+        if kwargs.get("target") is not None or kwargs.get("reduction", "mean") != "mean":
+            raise NotImplementedError("only the default in-batch target with mean reduction has a HIP path")
+        gx, gy = self.gather_tensor(x), self.gather_tensor(y)
+        n_psg = gy.size(0) // gx.size(0)
+        scale = float(self.word_size) if self.scale_loss else 1.0
+        loss, _ = contrastive_loss(gx, gy, n_psg, scale, x, self.rank * x.size(0), y, self.rank * y.size(0))
+        return loss
+
+    def gather_tensor(self, t):
+        out = torch.empty((self.word_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.detach().contiguous())
+        return out

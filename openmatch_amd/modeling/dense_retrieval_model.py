@@ -1,0 +1,217 @@
+"""Bi-encoder wrapper with the reference's public surface
+(src/openmatch/modeling/dense_retrieval_model.py): `DROutput`, `DRModel`, `DRModelForInference`.
+
+Same constructor, `forward(query, passage) -> DROutput`, `encode*`, `build`, `save`,
+`dist_gather_tensor`, checkpoint files and error messages.  What differs is underneath:
+`encode` never calls the HF module; it hands the token ids to `om_encoder_forward`
+(HIP: MFMA GEMMs, fused attention, LDS LayerNorm, pooling/head/normalise tail), the in-batch
+negatives loss runs in `om_contrastive_fwd_bwd`, and cross-device negatives are exchanged with
+one all-gather over RCCL.  There is no CPU or eager fallback.
+"""
+import copy
+import json
+import logging
+import os
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+from transformers import AutoModel, BatchEncoding, PreTrainedModel, T5EncoderModel
+from transformers.modeling_outputs import ModelOutput
+
+from ..arguments import DataArguments, ModelArguments
+from ..arguments import DRTrainingArguments as TrainingArguments
+from ..encoder import compute_dtype_code, hip_encode
+from ..ops import contrastive_loss, encode_with_grad
+from .linear import LinearHead
+
+logger = logging.getLogger(__name__)
+
+
+@dataclass
+class DROutput(ModelOutput):
+    q_reps: Tensor = None
+    p_reps: Tensor = None
+    loss: Tensor = None
+    scores: Tensor = None
+
+
+class DRModel(nn.Module):
+    def __init__(
+            self,
+            lm_q: PreTrainedModel,
+            lm_p: PreTrainedModel,
+            tied: bool = True,
+            feature: str = "last_hidden_state",
+            pooling: str = "first",
+            head_q: nn.Module = None,
+            head_p: nn.Module = None,
+            normalize: bool = False,
+            model_args: ModelArguments = None,
+            data_args: DataArguments = None,
+            train_args: TrainingArguments = None,
+    ):
+        super().__init__()
+        self.tied = tied
+        self.lm_q, self.lm_p = lm_q, lm_p
+        self.head_q, self.head_p = head_q, head_p
+        self.feature, self.pooling, self.normalize = feature, pooling, normalize
+        self.model_args, self.data_args, self.train_args = model_args, data_args, train_args
+
+        if train_args is not None and train_args.negatives_x_device:
+            if not dist.is_initialized():
+                raise ValueError('Distributed training has not been initialized for representation all gather.')
+            self.process_rank = dist.get_rank()
+            self.world_size = dist.get_world_size()
+
+    def _get_config_dict(self):
+        return {
+            "tied": self.tied,
+            "plm_backbone": {"type": type(self.lm_q).__name__, "feature": self.feature},
+            "pooling": self.pooling,
+            "linear_head": bool(self.head_q),
+            "normalize": self.normalize,
+        }
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, query: Dict[str, Tensor] = None, passage: Dict[str, Tensor] = None):
+        _, q_reps = self.encode_query(query)
+        _, p_reps = self.encode_passage(passage)
+        if q_reps is None or p_reps is None:
+            return DROutput(q_reps=q_reps, p_reps=p_reps)
+
+        xdev = self.train_args.negatives_x_device      # (the reference dereferences train_args too)
+        if xdev:
+            q_all, p_all = self.dist_gather_tensor(q_reps), self.dist_gather_tensor(p_reps)
+            q_row0, p_row0 = self.process_rank * q_reps.shape[0], self.process_rank * p_reps.shape[0]
+        else:
+            q_all, p_all, q_row0, p_row0 = q_reps, p_reps, 0, 0
+        # loss = mean_i CE(q_i . P^T, i * n_psg); x world_size in training to undo DDP's mean
+        scale = float(self.world_size) if (self.training and xdev) else 1.0
+        loss, scores = contrastive_loss(q_all, p_all, self.data_args.train_n_passages, scale,
+                                        q_reps, q_row0, p_reps, p_row0)
+        return DROutput(loss=loss, scores=scores, q_reps=q_all, p_reps=p_all)
+
+    # ------------------------------------------------------------------ encode
+    def encode(self, items, model, head):
+        if items is None:
+            return None, None
+        items = BatchEncoding(items)
+        if "T5" in type(model).__name__ and not self.model_args.encoder_only:
+            raise NotImplementedError(
+                "T5 encoder-decoder pooling (decoder step) has no HIP path yet; use "
+                "--encoder_only (T5EncoderModel), which is what GTR/sentence-T5 checkpoints need.")
+        if self.feature != "last_hidden_state":
+            raise NotImplementedError("only feature='last_hidden_state' is produced by the HIP encoder")
+        if self.pooling not in ("first", "mean"):
+            raise ValueError("Unknown pooling type: {}".format(self.pooling))
+        code = compute_dtype_code(self.model_args)
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
+        if needs_grad:
+            return encode_with_grad(model, head, items, self.pooling, self.normalize, code,
+                                    self.training)
+        return hip_encode(model, items, self.pooling, head, self.normalize, code)
+
+    def encode_passage(self, psg):
+        return self.encode(psg, self.lm_p, self.head_p)
+
+    def encode_query(self, qry):
+        return self.encode(qry, self.lm_q, self.head_q)
+
+    # ------------------------------------------------------------------ build / save
+    @classmethod
+    def build(cls, model_args: ModelArguments, data_args: DataArguments = None,
+              train_args: TrainingArguments = None, **hf_kwargs):
+        path = model_args.model_name_or_path
+        model_class = T5EncoderModel if model_args.encoder_only else AutoModel
+        config = None
+        head_q = head_p = None
+        cfg_file = os.path.join(path, "openmatch_config.json")
+        if os.path.exists(cfg_file):
+            with open(cfg_file) as f:
+                config = json.load(f)
+
+        if os.path.isdir(path) and config is not None:      # an OpenMatch checkpoint directory
+            tied = config["tied"]
+            if tied:
+                logger.info("loading model weight from %s", path)
+                lm_q = lm_p = model_class.from_pretrained(path, **hf_kwargs)
+                if config["linear_head"]:
+                    head_q = head_p = LinearHead.load(path)
+            else:
+                sub = lambda name: os.path.join(path, name)
+                logger.info("loading query model weight from %s", sub("query_model"))
+                lm_q = model_class.from_pretrained(sub("query_model"), **hf_kwargs)
+                logger.info("loading passage model weight from %s", sub("passage_model"))
+                lm_p = model_class.from_pretrained(sub("passage_model"), **hf_kwargs)
+                if config["linear_head"]:
+                    head_q = LinearHead.load(sub("query_head"))
+                    head_p = LinearHead.load(sub("passage_head"))
+        else:                                                # a plain Hugging Face model
+            tied = not model_args.untie_encoder
+            lm_q = model_class.from_pretrained(path, **hf_kwargs)
+            lm_p = lm_q if tied else copy.deepcopy(lm_q)
+            if model_args.add_linear_head:
+                head_q = LinearHead(model_args.projection_in_dim, model_args.projection_out_dim)
+                head_p = head_q if tied else copy.deepcopy(head_q)
+
+        return cls(
+            lm_q=lm_q, lm_p=lm_p, tied=tied,
+            feature=model_args.feature if config is None else config["plm_backbone"]["feature"],
+            pooling=model_args.pooling if config is None else config["pooling"],
+            head_q=head_q, head_p=head_p,
+            normalize=model_args.normalize if config is None else config["normalize"],
+            model_args=model_args, data_args=data_args, train_args=train_args,
+        )
+
+    def save(self, output_dir: str):
+        if self.tied:
+            self.lm_q.save_pretrained(output_dir)
+            if self.head_q is not None:
+                self.head_q.save(output_dir)
+        else:
+            for name, lm, head in (("query", self.lm_q, self.head_q), ("passage", self.lm_p, self.head_p)):
+                os.makedirs(os.path.join(output_dir, name + "_model"))
+                lm.save_pretrained(os.path.join(output_dir, name + "_model"))
+            if self.head_q is not None:
+                # (the reference writes the heads into directories it never creates; create them)
+                for name, head in (("query_head", self.head_q), ("passage_head", self.head_p)):
+                    os.makedirs(os.path.join(output_dir, name), exist_ok=True)
+                    head.save(os.path.join(output_dir, name))
+        with open(os.path.join(output_dir, "openmatch_config.json"), "w") as f:
+            json.dump(self._get_config_dict(), f, indent=4)
+
+    # ------------------------------------------------------------------ collectives
+    def dist_gather_tensor(self, t: Optional[torch.Tensor]):
+        """Rank-major concatenation of every rank's `t`; only this rank's slot keeps its autograd
+        history (reference :247-258).  One all_gather into a single buffer over RCCL/xGMI."""
+        if t is None:
+            return None
+        t = t.contiguous()
+        out = torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype,
+                          device=t.device)
+        dist.all_gather_into_tensor(out, t.detach())
+        if t.requires_grad:
+            parts = list(out.split(t.shape[0], dim=0))
+            parts[self.process_rank] = t
+            out = torch.cat(parts, dim=0)
+        return out
+
+
+class DRModelForInference(DRModel):
+    """No-grad variant (reference :261-282): `forward` returns only the representations."""
+
+    @torch.no_grad()
+    def encode_passage(self, psg):
+        return super().encode_passage(psg)
+
+    @torch.no_grad()
+    def encode_query(self, qry):
+        return super().encode_query(qry)
+
+    def forward(self, query: Dict[str, Tensor] = None, passage: Dict[str, Tensor] = None):
+        _, q_reps = self.encode_query(query)
+        _, p_reps = self.encode_passage(passage)
+        return DROutput(q_reps=q_reps, p_reps=p_reps)

@@ -1,0 +1,299 @@
+"""Corpus / query encoding loops and exact top-k retrieval with the reference's `Retriever`
+surface (src/openmatch/retriever/dense_retriever.py:25-236), re-designed for one process per
+MI355X:
+
+* embeddings stay resident on the GPU that produced them (one device->host copy at the end of
+  the loop, for the compatibility pickle, instead of one per batch — reference :81);
+* the index is `FlatIPIndex` (HIP, no faiss): in a multi-rank job every rank keeps ITS shard,
+  queries are all-gathered over RCCL, every shard is searched in parallel and the per-shard
+  top-k are merged on the GPU — replacing "rank 0 reads all pickles, faiss shards across GPUs,
+  7 ranks wait at a barrier" (:43-58,94-106,166-206);
+* file formats are unchanged: `embeddings.{corpus,query}.rank.{r}` = pickle protocol 4 of
+  (float32 ndarray [n,dim], list of ids).
+"""
+import gc
+import glob
+import logging
+import os
+import pickle
+import re
+from contextlib import nullcontext
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader, IterableDataset
+from tqdm import tqdm
+
+from ..arguments import InferenceArguments as EncodingArguments
+from ..dataset import DRInferenceCollator
+from ..index import FlatIPIndex, merge_topk
+from ..modeling import DRModelForInference, DROutput
+from ..utils import merge_retrieval_results_by_score
+
+logger = logging.getLogger(__name__)
+
+
+def _rank_of(path):
+    m = re.search(r"\.rank\.(\d+)$", path)
+    return int(m.group(1)) if m else 1 << 30
+
+
+def _corpus_partitions(output_dir):
+    """Shard files in rank order (the reference takes raw glob order, which is OS dependent)."""
+    return sorted(glob.glob(os.path.join(output_dir, "embeddings.corpus.rank.*")), key=lambda p: (_rank_of(p), p))
+
+
+class Retriever:
+
+    def __init__(self, model: DRModelForInference, corpus_dataset: IterableDataset, args: EncodingArguments):
+        logger.info("Initializing retriever")
+        self.model = model
+        self.corpus_dataset = corpus_dataset
+        self.args = args
+        self.doc_lookup = []
+        self.query_lookup = []
+        self.index = None
+        self._sharded = False          # True: self.index holds only this rank's rows
+        self._shard_offset = 0
+        self._resident_docs = None     # (device tensor [n,dim], ids) left by doc_embedding_inference
+        self._resident_queries = None
+
+        self.model.to(self.args.device)
+        self.model.eval()
+
+    # ------------------------------------------------------------------ encoding
+    def _autocast(self):
+        return torch.autocast("cuda", dtype=torch.bfloat16) if getattr(self.args, "fp16", False) else nullcontext()
+
+    def _encode_loop(self, dataset, is_query):
+        loader = DataLoader(
+            dataset,
+            batch_size=self.args.per_device_eval_batch_size,
+            collate_fn=DRInferenceCollator(),
+            num_workers=self.args.dataloader_num_workers,
+            pin_memory=self.args.dataloader_pin_memory,
+        )
+        chunks, ids = [], []
+        for batch_ids, batch in tqdm(loader, disable=self.args.local_process_index > 0):
+            ids.extend(batch_ids)
+            with self._autocast(), torch.no_grad():
+                batch = {k: v.to(self.args.device, non_blocking=True) for k, v in batch.items()}
+                out: DROutput = self.model(query=batch) if is_query else self.model(passage=batch)
+                chunks.append(out.q_reps if is_query else out.p_reps)      # stays in HBM
+        if chunks:
+            encoded = torch.cat(chunks)
+        else:
+            encoded = torch.empty(0, 0, device=self.args.device)
+        return encoded, ids
+
+    def _dump(self, kind, encoded, ids):
+        os.makedirs(self.args.output_dir, exist_ok=True)
+        path = os.path.join(self.args.output_dir, "embeddings.{}.rank.{}".format(kind, self.args.process_index))
+        with open(path, "wb") as f:
+            pickle.dump((encoded.cpu().numpy(), ids), f, protocol=4)
+
+    def doc_embedding_inference(self):
+        if self.corpus_dataset is None:
+            raise ValueError("No corpus dataset provided")
+        encoded, ids = self._encode_loop(self.corpus_dataset, is_query=False)
+        self._resident_docs = (encoded, ids)
+        self._dump("corpus", encoded, ids)
+        if self.args.world_size > 1:
+            dist.barrier()
+
+    def query_embedding_inference(self, query_dataset: IterableDataset):
+        encoded, ids = self._encode_loop(query_dataset, is_query=True)
+        self._resident_queries = (encoded, ids)
+        self._dump("query", encoded, ids)
+        if self.args.world_size > 1:
+            dist.barrier()
+
+    # ------------------------------------------------------------------ index
+    def _initialize_faiss_index(self, dim: int):
+        """Kept under the reference's name; the index is the HIP FlatIPIndex."""
+        self.index = FlatIPIndex(dim, device=self.args.device,
+                                 precision=os.environ.get("OPENMATCH_AMD_SEARCH", "bf16_rescore"))
+
+    def _move_index_to_gpu(self):
+        """No-op: the index is born on the GPU (the reference clones a CPU index into faiss-GPU)."""
+        logger.info("Index already resides in HBM")
+
+    def init_index_and_add(self, partition: str = None):
+        """Reference semantics (:94-106): load the given partition file, or ALL of them, into one
+        complete local index; `doc_lookup[i]` is the id of index row i."""
+        logger.info("Initializing the inner-product index from pre-computed document embeddings")
+        partitions = [partition] if partition is not None else _corpus_partitions(self.args.output_dir)
+        for i, part in enumerate(partitions):
+            with open(part, "rb") as f:
+                encoded, lookup = pickle.load(f)
+            if i == 0:
+                self._initialize_faiss_index(encoded.shape[1])
+            self.index.add(encoded)
+            self.doc_lookup.extend(lookup)
+        self._sharded = False
+
+    def _init_sharded_index(self):
+        """Multi-rank path: every rank indexes only its own rows (resident tensor if this process
+        encoded them, else the partition files rank, rank+W, ...).  Collective."""
+        W, r = self.args.world_size, self.args.process_index
+        if self._resident_docs is not None:
+            encoded, lookup = self._resident_docs
+            parts = [(encoded, lookup)]
+        else:
+            files = _corpus_partitions(self.args.output_dir)
+            if len(files) % W != 0:
+                raise ValueError(f"{len(files)} corpus partitions cannot be split evenly over {W} ranks")
+            parts = []
+            for path in files[r * (len(files) // W):(r + 1) * (len(files) // W)]:
+                with open(path, "rb") as f:
+                    parts.append(pickle.load(f))
+        local_lookup = []
+        for i, (encoded, lookup) in enumerate(parts):
+            if i == 0:
+                self._initialize_faiss_index(encoded.shape[1])
+            self.index.add(encoded)
+            local_lookup.extend(lookup)
+        sizes = [None] * W
+        dist.all_gather_object(sizes, len(local_lookup))
+        self._shard_offset = int(sum(sizes[:r]))
+        gathered = [None] * W if r == 0 else None
+        dist.gather_object(local_lookup, gathered, dst=0)
+        self.doc_lookup = [x for part in gathered for x in part] if r == 0 else []
+        self._sharded = True
+
+    @classmethod
+    def build_all(cls, model: DRModelForInference, corpus_dataset: IterableDataset, args: EncodingArguments):
+        retriever = cls(model, corpus_dataset, args)
+        retriever.doc_embedding_inference()
+        if args.world_size > 1:
+            retriever._init_sharded_index()
+            dist.barrier()
+        else:
+            retriever.init_index_and_add()
+        return retriever
+
+    @classmethod
+    def build_embeddings(cls, model: DRModelForInference, corpus_dataset: IterableDataset, args: EncodingArguments):
+        retriever = cls(model, corpus_dataset, args)
+        retriever.doc_embedding_inference()
+        return retriever
+
+    @classmethod
+    def from_embeddings(cls, model: DRModelForInference, args: EncodingArguments):
+        retriever = cls(model, None, args)
+        if args.world_size > 1:
+            retriever._init_sharded_index()
+            dist.barrier()
+        else:
+            retriever.init_index_and_add()
+        return retriever
+
+    def reset_index(self):
+        if self.index:
+            self.index.reset()
+        self.doc_lookup = []
+        self.query_lookup = []
+
+    # ------------------------------------------------------------------ search
+    def _load_queries(self):
+        """All ranks' query embeddings in rank order + ids (reference :170-177)."""
+        encoded, lookup = [], []
+        for i in range(self.args.world_size):
+            with open(os.path.join(self.args.output_dir, "embeddings.query.rank.{}".format(i)), "rb") as f:
+                e, ids = pickle.load(f)
+            encoded.append(e)
+            lookup.extend(ids)
+        return np.concatenate(encoded), lookup
+
+    def _hits_to_dict(self, D, I, topk):
+        original = np.array(self.doc_lookup)[I]      # I == -1 (fewer than k rows) -> last doc, as in faiss+numpy
+        out = {}
+        for q in range(D.shape[0]):
+            qid = str(self.query_lookup[q])
+            out[qid] = {str(doc): float(score) for doc, score in zip(original[q], D[q])}
+        return out
+
+    def search(self, topk: int = 100):
+        logger.info("Searching")
+        if self.index is None:
+            raise ValueError("Index is not initialized")
+        if self._sharded:
+            return self._search_sharded(topk)
+        encoded, lookup = self._load_queries()
+        self.query_lookup.extend(lookup)
+        D, I = self.index.search(encoded, topk)
+        result = self._hits_to_dict(D, I, topk)
+        logger.info("End searching with {} queries".format(len(result)))
+        return result
+
+    def _search_sharded(self, topk):
+        """Collective over all ranks: all-gather queries, search local shard, gather + merge on
+        rank 0.  Returns the result dict on rank 0 and {} elsewhere (as `retrieve` does)."""
+        W, r, dev = self.args.world_size, self.args.process_index, self.args.device
+        if self._resident_queries is not None:
+            q_local, ids_local = self._resident_queries
+        else:
+            with open(os.path.join(self.args.output_dir, "embeddings.query.rank.{}".format(r)), "rb") as f:
+                e, ids_local = pickle.load(f)
+            q_local = torch.from_numpy(e).to(dev)
+        counts = [None] * W
+        dist.all_gather_object(counts, (int(q_local.shape[0]), list(ids_local)))
+        nmax, dim = max(c[0] for c in counts), self.index.d
+        padded = torch.zeros(nmax, dim, dtype=torch.float32, device=dev)
+        if q_local.shape[0]:
+            padded[:q_local.shape[0]].copy_(q_local)
+        gathered = torch.empty(W * nmax, dim, dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(gathered, padded)
+        queries = torch.cat([gathered[i * nmax:i * nmax + counts[i][0]] for i in range(W)])
+        D, I = self.index.search_device(queries, topk, id_offset=self._shard_offset)
+        parts_D = [torch.empty_like(D) for _ in range(W)] if r == 0 else None
+        parts_I = [torch.empty_like(I) for _ in range(W)] if r == 0 else None
+        dist.gather(D, parts_D, dst=0)
+        dist.gather(I, parts_I, dst=0)
+        if r != 0:
+            return {}
+        Dm, Im = merge_topk(torch.stack(parts_D), torch.stack(parts_I), topk)
+        self.query_lookup.extend(x for c in counts for x in c[1])
+        return self._hits_to_dict(Dm.cpu().numpy(), Im.cpu().numpy(), topk)
+
+    def retrieve(self, query_dataset: IterableDataset, topk: int = 100):
+        self.query_embedding_inference(query_dataset)
+        del self.model                       # as the reference: the retriever gives the encoder up
+        gc.collect()
+        torch.cuda.empty_cache()
+        results = {}
+        if self._sharded:
+            results = self.search(topk)      # collective; non-zero ranks get {}
+        elif self.args.process_index == 0:
+            results = self.search(topk)
+        if self.args.world_size > 1:
+            dist.barrier()
+        return results
+
+
+class SuccessiveRetriever(Retriever):
+    """Out-of-core variant (reference :209-236): one partition resident at a time on rank 0,
+    partial results merged by score."""
+
+    @classmethod
+    def from_embeddings(cls, model: DRModelForInference, args: EncodingArguments):
+        return cls(model, None, args)
+
+    def retrieve(self, query_dataset: IterableDataset, topk: int = 100):
+        self.query_embedding_inference(query_dataset)
+        del self.model
+        gc.collect()
+        torch.cuda.empty_cache()
+        final_result: Dict[str, Dict[str, float]] = {}
+        if self.args.process_index == 0:
+            for partition in _corpus_partitions(self.args.output_dir):
+                logger.info("Loading partition {}".format(partition))
+                self.init_index_and_add(partition)
+                cur_result = self.search(topk)
+                self.reset_index()
+                final_result = merge_retrieval_results_by_score([final_result, cur_result], topk)
+        if self.args.world_size > 1:
+            dist.barrier()
+        return final_result

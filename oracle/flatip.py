@@ -40,7 +40,7 @@ class IndexFlatIP:
         x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dtype)
         Y = self._matrix()
         nq, n = x.shape[0], Y.shape[0]
-        D = torch.full((nq, k), -3.4028235e38, dtype=dtype)
+        D = torch.full((nq, k), float(np.finfo(np.float32).min), dtype=dtype)
         I = torch.full((nq, k), -1, dtype=torch.int64)
         best_s = torch.empty((nq, 0), dtype=dtype)
         best_i = torch.empty((nq, 0), dtype=torch.int64)
