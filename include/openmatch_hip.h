@@ -34,6 +34,7 @@ extern "C" {
 /* element types */
 #define OM_F32 0
 #define OM_BF16 1
+#define OM_F16 2 /* IEEE half: search shadow index only */
 
 /* GEMM epilogue activation */
 #define OM_ACT_NONE 0
@@ -53,7 +54,7 @@ extern "C" {
 
 /* search precision */
 #define OM_SEARCH_F32 0           /* exact f32 MFMA scan                                   */
-#define OM_SEARCH_BF16_RESCORE 1  /* bf16 MFMA candidate scan + exact f32 re-score (same ids) */
+#define OM_SEARCH_F16_RESCORE 1   /* f16 MFMA candidate scan + exact f32 re-score (same ids)  */
 
 const char* om_last_error(void);
 int om_abi_version(void);
@@ -163,25 +164,33 @@ int om_encoder_forward(const OmEncoderConfig* cfg, const OmEncoderWeights* w,
  * (retriever/dense_retriever.py:38-41,105,180) and faiss-GPU sharding (:43-58).
  * ------------------------------------------------------------------------ */
 
-/* index.add(): make the bf16 shadow copy of rows [0,N) and accumulate the
- * rounding statistics the certified candidate margin needs.
- * stats: device float[2] = {max_i ||p_i - bf16(p_i)||_2 , max_i ||bf16(p_i)||_2},
- * updated with max (initialise to 0 before the first add). */
-int om_index_to_bf16(const float* rows_f32, int64_t N, int d, void* rows_bf16, float* stats,
-                     void* stream);
+/* index.add(): make the 16-bit shadow copy of rows [0,N) and accumulate the rounding
+ * statistics the certified candidate margin needs.  The shadow is IEEE f16, not bf16: same
+ * MFMA rate, 8x smaller rounding error, which is what keeps the certified margin (and with it
+ * the candidate lists) narrow on anisotropic embedding sets.
+ * stats: device float[2] = {max_i ||p_i - f16(p_i)||_2 , max_i ||f16(p_i)||_2}, updated with
+ * max (initialise to 0 before the first add; +inf if a value overflows f16 -> f32 scan). */
+int om_index_to_f16(const float* rows_f32, int64_t N, int d, void* rows_f16, float* stats,
+                    void* stream);
 
 size_t om_sim_topk_workspace_bytes(int64_t n_queries, int d, int k);
 
 /* D,I = index.search(x, k):  scores[Q,k] f32 sorted descending, ids[Q,k] int64 =
  * id_offset + row, padded with (-3.4028235e38, -1) when N < k (faiss semantics).
- * Ties are ordered by ascending row.  mode OM_SEARCH_BF16_RESCORE needs
- * index_bf16 + stats from om_index_to_bf16; returned scores are always the
+ * Ties are ordered by ascending row.  mode OM_SEARCH_F16_RESCORE needs
+ * index_f16 + stats from om_index_to_f16; returned scores are always the
  * exact f32 inner products.  Synchronises `stream` internally (reads back
  * overflow flags between scan rounds).  k <= 2048. */
 int om_sim_topk(int mode, const float* queries, int64_t n_queries, const float* index_f32,
-                const void* index_bf16, const float* stats, int64_t N, int d, int k,
+                const void* index_f16, const float* stats, int64_t N, int d, int k,
                 int64_t id_offset, float* out_scores, int64_t* out_ids, void* workspace,
                 size_t workspace_bytes, void* stream);
+
+/* Diagnostics of the calling thread's last om_sim_topk: out[0] = scan precision that produced
+ * the result (0 f32, 1 f16+rescore), [1] = scan rounds, [2] = overflow fallbacks (chunks redone
+ * densely), [3] = longest candidate list, [4] = 1 if the certified f16 margin was too wide and
+ * the call fell back to the f32 scan. */
+void om_sim_topk_info(int64_t out[8]);
 
 /* Merge W partial results (utils.py:215-229 merge_retrieval_results_by_score /
  * faiss shard merge): parts are [W][Q,k_in] row-major, each row descending;

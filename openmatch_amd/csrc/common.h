@@ -10,6 +10,8 @@
 typedef unsigned short bf16_t;  // raw bfloat16 bits
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment (4 VGPR)
 typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef _Float16 f16_t;                                         // IEEE half (search shadow index)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 MFMA accumulator
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
@@ -52,6 +54,11 @@ template <> struct ElemOps<float> {
   static constexpr int dtype = OM_F32;
   __device__ static inline float load(const float* p) { return *p; }
   __device__ static inline void store(float* p, float v) { *p = v; }
+};
+template <> struct ElemOps<f16_t> {
+  static constexpr int dtype = OM_F16;
+  __device__ static inline float load(const f16_t* p) { return (float)*p; }
+  __device__ static inline void store(f16_t* p, float v) { *p = (f16_t)v; }
 };
 template <> struct ElemOps<bf16_t> {
   static constexpr int dtype = OM_BF16;

@@ -1,6 +1,6 @@
 // HBM-bound helpers of the encoder: embedding gather + LayerNorm (K1), LayerNorm / RMSNorm
 // (tails of K4/K6), pooling (K7), L2 normalise (K9), T5 relative-position bias, and the
-// f32 -> bf16 index shadow copy.  One wavefront (64 lanes) owns one row; 4 rows per block.
+// f32 -> f16 index shadow copy.  One wavefront (64 lanes) owns one row; 4 rows per block.
 #include "common.h"
 #include "kernels.h"
 
@@ -188,18 +188,18 @@ __global__ void t5_bias_kernel(const float* __restrict__ table, const int* __res
   }
 }
 
-// index.add(): bf16 shadow rows + rounding statistics for the certified search margin.
-__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void index_to_bf16_kernel(
-    const float* __restrict__ x, bf16_t* __restrict__ y, int64_t N, int d,
-    unsigned* __restrict__ stats) {
+// index.add(): f16 shadow rows + rounding statistics for the certified search margin.
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void index_to_f16_kernel(
+    const float* __restrict__ x, f16_t* __restrict__ y, int64_t N, int d,
+    unsigned* stats) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= N) return;
   float e2 = 0.f, n2 = 0.f;
   for (int c = lane; c < d; c += 64) {
     const float v = x[row * d + c];
-    const bf16_t r = f32_to_bf16(v);
-    const float rv = bf16_to_f32(r);
+    const f16_t r = (f16_t)v;             // round-to-nearest-even; |v| > 65504 -> inf -> margin inf
+    const float rv = (float)r;
     y[row * d + c] = r;
     e2 += (v - rv) * (v - rv);
     n2 += rv * rv;
@@ -207,8 +207,9 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void index_to_bf16_kernel(
   e2 = wave_sum(e2); n2 = wave_sum(n2);
   if (lane == 0) {
     // non-negative floats order like their bit patterns; round the norms UP a little
-    atomicMax(stats + 0, __float_as_uint(sqrtf(e2) * 1.0001f));
-    atomicMax(stats + 1, __float_as_uint(sqrtf(n2) * 1.0001f));
+    const unsigned ue = __float_as_uint(sqrtf(e2) * 1.0001f), un = __float_as_uint(sqrtf(n2) * 1.0001f);
+    if (ue > stats[0]) atomicMax(stats + 0, ue);     // monotone max: the plain read only skips
+    if (un > stats[1]) atomicMax(stats + 1, un);     // atomics that cannot change the value
   }
 }
 
@@ -283,12 +284,12 @@ int omk_t5_bias(const float* table, const int* lut, float* out, int L, int heads
   return 0;
 }
 
-extern "C" int om_index_to_bf16(const float* rows_f32, int64_t N, int d, void* rows_bf16,
-                                float* stats, void* stream) {
+extern "C" int om_index_to_f16(const float* rows_f32, int64_t N, int d, void* rows_f16,
+                               float* stats, void* stream) {
   if (N <= 0) return 0;
   const unsigned grid = (unsigned)((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
-  hipLaunchKernelGGL(index_to_bf16_kernel, dim3(grid), dim3(64 * ROWS_PER_BLOCK), 0,
-                     (hipStream_t)stream, rows_f32, (bf16_t*)rows_bf16, N, d, (unsigned*)stats);
+  hipLaunchKernelGGL(index_to_f16_kernel, dim3(grid), dim3(64 * ROWS_PER_BLOCK), 0,
+                     (hipStream_t)stream, rows_f32, (f16_t*)rows_f16, N, d, (unsigned*)stats);
   OM_LAUNCH_CHECK();
   return 0;
 }

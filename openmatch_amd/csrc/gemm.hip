@@ -2,6 +2,7 @@
 // Stands in for the ATen/BLAS GEMM under every nn.Linear on the hot path
 // (HF:models/bert/modeling_bert.py:175-177,289-293,334-351; linear.py:22-23).
 #include "gemm_core.h"
+#include "kernels.h"
 
 __device__ inline float act_apply(float x, int act) {
   if (act == OM_ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -14,11 +15,23 @@ __device__ inline float act_apply(float x, int act) {
   return x;
 }
 
+// d/dx of the erf GELU
+__device__ inline float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+
 template <typename T, typename OutT>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(
     const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, OutT* C,
-    int64_t ldc, int64_t M, int64_t N, int64_t K, const float* __restrict__ bias,
-    const OutT* resid, int64_t ldr, int act, int group_m) {  // resid may alias C (in-place +=)
+    int64_t ldc, int64_t M, int64_t N, int64_t K, GemmEpilogue ep, int group_m) {
+  // ep.resid may alias C (in-place +=)
+  const float* __restrict__ bias = ep.bias;
+  const OutT* resid = (const OutT*)ep.resid;
+  const int64_t ldr = ep.ldr;
+  const int act = ep.act;
+  OutT* pre_act = (OutT*)ep.pre_act;
+  const uint32_t drop_thresh = ep.drop_p > 0.f ? (uint32_t)(ep.drop_p * 4294967296.0) : 0u;
+  const float drop_scale = ep.drop_p > 0.f ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int64_t ntm = (M + GEMM_BM - 1) / GEMM_BM, ntn = (N + GEMM_BN - 1) / GEMM_BN;
   int64_t tm, tn;
@@ -43,10 +56,18 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(
       for (int r = 0; r < 16; ++r) {
         const int64_t m = mbase + (r & 3) + 8 * (r >> 2);
         if (m >= M) continue;
-        float v = act_apply(acc[mi][ni][r] + bv, act & 0xff);
-        if (resid) {
-          const float rv = ElemOps<OutT>::load(resid + m * ldr + n);
-          v = (act & OM_ACT_MUL_RESID) ? v * rv : v + rv;
+        float v = acc[mi][ni][r] + bv;
+        if ((act & 0xff) == OM_ACT_GELU_ERF_GRAD) {          // v = acc * gelu'(resid)
+          v *= gelu_erf_grad(ElemOps<OutT>::load(resid + m * ldr + n));
+        } else {
+          if (pre_act) ElemOps<OutT>::store(pre_act + m * ep.ldp + n, v);
+          v = act_apply(v, act & 0xff);
+          if (drop_thresh)
+            v = dropout_keep(ep.seed, (uint64_t)m * (uint64_t)N + (uint64_t)n, drop_thresh) ? v * drop_scale : 0.f;
+          if (resid) {
+            const float rv = ElemOps<OutT>::load(resid + m * ldr + n);
+            v = (act & OM_ACT_MUL_RESID) ? v * rv : v + rv;
+          }
         }
         ElemOps<OutT>::store(C + m * ldc + n, v);
       }
@@ -56,8 +77,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(
 
 template <typename T, typename OutT>
 static int launch_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                       int64_t M, int64_t N, int64_t K, const float* bias, const void* resid,
-                       int64_t ldr, int act, hipStream_t s) {
+                       int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
   const int64_t ntm = (M + GEMM_BM - 1) / GEMM_BM, ntn = (N + GEMM_BN - 1) / GEMM_BN;
   const int64_t nwg = ntm * ntn;
   if (nwg > 0x7fffffffLL) OM_FAIL("grid too large");
@@ -69,35 +89,45 @@ static int launch_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, v
   }
   // sweep order: keep `group_m` activation row-tiles resident while walking the weight tiles
   const int group_m = 8;
-  const int tclass = sizeof(T) == 2 ? OM_TIMING_GEMM_BF16 : OM_TIMING_GEMM_F32;
+  const int tclass = sizeof(T) == 2 ? OM_TIMING_GEMM_BF16 : OM_TIMING_GEMM_F32;  // (f16 counts as 16-bit)
   const bool timing = om_timing_on();
   if (timing) om_timing_begin(tclass, s);
   hipLaunchKernelGGL((gemm_nt_kernel<T, OutT>), dim3((unsigned)nwg), dim3(GEMM_THREADS),
                      GEMM_LDS_BYTES, s, (const T*)A, lda, (const T*)B, ldb, (OutT*)C, ldc, M, N, K,
-                     bias, (const OutT*)resid, ldr, act, group_m);
+                     ep, group_m);
   if (timing) om_timing_end(tclass, s, 2.0 * (double)M * (double)N * (double)K);
   OM_LAUNCH_CHECK();
   return 0;
+}
+
+int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int out_dtype,
+             void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep,
+             hipStream_t s) {
+  if (M <= 0 || N <= 0) return 0;
+  if (K <= 0) OM_FAIL("K must be positive");
+  const int64_t es = in_dtype == OM_F32 ? 4 : 2;
+  if ((K * es) % GEMM_ROW_BYTES != 0) OM_FAIL("K*sizeof(elem) must be a multiple of 128 bytes");
+  if ((lda * es) % 16 != 0 || (ldb * es) % 16 != 0) OM_FAIL("lda/ldb must keep rows 16-byte aligned");
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) OM_FAIL("A/B must be 16-byte aligned");
+  if ((ep.act & 0xff) == OM_ACT_GELU_ERF_GRAD && !ep.resid) OM_FAIL("gelu-grad epilogue needs resid");
+  if (in_dtype == OM_BF16 && out_dtype == OM_BF16)
+    return launch_gemm<bf16_t, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+  if (in_dtype == OM_BF16 && out_dtype == OM_F32)
+    return launch_gemm<bf16_t, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+  if (in_dtype == OM_F32 && out_dtype == OM_F32)
+    return launch_gemm<float, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+  if (in_dtype == OM_F32 && out_dtype == OM_BF16)
+    return launch_gemm<float, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+  if (in_dtype == OM_F16 && out_dtype == OM_F32)
+    return launch_gemm<f16_t, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+  OM_FAIL("unsupported dtype combination");
 }
 
 extern "C" int om_gemm_nt(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb,
                           int out_dtype, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                           const float* bias, const void* resid, int64_t ldr, int act,
                           void* stream) {
-  if (M <= 0 || N <= 0) return 0;
-  if (K <= 0) OM_FAIL("K must be positive");
-  const int64_t es = in_dtype == OM_BF16 ? 2 : 4;
-  if ((K * es) % GEMM_ROW_BYTES != 0) OM_FAIL("K*sizeof(elem) must be a multiple of 128 bytes");
-  if ((lda * es) % 16 != 0 || (ldb * es) % 16 != 0) OM_FAIL("lda/ldb must keep rows 16-byte aligned");
-  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) OM_FAIL("A/B must be 16-byte aligned");
-  hipStream_t s = (hipStream_t)stream;
-  if (in_dtype == OM_BF16 && out_dtype == OM_BF16)
-    return launch_gemm<bf16_t, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, act, s);
-  if (in_dtype == OM_BF16 && out_dtype == OM_F32)
-    return launch_gemm<bf16_t, float>(A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, act, s);
-  if (in_dtype == OM_F32 && out_dtype == OM_F32)
-    return launch_gemm<float, float>(A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, act, s);
-  if (in_dtype == OM_F32 && out_dtype == OM_BF16)
-    return launch_gemm<float, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, act, s);
-  OM_FAIL("unsupported dtype combination");
+  GemmEpilogue ep = {};
+  ep.bias = bias; ep.resid = resid; ep.ldr = ldr; ep.act = act;
+  return omk_gemm(in_dtype, A, lda, B, ldb, out_dtype, C, ldc, M, N, K, ep, (hipStream_t)stream);
 }

@@ -39,6 +39,12 @@ template <> struct MmaOps<bf16_t> {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
 };
+template <> struct MmaOps<f16_t> {
+  typedef f16x8_t frag_t;
+  __device__ static inline void mma(const frag_t& a, const frag_t& b, f32x16_t& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
 template <> struct MmaOps<float> {
   typedef f32x4_t frag_t;
   __device__ static inline void mma(const frag_t& a, const frag_t& b, f32x16_t& c) {

@@ -18,3 +18,34 @@ int omk_t5_bias(const float* table, const int* lut, float* out, int L, int heads
 int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
                   const float* pos_bias, int64_t B, int L, int H, int heads, float scale,
                   hipStream_t s);
+
+// ---- extended GEMM epilogue (training) ---------------------------------------------------
+// order: v = acc + bias ; [pre_act <- v] ; v = act(v) ; v = dropout(v) ; v = v (+|*) resid
+// act == OM_ACT_GELU_ERF_GRAD:  v = (acc + bias) * gelu'(resid)   (backward through GELU)
+#define OM_ACT_GELU_ERF_GRAD 4
+struct GemmEpilogue {
+  const float* bias;
+  const void* resid;   // out dtype
+  int64_t ldr;
+  int act;
+  void* pre_act;       // out dtype, optional: value before the activation
+  int64_t ldp;
+  float drop_p;        // 0 = no dropout
+  uint64_t seed;
+};
+int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int out_dtype,
+             void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep,
+             hipStream_t s);
+
+// Stateless counter-based dropout: element `idx` of stream `seed` is kept iff hash >= p * 2^32.
+// Forward and backward regenerate the same mask from (seed, idx); nothing is stored.
+__host__ __device__ inline uint32_t om_hash32(uint64_t seed, uint64_t idx) {
+  uint64_t x = idx * 0x9E3779B97F4A7C15ull + seed;
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  return (uint32_t)x;
+}
+__host__ __device__ inline bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
+  return om_hash32(seed, idx) >= thresh;
+}

@@ -13,11 +13,13 @@
 //      raises theta_q.  If a list overflows (adversarial row order) the chunk is redone
 //      through the dense path, which is always exact.
 // Scores in OM_SEARCH_F32 mode come from the exact-f32 MFMA (k-ordered fmaf chain).
-// In OM_SEARCH_BF16_RESCORE mode the scan runs on the bf16 shadow index with a CERTIFIED
-// margin: |s_bf16 - s_f32| <= E_q = ||q||*max||p-bf16(p)|| + ||q-bf16(q)||*max||bf16(p)|| (+ f32
+// In OM_SEARCH_F16_RESCORE mode the scan runs on the IEEE-f16 shadow index with a CERTIFIED
+// margin: |s_f16 - s_f32| <= E_q = ||q||*max||p-f16(p)|| + ||q-f16(q)||*max||f16(p)|| (+ f32
 // accumulation slop), the list keeps everything within 2*E_q of the running k-th best, and
 // the survivors are re-scored with exact f32 dot products before the final top-k -- so the
 // returned ids are those of the f32 scan.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "gemm_core.h"
@@ -30,6 +32,7 @@
 #define SORT_THREADS 512
 
 typedef unsigned long long u64;
+static thread_local int64_t g_info[8];   // last om_sim_topk call: see om_sim_topk_info()
 
 __host__ __device__ inline u64 pack_key(float score, uint32_t payload) {
   return ((u64)f32_orderable(score) << 32) | (u64)(uint32_t)~payload;
@@ -116,7 +119,7 @@ __device__ inline void bitonic_sort_desc(u64* s, int P, int tid, int nthr) {
 }
 
 // Sort one list, keep the best k (exact mode) or everything within margin[q] of the k-th
-// best (certified bf16 mode), publish the new threshold.  flag[1] = max list length,
+// best (certified f16 mode), publish the new threshold.  flag[1] = max list length,
 // flag[2] |= a certified list outgrew LIST_MAX.
 __global__ __launch_bounds__(SORT_THREADS) void select_kernel(
     u64* __restrict__ keys, unsigned* __restrict__ cnt, unsigned* __restrict__ cnt_prev,
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(SORT_THREADS) void select_kernel(
 
 // per-query certified margin and bf16 copy of the queries
 __global__ __launch_bounds__(256) void query_prep_kernel(const float* __restrict__ q,
-                                                         bf16_t* __restrict__ qb,
+                                                         f16_t* __restrict__ qb,
                                                          float* __restrict__ margin,
                                                          const float* __restrict__ stats,
                                                          int64_t nq, int d) {
@@ -176,8 +179,8 @@ __global__ __launch_bounds__(256) void query_prep_kernel(const float* __restrict
   float n2 = 0.f, e2 = 0.f, b2 = 0.f;
   for (int c = lane; c < d; c += 64) {
     const float v = q[row * d + c];
-    const bf16_t r = f32_to_bf16(v);
-    const float rv = bf16_to_f32(r);
+    const f16_t r = (f16_t)v;
+    const float rv = (float)r;
     qb[row * d + c] = r;
     n2 += v * v; e2 += (v - rv) * (v - rv); b2 += rv * rv;
   }
@@ -185,7 +188,8 @@ __global__ __launch_bounds__(256) void query_prep_kernel(const float* __restrict
   if (lane == 0) {
     const float qn = sqrtf(n2), qe = sqrtf(e2), qbn = sqrtf(b2);
     const float Ep = stats[0], Pn = stats[1];
-    const float slop = 8.0f * (float)d * 5.9604645e-8f * (qn + qbn) * (Pn + Ep);
+    // f32 accumulation of the 16-bit scan and of the f32 re-score: each <= d * 2^-24 * |q||p|
+    const float slop = 3.0f * (float)d * 5.9604645e-8f * fmaxf(qn, qbn) * (Pn + Ep);
     margin[row] = 1.01f * (qn * Ep + qe * Pn) + slop;
   }
 }
@@ -294,7 +298,7 @@ extern "C" int om_topk_merge(const float* part_scores, const int64_t* part_ids, 
 
 // ---- host orchestration -------------------------------------------------------------------
 struct SearchWs {
-  u64* keys; unsigned *cnt, *cnt_prev, *flag; float *thr, *margin, *dense; bf16_t* qb;
+  u64* keys; unsigned *cnt, *cnt_prev, *flag; float *thr, *margin, *dense; f16_t* qb;
   size_t total;
 };
 static SearchWs carve_search(int64_t nq, int d, char* base) {
@@ -308,9 +312,13 @@ static SearchWs carve_search(int64_t nq, int d, char* base) {
   w.thr = (float*)take((size_t)nq * 4);
   w.margin = (float*)take((size_t)nq * 4);
   w.dense = (float*)take((size_t)nq * DENSE_CHUNK * 4);
-  w.qb = (bf16_t*)take((size_t)nq * d * 2);
+  w.qb = (f16_t*)take((size_t)nq * d * 2);
   w.total = off;
   return w;
+}
+
+extern "C" void om_sim_topk_info(int64_t out[8]) {
+  for (int i = 0; i < 8; ++i) out[i] = g_info[i];
 }
 
 extern "C" size_t om_sim_topk_workspace_bytes(int64_t n_queries, int d, int k) {
@@ -321,7 +329,7 @@ extern "C" size_t om_sim_topk_workspace_bytes(int64_t n_queries, int d, int k) {
 
 namespace {
 struct Scan {
-  int mode; const float* q32; const float* idx32; const bf16_t* idx16; int64_t nq, N; int d, k;
+  int mode; const float* q32; const float* idx32; const f16_t* idx16; int64_t nq, N; int d, k;
   SearchWs ws; hipStream_t s;
 
   int select(bool certified) {
@@ -339,7 +347,7 @@ struct Scan {
   // dense-score rows [r0, r0+n) and merge them into the lists (always exact, HBM heavy)
   int dense_step(int64_t r0, int n, bool bf16) {
     if (bf16) {
-      if (om_gemm_nt(OM_BF16, ws.qb, d, idx16 + r0 * d, d, OM_F32, ws.dense, DENSE_CHUNK, nq, n, d,
+      if (om_gemm_nt(OM_F16, ws.qb, d, idx16 + r0 * d, d, OM_F32, ws.dense, DENSE_CHUNK, nq, n, d,
                      nullptr, nullptr, 0, OM_ACT_NONE, s)) return 1;
     } else {
       if (om_gemm_nt(OM_F32, q32, d, idx32 + r0 * d, d, OM_F32, ws.dense, DENSE_CHUNK, nq, n, d,
@@ -356,7 +364,7 @@ struct Scan {
     const bool timing = om_timing_on();
     if (timing) om_timing_begin(OM_TIMING_SCAN, s);
     if (bf16)
-      hipLaunchKernelGGL((sim_filter_kernel<bf16_t>), dim3((unsigned)(ntm * ntn)), dim3(GEMM_THREADS),
+      hipLaunchKernelGGL((sim_filter_kernel<f16_t>), dim3((unsigned)(ntm * ntn)), dim3(GEMM_THREADS),
                          GEMM_LDS_BYTES, s, idx16 + r0 * d, n, (uint32_t)r0, ws.qb, nq, (int64_t)d,
                          ws.thr, ws.keys, ws.cnt, 8);
     else
@@ -369,6 +377,14 @@ struct Scan {
                        ws.cnt, nq, ws.flag);
     OM_LAUNCH_CHECK();
     return 0;
+  }
+
+  void trace(const char* what, int64_t done, int64_t chunk, const unsigned (&f)[4]) {
+    g_info[1]++;                                  // rounds
+    if (f[1] > (unsigned)g_info[3]) g_info[3] = f[1];
+    static const bool dbg = getenv("OM_SEARCH_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[om_sim_topk] %-8s done=%ld chunk=%ld overflow=%u max_list=%u too_wide=%u\n",
+                     what, (long)done, (long)chunk, f[0], f[1], f[2]);
   }
 
   // returns 0 ok, 1 error, 2 certified margin too wide (caller retries in f32)
@@ -390,6 +406,7 @@ struct Scan {
       if (dense_step(0, n, bf16)) return 1;
       done = n;
       if (read_flags(f)) return 1;
+      trace("boot", 0, n, f);
       if (f[2]) return 2;
     }
     while (done < N) {
@@ -404,6 +421,7 @@ struct Scan {
       if (!f[0]) {
         if (select(bf16)) return 1;
       } else {
+        g_info[2]++;
         // a list overflowed: rewind to the pre-chunk lists and redo the chunk densely
         hipLaunchKernelGGL(restore_cnt_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s,
                            ws.cnt, ws.cnt_prev, nq);
@@ -418,6 +436,7 @@ struct Scan {
         }
       }
       if (read_flags(f)) return 1;
+      trace("scan", done, chunk, f);
       if (f[2]) return 2;
       done += chunk;
     }
@@ -436,7 +455,7 @@ struct Scan {
 }  // namespace
 
 extern "C" int om_sim_topk(int mode, const float* queries, int64_t n_queries,
-                           const float* index_f32, const void* index_bf16, const float* stats,
+                           const float* index_f32, const void* index_f16, const float* stats,
                            int64_t N, int d, int k, int64_t id_offset, float* out_scores,
                            int64_t* out_ids, void* workspace, size_t workspace_bytes,
                            void* stream) {
@@ -451,7 +470,7 @@ extern "C" int om_sim_topk(int mode, const float* queries, int64_t n_queries,
   Scan sc;
   sc.ws = carve_search(n_queries, d, (char*)workspace);
   if (sc.ws.total > workspace_bytes) OM_FAIL("workspace too small");
-  sc.mode = mode; sc.q32 = queries; sc.idx32 = index_f32; sc.idx16 = (const bf16_t*)index_bf16;
+  sc.mode = mode; sc.q32 = queries; sc.idx32 = index_f32; sc.idx16 = (const f16_t*)index_f16;
   sc.nq = n_queries; sc.N = N; sc.d = d; sc.k = k; sc.s = s; sc.stats = stats;
 
   static bool attr_set = false;
@@ -460,19 +479,25 @@ extern "C" int om_sim_topk(int mode, const float* queries, int64_t n_queries,
                                SORT_CAP * 8 + 16));
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel<float>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel<bf16_t>,
+    OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel<f16_t>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     attr_set = true;
   }
+  for (auto& v : g_info) v = 0;
   if (N > 0) {
     if (!index_f32) OM_FAIL("index_f32 is null");
     int rc = 2;
-    if (mode == OM_SEARCH_BF16_RESCORE) {
-      if (!index_bf16 || !stats) OM_FAIL("bf16 mode needs index_bf16 and stats");
+    if (mode == OM_SEARCH_F16_RESCORE) {
+      if (!index_f16 || !stats) OM_FAIL("f16 mode needs index_f16 and stats");
       rc = sc.run(true);
       if (rc == 1) return 1;
+      g_info[0] = 1;
+      if (rc == 2) g_info[4] = 1;
     }
-    if (rc == 2 && sc.run(false)) return 1;  // f32 scan (requested, or margin too wide)
+    if (rc == 2) {                           // f32 scan (requested, or margin too wide)
+      g_info[0] = 0;
+      if (sc.run(false)) return 1;
+    }
   } else {
     hipLaunchKernelGGL(init_lists_kernel, dim3((unsigned)((n_queries + 255) / 256)), dim3(256), 0, s,
                        sc.ws.cnt, sc.ws.cnt_prev, sc.ws.thr, n_queries);

@@ -2,7 +2,7 @@
 methods the reference uses (`add`, `search`, `reset`, `ntotal`;
 src/openmatch/retriever/dense_retriever.py:38-41,105,135,180) and no faiss underneath.
 
-Rows stay on the GPU that encoded them (f32, plus a bf16 shadow copy for the MFMA candidate
+Rows stay on the GPU that encoded them (f32, plus an IEEE-f16 shadow copy for the MFMA candidate
 scan); `search` runs `om_sim_topk` on the local shard and, when the process group has more than
 one rank, all-gathers the queries, searches every shard in parallel and merges the per-shard
 top-k with `om_topk_merge` — the reference's "rank 0 loads every pickle and calls faiss" step
@@ -17,18 +17,20 @@ _GROW = 1.5
 
 
 class FlatIPIndex:
-    def __init__(self, d: int, device=None, precision: str = "bf16_rescore"):
-        """precision: 'bf16_rescore' (bf16 MFMA scan with a certified margin + exact f32 re-score;
+    def __init__(self, d: int, device=None, precision: str = "f16_rescore"):
+        """precision: 'f16_rescore' (f16 MFMA scan with a certified margin + exact f32 re-score;
         same ids as the f32 scan) or 'f32' (exact f32 MFMA scan)."""
-        if precision not in ("bf16_rescore", "f32"):
-            raise ValueError("precision must be 'bf16_rescore' or 'f32'")
+        if precision in ("bf16_rescore", "fp16_rescore"):     # accepted aliases
+            precision = "f16_rescore"
+        if precision not in ("f16_rescore", "f32"):
+            raise ValueError("precision must be 'f16_rescore' or 'f32'")
         self.d = int(d)
         self.dpad = (self.d + 63) // 64 * 64      # kernels need d % 64 == 0; zero columns are free
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.precision = precision
         self.ntotal = 0
         self._f32 = None
-        self._bf16 = None
+        self._f16 = None
         self._stats = torch.zeros(2, dtype=torch.float32, device=self.device)
 
     # -- storage ---------------------------------------------------------------------------
@@ -38,11 +40,11 @@ class FlatIPIndex:
             return
         new_cap = max(n, int(cap * _GROW), 1024)
         f32 = torch.zeros(new_cap, self.dpad, dtype=torch.float32, device=self.device)
-        b16 = torch.zeros(new_cap, self.dpad, dtype=torch.bfloat16, device=self.device)
+        b16 = torch.zeros(new_cap, self.dpad, dtype=torch.float16, device=self.device)
         if self.ntotal:
             f32[:self.ntotal].copy_(self._f32[:self.ntotal])
-            b16[:self.ntotal].copy_(self._bf16[:self.ntotal])
-        self._f32, self._bf16 = f32, b16
+            b16[:self.ntotal].copy_(self._f16[:self.ntotal])
+        self._f32, self._f16 = f32, b16
 
     def add(self, x):
         """Append rows (numpy array or tensor, any device) in insertion order."""
@@ -57,14 +59,14 @@ class FlatIPIndex:
         dst = self._f32[self.ntotal:self.ntotal + n]
         dst[:, :self.d].copy_(x.to(device=self.device, dtype=torch.float32), non_blocking=True)
         with torch.cuda.device(self.device):
-            N.check(N.lib().om_index_to_bf16(N.ptr(dst), n, self.dpad,
-                                             N.ptr(self._bf16[self.ntotal:self.ntotal + n]),
+            N.check(N.lib().om_index_to_f16(N.ptr(dst), n, self.dpad,
+                                             N.ptr(self._f16[self.ntotal:self.ntotal + n]),
                                              N.ptr(self._stats), N.stream_ptr(self.device)))
         self.ntotal += n
 
     def reset(self):
         self.ntotal = 0
-        self._f32 = self._bf16 = None
+        self._f32 = self._f16 = None
         self._stats.zero_()
 
     # -- search ----------------------------------------------------------------------------
@@ -77,7 +79,7 @@ class FlatIPIndex:
         nq = q.shape[0]
         D = torch.empty(nq, k, dtype=torch.float32, device=self.device)
         I = torch.empty(nq, k, dtype=torch.int64, device=self.device)
-        mode = N.SEARCH_BF16_RESCORE if self.precision == "bf16_rescore" else N.SEARCH_F32
+        mode = N.SEARCH_F16_RESCORE if self.precision == "f16_rescore" else N.SEARCH_F32
         lib = N.lib()
         step = 32768                       # the kernel takes <= 65535 queries per call
         with torch.cuda.device(self.device):
@@ -85,10 +87,15 @@ class FlatIPIndex:
                 n = min(step, nq - s)
                 nbytes = lib.om_sim_topk_workspace_bytes(n, self.dpad, k)
                 _buf, ws = N.Workspace.get(self.device, nbytes, "search")
-                N.check(lib.om_sim_topk(mode, N.ptr(q[s:s + n]), n, N.ptr(self._f32), N.ptr(self._bf16),
+                N.check(lib.om_sim_topk(mode, N.ptr(q[s:s + n]), n, N.ptr(self._f32), N.ptr(self._f16),
                                         N.ptr(self._stats), self.ntotal, self.dpad, k, int(id_offset),
                                         N.ptr(D[s:s + n]), N.ptr(I[s:s + n]), N.c_void_p(ws), nbytes,
                                         N.stream_ptr(self.device)))
+        info = (N.c_int64 * 8)()
+        lib.om_sim_topk_info(info)
+        self.last_search_info = {"scan": "f16+rescore" if info[0] == 1 else "f32", "rounds": int(info[1]),
+                                 "overflow_fallbacks": int(info[2]), "max_list": int(info[3]),
+                                 "margin_too_wide": bool(info[4])}
         return D, I
 
     def search(self, x, k: int):

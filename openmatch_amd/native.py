@@ -11,12 +11,12 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libopenmatch_hip.so")
 
-OM_F32, OM_BF16 = 0, 1
+OM_F32, OM_BF16, OM_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU_ERF, ACT_RELU, ACT_GELU_TANH = 0, 1, 2, 3
 ACT_MUL_RESID = 0x100
 ARCH_BERT, ARCH_T5 = 0, 1
 POOL_NONE, POOL_FIRST, POOL_MEAN = 0, 1, 2
-SEARCH_F32, SEARCH_BF16_RESCORE = 0, 1
+SEARCH_F32, SEARCH_F16_RESCORE = 0, 1
 ABI_VERSION = 1
 
 c_void_p, c_int, c_int64, c_float, c_size_t = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
@@ -56,10 +56,11 @@ _SIGNATURES = {
     "om_encoder_forward": (c_int, [C.POINTER(OmEncoderConfig), C.POINTER(OmEncoderWeights), c_void_p,
                                    c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                    c_void_p, c_size_t, c_void_p]),
-    "om_index_to_bf16": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "om_index_to_f16": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "om_sim_topk_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "om_sim_topk": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                             c_int, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "om_sim_topk_info": (None, [C.POINTER(c_int64)]),
     "om_topk_merge": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p,
                               c_void_p]),
     "om_contrastive_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,

@@ -114,7 +114,7 @@ class Retriever:
     def _initialize_faiss_index(self, dim: int):
         """Kept under the reference's name; the index is the HIP FlatIPIndex."""
         self.index = FlatIPIndex(dim, device=self.args.device,
-                                 precision=os.environ.get("OPENMATCH_AMD_SEARCH", "bf16_rescore"))
+                                 precision=os.environ.get("OPENMATCH_AMD_SEARCH", "f16_rescore"))
 
     def _move_index_to_gpu(self):
         """No-op: the index is born on the GPU (the reference clones a CPU index into faiss-GPU)."""

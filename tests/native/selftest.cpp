@@ -185,7 +185,7 @@ static void test_search(int mode, int64_t N, int Q, int d, int k, int order /*0 
   }
   float* dP = upload(P); float* dQ = upload(Qv);
   bf16* dPb = dalloc<bf16>((size_t)N * d); float* dstats = dalloc<float>(2); CK(hipMemset(dstats, 0, 8));
-  OMCK(om_index_to_bf16(dP, N, d, dPb, dstats, nullptr));
+  OMCK(om_index_to_f16(dP, N, d, dPb, dstats, nullptr));
   size_t wsb = om_sim_topk_workspace_bytes(Q, d, k); char* ws = dalloc<char>(wsb);
   float* dD = dalloc<float>((size_t)Q * k); int64_t* dI = dalloc<int64_t>((size_t)Q * k);
   auto t0 = std::chrono::steady_clock::now();
@@ -215,9 +215,10 @@ static void test_search(int mode, int64_t N, int Q, int d, int k, int order /*0 
     }
     if (!set_ok) { bad_sets++; if (tie_only) near_tie_only++; }
   }
-  char name[200], extra[160];
+  char name[200], extra[260];
   snprintf(name, sizeof name, "sim_topk mode=%d N=%ld Q=%d d=%d k=%d order=%d clustered=%d", mode, (long)N, Q, d, k, order, clustered);
-  snprintf(extra, sizeof extra, "id-set mismatches=%d (near-tie only=%d) unsorted=%d  %.1f ms", bad_sets, near_tie_only, bad_order, ms);
+  int64_t info[8]; om_sim_topk_info(info);
+  snprintf(extra, sizeof extra, "id-set mismatches=%d (near-tie only=%d) unsorted=%d %.1f ms [used=%ld rounds=%ld ovf=%ld list=%ld wide=%ld]", bad_sets, near_tie_only, bad_order, ms, (long)info[0], (long)info[1], (long)info[2], (long)info[3], (long)info[4]);
   const bool ok = (bad_sets - near_tie_only) == 0 && bad_order == 0;
   report(name, ok ? maxdiff : 1e9, 1e-5, extra);
   hipFree(dP); hipFree(dQ); hipFree(dPb); hipFree(dstats); hipFree(ws); hipFree(dD); hipFree(dI);
@@ -288,7 +289,7 @@ static void bench_search(int mode, int64_t N, int Q, int d, int k) {
   // overkill for a timing run; ties only stress the tie-break path.
   float* dQ = upload(randn((size_t)Q * d, 0.3f));
   bf16* dPb = dalloc<bf16>((size_t)N * d); float* dstats = dalloc<float>(2); CK(hipMemset(dstats, 0, 8));
-  OMCK(om_index_to_bf16(dP, N, d, dPb, dstats, nullptr));
+  OMCK(om_index_to_f16(dP, N, d, dPb, dstats, nullptr));
   size_t wsb = om_sim_topk_workspace_bytes(Q, d, k); char* ws = dalloc<char>(wsb);
   float* dD = dalloc<float>((size_t)Q * k); int64_t* dI = dalloc<int64_t>((size_t)Q * k);
   for (int rep = 0; rep < 2; ++rep) {
@@ -297,7 +298,8 @@ static void bench_search(int mode, int64_t N, int Q, int d, int k) {
     OMCK(om_sim_topk(mode, dQ, Q, dP, dPb, dstats, N, d, k, 0, dD, dI, ws, wsb, nullptr));
     CK(hipDeviceSynchronize());
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    printf("[BENCH] sim_topk mode=%d N=%ld Q=%d d=%d k=%d : %.2f ms  %.1f q/s  %.1f TFLOP/s-equivalent\n", mode, (long)N, Q, d, k, ms, Q / ms * 1e3, 2.0 * N * Q * d / ms / 1e9);
+    int64_t info[8]; om_sim_topk_info(info);
+    printf("[BENCH] sim_topk mode=%d N=%ld Q=%d d=%d k=%d : %.2f ms  %.1f q/s  %.1f TFLOP/s-equivalent [used=%ld rounds=%ld ovf=%ld list=%ld wide=%ld]\n", mode, (long)N, Q, d, k, ms, Q / ms * 1e3, 2.0 * N * Q * d / ms / 1e9, (long)info[0], (long)info[1], (long)info[2], (long)info[3], (long)info[4]);
   }
   hipFree(dP); hipFree(dQ); hipFree(dPb); hipFree(dstats); hipFree(ws); hipFree(dD); hipFree(dI);
 }
@@ -335,13 +337,13 @@ int main(int argc, char** argv) {
     test_search(OM_SEARCH_F32, 500, 5, 64, 1000, 0, false);      // N < k: padding
     test_search(OM_SEARCH_F32, 50000, 33, 128, 100, 0, false);
     test_search(OM_SEARCH_F32, 50000, 33, 128, 1000, 0, true);
-    test_search(OM_SEARCH_BF16_RESCORE, 50000, 33, 128, 100, 0, false);
-    test_search(OM_SEARCH_BF16_RESCORE, 50000, 33, 128, 1000, 0, true);
+    test_search(OM_SEARCH_F16_RESCORE, 50000, 33, 128, 100, 0, false);
+    test_search(OM_SEARCH_F16_RESCORE, 50000, 33, 128, 1000, 0, true);
     test_search(OM_SEARCH_F32, 60000, 4, 64, 1000, 1, false);    // adversarial order -> overflow fallback
-    test_search(OM_SEARCH_BF16_RESCORE, 60000, 4, 64, 1000, 1, false);
+    test_search(OM_SEARCH_F16_RESCORE, 60000, 4, 64, 1000, 1, false);
     if (what == "full") {
       test_search(OM_SEARCH_F32, 300000, 130, 768, 1000, 0, true);
-      test_search(OM_SEARCH_BF16_RESCORE, 300000, 130, 768, 1000, 0, true);
+      test_search(OM_SEARCH_F16_RESCORE, 300000, 130, 768, 1000, 0, true);
     }
     test_merge();
     test_contrastive();
@@ -354,7 +356,7 @@ int main(int argc, char** argv) {
     bench_gemm(OM_BF16, 8192, 8192, 8192, 0);
     bench_gemm(OM_F32, 32768, 768, 768, 0);
     bench_gemm(OM_F32, 8192, 3072, 768, OM_ACT_GELU_ERF);
-    bench_search(OM_SEARCH_BF16_RESCORE, 2000000, 1024, 768, 1000);
+    bench_search(OM_SEARCH_F16_RESCORE, 2000000, 1024, 768, 1000);
     bench_search(OM_SEARCH_F32, 2000000, 1024, 768, 1000);
   }
   printf("%s: %d failure(s)\n", g_fail ? "SELFTEST FAILED" : "SELFTEST PASSED", g_fail);

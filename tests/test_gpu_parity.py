@@ -37,7 +37,7 @@ def test_encoder_f32_matches_reference_fixture(golden, name, arch, gated):
     model = build_drmodel(g, arch, gated)
     for kind in ("p", "q"):
         items = items_from_golden(g, kind, DEV)
-        hidden, reps = model.encode(items, model.lm_p, model.head_p)
+        hidden, reps = model.encode_passage(items)
         assert reps.dtype == torch.float32 and reps.is_cuda
         assert np.abs(reps.cpu().numpy() - g[kind + "_reps"]).max() < 1e-4
         if kind == "p":
@@ -55,7 +55,7 @@ def test_encoder_bf16_close_to_reference_fixture(golden, name, arch, gated):
     g = golden(name)
     model = build_drmodel(g, arch, gated, dtype="bfloat16")
     for kind in ("p", "q"):
-        _, reps = model.encode(items_from_golden(g, kind, DEV), model.lm_p, model.head_p)
+        _, reps = model.encode_passage(items_from_golden(g, kind, DEV))
         a, b = reps.cpu().double(), torch.from_numpy(g[kind + "_reps"]).double()
         cos = torch.nn.functional.cosine_similarity(a, b, dim=1)
         assert cos.min() > 0.999, cos
@@ -65,7 +65,7 @@ def test_autocast_selects_bf16_path(golden):
     g = golden("bert_tiny_first")
     model = build_drmodel(g, "bert", False)
     with torch.autocast("cuda", dtype=torch.bfloat16):
-        hidden, _ = model.encode(items_from_golden(g, "q", DEV), model.lm_q, model.head_q)
+        hidden, _ = model.encode_query(items_from_golden(g, "q", DEV))
     assert hidden.dtype == torch.bfloat16
 
 
@@ -92,14 +92,15 @@ def test_encoder_matches_oracle_on_ragged_batches():
     cfg = tiny_bert_config()
     cfg = type(cfg)(**{**cfg.to_dict(), "max_position_embeddings": 256})
     lm = BertModel(cfg).eval()
+    sd = {k: v.clone() for k, v in lm.state_dict().items()}      # CPU copy for the oracle
     model = DRModelForInference(lm_q=lm, lm_p=lm, pooling="mean", normalize=True,
                                 model_args=NS(encoder_only=False, dtype="float32")).to(DEV)
     rng = np.random.default_rng(5)
     for B, L in ((1, 7), (3, 50), (2, 162), (5, 33), (2, 256)):
         ids, mask = synth_tokens(rng, B, L, vocab=600, lo_len=min(4, L))
         items = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
-        _, ref = encoder_ref.encode(lm.state_dict(), cfg, "bert", items, "mean", None, True)
-        _, got = model.encode({k: v.to(DEV) for k, v in items.items()}, model.lm_p, None)
+        _, ref = encoder_ref.encode(sd, cfg, "bert", items, "mean", None, True)
+        _, got = model.encode_passage({k: v.to(DEV) for k, v in items.items()})
         assert np.abs(got.cpu().numpy() - ref.numpy()).max() < 1e-4, (B, L)
 
 
@@ -114,7 +115,7 @@ def _adjudicate(I_gpu, I_ref, P, Q, k):
     return flatip.topk_sets_equal(I_gpu, I_ref, full, rel_tol=2e-6)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16_rescore"])
+@pytest.mark.parametrize("precision", ["f32", "f16_rescore"])
 @pytest.mark.parametrize("n,nq,k,clustered", [(1000, 100, 100, True), (50000, 64, 1000, True),
                                                (50000, 17, 10, False), (300, 5, 1000, False)])
 def test_flat_ip_search_matches_oracle(precision, n, nq, k, clustered):
@@ -129,6 +130,8 @@ def test_flat_ip_search_matches_oracle(precision, n, nq, k, clustered):
     idx = FlatIPIndex(d, device=DEV, precision=precision)
     idx.add(P[: n // 2]); idx.add(P[n // 2:])
     D, I = idx.search(Q, k)
+    if precision == "f16_rescore" and n >= k:
+        assert idx.last_search_info["scan"] == "f16+rescore", idx.last_search_info   # no silent f32 retry
     ref = flatip.IndexFlatIP(d); ref.add(P)
     Dr, Ir = ref.search(Q, k)
     kk = min(n, k)
@@ -152,7 +155,7 @@ def test_search_properties_at_scale():
     P = torch.nn.functional.normalize(P + 0.5 * torch.randn(1, d, device=DEV, generator=g), dim=1)
     probe = torch.arange(0, n, n // 256, device=DEV)[:256]
     out = {}
-    for precision in ("f32", "bf16_rescore"):
+    for precision in ("f32", "f16_rescore"):
         idx = FlatIPIndex(d, device=DEV, precision=precision)
         idx.add(P)
         D, I = idx.search_device(P[probe], k)
@@ -160,9 +163,11 @@ def test_search_properties_at_scale():
         assert (D[:, 1:] <= D[:, :-1]).all()
         assert (I >= 0).all() and (I < n).all()
         assert all(len(set(row.tolist())) == k for row in I[:8].cpu())
+        if precision == "f16_rescore":
+            assert idx.last_search_info["scan"] == "f16+rescore", idx.last_search_info
         out[precision] = (D.cpu(), I.cpu())
-    same = [(set(a.tolist()) == set(b.tolist())) for a, b in zip(out["f32"][1], out["bf16_rescore"][1])]
-    print("bf16_rescore id sets identical to f32 scan for", sum(same), "of", len(same), "queries")
+    same = [(set(a.tolist()) == set(b.tolist())) for a, b in zip(out["f32"][1], out["f16_rescore"][1])]
+    print("f16_rescore id sets identical to f32 scan for", sum(same), "of", len(same), "queries")
     assert sum(same) >= len(same) - 2     # boundary near-ties between two f32 summation orders
 
 
