@@ -22,7 +22,7 @@
 
 #include <algorithm>
 
-#include "gemm_core.h"
+#include "gemm_core2.h"
 #include "kernels.h"
 
 #define SORT_CAP 8192      // keys one workgroup sorts in LDS (64 KiB)
@@ -42,17 +42,15 @@ __host__ __device__ inline uint32_t key_payload(u64 k) { return ~(uint32_t)k; }
 
 // ---- filtered scan: A = index rows [row0, row0+nrows), B = queries ----------------------
 template <typename T>
-__global__ __launch_bounds__(GEMM_THREADS) void sim_filter_kernel(
+__global__ __launch_bounds__(G2_THREADS) void sim_filter_kernel(
     const T* __restrict__ rows, int64_t nrows, uint32_t row_base, const T* __restrict__ queries,
     int64_t nq, int64_t d, const float* __restrict__ thr, u64* __restrict__ keys,
     unsigned* __restrict__ cnt, int group_m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int64_t ntm = (nrows + GEMM_BM - 1) / GEMM_BM, ntn = (nq + GEMM_BN - 1) / GEMM_BN;
-  int64_t tm, tn;
-  gemm_tile_coords(ntm, ntn, group_m, tm, tn);
-  const int64_t m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+  int64_t m0, n0;
+  g2_tile_coords(nrows, nq, group_m, m0, n0);       // 256 index rows x 128 queries per workgroup
   f32x16_t acc[2][2];
-  gemm_mainloop<T>(rows, d, queries, d, nrows, nq, d, m0, n0, smem, acc);
+  gemm_mainloop2<T>(rows, d, queries, d, nrows, nq, d, m0, n0, smem, acc);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -359,17 +357,17 @@ struct Scan {
     return select(bf16);
   }
   int filter_step(int64_t r0, int64_t n, bool bf16) {
-    const int64_t ntm = (n + GEMM_BM - 1) / GEMM_BM, ntn = (nq + GEMM_BN - 1) / GEMM_BN;
+    const int64_t ntm = (n + G2_BM - 1) / G2_BM, ntn = (nq + G2_BN - 1) / G2_BN;
     if (ntm * ntn > 0x7fffffffLL) OM_FAIL("scan grid too large");
     const bool timing = om_timing_on();
     if (timing) om_timing_begin(OM_TIMING_SCAN, s);
     if (bf16)
-      hipLaunchKernelGGL((sim_filter_kernel<f16_t>), dim3((unsigned)(ntm * ntn)), dim3(GEMM_THREADS),
-                         GEMM_LDS_BYTES, s, idx16 + r0 * d, n, (uint32_t)r0, ws.qb, nq, (int64_t)d,
+      hipLaunchKernelGGL((sim_filter_kernel<f16_t>), dim3((unsigned)(ntm * ntn)), dim3(G2_THREADS),
+                         G2_LDS_BYTES, s, idx16 + r0 * d, n, (uint32_t)r0, ws.qb, nq, (int64_t)d,
                          ws.thr, ws.keys, ws.cnt, 8);
     else
-      hipLaunchKernelGGL((sim_filter_kernel<float>), dim3((unsigned)(ntm * ntn)), dim3(GEMM_THREADS),
-                         GEMM_LDS_BYTES, s, idx32 + r0 * d, n, (uint32_t)r0, q32, nq, (int64_t)d,
+      hipLaunchKernelGGL((sim_filter_kernel<float>), dim3((unsigned)(ntm * ntn)), dim3(G2_THREADS),
+                         G2_LDS_BYTES, s, idx32 + r0 * d, n, (uint32_t)r0, q32, nq, (int64_t)d,
                          ws.thr, ws.keys, ws.cnt, 8);
     if (timing) om_timing_end(OM_TIMING_SCAN, s, 2.0 * (double)n * (double)nq * (double)d);
     OM_LAUNCH_CHECK();
@@ -478,9 +476,9 @@ extern "C" int om_sim_topk(int mode, const float* queries, int64_t n_queries,
     OM_HIP(hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                SORT_CAP * 8 + 16));
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel<float>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel<f16_t>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
     attr_set = true;
   }
   for (auto& v : g_info) v = 0;

@@ -40,13 +40,13 @@ def items_from_golden(g, kind, device="cpu"):
     return items
 
 
-def synth_tokens(rng, n, L, vocab=30522, lo_len=16):
+def synth_tokens(rng, n, L, vocab=30522, lo_len=16, lo_id=1000):
     """MS-MARCO-shaped BERT inputs: [CLS] body [SEP] pad, real length ~ U{lo_len..L}."""
     ids = np.zeros((n, L), np.int64)
     mask = np.zeros((n, L), np.int64)
     for i in range(n):
         ln = int(rng.integers(lo_len, L + 1))
-        body = rng.integers(1000, vocab, size=ln)
+        body = rng.integers(lo_id, vocab, size=ln)
         body[0], body[-1] = 101, 102
         ids[i, :ln] = body
         mask[i, :ln] = 1

@@ -324,6 +324,11 @@ int main(int argc, char** argv) {
     test_gemm(OM_F32, 77, 300, 64, false, true, OM_ACT_GELU_TANH | OM_ACT_MUL_RESID, OM_F32);
     test_gemm(OM_BF16, 4099, 768, 768, true, false, OM_ACT_GELU_ERF, OM_BF16);
     test_gemm(OM_F32, 1030, 768, 768, true, true, OM_ACT_NONE, OM_F32);
+    test_gemm(OM_BF16, 1000, 200, 128, true, true, OM_ACT_RELU, OM_BF16);        // v2 tile, ragged M and N tile
+    test_gemm(OM_BF16, 513, 2304, 768, true, false, OM_ACT_NONE, OM_BF16);
+    test_gemm(OM_BF16, 2048, 768, 3072, true, true, OM_ACT_NONE, OM_BF16);       // 48 K steps through the ring
+    test_gemm(OM_F32, 777, 132, 64, false, true, OM_ACT_GELU_TANH | OM_ACT_MUL_RESID, OM_F32);
+    test_gemm(OM_BF16, 600, 128, 64, false, false, OM_ACT_NONE, OM_F32);         // single K step
     // encoder end to end (embedding, attention incl. ragged L, LN, FFN, pooling, head, normalise)
     test_encoder(OM_F32, 5, 128, OM_POOL_FIRST, false, false);
     test_encoder(OM_F32, 3, 32, OM_POOL_MEAN, true, true);

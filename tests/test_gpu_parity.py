@@ -97,7 +97,7 @@ def test_encoder_matches_oracle_on_ragged_batches():
                                 model_args=NS(encoder_only=False, dtype="float32")).to(DEV)
     rng = np.random.default_rng(5)
     for B, L in ((1, 7), (3, 50), (2, 162), (5, 33), (2, 256)):
-        ids, mask = synth_tokens(rng, B, L, vocab=600, lo_len=min(4, L))
+        ids, mask = synth_tokens(rng, B, L, vocab=600, lo_len=min(4, L), lo_id=300)
         items = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
         _, ref = encoder_ref.encode(sd, cfg, "bert", items, "mean", None, True)
         _, got = model.encode_passage({k: v.to(DEV) for k, v in items.items()})
