@@ -8,75 +8,13 @@
 // the 32x32 accumulator map (col = lane&31, rows in registers) every lane then owns ONE query
 // row and 16 keys per key tile, so the softmax is lane-local plus one exchange with lane^32,
 // and the probabilities already sit in the A-operand layout of the P·V MFMA.
-#include "gemm_core.h"
-#include "kernels.h"
-
-template <typename T> struct AttnGeom;
-template <> struct AttnGeom<bf16_t> {
-  static constexpr int ROWB = 128, CPR = 8, EPC = 8, NKK = 4;
-  __device__ static inline int key(int row) { return (row >> 1) & 7; }
-  __device__ static inline float exp_(float x) { return __expf(x); }
-};
-template <> struct AttnGeom<float> {
-  static constexpr int ROWB = 256, CPR = 16, EPC = 4, NKK = 8;
-  __device__ static inline int key(int row) { return row & 15; }
-  __device__ static inline float exp_(float x) { return expf(x); }
-};
-
-template <typename T, int KT> struct PV;
-
-// bf16: P packed to bf16x8 A-fragments; k-slot j of half h  <->  key 16u + 8(j>>2) + (j&3) + 4h
-template <int KT> struct PV<bf16_t, KT> {
-  __device__ static inline void run(const f32x16_t (&s)[KT], const bf16_t* sVt, int LP, int l31,
-                                    int half, f32x16_t (&o)[2]) {
-    bf16x8_t pp[KT][2];
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pp[t][u][j] = (short)f32_to_bf16(s[t][8 * u + j]);
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      const bf16_t* vrow = sVt + (dt * 32 + l31) * LP + 4 * half;
-#pragma unroll
-      for (int t = 0; t < KT; ++t)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const bf16x4_t v0 = *(const bf16x4_t*)(vrow + t * 32 + 16 * u);
-          const bf16x4_t v1 = *(const bf16x4_t*)(vrow + t * 32 + 16 * u + 8);
-          bf16x8_t vb;
-          vb[0] = v0[0]; vb[1] = v0[1]; vb[2] = v0[2]; vb[3] = v0[3];
-          vb[4] = v1[0]; vb[5] = v1[1]; vb[6] = v1[2]; vb[7] = v1[3];
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pp[t][u], vb, o[dt], 0, 0, 0);
-        }
-    }
-  }
-};
-// f32: one probability register per MFMA (k = 2): register r of half h  <->  key (r&3)+8(r>>2)+4h
-template <int KT> struct PV<float, KT> {
-  __device__ static inline void run(const f32x16_t (&s)[KT], const float* sVt, int LP, int l31,
-                                    int half, f32x16_t (&o)[2]) {
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      const float* vrow = sVt + (dt * 32 + l31) * LP + 4 * half;
-#pragma unroll
-      for (int t = 0; t < KT; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4_t vb = *(const f32x4_t*)(vrow + t * 32 + 8 * g);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[t][4 * g + e], vb[e], o[dt], 0, 0, 0);
-        }
-    }
-  }
-};
+#include "attn_common.h"
 
 template <typename T, int KT>
 __global__ __launch_bounds__(64 * KT) void attention_kernel(
     const T* __restrict__ qkv, T* __restrict__ ctx, const int64_t* __restrict__ mask,
-    const float* __restrict__ pos_bias, int L, int H, int heads, float scale) {
+    const float* __restrict__ pos_bias, int L, int H, int heads, float scale, float drop_p,
+    uint64_t seed) {
   typedef AttnGeom<T> G;
   typedef typename MmaOps<T>::frag_t frag_t;
   constexpr int LP = KT * 32 + 4;
@@ -169,13 +107,25 @@ __global__ __launch_bounds__(64 * KT) void attention_kernel(
   for (int t = 0; t < KT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[t][r] *= inv;
+  if (drop_p > 0.f) {      // training: attention_probs dropout, mask regenerated in the backward
+    const uint32_t thresh = (uint32_t)(drop_p * 4294967296.0);
+    const float keep_scale = 1.0f / (1.0f - drop_p);
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        s[t][r] = dropout_keep(seed, attn_drop_idx(b, h, heads, L, q0 + l31, key), thresh) ? s[t][r] * keep_scale : 0.f;
+      }
+  }
 
   f32x16_t o[2];
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-  PV<T, KT>::run(s, sVt, LP, l31, half, o);
+#pragma unroll
+  for (int t = 0; t < KT; ++t) SlabMma<T>::run(s[t], sVt + l31 * LP + t * 32 + 4 * half, LP, o);
 
   T* out = ctx + b * L * H + h * 64;
 #pragma unroll
@@ -189,7 +139,8 @@ __global__ __launch_bounds__(64 * KT) void attention_kernel(
 
 template <typename T, int KT>
 static int launch_attn(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias,
-                       int64_t B, int L, int H, int heads, float scale, hipStream_t s) {
+                       int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
+                       hipStream_t s) {
   constexpr int LP = KT * 32 + 4;
   const int lds = KT * 32 * AttnGeom<T>::ROWB + 64 * LP * (int)sizeof(T) + KT * 32 * 4;
   static bool attr_set = false;
@@ -201,28 +152,29 @@ static int launch_attn(const void* qkv, void* ctx, const int64_t* mask, const fl
   const int waves = (L + 31) / 32;
   hipLaunchKernelGGL((attention_kernel<T, KT>), dim3((unsigned)(heads * B)),
                      dim3(64 * waves), lds, s, (const T*)qkv, (T*)ctx, mask, pos_bias, L, H, heads,
-                     scale);
+                     scale, drop_p, seed);
   OM_LAUNCH_CHECK();
   return 0;
 }
 
 template <typename T>
 static int dispatch_attn(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias,
-                         int64_t B, int L, int H, int heads, float scale, hipStream_t s) {
-  if (L <= 32) return launch_attn<T, 1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
-  if (L <= 64) return launch_attn<T, 2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
-  if (L <= 128) return launch_attn<T, 4>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
-  if (L <= 192) return launch_attn<T, 6>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
-  return launch_attn<T, 8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
+                         int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
+                         hipStream_t s) {
+  if (L <= 32) return launch_attn<T, 1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
+  if (L <= 64) return launch_attn<T, 2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
+  if (L <= 128) return launch_attn<T, 4>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
+  if (L <= 192) return launch_attn<T, 6>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
+  return launch_attn<T, 8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
 }
 
 int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
                   const float* pos_bias, int64_t B, int L, int H, int heads, float scale,
-                  hipStream_t s) {
+                  float drop_p, uint64_t seed, hipStream_t s) {
   if (B <= 0) return 0;
   if (L < 1 || L > 256) OM_FAIL("sequence length must be in [1,256]");
   if (H != heads * 64) OM_FAIL("head_dim must be 64");
   if (B * heads > 0x7fffffffLL) OM_FAIL("batch too large for one launch");
-  if (dtype == OM_BF16) return dispatch_attn<bf16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
-  return dispatch_attn<float>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
+  if (dtype == OM_BF16) return dispatch_attn<bf16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
+  return dispatch_attn<float>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
 }

@@ -108,7 +108,7 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
     for (int l = 0; l < c->n_layers; ++l) {
       const OmLayerWeights& lw = Ls[l];
       GEMM(ws.x, H, lw.qkv_w, H, ws.qkv, 3 * H, 3 * H, H, lw.qkv_b, nullptr, 0, OM_ACT_NONE);
-      RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, nullptr, B, (int)L, H, nh, scale, s));
+      RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, nullptr, B, (int)L, H, nh, scale, 0.f, 0, s));
       GEMM(ws.ctx, H, lw.o_w, H, ws.y, H, H, H, lw.o_b, ws.x, H, OM_ACT_NONE);
       RUN(omk_layernorm(dt, ws.y, H, ws.x1, H, lw.ln1_g, lw.ln1_b, M, H, c->ln_eps, 0, s));
       GEMM(ws.x1, H, lw.ffn1_w, H, ws.ff, F, F, H, lw.ffn1_b, nullptr, 0, c->act);
@@ -133,7 +133,7 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
       const OmLayerWeights& lw = Ls[l];
       RUN(omk_layernorm(dt, ws.x, H, ws.y, H, lw.ln1_g, nullptr, M, H, c->ln_eps, 1, s));
       GEMM(ws.y, H, lw.qkv_w, H, ws.qkv, 3 * H, 3 * H, H, nullptr, nullptr, 0, OM_ACT_NONE);
-      RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, ws.posbias, B, (int)L, H, nh, 1.0f, s));
+      RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, ws.posbias, B, (int)L, H, nh, 1.0f, 0.f, 0, s));
       GEMM(ws.ctx, H, lw.o_w, H, ws.x, H, H, H, nullptr, ws.x, H, OM_ACT_NONE);  // x += o(ctx)
       RUN(omk_layernorm(dt, ws.x, H, ws.y, H, lw.ln2_g, nullptr, M, H, c->ln_eps, 1, s));
       if (lw.ffn1g_w) {

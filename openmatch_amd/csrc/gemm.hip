@@ -113,9 +113,10 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_nt_kernel2(
   f32x16_t acc[2][2];
   gemm_mainloop2<T>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc);
 
-  constexpr int ES = (int)sizeof(OutT);
+  // The patch is staged in f32 whatever the output type, so bias/activation/dropout/residual are
+  // all applied in f32 and the result is rounded ONCE (staging in bf16 would double-round).
   constexpr int VEC = OutVec<OutT>::VEC;
-  constexpr int STRIDE = 64 * ES + 16;          // +16 B: rows of a lane group land on different banks
+  constexpr int STRIDE = 64 * 4 + 16;           // +16 B: rows of a lane group land on different banks
   const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
   const int wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_nt_kernel2(
           if (drop_thresh)
             v = dropout_keep(ep.seed, (uint64_t)m * (uint64_t)N + (uint64_t)n, drop_thresh) ? v * drop_scale : 0.f;
         }
-        ElemOps<OutT>::store((OutT*)(region + row * STRIDE) + ni * 32 + l31, v);
+        ((float*)(region + row * STRIDE))[ni * 32 + l31] = v;
       }
   }
   __syncthreads();
@@ -158,19 +159,22 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_nt_kernel2(
     const int64_t m = m0 + wm * 64 + row;
     const int64_t n = n0 + wn * 64 + c * VEC;
     if (m < M && n < N) {
-      uint4 x = *(const uint4*)(region + row * STRIDE + c * 16);
+      float xv[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; e += 4) {
+        const f32x4_t t4 = *(const f32x4_t*)(region + row * STRIDE + (c * VEC + e) * 4);
+        xv[e] = t4[0]; xv[e + 1] = t4[1]; xv[e + 2] = t4[2]; xv[e + 3] = t4[3];
+      }
       if (resid) {
-        float xv[VEC], rv[VEC];
-        OutVec<OutT>::unpack(x, xv);
+        float rv[VEC];
         OutVec<OutT>::unpack(*(const uint4*)(resid + m * ep.ldr + n), rv);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           if (act == OM_ACT_GELU_ERF_GRAD) xv[e] *= gelu_erf_grad(rv[e]);
           else xv[e] = mul_resid ? xv[e] * rv[e] : xv[e] + rv[e];
         }
-        x = OutVec<OutT>::pack(xv);
       }
-      *(uint4*)(C + m * ldc + n) = x;
+      *(uint4*)(C + m * ldc + n) = OutVec<OutT>::pack(xv);
     }
   }
 }

@@ -35,18 +35,21 @@ template <typename T> struct MmaOps;
 
 template <> struct MmaOps<bf16_t> {
   typedef bf16x8_t frag_t;
+  static constexpr int kMfmaPerMma = 1;
   __device__ static inline void mma(const frag_t& a, const frag_t& b, f32x16_t& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
 };
 template <> struct MmaOps<f16_t> {
   typedef f16x8_t frag_t;
+  static constexpr int kMfmaPerMma = 1;
   __device__ static inline void mma(const frag_t& a, const frag_t& b, f32x16_t& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
 };
 template <> struct MmaOps<float> {
   typedef f32x4_t frag_t;
+  static constexpr int kMfmaPerMma = 4;
   __device__ static inline void mma(const frag_t& a, const frag_t& b, f32x16_t& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], c, 0, 0, 0);

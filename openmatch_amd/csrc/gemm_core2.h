@@ -88,17 +88,35 @@ __device__ inline void gemm_mainloop2(const T* __restrict__ A, int64_t lda, cons
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS reads of tile t-1 are done
     __builtin_amdgcn_s_barrier();                         // -> true for every wave
     if (t + 2 < nk) g2_stage(pa, pb, (size_t)(t + 2) * GEMM_ROW_BYTES, s_far, wave);
+    // register double-buffering of the fragments: the LDS reads of sub-step kk+1 are in flight
+    // while the MFMAs of sub-step kk issue (LDS latency under load is several hundred cycles)
+    frag_t a0[2], a1[2], b0[2], b1[2];
+    {
+      const int slot = ((0 | half) ^ key) << 4;
+      a0[0] = *(const frag_t*)(s_cur + rowa + slot);
+      a1[0] = *(const frag_t*)(s_cur + rowa + 32 * GEMM_ROW_BYTES + slot);
+      b0[0] = *(const frag_t*)(s_cur + rowb + slot);
+      b1[0] = *(const frag_t*)(s_cur + rowb + 32 * GEMM_ROW_BYTES + slot);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);        // pin: 4 LDS reads (sub-step 0) first
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const int slot = (((kk << 1) | half) ^ key) << 4;
-      frag_t a0 = *(const frag_t*)(s_cur + rowa + slot);
-      frag_t a1 = *(const frag_t*)(s_cur + rowa + 32 * GEMM_ROW_BYTES + slot);
-      frag_t b0 = *(const frag_t*)(s_cur + rowb + slot);
-      frag_t b1 = *(const frag_t*)(s_cur + rowb + 32 * GEMM_ROW_BYTES + slot);
-      MmaOps<T>::mma(a0, b0, acc[0][0]);
-      MmaOps<T>::mma(a0, b1, acc[0][1]);
-      MmaOps<T>::mma(a1, b0, acc[1][0]);
-      MmaOps<T>::mma(a1, b1, acc[1][1]);
+      const int cb = kk & 1, nb = cb ^ 1;
+      if (kk < 3) {
+        const int slot = ((((kk + 1) << 1) | half) ^ key) << 4;
+        a0[nb] = *(const frag_t*)(s_cur + rowa + slot);
+        a1[nb] = *(const frag_t*)(s_cur + rowa + 32 * GEMM_ROW_BYTES + slot);
+        b0[nb] = *(const frag_t*)(s_cur + rowb + slot);
+        b1[nb] = *(const frag_t*)(s_cur + rowb + 32 * GEMM_ROW_BYTES + slot);
+      }
+      MmaOps<T>::mma(a0[cb], b0[cb], acc[0][0]);
+      MmaOps<T>::mma(a0[cb], b1[cb], acc[0][1]);
+      MmaOps<T>::mma(a1[cb], b0[cb], acc[1][0]);
+      MmaOps<T>::mma(a1[cb], b1[cb], acc[1][1]);
+      // pin the issue order: the next sub-step's 4 LDS reads go out BEFORE this sub-step's MFMAs
+      // (hipcc otherwise re-serialises read -> wait -> MFMA to save registers)
+      if (kk < 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MmaOps<T>::kMfmaPerMma * 4, 0);
     }
     char* tmp = s_cur; s_cur = s_nxt; s_nxt = s_far; s_far = tmp;
   }

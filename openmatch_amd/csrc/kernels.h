@@ -17,7 +17,7 @@ int omk_t5_bias(const float* table, const int* lut, float* out, int L, int heads
 // projection output [B*L, 3H] (q | k | v), ctx is [B*L, H].  L <= 256, head_dim == 64.
 int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
                   const float* pos_bias, int64_t B, int L, int H, int heads, float scale,
-                  hipStream_t s);
+                  float drop_p, uint64_t seed, hipStream_t s);
 
 // ---- extended GEMM epilogue (training) ---------------------------------------------------
 // order: v = acc + bias ; [pre_act <- v] ; v = act(v) ; v = dropout(v) ; v = v (+|*) resid

@@ -1,0 +1,580 @@
+// Backward-pass kernels of the BERT encoder (training path, K1..K9 reversed):
+// operand transposes for the weight-gradient GEMMs, bias column sums, dropout masks,
+// LayerNorm / embedding / pooling / normalise backward, and the fused attention backward.
+// The dense contractions themselves (dgrad, wgrad) run on the MFMA GEMM of gemm.hip.
+#include "attn_common.h"
+#include "train_kernels.h"
+
+// ---------------------------------------------------------------------------------------
+// out[c][r] = op(in[r][c]),  r < R (rows R..Rp-1 of the output pitch are zero-filled so the
+// result can be the K-padded operand of an NT GEMM).  OP 1 = erf-GELU (recompute of the FFN
+// activation instead of saving it).
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, int64_t ldi,
+                                                        int64_t R, int C, T* __restrict__ out,
+                                                        int64_t ldo, int64_t Rp) {
+  __shared__ float tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int64_t r = r0 + ty + 4 * i;
+    const int c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < C) {
+      v = ElemOps<T>::load(in + r * ldi + c);
+      if (OP == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    }
+    tile[ty + 4 * i][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i;
+    const int64_t r = r0 + tx;
+    if (c < C && r < Rp) ElemOps<T>::store(out + (int64_t)c * ldo + r, tile[tx][ty + 4 * i]);
+  }
+}
+
+int omk_transpose(int dtype, const void* in, int64_t ldi, int64_t R, int C, void* out, int64_t ldo,
+                  int64_t Rp, int op, hipStream_t s) {
+  if (R <= 0 || C <= 0) return 0;
+  dim3 grid((unsigned)((Rp + 63) / 64), (unsigned)((C + 63) / 64));
+#define TR(TT, OPV) hipLaunchKernelGGL((transpose_kernel<TT, OPV>), grid, dim3(256), 0, s, (const TT*)in, ldi, R, C, (TT*)out, ldo, Rp)
+  if (dtype == OM_BF16) { if (op) TR(bf16_t, 1); else TR(bf16_t, 0); }
+  else { if (op) TR(float, 1); else TR(float, 0); }
+#undef TR
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[c] += sum_r x[r][c]      (out is f32 and zero-initialised by the caller)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t ld, int64_t M,
+                                                     int N, float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int64_t rows_per = (M + gridDim.y - 1) / gridDim.y;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per;
+  const int64_t r1 = (r0 + rows_per) < M ? (r0 + rows_per) : M;
+  float acc = 0.f;
+  if (c < N)
+    for (int64_t r = r0 + w; r < r1; r += 4) acc += ElemOps<T>::load(x + r * ld + c);
+  part[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && c < N) atomicAdd(out + c, (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+}
+
+int omk_colsum(int dtype, const void* x, int64_t ld, int64_t M, int N, float* out, hipStream_t s) {
+  if (M <= 0 || N <= 0) return 0;
+  dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 255) / 256 > 64 ? 64 : (M + 255) / 256));
+  if (dtype == OM_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, ld, M, N, out);
+  else hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)x, ld, M, N, out);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+// y[i] = keep(seed, i) ? x[i] / (1 - p) : 0     (forward and backward of inverted dropout)
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p,
+                               uint64_t seed) {
+  const uint32_t thresh = (uint32_t)(p * 4294967296.0);
+  const float scale = 1.0f / (1.0f - p);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    ElemOps<T>::store(y + i, dropout_keep(seed, (uint64_t)i, thresh) ? ElemOps<T>::load(x + i) * scale : 0.f);
+}
+
+int omk_dropout(int dtype, const void* x, void* y, int64_t n, float p, uint64_t seed, hipStream_t s) {
+  if (n <= 0) return 0;
+  const unsigned grid = (unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+  if (dtype == OM_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, n, p, seed);
+  else hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, n, p, seed);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm backward.  One wavefront per row, 4 rows per block pass, grid-stride over rows;
+// d_gamma / d_beta are accumulated per lane in registers and flushed once per block.
+//   xhat = (x - mean) * rstd ; dxhat = dy * g
+//   dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat))
+// MODE 0: x is read from memory (the saved pre-LN sum).
+// MODE 1: x = word[id] + type[tt] + pos[t] is recomputed and dx is scattered into the three
+//         embedding-table gradients (BERT embeddings backward).
+template <typename T, int NV, int MODE>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(
+    const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ g,
+    T* __restrict__ dx, float* __restrict__ dg, float* __restrict__ db, int64_t M, int H, float eps,
+    const int64_t* __restrict__ ids, const int64_t* __restrict__ type_ids,
+    const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
+    float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype_, int L, int vocab,
+    int type_vocab) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = (float*)smem;                       // [2][4][H]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float gacc[NV][4], bacc[NV][4], gv[NV][4];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (lane + 64 * j) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { gacc[j][e] = 0.f; bacc[j][e] = 0.f; gv[j][e] = (c + e < H) ? g[c + e] : 0.f; }
+  }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < M; row += (int64_t)gridDim.x * 4) {
+    float xv[NV][4], dv[NV][4];
+    int64_t id = 0, tt = 0;
+    int t = 0;
+    if (MODE == 1) {
+      id = ids[row]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+      tt = type_ids ? type_ids[row] : 0; tt = tt < 0 ? 0 : (tt >= type_vocab ? type_vocab - 1 : tt);
+      t = (int)(row % L);
+    }
+    float s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (lane + 64 * j) * 4;
+      if (c < H) {
+        if (MODE == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xv[j][e] = ElemOps<T>::load(x + row * H + c + e);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xv[j][e] = (word[id * H + c + e] + type[tt * H + c + e]) + pos[(int64_t)t * H + c + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dv[j][e] = ElemOps<T>::load(dy + row * H + c + e); s1 += xv[j][e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xv[j][e] = 0.f; dv[j][e] = 0.f; }
+      }
+    }
+    const float mean = wave_sum(s1) / (float)H;
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      if ((lane + 64 * j) * 4 < H) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = xv[j][e] - mean; s2 += d * d; }
+      }
+    const float rstd = rsqrtf(wave_sum(s2) / (float)H + eps);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      if ((lane + 64 * j) * 4 < H) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (xv[j][e] - mean) * rstd;
+          const float dxh = dv[j][e] * gv[j][e];
+          xv[j][e] = xh;
+          m1 += dxh; m2 += dxh * xh;
+          gacc[j][e] += dv[j][e] * xh;
+          bacc[j][e] += dv[j][e];
+        }
+      }
+    m1 = wave_sum(m1) / (float)H; m2 = wave_sum(m2) / (float)H;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (lane + 64 * j) * 4;
+      if (c < H) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = rstd * (dv[j][e] * gv[j][e] - m1 - xv[j][e] * m2);
+          if (MODE == 0) {
+            ElemOps<T>::store(dx + row * H + c + e, v);
+          } else {
+            atomicAdd(dword + id * H + c + e, v);
+            atomicAdd(dtype_ + tt * H + c + e, v);
+            atomicAdd(dpos + (int64_t)t * H + c + e, v);
+          }
+        }
+      }
+    }
+  }
+  // block reduction of the parameter gradients
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (lane + 64 * j) * 4;
+    if (c < H) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { red[(0 * 4 + w) * H + c + e] = gacc[j][e]; red[(1 * 4 + w) * H + c + e] = bacc[j][e]; }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 256) {
+    atomicAdd(dg + c, (red[0 * H + c] + red[1 * H + c]) + (red[2 * H + c] + red[3 * H + c]));
+    if (db) atomicAdd(db + c, (red[4 * H + c] + red[5 * H + c]) + (red[6 * H + c] + red[7 * H + c]));
+  }
+}
+
+template <typename T, int MODE>
+static int launch_ln_bwd(const void* dy, const void* x, const float* g, void* dx, float* dg, float* db,
+                         int64_t M, int H, float eps, const int64_t* ids, const int64_t* tt,
+                         const float* word, const float* pos, const float* type, float* dword,
+                         float* dpos, float* dtype_, int L, int vocab, int type_vocab, hipStream_t s) {
+  const unsigned grid = (unsigned)((M + 3) / 4 > 1024 ? 1024 : (M + 3) / 4);
+  const size_t lds = (size_t)8 * H * sizeof(float);
+#define LNB(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, MODE>), dim3(grid), dim3(256), lds, s, (const T*)dy, (const T*)x, g, (T*)dx, dg, db, M, H, eps, ids, tt, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab)
+  if (H <= 1024) LNB(4); else LNB(8);
+#undef LNB
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int omk_ln_bwd(int dtype, const void* dy, const void* x, const float* g, void* dx, float* dg,
+               float* db, int64_t M, int H, float eps, hipStream_t s) {
+  if (M <= 0) return 0;
+  if (H % 4 || H > 2048) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
+  if (dtype == OM_BF16)
+    return launch_ln_bwd<bf16_t, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s);
+  return launch_ln_bwd<float, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s);
+}
+
+int omk_embed_bwd(int dtype, const void* dy, const int64_t* ids, const int64_t* type_ids,
+                  const float* word, const float* pos, const float* type, const float* g,
+                  float* dword, float* dpos, float* dtype_, float* dg, float* db, int64_t M, int L,
+                  int H, int vocab, int type_vocab, float eps, hipStream_t s) {
+  if (M <= 0) return 0;
+  if (H % 4 || H > 2048) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
+  if (dtype == OM_BF16)
+    return launch_ln_bwd<bf16_t, 1>(dy, nullptr, g, nullptr, dg, db, M, H, eps, ids, type_ids, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, s);
+  return launch_ln_bwd<float, 1>(dy, nullptr, g, nullptr, dg, db, M, H, eps, ids, type_ids, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, s);
+}
+
+// ---------------------------------------------------------------------------------------
+// pooling backward: d_hidden[b,t,:] from d_pooled[b,:]
+template <typename T>
+__global__ void pool_bwd_kernel(const float* __restrict__ dp, const int64_t* __restrict__ mask,
+                                T* __restrict__ dh, int L, int H, int mode) {
+  const int64_t b = blockIdx.x;
+  float cnt = 0.f;
+  if (mode == OM_POOL_MEAN) {
+    for (int t = 0; t < L; ++t) cnt += (float)mask[b * L + t];
+    cnt = fmaxf(cnt, 1e-9f);
+  }
+  for (int64_t i = threadIdx.x; i < (int64_t)L * H; i += blockDim.x) {
+    const int t = (int)(i / H), c = (int)(i % H);
+    float v;
+    if (mode == OM_POOL_FIRST) v = t == 0 ? dp[b * H + c] : 0.f;
+    else v = dp[b * H + c] * (float)mask[b * L + t] / cnt;
+    ElemOps<T>::store(dh + (b * L + t) * H + c, v);
+  }
+}
+
+int omk_pool_bwd(int dtype, const float* dp, const int64_t* mask, void* dh, int64_t B, int L, int H,
+                 int mode, hipStream_t s) {
+  if (B <= 0) return 0;
+  if (dtype == OM_BF16) hipLaunchKernelGGL((pool_bwd_kernel<bf16_t>), dim3((unsigned)B), dim3(256), 0, s, dp, mask, (bf16_t*)dh, L, H, mode);
+  else hipLaunchKernelGGL((pool_bwd_kernel<float>), dim3((unsigned)B), dim3(256), 0, s, dp, mask, (float*)dh, L, H, mode);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+// y = x / max(|x|, eps):  dx = (dy - y (y . dy)) / max(|x|, eps)     (eps clamp inactive branch: dx = dy/eps)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ dy,
+                                                         float* __restrict__ dx, int64_t M, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float ss = 0.f, dot = 0.f;
+  for (int c = lane; c < D; c += 64) { const float v = x[row * D + c]; ss += v * v; dot += v * dy[row * D + c]; }
+  ss = wave_sum(ss); dot = wave_sum(dot);
+  const float nrm = sqrtf(ss);
+  if (nrm > 1e-12f) {
+    const float inv = 1.0f / nrm;
+    for (int c = lane; c < D; c += 64) {
+      const float y = x[row * D + c] * inv;
+      dx[row * D + c] = (dy[row * D + c] - y * (dot * inv)) * inv;
+    }
+  } else {
+    for (int c = lane; c < D; c += 64) dx[row * D + c] = dy[row * D + c] * 1e12f;
+  }
+}
+
+int omk_l2norm_bwd(const float* x, const float* dy, float* dx, int64_t M, int D, hipStream_t s) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, dy, dx, M, D);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+// small f32 contractions (LinearHead backward, [B,768]-sized):
+//   nn: C[i,c] = sum_j A[i,j] * Bm[j,c]      tn: C[j,c] = sum_i A[i,j] * Bm[i,c]
+__global__ void small_nn_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                float* __restrict__ C, int J, int Cc) {
+  const int i = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cc) return;
+  float acc = 0.f;
+  for (int j = 0; j < J; ++j) acc = fmaf(A[(int64_t)i * J + j], Bm[(int64_t)j * Cc + c], acc);
+  C[(int64_t)i * Cc + c] = acc;
+}
+__global__ void small_tn_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                float* __restrict__ C, int I, int J, int Cc) {
+  const int j = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cc) return;
+  float acc = 0.f;
+  for (int i = 0; i < I; ++i) acc = fmaf(A[(int64_t)i * J + j], Bm[(int64_t)i * Cc + c], acc);
+  C[(int64_t)j * Cc + c] = acc;
+}
+int omk_small_nn(const float* A, const float* Bm, float* C, int I, int J, int Cc, hipStream_t s) {
+  if (I <= 0 || Cc <= 0) return 0;
+  hipLaunchKernelGGL(small_nn_kernel, dim3((Cc + 255) / 256, I), dim3(256), 0, s, A, Bm, C, J, Cc);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+int omk_small_tn(const float* A, const float* Bm, float* C, int I, int J, int Cc, hipStream_t s) {
+  if (J <= 0 || Cc <= 0) return 0;
+  hipLaunchKernelGGL(small_tn_kernel, dim3((Cc + 255) / 256, J), dim3(256), 0, s, A, Bm, C, I, J, Cc);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Attention backward for one (batch, head) per workgroup, L <= 128 (KT <= 4 key/query tiles).
+//   P = softmax(scale QK^T + mask), Pd = dropout(P), O = Pd V           (forward, recomputed)
+//   dPd = dO V^T ; dP = dropout'(dPd) ; dS = P o (dP - rowsum(P o dP)) * scale
+//   dQ = dS K ; dK = dS^T Q ; dV = Pd^T dO
+// Phase A (wave w <-> query block w): scores in the swapped orientation (lane <-> query, as in
+// the forward) give the row statistics (max, 1/sum, delta) and dQ.
+// Phase B (wave w <-> key block w): the same scores in the direct orientation (lane <-> key,
+// registers <-> queries) are exactly the A-operand layout needed to contract over queries, so
+// dV and dK need no cross-lane traffic; the row statistics come from LDS.
+// Only the three transposed images (K^T, Q^T, dO^T: [64][L+4]) live in LDS; row fragments of
+// Q / K / V / dO are read straight from global memory (L2 resident, 16 KiB each).
+template <typename T, int KT>
+__global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
+    const T* __restrict__ qkv, const T* __restrict__ dctx, T* __restrict__ dqkv,
+    const int64_t* __restrict__ mask, int L, int H, int heads, float scale, float drop_p,
+    uint64_t seed) {
+  typedef AttnGeom<T> G;
+  typedef typename MmaOps<T>::frag_t frag_t;
+  constexpr int LP = KT * 32 + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sKt = (T*)smem;
+  T* sQt = sKt + 64 * LP;
+  T* sDOt = sQt + 64 * LP;
+  float* sM = (float*)(sDOt + 64 * LP);        // additive key mask
+  float* sMax = sM + KT * 32;                  // per query: row max, 1/row sum, delta
+  float* sInv = sMax + KT * 32;
+  float* sDelta = sInv + KT * 32;
+
+  const int h = blockIdx.x % heads;
+  const int64_t b = blockIdx.x / heads;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int64_t ld = 3 * (int64_t)H;
+  const T* base = qkv + b * L * ld + h * 64;
+  const T* dob = dctx + b * L * H + h * 64;
+  T* dbase = dqkv + b * L * ld + h * 64;
+  const uint32_t thresh = drop_p > 0.f ? (uint32_t)(drop_p * 4294967296.0) : 0u;
+  const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+
+  for (int idx = tid; idx < KT * 32 * G::CPR; idx += nthr) {
+    const int row = idx / G::CPR, c = idx % G::CPR;
+    uint4 kv = make_uint4(0, 0, 0, 0), qv = kv, dv = kv;
+    if (row < L) {
+      qv = *(const uint4*)(base + (int64_t)row * ld + c * G::EPC);
+      kv = *(const uint4*)(base + (int64_t)row * ld + H + c * G::EPC);
+      dv = *(const uint4*)(dob + (int64_t)row * H + c * G::EPC);
+    }
+    const T* ke = (const T*)&kv; const T* qe = (const T*)&qv; const T* de = (const T*)&dv;
+#pragma unroll
+    for (int e = 0; e < G::EPC; ++e) {
+      sKt[(c * G::EPC + e) * LP + row] = ke[e];
+      sQt[(c * G::EPC + e) * LP + row] = qe[e];
+      sDOt[(c * G::EPC + e) * LP + row] = de[e];
+    }
+  }
+  for (int k = tid; k < KT * 32; k += nthr)
+    sM[k] = k < L ? (mask[b * L + k] != 0 ? 0.f : -3.4028235e38f) : -INFINITY;
+  __syncthreads();
+
+  const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int blk0 = wave * 32;                  // first query (phase A) / key (phase B) of this wave
+  const bool active = blk0 < L;
+  const int myrow = (blk0 + l31) < L ? (blk0 + l31) : (L - 1);
+
+  // ------------------------------------------------------------------ phase A
+  if (active) {
+    frag_t qf[G::NKK], dof[G::NKK];
+#pragma unroll
+    for (int kk = 0; kk < G::NKK; ++kk) {
+      qf[kk] = *(const frag_t*)(base + (int64_t)myrow * ld + (kk * 2 + half) * G::EPC);
+      dof[kk] = *(const frag_t*)(dob + (int64_t)myrow * H + (kk * 2 + half) * G::EPC);
+    }
+    f32x16_t s[KT], dp[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[t][r] = 0.f; dp[t][r] = 0.f; }
+      const int krow = (t * 32 + l31) < L ? (t * 32 + l31) : (L - 1);
+      const T* kp = base + (int64_t)krow * ld + H;
+      const T* vp = base + (int64_t)krow * ld + 2 * H;
+#pragma unroll
+      for (int kk = 0; kk < G::NKK; ++kk) {
+        const frag_t ka = *(const frag_t*)(kp + (kk * 2 + half) * G::EPC);
+        const frag_t va = *(const frag_t*)(vp + (kk * 2 + half) * G::EPC);
+        MmaOps<T>::mma(ka, qf[kk], s[t]);      // S^T[key][query]
+        MmaOps<T>::mma(va, dof[kk], dp[t]);    // dPd^T[key][query]
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4_t mb = *(const f32x4_t*)(sM + t * 32 + 8 * g + 4 * half);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float v = s[t][4 * g + e] * scale + mb[e]; s[t][4 * g + e] = v; mx = fmaxf(mx, v); }
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float e = G::exp_(s[t][r] - mx); s[t][r] = e; sum += e; }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    float delta = 0.f;
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = s[t][r] * inv;
+        float dpp = dp[t][r];
+        if (thresh) {
+          const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          dpp = dropout_keep(seed, attn_drop_idx(b, h, heads, L, blk0 + l31, key), thresh) ? dpp * keep_scale : 0.f;
+        }
+        s[t][r] = p; dp[t][r] = dpp;
+        delta += p * dpp;
+      }
+    delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = s[t][r] * (dp[t][r] - delta) * scale;   // dS
+    if (half == 0 && blk0 + l31 < L) { sMax[blk0 + l31] = mx; sInv[blk0 + l31] = inv; sDelta[blk0 + l31] = delta; }
+    f32x16_t o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) SlabMma<T>::run(s[t], sKt + l31 * LP + t * 32 + 4 * half, LP, o);   // dQ = dS K
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = blk0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (q < L) ElemOps<T>::store(dbase + (int64_t)q * ld + dt * 32 + l31, o[dt][r]);
+      }
+  }
+  __syncthreads();
+  if (!active) return;
+
+  // ------------------------------------------------------------------ phase B
+  {
+    const bool kvalid = (blk0 + l31) < L;
+    const float mbk = sM[blk0 + l31];
+    frag_t kf[G::NKK], vf[G::NKK];
+#pragma unroll
+    for (int kk = 0; kk < G::NKK; ++kk) {
+      kf[kk] = *(const frag_t*)(base + (int64_t)myrow * ld + H + (kk * 2 + half) * G::EPC);
+      vf[kk] = *(const frag_t*)(base + (int64_t)myrow * ld + 2 * H + (kk * 2 + half) * G::EPC);
+    }
+    f32x16_t dv[2], dk[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dv[dt][r] = 0.f; dk[dt][r] = 0.f; }
+#pragma unroll
+    for (int tq = 0; tq < KT; ++tq) {
+      if (tq * 32 >= L) break;
+      const int qr = (tq * 32 + l31) < L ? (tq * 32 + l31) : (L - 1);
+      f32x16_t sb, dpb;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sb[r] = 0.f; dpb[r] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < G::NKK; ++kk) {
+        const frag_t qa = *(const frag_t*)(base + (int64_t)qr * ld + (kk * 2 + half) * G::EPC);
+        const frag_t da = *(const frag_t*)(dob + (int64_t)qr * H + (kk * 2 + half) * G::EPC);
+        MmaOps<T>::mma(qa, kf[kk], sb);        // S[query][key]
+        MmaOps<T>::mma(da, vf[kk], dpb);       // dPd[query][key]
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int q4 = tq * 32 + 8 * g + 4 * half;
+        const f32x4_t m4 = *(const f32x4_t*)(sMax + q4);
+        const f32x4_t i4 = *(const f32x4_t*)(sInv + q4);
+        const f32x4_t d4 = *(const f32x4_t*)(sDelta + q4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int q = q4 + e;
+          float p = 0.f, pd = 0.f, dpp = 0.f;
+          if (q < L && kvalid) {
+            p = G::exp_(sb[4 * g + e] * scale + mbk - m4[e]) * i4[e];
+            pd = p; dpp = dpb[4 * g + e];
+            if (thresh) {
+              const bool keep = dropout_keep(seed, attn_drop_idx(b, h, heads, L, q, blk0 + l31), thresh);
+              pd = keep ? p * keep_scale : 0.f;
+              dpp = keep ? dpp * keep_scale : 0.f;
+            }
+          }
+          sb[4 * g + e] = pd;                                   // Pd[q][key]
+          dpb[4 * g + e] = (q < L && kvalid) ? p * (dpp - d4[e]) * scale : 0.f;   // dS[q][key]
+        }
+      }
+      SlabMma<T>::run(sb, sDOt + l31 * LP + tq * 32 + 4 * half, LP, dv);    // dV += Pd^T dO
+      SlabMma<T>::run(dpb, sQt + l31 * LP + tq * 32 + 4 * half, LP, dk);    // dK += dS^T Q
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = blk0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (key < L) {
+          ElemOps<T>::store(dbase + (int64_t)key * ld + H + dt * 32 + l31, dk[dt][r]);
+          ElemOps<T>::store(dbase + (int64_t)key * ld + 2 * H + dt * 32 + l31, dv[dt][r]);
+        }
+      }
+  }
+}
+
+template <typename T, int KT>
+static int launch_attn_bwd(const void* qkv, const void* dctx, void* dqkv, const int64_t* mask,
+                           int64_t B, int L, int H, int heads, float scale, float drop_p,
+                           uint64_t seed, hipStream_t s) {
+  constexpr int LP = KT * 32 + 4;
+  const int lds = 3 * 64 * LP * (int)sizeof(T) + 4 * KT * 32 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OM_HIP(hipFuncSetAttribute((const void*)attention_bwd_kernel<T, KT>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const int waves = (L + 31) / 32;
+  hipLaunchKernelGGL((attention_bwd_kernel<T, KT>), dim3((unsigned)(heads * B)), dim3(64 * waves), lds, s,
+                     (const T*)qkv, (const T*)dctx, (T*)dqkv, mask, L, H, heads, scale, drop_p, seed);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int omk_attention_bwd(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask,
+                      int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
+                      hipStream_t s) {
+  if (B <= 0) return 0;
+  if (L < 1 || L > 128) OM_FAIL("training supports sequence lengths up to 128");
+  if (H != heads * 64) OM_FAIL("head_dim must be 64");
+#define AB(TT)                                                                                       \
+  do {                                                                                               \
+    if (L <= 32) return launch_attn_bwd<TT, 1>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s); \
+    if (L <= 64) return launch_attn_bwd<TT, 2>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s); \
+    return launch_attn_bwd<TT, 4>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s);    \
+  } while (0)
+  if (dtype == OM_BF16) AB(bf16_t);
+  AB(float);
+#undef AB
+}

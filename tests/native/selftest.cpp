@@ -312,7 +312,7 @@ int main(int argc, char** argv) {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs=%d  clock=%d MHz  mem=%.1f GB  LDS/block=%zu\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000, prop.totalGlobalMem / 1e9, prop.sharedMemPerBlock);
 
-  if (what != "bench") {
+  if (what != "bench" && what != "prof") {
     // GEMM: aligned, ragged M/N tails, every epilogue, both dtypes
     test_gemm(OM_F32, 128, 128, 32, false, false, OM_ACT_NONE, OM_F32);
     test_gemm(OM_BF16, 128, 128, 64, false, false, OM_ACT_NONE, OM_F32);
@@ -352,6 +352,13 @@ int main(int argc, char** argv) {
     }
     test_merge();
     test_contrastive();
+  }
+  if (what == "prof") {     // short run for rocprofv3 --pmc passes
+    bench_gemm(OM_BF16, 32768, 768, 768, 0);
+    bench_gemm(OM_BF16, 32768, 3072, 768, OM_ACT_GELU_ERF);
+    bench_gemm(OM_BF16, 32768, 768, 3072, 0);
+    bench_gemm(OM_BF16, 8192, 8192, 8192, 0);
+    return 0;
   }
   if (what == "bench" || what == "full") {
     bench_gemm(OM_BF16, 32768, 2304, 768, 0);
