@@ -70,6 +70,9 @@ int om_device_count(void);
 #define OM_TIMING_GEMM_BF16 0
 #define OM_TIMING_GEMM_F32 1
 #define OM_TIMING_SCAN 2
+/* Debug hook: when `buf` is non-NULL every 256-row-tile GEMM workgroup writes 32 shader-clock
+ * stamps (start, prologue, per-K-step, epilogue) to buf[32*block]; NULL switches it off. */
+void om_debug_gemm_trace(unsigned long long* buf);
 int om_kernel_timing_enable(int enable);
 int om_kernel_timing_read(int kernel_class, double* total_ms, int64_t* launches, double* flops);
 

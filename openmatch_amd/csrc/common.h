@@ -40,8 +40,12 @@ __host__ __device__ inline float bf16_to_f32(bf16_t v) {
   c.u = ((uint32_t)v) << 16;
   return c.f;
 }
-// round-to-nearest-even, NaN preserved (same rule as torch's c10::BFloat16)
+// round-to-nearest-even, NaN preserved (same rule as torch's c10::BFloat16).  On the device the
+// __bf16 cast lets hipcc use gfx950's v_cvt_pk_bf16_f32 (one instruction per two values).
 __host__ __device__ inline bf16_t f32_to_bf16(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(unsigned short, (__bf16)f);
+#endif
   union { uint32_t u; float f; } c;
   c.f = f;
   if ((c.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((c.u >> 16) | 0x40);

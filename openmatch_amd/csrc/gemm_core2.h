@@ -39,7 +39,8 @@ __device__ inline void g2_stage(const char* const (&pa)[4], const char* const (&
 template <typename T>
 __device__ inline void gemm_mainloop2(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
                                       int64_t ldb, int64_t M, int64_t N, int64_t K, int64_t m0,
-                                      int64_t n0, char* smem, f32x16_t (&acc)[2][2]) {
+                                      int64_t n0, char* smem, f32x16_t (&acc)[2][2],
+                                      unsigned long long* tr = nullptr) {
   typedef typename MmaOps<T>::frag_t frag_t;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -78,6 +79,7 @@ __device__ inline void gemm_mainloop2(const T* __restrict__ A, int64_t lda, cons
   char* s_cur = smem;                        // slot of tile t
   char* s_nxt = smem + G2_STAGE_BYTES;       // slot of tile t+1
   char* s_far = smem + 2 * G2_STAGE_BYTES;   // slot of tile t+2 (== slot of tile t-1)
+  if (tr && tid == 0) tr[1] = clock64();
   g2_stage(pa, pb, 0, s_cur, wave);
   if (nk > 1) g2_stage(pa, pb, GEMM_ROW_BYTES, s_nxt, wave);
 
@@ -87,6 +89,7 @@ __device__ inline void gemm_mainloop2(const T* __restrict__ A, int64_t lda, cons
     else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS reads of tile t-1 are done
     __builtin_amdgcn_s_barrier();                         // -> true for every wave
+    if (tr && tid == 0 && t < 13) tr[2 + t] = clock64();
     if (t + 2 < nk) g2_stage(pa, pb, (size_t)(t + 2) * GEMM_ROW_BYTES, s_far, wave);
     // register double-buffering of the fragments: the LDS reads of sub-step kk+1 are in flight
     // while the MFMAs of sub-step kk issue (LDS latency under load is several hundred cycles)

@@ -32,6 +32,7 @@ struct GemmEpilogue {
   int64_t ldp;
   float drop_p;        // 0 = no dropout
   uint64_t seed;
+  unsigned long long* trace;  // debug: per-block phase timestamps (om_debug_gemm_trace), else NULL
 };
 int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int out_dtype,
              void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep,

@@ -23,6 +23,7 @@
 #include <algorithm>
 
 #include "gemm_core2.h"
+#include "gemm_core3.h"
 #include "kernels.h"
 
 #define SORT_CAP 8192      // keys one workgroup sorts in LDS (64 KiB)
@@ -62,6 +63,40 @@ __global__ __launch_bounds__(G2_THREADS) void sim_filter_kernel(
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int64_t mbase = m0 + wm * 64 + mi * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = mbase + (r & 3) + 8 * (r >> 2);
+        const float v = acc[mi][ni][r];
+        if (m < nrows && v >= th) {
+          const unsigned pos = atomicAdd(cnt + q, 1u);
+          if (pos < SORT_CAP) keys[q * SORT_CAP + pos] = pack_key(v, row_base + (uint32_t)m);
+        }
+      }
+    }
+  }
+}
+
+// same scan on the 256 x 256 tile (gemm_core3.h) for query batches wider than one 128 tile
+template <typename T>
+__global__ __launch_bounds__(G3_THREADS) void sim_filter_kernel3(
+    const T* __restrict__ rows, int64_t nrows, uint32_t row_base, const T* __restrict__ queries,
+    int64_t nq, int64_t d, const float* __restrict__ thr, u64* __restrict__ keys,
+    unsigned* __restrict__ cnt, int group_m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int64_t m0, n0;
+  g3_tile_coords(nrows, nq, group_m, m0, n0);
+  f32x16_t acc[4][2];
+  gemm_mainloop3<T>(rows, d, queries, d, nrows, nq, d, m0, n0, smem, acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int64_t q = n0 + wn * 64 + ni * 32 + (lane & 31);
+    if (q >= nq) continue;
+    const float th = thr[q];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int64_t mbase = m0 + wm * 128 + mi * 32 + 4 * (lane >> 5);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t m = mbase + (r & 3) + 8 * (r >> 2);
@@ -357,18 +392,23 @@ struct Scan {
     return select(bf16);
   }
   int filter_step(int64_t r0, int64_t n, bool bf16) {
-    const int64_t ntm = (n + G2_BM - 1) / G2_BM, ntn = (nq + G2_BN - 1) / G2_BN;
+    const bool wide = nq > 128;
+    const int64_t ntm = (n + 255) / 256, ntn = wide ? (nq + G3_BN - 1) / G3_BN : (nq + G2_BN - 1) / G2_BN;
     if (ntm * ntn > 0x7fffffffLL) OM_FAIL("scan grid too large");
     const bool timing = om_timing_on();
     if (timing) om_timing_begin(OM_TIMING_SCAN, s);
-    if (bf16)
-      hipLaunchKernelGGL((sim_filter_kernel<f16_t>), dim3((unsigned)(ntm * ntn)), dim3(G2_THREADS),
-                         G2_LDS_BYTES, s, idx16 + r0 * d, n, (uint32_t)r0, ws.qb, nq, (int64_t)d,
-                         ws.thr, ws.keys, ws.cnt, 8);
-    else
-      hipLaunchKernelGGL((sim_filter_kernel<float>), dim3((unsigned)(ntm * ntn)), dim3(G2_THREADS),
-                         G2_LDS_BYTES, s, idx32 + r0 * d, n, (uint32_t)r0, q32, nq, (int64_t)d,
-                         ws.thr, ws.keys, ws.cnt, 8);
+    const dim3 grid((unsigned)(ntm * ntn));
+#define SCAN(KERNEL, THREADS, LDS, TT, ROWS, QUERIES)                                              \
+  hipLaunchKernelGGL((KERNEL<TT>), grid, dim3(THREADS), LDS, s, ROWS + r0 * d, n, (uint32_t)r0, QUERIES, \
+                     nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8)
+    if (bf16) {
+      if (wide) SCAN(sim_filter_kernel3, G3_THREADS, G3_LDS_BYTES, f16_t, idx16, ws.qb);
+      else SCAN(sim_filter_kernel, G2_THREADS, G2_LDS_BYTES, f16_t, idx16, ws.qb);
+    } else {
+      if (wide) SCAN(sim_filter_kernel3, G3_THREADS, G3_LDS_BYTES, float, idx32, q32);
+      else SCAN(sim_filter_kernel, G2_THREADS, G2_LDS_BYTES, float, idx32, q32);
+    }
+#undef SCAN
     if (timing) om_timing_end(OM_TIMING_SCAN, s, 2.0 * (double)n * (double)nq * (double)d);
     OM_LAUNCH_CHECK();
     hipLaunchKernelGGL(check_overflow_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s,
@@ -479,6 +519,10 @@ extern "C" int om_sim_topk(int mode, const float* queries, int64_t n_queries,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel<f16_t>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+    OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel3<float>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
+    OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel3<f16_t>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
     attr_set = true;
   }
   for (auto& v : g_info) v = 0;

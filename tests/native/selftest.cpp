@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/openmatch_hip.h"
+#include <stdlib.h>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 #define OMCK(x) do { if (x) { printf("OM error: %s  (%s:%d)\n", om_last_error(), __FILE__, __LINE__); g_fail++; } } while (0)
@@ -312,7 +313,7 @@ int main(int argc, char** argv) {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs=%d  clock=%d MHz  mem=%.1f GB  LDS/block=%zu\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000, prop.totalGlobalMem / 1e9, prop.sharedMemPerBlock);
 
-  if (what != "bench" && what != "prof") {
+  if (what != "bench" && what != "prof" && what != "trace") {
     // GEMM: aligned, ragged M/N tails, every epilogue, both dtypes
     test_gemm(OM_F32, 128, 128, 32, false, false, OM_ACT_NONE, OM_F32);
     test_gemm(OM_BF16, 128, 128, 64, false, false, OM_ACT_NONE, OM_F32);
@@ -352,6 +353,26 @@ int main(int argc, char** argv) {
     }
     test_merge();
     test_contrastive();
+  }
+  if (what == "trace") {    // per-block phase timelines of one GEMM launch (shader clocks)
+    const int64_t M = 32768, N = argc > 2 ? atoi(argv[2]) : 768, K = argc > 3 ? atoi(argv[3]) : 768;
+    char* A = dalloc<char>(M * K * 2); char* B = dalloc<char>(N * K * 2); char* C = dalloc<char>(M * N * 2);
+    { auto t = to_bf16(randn(1 << 22)); for (size_t o = 0; o < (size_t)M * K; o += t.size()) CK(hipMemcpy(A + o * 2, t.data(), std::min(t.size(), (size_t)M * K - o) * 2, hipMemcpyHostToDevice)); auto tb = to_bf16(randn((size_t)N * K, 0.05f)); CK(hipMemcpy(B, tb.data(), tb.size() * 2, hipMemcpyHostToDevice)); }
+    const size_t nblk = 8192; unsigned long long* tr = dalloc<unsigned long long>(nblk * 32);
+    for (int i = 0; i < 3; ++i) OMCK(om_gemm_nt(OM_BF16, A, K, B, K, OM_BF16, C, N, M, N, K, nullptr, nullptr, 0, 0, nullptr));
+    CK(hipMemset(tr, 0, nblk * 32 * 8)); om_debug_gemm_trace(tr);
+    OMCK(om_gemm_nt(OM_BF16, A, K, B, K, OM_BF16, C, N, M, N, K, nullptr, nullptr, 0, 0, nullptr));
+    CK(hipDeviceSynchronize()); om_debug_gemm_trace(nullptr);
+    auto h = download(tr, nblk * 32);
+    unsigned long long t0 = ~0ull; size_t used = 0;
+    for (size_t b = 0; b < nblk; ++b) if (h[b * 32]) { t0 = std::min(t0, h[b * 32]); used = b + 1; }
+    printf("trace M=%ld N=%ld K=%ld blocks=%zu (cycles since first block start)\n", (long)M, (long)N, (long)K, used);
+    for (size_t b = 0; b < used; b += std::max<size_t>(1, used / 24)) {
+      printf("blk %5zu:", b);
+      for (int i = 0; i < 30; ++i) if (h[b * 32 + i] && i != 29) printf(" [%d]%llu", i, h[b * 32 + i] - t0);
+      printf("\n");
+    }
+    return 0;
   }
   if (what == "prof") {     // short run for rocprofv3 --pmc passes
     bench_gemm(OM_BF16, 32768, 768, 768, 0);
