@@ -163,6 +163,50 @@ int om_encoder_forward(const OmEncoderConfig* cfg, const OmEncoderWeights* w,
                        size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Encoder forward + backward for training (BERT; sequence length <= 128).
+ * Replaces the autograd graph HF builds under DRModel.forward in train mode
+ * (modeling/dense_retrieval_model.py:89-131 -> HF BertModel with dropout) and
+ * `loss.backward()` through it (trainer/dense_trainer.py:102-108).
+ *
+ * The forward saves one "tape" of activations (caller-provided memory); dropout masks are
+ * regenerated from (seed, element index) in the backward, never stored.  Gradients are written
+ * (not accumulated) into caller-provided f32 buffers laid out like the weights; buffers that
+ * are reduced with atomics (LayerNorm gamma/beta, biases, embedding tables) must be ZEROED by
+ * the caller before the call.
+ * ------------------------------------------------------------------------ */
+typedef struct OmLayerGrads {
+  float* qkv_w;  float* qkv_b;  float* o_w;    float* o_b;   float* ln1_g; float* ln1_b;
+  float* ffn1_w; float* ffn1_b; float* ffn2_w; float* ffn2_b; float* ln2_g; float* ln2_b;
+} OmLayerGrads;
+
+typedef struct OmEncoderGrads {
+  float* word_emb; float* pos_emb; float* type_emb; float* emb_ln_g; float* emb_ln_b;
+  const OmLayerGrads* layers_host;  /* HOST array [n_layers] of device pointers */
+  float* head_w;                    /* [head_out, head_in] or NULL              */
+} OmEncoderGrads;
+
+size_t om_encoder_tape_bytes(const OmEncoderConfig* cfg, int64_t B, int64_t L);
+size_t om_encoder_train_workspace_bytes(const OmEncoderConfig* cfg, int64_t B, int64_t L);
+
+/* hidden_dropout / attn_dropout: HF config hidden_dropout_prob / attention_probs_dropout_prob
+ * (0 disables).  out_reps: f32 [B,D] as om_encoder_forward. */
+int om_encoder_train_forward(const OmEncoderConfig* cfg, const OmEncoderWeights* w,
+                             const int64_t* input_ids, const int64_t* attention_mask,
+                             const int64_t* token_type_ids, int64_t B, int64_t L,
+                             float hidden_dropout, float attn_dropout, uint64_t seed, void* tape,
+                             size_t tape_bytes, float* out_reps, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
+/* d_reps: f32 [B,D] gradient of the loss w.r.t. out_reps.  Same ids / mask / dropout / seed /
+ * tape as the matching forward call. */
+int om_encoder_train_backward(const OmEncoderConfig* cfg, const OmEncoderWeights* w,
+                              const int64_t* input_ids, const int64_t* attention_mask,
+                              const int64_t* token_type_ids, int64_t B, int64_t L,
+                              float hidden_dropout, float attn_dropout, uint64_t seed,
+                              const void* tape, const float* d_reps, const OmEncoderGrads* grads,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
  * Exact inner-product search.  Replaces faiss.IndexFlatIP.add / .search
  * (retriever/dense_retriever.py:38-41,105,180) and faiss-GPU sharding (:43-58).
  * ------------------------------------------------------------------------ */

@@ -16,8 +16,8 @@ OBJ_DIR = os.path.join(REPO, "build", "obj")
 LIB_PATH = os.path.join(CSRC, "libopenmatch_hip.so")
 ARCH = "gfx950"
 SOURCES = ["abi.cpp", "gemm.hip", "elementwise.hip", "attention.hip", "encoder.hip",
-           "search.hip", "contrastive.hip", "train.hip"]
-HEADERS = ["common.h", "gemm_core.h", "kernels.h", os.path.join("..", "..", "include", "openmatch_hip.h")]
+           "search.hip", "contrastive.hip", "train_kernels.hip", "train.hip"]
+HEADERS = ["common.h", "gemm_core.h", "gemm_core2.h", "gemm_core3.h", "attn_common.h", "train_kernels.h", "kernels.h", os.path.join("..", "..", "include", "openmatch_hip.h")]
 
 
 def _hipcc():

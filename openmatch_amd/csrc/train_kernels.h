@@ -1,0 +1,22 @@
+// Launchers of the backward-pass kernels (train_kernels.hip), shared with train.hip.
+#pragma once
+#include "kernels.h"
+
+int omk_transpose(int dtype, const void* in, int64_t ldi, int64_t R, int C, void* out, int64_t ldo,
+                  int64_t Rp, int op, hipStream_t s);
+int omk_colsum(int dtype, const void* x, int64_t ld, int64_t M, int N, float* out, hipStream_t s);
+int omk_dropout(int dtype, const void* x, void* y, int64_t n, float p, uint64_t seed, hipStream_t s);
+int omk_ln_bwd(int dtype, const void* dy, const void* x, const float* g, void* dx, float* dg,
+               float* db, int64_t M, int H, float eps, hipStream_t s);
+int omk_embed_bwd(int dtype, const void* dy, const int64_t* ids, const int64_t* type_ids,
+                  const float* word, const float* pos, const float* type, const float* g,
+                  float* dword, float* dpos, float* dtype_, float* dg, float* db, int64_t M, int L,
+                  int H, int vocab, int type_vocab, float eps, hipStream_t s);
+int omk_pool_bwd(int dtype, const float* dp, const int64_t* mask, void* dh, int64_t B, int L, int H,
+                 int mode, hipStream_t s);
+int omk_l2norm_bwd(const float* x, const float* dy, float* dx, int64_t M, int D, hipStream_t s);
+int omk_small_nn(const float* A, const float* Bm, float* C, int I, int J, int Cc, hipStream_t s);
+int omk_small_tn(const float* A, const float* Bm, float* C, int I, int J, int Cc, hipStream_t s);
+int omk_attention_bwd(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask,
+                      int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
+                      hipStream_t s);

@@ -43,6 +43,18 @@ class OmEncoderWeights(C.Structure):
                 ("rel_bias", c_void_p), ("head_w", c_void_p)]
 
 
+class OmLayerGrads(C.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "qkv_w", "qkv_b", "o_w", "o_b", "ln1_g", "ln1_b", "ffn1_w", "ffn1_b", "ffn2_w", "ffn2_b",
+        "ln2_g", "ln2_b")]
+
+
+class OmEncoderGrads(C.Structure):
+    _fields_ = [("word_emb", c_void_p), ("pos_emb", c_void_p), ("type_emb", c_void_p),
+                ("emb_ln_g", c_void_p), ("emb_ln_b", c_void_p),
+                ("layers_host", C.POINTER(OmLayerGrads)), ("head_w", c_void_p)]
+
+
 _SIGNATURES = {
     "om_last_error": (C.c_char_p, []),
     "om_abi_version": (c_int, []),
@@ -57,6 +69,15 @@ _SIGNATURES = {
     "om_encoder_forward": (c_int, [C.POINTER(OmEncoderConfig), C.POINTER(OmEncoderWeights), c_void_p,
                                    c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                    c_void_p, c_size_t, c_void_p]),
+    "om_encoder_tape_bytes": (c_size_t, [C.POINTER(OmEncoderConfig), c_int64, c_int64]),
+    "om_encoder_train_workspace_bytes": (c_size_t, [C.POINTER(OmEncoderConfig), c_int64, c_int64]),
+    "om_encoder_train_forward": (c_int, [C.POINTER(OmEncoderConfig), C.POINTER(OmEncoderWeights), c_void_p,
+                                         c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, C.c_uint64,
+                                         c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "om_encoder_train_backward": (c_int, [C.POINTER(OmEncoderConfig), C.POINTER(OmEncoderWeights), c_void_p,
+                                          c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, C.c_uint64,
+                                          c_void_p, c_void_p, C.POINTER(OmEncoderGrads), c_void_p, c_size_t,
+                                          c_void_p]),
     "om_index_to_f16": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "om_sim_topk_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "om_sim_topk": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int,

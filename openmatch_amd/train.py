@@ -1,0 +1,128 @@
+"""Training path of the encoder: `om_encoder_train_forward` / `om_encoder_train_backward` behind a
+`torch.autograd.Function`, so `DRModel.forward(...).loss.backward()` fills `param.grad` of the HF
+module's parameters exactly as autograd through HF's own forward would (reference:
+modeling/dense_retrieval_model.py:89-131, trainer/dense_trainer.py:102-108), without ever
+running that forward."""
+import ctypes as C
+
+import torch
+
+from . import native as N
+from .encoder import _POOL, _arch_of, packed_weights
+
+
+def _bert_params(model, head):
+    """Parameters in the order the backward returns their gradients."""
+    emb = model.embeddings
+    ps = [emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight,
+          emb.LayerNorm.weight, emb.LayerNorm.bias]
+    for layer in model.encoder.layer:
+        at = layer.attention
+        ps += [at.self.query.weight, at.self.key.weight, at.self.value.weight,
+               at.self.query.bias, at.self.key.bias, at.self.value.bias,
+               at.output.dense.weight, at.output.dense.bias, at.output.LayerNorm.weight, at.output.LayerNorm.bias,
+               layer.intermediate.dense.weight, layer.intermediate.dense.bias,
+               layer.output.dense.weight, layer.output.dense.bias,
+               layer.output.LayerNorm.weight, layer.output.LayerNorm.bias]
+    if head is not None:
+        ps.append(head.linear.weight)
+    return ps
+
+
+class _EncoderTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, head, ids, mask, tti, pooling, normalize, code, p_hidden, p_attn, seed, *params):
+        device = ids.device
+        pk = packed_weights(model, head, code, device)
+        cfg = N.OmEncoderConfig(pooling=_POOL[pooling], normalize=int(bool(normalize)), **pk.cfg)
+        B, L = ids.shape
+        D = cfg.head_out if cfg.head_in > 0 else cfg.hidden
+        lib = N.lib()
+        with torch.cuda.device(device):
+            tape = torch.empty(lib.om_encoder_tape_bytes(C.byref(cfg), B, L) + 256, dtype=torch.uint8, device=device)
+            tape_ptr = tape.data_ptr() + (-tape.data_ptr()) % 256
+            nws = lib.om_encoder_train_workspace_bytes(C.byref(cfg), B, L)
+            _buf, ws_ptr = N.Workspace.get(device, nws, "train")
+            reps = torch.empty(B, D, device=device, dtype=torch.float32)
+            N.check(lib.om_encoder_train_forward(
+                C.byref(cfg), C.byref(pk.weights), N.ptr(ids), N.ptr(mask), N.ptr(tti), B, L,
+                float(p_hidden), float(p_attn), int(seed), C.c_void_p(tape_ptr), tape.numel() - 256,
+                N.ptr(reps), C.c_void_p(ws_ptr), nws, N.stream_ptr(device)))
+        ctx.model, ctx.head, ctx.cfg, ctx.pk = model, head, cfg, pk
+        ctx.ids, ctx.mask, ctx.tti, ctx.tape, ctx.tape_ptr = ids, mask, tti, tape, tape_ptr
+        ctx.drop = (float(p_hidden), float(p_attn), int(seed))
+        ctx.n_params = len(params)
+        return reps
+
+    @staticmethod
+    def backward(ctx, d_reps):
+        cfg, pk, model, head = ctx.cfg, ctx.pk, ctx.model, ctx.head
+        device = ctx.ids.device
+        B, L = ctx.ids.shape
+        H, F, nl = cfg.hidden, cfg.ffn, cfg.n_layers
+        z = lambda *shape: torch.zeros(*shape, device=device, dtype=torch.float32)
+        g = N.OmEncoderGrads()
+        keep = []
+
+        def buf(field_owner, name, *shape):
+            t = z(*shape)
+            keep.append(t)
+            setattr(field_owner, name, t.data_ptr())
+            return t
+        emb = model.embeddings
+        gw = buf(g, "word_emb", *emb.word_embeddings.weight.shape)
+        gp = buf(g, "pos_emb", *emb.position_embeddings.weight.shape)
+        gt = buf(g, "type_emb", *emb.token_type_embeddings.weight.shape)
+        gg = buf(g, "emb_ln_g", H)
+        gb = buf(g, "emb_ln_b", H)
+        layers = (N.OmLayerGrads * nl)()
+        per_layer = []
+        for l in range(nl):
+            lg = layers[l]
+            per_layer.append(dict(
+                qkv_w=buf(lg, "qkv_w", 3 * H, H), qkv_b=buf(lg, "qkv_b", 3 * H), o_w=buf(lg, "o_w", H, H),
+                o_b=buf(lg, "o_b", H), ln1_g=buf(lg, "ln1_g", H), ln1_b=buf(lg, "ln1_b", H),
+                ffn1_w=buf(lg, "ffn1_w", F, H), ffn1_b=buf(lg, "ffn1_b", F), ffn2_w=buf(lg, "ffn2_w", H, F),
+                ffn2_b=buf(lg, "ffn2_b", H), ln2_g=buf(lg, "ln2_g", H), ln2_b=buf(lg, "ln2_b", H)))
+        g.layers_host = C.cast(layers, C.POINTER(N.OmLayerGrads))
+        ghead = buf(g, "head_w", cfg.head_out, cfg.head_in) if cfg.head_in > 0 else None
+        d_reps = d_reps.to(torch.float32).contiguous()
+        lib = N.lib()
+        with torch.cuda.device(device):
+            nws = lib.om_encoder_train_workspace_bytes(C.byref(cfg), B, L)
+            _buf, ws_ptr = N.Workspace.get(device, nws, "train")
+            N.check(lib.om_encoder_train_backward(
+                C.byref(cfg), C.byref(pk.weights), N.ptr(ctx.ids), N.ptr(ctx.mask), N.ptr(ctx.tti), B, L,
+                ctx.drop[0], ctx.drop[1], ctx.drop[2], C.c_void_p(ctx.tape_ptr), N.ptr(d_reps), C.byref(g),
+                C.c_void_p(ws_ptr), nws, N.stream_ptr(device)))
+        grads = [gw, gp, gt, gg, gb]
+        for d in per_layer:
+            q, k, v = d["qkv_w"].split(H, dim=0)
+            qb, kb, vb = d["qkv_b"].split(H, dim=0)
+            grads += [q, k, v, qb, kb, vb, d["o_w"], d["o_b"], d["ln1_g"], d["ln1_b"], d["ffn1_w"], d["ffn1_b"],
+                      d["ffn2_w"], d["ffn2_b"], d["ln2_g"], d["ln2_b"]]
+        if ghead is not None:
+            grads.append(ghead)
+        ctx.tape = None
+        return (None,) * 11 + tuple(grads)
+
+
+def encode_train(model, head, items, pooling, normalize, code, training):
+    """(None, reps) with an autograd edge from `reps` to every encoder / head parameter.
+    Dropout follows the HF config only in training mode (model.train())."""
+    if _arch_of(model) != "bert":
+        raise NotImplementedError("the HIP backward pass exists for BERT encoders; T5 training is not implemented")
+    ids = items["input_ids"].to(torch.int64).contiguous()
+    mask = items["attention_mask"].to(device=ids.device, dtype=torch.int64).contiguous()
+    tti = items.get("token_type_ids") if hasattr(items, "get") else None
+    if tti is not None:
+        tti = tti.to(device=ids.device, dtype=torch.int64).contiguous()
+    N.require_device(ids, mask, tti)
+    cfg = model.config
+    p_hidden = float(cfg.hidden_dropout_prob) if training else 0.0
+    p_attn = float(cfg.attention_probs_dropout_prob) if training else 0.0
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p_hidden > 0 or p_attn > 0) else 0
+    params = _bert_params(model, head)
+    reps = _EncoderTrain.apply(model, head, ids, mask, tti, pooling, normalize, code, p_hidden, p_attn, seed,
+                               *params)
+    return None, reps

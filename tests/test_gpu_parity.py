@@ -228,3 +228,80 @@ def test_contrastive_loss_matches_reference_fixture(golden):
     lref, _ = retrieval_ref.contrastive_loss(qc, pc, int(g["n_psg"]))
     lref.backward()
     assert (q.grad.cpu() - qc.grad).abs().max() < 1e-6 and (p.grad.cpu() - pc.grad).abs().max() < 1e-6
+
+
+# ------------------------------------------------------------------------------- training
+def _train_model(g, dtype="float32", p_drop=0.0):
+    from openmatch.modeling import DRModel, LinearHead
+    cfg, lm = model_from_golden(g, "bert", hidden_dropout_prob=p_drop, attention_probs_dropout_prob=p_drop)
+    head = LinearHead(128, 128)
+    head.linear.weight.data.copy_(torch.from_numpy(g["head_w"]))
+    model = DRModel(lm_q=lm, lm_p=lm, pooling="mean", head_q=head, head_p=head, normalize=True,
+                    model_args=NS(encoder_only=False, dtype=dtype), data_args=NS(train_n_passages=int(g["n_psg"])),
+                    train_args=NS(negatives_x_device=False, per_device_train_batch_size=4))
+    return model.to(DEV).train()
+
+
+def _train_batch(g):
+    mk = lambda k: {"input_ids": torch.from_numpy(g[k + "_input_ids"]).to(DEV),
+                    "attention_mask": torch.from_numpy(g[k + "_attention_mask"]).to(DEV),
+                    "token_type_ids": torch.zeros_like(torch.from_numpy(g[k + "_input_ids"])).to(DEV)}
+    return mk("q"), mk("p")
+
+
+def test_training_step_f32_matches_reference_gradients(golden):
+    """DRModel.forward(train) + loss.backward() through the HIP encoder backward vs the reference's
+    autograd (dropout 0): loss within 1e-5, every parameter gradient within 1e-3 relative L2 and
+    2e-5 absolute of the reference's."""
+    g = golden("train_bert_tiny")
+    model = _train_model(g)
+    q, p = _train_batch(g)
+    out = model(query=q, passage=p)
+    assert abs(out.loss.item() - float(g["loss"])) < 1e-5
+    assert np.abs(out.scores.detach().cpu().numpy() - g["scores"]).max() < 1e-5
+    out.loss.backward()
+    worst = ("", 0.0)
+    names = dict(model.lm_q.named_parameters())
+    checked = 0
+    for key in g.files:
+        if not key.startswith("g::"):
+            continue
+        name = key[3:]
+        ref = torch.from_numpy(g[key])
+        got = (model.head_q.linear.weight.grad if name == "head_w" else names[name].grad)
+        assert got is not None, name
+        got = got.cpu()
+        rel = ((got - ref).norm() / (ref.norm() + 1e-12)).item()
+        assert rel < 1e-3 and (got - ref).abs().max() < 2e-5, (name, rel, (got - ref).abs().max().item())
+        worst = max(worst, (name, rel), key=lambda t: t[1])
+        checked += 1
+    assert checked > 30
+    print("worst relative gradient error:", worst)
+
+
+def test_training_step_bf16_and_dropout_are_sane(golden):
+    g = golden("train_bert_tiny")
+    q, p = _train_batch(g)
+    # bf16 compute, no dropout: gradients close to the f32 reference (cosine per tensor)
+    model = _train_model(g, dtype="bfloat16")
+    out = model(query=q, passage=p)
+    assert abs(out.loss.item() - float(g["loss"])) < 2e-2
+    out.loss.backward()
+    names = dict(model.lm_q.named_parameters())
+    for key in ("g::encoder.layer.0.attention.self.query.weight", "g::encoder.layer.1.output.dense.weight",
+                "g::embeddings.word_embeddings.weight", "g::encoder.layer.0.intermediate.dense.bias"):
+        ref = torch.from_numpy(g[key]).flatten().double()
+        got = names[key[3:]].grad.cpu().flatten().double()
+        cos = torch.dot(ref, got) / (ref.norm() * got.norm())
+        assert cos > 0.99, (key, cos.item())
+    # dropout 0.1: finite loss / gradients, different masks on different calls, eval() is deterministic
+    model = _train_model(g, p_drop=0.1)
+    l1 = model(query=q, passage=p).loss
+    l2 = model(query=q, passage=p).loss
+    assert torch.isfinite(l1) and torch.isfinite(l2) and l1.item() != l2.item()
+    l1.backward()
+    assert all(torch.isfinite(p_.grad).all() for p_ in model.lm_q.parameters() if p_.grad is not None)
+    model.eval()
+    with torch.no_grad():
+        a = model(query=q, passage=p).loss.item(); b = model(query=q, passage=p).loss.item()
+    assert a == b
