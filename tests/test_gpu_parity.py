@@ -272,8 +272,12 @@ def test_training_step_f32_matches_reference_gradients(golden):
         assert got is not None, name
         got = got.cpu()
         rel = ((got - ref).norm() / (ref.norm() + 1e-12)).item()
-        assert rel < 1e-3 and (got - ref).abs().max() < 2e-5, (name, rel, (got - ref).abs().max().item())
-        worst = max(worst, (name, rel), key=lambda t: t[1])
+        amax = (got - ref).abs().max().item()
+        # (the key-bias gradient is identically zero -- softmax is shift invariant -- so only its
+        # absolute size can be checked)
+        assert (rel < 1e-3 or amax < 1e-7) and amax < 2e-5, (name, rel, amax)
+        if amax >= 1e-7:
+            worst = max(worst, (name, rel), key=lambda t: t[1])
         checked += 1
     assert checked > 30
     print("worst relative gradient error:", worst)
@@ -305,3 +309,47 @@ def test_training_step_bf16_and_dropout_are_sane(golden):
     with torch.no_grad():
         a = model(query=q, passage=p).loss.item(); b = model(query=q, passage=p).loss.item()
     assert a == b
+
+
+def test_training_gradients_match_oracle_autograd_at_bert_width():
+    """One bert-base-WIDTH layer (H=768, F=3072, 12 heads), 8 x 128-token passages + 4 x 32-token
+    queries: exercises the 256-row GEMM tiles, the fused GELU' epilogue and the wgrad path at real
+    shapes.  Reference = torch autograd through the CPU oracle (oracle/encoder_ref.py)."""
+    from transformers import BertConfig, BertModel
+    from openmatch.modeling import DRModel
+    torch.manual_seed(11)
+    cfg = BertConfig(hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=3072,
+                     vocab_size=600, max_position_embeddings=160, hidden_dropout_prob=0.0,
+                     attention_probs_dropout_prob=0.0)
+    lm = BertModel(cfg)
+    ref_lm = BertModel(cfg); ref_lm.load_state_dict(lm.state_dict())
+    rng = np.random.default_rng(4)
+    p_ids, p_mask = synth_tokens(rng, 8, 128, vocab=600, lo_len=16, lo_id=300)
+    q_ids, q_mask = synth_tokens(rng, 4, 32, vocab=600, lo_len=4, lo_id=300)
+    tens = lambda a: torch.from_numpy(a)
+    # reference on CPU
+    sd = dict(ref_lm.named_parameters())
+    sd.update({k: v for k, v in ref_lm.named_buffers()})
+    hq = encoder_ref.encode(sd, cfg, "bert", {"input_ids": tens(q_ids), "attention_mask": tens(q_mask)}, "first")[1]
+    hp = encoder_ref.encode(sd, cfg, "bert", {"input_ids": tens(p_ids), "attention_mask": tens(p_mask)}, "first")[1]
+    loss_ref, _ = retrieval_ref.contrastive_loss(hq, hp, 2)
+    loss_ref.backward()
+    model = DRModel(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype="float32"),
+                    data_args=NS(train_n_passages=2),
+                    train_args=NS(negatives_x_device=False, per_device_train_batch_size=4)).to(DEV).train()
+    out = model(query={"input_ids": tens(q_ids).to(DEV), "attention_mask": tens(q_mask).to(DEV)},
+                passage={"input_ids": tens(p_ids).to(DEV), "attention_mask": tens(p_mask).to(DEV)})
+    assert abs(out.loss.item() - loss_ref.item()) < 1e-3 * max(1.0, abs(loss_ref.item()))
+    out.loss.backward()
+    got = dict(lm.named_parameters())
+    worst = ("", 0.0)
+    for name, p in ref_lm.named_parameters():
+        if p.grad is None:
+            continue
+        gg = got[name].grad.cpu()
+        rel = ((gg - p.grad).norm() / (p.grad.norm() + 1e-20)).item()
+        amax = (gg - p.grad).abs().max().item()
+        assert rel < 2e-3 or amax < 1e-7, (name, rel, amax)
+        if amax >= 1e-7:
+            worst = max(worst, (name, rel), key=lambda t: t[1])
+    print("worst relative gradient error at bert width:", worst)
