@@ -109,7 +109,10 @@ class DRModel(nn.Module):
             raise ValueError("Unknown pooling type: {}".format(self.pooling))
         code = compute_dtype_code(self.model_args)
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
-        if needs_grad:
+        cfg = getattr(model, "config", None)
+        has_dropout = self.training and (getattr(cfg, "hidden_dropout_prob", 0.0) > 0
+                                         or getattr(cfg, "attention_probs_dropout_prob", 0.0) > 0)
+        if needs_grad or has_dropout:      # train-mode forward (dropout), also under no_grad (GradCache)
             return encode_with_grad(model, head, items, self.pooling, self.normalize, code,
                                     self.training)
         return hip_encode(model, items, self.pooling, head, self.normalize, code)

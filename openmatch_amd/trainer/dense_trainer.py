@@ -1,0 +1,292 @@
+"""`DRTrainer` with the reference's constructor and public methods
+(src/openmatch/trainer/dense_trainer.py:27-108) but its OWN training loop: the reference
+subclasses HF `Trainer`, whose 4.10-era hooks (`tokenizer=` kwarg, `compute_loss(model, inputs)`,
+`self.scaler`) no longer exist in the installed transformers, and whose DDP wrapper would put an
+NCCL bucket hook on every HIP backward.  Here one process per MI355X runs
+
+    forward (HIP encoder, tape) -> all-gather of embeddings as cross-device negatives (RCCL) ->
+    fused contrastive loss fwd+bwd -> HIP encoder backward -> ONE flat-bucket gradient all-reduce
+    (mean, over xGMI) -> clip -> AdamW -> linear warm-up/decay schedule
+
+with the reference's loss conventions: the model multiplies the loss by world_size when
+negatives are shared (modeling :124-125), the mean all-reduce divides gradients back, and the
+logged loss is divided by `_dist_loss_scale_factor` (:30,107-108).
+"""
+import logging
+import math
+import os
+from types import SimpleNamespace
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader, IterableDataset
+from transformers.trainer import TRAINING_ARGS_NAME
+from transformers.trainer_pt_utils import IterableDatasetShard
+
+logger = logging.getLogger(__name__)
+
+
+def linear_schedule_factor(step: int, warmup_steps: int, total_steps: int) -> float:
+    """HF `get_linear_schedule_with_warmup`: 0 -> 1 over the warm-up, then 1 -> 0 at total_steps."""
+    if step < warmup_steps:
+        return float(step) / float(max(1, warmup_steps))
+    return max(0.0, float(total_steps - step) / float(max(1, total_steps - warmup_steps)))
+
+
+def parameter_groups(model, weight_decay: float):
+    """HF Trainer's default: no weight decay on biases and LayerNorm weights."""
+    decay, no_decay = [], []
+    seen = set()
+    for name, p in model.named_parameters():
+        if not p.requires_grad or id(p) in seen:
+            continue
+        seen.add(id(p))
+        (no_decay if (name.endswith("bias") or "LayerNorm" in name or "layer_norm" in name) else decay).append(p)
+    return [{"params": decay, "weight_decay": weight_decay}, {"params": no_decay, "weight_decay": 0.0}]
+
+
+def allreduce_mean_(params: List[torch.nn.Parameter], world_size: int, bucket_bytes: int = 256 << 20):
+    """Gradient averaging across ranks = what DistributedDataParallel does for the reference.
+    Gradients are packed into few large flat buckets: xGMI is point-to-point, a ring all-reduce is
+    per-link bound, so per-call latency (not bandwidth) is what many small calls would waste."""
+    grads = [p.grad for p in params if p.grad is not None]
+    bucket, size = [], 0
+
+    def flush():
+        if not bucket:
+            return
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(flat)
+            flat /= world_size
+        off = 0
+        for g in bucket:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+    for g in grads:
+        bucket.append(g)
+        size += g.numel() * g.element_size()
+        if size >= bucket_bytes:
+            flush()
+            bucket, size = [], 0
+    flush()
+
+
+class DRTrainer:
+    def __init__(self, model=None, args=None, data_collator=None, train_dataset=None, eval_dataset=None,
+                 tokenizer=None, callbacks=None, optimizers=(None, None), processing_class=None, **kwargs):
+        self.model = model
+        self.args = args
+        self.data_collator = data_collator
+        self.train_dataset = train_dataset
+        self.eval_dataset = eval_dataset
+        self.tokenizer = tokenizer if tokenizer is not None else processing_class
+        self.callbacks = list(callbacks or [])
+        self.optimizer, self.lr_scheduler = optimizers
+        self.state = SimpleNamespace(epoch=0.0, global_step=0, max_steps=0, log_history=[])
+        xdev = bool(getattr(args, "negatives_x_device", False))
+        self._dist_loss_scale_factor = dist.get_world_size() if xdev else 1
+
+    # ------------------------------------------------------------------ helpers
+    def is_world_process_zero(self) -> bool:
+        return getattr(self.args, "process_index", 0) == 0
+
+    def _world(self):
+        return getattr(self.args, "world_size", 1), getattr(self.args, "process_index", 0)
+
+    def _save(self, output_dir: Optional[str] = None):
+        output_dir = output_dir if output_dir is not None else self.args.output_dir
+        os.makedirs(output_dir, exist_ok=True)
+        logger.info("Saving model checkpoint to %s", output_dir)
+        self.model.save(output_dir)
+        if self.tokenizer is not None:
+            self.tokenizer.save_pretrained(output_dir)
+        torch.save(self.args, os.path.join(output_dir, TRAINING_ARGS_NAME))
+
+    def save_model(self, output_dir: Optional[str] = None):
+        if self.is_world_process_zero():
+            self._save(output_dir)
+
+    def _prepare_inputs(self, inputs: Tuple[Dict[str, Union[torch.Tensor, Any]], ...]) -> List[Dict[str, Any]]:
+        dev = self.args.device
+        out = []
+        for x in inputs:
+            if isinstance(x, torch.Tensor):
+                out.append(x.to(dev, non_blocking=True))
+            else:
+                out.append({k: (v.to(dev, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in x.items()})
+        return out
+
+    def get_train_dataloader(self) -> DataLoader:
+        if self.train_dataset is None:
+            raise ValueError("Trainer: training requires a train_dataset.")
+        ds = self.train_dataset
+        W, r = self._world()
+        per_dev = self.args.per_device_train_batch_size
+        common = dict(collate_fn=self.data_collator, drop_last=False,
+                      num_workers=getattr(self.args, "dataloader_num_workers", 0),
+                      pin_memory=getattr(self.args, "dataloader_pin_memory", True))
+        if isinstance(ds, IterableDataset):
+            if W > 1:      # every rank walks the same stream and keeps its slice of each global batch
+                ds = IterableDatasetShard(ds, batch_size=per_dev, drop_last=False, num_processes=W, process_index=r)
+            return DataLoader(ds, batch_size=per_dev, **common)
+        sampler = None
+        if W > 1:
+            sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=W, rank=r,
+                                                                      seed=getattr(self.args, "seed", 42))
+        return DataLoader(ds, batch_size=per_dev, sampler=sampler, shuffle=sampler is None, **common)
+
+    # ------------------------------------------------------------------ one step
+    def compute_loss(self, model, inputs, return_outputs=False, **_unused):
+        query, passage = inputs
+        outputs = model(query=query, passage=passage)
+        return (outputs.loss, outputs) if return_outputs else outputs.loss
+
+    def _autocast(self):
+        from contextlib import nullcontext
+        if getattr(self.args, "fp16", False) or getattr(self.args, "bf16", False):
+            return torch.autocast("cuda", dtype=torch.bfloat16)     # selects the bf16 MFMA path
+        return nullcontext()
+
+    def training_step(self, model, inputs, *_unused) -> torch.Tensor:
+        model.train()
+        inputs = self._prepare_inputs(inputs)
+        with self._autocast():
+            loss = self.compute_loss(model, inputs)
+        accum = max(1, getattr(self.args, "gradient_accumulation_steps", 1))
+        (loss / accum).backward()
+        return loss.detach() / self._dist_loss_scale_factor
+
+    # ------------------------------------------------------------------ loop
+    def create_optimizer_and_scheduler(self, num_training_steps: int):
+        a = self.args
+        if self.optimizer is None:
+            self.optimizer = torch.optim.AdamW(
+                parameter_groups(self.model, getattr(a, "weight_decay", 0.0)), lr=a.learning_rate,
+                betas=(getattr(a, "adam_beta1", 0.9), getattr(a, "adam_beta2", 0.999)),
+                eps=getattr(a, "adam_epsilon", 1e-8))
+        if self.lr_scheduler is None:
+            warm = getattr(a, "warmup_steps", 0) or math.ceil(num_training_steps * getattr(a, "warmup_ratio", 0.0))
+            self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(
+                self.optimizer, lambda s: linear_schedule_factor(s, warm, num_training_steps))
+
+    def _num_steps(self, loader):
+        a = self.args
+        accum = max(1, getattr(a, "gradient_accumulation_steps", 1))
+        if getattr(a, "max_steps", -1) and a.max_steps > 0:
+            return a.max_steps, None
+        try:
+            per_epoch = max(1, len(loader) // accum)
+        except TypeError:
+            raise ValueError("args.max_steps must be set for a dataset without a length")
+        return int(math.ceil(a.num_train_epochs * per_epoch)), per_epoch
+
+    def train(self, resume_from_checkpoint=None, **_unused):
+        a = self.args
+        W, _ = self._world()
+        self.model.to(a.device)
+        loader = self.get_train_dataloader()
+        total, per_epoch = self._num_steps(loader)
+        self.create_optimizer_and_scheduler(total)
+        self.state.max_steps = total
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        accum = max(1, getattr(a, "gradient_accumulation_steps", 1))
+        log_every = max(1, int(getattr(a, "logging_steps", 500) or 500))
+        save_every = int(getattr(a, "save_steps", 0) or 0)
+        running, micro, epoch = 0.0, 0, 0
+        self.optimizer.zero_grad(set_to_none=True)
+        while self.state.global_step < total:
+            if hasattr(self.train_dataset, "set_epoch"):
+                self.train_dataset.set_epoch(epoch)
+            if hasattr(getattr(loader, "sampler", None), "set_epoch"):
+                loader.sampler.set_epoch(epoch)
+            stepped = False
+            for batch in loader:
+                running += float(self.training_step(self.model, batch))
+                micro += 1
+                if micro % accum:
+                    continue
+                if W > 1:
+                    allreduce_mean_(params, W)
+                max_norm = getattr(a, "max_grad_norm", 0.0)
+                if max_norm and max_norm > 0:
+                    torch.nn.utils.clip_grad_norm_(params, max_norm)
+                self.optimizer.step()
+                self.lr_scheduler.step()
+                self.optimizer.zero_grad(set_to_none=True)
+                self.state.global_step += 1
+                stepped = True
+                self.state.epoch = (self.state.global_step / per_epoch) if per_epoch else float(epoch)
+                if self.state.global_step % log_every == 0:
+                    entry = {"loss": running / (log_every * accum), "learning_rate": self.lr_scheduler.get_last_lr()[0],
+                             "epoch": self.state.epoch, "step": self.state.global_step}
+                    self.state.log_history.append(entry)
+                    if self.is_world_process_zero():
+                        logger.info("%s", entry)
+                    running = 0.0
+                if save_every and self.state.global_step % save_every == 0 and self.is_world_process_zero():
+                    self._save(os.path.join(a.output_dir, f"checkpoint-{self.state.global_step}"))
+                if self.state.global_step >= total:
+                    break
+            epoch += 1
+            if not stepped:
+                raise ValueError("the training dataloader produced no batches")
+        return SimpleNamespace(global_step=self.state.global_step, training_loss=running)
+
+
+def split_dense_inputs(model_input: dict, chunk_size: int):
+    """{"query": {k: [B,...]}} -> list of {"query": {k: [chunk,...]}} (reference :111-120)."""
+    assert len(model_input) == 1
+    (arg_key, arg_val), = model_input.items()
+    keys = list(arg_val.keys())
+    pieces = zip(*[arg_val[k].split(chunk_size, dim=0) for k in keys])
+    return [{arg_key: dict(zip(keys, piece))} for piece in pieces]
+
+
+def get_dense_rep(x):
+    return x.p_reps if x.q_reps is None else x.q_reps
+
+
+class GCDenseTrainer(DRTrainer):
+    """Gradient-cache variant (reference :130-160, via the un-vendored `grad_cache` package):
+    representations are computed chunk by chunk without a tape, the contrastive loss and its
+    gradient w.r.t. every representation are computed once on the full (all-gathered) batch, then
+    each chunk is re-encoded WITH the tape and back-propagated with its cached representation
+    gradient.  Mathematically identical to the full-batch step, peak activation memory is one chunk."""
+
+    def training_step(self, model, inputs, *_unused) -> torch.Tensor:
+        from ..ops import contrastive_loss
+        model.train()
+        queries, passages = self._prepare_inputs(inputs)
+        a = self.args
+        q_chunks = split_dense_inputs({"query": queries}, a.gc_q_chunk_size)
+        p_chunks = split_dense_inputs({"passage": passages}, a.gc_p_chunk_size)
+        xdev = bool(getattr(a, "negatives_x_device", False))
+        with self._autocast():
+            # dropout must repeat between the two passes: fix the generator state per chunk
+            states = []
+            with torch.no_grad():
+                reps = []
+                for ch in q_chunks + p_chunks:
+                    states.append(torch.random.get_rng_state())
+                    reps.append(get_dense_rep(model(**ch)))
+            nq = len(q_chunks)
+            q_reps = torch.cat(reps[:nq]).requires_grad_()
+            p_reps = torch.cat(reps[nq:]).requires_grad_()
+            if xdev:
+                q_all, p_all = model.dist_gather_tensor(q_reps), model.dist_gather_tensor(p_reps)
+                q0, p0 = model.process_rank * q_reps.shape[0], model.process_rank * p_reps.shape[0]
+                scale = float(model.world_size)
+            else:
+                q_all, p_all, q0, p0, scale = q_reps, p_reps, 0, 0, 1.0
+            n_psg = p_all.shape[0] // q_all.shape[0]
+            loss, _ = contrastive_loss(q_all, p_all, n_psg, scale, q_reps, q0, p_reps, p0)
+            loss.backward()
+            grads = list(q_reps.grad.split(a.gc_q_chunk_size)) + list(p_reps.grad.split(a.gc_p_chunk_size))
+            for ch, st, gr in zip(q_chunks + p_chunks, states, grads):
+                torch.random.set_rng_state(st)
+                get_dense_rep(model(**ch)).backward(gr)
+        return loss.detach() / self._dist_loss_scale_factor
