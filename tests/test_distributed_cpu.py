@@ -1,0 +1,146 @@
+"""CPU, 2 processes over gloo: the multi-rank host logic (query all-gather, shard offsets, per-shard
+top-k gather + merge, cross-device negatives, gradient averaging).  The per-shard search and the
+merge are HIP on a GPU box; here they are swapped for the CPU oracle so the ORCHESTRATION is what
+is under test (the kernels themselves are covered by the -m gpu tests)."""
+import os
+import pickle
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.helpers import NS
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _OracleShard:
+    """FlatIPIndex stand-in with the same methods, backed by oracle/flatip.py."""
+
+    def __init__(self, d, device=None, precision=None):
+        from oracle import flatip
+        self.d, self._idx = d, flatip.IndexFlatIP(d)
+
+    ntotal = property(lambda self: self._idx.ntotal)
+
+    def add(self, x):
+        self._idx.add(x.cpu().numpy() if isinstance(x, torch.Tensor) else x)
+
+    def search_device(self, queries, k, id_offset=0):
+        D, I = self._idx.search(queries.cpu().numpy(), k)
+        I = np.where(I >= 0, I + id_offset, -1)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+    def search(self, x, k):
+        return self._idx.search(x, k)
+
+
+def _merge_cpu(ps, pi, k_out):
+    W, Q, k = ps.shape
+    flat_s = ps.permute(1, 0, 2).reshape(Q, W * k)
+    flat_i = pi.permute(1, 0, 2).reshape(Q, W * k)
+    flat_s = torch.where(flat_i >= 0, flat_s, torch.full_like(flat_s, -3.4e38))
+    order = torch.sort(flat_s, dim=1, descending=True, stable=True).indices[:, :k_out]
+    return torch.gather(flat_s, 1, order), torch.gather(flat_i, 1, order)
+
+
+def _search_worker(rank, world, port, tmp, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import openmatch_amd.retriever.dense_retriever as R
+    R.FlatIPIndex, R.merge_topk = _OracleShard, _merge_cpu
+    args = NS(device="cpu", output_dir=tmp, world_size=world, process_index=rank, local_process_index=rank, fp16=False)
+    retriever = R.Retriever.from_embeddings(torch.nn.Linear(1, 1), args)        # sharded: rank r loads file r
+    assert retriever._sharded and retriever.index.ntotal == 500
+    result = retriever.search(100)
+    if rank == 0:
+        out_q.put(result)
+    else:
+        assert result == {}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_search_equals_single_index(tmp_path, golden):
+    from oracle import flatip, retrieval_ref
+    g = golden("retrieval_1k")
+    doc_ids, qry_ids = list(g["doc_ids"]), list(g["qry_ids"])
+    for r in range(2):
+        with open(tmp_path / f"embeddings.corpus.rank.{r}", "wb") as f:
+            pickle.dump((g["P"][r * 500:(r + 1) * 500], doc_ids[r * 500:(r + 1) * 500]), f, protocol=4)
+        with open(tmp_path / f"embeddings.query.rank.{r}", "wb") as f:
+            pickle.dump((g["Q"][r * 50:(r + 1) * 50], qry_ids[r * 50:(r + 1) * 50]), f, protocol=4)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_search_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    [p.start() for p in procs]
+    result = q.get(timeout=180)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    single = flatip.IndexFlatIP(768); single.add(g["P"])
+    D, I = single.search(g["Q"], 100)
+    want = retrieval_ref.search_to_dict(D, I, doc_ids, qry_ids)
+    assert list(result) == list(want)
+    for qid in want:
+        assert list(result[qid]) == list(want[qid])                      # same ids, same order
+        assert np.allclose(list(result[qid].values()), list(want[qid].values()), atol=1e-6)
+
+
+def _train_worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from openmatch.modeling import DRModel
+    from openmatch_amd.trainer.dense_trainer import allreduce_mean_
+    from oracle import retrieval_ref
+    model = DRModel(lm_q=torch.nn.Linear(1, 1), lm_p=torch.nn.Linear(1, 1),
+                    train_args=NS(negatives_x_device=True, per_device_train_batch_size=2))
+    assert (model.process_rank, model.world_size) == (rank, world)
+    torch.manual_seed(rank)
+    t = torch.randn(2, 8, requires_grad=True)
+    gathered = model.dist_gather_tensor(t)
+    assert gathered.shape == (4, 8) and torch.equal(gathered[rank * 2:(rank + 1) * 2], t)
+    gathered.sum().backward()
+    assert torch.equal(t.grad, torch.ones_like(t))                          # gradient only through the local slot
+    parts = [torch.randn(2, 8, generator=torch.Generator().manual_seed(r)) for r in range(world)]
+    assert torch.allclose(gathered.detach(), torch.cat(parts))              # rank-major order
+    # gradient averaging == DDP mean
+    p = torch.nn.Parameter(torch.zeros(3)); p.grad = torch.full((3,), float(rank + 1))
+    allreduce_mean_([p], world)
+    assert torch.allclose(p.grad, torch.full((3,), 1.5))
+    # loss convention: every rank computes world * mean-CE over the gathered batch; after the mean
+    # all-reduce the parameter gradient equals that of the plain global mean-CE
+    qs = [torch.randn(2, 8, generator=torch.Generator().manual_seed(10 + r)) for r in range(world)]
+    ps = [torch.randn(4, 8, generator=torch.Generator().manual_seed(20 + r)) for r in range(world)]
+    ql, pl = qs[rank].clone().requires_grad_(), ps[rank].clone().requires_grad_()
+    qa = retrieval_ref.gather_with_local_grad([ql if r == rank else qs[r] for r in range(world)], rank)
+    pa = retrieval_ref.gather_with_local_grad([pl if r == rank else ps[r] for r in range(world)], rank)
+    loss, _ = retrieval_ref.contrastive_loss(qa, pa, 2, scale=float(world))
+    loss.backward()
+    qf, pf = torch.cat(qs).requires_grad_(), torch.cat(ps).requires_grad_()
+    full, _ = retrieval_ref.contrastive_loss(qf, pf, 2)
+    full.backward()
+    assert torch.allclose(ql.grad / world, qf.grad[rank * 2:(rank + 1) * 2], atol=1e-6)
+    assert torch.allclose(pl.grad / world, pf.grad[rank * 4:(rank + 1) * 4], atol=1e-6)
+    out_q.put((rank, float(loss)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cross_device_negatives_and_gradient_averaging():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = dict(q.get(timeout=180) for _ in range(2))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert got[0] == pytest.approx(got[1], abs=1e-6)                         # identical loss on every rank

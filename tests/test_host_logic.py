@@ -1,0 +1,199 @@
+"""CPU: host-side logic of the reference-shaped API (no kernels run here)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import REPO
+from tests.helpers import NS, tiny_bert_config
+
+
+def test_trec_roundtrip_templates_and_merge(tmp_path, golden):
+    from openmatch.utils import (eval_mrr, fill_template, find_all_markers, load_from_trec,
+                                 merge_retrieval_results_by_score, save_as_trec)
+    g = golden("retrieval_1k")
+    run = {q: {g["doc_ids"][i]: float(s) for i, s in zip(g["I"][j], g["D"][j])} for j, q in enumerate(g["qry_ids"])}
+    path = tmp_path / "run.trec"
+    save_as_trec(run, str(path))
+    assert path.read_text() == str(g["trec"])                      # byte-identical to the reference's writer
+    back = load_from_trec(str(path))
+    assert back.keys() == run.keys() and all(list(back[q]) == list(run[q]) for q in run)
+    assert len(load_from_trec(str(path), max_len_per_q=7)["Q3"]) == 7
+    assert load_from_trec(str(path), as_list=True)["Q0"][0][0] == list(run["Q0"])[0]
+    qrel = {q: {d: 1} for q, d in zip(g["qry_ids"], g["qrel_docs"])}
+    assert eval_mrr(qrel, back, cutoff=10)["all"] == pytest.approx(float(g["mrr10"]), abs=1e-12)
+    halves = [{q: dict(list(h.items())[:60]) for q, h in run.items()}, {q: dict(list(h.items())[40:]) for q, h in run.items()}]
+    merged = merge_retrieval_results_by_score(halves, 50)
+    assert [" ".join(merged[q]) for q in g["qry_ids"]] == list(g["merged_keys"])
+    assert find_all_markers("Title: <title> Text: <text>") == ["title", "text"]
+    assert fill_template("<a.b>-<c>", {"a": {"b": 1}, "c": "x"}) == "1-x"
+    with pytest.raises(ValueError, match="Cannot find the marker"):
+        fill_template("<zz>", {})
+    with pytest.warns(RuntimeWarning):
+        assert fill_template("[<zz>]", {}, allow_not_found=True) == "[]"
+    (tmp_path / "bad").write_text("a b\n")
+    with pytest.raises(ValueError, match="Invalid run format"):
+        load_from_trec(str(tmp_path / "bad"))
+
+
+def test_argument_dataclasses_keep_reference_names_and_defaults():
+    from dataclasses import fields
+    from transformers import HfArgumentParser
+    from openmatch.arguments import DataArguments, DRTrainingArguments, InferenceArguments, ModelArguments
+    d = {f.name: f.default for f in fields(DataArguments)}
+    assert (d["q_max_len"], d["p_max_len"], d["train_n_passages"], d["doc_template"]) == (32, 128, 8, "Title: <title> Text: <text>")
+    m = {f.name: f.default for f in fields(ModelArguments)}
+    assert (m["pooling"], m["feature"], m["normalize"], m["projection_in_dim"], m["encoder_only"]) == ("first", "last_hidden_state", False, 768, False)
+    parser = HfArgumentParser((ModelArguments, DataArguments, InferenceArguments))
+    ma, da, ia = parser.parse_args_into_dataclasses(["--model_name_or_path", "x", "--output_dir", "/tmp/o", "--use_gpu",
+                                                     "--q_max_len", "16", "--pooling", "mean"])
+    assert ma.pooling == "mean" and da.q_max_len == 16 and ia.use_gpu is True
+    t = {f.name: f.default for f in fields(DRTrainingArguments)}
+    assert t["warmup_ratio"] == 0.1 and t["negatives_x_device"] is False and t["gc_p_chunk_size"] == 32
+
+
+def test_weight_packing_layout_matches_hf_module():
+    """Packed device weights: q|k|v concatenated [3H,H], biases f32, matrices in the compute dtype."""
+    from transformers import BertModel
+    from openmatch_amd import native as N
+    from openmatch_amd.encoder import packed_weights
+    from openmatch.modeling import LinearHead
+    lm = BertModel(tiny_bert_config()).eval()
+    head = LinearHead(128, 64)
+    pk = packed_weights(lm, head, N.OM_BF16, torch.device("cpu"))
+    assert pk.cfg["hidden"] == 128 and pk.cfg["n_layers"] == 2 and pk.cfg["head_out"] == 64 and pk.cfg["act"] == N.ACT_GELU_ERF
+    qkv = [t for t in pk.keep if tuple(t.shape) == (384, 128)]
+    assert len(qkv) == 2 and qkv[0].dtype == torch.bfloat16
+    at = lm.encoder.layer[0].attention.self
+    want = torch.cat([at.query.weight, at.key.weight, at.value.weight]).to(torch.bfloat16)
+    assert torch.equal(qkv[0], want)
+    assert pk.layers[0].qkv_w == qkv[0].data_ptr()
+    assert packed_weights(lm, head, N.OM_BF16, torch.device("cpu")) is pk           # cached
+    with torch.no_grad():
+        at.query.weight.add_(1.0)                                                  # in-place update bumps _version
+    assert packed_weights(lm, head, N.OM_BF16, torch.device("cpu")) is not pk       # repacked after an optimizer step
+
+
+def test_model_save_build_roundtrip_and_config(tmp_path):
+    from transformers import BertModel
+    from openmatch.modeling import DRModel, LinearHead
+    lm = BertModel(tiny_bert_config())
+    head = LinearHead(128, 128)
+    model = DRModel(lm_q=lm, lm_p=lm, pooling="mean", head_q=head, head_p=head, normalize=True)
+    out = tmp_path / "ckpt"; out.mkdir()
+    model.save(str(out))
+    assert sorted(os.listdir(out)) == sorted(["config.json", "model.safetensors", "linear.pt", "head_config.json", "openmatch_config.json"])
+    cfg = model._get_config_dict()
+    assert cfg == {"tied": True, "plm_backbone": {"type": "BertModel", "feature": "last_hidden_state"},
+                   "pooling": "mean", "linear_head": True, "normalize": True}
+    back = DRModel.build(NS(model_name_or_path=str(out), encoder_only=False, untie_encoder=False, add_linear_head=False,
+                            feature="x", pooling="first", normalize=False, projection_in_dim=1, projection_out_dim=1))
+    assert back.pooling == "mean" and back.normalize and back.tied and back.lm_q is back.lm_p
+    assert torch.equal(back.head_q.linear.weight, head.linear.weight)
+    assert torch.equal(back.lm_q.embeddings.word_embeddings.weight, lm.embeddings.word_embeddings.weight)
+    # untied layout
+    import copy
+    m2 = DRModel(lm_q=lm, lm_p=copy.deepcopy(lm), tied=False)
+    out2 = tmp_path / "untied"; out2.mkdir()
+    m2.save(str(out2))
+    assert {"query_model", "passage_model", "openmatch_config.json"} <= set(os.listdir(out2))
+    with pytest.raises(ValueError, match="Distributed training has not been initialized"):
+        DRModel(lm_q=lm, lm_p=lm, train_args=NS(negatives_x_device=True))
+
+
+class _FakeEncoder(torch.nn.Module):
+    """Stands in for the HIP encoder so the CPU suite can walk the Retriever's loops."""
+
+    def forward(self, query=None, passage=None):
+        from openmatch.modeling import DROutput
+        x = query if query is not None else passage
+        reps = torch.nn.functional.one_hot(x["input_ids"][:, 0] % 8, 8).float() + 0.01 * x["input_ids"][:, 1:2].float()
+        return DROutput(q_reps=reps if query is not None else None, p_reps=reps if passage is not None else None)
+
+
+def test_retriever_encoding_loop_writes_reference_pickles(tmp_path):
+    from openmatch.retriever import Retriever
+    rows = [{"text_id": f"d{i}", "input_ids": [i, i + 1, 0], "attention_mask": [1, 1, 0]} for i in range(10)]
+    args = NS(device="cpu", output_dir=str(tmp_path), world_size=1, process_index=0, local_process_index=0, fp16=False,
+              per_device_eval_batch_size=4, dataloader_num_workers=0, dataloader_pin_memory=False)
+    r = Retriever(_FakeEncoder(), rows, args)
+    r.doc_embedding_inference()
+    with open(tmp_path / "embeddings.corpus.rank.0", "rb") as f:
+        enc, ids = pickle.load(f)
+    assert isinstance(enc, np.ndarray) and enc.dtype == np.float32 and enc.shape == (10, 8) and ids == [f"d{i}" for i in range(10)]
+    r.query_embedding_inference(rows[:3])
+    with open(tmp_path / "embeddings.query.rank.0", "rb") as f:
+        qenc, qids = pickle.load(f)
+    assert qenc.shape == (3, 8) and qids == ["d0", "d1", "d2"]
+    with pytest.raises(ValueError, match="No corpus dataset provided"):
+        Retriever(_FakeEncoder(), None, args).doc_embedding_inference()
+    with pytest.raises(ValueError, match="Index is not initialized"):
+        Retriever(_FakeEncoder(), None, args).search(5)
+    # -1 padding maps to the LAST doc, as numpy fancy indexing does in the reference
+    r.doc_lookup, r.query_lookup = ids, ["q"]
+    hits = r._hits_to_dict(np.array([[0.5, -3.4e38]], np.float32), np.array([[2, -1]]), 2)
+    assert list(hits["q"]) == ["d2", "d9"]
+
+
+def test_trainer_schedule_param_groups_and_sharded_loader():
+    from openmatch_amd.trainer.dense_trainer import DRTrainer, linear_schedule_factor, parameter_groups, split_dense_inputs
+    from transformers import BertModel
+    assert [linear_schedule_factor(s, 10, 100) for s in (0, 5, 10, 100)] == [0.0, 0.5, 1.0, 0.0]
+    lm = BertModel(tiny_bert_config())
+    decay, no_decay = parameter_groups(lm, 0.01)
+    assert decay["weight_decay"] == 0.01 and no_decay["weight_decay"] == 0.0
+    n_all = sum(1 for _ in lm.parameters())
+    assert len(decay["params"]) + len(no_decay["params"]) == n_all
+    assert all(p.dim() == 1 for p in no_decay["params"])
+
+    class Stream(torch.utils.data.IterableDataset):
+        def __iter__(self):
+            return iter(range(16))
+    seen = []
+    for rank in range(2):
+        args = NS(world_size=2, process_index=rank, per_device_train_batch_size=2, dataloader_num_workers=0,
+                  dataloader_pin_memory=False, negatives_x_device=False)
+        t = DRTrainer(model=None, args=args, train_dataset=Stream(), data_collator=lambda b: b)
+        seen.append([x for b in t.get_train_dataloader() for x in b])
+    assert seen[0] == [0, 1, 4, 5, 8, 9, 12, 13] and seen[1] == [2, 3, 6, 7, 10, 11, 14, 15]   # reference interleave
+    chunks = split_dense_inputs({"query": {"input_ids": torch.arange(10).view(5, 2), "attention_mask": torch.ones(5, 2)}}, 2)
+    assert [c["query"]["input_ids"].shape[0] for c in chunks] == [2, 2, 1]
+
+
+def test_no_kernel_spills_to_scratch():
+    """Accumulators in scratch cost 5-7x (seen once with a lambda capture): keep every kernel of the
+    library at private_segment_fixed_size == 0, except the two L<=256 attention variants."""
+    import re
+    import subprocess
+    from openmatch_amd import native as N
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not available")
+    # the device code sits in the library as a clang offload bundle: magic, count, then
+    # (offset, size, triple-size, triple) records relative to the magic
+    import struct
+    blob = open(N.LIB_PATH, "rb").read()
+    os.makedirs(os.path.join(REPO, "build"), exist_ok=True)
+    kernels, base = {}, blob.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    while base >= 0:                                   # one bundle per translation unit
+        (count,) = struct.unpack_from("<Q", blob, base + 24)
+        pos = base + 32
+        for _ in range(count):
+            off, size, tlen = struct.unpack_from("<QQQ", blob, pos)
+            triple = blob[pos + 24:pos + 24 + tlen].decode()
+            pos += 24 + tlen
+            if "gfx950" in triple and size:
+                co = os.path.join(REPO, "build", "device_gfx950.co")
+                open(co, "wb").write(blob[base + off:base + off + size])
+                notes = subprocess.run([readelf, "--notes", co], capture_output=True, text=True).stdout
+                syms = re.findall(r"\.symbol:\s+(\S+)\.kd", notes)
+                scratch = re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)
+                assert len(syms) == len(scratch)
+                kernels.update(zip(syms, map(int, scratch)))
+        base = blob.find(b"__CLANG_OFFLOAD_BUNDLE__", base + 1)
+    assert len(kernels) > 60, len(kernels)
+    # known exceptions: the L > 128 attention instantiations (KT = 6, 8) hold up to 128 score registers
+    bad = {k: v for k, v in kernels.items() if v > 0 and not ("attention_kernelI" in k and ("Li8E" in k or "Li6E" in k))}
+    assert not bad, bad
