@@ -174,10 +174,18 @@ def main():
     lib.om_kernel_timing_enable(0)
     gemm_tflops = flops.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
     peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else 157.3
+    traffic = None        # HBM bytes per launch of the dominant kernel, from the committed PMC passes
+    tpath = os.path.join(REPO, "profiles", "r01_hbm_traffic.json")
+    if a.precision == "bf16" and a.batch == 1024 and os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
     roofline = {
         "kernel": "gemm_nt_kernel<%s> (encoder QKV / out-proj / FFN contractions)" % a.precision,
         "bound": "mfma", "achieved": round(gemm_tflops, 1), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(gemm_tflops / peak, 4), "traffic": None,
+        "frac": round(gemm_tflops / peak, 4), "traffic": traffic,
+        "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH doubled per the gfx950 note)" if traffic else None,
         "launches": int(n_launch.value), "avg_launch_us": round(ms.value * 1e3 / max(n_launch.value, 1), 2),
         "flops_per_launch": flops.value / max(n_launch.value, 1),
         "measured": "hipEvents around every launch of the kernel on its stream, second pass of the same K steps",

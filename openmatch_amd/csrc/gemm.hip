@@ -14,6 +14,7 @@
 
 #include "gemm_core2.h"
 #include "gemm_core3.h"
+#include "gemm_core4.h"
 #include "kernels.h"
 
 // erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): ~15 instructions instead of erff's ~60.
@@ -278,6 +279,37 @@ __global__ __launch_bounds__(G3_THREADS) void gemm_nt_kernel3(
   if (tr && threadIdx.x == 0) { tr[28] = clock64(); tr[29] = blockIdx.x; }
 }
 
+// ---- v4: 256x256 tile, 4-deep ring of 64-byte K steps (gemm_core4.h) -------------------------------
+template <typename T, typename OutT>
+__global__ __launch_bounds__(G4_THREADS) void gemm_nt_kernel4(
+    const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, OutT* C,
+    int64_t ldc, int64_t M, int64_t N, int64_t K, GemmEpilogue ep, int group_m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int64_t m0, n0;
+  g4_tile_coords(M, N, group_m, m0, n0);
+  f32x16_t acc[4][2];
+  unsigned long long* tr = ep.trace ? ep.trace + (size_t)blockIdx.x * 32 : nullptr;
+  if (tr && threadIdx.x == 0) tr[0] = clock64();
+  gemm_mainloop4<T>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, tr);   // ends on a barrier
+  if (tr && threadIdx.x == 0) tr[15] = clock64();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const EpiScalars es(ep);
+  const int64_t nc = n0 + wn * 64;
+  const float b0 = (ep.bias && nc + (lane & 31) < N) ? ep.bias[nc + (lane & 31)] : 0.f;
+  const float b1 = (ep.bias && nc + 32 + (lane & 31) < N) ? ep.bias[nc + 32 + (lane & 31)] : 0.f;
+  char* region = smem + wave * (32 * PATCH_STRIDE);
+#define OM_V4_CALL(A, TR)                                                                                        \
+  store_patch<OutT, A, TR>(acc[0][0], acc[0][1], b0, b1, m0 + wm * 128, nc, C, ldc, M, N, ep, es, region);        \
+  store_patch<OutT, A, TR>(acc[1][0], acc[1][1], b0, b1, m0 + wm * 128 + 32, nc, C, ldc, M, N, ep, es, region);   \
+  store_patch<OutT, A, TR>(acc[2][0], acc[2][1], b0, b1, m0 + wm * 128 + 64, nc, C, ldc, M, N, ep, es, region);   \
+  store_patch<OutT, A, TR>(acc[3][0], acc[3][1], b0, b1, m0 + wm * 128 + 96, nc, C, ldc, M, N, ep, es, region)
+  OM_EPI_SWITCH(es.act, es.train, OM_V4_CALL)
+#undef OM_V4_CALL
+  if (tr && threadIdx.x == 0) { tr[28] = clock64(); tr[29] = blockIdx.x; }
+}
+
 // ---- launchers -------------------------------------------------------------------------------------
 #define OM_DEFINE_LAUNCHER(NAME, KERNEL, THREADS, LDS, BMV, BNV)                                        \
   template <typename T, typename OutT>                                                                  \
@@ -303,6 +335,7 @@ __global__ __launch_bounds__(G3_THREADS) void gemm_nt_kernel3(
 OM_DEFINE_LAUNCHER(launch_gemm, gemm_nt_kernel, GEMM_THREADS, GEMM_LDS_BYTES, GEMM_BM, GEMM_BN)
 OM_DEFINE_LAUNCHER(launch_gemm2, gemm_nt_kernel2, G2_THREADS, G2_LDS_BYTES, G2_BM, G2_BN)
 OM_DEFINE_LAUNCHER(launch_gemm3, gemm_nt_kernel3, G3_THREADS, G3_LDS_BYTES, G3_BM, G3_BN)
+OM_DEFINE_LAUNCHER(launch_gemm4, gemm_nt_kernel4, G4_THREADS, G4_LDS_BYTES, G4_BM, G4_BN)
 
 static int gemm_variant() {     // OM_GEMM_VARIANT=1|2|3 pins a kernel generation (A/B measurements)
   static const int v = getenv("OM_GEMM_VARIANT") ? atoi(getenv("OM_GEMM_VARIANT")) : 0;
@@ -334,9 +367,11 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) OM_FAIL("A/B must be 16-byte aligned");
   if ((ep.act & 0xff) == OM_ACT_GELU_ERF_GRAD && !ep.resid) OM_FAIL("gelu-grad epilogue needs resid");
   const bool wide = wide_ok(out_dtype, C, ldc, M, N, ep);
-  const int gen = !wide ? 1 : ((N >= 256 && gemm_variant() != 2) ? 3 : 2);
+  int gen = !wide ? 1 : ((N >= 256 && gemm_variant() != 2) ? 4 : 2);
+  if (gen == 4 && (gemm_variant() == 3 || (K * es) % 128 != 0)) gen = 3;
 #define OM_GEMM_GO(TI, TO)                                                                            \
   do {                                                                                                \
+    if (gen == 4) return launch_gemm4<TI, TO>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);                 \
     if (gen == 3) return launch_gemm3<TI, TO>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);                 \
     if (gen == 2) return launch_gemm2<TI, TO>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);                 \
     return launch_gemm<TI, TO>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);                                \

@@ -1,10 +1,10 @@
 #!/bin/bash
-# rocprofv3 PMC passes over the native GEMM micro-benchmark (run on the GPU box from the repo root)
+# Round profile of bench.py on the GPU box (run from the repo root):
+#   1. kernel-trace stats of the default bench command
+#   2. PMC passes (each in its own run, kernel-trace only) for the HBM traffic of the dominant kernel
 R=$PWD; cd /tmp; export TMPDIR=/tmp
-run() { name=$1; shift; timeout 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_$name -- $R/build/selftest prof > $R/gpurun_out/pmc_$name.log 2>&1; }
-run sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16
-run fetch FETCH_SIZE
-run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
-run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL GRBM_GUI_ACTIVE
-run write WRITE_SIZE
-cd $R; ls gpurun_out/pmc_*/*/ 2>/dev/null | head -30
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_stats.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/prof_$c -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-search > $R/gpurun_out/prof_$c.log 2>&1
+done
+cd $R; ls gpurun_out/prof_*/*/ | head -20
