@@ -169,10 +169,10 @@ int om_encoder_forward(const OmEncoderConfig* cfg, const OmEncoderWeights* w,
  * `loss.backward()` through it (trainer/dense_trainer.py:102-108).
  *
  * The forward saves one "tape" of activations (caller-provided memory); dropout masks are
- * regenerated from (seed, element index) in the backward, never stored.  Gradients are written
- * (not accumulated) into caller-provided f32 buffers laid out like the weights; buffers that
- * are reduced with atomics (LayerNorm gamma/beta, biases, embedding tables) must be ZEROED by
- * the caller before the call.
+ * regenerated from (seed, element index) in the backward, never stored.  Gradients are ADDED
+ * (f32 atomics: split-K weight gradients, bias / LayerNorm / embedding reductions) into
+ * caller-provided f32 buffers laid out like the weights; ZERO them before the call (or pass the
+ * same buffers to several calls to accumulate).
  * ------------------------------------------------------------------------ */
 typedef struct OmLayerGrads {
   float* qkv_w;  float* qkv_b;  float* o_w;    float* o_b;   float* ln1_g; float* ln1_b;

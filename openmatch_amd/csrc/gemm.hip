@@ -218,6 +218,37 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(
 #undef OM_V1_CALL
 }
 
+// ---- split-K: C (f32, zero-initialised by the caller) += A[:, ks] · B[:, ks]^T per K slice --------
+// Weight-gradient contractions have a long K (the token count) and a small output (768 x 768 is
+// 9 tiles of 256^2): slicing K over blockIdx.y fills the chip; partial sums meet in f32 atomics.
+template <typename T>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_splitk_kernel(
+    const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, float* __restrict__ C,
+    int64_t ldc, int64_t M, int64_t N, int64_t K, int steps_per_slice) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int64_t ntn = (N + GEMM_BN - 1) / GEMM_BN;
+  const int64_t m0 = (blockIdx.x / ntn) * GEMM_BM, n0 = (blockIdx.x % ntn) * GEMM_BN;
+  f32x16_t acc[2][2];
+  gemm_mainloop<T>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc,
+                   (int64_t)blockIdx.y * steps_per_slice * GEMM_ROW_BYTES, steps_per_slice);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int64_t n = n0 + wn * 64 + ni * 32 + (lane & 31);
+    if (n >= N) continue;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int64_t mbase = m0 + wm * 64 + mi * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = mbase + (r & 3) + 8 * (r >> 2);
+        if (m < M) atomicAdd(C + m * ldc + n, acc[mi][ni][r]);
+      }
+    }
+  }
+}
+
 // ---- v2: 256x128 tile, 3-deep LDS ring -----------------------------------------------------------
 template <typename T, typename OutT>
 __global__ __launch_bounds__(G2_THREADS) void gemm_nt_kernel2(
@@ -383,6 +414,37 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
   if (in_dtype == OM_F32 && out_dtype == OM_BF16) return launch_gemm<float, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
 #undef OM_GEMM_GO
   OM_FAIL("unsupported dtype combination");
+}
+
+int omk_gemm_splitk(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C,
+                    int64_t ldc, int64_t M, int64_t N, int64_t K, hipStream_t s) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int64_t es = in_dtype == OM_F32 ? 4 : 2;
+  if ((K * es) % GEMM_ROW_BYTES != 0) OM_FAIL("K*sizeof(elem) must be a multiple of 128 bytes");
+  const int64_t tiles = ((M + GEMM_BM - 1) / GEMM_BM) * ((N + GEMM_BN - 1) / GEMM_BN);
+  const int nk = (int)(K * es / GEMM_ROW_BYTES);
+  int slices = (int)((1024 + tiles - 1) / tiles);          // aim at ~4 workgroups per CU
+  if (slices > nk / 4) slices = nk / 4 > 0 ? nk / 4 : 1;   // but at least 4 K steps per slice
+  const int per = (nk + slices - 1) / slices;
+  slices = (nk + per - 1) / per;
+  static bool attr_bf16 = false, attr_f32 = false;
+  const bool timing = om_timing_on();
+  const int tclass = es == 2 ? OM_TIMING_GEMM_BF16 : OM_TIMING_GEMM_F32;
+  if (timing) om_timing_begin(tclass, s);
+  if (in_dtype == OM_BF16) {
+    if (!attr_bf16) { OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_splitk_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES)); attr_bf16 = true; }
+    hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16_t>), dim3((unsigned)tiles, slices), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s,
+                       (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, per);
+  } else if (in_dtype == OM_F32) {
+    if (!attr_f32) { OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_splitk_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES)); attr_f32 = true; }
+    hipLaunchKernelGGL((gemm_nt_splitk_kernel<float>), dim3((unsigned)tiles, slices), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s,
+                       (const float*)A, lda, (const float*)B, ldb, C, ldc, M, N, K, per);
+  } else {
+    OM_FAIL("unsupported dtype");
+  }
+  if (timing) om_timing_end(tclass, s, 2.0 * (double)M * (double)N * (double)K);
+  OM_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int om_gemm_nt(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb,

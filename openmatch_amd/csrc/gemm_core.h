@@ -82,7 +82,7 @@ template <typename T>
 __device__ inline void gemm_mainloop(const T* __restrict__ A, int64_t lda,
                                      const T* __restrict__ B, int64_t ldb, int64_t M, int64_t N,
                                      int64_t K, int64_t m0, int64_t n0, char* smem,
-                                     f32x16_t (&acc)[2][2]) {
+                                     f32x16_t (&acc)[2][2], int64_t kbyte0 = 0, int nk_limit = -1) {
   typedef typename MmaOps<T>::frag_t frag_t;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -110,20 +110,21 @@ __device__ inline void gemm_mainloop(const T* __restrict__ A, int64_t lda,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  const int nk = (int)((K * (int64_t)sizeof(T)) / GEMM_ROW_BYTES);
+  int nk = (int)((K * (int64_t)sizeof(T) - kbyte0) / GEMM_ROW_BYTES);   // K range [kbyte0, kbyte0 + nk*128)
+  if (nk_limit >= 0 && nk > nk_limit) nk = nk_limit;
   const int key = (lane >> 1) & 7;   // == ((row>>1)&7) for row = 32*x + (lane&31)
   const int half = lane >> 5;
   const int rowa = (wm * 64 + (lane & 31)) * GEMM_ROW_BYTES;
   const int rowb = (wn * 64 + (lane & 31)) * GEMM_ROW_BYTES;
 
-  gemm_stage(pa, pb, 0, smem, wave);
+  gemm_stage(pa, pb, (size_t)kbyte0, smem, wave);
   __syncthreads();  // drains the DMA (vmcnt(0)) and publishes stage 0
 
   for (int t = 0; t < nk; ++t) {
     char* cur = smem + (t & 1) * GEMM_STAGE_BYTES;
     if (t + 1 < nk)
-      gemm_stage(pa, pb, (size_t)(t + 1) * GEMM_ROW_BYTES, smem + ((t + 1) & 1) * GEMM_STAGE_BYTES,
-                 wave);
+      gemm_stage(pa, pb, (size_t)kbyte0 + (size_t)(t + 1) * GEMM_ROW_BYTES,
+                 smem + ((t + 1) & 1) * GEMM_STAGE_BYTES, wave);
     const char* sA = cur;
     const char* sB = cur + GEMM_OPERAND_BYTES;
 #pragma unroll

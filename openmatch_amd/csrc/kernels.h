@@ -38,6 +38,10 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
              void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep,
              hipStream_t s);
 
+// C (f32, pre-zeroed) += A · B^T with K sliced across workgroups (weight gradients)
+int omk_gemm_splitk(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C,
+                    int64_t ldc, int64_t M, int64_t N, int64_t K, hipStream_t s);
+
 // Stateless counter-based dropout: element `idx` of stream `seed` is kept iff hash >= p * 2^32.
 // Forward and backward regenerate the same mask from (seed, idx); nothing is stored.
 __host__ __device__ inline uint32_t om_hash32(uint64_t seed, uint64_t idx) {

@@ -212,11 +212,9 @@ extern "C" int om_encoder_train_backward(const OmEncoderConfig* c, const OmEncod
   char* dx_prev = ws.dxb;  // gradient w.r.t. its input (next iteration's dx)
   RUN(omk_pool_bwd(dt, dpooled, attention_mask, dx, B, (int)L, H, c->pooling, s));
 
-#define WGRAD(left, right, rows_out, cols_in, dst)                                                    \
-  do {                                                                                               \
-    GemmEpilogue e0 = {};                                                                            \
-    RUN(omk_gemm(dt, left, Mp, right, Mp, OM_F32, dst, cols_in, rows_out, cols_in, Mp, e0, s));       \
-  } while (0)
+  // weight gradients: split-K over the token axis, f32 atomics into the caller-zeroed buffers
+#define WGRAD(left, right, rows_out, cols_in, dst) \
+  RUN(omk_gemm_splitk(dt, left, Mp, right, Mp, dst, cols_in, rows_out, cols_in, Mp, s))
 
   for (int l = d.nl - 1; l >= 0; --l) {
     const OmLayerWeights& lw = Ls[l];

@@ -60,16 +60,24 @@ class _EncoderTrain(torch.autograd.Function):
         device = ctx.ids.device
         B, L = ctx.ids.shape
         H, F, nl = cfg.hidden, cfg.ffn, cfg.n_layers
-        z = lambda *shape: torch.zeros(*shape, device=device, dtype=torch.float32)
+        # one zero-filled arena for every gradient (the backward ADDS into it with f32 atomics)
+        emb = model.embeddings
+        n_emb = sum(t.numel() for t in (emb.word_embeddings.weight, emb.position_embeddings.weight,
+                                        emb.token_type_embeddings.weight)) + 2 * H
+        n_layer = 3 * H * H + 3 * H + H * H + H + 2 * H + F * H + F + H * F + H + 2 * H
+        n_head = cfg.head_out * cfg.head_in if cfg.head_in > 0 else 0
+        arena = torch.zeros(n_emb + nl * n_layer + n_head + 64 * (8 + 12 * nl), device=device, dtype=torch.float32)
+        cursor = [0]
         g = N.OmEncoderGrads()
-        keep = []
 
         def buf(field_owner, name, *shape):
-            t = z(*shape)
-            keep.append(t)
+            n = 1
+            for d_ in shape:
+                n *= d_
+            t = arena[cursor[0]:cursor[0] + n].view(*shape)
+            cursor[0] += (n + 63) // 64 * 64            # keep every buffer 256-byte aligned
             setattr(field_owner, name, t.data_ptr())
             return t
-        emb = model.embeddings
         gw = buf(g, "word_emb", *emb.word_embeddings.weight.shape)
         gp = buf(g, "pos_emb", *emb.position_embeddings.weight.shape)
         gt = buf(g, "type_emb", *emb.token_type_embeddings.weight.shape)

@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Throughput of one contrastive training step at the reference's coCondenser shape
+(BASELINE config 3 per GPU: 8 queries x 32 tok + 64 passages x 128 tok, bert-base, AdamW).
+  python tools/train_bench.py [--precision bf16|f32] [--steps 10]"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from types import SimpleNamespace as NS
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--dropout", type=float, default=0.1)
+    a = ap.parse_args()
+    from transformers import BertConfig, BertModel
+    from openmatch.modeling import DRModel
+    from openmatch.trainer import DRTrainer
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    cfg = BertConfig(hidden_dropout_prob=a.dropout, attention_probs_dropout_prob=a.dropout)
+    lm = BertModel(cfg)
+    model = DRModel(lm_q=lm, lm_p=lm, pooling="first",
+                    model_args=NS(encoder_only=False, dtype="bfloat16" if a.precision == "bf16" else "float32"),
+                    data_args=NS(train_n_passages=8),
+                    train_args=NS(negatives_x_device=False, per_device_train_batch_size=8)).to(dev)
+    g = torch.Generator().manual_seed(1)
+    mk = lambda n, L: {"input_ids": torch.randint(1000, 30000, (n, L), generator=g), "attention_mask": torch.ones(n, L, dtype=torch.long)}
+    batch = (mk(8, 32), mk(64, 128))
+    args = NS(device=dev, world_size=1, process_index=0, per_device_train_batch_size=8, negatives_x_device=False,
+              learning_rate=5e-6, weight_decay=0.0, adam_beta1=0.9, adam_beta2=0.999, adam_epsilon=1e-8,
+              gradient_accumulation_steps=1, max_grad_norm=1.0, fp16=False, bf16=False)
+    trainer = DRTrainer(model=model, args=args)
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-6, fused=True)
+    def step():
+        loss = trainer.training_step(model, batch)
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step(); opt.zero_grad(set_to_none=True)
+        return loss
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
+    flop = 3 * (8 * 5.474e9 + 64 * 22.347e9)
+    print(json.dumps({"metric": "contrastive train steps/s (8 q x 32 + 64 p x 128, bert-base, fwd+bwd+AdamW)", "steps_per_s": round(1 / dt, 2),
+                      "ms_per_step": round(dt * 1e3, 2), "precision": a.precision, "dropout": a.dropout,
+                      "algorithmic_tflops": round(flop / dt / 1e12, 1), "loss": float(loss)}))
+
+
+if __name__ == "__main__":
+    main()
