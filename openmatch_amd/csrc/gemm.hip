@@ -398,8 +398,22 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) OM_FAIL("A/B must be 16-byte aligned");
   if ((ep.act & 0xff) == OM_ACT_GELU_ERF_GRAD && !ep.resid) OM_FAIL("gelu-grad epilogue needs resid");
   const bool wide = wide_ok(out_dtype, C, ldc, M, N, ep);
-  int gen = !wide ? 1 : ((N >= 256 && gemm_variant() != 2) ? 4 : 2);
-  if (gen == 4 && (gemm_variant() == 3 || (K * es) % 128 != 0)) gen = 3;
+  // Pick the tile generation that finishes first: whole rounds of (256 CUs x resident workgroups)
+  // times the tile's work over its measured relative efficiency (profiles/r01_selftest_gemm_v4.log).
+  int gen = 1;
+  if (wide) {
+    auto rounds = [&](int64_t bm, int64_t bn, int64_t slots) {
+      const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+      return (double)((tiles + slots - 1) / slots);
+    };
+    const double c4 = N >= 256 ? rounds(256, 256, 256) * (256.0 * 256.0) / 1.00 : 1e30;
+    const double c2 = rounds(256, 128, 256) * (256.0 * 128.0) / 0.92;
+    const double c1 = rounds(128, 128, 512) * (128.0 * 128.0) / 0.70;
+    gen = c4 <= c2 && c4 <= c1 ? 4 : (c2 <= c1 ? 2 : 1);
+    if (gemm_variant() == 2) gen = 2;
+    if (gemm_variant() == 3 || gemm_variant() == 4) gen = N >= 256 ? gemm_variant() : 2;
+  }
+  if (gen == 4 && (K * es) % 128 != 0) gen = 3;
 #define OM_GEMM_GO(TI, TO)                                                                            \
   do {                                                                                                \
     if (gen == 4) return launch_gemm4<TI, TO>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);                 \

@@ -1,1 +1,1 @@
-from .data_collator import DRInferenceCollator, QPCollator
+from .data_collator import DRInferenceCollator, QPCollator, RRInferenceCollator

@@ -30,3 +30,14 @@ class DRInferenceCollator(DefaultDataCollator):
     def __call__(self, features):
         text_ids = [f["text_id"] for f in features]
         return text_ids, super().__call__(features)
+
+
+@dataclass
+class RRInferenceCollator(DefaultDataCollator):
+    """(query ids, doc ids, tensor batch) for the re-ranking loop (reference :86-91)."""
+
+    def __call__(self, features):
+        query_ids = [f["query_id"] for f in features]
+        doc_ids = [f["doc_id"] for f in features]
+        keep = [{k: v for k, v in f.items() if k not in ("query_id", "doc_id")} for f in features]
+        return query_ids, doc_ids, super().__call__(keep)

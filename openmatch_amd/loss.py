@@ -37,3 +37,37 @@ class DistributedContrastiveLoss(SimpleContrastiveLoss):
         out = torch.empty((self.word_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, t.detach().contiguous())
         return out
+
+
+# Pair losses of the re-ranker (reference loss.py:41-73).  They act on [B,1] score tensors: a few
+# hundred scalar operations, plain torch.
+import torch.nn.functional as _F
+
+
+class MarginRankingLoss:
+    def __init__(self, margin: float = 1.0):
+        self.margin = margin
+
+    def __call__(self, pos_scores: Tensor, neg_scores: Tensor):
+        return torch.mean(_F.relu(self.margin - pos_scores + neg_scores))
+
+
+class SoftMarginRankingLoss(MarginRankingLoss):
+    def __call__(self, pos_scores: Tensor, neg_scores: Tensor):
+        return torch.mean(_F.softplus(self.margin - pos_scores + neg_scores))
+
+
+class BinaryCrossEntropyLoss:
+    def __call__(self, pos_scores: Tensor, neg_scores: Tensor):
+        bce = _F.binary_cross_entropy_with_logits
+        return bce(pos_scores, torch.ones_like(pos_scores)) + bce(neg_scores, torch.zeros_like(neg_scores))
+
+
+class CrossEntropyLoss:
+    def __call__(self, pos_scores: Tensor, neg_scores: Tensor):
+        ones = torch.ones(pos_scores.shape[0], dtype=torch.long, device=pos_scores.device)
+        return _F.cross_entropy(pos_scores, ones) + _F.cross_entropy(neg_scores, torch.zeros_like(ones))
+
+
+rr_loss_functions = {"mr": MarginRankingLoss, "smr": SoftMarginRankingLoss, "bce": BinaryCrossEntropyLoss,
+                     "ce": CrossEntropyLoss}

@@ -1,1 +1,2 @@
 from .dense_retriever import Retriever, SuccessiveRetriever
+from .reranker import Reranker, RRPredictDataset

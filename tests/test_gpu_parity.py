@@ -401,3 +401,41 @@ def test_gradient_cache_step_equals_full_batch_step(golden, tmp_path):
     for n in grads[0]:
         a, b = grads[0][n], grads[1][n]
         assert (a - b).abs().max() <= 1e-6 + 1e-4 * a.abs().max(), n
+
+
+# ------------------------------------------------------------------------------- cross-encoder (config 5)
+def test_cross_encoder_bert_large_width_matches_oracle():
+    """RRModel scoring at BASELINE config 5's shape: H = 1024, 16 heads, F = 4096, L = 162 pairs with
+    token types 0/1 (2 layers, random weights): scores vs the CPU oracle, then Reranker.rerank order."""
+    from transformers import BertConfig, BertModel
+    from openmatch.modeling import LinearHead, RRModel
+    from openmatch.retriever import Reranker
+    torch.manual_seed(21)
+    cfg = BertConfig(hidden_size=1024, num_hidden_layers=2, num_attention_heads=16, intermediate_size=4096,
+                     vocab_size=600, max_position_embeddings=192)
+    lm = BertModel(cfg).eval()
+    head = LinearHead(1024, 1)
+    sd = {k: v.clone() for k, v in lm.state_dict().items()}
+    hw = head.linear.weight.detach().clone()
+    rng = np.random.default_rng(9)
+    n = 24
+    ids, mask = synth_tokens(rng, n, 162, vocab=600, lo_len=20, lo_id=300)
+    tt = np.zeros_like(ids)
+    for i in range(n):
+        ln = int(mask[i].sum()); tt[i, ln // 3:ln] = 1
+    items = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask), "token_type_ids": torch.from_numpy(tt)}
+    _, ref = encoder_ref.encode(sd, cfg, "bert", items, "first", hw, False)
+    model = RRModel(lm=lm, head=head, pooling="first", model_args=NS(encoder_only=False, dtype="float32"))
+    args = NS(device=DEV, world_size=1, process_index=0, local_process_index=0, fp16=False, eval_batch_size=8,
+              per_device_eval_batch_size=8, dataloader_num_workers=0, dataloader_pin_memory=False)
+    rr = Reranker(model, None, None, args)
+    got = rr.model.encode({k: v.to(DEV) for k, v in items.items()})
+    assert got.shape == (n, 1)
+    assert np.abs(got.cpu().numpy() - ref.numpy()).max() < 1e-4 * max(1.0, np.abs(ref.numpy()).max())
+    pairs = [{"query_id": f"q{i // 8}", "doc_id": f"d{i}", "input_ids": ids[i], "attention_mask": mask[i],
+              "token_type_ids": tt[i]} for i in range(n)]
+    run = rr.rerank(None, None, pair_dataset=pairs)
+    for q in range(3):
+        want = sorted(range(q * 8, q * 8 + 8), key=lambda i: -float(ref[i, 0]))
+        have = [int(d[1:]) for d, _ in sorted(run[f"q{q}"].items(), key=lambda kv: -kv[1])]
+        assert have == want
