@@ -402,13 +402,14 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
   // times the tile's work over its measured relative efficiency (profiles/r01_selftest_gemm_v4.log).
   int gen = 1;
   if (wide) {
+    // cost = rounds x (work a CU has in flight per round) / efficiency; v1 keeps 2 workgroups per CU
     auto rounds = [&](int64_t bm, int64_t bn, int64_t slots) {
       const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
       return (double)((tiles + slots - 1) / slots);
     };
     const double c4 = N >= 256 ? rounds(256, 256, 256) * (256.0 * 256.0) / 1.00 : 1e30;
     const double c2 = rounds(256, 128, 256) * (256.0 * 128.0) / 0.92;
-    const double c1 = rounds(128, 128, 512) * (128.0 * 128.0) / 0.70;
+    const double c1 = rounds(128, 128, 512) * (2 * 128.0 * 128.0) / 0.70;
     gen = c4 <= c2 && c4 <= c1 ? 4 : (c2 <= c1 ? 2 : 1);
     if (gemm_variant() == 2) gen = 2;
     if (gemm_variant() == 3 || gemm_variant() == 4) gen = N >= 256 ? gemm_variant() : 2;

@@ -313,7 +313,7 @@ int main(int argc, char** argv) {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs=%d  clock=%d MHz  mem=%.1f GB  LDS/block=%zu\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000, prop.totalGlobalMem / 1e9, prop.sharedMemPerBlock);
 
-  if (what != "bench" && what != "prof" && what != "trace") {
+  if (what != "bench" && what != "prof" && what != "trace" && what != "shapes") {
     // GEMM: aligned, ragged M/N tails, every epilogue, both dtypes
     test_gemm(OM_F32, 128, 128, 32, false, false, OM_ACT_NONE, OM_F32);
     test_gemm(OM_BF16, 128, 128, 64, false, false, OM_ACT_NONE, OM_F32);
@@ -373,6 +373,16 @@ int main(int argc, char** argv) {
       printf("\n");
     }
     return 0;
+  }
+  if (what == "shapes") {   // the encoder's own GEMM shapes at a small token count, every dtype
+    for (int dt : {OM_F32, OM_BF16}) {
+      test_gemm(dt, 1024, 2304, 768, true, false, OM_ACT_NONE, dt);
+      test_gemm(dt, 1024, 768, 768, true, true, OM_ACT_NONE, dt);
+      test_gemm(dt, 1024, 3072, 768, true, false, OM_ACT_GELU_ERF, dt);
+      test_gemm(dt, 1024, 768, 3072, true, true, OM_ACT_NONE, dt);
+    }
+    printf("%s: %d failure(s)\n", g_fail ? "SELFTEST FAILED" : "SELFTEST PASSED", g_fail);
+    return g_fail ? 1 : 0;
   }
   if (what == "prof") {     // short run for rocprofv3 --pmc passes
     bench_gemm(OM_BF16, 32768, 768, 768, 0);

@@ -75,7 +75,7 @@ def test_bert_base_f32_dot_products_within_1e4(golden):
     g = golden("bert_base_seed0")
     torch.manual_seed(0)
     lm = BertModel(BertConfig()).eval()
-    model = DRModelForInference(lm_q=lm, lm_p=lm, model_args=NS(encoder_only=False, dtype="float32")).to(DEV)
+    model = DRModelForInference(lm_q=lm, lm_p=lm, model_args=NS(encoder_only=False, dtype="float32")).to(DEV).eval()
     out = model(query=items_from_golden(g, "q", DEV), passage=items_from_golden(g, "p", DEV))
     assert np.abs(out.p_reps.cpu().numpy() - g["p_reps"]).max() < 1e-4
     assert np.abs(out.q_reps.cpu().numpy() - g["q_reps"]).max() < 1e-4
@@ -94,7 +94,7 @@ def test_encoder_matches_oracle_on_ragged_batches():
     lm = BertModel(cfg).eval()
     sd = {k: v.clone() for k, v in lm.state_dict().items()}      # CPU copy for the oracle
     model = DRModelForInference(lm_q=lm, lm_p=lm, pooling="mean", normalize=True,
-                                model_args=NS(encoder_only=False, dtype="float32")).to(DEV)
+                                model_args=NS(encoder_only=False, dtype="float32")).to(DEV).eval()
     rng = np.random.default_rng(5)
     for B, L in ((1, 7), (3, 50), (2, 162), (5, 33), (2, 256)):
         ids, mask = synth_tokens(rng, B, L, vocab=600, lo_len=min(4, L), lo_id=300)
@@ -429,7 +429,8 @@ def test_cross_encoder_bert_large_width_matches_oracle():
     args = NS(device=DEV, world_size=1, process_index=0, local_process_index=0, fp16=False, eval_batch_size=8,
               per_device_eval_batch_size=8, dataloader_num_workers=0, dataloader_pin_memory=False)
     rr = Reranker(model, None, None, args)
-    got = rr.model.encode({k: v.to(DEV) for k, v in items.items()})
+    with torch.no_grad():
+        got = rr.model.encode({k: v.to(DEV) for k, v in items.items()})
     assert got.shape == (n, 1)
     assert np.abs(got.cpu().numpy() - ref.numpy()).max() < 1e-4 * max(1.0, np.abs(ref.numpy()).max())
     pairs = [{"query_id": f"q{i // 8}", "doc_id": f"d{i}", "input_ids": ids[i], "attention_mask": mask[i],
