@@ -1,0 +1,141 @@
+// Sixth-generation NT GEMM main loop for gfx950: 256 x 256 tile, FOUR waves (one per SIMD), each
+// owning a 128 x 128 accumulator block (16 MFMA tiles = 256 accumulator registers).
+//
+// Why (profiles/r01_gemm_variants_trace.log): with eight waves of 128 x 64 (v3/v4) a
+// 64-byte K step reads 8 x 12 KiB of fragments out of LDS and the DMA writes 32 KiB into it:
+// 128 KiB per step against an LDS port of 128 B/clk is 1024 cycles -- exactly the MFMA time of the
+// step, so the LDS is a co-bottleneck and measured steps take ~1750 cycles.  A 128 x 128 wave tile
+// reads (128 + 128) rows for twice the outputs: 4 x 16 KiB + 32 KiB = 96 KiB per step (75 % of the
+// port).  With one wave per SIMD nothing else hides latency, so the loop is software pipelined:
+// the fragments of sub-step kk+1 are read while the 16 MFMAs of sub-step kk issue.
+//
+//   stage = A tile [256 rows][64 B] + B tile [256 rows][64 B], ring of 4 (same layout/swizzle as v4)
+//   per wave and stage: 4 + 4 global_load_lds_dwordx4 (vmcnt counts 8 per stage)
+#pragma once
+#include "gemm_core4.h"
+
+#define G6_THREADS 256
+
+__device__ inline void g6_stage(const char* const (&pa)[4], const char* const (&pb)[4], size_t kbyte,
+                                char* slot, int wave) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    __builtin_amdgcn_global_load_lds((gptr_t)(pa[i] + kbyte), (lptr_t)(slot + (i * 4 + wave) * 1024),
+                                     16, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    __builtin_amdgcn_global_load_lds((gptr_t)(pb[i] + kbyte),
+                                     (lptr_t)(slot + G4_OPERAND_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+}
+
+template <typename T>
+__device__ __forceinline__ void g6_read(typename MmaOps<T>::frag_t (&a)[4], typename MmaOps<T>::frag_t (&b)[4],
+                                        const char* cur, int rowa, int rowb, int slot) {
+  typedef typename MmaOps<T>::frag_t frag_t;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = *(const frag_t*)(cur + rowa + i * 32 * G4_ROW_BYTES + slot);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b[i] = *(const frag_t*)(cur + rowb + i * 32 * G4_ROW_BYTES + slot);
+}
+
+// acc[mi][ni] = rows m0 + wm*128 + mi*32.., cols n0 + wn*128 + ni*32..   (wm = wave>>1, wn = wave&1);
+// every row of acc[.][ni] starts at init[ni] (this lane's column of the bias, or 0).
+// PROBE (tools/gemm_loop_probe.hip only; 0 in the product): bit 0 drops the steady-state DMA issue,
+// bit 1 the fragment reads, bit 2 the per-step barrier -- to attribute the cycles of a K step.
+template <typename T, int PROBE = 0>
+__device__ inline void gemm_mainloop6(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
+                                      int64_t ldb, int64_t M, int64_t N, int64_t K, int64_t m0,
+                                      int64_t n0, char* smem, f32x16_t (&acc)[4][4],
+                                      const float (&init)[4], unsigned long long* tr = nullptr) {
+  typedef typename MmaOps<T>::frag_t frag_t;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..3
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const char* pa[4];
+  const char* pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (i * 4 + wave) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((r >> 2) & 3);
+    int64_t ra = m0 + r; if (ra > M - 1) ra = M - 1;
+    int64_t rb = n0 + r; if (rb > N - 1) rb = N - 1;
+    pa[i] = (const char*)(A + ra * lda) + c * 16;
+    pb[i] = (const char*)(B + rb * ldb) + c * 16;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = init[ni];   // the column's bias (or 0)
+
+  const int nk = (int)((K * (int64_t)sizeof(T)) / G4_ROW_BYTES);
+  const int key = (lane >> 2) & 3;
+  const int half = lane >> 5;
+  const int slot0 = ((half ^ key) << 4), slot1 = (((2 | half) ^ key) << 4);
+  const int rowa = (wm * 128 + (lane & 31)) * G4_ROW_BYTES;
+  const int rowb = G4_OPERAND_BYTES + (wn * 128 + (lane & 31)) * G4_ROW_BYTES;
+
+  if (tr && tid == 0) tr[1] = clock64();
+  g6_stage(pa, pb, 0, smem, wave);
+  if (nk > 1) g6_stage(pa, pb, G4_ROW_BYTES, smem + G4_STAGE_BYTES, wave);
+  if (nk > 2) g6_stage(pa, pb, 2 * G4_ROW_BYTES, smem + 2 * G4_STAGE_BYTES, wave);
+  if (nk > 2) __builtin_amdgcn_s_waitcnt(0x4070);
+  else if (nk > 1) __builtin_amdgcn_s_waitcnt(0x0078);
+  else __builtin_amdgcn_s_waitcnt(0x0070);
+  __builtin_amdgcn_s_barrier();
+
+  frag_t a0[4], b0[4], a1[4], b1[4];
+  g6_read<T>(a0, b0, smem, rowa, rowb, slot0);
+  if (PROBE & 2) g6_read<T>(a1, b1, smem, rowa, rowb, slot1);
+
+  // One K step.  ISSUE: start the DMA of tile t+3; VMW: s_waitcnt immediate that proves tile t+1
+  // has landed; NEXT: read tile t+1's first fragments.  All compile-time, so the steady-state loop
+  // is straight-line code.  Issue order is pinned by hand (sched_barrier fences): every MFMA covers
+  // at most one LDS read or one DMA issue -- eight back-to-back global_load_lds cost ~320 cycles of
+  // a 1024-cycle step when they sit in front of the MFMAs (tools/gemm_loop_probe.hip).
+#define G6_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define G6_DMA(P, I, OFF)                                                                                \
+  __builtin_amdgcn_global_load_lds((gptr_t)(P[I] + (size_t)(t + 3) * G4_ROW_BYTES),                      \
+                                   (lptr_t)(smem + ((t + 3) & 3) * G4_STAGE_BYTES + (OFF) + ((I) * 4 + wave) * 1024), 16, 0, 0)
+#define G6_HALF(AF, BF, AN, BN, SRC, SLOT, DO_READ, DO_DMA, P, OFF)                                      \
+  _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                       \
+    MmaOps<T>::mma(AF[q >> 2], BF[q & 3], acc[q >> 2][q & 3]);                                           \
+    if (q < 8) {                                                                                         \
+      if (DO_READ) {                                                                                     \
+        if (q < 4) AN[q] = *(const frag_t*)((SRC) + rowa + q * 32 * G4_ROW_BYTES + (SLOT));              \
+        else BN[q - 4] = *(const frag_t*)((SRC) + rowb + (q - 4) * 32 * G4_ROW_BYTES + (SLOT));          \
+      }                                                                                                  \
+    } else if (!(q & 1)) {                                                                               \
+      if (DO_DMA) G6_DMA(P, (q - 8) >> 1, OFF);                                                          \
+    }                                                                                                    \
+    G6_FENCE();                                                                                          \
+  }
+#define G6_STEP(ISSUE, VMW, NEXT)                                                                        \
+  do {                                                                                                   \
+    const char* cur = smem + (t & 3) * G4_STAGE_BYTES;                                                   \
+    const char* nxt = smem + ((t + 1) & 3) * G4_STAGE_BYTES;                                             \
+    if (tr && tid == 0 && t < 12) tr[3 + t] = clock64();                                                 \
+    /* slot (t+3)&3 held tile t-1: every wave finished reading it before the barrier of step t-1 */      \
+    G6_HALF(a0, b0, a1, b1, cur, slot1, !(PROBE & 2), (ISSUE) && !(PROBE & 1), pa, 0)                    \
+    __builtin_amdgcn_s_waitcnt(VMW);     /* vmcnt(n) lgkmcnt(0): tile t+1 landed, my reads done */       \
+    if (!(PROBE & 4)) __builtin_amdgcn_s_barrier();                                                      \
+    G6_FENCE();                                                                                          \
+    G6_HALF(a1, b1, a0, b0, nxt, slot0, (NEXT) && !(PROBE & 2), (ISSUE) && !(PROBE & 1), pb, G4_OPERAND_BYTES) \
+  } while (0)
+
+  int t = 0;
+  // s_waitcnt immediates (gfx9 encoding: vmcnt = [15:14][3:0], expcnt [6:4] = 7 "no wait", lgkmcnt [11:8] = 0)
+  for (; t + 3 < nk; ++t) G6_STEP(true, 0x007C, true);      // vmcnt(12): tile t+2 and the A half of t+3 may be in flight
+  if (t + 2 < nk) { G6_STEP(false, 0x0078, true); ++t; }    // vmcnt(8):  t+2
+  if (t + 1 < nk) { G6_STEP(false, 0x0070, true); ++t; }    // vmcnt(0)
+  G6_STEP(false, 0x0070, false);                            // last tile
+#undef G6_STEP
+#undef G6_HALF
+#undef G6_DMA
+#undef G6_FENCE
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                             // everyone is done with the ring
+}

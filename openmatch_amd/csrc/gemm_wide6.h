@@ -1,0 +1,66 @@
+// Shared by gemm_wide6_bf16.hip / gemm_wide6_f32.hip (one translation unit per input type so the
+// epilogue variants compile in parallel).
+#pragma once
+#include "gemm_core6.h"
+#include "gemm_epilogue.h"
+
+// ---- v6: 256x256 tile, four waves of 128x128, software-pipelined fragment reads (gemm_core6.h) ----
+// The epilogue variant (activation, training extras) is a KERNEL template parameter chosen on the
+// host: with all variants behind one in-kernel switch hipcc spills the 256 accumulators to scratch
+// at the switch (1 KiB per lane) and takes minutes to compile.
+template <typename T, typename OutT, int ACT, bool TRAIN>
+__global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel6(
+    const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, OutT* C,
+    int64_t ldc, int64_t M, int64_t N, int64_t K, GemmEpilogue ep, int group_m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int64_t m0, n0;
+  g4_tile_coords(M, N, group_m, m0, n0);
+  f32x16_t acc[4][4];
+  unsigned long long* tr = ep.trace ? ep.trace + (size_t)blockIdx.x * 32 : nullptr;
+  if (tr && threadIdx.x == 0) tr[0] = clock64();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t nc = n0 + wn * 128;
+  float bv[4];          // the bias rides in the accumulators' initial value
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bv[i] = (ep.bias && nc + i * 32 + (lane & 31) < N) ? ep.bias[nc + i * 32 + (lane & 31)] : 0.f;
+  gemm_mainloop6<T>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, bv, tr);   // ends on a barrier
+  if (tr && threadIdx.x == 0) tr[15] = clock64();
+
+  const EpiScalars es(ep);
+  char* region = smem + wave * (32 * PATCH_STRIDE);
+  store_wave_tile<OutT, ACT, TRAIN, 4, 4, true>(acc, bv, m0 + wm * 128, nc, C, ldc, M, N, ep, es, region);
+  if (tr && threadIdx.x == 0) { tr[28] = clock64(); tr[29] = blockIdx.x; }
+}
+
+template <typename T, typename OutT, int ACT, bool TRAIN>
+static int launch6(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                   int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
+  const int64_t nwg = ((M + G4_BM - 1) / G4_BM) * ((N + G4_BN - 1) / G4_BN);
+  if (nwg > 0x7fffffffLL) OM_FAIL("grid too large");
+  static bool attr_set = false;
+  if (!attr_set) {
+    OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel6<T, OutT, ACT, TRAIN>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES));
+    attr_set = true;
+  }
+  const int tclass = sizeof(T) == 2 ? OM_TIMING_GEMM_BF16 : OM_TIMING_GEMM_F32;
+  const bool timing = om_timing_on();
+  if (timing) om_timing_begin(tclass, s);
+  // sweep order: 8 row tiles stay resident while the column tiles are walked (L2 reuse per XCD)
+  hipLaunchKernelGGL((gemm_nt_kernel6<T, OutT, ACT, TRAIN>), dim3((unsigned)nwg), dim3(G6_THREADS), G4_LDS_BYTES, s,
+                     (const T*)A, lda, (const T*)B, ldb, (OutT*)C, ldc, M, N, K, ep, 8);
+  if (timing) om_timing_end(tclass, s, 2.0 * (double)M * (double)N * (double)K);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+// every (activation, training) variant for one dtype pair
+template <typename T, typename OutT>
+static int launch6_any(int act, bool train, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+                       int64_t ldc, int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
+#define OM_L6(A_, TR_) return launch6<T, OutT, A_, TR_>(A, lda, B, ldb, C, ldc, M, N, K, ep, s)
+  OM_EPI_SWITCH(act, train, OM_L6)
+#undef OM_L6
+  return 1;
+}

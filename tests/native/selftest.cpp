@@ -355,19 +355,28 @@ int main(int argc, char** argv) {
     test_contrastive();
   }
   if (what == "trace") {    // per-block phase timelines of one GEMM launch (shader clocks)
-    const int64_t M = 32768, N = argc > 2 ? atoi(argv[2]) : 768, K = argc > 3 ? atoi(argv[3]) : 768;
+    const int64_t N = argc > 2 ? atoi(argv[2]) : 768, K = argc > 3 ? atoi(argv[3]) : 768, M = argc > 4 ? atoll(argv[4]) : 32768;
+    const int64_t ld = argc > 5 ? atoll(argv[5]) : K;   // 0: every row aliases row 0 (operands always cache-hot)
     char* A = dalloc<char>(M * K * 2); char* B = dalloc<char>(N * K * 2); char* C = dalloc<char>(M * N * 2);
     { auto t = to_bf16(randn(1 << 22)); for (size_t o = 0; o < (size_t)M * K; o += t.size()) CK(hipMemcpy(A + o * 2, t.data(), std::min(t.size(), (size_t)M * K - o) * 2, hipMemcpyHostToDevice)); auto tb = to_bf16(randn((size_t)N * K, 0.05f)); CK(hipMemcpy(B, tb.data(), tb.size() * 2, hipMemcpyHostToDevice)); }
     const size_t nblk = 8192; unsigned long long* tr = dalloc<unsigned long long>(nblk * 32);
-    for (int i = 0; i < 3; ++i) OMCK(om_gemm_nt(OM_BF16, A, K, B, K, OM_BF16, C, N, M, N, K, nullptr, nullptr, 0, 0, nullptr));
+    for (int i = 0; i < 3; ++i) OMCK(om_gemm_nt(OM_BF16, A, ld, B, ld, OM_BF16, C, N, M, N, K, nullptr, nullptr, 0, 0, nullptr));
     CK(hipMemset(tr, 0, nblk * 32 * 8)); om_debug_gemm_trace(tr);
-    OMCK(om_gemm_nt(OM_BF16, A, K, B, K, OM_BF16, C, N, M, N, K, nullptr, nullptr, 0, 0, nullptr));
+    OMCK(om_gemm_nt(OM_BF16, A, ld, B, ld, OM_BF16, C, N, M, N, K, nullptr, nullptr, 0, 0, nullptr));
     CK(hipDeviceSynchronize()); om_debug_gemm_trace(nullptr);
     auto h = download(tr, nblk * 32);
     unsigned long long t0 = ~0ull; size_t used = 0;
     for (size_t b = 0; b < nblk; ++b) if (h[b * 32]) { t0 = std::min(t0, h[b * 32]); used = b + 1; }
-    printf("trace M=%ld N=%ld K=%ld blocks=%zu (cycles since first block start)\n", (long)M, (long)N, (long)K, used);
-    for (size_t b = 0; b < used; b += std::max<size_t>(1, used / 24)) {
+    printf("trace M=%ld N=%ld K=%ld ld=%ld blocks=%zu (cycles since first block start)\n", (long)M, (long)N, (long)K, (long)ld, used);
+    {   // averages over all blocks: prologue [1]->[3], first 11 K steps [3]->[14], epilogue [15]->[28]
+      double pro = 0, step = 0, epi = 0, tot = 0; size_t n = 0;
+      for (size_t b = 0; b < used; ++b) if (h[b * 32] && h[b * 32 + 28] && h[b * 32 + 14]) {
+        pro += (double)(h[b * 32 + 3] - h[b * 32 + 1]); step += (double)(h[b * 32 + 14] - h[b * 32 + 3]) / 11.0;
+        epi += (double)(h[b * 32 + 28] - h[b * 32 + 15]); tot += (double)(h[b * 32 + 28] - h[b * 32]); ++n;
+      }
+      if (n) printf("avg over %zu blocks: prologue %.0f  K-step %.0f  epilogue %.0f  whole tile %.0f (memtime ticks)\n", n, pro / n, step / n, epi / n, tot / n);
+    }
+    for (size_t b = 0; b < used; b += std::max<size_t>(1, used / 8)) {
       printf("blk %5zu:", b);
       for (int i = 0; i < 30; ++i) if (h[b * 32 + i] && i != 29) printf(" [%d]%llu", i, h[b * 32 + i] - t0);
       printf("\n");
