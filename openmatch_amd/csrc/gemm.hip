@@ -137,16 +137,20 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
     const double c4 = N >= 256 ? rounds(256, 256, 256) * (256.0 * 256.0) / 1.00 : 1e30;
     const double c2 = rounds(256, 128, 256) * (256.0 * 128.0) / 0.92;
     const double c1 = rounds(128, 128, 512) * (2 * 128.0 * 128.0) / 0.70;
-    gen = c4 <= c2 && c4 <= c1 ? 4 : (c2 <= c1 ? 2 : 1);
+    gen = c4 <= c2 && c4 <= c1 ? 6 : (c2 <= c1 ? 2 : 1);     // 6 falls back to 4 where it has no variant
     if (gemm_variant() == 2) gen = 2;
     if (gemm_variant() == 4 || gemm_variant() == 6) gen = N >= 256 ? gemm_variant() : 2;
   }
   if (gen == 6) {
     const int act = ep.act & 0xff;
     const bool train = ep.pre_act != nullptr || ep.drop_p > 0.f;
-    if (omk_gemm_wide6_b16_has(in_dtype, out_dtype, act, train))
+    const bool resid = ep.resid != nullptr;
+    // v6 reads the bias as float4 and writes pre-activation pairs
+    const bool aligned = (((uintptr_t)ep.bias & 15) == 0) && (ep.ldp % 2 == 0) && (((uintptr_t)ep.pre_act & 3) == 0);
+    if (!aligned) gen = 4;
+    else if (omk_gemm_wide6_b16_has(in_dtype, out_dtype, act, train, resid))
       return omk_gemm_wide6_b16(in_dtype, A, lda, B, ldb, out_dtype, C, ldc, M, N, K, ep, s);
-    if (omk_gemm_wide6_f32_has(in_dtype, out_dtype, act, train))
+    else if (omk_gemm_wide6_f32_has(in_dtype, out_dtype, act, train, resid))
       return omk_gemm_wide6_f32(in_dtype, A, lda, B, ldb, out_dtype, C, ldc, M, N, K, ep, s);
     gen = 4;
   }

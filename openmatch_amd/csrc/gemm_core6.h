@@ -38,15 +38,17 @@ __device__ __forceinline__ void g6_read(typename MmaOps<T>::frag_t (&a)[4], type
   for (int i = 0; i < 4; ++i) b[i] = *(const frag_t*)(cur + rowb + i * 32 * G4_ROW_BYTES + slot);
 }
 
-// acc[mi][ni] = rows m0 + wm*128 + mi*32.., cols n0 + wn*128 + ni*32..   (wm = wave>>1, wn = wave&1);
-// every row of acc[.][ni] starts at init[ni] (this lane's column of the bias, or 0).
+// The MFMA operands are SWAPPED (B tile rows as the A operand), so a lane owns one output ROW and
+// four consecutive accumulator registers are four consecutive output COLUMNS (wm = wave>>1, wn = wave&1):
+//   acc[mi][ni][r] = C[m0 + wm*128 + mi*32 + (lane&31)][n0 + wn*128 + ni*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)]
+// -- the layout gemm_epilogue6.h streams out.  acc[.][ni] starts at init[ni] (the bias in that order, or 0).
 // PROBE (tools/gemm_loop_probe.hip only; 0 in the product): bit 0 drops the steady-state DMA issue,
 // bit 1 the fragment reads, bit 2 the per-step barrier -- to attribute the cycles of a K step.
 template <typename T, int PROBE = 0>
 __device__ inline void gemm_mainloop6(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
                                       int64_t ldb, int64_t M, int64_t N, int64_t K, int64_t m0,
                                       int64_t n0, char* smem, f32x16_t (&acc)[4][4],
-                                      const float (&init)[4], unsigned long long* tr = nullptr) {
+                                      const f32x16_t (&init)[4], unsigned long long* tr = nullptr) {
   typedef typename MmaOps<T>::frag_t frag_t;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -69,7 +71,7 @@ __device__ inline void gemm_mainloop6(const T* __restrict__ A, int64_t lda, cons
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = init[ni];   // the column's bias (or 0)
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = init[ni][r];   // the columns' bias (or 0)
 
   const int nk = (int)((K * (int64_t)sizeof(T)) / G4_ROW_BYTES);
   const int key = (lane >> 2) & 3;
@@ -102,7 +104,7 @@ __device__ inline void gemm_mainloop6(const T* __restrict__ A, int64_t lda, cons
                                    (lptr_t)(smem + ((t + 3) & 3) * G4_STAGE_BYTES + (OFF) + ((I) * 4 + wave) * 1024), 16, 0, 0)
 #define G6_HALF(AF, BF, AN, BN, SRC, SLOT, DO_READ, DO_DMA, P, OFF)                                      \
   _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                       \
-    MmaOps<T>::mma(AF[q >> 2], BF[q & 3], acc[q >> 2][q & 3]);                                           \
+    MmaOps<T>::mma(BF[q & 3], AF[q >> 2], acc[q >> 2][q & 3]);                                           \
     if (q < 8) {                                                                                         \
       if (DO_READ) {                                                                                     \
         if (q < 4) AN[q] = *(const frag_t*)((SRC) + rowa + q * 32 * G4_ROW_BYTES + (SLOT));              \

@@ -174,92 +174,6 @@ __device__ __forceinline__ void store_patch(const f32x16_t acc0, const f32x16_t 
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next patch overwrites
 }
 
-// Whole-wave-tile epilogue for the one-wave-per-SIMD kernels (v6): acc[NM][NN] 32 x 32 MFMA tiles are
-// streamed out as [32 x 64] f32 patches through ONE wave-private LDS region.  With a single wave per
-// SIMD nothing else hides latency, so the patches are software pipelined by hand: the LDS reads of
-// patch p are issued, then the LDS writes of patch p+1 and the residual loads of patch p+1, and
-// only then is patch p converted and stored.  A wave's LDS operations execute in order, so reusing the
-// one region needs no waits beyond the register dependencies the compiler tracks itself.
-// BIAS_FOLDED: the accumulators were initialised with the bias (no add here).
-template <typename OutT, int ACT, bool TRAIN, int NM, int NN, bool BIAS_FOLDED>
-__device__ __forceinline__ void store_wave_tile(f32x16_t (&acc)[NM][NN], const float (&bias)[NN], int64_t mrow0,
-                                                int64_t ncol0, OutT* C, int64_t ldc, int64_t M, int64_t N,
-                                                const GemmEpilogue& ep, const EpiScalars& es, char* region) {
-  constexpr int VEC = OutVec<OutT>::VEC;      // elements per 16-byte output vector
-  constexpr int CPR = 64 / VEC;               // vectors per 64-column patch row
-  constexpr int RPI = 64 / CPR;               // patch rows covered by one 64-lane pass
-  constexpr int ITER = 32 / RPI;
-  constexpr int NP = NM * (NN / 2);
-  const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
-  const int rl = lane / CPR, c = lane % CPR;  // this lane's row (within a pass) and 16-byte column slot
-  const int64_t rows_left64 = M - mrow0, cols_left64 = N - ncol0;
-  const int rows_left = rows_left64 > NM * 32 ? NM * 32 : (int)rows_left64;
-  const int cols_left = cols_left64 > NN * 32 ? NN * 32 : (int)cols_left64;
-  const OutT* resid = (const OutT*)ep.resid;   // may alias C (in-place +=)
-  OutT* cp = C + (mrow0 + rl) * ldc + ncol0 + c * VEC;
-  const OutT* rp = resid ? resid + (mrow0 + rl) * ep.ldr + ncol0 + c * VEC : nullptr;
-  const char* lds_rd = region + rl * PATCH_STRIDE + c * VEC * 4;
-
-  uint4 rres[2][ITER];
-#define OM_SWT_WRITE(P)                                                                                   \
-  do {                                                                                                    \
-    const int mi_ = (P) / (NN / 2), n0_ = 2 * ((P) % (NN / 2));                                           \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                      \
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;                                                  \
-      float* dst = (float*)(region + row * PATCH_STRIDE);                                                 \
-      const float v0 = BIAS_FOLDED ? acc[mi_][n0_][r] : acc[mi_][n0_][r] + bias[n0_];                     \
-      const float v1 = BIAS_FOLDED ? acc[mi_][n0_ + 1][r] : acc[mi_][n0_ + 1][r] + bias[n0_ + 1];         \
-      dst[l31] = epi_value<ACT, TRAIN, OutT>(v0, mrow0 + mi_ * 32 + row, ncol0 + n0_ * 32 + l31, M, N, ep, \
-                                             es.drop_thresh, es.drop_scale);                              \
-      dst[32 + l31] = epi_value<ACT, TRAIN, OutT>(v1, mrow0 + mi_ * 32 + row, ncol0 + n0_ * 32 + 32 + l31, \
-                                                  M, N, ep, es.drop_thresh, es.drop_scale);               \
-    }                                                                                                     \
-  } while (0)
-#define OM_SWT_OK(P, IT)                                                                                  \
-  (((P) / (NN / 2)) * 32 + (IT) * RPI + rl < rows_left && ((P) % (NN / 2)) * 64 + c * VEC < cols_left)
-#define OM_SWT_OFF(P, IT, LD) ((int64_t)(((P) / (NN / 2)) * 32 + (IT) * RPI) * (LD) + ((P) % (NN / 2)) * 64)
-#define OM_SWT_RESID(P)                                                                                   \
-  do {                                                                                                    \
-    _Pragma("unroll") for (int it = 0; it < ITER; ++it)                                                   \
-      if (OM_SWT_OK(P, it)) rres[(P) & 1][it] = *(const uint4*)(rp + OM_SWT_OFF(P, it, ep.ldr));          \
-  } while (0)
-
-  if (resid) OM_SWT_RESID(0);
-  OM_SWT_WRITE(0);
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    f32x4_t xq[ITER][VEC / 4];
-#pragma unroll
-    for (int it = 0; it < ITER; ++it)
-#pragma unroll
-      for (int e = 0; e < VEC / 4; ++e)
-        xq[it][e] = *(const f32x4_t*)(lds_rd + it * RPI * PATCH_STRIDE + e * 16);
-    if (p + 1 < NP) {
-      OM_SWT_WRITE(p + 1);
-      if (resid) OM_SWT_RESID(p + 1);
-    }
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      if (OM_SWT_OK(p, it)) {
-        float xv[VEC];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) xv[e] = xq[it][e >> 2][e & 3];
-        if (resid) {
-          float rv[VEC];
-          OutVec<OutT>::unpack(rres[p & 1][it], rv);
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) xv[e] = epi_resid<ACT>(xv[e], rv[e], es.mul);
-        }
-        *(uint4*)(cp + OM_SWT_OFF(p, it, ldc)) = OutVec<OutT>::pack(xv);
-      }
-    }
-  }
-#undef OM_SWT_WRITE
-#undef OM_SWT_OK
-#undef OM_SWT_OFF
-#undef OM_SWT_RESID
-}
-
 // v1 epilogue: the wave's 64 x 64 sub-tile goes straight from the accumulators to memory.
 template <typename OutT, int ACT, bool TRAIN>
 __device__ __forceinline__ void store_direct(const f32x16_t a00, const f32x16_t a01, const f32x16_t a10,

@@ -1,0 +1,176 @@
+// Epilogue of the one-wave-per-SIMD GEMM (gemm_core6.h).  The MFMA operands are swapped there, so a
+// lane owns ONE output row and every four consecutive accumulator registers are four consecutive
+// output columns:
+//     acc[mi][ni][r]  =  C[ mrow0 + mi*32 + (lane & 31) ][ ncol0 + ni*32 + 8*(r>>2) + 4*(lane>>5) + (r&3) ]
+// That makes the LDS transposition cheap (tools/gemm_epilogue_probe.hip: the f32 `ds_write_b32`
+// staging of the column-per-lane layout cost ~7 k cycles per 256 x 256 tile before any store):
+//   * 16-bit output, no residual: pack to bf16 in registers, ds_write_b64 (4 columns), rows of 264 B
+//   * otherwise: ds_write_b128 of four f32, rows of 528 B; residual added in f32 after the read-back
+//     (a single rounding)
+// then whole 16-byte vectors are read back row-major and stored fully coalesced (a wave instruction
+// covers 4 (bf16) or 2 (f32) complete 256 / 512-byte row segments).
+// One patch = one mi block (32 rows x 128 columns).  With a single wave per SIMD nothing else hides
+// latency, so patches are software pipelined by hand: read back patch p, write patch p+1, then
+// finish patch p.  A wave's LDS operations execute in order, so reusing
+// the one region needs no waits beyond the register dependencies the compiler tracks itself.
+#pragma once
+#include "gemm_epilogue.h"
+
+// erf-GELU for 16-bit outputs without transcendentals, two elements per instruction
+// (v_pk_mul_f32 / v_pk_fma_f32):  gelu(x) = 0.5 x + x h(x),  h(x) = 0.5 erf(x / sqrt 2) ~ xc Q(xc^2)
+// with xc = clamp(x, +-4.2), Q the degree-8 minimax fit (|h error| <= 7.4e-6), h clamped to +-0.5 so
+// the tails are exactly 0 and x.  |gelu error| <= 6e-5 everywhere -- far inside a bf16 ulp.  The f32
+// output path keeps erff.
+__device__ __forceinline__ f32x2_t gelu_erf_poly2(f32x2_t x) {
+  const f32x2_t xc = {__builtin_amdgcn_fmed3f(x[0], -4.2f, 4.2f), __builtin_amdgcn_fmed3f(x[1], -4.2f, 4.2f)};
+  const f32x2_t t = xc * xc;
+  f32x2_t q = {5.998145036e-11f, 5.998145036e-11f};
+#define OM_G2(K) q = __builtin_elementwise_fma(q, t, (f32x2_t){K, K})
+  OM_G2(-5.633389311e-09f); OM_G2(2.343703613e-07f); OM_G2(-5.760840850e-06f); OM_G2(9.457556007e-05f);
+  OM_G2(-1.114161685e-03f); OM_G2(9.830250405e-03f); OM_G2(-6.636118144e-02f); OM_G2(3.989123106e-01f);
+#undef OM_G2
+  f32x2_t h = xc * q;
+  h = (f32x2_t){__builtin_amdgcn_fmed3f(h[0], -0.5f, 0.5f), __builtin_amdgcn_fmed3f(h[1], -0.5f, 0.5f)};
+  return __builtin_elementwise_fma(x, h, x * (f32x2_t){0.5f, 0.5f});
+}
+
+// two adjacent output elements (columns n, n+1 of row m) before the residual
+template <int ACT, bool TRAIN, typename OutT>
+__device__ __forceinline__ f32x2_t epi_pair(f32x2_t v, int64_t m, int64_t n, int64_t M, int64_t N,
+                                           const GemmEpilogue& ep, const EpiScalars& es) {
+  if (ACT == OM_ACT_GELU_ERF && sizeof(OutT) == 2) {
+    if (TRAIN) {
+      if (ep.pre_act && m < M && n < N)
+        *(uint32_t*)((OutT*)ep.pre_act + m * ep.ldp + n) = pack_bf16x2(v[0], v[1]);
+    }
+    v = gelu_erf_poly2(v);
+    if (TRAIN) {
+      if (es.drop_thresh) {
+        v[0] = dropout_keep(ep.seed, (uint64_t)m * (uint64_t)N + (uint64_t)n, es.drop_thresh) ? v[0] * es.drop_scale : 0.f;
+        v[1] = dropout_keep(ep.seed, (uint64_t)m * (uint64_t)N + (uint64_t)n + 1, es.drop_thresh) ? v[1] * es.drop_scale : 0.f;
+      }
+    }
+    return v;
+  }
+  return (f32x2_t){epi_value<ACT, TRAIN, OutT>(v[0], m, n, M, N, ep, es.drop_thresh, es.drop_scale),
+                   epi_value<ACT, TRAIN, OutT>(v[1], m, n + 1, M, N, ep, es.drop_thresh, es.drop_scale)};
+}
+
+#define G6E_STRIDE16 264      // bf16 staging row: 128 columns x 2 B + 8 (ds_write_b64 / ds_read_b64 conflict-free)
+#define G6E_STRIDE32 528      // f32 staging row: 128 columns x 4 B + 16 (ds_write_b128 / ds_read_b128 conflict-free)
+#define G6E_REGION_BYTES (32 * G6E_STRIDE32)
+
+// this lane's 64 bias values in accumulator order (the accumulators start from them)
+__device__ __forceinline__ void g6_bias_init(f32x16_t (&init)[4], const float* bias, int64_t ncol0, int64_t N) {
+  const int half = (threadIdx.x & 63) >> 5;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = ncol0 + ni * 32 + 8 * j + 4 * half;
+      f32x4_t b = {0.f, 0.f, 0.f, 0.f};
+      if (bias && n < N) b = *(const f32x4_t*)(bias + n);       // N % 4 == 0 and bias 16-byte aligned (wide_ok)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) init[ni][4 * j + e] = b[e];
+    }
+}
+
+// PROBE (tools/gemm_epilogue_probe.hip only): bit 0 drops the LDS writes, bit 2 the global stores.
+template <typename OutT, int ACT, bool TRAIN, bool RESID, int PROBE = 0>
+__device__ __forceinline__ void store_wave_tile6(f32x16_t (&acc)[4][4], int64_t mrow0, int64_t ncol0, OutT* C,
+                                                 int64_t ldc, int64_t M, int64_t N, const GemmEpilogue& ep,
+                                                 const EpiScalars& es, char* region) {
+  constexpr bool STAGE16 = sizeof(OutT) == 2 && !RESID;
+  constexpr int STRIDE = STAGE16 ? G6E_STRIDE16 : G6E_STRIDE32;
+  constexpr int SB = STAGE16 ? 2 : 4;           // staged bytes per element
+  constexpr int VEC = OutVec<OutT>::VEC;        // elements per 16-byte output vector
+  constexpr int CPR = 128 / VEC;                // vectors per patch row
+  constexpr int RPI = 64 / CPR;                 // rows covered by one 64-lane pass
+  constexpr int ITER = 32 / RPI;
+  const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+  const int rl = lane / CPR, c = lane % CPR;
+  const int64_t rows_left64 = M - mrow0, cols_left64 = N - ncol0;
+  const int rows_left = rows_left64 > 128 ? 128 : (int)rows_left64;
+  const int cols_left = cols_left64 > 128 ? 128 : (int)cols_left64;
+  const bool col_ok = c * VEC < cols_left;
+  OutT* cp = C + (mrow0 + rl) * ldc + ncol0 + c * VEC;
+  const OutT* rp = RESID ? (const OutT*)ep.resid + (mrow0 + rl) * ep.ldr + ncol0 + c * VEC : nullptr;   // may alias C
+  char* lds_wr = region + l31 * STRIDE + half * 4 * SB;
+  const char* lds_rd = region + rl * STRIDE + c * VEC * SB;
+
+  uint4 rres[2][ITER];   // residual vectors of the patch in flight and of the next one
+#define G6E_ROW_OK(MI, IT) ((MI) * 32 + (IT) * RPI + rl < rows_left && col_ok)
+#define G6E_WRITE(MI)                                                                                      \
+  do {                                                                                                     \
+    const int64_t m = mrow0 + (MI) * 32 + l31;                                                             \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                       \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
+        const int64_t n = ncol0 + ni * 32 + 8 * j + 4 * half;                                              \
+        const f32x2_t lo = epi_pair<ACT, TRAIN, OutT>((f32x2_t){acc[MI][ni][4 * j], acc[MI][ni][4 * j + 1]}, m, n, M, N, ep, es);         \
+        const f32x2_t hi = epi_pair<ACT, TRAIN, OutT>((f32x2_t){acc[MI][ni][4 * j + 2], acc[MI][ni][4 * j + 3]}, m, n + 2, M, N, ep, es); \
+        char* dst = lds_wr + (ni * 32 + 8 * j) * SB;                                                       \
+        if (PROBE & 1) { asm volatile("" :: "v"(lo), "v"(hi)); }                                           \
+        else if (STAGE16) *(uint2*)dst = make_uint2(pack_bf16x2(lo[0], lo[1]), pack_bf16x2(hi[0], hi[1])); \
+        else *(f32x4_t*)dst = (f32x4_t){lo[0], lo[1], hi[0], hi[1]};                                       \
+      }                                                                                                    \
+  } while (0)
+#define G6E_RESID(MI)                                                                                      \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int it = 0; it < ITER; ++it)                                                    \
+      if (G6E_ROW_OK(MI, it)) rres[(MI) & 1][it] = *(const uint4*)(rp + (int64_t)((MI) * 32 + it * RPI) * ep.ldr); \
+  } while (0)
+
+  if (RESID) G6E_RESID(0);
+  G6E_WRITE(0);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    // read back patch mi
+    uint4 st16[STAGE16 ? ITER : 1];
+    f32x4_t st32[STAGE16 ? 1 : ITER][VEC / 4];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const char* src = lds_rd + it * RPI * STRIDE;
+      if (STAGE16) {
+        const uint2 a = *(const uint2*)src, b = *(const uint2*)(src + 8);
+        st16[it] = make_uint4(a.x, a.y, b.x, b.y);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC / 4; ++e) st32[it][e] = *(const f32x4_t*)(src + e * 16);
+      }
+    }
+    if (mi + 1 < 4) {
+      G6E_WRITE(mi + 1);
+      if (RESID) G6E_RESID(mi + 1);
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      if (G6E_ROW_OK(mi, it)) {
+        uint4 packed;
+        if (STAGE16) {
+          packed = st16[it];
+        } else {
+          float xv[VEC];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) xv[e] = st32[it][e >> 2][e & 3];
+          if (RESID) {
+            float rv[VEC];
+            OutVec<OutT>::unpack(rres[mi & 1][it], rv);
+            if (es.mul) {                                  // T5 gated FFN: act(wi_0 x) * (wi_1 x)
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) xv[e] *= rv[e];
+            } else {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) xv[e] = epi_resid<ACT>(xv[e], rv[e], false);
+            }
+          }
+          packed = OutVec<OutT>::pack(xv);
+        }
+        if (PROBE & 4) asm volatile("" :: "v"(packed.x), "v"(packed.y), "v"(packed.z), "v"(packed.w));
+        else *(uint4*)(cp + (int64_t)(mi * 32 + it * RPI) * ldc) = packed;
+      }
+    }
+  }
+#undef G6E_ROW_OK
+#undef G6E_WRITE
+#undef G6E_RESID
+}

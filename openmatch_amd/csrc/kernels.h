@@ -37,10 +37,10 @@ struct GemmEpilogue {
 // wide-tile generations, one translation unit each (gemm_wide4.hip / gemm_wide6_*.hip); omk_gemm dispatches
 int omk_gemm_wide4(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int out_dtype,
                    void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s);
-bool omk_gemm_wide6_b16_has(int in_dtype, int out_dtype, int act, bool train);
+bool omk_gemm_wide6_b16_has(int in_dtype, int out_dtype, int act, bool train, bool resid);
 int omk_gemm_wide6_b16(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int out_dtype,
                        void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s);
-bool omk_gemm_wide6_f32_has(int in_dtype, int out_dtype, int act, bool train);
+bool omk_gemm_wide6_f32_has(int in_dtype, int out_dtype, int act, bool train, bool resid);
 int omk_gemm_wide6_f32(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int out_dtype,
                        void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s);
 int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int out_dtype,

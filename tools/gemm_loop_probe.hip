@@ -11,7 +11,8 @@ template <int PROBE>
 __global__ __launch_bounds__(G6_THREADS) void probe(const bf16_t* A, const bf16_t* B, float* sink, long long* ticks, int64_t K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x16_t acc[4][4];
-  const float zero[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x16_t zero[4];
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) zero[i][r] = 0.f;
   const long long t0 = clock64();
   gemm_mainloop6<bf16_t, PROBE>(A, 0, B, 0, 1 << 20, 1 << 20, K, (int64_t)blockIdx.x * 256, 0, smem, acc, zero, nullptr);
   const long long t1 = clock64();
