@@ -44,19 +44,11 @@ __device__ __forceinline__ void g6_read(typename MmaOps<T>::frag_t (&a)[4], type
 // -- the layout gemm_epilogue6.h streams out.  acc[.][ni] starts at init[ni] (the bias in that order, or 0).
 // PROBE (tools/gemm_loop_probe.hip only; 0 in the product): bit 0 drops the steady-state DMA issue,
 // bit 1 the fragment reads, bit 2 the per-step barrier -- to attribute the cycles of a K step.
-template <typename T, int PROBE = 0>
-__device__ inline void gemm_mainloop6(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
-                                      int64_t ldb, int64_t M, int64_t N, int64_t K, int64_t m0,
-                                      int64_t n0, char* smem, f32x16_t (&acc)[4][4],
-                                      const f32x16_t (&init)[4], unsigned long long* tr = nullptr) {
-  typedef typename MmaOps<T>::frag_t frag_t;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..3
-  const int wm = wave >> 1, wn = wave & 1;
-
-  const char* pa[4];
-  const char* pb[4];
+// Per-lane DMA source pointers of tile (m0, n0): 4 + 4 rows, swizzled chunk (see gemm_core4.h).
+template <typename T>
+__device__ __forceinline__ void g6_point(const char* (&pa)[4], const char* (&pb)[4], const T* __restrict__ A,
+                                         int64_t lda, const T* __restrict__ B, int64_t ldb, int64_t M, int64_t N,
+                                         int64_t m0, int64_t n0, int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = (i * 4 + wave) * 16 + (lane >> 2);
@@ -66,27 +58,39 @@ __device__ inline void gemm_mainloop6(const T* __restrict__ A, int64_t lda, cons
     pa[i] = (const char*)(A + ra * lda) + c * 16;
     pb[i] = (const char*)(B + rb * ldb) + c * 16;
   }
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = init[ni][r];   // the columns' bias (or 0)
+}
 
-  const int nk = (int)((K * (int64_t)sizeof(T)) / G4_ROW_BYTES);
+// Start a tile: K steps 0 and 1 go into ring slots 0 and 1.  The persistent kernel calls this for the
+// NEXT tile before it runs the epilogue of the current one.
+__device__ __forceinline__ void g6_begin(const char* const (&pa)[4], const char* const (&pb)[4], int nk,
+                                         char* smem, int wave) {
+  g6_stage(pa, pb, 0, smem, wave);
+  if (nk > 1) g6_stage(pa, pb, G4_ROW_BYTES, smem + G4_STAGE_BYTES, wave);
+}
+
+// The K loop of one tile whose steps 0 and 1 are already in flight (g6_begin).  Issues step 2, then
+// waits for everything older (steps 0, 1 -- and, in the persistent kernel, the previous tile's
+// epilogue stores: vmcnt retires in order).  acc must be initialised by the caller.
+template <typename T, int PROBE = 0>
+__device__ inline void gemm_mainloop6_run(const char* (&pa)[4], const char* (&pb)[4], int nk, char* smem,
+                                          f32x16_t (&acc)[4][4], unsigned long long* tr = nullptr) {
+  typedef typename MmaOps<T>::frag_t frag_t;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..3
+  const int wm = wave >> 1, wn = wave & 1;
   const int key = (lane >> 2) & 3;
   const int half = lane >> 5;
   const int slot0 = ((half ^ key) << 4), slot1 = (((2 | half) ^ key) << 4);
   const int rowa = (wm * 128 + (lane & 31)) * G4_ROW_BYTES;
   const int rowb = G4_OPERAND_BYTES + (wn * 128 + (lane & 31)) * G4_ROW_BYTES;
 
-  if (tr && tid == 0) tr[1] = clock64();
-  g6_stage(pa, pb, 0, smem, wave);
-  if (nk > 1) g6_stage(pa, pb, G4_ROW_BYTES, smem + G4_STAGE_BYTES, wave);
-  if (nk > 2) g6_stage(pa, pb, 2 * G4_ROW_BYTES, smem + 2 * G4_STAGE_BYTES, wave);
-  if (nk > 2) __builtin_amdgcn_s_waitcnt(0x4070);
-  else if (nk > 1) __builtin_amdgcn_s_waitcnt(0x0078);
-  else __builtin_amdgcn_s_waitcnt(0x0070);
+  if (nk > 2) {
+    g6_stage(pa, pb, 2 * G4_ROW_BYTES, smem + 2 * G4_STAGE_BYTES, wave);
+    __builtin_amdgcn_s_waitcnt(0x0078);      // vmcnt(8): all but step 2
+  } else {
+    __builtin_amdgcn_s_waitcnt(0x0070);
+  }
   __builtin_amdgcn_s_barrier();
 
   frag_t a0[4], b0[4], a1[4], b1[4];
@@ -141,3 +145,27 @@ __device__ inline void gemm_mainloop6(const T* __restrict__ A, int64_t lda, cons
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                             // everyone is done with the ring
 }
+
+// One tile start to finish (the non-persistent kernels and the probes).
+template <typename T, int PROBE = 0>
+__device__ inline void gemm_mainloop6(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
+                                      int64_t ldb, int64_t M, int64_t N, int64_t K, int64_t m0,
+                                      int64_t n0, char* smem, f32x16_t (&acc)[4][4],
+                                      const f32x16_t (&init)[4], unsigned long long* tr = nullptr) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const char* pa[4];
+  const char* pb[4];
+  g6_point<T>(pa, pb, A, lda, B, ldb, M, N, m0, n0, wave, lane);
+  const int nk = (int)((K * (int64_t)sizeof(T)) / G4_ROW_BYTES);
+  if (tr && threadIdx.x == 0) tr[1] = clock64();
+  g6_begin(pa, pb, nk, smem, wave);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = init[ni][r];   // the columns' bias (or 0)
+  gemm_mainloop6_run<T, PROBE>(pa, pb, nk, smem, acc, tr);
+}
+

@@ -34,6 +34,10 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel6(
   if (tr && threadIdx.x == 0) { tr[28] = clock64(); tr[29] = blockIdx.x; }
 }
 
+// A persistent form (one workgroup per CU walking tiles, the next tile's first two K steps issued
+// before the epilogue) was measured and dropped twice (v5, v6p: 3-8 % SLOWER): vmcnt retires in
+// order, so waiting for the prefetched operands also waits for the acknowledgement of every store of
+// the epilogue in front of them, which costs more than the cold start it hides.
 template <typename T, typename OutT, int ACT, bool TRAIN, bool RESID>
 static int launch6(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                    int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
