@@ -1,4 +1,4 @@
-// Fourth-generation NT GEMM main loop for gfx950: the 256 x 256 tile of gemm_core3.h fed through a
+// Fourth-generation NT GEMM main loop for gfx950: a 256 x 256 tile on eight waves fed through a
 // 4-deep ring of HALF-depth stages (K step = 64 bytes: 32 bf16 / 16 f32).
 //
 // Why (profiles/r01_gemm_variants_trace.log): with two 64 KiB stages only ONE stage (64 KiB per CU)

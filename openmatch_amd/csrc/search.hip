@@ -23,7 +23,7 @@
 #include <algorithm>
 
 #include "gemm_core2.h"
-#include "gemm_core3.h"
+#include "gemm_core6.h"
 #include "kernels.h"
 
 #define SORT_CAP 8192      // keys one workgroup sorts in LDS (64 KiB)
@@ -76,34 +76,55 @@ __global__ __launch_bounds__(G2_THREADS) void sim_filter_kernel(
   }
 }
 
-// same scan on the 256 x 256 tile (gemm_core3.h) for query batches wider than one 128 tile
+// The scan for query batches wider than one 128 tile: 256 queries x 256 index rows per workgroup on
+// the one-wave-per-SIMD main loop of gemm_core6.h.  The QUERIES are its A operand, so (operands
+// swapped inside, see there) a lane owns one query and its registers walk index rows:
+//   acc[mi][ni][r] = <query q0 + wm*128 + mi*32 + (lane&31),  row r0 + wn*128 + ni*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)>
+// The filter first takes the maximum of each 16-register tile (8 v_max3) and only walks the tile
+// when some lane of the wave has a survivor -- survivors are rare by construction of theta.
 template <typename T>
-__global__ __launch_bounds__(G3_THREADS) void sim_filter_kernel3(
+__global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel6(
     const T* __restrict__ rows, int64_t nrows, uint32_t row_base, const T* __restrict__ queries,
     int64_t nq, int64_t d, const float* __restrict__ thr, u64* __restrict__ keys,
     unsigned* __restrict__ cnt, int group_m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int64_t m0, n0;
-  g3_tile_coords(nrows, nq, group_m, m0, n0);
-  f32x16_t acc[4][2];
-  gemm_mainloop3<T>(rows, d, queries, d, nrows, nq, d, m0, n0, smem, acc);
+  // `group_m` index-row tiles stay resident (L2) while every query tile sweeps over them
+  const int64_t ntr = (nrows + G4_BN - 1) / G4_BN, ntq = (nq + G4_BM - 1) / G4_BM;
+  int64_t tr_, tq_;
+  gemm_tile_coords(ntr, ntq, group_m, tr_, tq_);
+  const int64_t q0 = tq_ * G4_BM, r0 = tr_ * G4_BN;
+  f32x16_t acc[4][4];
+  {
+    f32x16_t zero[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zero[i][r] = 0.f;
+    gemm_mainloop6<T>(queries, d, rows, d, nq, nrows, d, q0, r0, smem, acc, zero);
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave >> 1, wn = wave & 1;
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int64_t q = n0 + wn * 64 + ni * 32 + (lane & 31);
-    if (q >= nq) continue;
-    const float th = thr[q];
+  for (int mi = 0; mi < 4; ++mi) {
+    const int64_t q = q0 + wm * 128 + mi * 32 + (lane & 31);
+    const float th = q < nq ? thr[q] : __builtin_inff();
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int64_t mbase = m0 + wm * 128 + mi * 32 + 4 * (lane >> 5);
+    for (int ni = 0; ni < 4; ++ni) {
+      const f32x16_t a = acc[mi][ni];
+      float mx = fmaxf(fmaxf(a[0], a[1]), a[2]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t m = mbase + (r & 3) + 8 * (r >> 2);
-        const float v = acc[mi][ni][r];
-        if (m < nrows && v >= th) {
-          const unsigned pos = atomicAdd(cnt + q, 1u);
-          if (pos < SORT_CAP) keys[q * SORT_CAP + pos] = pack_key(v, row_base + (uint32_t)m);
+      for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, a[r]), a[r + 1]);
+      mx = fmaxf(mx, a[15]);
+      if (mx >= th) {
+        const int64_t nbase = r0 + wn * 128 + ni * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t n = nbase + (r & 3) + 8 * (r >> 2);
+          const float v = a[r];
+          if (n < nrows && v >= th) {
+            const unsigned pos = atomicAdd(cnt + q, 1u);
+            if (pos < SORT_CAP) keys[q * SORT_CAP + pos] = pack_key(v, row_base + (uint32_t)n);
+          }
         }
       }
     }
@@ -393,7 +414,7 @@ struct Scan {
   }
   int filter_step(int64_t r0, int64_t n, bool bf16) {
     const bool wide = nq > 128;
-    const int64_t ntm = (n + 255) / 256, ntn = wide ? (nq + G3_BN - 1) / G3_BN : (nq + G2_BN - 1) / G2_BN;
+    const int64_t ntm = (n + 255) / 256, ntn = wide ? (nq + G4_BM - 1) / G4_BM : (nq + G2_BN - 1) / G2_BN;
     if (ntm * ntn > 0x7fffffffLL) OM_FAIL("scan grid too large");
     const bool timing = om_timing_on();
     if (timing) om_timing_begin(OM_TIMING_SCAN, s);
@@ -402,10 +423,10 @@ struct Scan {
   hipLaunchKernelGGL((KERNEL<TT>), grid, dim3(THREADS), LDS, s, ROWS + r0 * d, n, (uint32_t)r0, QUERIES, \
                      nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8)
     if (bf16) {
-      if (wide) SCAN(sim_filter_kernel3, G3_THREADS, G3_LDS_BYTES, f16_t, idx16, ws.qb);
+      if (wide) SCAN(sim_filter_kernel6, G6_THREADS, G4_LDS_BYTES, f16_t, idx16, ws.qb);
       else SCAN(sim_filter_kernel, G2_THREADS, G2_LDS_BYTES, f16_t, idx16, ws.qb);
     } else {
-      if (wide) SCAN(sim_filter_kernel3, G3_THREADS, G3_LDS_BYTES, float, idx32, q32);
+      if (wide) SCAN(sim_filter_kernel6, G6_THREADS, G4_LDS_BYTES, float, idx32, q32);
       else SCAN(sim_filter_kernel, G2_THREADS, G2_LDS_BYTES, float, idx32, q32);
     }
 #undef SCAN
@@ -519,10 +540,10 @@ extern "C" int om_sim_topk(int mode, const float* queries, int64_t n_queries,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel<f16_t>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
-    OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel3<float>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
-    OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel3<f16_t>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
+    OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel6<float>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES));
+    OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel6<f16_t>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES));
     attr_set = true;
   }
   for (auto& v : g_info) v = 0;
