@@ -9,12 +9,22 @@
 // port).  With one wave per SIMD nothing else hides latency, so the loop is software pipelined:
 // the fragments of sub-step kk+1 are read while the 16 MFMAs of sub-step kk issue.
 //
-//   stage = A tile [256 rows][64 B] + B tile [256 rows][64 B], ring of 4 (same layout/swizzle as v4)
+//   stage = A tile [256 rows][64 B] + B tile [256 rows][64 B], ring of G6_STAGES (layout/swizzle as v4)
 //   per wave and stage: 4 + 4 global_load_lds_dwordx4 (vmcnt counts 8 per stage)
 #pragma once
 #include "gemm_core4.h"
 
 #define G6_THREADS 256
+// Ring depth: 4 x 32 KiB, three K steps in flight (2.5 steps ~ 2.8 k cycles of lead).  5 slots (the
+// whole 160 KiB LDS, 3.5 steps of lead) were measured and are SLOWER (K step 1489 -> 1520 cycles at
+// M = 131072, N = K = 768; encoder shapes -3..-15 %): the K loop's stalls on streamed operands are a
+// throughput limit of the L2 / fabric path, not a latency one, and more requests in flight only
+// queue.  -DG6_STAGES=5 rebuilds that variant.
+#ifndef G6_STAGES
+#define G6_STAGES 4
+#endif
+#define G6_AHEAD (G6_STAGES - 1)
+#define G6_LDS_BYTES (G6_STAGES * G4_STAGE_BYTES)
 
 __device__ inline void g6_stage(const char* const (&pa)[4], const char* const (&pb)[4], size_t kbyte,
                                 char* slot, int wave) {
@@ -85,12 +95,14 @@ __device__ inline void gemm_mainloop6_run(const char* (&pa)[4], const char* (&pb
   const int rowa = (wm * 128 + (lane & 31)) * G4_ROW_BYTES;
   const int rowb = G4_OPERAND_BYTES + (wn * 128 + (lane & 31)) * G4_ROW_BYTES;
 
-  if (nk > 2) {
-    g6_stage(pa, pb, 2 * G4_ROW_BYTES, smem + 2 * G4_STAGE_BYTES, wave);
-    __builtin_amdgcn_s_waitcnt(0x0078);      // vmcnt(8): all but step 2
-  } else {
-    __builtin_amdgcn_s_waitcnt(0x0070);
-  }
+  // steps 2 .. G6_AHEAD-1 join steps 0, 1; then wait until only those newer than step 0 are outstanding
+  const int pre = nk < G6_AHEAD ? nk : G6_AHEAD;
+  for (int sidx = 2; sidx < pre; ++sidx) g6_stage(pa, pb, (size_t)sidx * G4_ROW_BYTES, smem + sidx * G4_STAGE_BYTES, wave);
+  // s_waitcnt immediates (gfx9 encoding: vmcnt = [15:14][3:0], expcnt [6:4] = 7 "no wait", lgkmcnt [11:8] = 0)
+  if (pre >= 4) __builtin_amdgcn_s_waitcnt(0x4078);        // vmcnt(24)
+  else if (pre == 3) __builtin_amdgcn_s_waitcnt(0x4070);   // vmcnt(16)
+  else if (pre == 2) __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8)
+  else __builtin_amdgcn_s_waitcnt(0x0070);
   __builtin_amdgcn_s_barrier();
 
   frag_t a0[4], b0[4], a1[4], b1[4];
@@ -104,8 +116,8 @@ __device__ inline void gemm_mainloop6_run(const char* (&pa)[4], const char* (&pb
   // a 1024-cycle step when they sit in front of the MFMAs (tools/gemm_loop_probe.hip).
 #define G6_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define G6_DMA(P, I, OFF)                                                                                \
-  __builtin_amdgcn_global_load_lds((gptr_t)(P[I] + (size_t)(t + 3) * G4_ROW_BYTES),                      \
-                                   (lptr_t)(smem + ((t + 3) & 3) * G4_STAGE_BYTES + (OFF) + ((I) * 4 + wave) * 1024), 16, 0, 0)
+  __builtin_amdgcn_global_load_lds((gptr_t)(P[I] + (size_t)(t + G6_AHEAD) * G4_ROW_BYTES),               \
+                                   (lptr_t)(smem + o_far + (OFF) + ((I) * 4 + wave) * 1024), 16, 0, 0)
 #define G6_HALF(AF, BF, AN, BN, SRC, SLOT, DO_READ, DO_DMA, P, OFF)                                      \
   _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                       \
     MmaOps<T>::mma(BF[q & 3], AF[q >> 2], acc[q >> 2][q & 3]);                                           \
@@ -121,20 +133,28 @@ __device__ inline void gemm_mainloop6_run(const char* (&pa)[4], const char* (&pb
   }
 #define G6_STEP(ISSUE, VMW, NEXT)                                                                        \
   do {                                                                                                   \
-    const char* cur = smem + (t & 3) * G4_STAGE_BYTES;                                                   \
-    const char* nxt = smem + ((t + 1) & 3) * G4_STAGE_BYTES;                                             \
+    const char* cur = smem + o_cur;                                                                      \
+    const char* nxt = smem + o_nxt;                                                                      \
     if (tr && tid == 0 && t < 12) tr[3 + t] = clock64();                                                 \
-    /* slot (t+3)&3 held tile t-1: every wave finished reading it before the barrier of step t-1 */      \
+    /* slot o_far held tile t-1: every wave finished reading it before the barrier of step t-1 */        \
     G6_HALF(a0, b0, a1, b1, cur, slot1, !(PROBE & 2), (ISSUE) && !(PROBE & 1), pa, 0)                    \
     __builtin_amdgcn_s_waitcnt(VMW);     /* vmcnt(n) lgkmcnt(0): tile t+1 landed, my reads done */       \
     if (!(PROBE & 4)) __builtin_amdgcn_s_barrier();                                                      \
     G6_FENCE();                                                                                          \
     G6_HALF(a1, b1, a0, b0, nxt, slot0, (NEXT) && !(PROBE & 2), (ISSUE) && !(PROBE & 1), pb, G4_OPERAND_BYTES) \
+    o_cur = o_nxt;                                                                                       \
+    o_nxt = o_nxt + G4_STAGE_BYTES == G6_LDS_BYTES ? 0 : o_nxt + G4_STAGE_BYTES;                         \
+    o_far = o_far + G4_STAGE_BYTES == G6_LDS_BYTES ? 0 : o_far + G4_STAGE_BYTES;                         \
   } while (0)
 
   int t = 0;
-  // s_waitcnt immediates (gfx9 encoding: vmcnt = [15:14][3:0], expcnt [6:4] = 7 "no wait", lgkmcnt [11:8] = 0)
-  for (; t + 3 < nk; ++t) G6_STEP(true, 0x007C, true);      // vmcnt(12): tile t+2 and the A half of t+3 may be in flight
+  int o_cur = 0, o_nxt = G4_STAGE_BYTES, o_far = G6_AHEAD * G4_STAGE_BYTES;   // ring offsets of steps t, t+1, t+G6_AHEAD
+#if G6_STAGES == 5
+  for (; t + 4 < nk; ++t) G6_STEP(true, 0x4074, true);      // vmcnt(20): t+2, t+3 and the A half of t+4 may be in flight
+  if (t + 3 < nk) { G6_STEP(false, 0x4070, true); ++t; }    // vmcnt(16): t+2, t+3
+#else
+  for (; t + 3 < nk; ++t) G6_STEP(true, 0x007C, true);      // vmcnt(12): t+2 and the A half of t+3
+#endif
   if (t + 2 < nk) { G6_STEP(false, 0x0078, true); ++t; }    // vmcnt(8):  t+2
   if (t + 1 < nk) { G6_STEP(false, 0x0070, true); ++t; }    // vmcnt(0)
   G6_STEP(false, 0x0070, false);                            // last tile

@@ -46,14 +46,14 @@ static int launch6(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   static bool attr_set = false;
   if (!attr_set) {
     OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel6<T, OutT, ACT, TRAIN, RESID>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES));
     attr_set = true;
   }
   const int tclass = sizeof(T) == 2 ? OM_TIMING_GEMM_BF16 : OM_TIMING_GEMM_F32;
   const bool timing = om_timing_on();
   if (timing) om_timing_begin(tclass, s);
   // sweep order: 8 row tiles stay resident while the column tiles are walked (L2 reuse per XCD)
-  hipLaunchKernelGGL((gemm_nt_kernel6<T, OutT, ACT, TRAIN, RESID>), dim3((unsigned)nwg), dim3(G6_THREADS), G4_LDS_BYTES, s,
+  hipLaunchKernelGGL((gemm_nt_kernel6<T, OutT, ACT, TRAIN, RESID>), dim3((unsigned)nwg), dim3(G6_THREADS), G6_LDS_BYTES, s,
                      (const T*)A, lda, (const T*)B, ldb, (OutT*)C, ldc, M, N, K, ep, 8);
   if (timing) om_timing_end(tclass, s, 2.0 * (double)M * (double)N * (double)K);
   OM_LAUNCH_CHECK();

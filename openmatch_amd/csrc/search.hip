@@ -423,10 +423,10 @@ struct Scan {
   hipLaunchKernelGGL((KERNEL<TT>), grid, dim3(THREADS), LDS, s, ROWS + r0 * d, n, (uint32_t)r0, QUERIES, \
                      nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8)
     if (bf16) {
-      if (wide) SCAN(sim_filter_kernel6, G6_THREADS, G4_LDS_BYTES, f16_t, idx16, ws.qb);
+      if (wide) SCAN(sim_filter_kernel6, G6_THREADS, G6_LDS_BYTES, f16_t, idx16, ws.qb);
       else SCAN(sim_filter_kernel, G2_THREADS, G2_LDS_BYTES, f16_t, idx16, ws.qb);
     } else {
-      if (wide) SCAN(sim_filter_kernel6, G6_THREADS, G4_LDS_BYTES, float, idx32, q32);
+      if (wide) SCAN(sim_filter_kernel6, G6_THREADS, G6_LDS_BYTES, float, idx32, q32);
       else SCAN(sim_filter_kernel, G2_THREADS, G2_LDS_BYTES, float, idx32, q32);
     }
 #undef SCAN
@@ -541,9 +541,9 @@ extern "C" int om_sim_topk(int mode, const float* queries, int64_t n_queries,
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel<f16_t>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel6<float>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES));
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel6<f16_t>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES));
     attr_set = true;
   }
   for (auto& v : g_info) v = 0;

@@ -23,11 +23,11 @@ __global__ __launch_bounds__(G6_THREADS) void probe(const bf16_t* A, const bf16_
 }
 
 template <int PROBE> static void run(const char* what, const bf16_t* A, const bf16_t* B, float* sink, long long* ticks, int64_t K, int blocks) {
-  hipFuncSetAttribute((const void*)probe<PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
+  hipFuncSetAttribute((const void*)probe<PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL(probe<PROBE>, dim3(blocks), dim3(G6_THREADS), G4_LDS_BYTES, 0, A, B, sink, ticks, K);
+  hipLaunchKernelGGL(probe<PROBE>, dim3(blocks), dim3(G6_THREADS), G6_LDS_BYTES, 0, A, B, sink, ticks, K);
   hipEventRecord(e0, 0);
-  hipLaunchKernelGGL(probe<PROBE>, dim3(blocks), dim3(G6_THREADS), G4_LDS_BYTES, 0, A, B, sink, ticks, K);
+  hipLaunchKernelGGL(probe<PROBE>, dim3(blocks), dim3(G6_THREADS), G6_LDS_BYTES, 0, A, B, sink, ticks, K);
   hipEventRecord(e1, 0);
   hipDeviceSynchronize();
   float ms = 0; hipEventElapsedTime(&ms, e0, e1);
