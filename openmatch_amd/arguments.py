@@ -62,8 +62,16 @@ class DataArguments:
     doc_column_names: str = _f("id,title,text", "tsv columns of the corpus file")
 
 
+# `--overwrite_output_dir` is read by the reference's training drivers (train_dr.py:31-39) but
+# transformers >= 5 no longer defines it on TrainingArguments; declared below when missing so the
+# reference's command lines keep parsing on either version.
+_HAS_OVERWRITE = any(f.name == "overwrite_output_dir" for f in __import__("dataclasses").fields(TrainingArguments))
+
+
 @dataclass
 class DRTrainingArguments(TrainingArguments):
+    if not _HAS_OVERWRITE:
+        overwrite_output_dir: bool = _f(False, "allow a non-empty output_dir")
     warmup_ratio: float = _f(0.1)
     remove_unused_columns: Optional[bool] = _f(False, "keep every dataset column")
     negatives_x_device: bool = _f(False, "use every rank's passages as negatives")
@@ -75,6 +83,8 @@ class DRTrainingArguments(TrainingArguments):
 
 @dataclass
 class RRTrainingArguments(TrainingArguments):
+    if not _HAS_OVERWRITE:
+        overwrite_output_dir: bool = _f(False, "allow a non-empty output_dir")
     warmup_ratio: float = _f(0.1)
     remove_unused_columns: Optional[bool] = _f(False, "keep every dataset column")
     margin: float = _f(1.0)

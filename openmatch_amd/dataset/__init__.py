@@ -1,1 +1,3 @@
-from .data_collator import DRInferenceCollator, QPCollator, RRInferenceCollator
+from .data_collator import DRInferenceCollator, PairCollator, QPCollator, RRInferenceCollator
+from .inference_dataset import InferenceDataset, JsonlDataset, TsvDataset
+from .train_dataset import DREvalDataset, DRTrainDataset, RREvalDataset, RRTrainDataset

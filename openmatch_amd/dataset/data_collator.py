@@ -24,6 +24,19 @@ class QPCollator(DataCollatorWithPadding):
 
 
 @dataclass
+class PairCollator(DataCollatorWithPadding):
+    """List of {"pos_pair": enc, "neg_pair": enc} -> (positive pairs, negative pairs), both padded to
+    q_max_len + p_max_len + 2 (the cross-encoder's fixed [B,162] shape; reference :43-75)."""
+    max_q_len: int = 32
+    max_p_len: int = 128
+
+    def __call__(self, features):
+        n = self.max_q_len + self.max_p_len + 2
+        pad = lambda items: self.tokenizer.pad(items, padding="max_length", max_length=n, return_tensors="pt")
+        return pad(_flatten([f["pos_pair"] for f in features])), pad(_flatten([f["neg_pair"] for f in features]))
+
+
+@dataclass
 class DRInferenceCollator(DefaultDataCollator):
     """(text ids, tensor batch) for the encoding loops (reference :78-83)."""
 
