@@ -20,9 +20,24 @@ logger = logging.getLogger(__name__)
 
 
 def encode_pair(tokenizer, item1, item2, max_len_1=32, max_len_2=128):
-    """[CLS] q [SEP] d [SEP] padded to max_len_1 + max_len_2 + 2 (= 162), reference :23-29."""
-    return tokenizer.encode_plus(item1, item2, truncation='longest_first', padding='max_length',
-                                 max_length=max_len_1 + max_len_2 + 2)
+    """Two token-id lists -> [CLS] q [SEP] d [SEP] padded to max_len_1 + max_len_2 + 2 (= 162) with
+    type ids 0/1 and a mask -- what the reference gets from `tokenizer.encode_plus(ids, ids,
+    truncation='longest_first', padding='max_length')` (reranker.py:23-29) under transformers 4.x.
+    transformers 5 has no id-list entry point any more, so the same rule is applied directly."""
+    n = max_len_1 + max_len_2 + 2
+    if hasattr(tokenizer, "prepare_for_model"):
+        return tokenizer.prepare_for_model(item1, item2, truncation="longest_first", padding="max_length", max_length=n)
+    a, b = list(item1), list(item2)
+    while len(a) + len(b) > n - 3:              # longest first; a tie shortens the second sequence
+        if len(a) > len(b):
+            a.pop()
+        else:
+            b.pop()
+    ids = [tokenizer.cls_token_id] + a + [tokenizer.sep_token_id] + b + [tokenizer.sep_token_id]
+    types = [0] * (len(a) + 2) + [1] * (len(b) + 1)
+    pad = n - len(ids)
+    return {"input_ids": ids + [tokenizer.pad_token_id] * pad, "token_type_ids": types + [0] * pad,
+            "attention_mask": [1] * len(ids) + [0] * pad}
 
 
 def add_to_result_dict(result_dicts, qids, dids, scores):

@@ -1,1 +1,2 @@
 from .dense_trainer import DRTrainer, GCDenseTrainer
+from .reranker_trainer import RRTrainer

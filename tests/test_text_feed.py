@@ -199,3 +199,17 @@ def test_drivers_end_to_end(tok, tmp_path):
                              "--max_steps", 3, "--learning_rate", 1e-4, "--logging_steps", 1, "--save_steps", 1000])
     saved = set(os.listdir(out))
     assert {"openmatch_config.json", "config.json"} <= saved and saved & {"vocab.txt", "tokenizer.json"}
+    # cross-encoder: train_rr on the same groups, then rerank the first-stage run with the result
+    rr = tmp_path / "trained_rr"
+    _run_driver("train_rr", ["--model_name_or_path", ckpt, "--output_dir", rr, "--do_train",
+                             "--train_path", os.path.join(TEXT, "train.jsonl"), "--q_max_len", 8, "--p_max_len", 24,
+                             "--per_device_train_batch_size", 2, "--max_steps", 3, "--learning_rate", 1e-4,
+                             "--logging_steps", 1, "--save_steps", 1000, "--loss_fn", "bce", "--projection_in_dim", 128])
+    assert "openmatch_config.json" in os.listdir(rr)
+    _run_driver("rerank", ["--model_name_or_path", rr, "--output_dir", tmp_path / "rr_out", "--per_device_eval_batch_size", 8,
+                           "--trec_run_path", tmp_path / "run.trec", "--reranking_depth", 5,
+                           "--trec_save_path", tmp_path / "reranked.trec"] + CORPUS_FLAGS + QUERY_FLAGS)
+    reranked = load_from_trec(str(tmp_path / "reranked.trec"))
+    for q in qry_ids:
+        first5 = sorted(run[q], key=run[q].get, reverse=True)[:5]
+        assert set(reranked[q]) == set(first5)
