@@ -182,7 +182,7 @@ def main():
         except Exception:
             traffic = None
     roofline = {
-        "kernel": "gemm_nt_kernel<%s> (encoder QKV / out-proj / FFN contractions)" % a.precision,
+        "kernel": "gemm_nt_kernel6<%s> (encoder QKV / out-proj / FFN contractions; three epilogue variants)" % a.precision,
         "bound": "mfma", "achieved": round(gemm_tflops, 1), "peak": peak, "unit": "TFLOP/s",
         "frac": round(gemm_tflops / peak, 4), "traffic": traffic,
         "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH doubled per the gfx950 note)" if traffic else None,

@@ -38,6 +38,12 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel6(
 // before the epilogue) was measured and dropped twice (v5, v6p: 3-8 % SLOWER): vmcnt retires in
 // order, so waiting for the prefetched operands also waits for the acknowledgement of every store of
 // the epilogue in front of them, which costs more than the cold start it hides.
+// row tiles that sweep the column tiles together (OM_GEMM_GROUP_M overrides, for A/B measurements)
+static int g6_group_m() {
+  static const int v = getenv("OM_GEMM_GROUP_M") ? atoi(getenv("OM_GEMM_GROUP_M")) : 8;
+  return v > 0 ? v : 8;
+}
+
 template <typename T, typename OutT, int ACT, bool TRAIN, bool RESID>
 static int launch6(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                    int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
@@ -54,7 +60,7 @@ static int launch6(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   if (timing) om_timing_begin(tclass, s);
   // sweep order: 8 row tiles stay resident while the column tiles are walked (L2 reuse per XCD)
   hipLaunchKernelGGL((gemm_nt_kernel6<T, OutT, ACT, TRAIN, RESID>), dim3((unsigned)nwg), dim3(G6_THREADS), G6_LDS_BYTES, s,
-                     (const T*)A, lda, (const T*)B, ldb, (OutT*)C, ldc, M, N, K, ep, 8);
+                     (const T*)A, lda, (const T*)B, ldb, (OutT*)C, ldc, M, N, K, ep, g6_group_m());
   if (timing) om_timing_end(tclass, s, 2.0 * (double)M * (double)N * (double)K);
   OM_LAUNCH_CHECK();
   return 0;

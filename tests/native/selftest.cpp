@@ -313,7 +313,7 @@ int main(int argc, char** argv) {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs=%d  clock=%d MHz  mem=%.1f GB  LDS/block=%zu\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000, prop.totalGlobalMem / 1e9, prop.sharedMemPerBlock);
 
-  if (what != "bench" && what != "prof" && what != "trace" && what != "shapes") {
+  if (what != "bench" && what != "prof" && what != "trace" && what != "shapes" && what != "layer") {
     // GEMM: aligned, ragged M/N tails, every epilogue, both dtypes
     test_gemm(OM_F32, 128, 128, 32, false, false, OM_ACT_NONE, OM_F32);
     test_gemm(OM_BF16, 128, 128, 64, false, false, OM_ACT_NONE, OM_F32);
@@ -392,6 +392,14 @@ int main(int argc, char** argv) {
     }
     printf("%s: %d failure(s)\n", g_fail ? "SELFTEST FAILED" : "SELFTEST PASSED", g_fail);
     return g_fail ? 1 : 0;
+  }
+  if (what == "layer") {    // the four contractions of one bert-base layer at the bench's token count
+    const int64_t M = argc > 2 ? atoll(argv[2]) : 131072;
+    bench_gemm(OM_BF16, M, 2304, 768, 0);
+    bench_gemm(OM_BF16, M, 768, 768, 0);
+    bench_gemm(OM_BF16, M, 3072, 768, OM_ACT_GELU_ERF);
+    bench_gemm(OM_BF16, M, 768, 3072, 0);
+    return 0;
   }
   if (what == "prof") {     // short run for rocprofv3 --pmc passes
     bench_gemm(OM_BF16, 32768, 768, 768, 0);
