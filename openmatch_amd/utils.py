@@ -107,3 +107,23 @@ def eval_mrr(qrel, run, cutoff=None):
         total += rr
     per_query["all"] = total / ranked_queries
     return per_query
+
+
+def eval_ndcg(qrel, run, cutoff=10):
+    """nDCG@cutoff the way trec_eval / pytrec_eval's `ndcg_cut` computes it (what the reference's BEIR
+    driver asks pytrec_eval for, driver/retrieve_beir.py:63-65): gain = the relevance grade, discount
+    1/log2(rank+1), documents ranked by descending score with ties broken by descending doc id,
+    ideal ranking from the judged documents; queries without judged relevant documents score 0 and
+    only judged queries count.  Returns {qid: value, ..., "all": mean}."""
+    import math
+    out = {}
+    for qid, judged in qrel.items():
+        if qid not in run:
+            continue
+        ranking = sorted(run[qid].items(), key=lambda kv: (kv[1], kv[0]), reverse=True)[:cutoff]
+        dcg = sum(max(judged.get(doc, 0), 0) / math.log2(i + 2) for i, (doc, _) in enumerate(ranking))
+        ideal = sorted((r for r in judged.values() if r > 0), reverse=True)[:cutoff]
+        idcg = sum(r / math.log2(i + 2) for i, r in enumerate(ideal))
+        out[qid] = dcg / idcg if idcg > 0 else 0.0
+    out["all"] = sum(out.values()) / len(out) if out else 0.0
+    return out

@@ -213,3 +213,55 @@ def test_drivers_end_to_end(tok, tmp_path):
     for q in qry_ids:
         first5 = sorted(run[q], key=run[q].get, reverse=True)[:5]
         assert set(reranked[q]) == set(first5)
+    # BEIR layout: encode + search + nDCG@10 in one command; same model, so the same ranking
+    _run_driver("retrieve_beir", ["--model_name_or_path", ckpt, "--output_dir", tmp_path / "beir_emb",
+                                  "--per_device_eval_batch_size", 8, "--data_dir", _beir_dir(tmp_path / "beir"),
+                                  "--doc_template", "<title> [SEP] <text>", "--q_max_len", 8, "--p_max_len", 24,
+                                  "--trec_save_path", tmp_path / "beir.trec"])
+    beir_run = load_from_trec(str(tmp_path / "beir.trec"))
+    assert sorted(beir_run) == ["q%d" % i for i in range(6)]
+    same = [q for q in beir_run if max(beir_run[q], key=beir_run[q].get) == max(run[q], key=run[q].get)]
+    assert len(same) >= 5          # d101 lost its title in the BEIR copy; everything else is identical
+
+
+# ---------------------------------------------------------------------------------- BEIR
+def _beir_dir(path):
+    """The fixture corpus / queries in BEIR layout, with graded judgements."""
+    os.makedirs(path / "qrels")
+    with open(path / "corpus.jsonl", "w") as f:
+        for line in open(os.path.join(TEXT, "corpus.tsv")):
+            did, title, text = line.rstrip("\n").split("\t")
+            f.write(json.dumps({"_id": did, "title": "" if did == "d101" else title, "text": text}) + "\n")
+    with open(path / "queries.jsonl", "w") as f:
+        for line in open(os.path.join(TEXT, "queries.tsv")):
+            qid, text = line.rstrip("\n").split("\t")
+            f.write(json.dumps({"_id": qid, "text": text, "metadata": {}}) + "\n")
+    with open(path / "qrels" / "test.tsv", "w") as f:
+        f.write("query-id\tcorpus-id\tscore\n")
+        for i in range(6):                      # q6..q8 have no judgements: they are not encoded
+            f.write("q%d\td%d\t2\nq%d\td%d\t1\nq%d\td%d\t0\n" % (i, 100 + i, i, 110 + i, i, 120))
+    return path
+
+
+def test_beir_dataset_and_ndcg(tok, tmp_path):
+    from openmatch.dataset import BEIRDataset
+    from openmatch.utils import eval_ndcg
+    beir = BEIRDataset(tok, data_args(data_dir=str(_beir_dir(tmp_path / "beir")), doc_template="<title> [SEP] <text>"))
+    corpus, queries = list(beir.corpus_dataset), list(beir.query_dataset)
+    assert [r["text_id"] for r in corpus] == ["d%d" % (100 + i) for i in range(23)]
+    assert [r["text_id"] for r in queries] == ["q%d" % i for i in range(6)]
+    assert all(len(r["input_ids"]) == 24 for r in corpus) and all(len(r["input_ids"]) == 8 for r in queries)
+    dash = tok.convert_tokens_to_ids("-")
+    assert corpus[1]["input_ids"][1] == dash            # empty title -> "-"
+    assert beir.qrel["q3"] == {"d103": 2, "d113": 1, "d120": 0}
+    # rank partition as in the encode path
+    halves = [list(BEIRDataset(tok, data_args(data_dir=str(tmp_path / "beir")), batch_size=4, num_processes=2,
+                               process_index=r).corpus_dataset) for r in range(2)]
+    assert [r["text_id"] for r in halves[1]][:4] == ["d104", "d105", "d106", "d107"]
+    assert len(halves[0]) + len(halves[1]) == 23
+    # nDCG@10 by hand: judged docs at ranks 1 (rel 1) and 3 (rel 2), ideal = [2, 1]
+    import math
+    run = {"q0": {"d110": 3.0, "d999": 2.5, "d100": 2.0, "d120": 1.0}, "q9": {"d1": 1.0}}
+    want = (1 / math.log2(2) + 2 / math.log2(4)) / (2 / math.log2(2) + 1 / math.log2(3))
+    got = eval_ndcg({"q0": beir.qrel["q0"], "q1": beir.qrel["q1"]}, run)
+    assert abs(got["q0"] - want) < 1e-12 and "q1" not in got and abs(got["all"] - want) < 1e-12
