@@ -127,3 +127,11 @@ def eval_ndcg(qrel, run, cutoff=10):
         out[qid] = dcg / idcg if idcg > 0 else 0.0
     out["all"] = sum(out.values()) / len(out) if out else 0.0
     return out
+
+
+def __getattr__(name):
+    # `from openmatch.utils import SimpleTrainPreProcessor` (reference utils.py:14) -- lives in preprocess.py
+    if name == "SimpleTrainPreProcessor":
+        from .preprocess import SimpleTrainPreProcessor
+        return SimpleTrainPreProcessor
+    raise AttributeError(name)

@@ -265,3 +265,35 @@ def test_beir_dataset_and_ndcg(tok, tmp_path):
     want = (1 / math.log2(2) + 2 / math.log2(4)) / (2 / math.log2(2) + 1 / math.log2(3))
     got = eval_ndcg({"q0": beir.qrel["q0"], "q1": beir.qrel["q1"]}, run)
     assert abs(got["q0"] - want) < 1e-12 and "q1" not in got and abs(got["all"] - want) < 1e-12
+
+
+# ---------------------------------------------------------------------------------- hard negatives
+def test_hard_negative_mining_closes_the_loop(tok, tmp_path):
+    """TREC run over training queries -> sampled hard negatives -> jsonl groups DRTrainDataset reads."""
+    import random
+    from openmatch.dataset import DRTrainDataset
+    from openmatch.preprocess import negatives_from_run, write_shards
+    from openmatch.utils import SimpleTrainPreProcessor
+    coll = tmp_path / "collection.tsv"                      # MS MARCO convention: id == row number
+    rows = [line.rstrip("\n").split("\t") for line in open(os.path.join(TEXT, "corpus.tsv"))]
+    coll.write_text("".join("%d\t%s\t%s\n" % (i, r[1], r[2]) for i, r in enumerate(rows)))
+    (tmp_path / "qrels.tsv").write_text("q0\t0\t3\t1\nq0\t0\t7\t1\nq1\t0\t5\t1\n")
+    run = tmp_path / "train.trec"
+    run.write_text("".join("q0 Q0 %d %d %.3f r\n" % (d, i + 1, 9 - i) for i, d in enumerate([7, 1, 2, 3, 4, 6, 8])) +
+                   "".join("q1 Q0 %d %d %.3f r\n" % (d, i + 1, 9 - i) for i, d in enumerate([9, 5, 10])))
+    qrel = SimpleTrainPreProcessor.read_qrel(str(tmp_path / "qrels.tsv"))
+    assert qrel == {"q0": ["3", "7"], "q1": ["5"]}
+    triples = list(negatives_from_run(str(run), qrel, n_sample=3, depth=4, rng=random.Random(0)))
+    assert [t[0] for t in triples] == ["q0", "q1"] and triples[0][1] == ["3", "7"]
+    assert set(triples[0][2]) <= {"1", "2", "4", "6"} and len(triples[0][2]) == 3      # first 4 non-relevant hits
+    assert sorted(triples[1][2]) == ["10", "9"]
+    proc = SimpleTrainPreProcessor(os.path.join(TEXT, "queries.tsv"), str(coll), tok, doc_max_len=20, query_max_len=6,
+                                   doc_template="<title> [SEP] <text>", query_template="<text>", allow_not_found=True)
+    want = tok.encode(rows[7][1] + " [SEP] " + rows[7][2], add_special_tokens=False)[:20]
+    assert proc.get_passage("7") == want
+    paths = write_shards(map(proc.process_one, triples), str(tmp_path / "hn"), shard_size=1, suffix=".hn.jsonl")
+    assert [os.path.basename(p) for p in paths] == ["split00.hn.jsonl", "split01.hn.jsonl"]
+    groups = list(DRTrainDataset(tok, data_args(train_path=None, train_dir=str(tmp_path / "hn"), train_n_passages=3),
+                                 trainer=_trainer(1, 0)))
+    assert len(groups) == 2 and all(len(g["passages"]) == 3 for g in groups)
+    assert groups[0]["passages"][0]["input_ids"][1:-1] in ([*proc.get_passage("3")], [*proc.get_passage("7")])
