@@ -7,6 +7,13 @@
 //   * 16-bit output, no residual: pack to bf16 in registers, ds_write_b64 (4 columns), rows of 264 B
 //   * otherwise: ds_write_b128 of four f32, rows of 528 B; residual added in f32 after the read-back
 //     (a single rounding)
+//   * 16-bit output WITH residual: the residual patch (32 rows x 256 B) is brought into LDS by the same
+//     LDS-DMA the K loop uses (8 wave instructions per patch, chunk position XOR row so the
+//     row-per-lane read-back is 2-way instead of 32-way conflicted), two patches ahead, and added in
+//     f32 in registers BEFORE packing -- a single rounding and the cheap bf16 staging.  Loading the
+//     residual as 16-byte vectors into VGPRs after the read-back cost 20 k cycles per tile
+//     (tools/gemm_epilogue_probe.hip): HBM latency per patch, and `vmcnt` retiring in order ties those
+//     loads to the stores in front of them.
 // then whole 16-byte vectors are read back row-major and stored fully coalesced (a wave instruction
 // covers 4 (bf16) or 2 (f32) complete 256 / 512-byte row segments).
 // One patch = one mi block (32 rows x 128 columns).  With a single wave per SIMD nothing else hides
@@ -59,6 +66,7 @@ __device__ __forceinline__ f32x2_t epi_pair(f32x2_t v, int64_t m, int64_t n, int
 #define G6E_STRIDE16 264      // bf16 staging row: 128 columns x 2 B + 8 (ds_write_b64 / ds_read_b64 conflict-free)
 #define G6E_STRIDE32 528      // f32 staging row: 128 columns x 4 B + 16 (ds_write_b128 / ds_read_b128 conflict-free)
 #define G6E_REGION_BYTES (32 * G6E_STRIDE32)
+#define G6E_RES_LDS_BYTES (65536 + 4 * 3 * 8192)      // LDS of a 16-bit kernel with residual: staging + residual ring
 
 // this lane's 64 bias values in accumulator order (the accumulators start from them)
 __device__ __forceinline__ void g6_bias_init(f32x16_t (&init)[4], const float* bias, int64_t ncol0, int64_t N) {
@@ -80,7 +88,8 @@ template <typename OutT, int ACT, bool TRAIN, bool RESID, int PROBE = 0>
 __device__ __forceinline__ void store_wave_tile6(f32x16_t (&acc)[4][4], int64_t mrow0, int64_t ncol0, OutT* C,
                                                  int64_t ldc, int64_t M, int64_t N, const GemmEpilogue& ep,
                                                  const EpiScalars& es, char* region) {
-  constexpr bool STAGE16 = sizeof(OutT) == 2 && !RESID;
+  constexpr bool RES_DMA = RESID && sizeof(OutT) == 2;      // residual through LDS-DMA, added before packing
+  constexpr bool STAGE16 = sizeof(OutT) == 2;
   constexpr int STRIDE = STAGE16 ? G6E_STRIDE16 : G6E_STRIDE32;
   constexpr int SB = STAGE16 ? 2 : 4;           // staged bytes per element
   constexpr int VEC = OutVec<OutT>::VEC;        // elements per 16-byte output vector
@@ -94,7 +103,11 @@ __device__ __forceinline__ void store_wave_tile6(f32x16_t (&acc)[4][4], int64_t 
   const int cols_left = cols_left64 > 128 ? 128 : (int)cols_left64;
   const bool col_ok = c * VEC < cols_left;
   OutT* cp = C + (mrow0 + rl) * ldc + ncol0 + c * VEC;
-  const OutT* rp = RESID ? (const OutT*)ep.resid + (mrow0 + rl) * ep.ldr + ncol0 + c * VEC : nullptr;   // may alias C
+  const OutT* rp = (RESID && !RES_DMA) ? (const OutT*)ep.resid + (mrow0 + rl) * ep.ldr + ncol0 + c * VEC : nullptr;   // may alias C
+  // residual patches in LDS: three 8 KiB buffers per wave above the first 64 KiB of the (now idle)
+  // ring, up to the end of the 160 KiB allocation of the residual kernels (G6E_RES_LDS_BYTES); the
+  // bf16 staging regions (8448 B at wave * G6E_REGION_BYTES) all end below 64 KiB
+  char* resbuf = region - (threadIdx.x >> 6) * G6E_REGION_BYTES + 65536 + (threadIdx.x >> 6) * 24576;
   char* lds_wr = region + l31 * STRIDE + half * 4 * SB;
   const char* lds_rd = region + rl * STRIDE + c * VEC * SB;
 
@@ -103,16 +116,47 @@ __device__ __forceinline__ void store_wave_tile6(f32x16_t (&acc)[4][4], int64_t 
 #define G6E_WRITE(MI)                                                                                      \
   do {                                                                                                     \
     const int64_t m = mrow0 + (MI) * 32 + l31;                                                             \
+    /* all 16 residual reads of the patch first: behind the staging writes each would expose its     \
+       LDS latency (the compiler cannot prove the two LDS areas distinct and keeps program order) */ \
+    uint2 rpatch[4][4];                                                                                    \
+    if (RES_DMA) {                                                                                         \
+      _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                     \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
+          rpatch[ni][j] = *(const uint2*)(resbuf + ((MI) % 3) * 8192 + l31 * 256 +                         \
+                                          (((ni * 4 + j) ^ (l31 & 15)) << 4) + 8 * half);                  \
+    }                                                                                                      \
     _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                       \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
         const int64_t n = ncol0 + ni * 32 + 8 * j + 4 * half;                                              \
         const f32x2_t lo = epi_pair<ACT, TRAIN, OutT>((f32x2_t){acc[MI][ni][4 * j], acc[MI][ni][4 * j + 1]}, m, n, M, N, ep, es);         \
         const f32x2_t hi = epi_pair<ACT, TRAIN, OutT>((f32x2_t){acc[MI][ni][4 * j + 2], acc[MI][ni][4 * j + 3]}, m, n + 2, M, N, ep, es); \
+        f32x2_t lo_ = lo, hi_ = hi;                                                                        \
+        if (RES_DMA) {                                                                                     \
+          const uint2 rr = rpatch[ni][j];                                                                  \
+          const float r0 = bf16_to_f32((bf16_t)(rr.x & 0xffff)), r1 = bf16_to_f32((bf16_t)(rr.x >> 16));  \
+          const float r2 = bf16_to_f32((bf16_t)(rr.y & 0xffff)), r3 = bf16_to_f32((bf16_t)(rr.y >> 16));  \
+          if (es.mul) { lo_[0] *= r0; lo_[1] *= r1; hi_[0] *= r2; hi_[1] *= r3; }                          \
+          else {                                                                                           \
+            lo_[0] = epi_resid<ACT>(lo_[0], r0, false); lo_[1] = epi_resid<ACT>(lo_[1], r1, false);        \
+            hi_[0] = epi_resid<ACT>(hi_[0], r2, false); hi_[1] = epi_resid<ACT>(hi_[1], r3, false);        \
+          }                                                                                                \
+        }                                                                                                  \
         char* dst = lds_wr + (ni * 32 + 8 * j) * SB;                                                       \
-        if (PROBE & 1) { asm volatile("" :: "v"(lo), "v"(hi)); }                                           \
-        else if (STAGE16) *(uint2*)dst = make_uint2(pack_bf16x2(lo[0], lo[1]), pack_bf16x2(hi[0], hi[1])); \
-        else *(f32x4_t*)dst = (f32x4_t){lo[0], lo[1], hi[0], hi[1]};                                       \
+        if (PROBE & 1) { asm volatile("" :: "v"(lo_), "v"(hi_)); }                                         \
+        else if (STAGE16) *(uint2*)dst = make_uint2(pack_bf16x2(lo_[0], lo_[1]), pack_bf16x2(hi_[0], hi_[1])); \
+        else *(f32x4_t*)dst = (f32x4_t){lo_[0], lo_[1], hi_[0], hi_[1]};                                   \
       }                                                                                                    \
+  } while (0)
+#define G6E_RES_DMA(MI)                                                                                    \
+  do {                                                                                                     \
+    char* buf = resbuf + ((MI) % 3) * 8192;                                                                \
+    _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                        \
+      const int row = 4 * k + (lane >> 4), src_chunk = (lane & 15) ^ (row & 15);                           \
+      int64_t gr = mrow0 + (MI) * 32 + row; if (gr > M - 1) gr = M - 1;                                     \
+      int64_t gc = ncol0 + src_chunk * 8; if (gc > N - 8) gc = ncol0;                                      \
+      __builtin_amdgcn_global_load_lds((gptr_t)((const OutT*)ep.resid + gr * ep.ldr + gc),                  \
+                                       (lptr_t)(buf + k * 1024), 16, 0, 0);                                \
+    }                                                                                                      \
   } while (0)
 #define G6E_RESID(MI)                                                                                      \
   do {                                                                                                     \
@@ -120,7 +164,18 @@ __device__ __forceinline__ void store_wave_tile6(f32x16_t (&acc)[4][4], int64_t 
       if (G6E_ROW_OK(MI, it)) rres[(MI) & 1][it] = *(const uint4*)(rp + (int64_t)((MI) * 32 + it * RPI) * ep.ldr); \
   } while (0)
 
-  if (RESID) G6E_RESID(0);
+  // Residual patches 0, 1, 2 are requested up front, patch 3 as soon as WRITE(0) has consumed
+  // buffer 0.  vmcnt retires in order and stores are predicated, so each wait counts only the DMA
+  // instructions that are certainly younger than the patch it needs (8 per patch); the inline asm
+  // (memory clobber) keeps the LDS reads behind the wait.
+  if (RES_DMA) {
+    G6E_RES_DMA(0);
+    G6E_RES_DMA(1);
+    G6E_RES_DMA(2);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  } else if (RESID) {
+    G6E_RESID(0);
+  }
   G6E_WRITE(0);
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
@@ -139,8 +194,13 @@ __device__ __forceinline__ void store_wave_tile6(f32x16_t (&acc)[4][4], int64_t 
       }
     }
     if (mi + 1 < 4) {
+      if (RES_DMA) {
+        if (mi == 0) { G6E_RES_DMA(3); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }   // patch 1; younger: 2, 3
+        else if (mi == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                     // patch 2; younger: 3
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                  // patch 3
+      }
       G6E_WRITE(mi + 1);
-      if (RESID) G6E_RESID(mi + 1);
+      if (RESID && !RES_DMA) G6E_RESID(mi + 1);
     }
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
@@ -152,7 +212,7 @@ __device__ __forceinline__ void store_wave_tile6(f32x16_t (&acc)[4][4], int64_t 
           float xv[VEC];
 #pragma unroll
           for (int e = 0; e < VEC; ++e) xv[e] = st32[it][e >> 2][e & 3];
-          if (RESID) {
+          if (RESID && !RES_DMA) {
             float rv[VEC];
             OutVec<OutT>::unpack(rres[mi & 1][it], rv);
             if (es.mul) {                                  // T5 gated FFN: act(wi_0 x) * (wi_1 x)
@@ -173,4 +233,5 @@ __device__ __forceinline__ void store_wave_tile6(f32x16_t (&acc)[4][4], int64_t 
 #undef G6E_ROW_OK
 #undef G6E_WRITE
 #undef G6E_RESID
+#undef G6E_RES_DMA
 }

@@ -49,17 +49,19 @@ static int launch6(const void* A, int64_t lda, const void* B, int64_t ldb, void*
                    int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
   const int64_t nwg = ((M + G4_BM - 1) / G4_BM) * ((N + G4_BN - 1) / G4_BN);
   if (nwg > 0x7fffffffLL) OM_FAIL("grid too large");
+  // 16-bit kernels with a residual keep three residual patches per wave in LDS next to the staging
+  constexpr int lds_bytes = (RESID && sizeof(OutT) == 2 && G6E_RES_LDS_BYTES > G6_LDS_BYTES) ? G6E_RES_LDS_BYTES : G6_LDS_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
     OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel6<T, OutT, ACT, TRAIN, RESID>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
   const int tclass = sizeof(T) == 2 ? OM_TIMING_GEMM_BF16 : OM_TIMING_GEMM_F32;
   const bool timing = om_timing_on();
   if (timing) om_timing_begin(tclass, s);
   // sweep order: 8 row tiles stay resident while the column tiles are walked (L2 reuse per XCD)
-  hipLaunchKernelGGL((gemm_nt_kernel6<T, OutT, ACT, TRAIN, RESID>), dim3((unsigned)nwg), dim3(G6_THREADS), G6_LDS_BYTES, s,
+  hipLaunchKernelGGL((gemm_nt_kernel6<T, OutT, ACT, TRAIN, RESID>), dim3((unsigned)nwg), dim3(G6_THREADS), lds_bytes, s,
                      (const T*)A, lda, (const T*)B, ldb, (OutT*)C, ldc, M, N, K, ep, g6_group_m());
   if (timing) om_timing_end(tclass, s, 2.0 * (double)M * (double)N * (double)K);
   OM_LAUNCH_CHECK();

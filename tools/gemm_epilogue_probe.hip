@@ -37,8 +37,8 @@ __global__ __launch_bounds__(G6_THREADS) void probe(bf16_t* C, const bf16_t* R, 
 
 template <int PROBE, int ACT, bool RESID> static void run(const char* what, bf16_t* C, const bf16_t* R, int64_t M, int64_t N, long long* ticks, int blocks) {
   const int reps = 8;
-  hipFuncSetAttribute((const void*)probe<PROBE, ACT, RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES);
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((probe<PROBE, ACT, RESID>), dim3(blocks), dim3(G6_THREADS), G6_LDS_BYTES, 0, C, R, N, M, N, ticks, reps);
+  hipFuncSetAttribute((const void*)probe<PROBE, ACT, RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, G6E_RES_LDS_BYTES);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((probe<PROBE, ACT, RESID>), dim3(blocks), dim3(G6_THREADS), G6E_RES_LDS_BYTES, 0, C, R, N, M, N, ticks, reps);
   hipDeviceSynchronize();
   std::vector<long long> h(blocks);
   hipMemcpy(h.data(), ticks, blocks * sizeof(long long), hipMemcpyDeviceToHost);
