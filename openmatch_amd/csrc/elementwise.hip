@@ -158,6 +158,44 @@ __global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(
   }
 }
 
+// Fold a LayerNorm into the bf16 weight that consumes its output (kernels.h, GemmEpilogue::ln_*):
+//   W'[n,k] = bf16(W[n,k] gamma[k]),  s[n] = sum_k W'[n,k],  b'[n] = b[n] + sum_k beta[k] W[n,k]
+// so that LN(y) W^T + b = rstd (y W'^T - mu s) + b'.  One wave per output row.
+__global__ __launch_bounds__(256) void ln_fold_kernel(const bf16_t* __restrict__ W, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ b,
+                                                      bf16_t* __restrict__ Wf, float* __restrict__ colsum,
+                                                      float* __restrict__ bf, int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float s = 0.f, t = 0.f;
+  for (int k = lane * 8; k < K; k += 64 * 8) {              // K % 8 == 0
+    const uint4 w4 = *(const uint4*)(W + (int64_t)n * K + k);
+    const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float w0 = bf16_to_f32((bf16_t)(w[e] & 0xffff)), w1 = bf16_to_f32((bf16_t)(w[e] >> 16));
+      const bf16_t f0 = f32_to_bf16(w0 * gamma[k + 2 * e]), f1 = f32_to_bf16(w1 * gamma[k + 2 * e + 1]);
+      s += bf16_to_f32(f0) + bf16_to_f32(f1);
+      t += w0 * beta[k + 2 * e] + w1 * beta[k + 2 * e + 1];
+      o[e] = (uint32_t)f0 | ((uint32_t)f1 << 16);
+    }
+    *(uint4*)(Wf + (int64_t)n * K + k) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+  s = wave_sum(s); t = wave_sum(t);
+  if (lane == 0) { colsum[n] = s; bf[n] = (b ? b[n] : 0.f) + t; }
+}
+
+int omk_ln_fold(const void* W, const float* gamma, const float* beta, const float* b, void* Wf,
+                float* colsum, float* bf, int N, int K, hipStream_t s) {
+  if (K % 8 != 0) OM_FAIL("K must be a multiple of 8");
+  hipLaunchKernelGGL(ln_fold_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, (const bf16_t*)W, gamma, beta, b,
+                     (bf16_t*)Wf, colsum, bf, N, K);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
 // BERT: LN(word[id] + type[tt] + pos[t])  (HF:models/bert/modeling_bert.py:68-108).
 // T5  : word[id]                          (shared embedding, no norm).
 template <typename TOut, int MAX_VEC>

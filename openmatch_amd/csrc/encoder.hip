@@ -11,6 +11,9 @@
 //   ff  [M,F]   FFN inner activation  ff2 [M,F] gate (T5 v1.1 only)
 #include <math.h>
 
+#include <stdlib.h>
+
+#include <algorithm>
 #include <vector>
 
 #include "kernels.h"
@@ -19,6 +22,9 @@ struct EncWs {
   char *x, *y, *x1, *qkv, *ctx, *ff, *ff2;
   float *pooled, *headout, *posbias;
   int* lut;
+  // fused-LayerNorm path (bf16 BERT): folded weight, its column sums and bias, two statistics buffers
+  char* wfold;
+  float *colsum, *bfold, *stats1, *stats2;
   size_t total;
 };
 
@@ -39,6 +45,13 @@ static EncWs carve(const OmEncoderConfig* c, int64_t B, int64_t L, char* base) {
   w.headout = (float*)take((size_t)B * (c->head_out > 0 ? c->head_out : 1) * 4);
   w.posbias = (float*)take(c->arch == OM_ARCH_T5 ? (size_t)c->n_heads * L * L * 4 : 0);
   w.lut = (int*)take(c->arch == OM_ARCH_T5 ? (size_t)(2 * L) * 4 : 0);
+  const bool fuse = c->arch == OM_ARCH_BERT && c->dtype == OM_BF16;
+  const size_t wide = std::max((size_t)3 * H, F);
+  w.wfold = take(fuse ? wide * H * es : 0);
+  w.colsum = (float*)take(fuse ? wide * 4 : 0);
+  w.bfold = (float*)take(fuse ? wide * 4 : 0);
+  w.stats1 = (float*)take(fuse ? M * 8 : 0);
+  w.stats2 = (float*)take(fuse ? M * 8 : 0);
   w.total = off;
   return w;
 }
@@ -105,6 +118,62 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
     RUN(omk_embed(dt, input_ids, token_type_ids, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g,
                   w->emb_ln_b, ws.x, M, (int)L, H, c->vocab, c->type_vocab, c->ln_eps, 1, s));
     const float scale = 1.0f / sqrtf((float)c->head_dim);
+    // LayerNorm fused across the GEMMs (bf16, large batches): the LayerNorm outputs are never
+    // written.  The GEMM that produces a pre-LayerNorm sum y also accumulates its row statistics; the
+    // GEMM that consumes LN(y) reads y itself against the folded weight W*gamma and rescales its
+    // rows in the epilogue; the GEMM that adds LN(y) as a residual normalises it on the fly
+    // (kernels.h: GemmEpilogue::ln_*, rln_*, stats_out).  23 of the 25 LayerNorm passes over
+    // [M,H] disappear (the embedding LayerNorm and the last one stay).
+    const bool no_fuse = getenv("OM_ENCODER_FUSED_LN") && atoi(getenv("OM_ENCODER_FUSED_LN")) == 0;   // A/B switch
+    const bool fuse = !no_fuse && c->act == OM_ACT_GELU_ERF && c->n_layers > 0 && H % 8 == 0 &&
+                      omk_gemm_ln_fusable(dt, M, H, H) && omk_gemm_ln_fusable(dt, M, F, H) &&
+                      omk_gemm_ln_fusable(dt, M, 3 * H, H) && omk_gemm_ln_fusable(dt, M, H, F);
+    if (getenv("OM_ENCODER_DEBUG")) fprintf(stderr, "om_encoder_forward: M=%ld fused_ln=%d\n", (long)M, (int)fuse);
+    if (fuse) {
+      const float inv_h = 1.0f / (float)H;
+      // y1 lives in ws.y, y2 in ws.x1; ws.x is the embedding output (layer 0's input)
+      for (int l = 0; l < c->n_layers; ++l) {
+        const OmLayerWeights& lw = Ls[l];
+        GemmEpilogue e = {};
+        // ---- QKV: x0 for the first layer, LN2_{l-1}(y2) folded afterwards
+        if (l == 0) {
+          e.bias = lw.qkv_b;
+          RUN(omk_gemm(dt, ws.x, H, lw.qkv_w, H, dt, ws.qkv, 3 * H, M, 3 * H, H, e, s));
+        } else {
+          const OmLayerWeights& pw = Ls[l - 1];
+          RUN(omk_ln_fold(lw.qkv_w, pw.ln2_g, pw.ln2_b, lw.qkv_b, ws.wfold, ws.colsum, ws.bfold, 3 * H, H, s));
+          e.bias = ws.bfold; e.ln_stats = ws.stats2; e.ln_colsum = ws.colsum; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+          RUN(omk_gemm(dt, ws.x1, H, ws.wfold, H, dt, ws.qkv, 3 * H, M, 3 * H, H, e, s));
+        }
+        RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, nullptr, B, (int)L, H, nh, scale, 0.f, 0, s));
+        // ---- attention output + residual -> y1, statistics of LN1
+        OM_HIP(hipMemsetAsync(ws.stats1, 0, (size_t)M * 8, s));
+        e = GemmEpilogue{};
+        e.bias = lw.o_b; e.ldr = H; e.stats_out = ws.stats1; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+        if (l == 0) {
+          e.resid = ws.x;
+        } else {
+          const OmLayerWeights& pw = Ls[l - 1];
+          e.resid = ws.x1; e.rln_stats = ws.stats2; e.rln_g = pw.ln2_g; e.rln_b = pw.ln2_b;
+        }
+        RUN(omk_gemm(dt, ws.ctx, H, lw.o_w, H, dt, ws.y, H, M, H, H, e, s));
+        // ---- FFN1 on LN1(y1), folded
+        RUN(omk_ln_fold(lw.ffn1_w, lw.ln1_g, lw.ln1_b, lw.ffn1_b, ws.wfold, ws.colsum, ws.bfold, F, H, s));
+        e = GemmEpilogue{};
+        e.bias = ws.bfold; e.act = c->act; e.ln_stats = ws.stats1; e.ln_colsum = ws.colsum; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+        RUN(omk_gemm(dt, ws.y, H, ws.wfold, H, dt, ws.ff, F, M, F, H, e, s));
+        // ---- FFN2 + LN1(y1) as the residual -> y2, statistics of LN2
+        OM_HIP(hipMemsetAsync(ws.stats2, 0, (size_t)M * 8, s));
+        e = GemmEpilogue{};
+        e.bias = lw.ffn2_b; e.resid = ws.y; e.ldr = H; e.rln_stats = ws.stats1; e.rln_g = lw.ln1_g; e.rln_b = lw.ln1_b;
+        e.stats_out = ws.stats2; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+        RUN(omk_gemm(dt, ws.ff, F, lw.ffn2_w, F, dt, ws.x1, H, M, H, F, e, s));
+      }
+      const OmLayerWeights& last = Ls[c->n_layers - 1];
+      void* dst = out_hidden ? out_hidden : (void*)ws.x;
+      RUN(omk_layernorm(dt, ws.x1, H, dst, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, 0, s));
+      final_hidden = (char*)dst;
+    } else
     for (int l = 0; l < c->n_layers; ++l) {
       const OmLayerWeights& lw = Ls[l];
       GEMM(ws.x, H, lw.qkv_w, H, ws.qkv, 3 * H, 3 * H, H, lw.qkv_b, nullptr, 0, OM_ACT_NONE);

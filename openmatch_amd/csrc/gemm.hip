@@ -109,6 +109,11 @@ static bool wide_ok(int out_dtype, const void* C, int64_t ldc, int64_t M, int64_
   return true;
 }
 
+bool omk_gemm_ln_fusable(int dtype, int64_t M, int64_t N, int64_t K) {
+  return dtype == OM_BF16 && M >= 512 && N >= 256 && N % 8 == 0 && (K * 2) % 128 == 0 && gemm_variant() != 1 &&
+         gemm_variant() != 2 && gemm_variant() != 4;
+}
+
 static unsigned long long* g_trace = nullptr;
 extern "C" void om_debug_gemm_trace(unsigned long long* buf) { g_trace = buf; }
 
@@ -141,17 +146,22 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
     if (gemm_variant() == 2) gen = 2;
     if (gemm_variant() == 4 || gemm_variant() == 6) gen = N >= 256 ? gemm_variant() : 2;
   }
+  const bool ln_fused = ep.ln_stats || ep.rln_stats || ep.stats_out;
+  if (ln_fused && !(wide && in_dtype == OM_BF16 && out_dtype == OM_BF16 && N >= 256)) OM_FAIL("fused LayerNorm epilogue needs the 256x256 bf16 kernel");
+  if (ln_fused) gen = 6;
   if (gen == 6) {
     const int act = ep.act & 0xff;
     const bool train = ep.pre_act != nullptr || ep.drop_p > 0.f;
     const bool resid = ep.resid != nullptr;
     // v6 reads the bias as float4 and writes pre-activation pairs
     const bool aligned = (((uintptr_t)ep.bias & 15) == 0) && (ep.ldp % 2 == 0) && (((uintptr_t)ep.pre_act & 3) == 0);
+    if (!aligned && ln_fused) OM_FAIL("fused LayerNorm epilogue needs 16-byte aligned bias");
     if (!aligned) gen = 4;
     else if (omk_gemm_wide6_b16_has(in_dtype, out_dtype, act, train, resid))
       return omk_gemm_wide6_b16(in_dtype, A, lda, B, ldb, out_dtype, C, ldc, M, N, K, ep, s);
     else if (omk_gemm_wide6_f32_has(in_dtype, out_dtype, act, train, resid))
       return omk_gemm_wide6_f32(in_dtype, A, lda, B, ldb, out_dtype, C, ldc, M, N, K, ep, s);
+    if (ln_fused) OM_FAIL("no kernel for this fused LayerNorm epilogue");
     gen = 4;
   }
   if (gen == 4) return omk_gemm_wide4(in_dtype, A, lda, B, ldb, out_dtype, C, ldc, M, N, K, ep, s);

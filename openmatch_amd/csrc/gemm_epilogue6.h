@@ -9,7 +9,7 @@
 //     (a single rounding)
 //   * 16-bit output WITH residual: the residual patch (32 rows x 256 B) is brought into LDS by the same
 //     LDS-DMA the K loop uses (8 wave instructions per patch, chunk position XOR row so the
-//     row-per-lane read-back is 2-way instead of 32-way conflicted), two patches ahead, and added in
+//     row-per-lane read-back is 2-way instead of 32-way conflicted), one to two patches ahead, and added in
 //     f32 in registers BEFORE packing -- a single rounding and the cheap bf16 staging.  Loading the
 //     residual as 16-byte vectors into VGPRs after the read-back cost 20 k cycles per tile
 //     (tools/gemm_epilogue_probe.hip): HBM latency per patch, and `vmcnt` retiring in order ties those
@@ -65,28 +65,16 @@ __device__ __forceinline__ f32x2_t epi_pair(f32x2_t v, int64_t m, int64_t n, int
 #define G6E_STRIDE16 264      // bf16 staging row: 128 columns x 2 B + 8 (ds_write_b64 / ds_read_b64 conflict-free)
 #define G6E_STRIDE32 528      // f32 staging row: 128 columns x 4 B + 16 (ds_write_b128 / ds_read_b128 conflict-free)
 #define G6E_REGION_BYTES (32 * G6E_STRIDE32)
-#define G6E_RES_LDS_BYTES (65536 + 4 * 3 * 8192)      // LDS of a 16-bit kernel with residual: staging + residual ring
-
-// this lane's 64 bias values in accumulator order (the accumulators start from them)
-__device__ __forceinline__ void g6_bias_init(f32x16_t (&init)[4], const float* bias, int64_t ncol0, int64_t N) {
-  const int half = (threadIdx.x & 63) >> 5;
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t n = ncol0 + ni * 32 + 8 * j + 4 * half;
-      f32x4_t b = {0.f, 0.f, 0.f, 0.f};
-      if (bias && n < N) b = *(const f32x4_t*)(bias + n);       // N % 4 == 0 and bias 16-byte aligned (wide_ok)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) init[ni][4 * j + e] = b[e];
-    }
-}
+#define G6E_RES_LDS_BYTES (65536 + 4 * 2 * 8192)      // LDS of a 16-bit kernel with residual: staging + residual ring (= the K ring)
 
 // PROBE (tools/gemm_epilogue_probe.hip only): bit 0 drops the LDS writes, bit 2 the global stores.
-template <typename OutT, int ACT, bool TRAIN, bool RESID, int PROBE = 0>
+// LNF: which fused-LayerNorm features are compiled in -- 0 none, 1 the A-operand side (GemmEpilogue::ln_*),
+// 2 the output side (rln_* and stats_out); kept out of the kernels that do not use them, whose
+// register allocation they would otherwise burden.
+template <typename OutT, int ACT, bool TRAIN, bool RESID, int LNF = 0, int PROBE = 0>
 __device__ __forceinline__ void store_wave_tile6(f32x16_t (&acc)[4][4], int64_t mrow0, int64_t ncol0, OutT* C,
                                                  int64_t ldc, int64_t M, int64_t N, const GemmEpilogue& ep,
-                                                 const EpiScalars& es, char* region) {
+                                                 const EpiScalars& es, char* region, const float (&rs)[4]) {
   constexpr bool RES_DMA = RESID && sizeof(OutT) == 2;      // residual through LDS-DMA, added before packing
   constexpr bool STAGE16 = sizeof(OutT) == 2;
   constexpr int STRIDE = STAGE16 ? G6E_STRIDE16 : G6E_STRIDE32;
@@ -103,10 +91,34 @@ __device__ __forceinline__ void store_wave_tile6(f32x16_t (&acc)[4][4], int64_t 
   const bool col_ok = c * VEC < cols_left;
   OutT* cp = C + (mrow0 + rl) * ldc + ncol0 + c * VEC;
   const OutT* rp = (RESID && !RES_DMA) ? (const OutT*)ep.resid + (mrow0 + rl) * ep.ldr + ncol0 + c * VEC : nullptr;   // may alias C
-  // residual patches in LDS: three 8 KiB buffers per wave above the first 64 KiB of the (now idle)
-  // ring, up to the end of the 160 KiB allocation of the residual kernels (G6E_RES_LDS_BYTES); the
-  // bf16 staging regions (8448 B at wave * G6E_REGION_BYTES) all end below 64 KiB
-  char* resbuf = region - (threadIdx.x >> 6) * G6E_REGION_BYTES + 65536 + (threadIdx.x >> 6) * 24576;
+  // residual patches in LDS: two 8 KiB buffers per wave in the upper half of the (now idle) ring;
+  // the bf16 staging regions (8448 B at wave * G6E_REGION_BYTES) all end below 64 KiB
+  const int wave_ = threadIdx.x >> 6;
+  char* resbuf = region - wave_ * G6E_REGION_BYTES + 65536 + wave_ * 16384;
+  // Fused LayerNorm pieces (GemmEpilogue::ln_* / rln_* / stats_out; all wave-uniform switches):
+  //   rs[mi]        row scale rstd_m of an A operand that is a raw pre-LayerNorm tensor (the rest of
+  //                 that affine sits in the accumulators' initial value, gemm_wide6.h)
+  //   ra, rc        the residual row's (rstd, -mu rstd): LN(r) = (r ra + rc) gamma_n + beta_n
+  //   gbtab         this wave's 128 gamma | 128 beta (a static LDS object, so the compiler may move
+  //                 its reads across the staging writes)
+  __shared__ float gbtab[LNF == 2 ? 4 : 1][2][128];
+  const bool ln_in = LNF == 1 && ep.ln_stats != nullptr, res_ln = LNF == 2 && RES_DMA && ep.rln_stats != nullptr;
+  const bool stats_out = LNF == 2 && ep.stats_out != nullptr;
+  float ra[4] = {1.f, 1.f, 1.f, 1.f}, rc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (res_ln) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      int64_t m = mrow0 + mi * 32 + l31; if (m > M - 1) m = M - 1;
+      const float2 st = ((const float2*)ep.rln_stats)[m];
+      const float mu = st.x * ep.ln_inv_h;
+      const float rstd = rsqrtf(fmaxf(st.y * ep.ln_inv_h - mu * mu, 0.f) + ep.ln_eps);
+      ra[mi] = rstd; rc[mi] = -mu * rstd;
+    }
+    const int64_t n4 = ncol0 + l31 * 4;
+    f32x4_t t = {0.f, 0.f, 0.f, 0.f};
+    if (n4 < N) t = *(const f32x4_t*)((half ? ep.rln_b : ep.rln_g) + n4);
+    *(f32x4_t*)&gbtab[LNF == 2 ? wave_ : 0][half][l31 * 4] = t;
+  }
   char* lds_wr = region + l31 * STRIDE + half * 4 * SB;
   const char* lds_rd = region + rl * STRIDE + c * VEC * SB;
 
@@ -118,37 +130,55 @@ __device__ __forceinline__ void store_wave_tile6(f32x16_t (&acc)[4][4], int64_t 
     /* all 16 residual reads of the patch first: behind the staging writes each would expose its     \
        LDS latency (the compiler cannot prove the two LDS areas distinct and keeps program order) */ \
     uint2 rpatch[4][4];                                                                                    \
+    f32x2_t ssum = {0.f, 0.f}, ssq = {0.f, 0.f};     /* this row's (sum, sum of squares) over my 64 columns */ \
     if (RES_DMA) {                                                                                         \
       _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                     \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
-          rpatch[ni][j] = *(const uint2*)(resbuf + ((MI) % 3) * 8192 + l31 * 256 +                         \
+          rpatch[ni][j] = *(const uint2*)(resbuf + ((MI) & 1) * 8192 + l31 * 256 +                         \
                                           (((ni * 4 + j) ^ (l31 & 15)) << 4) + 8 * half);                  \
     }                                                                                                      \
     _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                       \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
         const int64_t n = ncol0 + ni * 32 + 8 * j + 4 * half;                                              \
-        const f32x2_t lo = epi_pair<ACT, TRAIN, OutT>((f32x2_t){acc[MI][ni][4 * j], acc[MI][ni][4 * j + 1]}, m, n, M, N, ep, es);         \
-        const f32x2_t hi = epi_pair<ACT, TRAIN, OutT>((f32x2_t){acc[MI][ni][4 * j + 2], acc[MI][ni][4 * j + 3]}, m, n + 2, M, N, ep, es); \
+        f32x2_t a_lo = {acc[MI][ni][4 * j], acc[MI][ni][4 * j + 1]}, a_hi = {acc[MI][ni][4 * j + 2], acc[MI][ni][4 * j + 3]};  \
+        if (ln_in) { a_lo *= rs[MI]; a_hi *= rs[MI]; }                                                     \
+        const f32x2_t lo = epi_pair<ACT, TRAIN, OutT>(a_lo, m, n, M, N, ep, es);                           \
+        const f32x2_t hi = epi_pair<ACT, TRAIN, OutT>(a_hi, m, n + 2, M, N, ep, es);                       \
         f32x2_t lo_ = lo, hi_ = hi;                                                                        \
         if (RES_DMA) {                                                                                     \
           const uint2 rr = rpatch[ni][j];                                                                  \
-          const float r0 = bf16_to_f32((bf16_t)(rr.x & 0xffff)), r1 = bf16_to_f32((bf16_t)(rr.x >> 16));  \
-          const float r2 = bf16_to_f32((bf16_t)(rr.y & 0xffff)), r3 = bf16_to_f32((bf16_t)(rr.y >> 16));  \
+          float r0 = bf16_to_f32((bf16_t)(rr.x & 0xffff)), r1 = bf16_to_f32((bf16_t)(rr.x >> 16));        \
+          float r2 = bf16_to_f32((bf16_t)(rr.y & 0xffff)), r3 = bf16_to_f32((bf16_t)(rr.y >> 16));        \
+          if (res_ln) {                                                                                    \
+            const f32x4_t g4 = *(const f32x4_t*)&gbtab[LNF == 2 ? wave_ : 0][0][ni * 32 + 8 * j + 4 * half];              \
+            const f32x4_t b4 = *(const f32x4_t*)&gbtab[LNF == 2 ? wave_ : 0][1][ni * 32 + 8 * j + 4 * half];              \
+            r0 = fmaf(fmaf(r0, ra[MI], rc[MI]), g4[0], b4[0]); r1 = fmaf(fmaf(r1, ra[MI], rc[MI]), g4[1], b4[1]); \
+            r2 = fmaf(fmaf(r2, ra[MI], rc[MI]), g4[2], b4[2]); r3 = fmaf(fmaf(r3, ra[MI], rc[MI]), g4[3], b4[3]); \
+          }                                                                                                \
           if (es.mul) { lo_[0] *= r0; lo_[1] *= r1; hi_[0] *= r2; hi_[1] *= r3; }                          \
           else {                                                                                           \
             lo_[0] = epi_resid<ACT>(lo_[0], r0, false); lo_[1] = epi_resid<ACT>(lo_[1], r1, false);        \
             hi_[0] = epi_resid<ACT>(hi_[0], r2, false); hi_[1] = epi_resid<ACT>(hi_[1], r3, false);        \
           }                                                                                                \
         }                                                                                                  \
+        if (stats_out && n < N) {                                                                          \
+          ssum += lo_ + hi_;                                                                               \
+          ssq = __builtin_elementwise_fma(lo_, lo_, __builtin_elementwise_fma(hi_, hi_, ssq));             \
+        }                                                                                                  \
         char* dst = lds_wr + (ni * 32 + 8 * j) * SB;                                                       \
         if (PROBE & 1) { asm volatile("" :: "v"(lo_), "v"(hi_)); }                                         \
         else if (STAGE16) *(uint2*)dst = make_uint2(pack_bf16x2(lo_[0], lo_[1]), pack_bf16x2(hi_[0], hi_[1])); \
         else *(f32x4_t*)dst = (f32x4_t){lo_[0], lo_[1], hi_[0], hi_[1]};                                   \
       }                                                                                                    \
+    if (stats_out) {          /* the other half of the row sits in lane ^ 32; one atomic pair per row */  \
+      float s1 = ssum[0] + ssum[1], s2 = ssq[0] + ssq[1];                                                  \
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);                                          \
+      if (half == 0 && m < M) { atomicAdd(ep.stats_out + 2 * m, s1); atomicAdd(ep.stats_out + 2 * m + 1, s2); } \
+    }                                                                                                      \
   } while (0)
 #define G6E_RES_DMA(MI)                                                                                    \
   do {                                                                                                     \
-    char* buf = resbuf + ((MI) % 3) * 8192;                                                                \
+    char* buf = resbuf + ((MI) & 1) * 8192;                                                                \
     _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                        \
       const int row = 4 * k + (lane >> 4), src_chunk = (lane & 15) ^ (row & 15);                           \
       int64_t gr = mrow0 + (MI) * 32 + row; if (gr > M - 1) gr = M - 1;                                     \
@@ -163,15 +193,14 @@ __device__ __forceinline__ void store_wave_tile6(f32x16_t (&acc)[4][4], int64_t 
       if (G6E_ROW_OK(MI, it)) rres[(MI) & 1][it] = *(const uint4*)(rp + (int64_t)((MI) * 32 + it * RPI) * ep.ldr); \
   } while (0)
 
-  // Residual patches 0, 1, 2 are requested up front, patch 3 as soon as WRITE(0) has consumed
-  // buffer 0.  vmcnt retires in order and stores are predicated, so each wait counts only the DMA
+  // Residual patches 0 and 1 are requested up front, patch p+2 as soon as WRITE(p) has consumed its
+  // buffer.  vmcnt retires in order and stores are predicated, so each wait counts only the DMA
   // instructions that are certainly younger than the patch it needs (8 per patch); the inline asm
   // (memory clobber) keeps the LDS reads behind the wait.
   if (RES_DMA) {
     G6E_RES_DMA(0);
     G6E_RES_DMA(1);
-    G6E_RES_DMA(2);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   } else if (RESID) {
     G6E_RESID(0);
   }
@@ -194,9 +223,8 @@ __device__ __forceinline__ void store_wave_tile6(f32x16_t (&acc)[4][4], int64_t 
     }
     if (mi + 1 < 4) {
       if (RES_DMA) {
-        if (mi == 0) { G6E_RES_DMA(3); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }   // patch 1; younger: 2, 3
-        else if (mi == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                     // patch 2; younger: 3
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                  // patch 3
+        if (mi + 2 < 4) { G6E_RES_DMA(mi + 2); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }   // younger: patch mi+2
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       G6E_WRITE(mi + 1);
       if (RESID && !RES_DMA) G6E_RESID(mi + 1);

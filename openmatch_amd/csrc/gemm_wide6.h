@@ -8,7 +8,7 @@
 // The epilogue variant (activation, training extras) is a KERNEL template parameter chosen on the
 // host: with all variants behind one in-kernel switch hipcc spills the 256 accumulators to scratch
 // at the switch (1 KiB per lane) and takes minutes to compile.
-template <typename T, typename OutT, int ACT, bool TRAIN, bool RESID>
+template <typename T, typename OutT, int ACT, bool TRAIN, bool RESID, int LNF = 0>
 __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel6(
     const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, OutT* C,
     int64_t ldc, int64_t M, int64_t N, int64_t K, GemmEpilogue ep, int group_m) {
@@ -18,19 +18,84 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel6(
   f32x16_t acc[4][4];
   unsigned long long* tr = ep.trace ? ep.trace + (size_t)blockIdx.x * 32 : nullptr;
   if (tr && threadIdx.x == 0) tr[0] = clock64();
-  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t nc = n0 + wn * 128;
-  {
-    f32x16_t init[4];          // the bias rides in the accumulators' initial value
-    g6_bias_init(init, ep.bias, nc, N);
-    gemm_mainloop6<T>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, init, tr);   // ends on a barrier
+  const int64_t mc = m0 + wm * 128, nc = n0 + wn * 128;
+  const char* pa[4];
+  const char* pb[4];
+  g6_point<T>(pa, pb, A, lda, B, ldb, M, N, m0, n0, wave, lane);
+  const int nk = (int)((K * (int64_t)sizeof(T)) / G4_ROW_BYTES);
+  // Initial value of the accumulators (loads issued BEFORE the first operand DMA: vmcnt retires in
+  // order, so they return first and the arithmetic runs while the operands are in flight):
+  //   * the bias; or
+  //   * LNF == 1 and A is a raw pre-LayerNorm tensor (GemmEpilogue::ln_stats):  b'_n / rstd_m - mu_m s_n,
+  //     so that the epilogue's rstd_m * acc = rstd_m (A W'^T - mu_m s_n) + b'_n.  s | b' go through a
+  //     wave-private static LDS table so that only one column quad is in registers at a time.
+  __shared__ float lntab[LNF == 1 ? 4 : 1][2][128];
+  float rs[4] = {1.f, 1.f, 1.f, 1.f};                                  // rstd_m (row scale of the epilogue)
+  const int l31 = lane & 31, half = lane >> 5;
+  const bool ln_in = LNF == 1 && ep.ln_stats != nullptr;
+  if (ln_in) {
+    float mu[4], inv[4];
+    float2 st[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      int64_t m = mc + mi * 32 + l31; if (m > M - 1) m = M - 1;
+      st[mi] = ((const float2*)ep.ln_stats)[m];
+    }
+    const int64_t n4 = nc + l31 * 4;                    // lanes 0-31: s, lanes 32-63: b'
+    f32x4_t t = {0.f, 0.f, 0.f, 0.f};
+    if (n4 < N) t = *(const f32x4_t*)((half ? ep.bias : ep.ln_colsum) + n4);
+    if (tr && threadIdx.x == 0) tr[1] = clock64();
+    g6_begin(pa, pb, nk, smem, wave);
+    float* tab = &lntab[LNF == 1 ? wave : 0][0][0];
+    *(f32x4_t*)(tab + half * 128 + l31 * 4) = t;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      mu[mi] = st[mi].x * ep.ln_inv_h;
+      const float var = fmaxf(st[mi].y * ep.ln_inv_h - mu[mi] * mu[mi], 0.f) + ep.ln_eps;
+      rs[mi] = rsqrtf(var);
+      inv[mi] = sqrtf(var);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4_t s4 = *(const f32x4_t*)(tab + ni * 32 + 8 * j + 4 * half);
+        const f32x4_t b4 = *(const f32x4_t*)(tab + 128 + ni * 32 + 8 * j + 4 * half);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[mi][ni][4 * j + e] = fmaf(-mu[mi], s4[e], b4[e] * inv[mi]);
+      }
+  } else {
+    f32x4_t bn[4][4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t n = nc + ni * 32 + 8 * j + 4 * half;
+        bn[ni][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (ep.bias && n < N) bn[ni][j] = *(const f32x4_t*)(ep.bias + n);   // N % 4 == 0, 16-byte aligned (wide_ok)
+      }
+    if (tr && threadIdx.x == 0) tr[1] = clock64();
+    g6_begin(pa, pb, nk, smem, wave);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[mi][ni][4 * j + e] = bn[ni][j][e];
   }
+  gemm_mainloop6_run<T>(pa, pb, nk, smem, acc, tr);   // ends on a barrier
   if (tr && threadIdx.x == 0) tr[15] = clock64();
 
   const EpiScalars es(ep);
   char* region = smem + wave * G6E_REGION_BYTES;
-  store_wave_tile6<OutT, ACT, TRAIN, RESID>(acc, m0 + wm * 128, nc, C, ldc, M, N, ep, es, region);
+  store_wave_tile6<OutT, ACT, TRAIN, RESID, LNF>(acc, mc, nc, C, ldc, M, N, ep, es, region, rs);
   if (tr && threadIdx.x == 0) { tr[28] = clock64(); tr[29] = blockIdx.x; }
 }
 
@@ -44,7 +109,7 @@ static int g6_group_m() {
   return v > 0 ? v : 8;
 }
 
-template <typename T, typename OutT, int ACT, bool TRAIN, bool RESID>
+template <typename T, typename OutT, int ACT, bool TRAIN, bool RESID, int LNF = 0>
 static int launch6(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                    int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
   const int64_t nwg = ((M + G4_BM - 1) / G4_BM) * ((N + G4_BN - 1) / G4_BN);
@@ -53,7 +118,7 @@ static int launch6(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   constexpr int lds_bytes = (RESID && sizeof(OutT) == 2 && G6E_RES_LDS_BYTES > G6_LDS_BYTES) ? G6E_RES_LDS_BYTES : G6_LDS_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel6<T, OutT, ACT, TRAIN, RESID>,
+    OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel6<T, OutT, ACT, TRAIN, RESID, LNF>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
@@ -61,7 +126,7 @@ static int launch6(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   const bool timing = om_timing_on();
   if (timing) om_timing_begin(tclass, s);
   // sweep order: 8 row tiles stay resident while the column tiles are walked (L2 reuse per XCD)
-  hipLaunchKernelGGL((gemm_nt_kernel6<T, OutT, ACT, TRAIN, RESID>), dim3((unsigned)nwg), dim3(G6_THREADS), lds_bytes, s,
+  hipLaunchKernelGGL((gemm_nt_kernel6<T, OutT, ACT, TRAIN, RESID, LNF>), dim3((unsigned)nwg), dim3(G6_THREADS), lds_bytes, s,
                      (const T*)A, lda, (const T*)B, ldb, (OutT*)C, ldc, M, N, K, ep, g6_group_m());
   if (timing) om_timing_end(tclass, s, 2.0 * (double)M * (double)N * (double)K);
   OM_LAUNCH_CHECK();

@@ -13,6 +13,14 @@ int omk_gemm_wide6_b16(int in_dtype, const void* A, int64_t lda, const void* B, 
   const int act = ep.act & 0xff;
   const bool train = ep.pre_act != nullptr || ep.drop_p > 0.f;
   const bool resid = ep.resid != nullptr;
+  if (ep.ln_stats || ep.rln_stats || ep.stats_out) {     // LayerNorm fused across GEMMs: three dedicated variants
+    if (in_dtype != OM_BF16 || out_dtype != OM_BF16 || train) OM_FAIL("fused LayerNorm epilogue: bf16 inference only");
+    if ((ep.ln_stats != nullptr) == (resid || ep.stats_out != nullptr)) OM_FAIL("fused LayerNorm epilogue: either the A side or the output side");
+    if (act == OM_ACT_NONE && !resid) return launch6<bf16_t, bf16_t, OM_ACT_NONE, false, false, 1>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    if (act == OM_ACT_GELU_ERF && !resid) return launch6<bf16_t, bf16_t, OM_ACT_GELU_ERF, false, false, 1>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    if (act == OM_ACT_NONE && resid) return launch6<bf16_t, bf16_t, OM_ACT_NONE, false, true, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    OM_FAIL("no fused-LayerNorm kernel for this activation");
+  }
   if (in_dtype == OM_BF16 && out_dtype == OM_BF16)
     return launch6_any<bf16_t, bf16_t>(act, train, resid, A, lda, B, ldb, C, ldc, M, N, K, ep, s);
   if (in_dtype == OM_BF16 && out_dtype == OM_F32 && act == OM_ACT_NONE && !train && !resid)

@@ -2,6 +2,9 @@
 #pragma once
 #include "common.h"
 
+// LayerNorm folded into the consuming bf16 weight (elementwise.hip)
+int omk_ln_fold(const void* W, const float* gamma, const float* beta, const float* b, void* Wf,
+                float* colsum, float* bf, int N, int K, hipStream_t s);
 int omk_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* g,
                   const float* b, int64_t M, int H, float eps, int rms, hipStream_t s);
 int omk_embed(int dtype, const int64_t* ids, const int64_t* type_ids, const float* word,
@@ -33,7 +36,18 @@ struct GemmEpilogue {
   float drop_p;        // 0 = no dropout
   uint64_t seed;
   unsigned long long* trace;  // debug: per-block phase timestamps (om_debug_gemm_trace), else NULL
+  // ---- LayerNorm fused across GEMMs (16-bit inference path of the BERT encoder, v6 kernel only) ----
+  // stats = [M][2] f32 (sum, sum of squares) of a row over `1 / ln_inv_h` columns.
+  const float* ln_stats;     // the A operand is a RAW pre-LayerNorm tensor: C = LN(A) W^T + b computed as
+  const float* ln_colsum;    //   rstd_m (A W'^T - mu_m s_n) + b'_n  with W' = W*gamma, s_n = sum_k W'_nk, bias = b'
+  const float* rln_stats;    // the residual is a RAW pre-LayerNorm tensor: add LN(resid) with these statistics
+  const float* rln_g;        //   and this affine (per output column)
+  const float* rln_b;
+  float* stats_out;          // accumulate (sum, sum of squares) of every output row (the next LayerNorm's input)
+  float ln_inv_h, ln_eps;
 };
+// true when omk_gemm will run [M,N] x K (16-bit) on the kernel that implements the ln_* / rln_* / stats_out fields
+bool omk_gemm_ln_fusable(int dtype, int64_t M, int64_t N, int64_t K);
 // wide-tile generations, one translation unit each (gemm_wide4.hip / gemm_wide6_*.hip); omk_gemm dispatches
 int omk_gemm_wide4(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int out_dtype,
                    void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s);

@@ -104,6 +104,43 @@ def test_encoder_matches_oracle_on_ragged_batches():
         assert np.abs(got.cpu().numpy() - ref.numpy()).max() < 1e-4, (B, L)
 
 
+def test_fused_layernorm_path_matches_unfused_and_oracle(monkeypatch):
+    """bf16 batches of >= 512 tokens take the path where LayerNorm is folded into the GEMMs around it
+    (encoder.hip): same embeddings as the launch-per-LayerNorm path and as the f32 oracle, incl. a
+    ragged batch, a non-multiple-of-256 row count and non-trivial LayerNorm affines."""
+    from transformers import BertConfig, BertModel
+    from openmatch.modeling import DRModelForInference
+    torch.manual_seed(11)
+    cfg = BertConfig(hidden_size=256, num_hidden_layers=3, num_attention_heads=4, intermediate_size=512,
+                     vocab_size=600, max_position_embeddings=128)
+    lm = BertModel(cfg).eval()
+    with torch.no_grad():                      # random-init LayerNorms are (1, 0): make the affines matter
+        for name, p in lm.named_parameters():
+            if "LayerNorm.weight" in name:
+                p.copy_(1.0 + 0.3 * torch.randn_like(p))
+            elif "LayerNorm.bias" in name:
+                p.copy_(0.2 * torch.randn_like(p))
+    sd = {k: v.clone() for k, v in lm.state_dict().items()}
+    model = DRModelForInference(lm_q=lm, lm_p=lm, pooling="mean", normalize=True,
+                                model_args=NS(encoder_only=False, dtype="bfloat16")).to(DEV).eval()
+    rng = np.random.default_rng(8)
+    for B, L in ((8, 64), (9, 77), (40, 128)):
+        ids, mask = synth_tokens(rng, B, L, vocab=600, lo_len=5, lo_id=300)
+        items = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
+        dev_items = {k: v.to(DEV) for k, v in items.items()}
+        _, ref = encoder_ref.encode(sd, cfg, "bert", items, "mean", None, True)
+        monkeypatch.setenv("OM_ENCODER_FUSED_LN", "1")
+        _, fused = model.encode_passage(dev_items)
+        monkeypatch.setenv("OM_ENCODER_FUSED_LN", "0")
+        _, plain = model.encode_passage(dev_items)
+        fused, plain, ref = fused.float().cpu(), plain.float().cpu(), ref.float()
+        cos = lambda a, b: torch.nn.functional.cosine_similarity(a, b, dim=1).min().item()
+        assert cos(plain, ref) > 0.999, (B, L, cos(plain, ref))
+        assert cos(fused, ref) > 0.999, (B, L, cos(fused, ref))
+        assert cos(fused, plain) > 0.9995, (B, L, cos(fused, plain))
+        assert not torch.equal(fused, plain)          # the two paths really are different code
+
+
 # ------------------------------------------------------------------------------- search
 def _adjudicate(I_gpu, I_ref, P, Q, k):
     P64, Q64 = torch.from_numpy(P).double(), torch.from_numpy(Q).double()

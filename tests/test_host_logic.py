@@ -202,7 +202,7 @@ def test_no_kernel_spills_to_scratch():
         if "attention_kernelI" in k and ("Li8E" in k or "Li6E" in k):
             return True
         if "gemm_nt_kernel6" in k:
-            return v <= (1280 if re.search(r"Li\dELb1ELb[01]EE", k) else 96)
+            return v <= (1280 if re.search(r"Li\dELb1ELb[01]ELi\dEE", k) else 96)
         return False
     bad = {k: v for k, v in kernels.items() if v > 0 and not allowed(k, v)}
     assert not bad, bad

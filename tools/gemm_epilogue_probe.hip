@@ -21,13 +21,14 @@ __global__ __launch_bounds__(G6_THREADS) void probe(bf16_t* C, const bf16_t* R, 
   GemmEpilogue ep = {};
   ep.act = ACT; ep.resid = RESID ? R : nullptr; ep.ldr = ldc;
   const EpiScalars es(ep);
+  const float one[4] = {1.f, 1.f, 1.f, 1.f};
   const int64_t ntn = N / 256;
   const int64_t m0 = (int64_t)(blockIdx.x / ntn) * 256, n0 = (int64_t)(blockIdx.x % ntn) * 256;
   char* region = smem + wave * G6E_REGION_BYTES;
   __syncthreads();
   const long long t0 = clock64();
   for (int rep = 0; rep < reps; ++rep) {
-    store_wave_tile6<bf16_t, ACT, false, RESID, PROBE>(acc, m0 + wm * 128, n0 + wn * 128, C, ldc, M, N, ep, es, region);
+    store_wave_tile6<bf16_t, ACT, false, RESID, 0, PROBE>(acc, m0 + wm * 128, n0 + wn * 128, C, ldc, M, N, ep, es, region, one);
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
   }
   __syncthreads();
