@@ -127,14 +127,27 @@ __global__ __launch_bounds__(64 * KT) void attention_kernel(
 #pragma unroll
   for (int t = 0; t < KT; ++t) SlabMma<T>::run(s[t], sVt + l31 * LP + t * 32 + 4 * half, LP, o);
 
-  T* out = ctx + b * L * H + h * 64;
+  // Context rows leave through LDS: the wave parks its [32 x 64] block in the K rows of its own
+  // queries (every wave is past K and V^T after the barrier; waves without query rows have exited)
+  // and writes whole 16-byte vectors, 8 (bf16) / 4 (f32) complete rows per instruction, instead of 32
+  // two-byte stores per lane.
+  __syncthreads();
+  T* so = (T*)(sK + (size_t)q0 * G::ROWB);
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (q < L) ElemOps<T>::store(out + (int64_t)q * H + dt * 32 + l31, o[dt][r]);
+      const int q = (r & 3) + 8 * (r >> 2) + 4 * half;
+      ElemOps<T>::store(so + q * 64 + dt * 32 + l31, o[dt][r]);
     }
+  T* out = ctx + (b * L + q0) * H + h * 64;
+  constexpr int VPR = G::ROWB / 16;                 // 16-byte vectors per row
+#pragma unroll
+  for (int it = 0; it < 32 * VPR / 64; ++it) {
+    const int idx = it * 64 + lane, row = idx / VPR, c = idx % VPR;
+    const uint4 v = *(const uint4*)((const char*)so + row * G::ROWB + c * 16);
+    if (q0 + row < L) *(uint4*)((char*)(out + (int64_t)row * H) + c * 16) = v;
+  }
 }
 
 template <typename T, int KT>

@@ -171,7 +171,10 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
       }
       const OmLayerWeights& last = Ls[c->n_layers - 1];
       void* dst = out_hidden ? out_hidden : (void*)ws.x;
-      RUN(omk_layernorm(dt, ws.x1, H, dst, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, 0, s));
+      if (!out_hidden && c->pooling == OM_POOL_FIRST)      // only the [CLS] rows are ever read
+        RUN(omk_layernorm(dt, ws.x1, L * H, dst, L * H, last.ln2_g, last.ln2_b, B, H, c->ln_eps, 0, s));
+      else
+        RUN(omk_layernorm(dt, ws.x1, H, dst, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, 0, s));
       final_hidden = (char*)dst;
     } else
     for (int l = 0; l < c->n_layers; ++l) {
