@@ -50,8 +50,9 @@ static EncWs carve(const OmEncoderConfig* c, int64_t B, int64_t L, char* base) {
   w.wfold = take(fuse ? wide * H * es : 0);
   w.colsum = (float*)take(fuse ? wide * 4 : 0);
   w.bfold = (float*)take(fuse ? wide * 4 : 0);
-  w.stats1 = (float*)take(fuse ? M * 8 : 0);
-  w.stats2 = (float*)take(fuse ? M * 8 : 0);
+  // one (sum, sum of squares) buffer per LayerNorm site, all zeroed by ONE memset per forward
+  w.stats1 = (float*)take(fuse ? (size_t)2 * c->n_layers * M * 8 : 0);
+  w.stats2 = w.stats1 ? w.stats1 + (size_t)c->n_layers * M * 2 : nullptr;
   w.total = off;
   return w;
 }
@@ -131,9 +132,13 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
     if (getenv("OM_ENCODER_DEBUG")) fprintf(stderr, "om_encoder_forward: M=%ld fused_ln=%d\n", (long)M, (int)fuse);
     if (fuse) {
       const float inv_h = 1.0f / (float)H;
+      OM_HIP(hipMemsetAsync(ws.stats1, 0, (size_t)2 * c->n_layers * M * 8, s));
       // y1 lives in ws.y, y2 in ws.x1; ws.x is the embedding output (layer 0's input)
       for (int l = 0; l < c->n_layers; ++l) {
         const OmLayerWeights& lw = Ls[l];
+        float* st1 = ws.stats1 + (size_t)l * M * 2;                     // LN1 of this layer
+        float* st2 = ws.stats2 + (size_t)l * M * 2;                     // LN2 of this layer
+        const float* st2p = l ? ws.stats2 + (size_t)(l - 1) * M * 2 : nullptr;   // LN2 of the previous one
         GemmEpilogue e = {};
         // ---- QKV: x0 for the first layer, LN2_{l-1}(y2) folded afterwards
         if (l == 0) {
@@ -142,31 +147,29 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
         } else {
           const OmLayerWeights& pw = Ls[l - 1];
           RUN(omk_ln_fold(lw.qkv_w, pw.ln2_g, pw.ln2_b, lw.qkv_b, ws.wfold, ws.colsum, ws.bfold, 3 * H, H, s));
-          e.bias = ws.bfold; e.ln_stats = ws.stats2; e.ln_colsum = ws.colsum; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+          e.bias = ws.bfold; e.ln_stats = st2p; e.ln_colsum = ws.colsum; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
           RUN(omk_gemm(dt, ws.x1, H, ws.wfold, H, dt, ws.qkv, 3 * H, M, 3 * H, H, e, s));
         }
         RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, nullptr, B, (int)L, H, nh, scale, 0.f, 0, s));
         // ---- attention output + residual -> y1, statistics of LN1
-        OM_HIP(hipMemsetAsync(ws.stats1, 0, (size_t)M * 8, s));
         e = GemmEpilogue{};
-        e.bias = lw.o_b; e.ldr = H; e.stats_out = ws.stats1; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+        e.bias = lw.o_b; e.ldr = H; e.stats_out = st1; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
         if (l == 0) {
           e.resid = ws.x;
         } else {
           const OmLayerWeights& pw = Ls[l - 1];
-          e.resid = ws.x1; e.rln_stats = ws.stats2; e.rln_g = pw.ln2_g; e.rln_b = pw.ln2_b;
+          e.resid = ws.x1; e.rln_stats = st2p; e.rln_g = pw.ln2_g; e.rln_b = pw.ln2_b;
         }
         RUN(omk_gemm(dt, ws.ctx, H, lw.o_w, H, dt, ws.y, H, M, H, H, e, s));
         // ---- FFN1 on LN1(y1), folded
         RUN(omk_ln_fold(lw.ffn1_w, lw.ln1_g, lw.ln1_b, lw.ffn1_b, ws.wfold, ws.colsum, ws.bfold, F, H, s));
         e = GemmEpilogue{};
-        e.bias = ws.bfold; e.act = c->act; e.ln_stats = ws.stats1; e.ln_colsum = ws.colsum; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+        e.bias = ws.bfold; e.act = c->act; e.ln_stats = st1; e.ln_colsum = ws.colsum; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
         RUN(omk_gemm(dt, ws.y, H, ws.wfold, H, dt, ws.ff, F, M, F, H, e, s));
         // ---- FFN2 + LN1(y1) as the residual -> y2, statistics of LN2
-        OM_HIP(hipMemsetAsync(ws.stats2, 0, (size_t)M * 8, s));
         e = GemmEpilogue{};
-        e.bias = lw.ffn2_b; e.resid = ws.y; e.ldr = H; e.rln_stats = ws.stats1; e.rln_g = lw.ln1_g; e.rln_b = lw.ln1_b;
-        e.stats_out = ws.stats2; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+        e.bias = lw.ffn2_b; e.resid = ws.y; e.ldr = H; e.rln_stats = st1; e.rln_g = lw.ln1_g; e.rln_b = lw.ln1_b;
+        e.stats_out = st2; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
         RUN(omk_gemm(dt, ws.ff, F, lw.ffn2_w, F, dt, ws.x1, H, M, H, F, e, s));
       }
       const OmLayerWeights& last = Ls[c->n_layers - 1];
