@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OM_ABI_VERSION 1
+#define OM_ABI_VERSION 2
 
 /* element types */
 #define OM_F32 0
@@ -177,12 +177,15 @@ int om_encoder_forward(const OmEncoderConfig* cfg, const OmEncoderWeights* w,
 typedef struct OmLayerGrads {
   float* qkv_w;  float* qkv_b;  float* o_w;    float* o_b;   float* ln1_g; float* ln1_b;
   float* ffn1_w; float* ffn1_b; float* ffn2_w; float* ffn2_b; float* ln2_g; float* ln2_b;
+  float* ffn1g_w;                   /* T5 v1.1 gate projection wi_1 (ABI v2)          */
 } OmLayerGrads;
 
 typedef struct OmEncoderGrads {
   float* word_emb; float* pos_emb; float* type_emb; float* emb_ln_g; float* emb_ln_b;
   const OmLayerGrads* layers_host;  /* HOST array [n_layers] of device pointers */
   float* head_w;                    /* [head_out, head_in] or NULL              */
+  float* final_ln_g;                /* T5: final RMSNorm weight [hidden] (ABI v2)     */
+  float* rel_bias;                  /* T5: relative_attention_bias [buckets, heads]   */
 } OmEncoderGrads;
 
 size_t om_encoder_tape_bytes(const OmEncoderConfig* cfg, int64_t B, int64_t L);

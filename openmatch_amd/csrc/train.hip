@@ -11,10 +11,12 @@
 // Every dense contraction runs on the NT MFMA GEMM (gemm.hip); wgrad outputs are f32.
 #include <math.h>
 
+#include <vector>
+
 #include "train_kernels.h"
 
 namespace {
-struct Dims { int64_t M, Mp, B, L; int H, F, nl, nh, D; size_t es; };
+struct Dims { int64_t M, Mp, B, L; int H, F, nl, nh, D; size_t es; bool t5, gated; };
 
 Dims dims_of(const OmEncoderConfig* c, int64_t B, int64_t L) {
   Dims d;
@@ -22,6 +24,8 @@ Dims dims_of(const OmEncoderConfig* c, int64_t B, int64_t L) {
   d.H = c->hidden; d.F = c->ffn; d.nl = c->n_layers; d.nh = c->n_heads;
   d.D = c->head_in > 0 ? c->head_out : c->hidden;
   d.es = c->dtype == OM_BF16 ? 2 : 4;
+  d.t5 = c->arch == OM_ARCH_T5;
+  d.gated = d.t5 && (c->act & 0xff) == OM_ACT_GELU_TANH;      // T5 v1.1: gated gelu_new (wi_0, wi_1)
   return d;
 }
 
@@ -30,6 +34,7 @@ struct Tape {
   char* x0pre;             // [M,H] embedding LayerNorm output BEFORE dropout (only if dropout)
   char* x;                 // [(nl+1)][M,H] layer inputs / final output
   char *qkv, *ctx, *y1, *x1, *f, *y2;   // per layer, strided by their per-layer size
+  char* f2;                // T5 gated FFN: the gate projection (per layer, stride sf)
   float *pooled, *headout;             // [B,H], [B,D] (pre-normalise)
   size_t total;
   size_t sx, sqkv, sf;     // per-layer strides in bytes
@@ -44,10 +49,11 @@ Tape carve_tape(const Dims& d, char* base) {
   t.x = take(t.sx * (d.nl + 1));
   t.qkv = take(t.sqkv * d.nl);
   t.ctx = take(t.sx * d.nl);
-  t.y1 = take(t.sx * d.nl);
+  t.y1 = take(d.t5 ? 0 : t.sx * d.nl);           // BERT: pre-LayerNorm sums; T5 (pre-norm) keeps none
   t.x1 = take(t.sx * d.nl);
   t.f = take(t.sf * d.nl);
-  t.y2 = take(t.sx * d.nl);
+  t.y2 = take(d.t5 ? 0 : t.sx * d.nl);
+  t.f2 = take(d.gated ? t.sf * d.nl : 0);
   t.pooled = (float*)take((size_t)d.B * d.H * 4);
   t.headout = (float*)take((size_t)d.B * d.D * 4);
   t.total = off;
@@ -60,6 +66,10 @@ struct Ws {
   char *dxa, *dxb, *dy, *dd, *df, *dqkv, *dctx;   // bwd activation gradients
   char *tl, *tr, *wt;               // transposed operands / transposed weight
   float *dhead, *dpooled;
+  // T5 extras: normed-input scratch, gate gradient, bias [nh,L,L], its LUT and per-offset gradient
+  char *nbuf, *df2;
+  float *posbias, *drel;
+  int* lut;
   size_t total;
 };
 Ws carve_ws(const Dims& d, char* base) {
@@ -76,16 +86,23 @@ Ws carve_ws(const Dims& d, char* base) {
   w.wt = take(wide * (size_t)std::max(d.H, d.F) * d.es);
   w.dhead = (float*)take((size_t)d.B * d.D * 4);
   w.dpooled = (float*)take((size_t)d.B * d.H * 4);
+  w.nbuf = take(d.t5 ? mh : 0);
+  w.df2 = take(d.gated ? mf : 0);
+  w.posbias = (float*)take(d.t5 ? (size_t)d.nh * d.L * d.L * 4 : 0);
+  w.drel = (float*)take(d.t5 ? (size_t)d.nh * (2 * d.L) * 4 : 0);
+  w.lut = (int*)take(d.t5 ? (size_t)(2 * d.L) * 4 : 0);
   w.total = off;
   return w;
 }
 
 int check_train_cfg(const OmEncoderConfig* c, int64_t L) {
-  if (c->arch != OM_ARCH_BERT) OM_FAIL("training is implemented for the BERT encoder");
+  if (c->arch != OM_ARCH_BERT && c->arch != OM_ARCH_T5) OM_FAIL("unknown arch");
   if (c->dtype != OM_F32 && c->dtype != OM_BF16) OM_FAIL("dtype must be OM_F32 or OM_BF16");
   if (c->head_dim != 64 || c->n_heads * 64 != c->hidden) OM_FAIL("head_dim must be 64");
   if (L < 1 || L > 128) OM_FAIL("training supports sequence lengths up to 128");
-  if (c->act != OM_ACT_GELU_ERF) OM_FAIL("training supports the erf-GELU FFN");
+  if (c->arch == OM_ARCH_BERT && c->act != OM_ACT_GELU_ERF) OM_FAIL("BERT training supports the erf-GELU FFN");
+  if (c->arch == OM_ARCH_T5 && (c->act & 0xff) != OM_ACT_RELU && (c->act & 0xff) != OM_ACT_GELU_TANH)
+    OM_FAIL("T5 training supports relu and gated gelu_new feed-forward layers");
   const int es = c->dtype == OM_BF16 ? 2 : 4;
   if ((c->hidden * es) % 128 || (c->ffn * es) % 128) OM_FAIL("hidden/ffn rows must be multiples of 128 bytes");
   if (c->pooling != OM_POOL_FIRST && c->pooling != OM_POOL_MEAN) OM_FAIL("pooling must be first or mean");
@@ -95,6 +112,155 @@ int check_train_cfg(const OmEncoderConfig* c, int64_t L) {
 inline uint64_t site_seed(uint64_t seed, int layer, int site) {
   return seed + 0x9E3779B97F4A7C15ull * (uint64_t)(16 * layer + site + 1);
 }
+#define RUN(expr) do { if (expr) return 1; } while (0)
+
+// relative-position bias [nh, L, L] from the bucket table (and the LUT the backward needs again)
+int t5_bias_setup(const OmEncoderConfig* c, const OmEncoderWeights* w, const Dims& d, Ws& ws, hipStream_t s) {
+  if (!w->rel_bias || !w->final_ln_g) OM_FAIL("T5 needs rel_bias and final_ln_g");
+  const int L = (int)d.L;
+  std::vector<int> lut(2 * L);
+  for (int rel = -(L - 1); rel <= L - 1; ++rel) lut[rel + (L - 1)] = om_t5_relative_bucket(rel, c->rel_buckets, c->rel_max_dist);
+  OM_HIP(hipMemcpyAsync(ws.lut, lut.data(), (2 * L - 1) * sizeof(int), hipMemcpyHostToDevice, s));
+  OM_HIP(hipStreamSynchronize(s));      // `lut` is a pageable host temporary
+  return omk_t5_bias(w->rel_bias, ws.lut, ws.posbias, L, d.nh, s);
+}
+
+// T5 encoder stack (pre-RMSNorm residual blocks, HF:models/t5/modeling_t5.py T5Stack / T5Block):
+//   x0 = drop(E[ids]);  per layer:  x1 = x + drop(Attn(rms(x)) Wo^T),  x' = x1 + drop(drop(act(rms(x1) Wi^T)) Wo2^T)
+//   out = drop(rms(x_last))
+int t5_train_forward(const OmEncoderConfig* c, const OmEncoderWeights* w, const int64_t* input_ids,
+                     const int64_t* attention_mask, const Dims& d, Tape& t, Ws& ws, float hd, float ad,
+                     uint64_t seed, char** final_hidden, hipStream_t s) {
+  const int dt = c->dtype, H = d.H, F = d.F;
+  const int64_t M = d.M;
+  const OmLayerWeights* Ls = w->layers_host;
+  RUN(t5_bias_setup(c, w, d, ws, s));
+  RUN(omk_embed(dt, input_ids, nullptr, w->word_emb, nullptr, nullptr, nullptr, nullptr, t.x, M, (int)d.L, H, c->vocab, 1, c->ln_eps, 0, s));
+  if (hd > 0.f) RUN(omk_dropout(dt, t.x, t.x, M * H, hd, site_seed(seed, 0, 0), s));
+  for (int l = 0; l < d.nl; ++l) {
+    const OmLayerWeights& lw = Ls[l];
+    char* x = t.x + t.sx * l;
+    char* qkv = t.qkv + t.sqkv * l;
+    char* ctx = t.ctx + t.sx * l;
+    char* x1 = t.x1 + t.sx * l;
+    char* f = t.f + t.sf * l;
+    RUN(omk_layernorm(dt, x, H, ws.nbuf, H, lw.ln1_g, nullptr, M, H, c->ln_eps, 1, s));
+    GemmEpilogue ep = {};
+    RUN(omk_gemm(dt, ws.nbuf, H, lw.qkv_w, H, dt, qkv, 3 * H, M, 3 * H, H, ep, s));
+    RUN(omk_attention(dt, qkv, ctx, attention_mask, ws.posbias, d.B, (int)d.L, H, d.nh, 1.0f, ad, site_seed(seed, l, 2), s));
+    ep = GemmEpilogue{};
+    ep.resid = x; ep.ldr = H; ep.drop_p = hd; ep.seed = site_seed(seed, l, 3);
+    RUN(omk_gemm(dt, ctx, H, lw.o_w, H, dt, x1, H, M, H, H, ep, s));
+    RUN(omk_layernorm(dt, x1, H, ws.nbuf, H, lw.ln2_g, nullptr, M, H, c->ln_eps, 1, s));
+    ep = GemmEpilogue{};
+    ep.pre_act = f; ep.ldp = F; ep.drop_p = hd; ep.seed = site_seed(seed, l, 5);
+    if (d.gated) {
+      if (!lw.ffn1g_w) OM_FAIL("gated T5 feed-forward needs ffn1g_w");
+      char* f2 = t.f2 + t.sf * l;
+      GemmEpilogue eg = {};
+      RUN(omk_gemm(dt, ws.nbuf, H, lw.ffn1g_w, H, dt, f2, F, M, F, H, eg, s));
+      ep.act = OM_ACT_GELU_TANH | OM_ACT_MUL_RESID; ep.resid = f2; ep.ldr = F;
+    } else {
+      ep.act = OM_ACT_RELU;
+    }
+    RUN(omk_gemm(dt, ws.nbuf, H, lw.ffn1_w, H, dt, ws.g, F, M, F, H, ep, s));
+    ep = GemmEpilogue{};
+    ep.resid = x1; ep.ldr = H; ep.drop_p = hd; ep.seed = site_seed(seed, l, 4);
+    RUN(omk_gemm(dt, ws.g, F, lw.ffn2_w, F, dt, t.x + t.sx * (l + 1), H, M, H, F, ep, s));
+  }
+  RUN(omk_layernorm(dt, t.x + t.sx * d.nl, H, ws.dxa, H, w->final_ln_g, nullptr, M, H, c->ln_eps, 1, s));
+  if (hd > 0.f) RUN(omk_dropout(dt, ws.dxa, ws.dxa, M * H, hd, site_seed(seed, d.nl, 1), s));
+  *final_hidden = ws.dxa;
+  return 0;
+}
+
+// dx: gradient w.r.t. the stack's output (after the final dropout); returns through the grads struct
+int t5_train_backward(const OmEncoderConfig* c, const OmEncoderWeights* w, const int64_t* input_ids,
+                      const int64_t* attention_mask, const Dims& d, const Tape& t, Ws& ws, float hd, float ad,
+                      uint64_t seed, char* dx, char* dx_other, const OmEncoderGrads* g, hipStream_t s) {
+  const int dt = c->dtype, H = d.H, F = d.F;
+  const int64_t M = d.M, Mp = d.Mp;
+  const OmLayerWeights* Ls = w->layers_host;
+  const OmLayerGrads* Gs = g->layers_host;
+  if (!g->final_ln_g || !g->rel_bias) OM_FAIL("T5 gradients need final_ln_g and rel_bias buffers");
+  RUN(t5_bias_setup(c, w, d, ws, s));
+  OM_HIP(hipMemsetAsync(ws.drel, 0, (size_t)d.nh * (2 * d.L) * 4, s));
+#define WGRAD(left, right, rows_out, cols_in, dst) \
+  RUN(omk_gemm_splitk(dt, left, Mp, right, Mp, dst, cols_in, rows_out, cols_in, Mp, s))
+  // final dropout + RMSNorm
+  if (hd > 0.f) RUN(omk_dropout(dt, dx, dx, M * H, hd, site_seed(seed, d.nl, 1), s));
+  RUN(omk_norm_bwd(dt, dx, t.x + t.sx * d.nl, w->final_ln_g, dx_other, g->final_ln_g, nullptr, M, H, c->ln_eps, 1, nullptr, s));
+  { char* tmp = dx; dx = dx_other; dx_other = tmp; }
+  const int kind = d.gated ? 1 : 0;
+  for (int l = d.nl - 1; l >= 0; --l) {
+    const OmLayerWeights& lw = Ls[l];
+    const OmLayerGrads& lg = Gs[l];
+    const char* x = t.x + t.sx * l;
+    const char* qkv = t.qkv + t.sqkv * l;
+    const char* ctx = t.ctx + t.sx * l;
+    const char* x1 = t.x1 + t.sx * l;
+    const char* f = t.f + t.sf * l;
+    const char* f2 = d.gated ? t.f2 + t.sf * l : nullptr;
+    // ---- feed-forward branch
+    const char* dO = dx;
+    if (hd > 0.f) { RUN(omk_dropout(dt, dx, ws.dd, M * H, hd, site_seed(seed, l, 4), s)); dO = ws.dd; }
+    RUN(omk_t5_act_fwd(dt, f, f2, ws.g, M * F, kind, s));                     // g = act(f) [* f2]
+    if (hd > 0.f) RUN(omk_dropout(dt, ws.g, ws.g, M * F, hd, site_seed(seed, l, 5), s));
+    RUN(omk_transpose(dt, dO, H, M, H, ws.tl, Mp, Mp, 0, s));
+    RUN(omk_transpose(dt, ws.g, F, M, F, ws.tr, Mp, Mp, 0, s));
+    WGRAD(ws.tl, ws.tr, H, F, lg.ffn2_w);                                     // dWo2 [H,F]
+    RUN(omk_transpose(dt, lw.ffn2_w, F, H, F, ws.wt, H, H, 0, s));            // Wo2^T [F,H]
+    GemmEpilogue e = {};
+    RUN(omk_gemm(dt, dO, H, ws.wt, H, dt, ws.df, F, M, F, H, e, s));          // dg = dO Wo2
+    if (hd > 0.f) RUN(omk_dropout(dt, ws.df, ws.df, M * F, hd, site_seed(seed, l, 5), s));
+    RUN(omk_t5_act_bwd(dt, ws.df, f, f2, ws.df, ws.df2, M * F, kind, s));     // df (in place), df2
+    RUN(omk_layernorm(dt, x1, H, ws.nbuf, H, lw.ln2_g, nullptr, M, H, c->ln_eps, 1, s));   // n2 again
+    RUN(omk_transpose(dt, ws.nbuf, H, M, H, ws.tr, Mp, Mp, 0, s));            // n2^T [H,Mp]
+    RUN(omk_transpose(dt, ws.df, F, M, F, ws.tl, Mp, Mp, 0, s));
+    WGRAD(ws.tl, ws.tr, F, H, lg.ffn1_w);                                     // dWi (wi / wi_0) [F,H]
+    if (d.gated) {
+      if (!lg.ffn1g_w) OM_FAIL("gated T5 gradients need ffn1g_w");
+      RUN(omk_transpose(dt, ws.df2, F, M, F, ws.tl, Mp, Mp, 0, s));
+      WGRAD(ws.tl, ws.tr, F, H, lg.ffn1g_w);                                  // dWi_1 [F,H]
+    }
+    RUN(omk_transpose(dt, lw.ffn1_w, H, F, H, ws.wt, F, F, 0, s));            // Wi^T [H,F]
+    e = GemmEpilogue{};
+    RUN(omk_gemm(dt, ws.df, F, ws.wt, F, dt, ws.dy, H, M, H, F, e, s));       // dn2 = df Wi
+    if (d.gated) {
+      RUN(omk_transpose(dt, lw.ffn1g_w, H, F, H, ws.wt, F, F, 0, s));
+      e = GemmEpilogue{};
+      e.resid = ws.dy; e.ldr = H;
+      RUN(omk_gemm(dt, ws.df2, F, ws.wt, F, dt, ws.dy, H, M, H, F, e, s));    // += df2 Wi_1
+    }
+    RUN(omk_norm_bwd(dt, ws.dy, x1, lw.ln2_g, dx_other, lg.ln2_g, nullptr, M, H, c->ln_eps, 1, dx, s));   // dx1
+    // ---- attention branch (dx_other now holds d/d x1)
+    const char* dA = dx_other;
+    if (hd > 0.f) { RUN(omk_dropout(dt, dx_other, ws.dd, M * H, hd, site_seed(seed, l, 3), s)); dA = ws.dd; }
+    RUN(omk_transpose(dt, dA, H, M, H, ws.tl, Mp, Mp, 0, s));
+    RUN(omk_transpose(dt, ctx, H, M, H, ws.tr, Mp, Mp, 0, s));
+    WGRAD(ws.tl, ws.tr, H, H, lg.o_w);
+    RUN(omk_transpose(dt, lw.o_w, H, H, H, ws.wt, H, H, 0, s));
+    e = GemmEpilogue{};
+    RUN(omk_gemm(dt, dA, H, ws.wt, H, dt, ws.dctx, H, M, H, H, e, s));        // dctx = dA Wo
+    RUN(omk_attention_bwd_bias(dt, qkv, ws.dctx, ws.dqkv, attention_mask, d.B, (int)d.L, H, d.nh, 1.0f, ad,
+                               site_seed(seed, l, 2), ws.posbias, ws.drel, s));
+    RUN(omk_layernorm(dt, x, H, ws.nbuf, H, lw.ln1_g, nullptr, M, H, c->ln_eps, 1, s));    // n1 again
+    RUN(omk_transpose(dt, ws.dqkv, 3 * H, M, 3 * H, ws.tl, Mp, Mp, 0, s));
+    RUN(omk_transpose(dt, ws.nbuf, H, M, H, ws.tr, Mp, Mp, 0, s));
+    WGRAD(ws.tl, ws.tr, 3 * H, H, lg.qkv_w);
+    RUN(omk_transpose(dt, lw.qkv_w, H, 3 * H, H, ws.wt, 3 * H, 3 * H, 0, s));
+    e = GemmEpilogue{};
+    RUN(omk_gemm(dt, ws.dqkv, 3 * H, ws.wt, 3 * H, dt, ws.dy, H, M, H, 3 * H, e, s));   // dn1
+    RUN(omk_norm_bwd(dt, ws.dy, x, lw.ln1_g, dx, lg.ln1_g, nullptr, M, H, c->ln_eps, 1, dx_other, s));   // dx of layer input
+  }
+#undef WGRAD
+  const char* de = dx;
+  if (hd > 0.f) { RUN(omk_dropout(dt, dx, ws.dd, M * H, hd, site_seed(seed, 0, 0), s)); de = ws.dd; }
+  RUN(omk_t5_embed_bwd(dt, de, input_ids, g->word_emb, M, H, c->vocab, s));
+  RUN(omk_t5_bias_bwd(ws.drel, ws.lut, g->rel_bias, (int)d.L, d.nh, s));
+  return 0;
+}
+#undef RUN
 }  // namespace
 
 extern "C" size_t om_encoder_tape_bytes(const OmEncoderConfig* cfg, int64_t B, int64_t L) {
@@ -127,6 +293,21 @@ extern "C" int om_encoder_train_forward(const OmEncoderConfig* c, const OmEncode
   const int64_t M = d.M;
   const OmLayerWeights* Ls = w->layers_host;
   if (!Ls) OM_FAIL("layers_host is null");
+  if (d.t5) {
+    char* xf_t5 = nullptr;
+    if (t5_train_forward(c, w, input_ids, attention_mask, d, t, ws, hidden_dropout, attn_dropout, seed, &xf_t5, s)) return 1;
+    const bool head_t5 = c->head_in > 0 && w->head_w;
+    RUN(omk_pool(dt, xf_t5, attention_mask, t.pooled, B, (int)L, H, c->pooling, s));
+    float* pre_t5 = c->normalize ? t.headout : out_reps;
+    if (head_t5) {
+      if (om_gemm_nt(OM_F32, t.pooled, H, w->head_w, c->head_in, OM_F32, pre_t5, d.D, B, d.D, c->head_in,
+                     nullptr, nullptr, 0, OM_ACT_NONE, s)) return 1;
+    } else {
+      OM_HIP(hipMemcpyAsync(pre_t5, t.pooled, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));
+    }
+    if (c->normalize) RUN(omk_l2norm(t.headout, out_reps, B, d.D, s));
+    return 0;
+  }
   if (L > c->max_pos) OM_FAIL("sequence longer than the position table");
 
   RUN(omk_embed(dt, input_ids, token_type_ids, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g,
@@ -211,6 +392,9 @@ extern "C" int om_encoder_train_backward(const OmEncoderConfig* c, const OmEncod
   char* dx = ws.dxa;       // gradient w.r.t. the current layer's OUTPUT
   char* dx_prev = ws.dxb;  // gradient w.r.t. its input (next iteration's dx)
   RUN(omk_pool_bwd(dt, dpooled, attention_mask, dx, B, (int)L, H, c->pooling, s));
+  if (d.t5)
+    return t5_train_backward(c, w, input_ids, attention_mask, d, t, ws, hidden_dropout, attn_dropout, seed, dx,
+                             dx_prev, g, s);
 
   // weight gradients: split-K over the token axis, f32 atomics into the caller-zeroed buffers
 #define WGRAD(left, right, rows_out, cols_in, dst) \

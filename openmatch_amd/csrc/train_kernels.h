@@ -8,6 +8,9 @@ int omk_colsum(int dtype, const void* x, int64_t ld, int64_t M, int N, float* ou
 int omk_dropout(int dtype, const void* x, void* y, int64_t n, float p, uint64_t seed, hipStream_t s);
 int omk_ln_bwd(int dtype, const void* dy, const void* x, const float* g, void* dx, float* dg,
                float* db, int64_t M, int H, float eps, hipStream_t s);
+// LayerNorm (rms = 0) or T5 RMSNorm (rms = 1) backward; `add` (optional, same shape) is added to dx
+int omk_norm_bwd(int dtype, const void* dy, const void* x, const float* g, void* dx, float* dg,
+                 float* db, int64_t M, int H, float eps, int rms, const void* add, hipStream_t s);
 int omk_embed_bwd(int dtype, const void* dy, const int64_t* ids, const int64_t* type_ids,
                   const float* word, const float* pos, const float* type, const float* g,
                   float* dword, float* dpos, float* dtype_, float* dg, float* db, int64_t M, int L,
@@ -20,3 +23,11 @@ int omk_small_tn(const float* A, const float* Bm, float* C, int I, int J, int Cc
 int omk_attention_bwd(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask,
                       int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
                       hipStream_t s);
+int omk_attention_bwd_bias(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask,
+                           int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
+                           const float* pos_bias, float* drel, hipStream_t s);
+// T5 feed-forward activation (kind 0 relu, 1 gated gelu_new) forward / backward, embedding and bias backward
+int omk_t5_act_fwd(int dtype, const void* f, const void* f2, void* g, int64_t n, int kind, hipStream_t s);
+int omk_t5_act_bwd(int dtype, const void* dg, const void* f, const void* f2, void* df, void* df2, int64_t n, int kind, hipStream_t s);
+int omk_t5_embed_bwd(int dtype, const void* dy, const int64_t* ids, float* dword, int64_t M, int H, int vocab, hipStream_t s);
+int omk_t5_bias_bwd(const float* drel, const int* lut, float* dtable, int L, int heads, hipStream_t s);

@@ -110,7 +110,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const int64_t* __restrict__ ids, const int64_t* __restrict__ type_ids,
     const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
     float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype_, int L, int vocab,
-    int type_vocab) {
+    int type_vocab, int rms, const T* __restrict__ add) {
+  // rms != 0: T5LayerNorm (no mean, no bias): xhat = x * rstd, rstd = rsqrt(mean(x^2) + eps).
+  // add != NULL: dx = (this backward) + add  (the residual stream's gradient, pre-norm stacks).
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = (float*)smem;                       // [2][4][H]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
         for (int e = 0; e < 4; ++e) { xv[j][e] = 0.f; dv[j][e] = 0.f; }
       }
     }
-    const float mean = wave_sum(s1) / (float)H;
+    const float mean = rms ? 0.f : wave_sum(s1) / (float)H;
     float s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j)
@@ -172,15 +174,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
           bacc[j][e] += dv[j][e];
         }
       }
-    m1 = wave_sum(m1) / (float)H; m2 = wave_sum(m2) / (float)H;
+    m1 = rms ? 0.f : wave_sum(m1) / (float)H; m2 = wave_sum(m2) / (float)H;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int c = (lane + 64 * j) * 4;
       if (c < H) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = rstd * (dv[j][e] * gv[j][e] - m1 - xv[j][e] * m2);
+          float v = rstd * (dv[j][e] * gv[j][e] - m1 - xv[j][e] * m2);
           if (MODE == 0) {
+            if (add) v += ElemOps<T>::load(add + row * H + c + e);
             ElemOps<T>::store(dx + row * H + c + e, v);
           } else {
             atomicAdd(dword + id * H + c + e, v);
@@ -211,10 +214,11 @@ template <typename T, int MODE>
 static int launch_ln_bwd(const void* dy, const void* x, const float* g, void* dx, float* dg, float* db,
                          int64_t M, int H, float eps, const int64_t* ids, const int64_t* tt,
                          const float* word, const float* pos, const float* type, float* dword,
-                         float* dpos, float* dtype_, int L, int vocab, int type_vocab, hipStream_t s) {
+                         float* dpos, float* dtype_, int L, int vocab, int type_vocab, hipStream_t s,
+                         int rms = 0, const void* add = nullptr) {
   const unsigned grid = (unsigned)((M + 3) / 4 > 1024 ? 1024 : (M + 3) / 4);
   const size_t lds = (size_t)8 * H * sizeof(float);
-#define LNB(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, MODE>), dim3(grid), dim3(256), lds, s, (const T*)dy, (const T*)x, g, (T*)dx, dg, db, M, H, eps, ids, tt, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab)
+#define LNB(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, MODE>), dim3(grid), dim3(256), lds, s, (const T*)dy, (const T*)x, g, (T*)dx, dg, db, M, H, eps, ids, tt, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, rms, (const T*)add)
   if (H <= 1024) LNB(4); else LNB(8);
 #undef LNB
   OM_LAUNCH_CHECK();
@@ -223,11 +227,16 @@ static int launch_ln_bwd(const void* dy, const void* x, const float* g, void* dx
 
 int omk_ln_bwd(int dtype, const void* dy, const void* x, const float* g, void* dx, float* dg,
                float* db, int64_t M, int H, float eps, hipStream_t s) {
+  return omk_norm_bwd(dtype, dy, x, g, dx, dg, db, M, H, eps, 0, nullptr, s);
+}
+
+int omk_norm_bwd(int dtype, const void* dy, const void* x, const float* g, void* dx, float* dg,
+                 float* db, int64_t M, int H, float eps, int rms, const void* add, hipStream_t s) {
   if (M <= 0) return 0;
   if (H % 4 || H > 2048) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
   if (dtype == OM_BF16)
-    return launch_ln_bwd<bf16_t, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s);
-  return launch_ln_bwd<float, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s);
+    return launch_ln_bwd<bf16_t, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, rms, add);
+  return launch_ln_bwd<float, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, rms, add);
 }
 
 int omk_embed_bwd(int dtype, const void* dy, const int64_t* ids, const int64_t* type_ids,
@@ -348,7 +357,9 @@ template <typename T, int KT>
 __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
     const T* __restrict__ qkv, const T* __restrict__ dctx, T* __restrict__ dqkv,
     const int64_t* __restrict__ mask, int L, int H, int heads, float scale, float drop_p,
-    uint64_t seed) {
+    uint64_t seed, const float* __restrict__ pos_bias, float* __restrict__ drel) {
+  // pos_bias [heads][L][L] (T5): added to the scaled scores; drel [heads][2L-1] accumulates the
+  // gradient of that bias per relative position key - query (+ L-1), summed over the batch.
   typedef AttnGeom<T> G;
   typedef typename MmaOps<T>::frag_t frag_t;
   constexpr int LP = KT * 32 + 4;
@@ -360,6 +371,7 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
   float* sMax = sM + KT * 32;                  // per query: row max, 1/row sum, delta
   float* sInv = sMax + KT * 32;
   float* sDelta = sInv + KT * 32;
+  float* sRel = sDelta + KT * 32;              // [2 * KT * 32] bias gradient per relative position
 
   const int h = blockIdx.x % heads;
   const int64_t b = blockIdx.x / heads;
@@ -389,6 +401,8 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
   }
   for (int k = tid; k < KT * 32; k += nthr)
     sM[k] = k < L ? (mask[b * L + k] != 0 ? 0.f : -3.4028235e38f) : -INFINITY;
+  if (drel)
+    for (int k = tid; k < 2 * KT * 32; k += nthr) sRel[k] = 0.f;
   __syncthreads();
 
   const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
@@ -427,7 +441,14 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
       for (int g = 0; g < 4; ++g) {
         const f32x4_t mb = *(const f32x4_t*)(sM + t * 32 + 8 * g + 4 * half);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float v = s[t][4 * g + e] * scale + mb[e]; s[t][4 * g + e] = v; mx = fmaxf(mx, v); }
+        for (int e = 0; e < 4; ++e) {
+          float v = s[t][4 * g + e] * scale + mb[e];
+          if (pos_bias) {
+            const int kc = (t * 32 + 8 * g + 4 * half + e) < L ? (t * 32 + 8 * g + 4 * half + e) : (L - 1);
+            v += pos_bias[((int64_t)h * L + myrow) * L + kc];
+          }
+          s[t][4 * g + e] = v; mx = fmaxf(mx, v);
+        }
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
@@ -455,7 +476,14 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
 #pragma unroll
     for (int t = 0; t < KT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[t][r] = s[t][r] * (dp[t][r] - delta) * scale;   // dS
+      for (int r = 0; r < 16; ++r) {
+        const float dlogit = s[t][r] * (dp[t][r] - delta);          // d loss / d (scaled score + bias)
+        if (drel) {
+          const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, q = blk0 + l31;
+          if (q < L && key < L) atomicAdd(&sRel[key - q + (L - 1)], dlogit);
+        }
+        s[t][r] = dlogit * scale;                                     // dS
+      }
     if (half == 0 && blk0 + l31 < L) { sMax[blk0 + l31] = mx; sInv[blk0 + l31] = inv; sDelta[blk0 + l31] = delta; }
     f32x16_t o[2];
 #pragma unroll
@@ -473,6 +501,8 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
       }
   }
   __syncthreads();
+  if (drel)
+    for (int k = tid; k < 2 * L - 1; k += nthr) atomicAdd(drel + (int64_t)h * (2 * L - 1) + k, sRel[k]);
   if (!active) return;
 
   // ------------------------------------------------------------------ phase B
@@ -515,7 +545,9 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
           const int q = q4 + e;
           float p = 0.f, pd = 0.f, dpp = 0.f;
           if (q < L && kvalid) {
-            p = G::exp_(sb[4 * g + e] * scale + mbk - m4[e]) * i4[e];
+            float lg = sb[4 * g + e] * scale + mbk;
+            if (pos_bias) lg += pos_bias[((int64_t)h * L + q) * L + (blk0 + l31)];
+            p = G::exp_(lg - m4[e]) * i4[e];
             pd = p; dpp = dpb[4 * g + e];
             if (thresh) {
               const bool keep = dropout_keep(seed, attn_drop_idx(b, h, heads, L, q, blk0 + l31), thresh);
@@ -546,9 +578,9 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
 template <typename T, int KT>
 static int launch_attn_bwd(const void* qkv, const void* dctx, void* dqkv, const int64_t* mask,
                            int64_t B, int L, int H, int heads, float scale, float drop_p,
-                           uint64_t seed, hipStream_t s) {
+                           uint64_t seed, const float* pos_bias, float* drel, hipStream_t s) {
   constexpr int LP = KT * 32 + 4;
-  const int lds = 3 * 64 * LP * (int)sizeof(T) + 4 * KT * 32 * 4;
+  const int lds = 3 * 64 * LP * (int)sizeof(T) + 6 * KT * 32 * 4;
   static bool attr_set = false;
   if (!attr_set) {
     OM_HIP(hipFuncSetAttribute((const void*)attention_bwd_kernel<T, KT>,
@@ -557,7 +589,7 @@ static int launch_attn_bwd(const void* qkv, const void* dctx, void* dqkv, const 
   }
   const int waves = (L + 31) / 32;
   hipLaunchKernelGGL((attention_bwd_kernel<T, KT>), dim3((unsigned)(heads * B)), dim3(64 * waves), lds, s,
-                     (const T*)qkv, (const T*)dctx, (T*)dqkv, mask, L, H, heads, scale, drop_p, seed);
+                     (const T*)qkv, (const T*)dctx, (T*)dqkv, mask, L, H, heads, scale, drop_p, seed, pos_bias, drel);
   OM_LAUNCH_CHECK();
   return 0;
 }
@@ -565,16 +597,103 @@ static int launch_attn_bwd(const void* qkv, const void* dctx, void* dqkv, const 
 int omk_attention_bwd(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask,
                       int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
                       hipStream_t s) {
+  return omk_attention_bwd_bias(dtype, qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, nullptr, nullptr, s);
+}
+
+int omk_attention_bwd_bias(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask,
+                           int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
+                           const float* pos_bias, float* drel, hipStream_t s) {
   if (B <= 0) return 0;
   if (L < 1 || L > 128) OM_FAIL("training supports sequence lengths up to 128");
   if (H != heads * 64) OM_FAIL("head_dim must be 64");
 #define AB(TT)                                                                                       \
   do {                                                                                               \
-    if (L <= 32) return launch_attn_bwd<TT, 1>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s); \
-    if (L <= 64) return launch_attn_bwd<TT, 2>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s); \
-    return launch_attn_bwd<TT, 4>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s);    \
+    if (L <= 32) return launch_attn_bwd<TT, 1>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s); \
+    if (L <= 64) return launch_attn_bwd<TT, 2>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s); \
+    return launch_attn_bwd<TT, 4>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s);    \
   } while (0)
   if (dtype == OM_BF16) AB(bf16_t);
   AB(float);
 #undef AB
+}
+
+
+// ---------------------------------------------------------------------------------------
+// T5 feed-forward activations (HF:models/t5/modeling_t5.py T5DenseActDense / T5DenseGatedActDense)
+//   kind 0 (relu):        g = relu(f)                      df  = dg (f > 0)
+//   kind 1 (gated gelu):  g = gelu_new(f) * f2             df  = dg f2 gelu_new'(f),  df2 = dg gelu_new(f)
+__device__ inline float gelu_new_f(float x) {
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ inline float gelu_new_grad_f(float x) {
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  const float t = tanhf(u);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+}
+template <typename T>
+__global__ void t5_act_fwd_kernel(const T* __restrict__ f, const T* __restrict__ f2, T* __restrict__ g, int64_t n, int kind) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = ElemOps<T>::load(f + i);
+  ElemOps<T>::store(g + i, kind == 0 ? fmaxf(x, 0.f) : gelu_new_f(x) * ElemOps<T>::load(f2 + i));
+}
+template <typename T>
+__global__ void t5_act_bwd_kernel(const T* __restrict__ dg, const T* __restrict__ f, const T* __restrict__ f2,
+                                  T* __restrict__ df, T* __restrict__ df2, int64_t n, int kind) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float d = ElemOps<T>::load(dg + i), x = ElemOps<T>::load(f + i);
+  if (kind == 0) {
+    ElemOps<T>::store(df + i, x > 0.f ? d : 0.f);
+  } else {
+    const float y = ElemOps<T>::load(f2 + i);
+    ElemOps<T>::store(df + i, d * y * gelu_new_grad_f(x));
+    ElemOps<T>::store(df2 + i, d * gelu_new_f(x));
+  }
+}
+int omk_t5_act_fwd(int dtype, const void* f, const void* f2, void* g, int64_t n, int kind, hipStream_t s) {
+  if (n <= 0) return 0;
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  if (dtype == OM_BF16) hipLaunchKernelGGL(t5_act_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)f, (const bf16_t*)f2, (bf16_t*)g, n, kind);
+  else hipLaunchKernelGGL(t5_act_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)f, (const float*)f2, (float*)g, n, kind);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+int omk_t5_act_bwd(int dtype, const void* dg, const void* f, const void* f2, void* df, void* df2, int64_t n, int kind, hipStream_t s) {
+  if (n <= 0) return 0;
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  if (dtype == OM_BF16) hipLaunchKernelGGL(t5_act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dg, (const bf16_t*)f, (const bf16_t*)f2, (bf16_t*)df, (bf16_t*)df2, n, kind);
+  else hipLaunchKernelGGL(t5_act_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dg, (const float*)f, (const float*)f2, (float*)df, (float*)df2, n, kind);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+// T5 embedding backward: d word_emb[id] += dy[row]   (shared embedding, no norm, no positions)
+template <typename T>
+__global__ void t5_embed_bwd_kernel(const T* __restrict__ dy, const int64_t* __restrict__ ids, float* __restrict__ dword,
+                                    int64_t M, int H, int vocab) {
+  const int64_t row = blockIdx.x;
+  int64_t id = ids[row]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  for (int c = threadIdx.x; c < H; c += blockDim.x) atomicAdd(dword + id * H + c, ElemOps<T>::load(dy + row * H + c));
+}
+int omk_t5_embed_bwd(int dtype, const void* dy, const int64_t* ids, float* dword, int64_t M, int H, int vocab, hipStream_t s) {
+  if (M <= 0) return 0;
+  if (dtype == OM_BF16) hipLaunchKernelGGL(t5_embed_bwd_kernel<bf16_t>, dim3((unsigned)M), dim3(256), 0, s, (const bf16_t*)dy, ids, dword, M, H, vocab);
+  else hipLaunchKernelGGL(t5_embed_bwd_kernel<float>, dim3((unsigned)M), dim3(256), 0, s, (const float*)dy, ids, dword, M, H, vocab);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+// relative-position bias backward: d table[bucket(rel)][h] += d rel[h][rel]   (table is [buckets][heads])
+__global__ void t5_bias_bwd_kernel(const float* __restrict__ drel, const int* __restrict__ lut, float* __restrict__ dtable,
+                                   int L, int heads) {
+  const int h = blockIdx.x;
+  for (int r = threadIdx.x; r < 2 * L - 1; r += blockDim.x)
+    atomicAdd(dtable + (int64_t)lut[r] * heads + h, drel[(int64_t)h * (2 * L - 1) + r]);
+}
+int omk_t5_bias_bwd(const float* drel, const int* lut, float* dtable, int L, int heads, hipStream_t s) {
+  hipLaunchKernelGGL(t5_bias_bwd_kernel, dim3((unsigned)heads), dim3(256), 0, s, drel, lut, dtable, L, heads);
+  OM_LAUNCH_CHECK();
+  return 0;
 }

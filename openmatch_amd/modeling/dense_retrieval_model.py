@@ -111,7 +111,8 @@ class DRModel(nn.Module):
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
         cfg = getattr(model, "config", None)
         has_dropout = self.training and (getattr(cfg, "hidden_dropout_prob", 0.0) > 0
-                                         or getattr(cfg, "attention_probs_dropout_prob", 0.0) > 0)
+                                         or getattr(cfg, "attention_probs_dropout_prob", 0.0) > 0
+                                         or getattr(cfg, "dropout_rate", 0.0) > 0)       # T5
         if needs_grad or has_dropout:      # train-mode forward (dropout), also under no_grad (GradCache)
             return encode_with_grad(model, head, items, self.pooling, self.normalize, code,
                                     self.training)

@@ -17,7 +17,7 @@ ACT_MUL_RESID = 0x100
 ARCH_BERT, ARCH_T5 = 0, 1
 POOL_NONE, POOL_FIRST, POOL_MEAN = 0, 1, 2
 SEARCH_F32, SEARCH_F16_RESCORE = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_void_p, c_int, c_int64, c_float, c_size_t = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
@@ -46,13 +46,14 @@ class OmEncoderWeights(C.Structure):
 class OmLayerGrads(C.Structure):
     _fields_ = [(n, c_void_p) for n in (
         "qkv_w", "qkv_b", "o_w", "o_b", "ln1_g", "ln1_b", "ffn1_w", "ffn1_b", "ffn2_w", "ffn2_b",
-        "ln2_g", "ln2_b")]
+        "ln2_g", "ln2_b", "ffn1g_w")]
 
 
 class OmEncoderGrads(C.Structure):
     _fields_ = [("word_emb", c_void_p), ("pos_emb", c_void_p), ("type_emb", c_void_p),
                 ("emb_ln_g", c_void_p), ("emb_ln_b", c_void_p),
-                ("layers_host", C.POINTER(OmLayerGrads)), ("head_w", c_void_p)]
+                ("layers_host", C.POINTER(OmLayerGrads)), ("head_w", c_void_p),
+                ("final_ln_g", c_void_p), ("rel_bias", c_void_p)]
 
 
 _SIGNATURES = {

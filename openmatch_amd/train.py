@@ -29,6 +29,22 @@ def _bert_params(model, head):
     return ps
 
 
+def _t5_params(model, head):
+    """T5EncoderModel parameters in the order the backward returns their gradients."""
+    enc = model.encoder
+    gated = bool(getattr(model.config, "is_gated_act", False))
+    ps = [enc.embed_tokens.weight, enc.final_layer_norm.weight,
+          enc.block[0].layer[0].SelfAttention.relative_attention_bias.weight]
+    for block in enc.block:
+        sa, ff = block.layer[0].SelfAttention, block.layer[1].DenseReluDense
+        ps += [sa.q.weight, sa.k.weight, sa.v.weight, sa.o.weight, block.layer[0].layer_norm.weight]
+        ps += [ff.wi_0.weight, ff.wi_1.weight] if gated else [ff.wi.weight]
+        ps += [ff.wo.weight, block.layer[1].layer_norm.weight]
+    if head is not None:
+        ps.append(head.linear.weight)
+    return ps
+
+
 class _EncoderTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, head, ids, mask, tti, pooling, normalize, code, p_hidden, p_attn, seed, *params):
@@ -61,12 +77,18 @@ class _EncoderTrain(torch.autograd.Function):
         B, L = ctx.ids.shape
         H, F, nl = cfg.hidden, cfg.ffn, cfg.n_layers
         # one zero-filled arena for every gradient (the backward ADDS into it with f32 atomics)
-        emb = model.embeddings
-        n_emb = sum(t.numel() for t in (emb.word_embeddings.weight, emb.position_embeddings.weight,
-                                        emb.token_type_embeddings.weight)) + 2 * H
-        n_layer = 3 * H * H + 3 * H + H * H + H + 2 * H + F * H + F + H * F + H + 2 * H
+        t5 = _arch_of(model) != "bert"
         n_head = cfg.head_out * cfg.head_in if cfg.head_in > 0 else 0
-        arena = torch.zeros(n_emb + nl * n_layer + n_head + 64 * (8 + 12 * nl), device=device, dtype=torch.float32)
+        if t5:
+            gated = bool(getattr(model.config, "is_gated_act", False))
+            n_emb = model.encoder.embed_tokens.weight.numel() + H + cfg.rel_buckets * cfg.n_heads
+            n_layer = 3 * H * H + H * H + 2 * H + (2 if gated else 1) * F * H + H * F
+        else:
+            emb = model.embeddings
+            n_emb = sum(t.numel() for t in (emb.word_embeddings.weight, emb.position_embeddings.weight,
+                                            emb.token_type_embeddings.weight)) + 2 * H
+            n_layer = 3 * H * H + 3 * H + H * H + H + 2 * H + F * H + F + H * F + H + 2 * H
+        arena = torch.zeros(n_emb + nl * n_layer + n_head + 64 * (8 + 13 * nl), device=device, dtype=torch.float32)
         cursor = [0]
         g = N.OmEncoderGrads()
 
@@ -78,20 +100,32 @@ class _EncoderTrain(torch.autograd.Function):
             cursor[0] += (n + 63) // 64 * 64            # keep every buffer 256-byte aligned
             setattr(field_owner, name, t.data_ptr())
             return t
-        gw = buf(g, "word_emb", *emb.word_embeddings.weight.shape)
-        gp = buf(g, "pos_emb", *emb.position_embeddings.weight.shape)
-        gt = buf(g, "type_emb", *emb.token_type_embeddings.weight.shape)
-        gg = buf(g, "emb_ln_g", H)
-        gb = buf(g, "emb_ln_b", H)
         layers = (N.OmLayerGrads * nl)()
         per_layer = []
-        for l in range(nl):
-            lg = layers[l]
-            per_layer.append(dict(
-                qkv_w=buf(lg, "qkv_w", 3 * H, H), qkv_b=buf(lg, "qkv_b", 3 * H), o_w=buf(lg, "o_w", H, H),
-                o_b=buf(lg, "o_b", H), ln1_g=buf(lg, "ln1_g", H), ln1_b=buf(lg, "ln1_b", H),
-                ffn1_w=buf(lg, "ffn1_w", F, H), ffn1_b=buf(lg, "ffn1_b", F), ffn2_w=buf(lg, "ffn2_w", H, F),
-                ffn2_b=buf(lg, "ffn2_b", H), ln2_g=buf(lg, "ln2_g", H), ln2_b=buf(lg, "ln2_b", H)))
+        if t5:
+            gw = buf(g, "word_emb", *model.encoder.embed_tokens.weight.shape)
+            gfin = buf(g, "final_ln_g", H)
+            grel = buf(g, "rel_bias", cfg.rel_buckets, cfg.n_heads)
+            for l in range(nl):
+                lg = layers[l]
+                d = dict(qkv_w=buf(lg, "qkv_w", 3 * H, H), o_w=buf(lg, "o_w", H, H), ln1_g=buf(lg, "ln1_g", H),
+                         ffn1_w=buf(lg, "ffn1_w", F, H), ffn2_w=buf(lg, "ffn2_w", H, F), ln2_g=buf(lg, "ln2_g", H))
+                if gated:
+                    d["ffn1g_w"] = buf(lg, "ffn1g_w", F, H)
+                per_layer.append(d)
+        else:
+            gw = buf(g, "word_emb", *emb.word_embeddings.weight.shape)
+            gp = buf(g, "pos_emb", *emb.position_embeddings.weight.shape)
+            gt = buf(g, "type_emb", *emb.token_type_embeddings.weight.shape)
+            gg = buf(g, "emb_ln_g", H)
+            gb = buf(g, "emb_ln_b", H)
+            for l in range(nl):
+                lg = layers[l]
+                per_layer.append(dict(
+                    qkv_w=buf(lg, "qkv_w", 3 * H, H), qkv_b=buf(lg, "qkv_b", 3 * H), o_w=buf(lg, "o_w", H, H),
+                    o_b=buf(lg, "o_b", H), ln1_g=buf(lg, "ln1_g", H), ln1_b=buf(lg, "ln1_b", H),
+                    ffn1_w=buf(lg, "ffn1_w", F, H), ffn1_b=buf(lg, "ffn1_b", F), ffn2_w=buf(lg, "ffn2_w", H, F),
+                    ffn2_b=buf(lg, "ffn2_b", H), ln2_g=buf(lg, "ln2_g", H), ln2_b=buf(lg, "ln2_b", H)))
         g.layers_host = C.cast(layers, C.POINTER(N.OmLayerGrads))
         ghead = buf(g, "head_w", cfg.head_out, cfg.head_in) if cfg.head_in > 0 else None
         d_reps = d_reps.to(torch.float32).contiguous()
@@ -103,12 +137,21 @@ class _EncoderTrain(torch.autograd.Function):
                 C.byref(cfg), C.byref(pk.weights), N.ptr(ctx.ids), N.ptr(ctx.mask), N.ptr(ctx.tti), B, L,
                 ctx.drop[0], ctx.drop[1], ctx.drop[2], C.c_void_p(ctx.tape_ptr), N.ptr(d_reps), C.byref(g),
                 C.c_void_p(ws_ptr), nws, N.stream_ptr(device)))
-        grads = [gw, gp, gt, gg, gb]
-        for d in per_layer:
-            q, k, v = d["qkv_w"].split(H, dim=0)
-            qb, kb, vb = d["qkv_b"].split(H, dim=0)
-            grads += [q, k, v, qb, kb, vb, d["o_w"], d["o_b"], d["ln1_g"], d["ln1_b"], d["ffn1_w"], d["ffn1_b"],
-                      d["ffn2_w"], d["ffn2_b"], d["ln2_g"], d["ln2_b"]]
+        if t5:
+            grads = [gw, gfin, grel]
+            for d in per_layer:
+                q, k, v = d["qkv_w"].split(H, dim=0)
+                grads += [q, k, v, d["o_w"], d["ln1_g"], d["ffn1_w"]]
+                if "ffn1g_w" in d:
+                    grads.append(d["ffn1g_w"])
+                grads += [d["ffn2_w"], d["ln2_g"]]
+        else:
+            grads = [gw, gp, gt, gg, gb]
+            for d in per_layer:
+                q, k, v = d["qkv_w"].split(H, dim=0)
+                qb, kb, vb = d["qkv_b"].split(H, dim=0)
+                grads += [q, k, v, qb, kb, vb, d["o_w"], d["o_b"], d["ln1_g"], d["ln1_b"], d["ffn1_w"], d["ffn1_b"],
+                          d["ffn2_w"], d["ffn2_b"], d["ln2_g"], d["ln2_b"]]
         if ghead is not None:
             grads.append(ghead)
         ctx.tape = None
@@ -118,8 +161,6 @@ class _EncoderTrain(torch.autograd.Function):
 def encode_train(model, head, items, pooling, normalize, code, training):
     """(None, reps) with an autograd edge from `reps` to every encoder / head parameter.
     Dropout follows the HF config only in training mode (model.train())."""
-    if _arch_of(model) != "bert":
-        raise NotImplementedError("the HIP backward pass exists for BERT encoders; T5 training is not implemented")
     ids = items["input_ids"].to(torch.int64).contiguous()
     mask = items["attention_mask"].to(device=ids.device, dtype=torch.int64).contiguous()
     tti = items.get("token_type_ids") if hasattr(items, "get") else None
@@ -127,10 +168,14 @@ def encode_train(model, head, items, pooling, normalize, code, training):
         tti = tti.to(device=ids.device, dtype=torch.int64).contiguous()
     N.require_device(ids, mask, tti)
     cfg = model.config
-    p_hidden = float(cfg.hidden_dropout_prob) if training else 0.0
-    p_attn = float(cfg.attention_probs_dropout_prob) if training else 0.0
+    bert = _arch_of(model) == "bert"
+    if bert:
+        p_hidden = float(cfg.hidden_dropout_prob) if training else 0.0
+        p_attn = float(cfg.attention_probs_dropout_prob) if training else 0.0
+    else:                                   # T5: one dropout_rate for every site
+        p_hidden = p_attn = float(cfg.dropout_rate) if training else 0.0
     seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p_hidden > 0 or p_attn > 0) else 0
-    params = _bert_params(model, head)
+    params = _bert_params(model, head) if bert else _t5_params(model, head)
     reps = _EncoderTrain.apply(model, head, ids, mask, tti, pooling, normalize, code, p_hidden, p_attn, seed,
                                *params)
     return None, reps

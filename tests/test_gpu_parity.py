@@ -320,6 +320,45 @@ def test_training_step_f32_matches_reference_gradients(golden):
     print("worst relative gradient error:", worst)
 
 
+@pytest.mark.parametrize("gated", [False, True])
+def test_t5_training_step_matches_reference_gradients(golden, gated):
+    """GTR-style T5 encoder (mean pooling, head, normalise): loss and EVERY parameter gradient --
+    shared embedding, RMSNorm weights, relative-position bias table, q/k/v/o, wi (/wi_0, wi_1), wo --
+    against the reference's autograd (tests/golden/train_t5_tiny_*.npz, dropout 0, L = 100 passages)."""
+    from openmatch.modeling import DRModel, LinearHead
+    g = golden("train_t5_tiny_gated" if gated else "train_t5_tiny_relu")
+    cfg, lm = model_from_golden(g, "t5", gated=gated)
+    lm.config.dropout_rate = 0.0
+    head = LinearHead(128, 128)
+    head.linear.weight.data.copy_(torch.from_numpy(g["head_w"]))
+    model = DRModel(lm_q=lm, lm_p=lm, pooling="mean", head_q=head, head_p=head, normalize=True,
+                    model_args=NS(encoder_only=True, dtype="float32"), data_args=NS(train_n_passages=int(g["n_psg"])),
+                    train_args=NS(negatives_x_device=False, per_device_train_batch_size=4)).to(DEV).train()
+    mk = lambda k: {"input_ids": torch.from_numpy(g[k + "_input_ids"]).to(DEV),
+                    "attention_mask": torch.from_numpy(g[k + "_attention_mask"]).to(DEV)}
+    out = model(query=mk("q"), passage=mk("p"))
+    assert abs(out.loss.item() - float(g["loss"])) < 1e-5
+    assert np.abs(out.scores.detach().cpu().numpy() - g["scores"]).max() < 1e-5
+    out.loss.backward()
+    names = dict(model.lm_q.named_parameters())
+    checked, worst = 0, ("", 0.0)
+    for key in g.files:
+        if not key.startswith("g::"):
+            continue
+        name = key[3:]
+        ref = torch.from_numpy(g[key])
+        got = model.head_q.linear.weight.grad if name == "head_w" else names[name].grad
+        assert got is not None, name
+        got = got.cpu()
+        rel = ((got - ref).norm() / (ref.norm() + 1e-12)).item()
+        amax = (got - ref).abs().max().item()
+        assert (rel < 1e-3 or amax < 1e-7) and amax < 2e-5, (name, rel, amax)
+        worst = max(worst, (name, rel), key=lambda t: t[1])
+        checked += 1
+    assert checked == (22 if gated else 20), checked
+    print("worst relative gradient error:", worst)
+
+
 def test_training_step_bf16_and_dropout_are_sane(golden):
     g = golden("train_bert_tiny")
     q, p = _train_batch(g)
@@ -346,6 +385,50 @@ def test_training_step_bf16_and_dropout_are_sane(golden):
     with torch.no_grad():
         a = model(query=q, passage=p).loss.item(); b = model(query=q, passage=p).loss.item()
     assert a == b
+
+
+def test_t5_training_bf16_and_dropout_are_sane(golden):
+    """T5 training in bf16 tracks the f32 reference gradients; with dropout_rate 0.1 the step stays finite,
+    masks change from call to call, and one optimiser-free descent step along -grad lowers the loss."""
+    from openmatch.modeling import DRModel, LinearHead
+    g = golden("train_t5_tiny_gated")
+
+    def build(dtype, p_drop):
+        cfg, lm = model_from_golden(g, "t5", gated=True)
+        lm.config.dropout_rate = p_drop
+        head = LinearHead(128, 128)
+        head.linear.weight.data.copy_(torch.from_numpy(g["head_w"]))
+        return DRModel(lm_q=lm, lm_p=lm, pooling="mean", head_q=head, head_p=head, normalize=True,
+                       model_args=NS(encoder_only=True, dtype=dtype), data_args=NS(train_n_passages=int(g["n_psg"])),
+                       train_args=NS(negatives_x_device=False, per_device_train_batch_size=4)).to(DEV).train()
+    mk = lambda k: {"input_ids": torch.from_numpy(g[k + "_input_ids"]).to(DEV),
+                    "attention_mask": torch.from_numpy(g[k + "_attention_mask"]).to(DEV)}
+    q, p = mk("q"), mk("p")
+    model = build("bfloat16", 0.0)
+    out = model(query=q, passage=p)
+    assert abs(out.loss.item() - float(g["loss"])) < 3e-2
+    out.loss.backward()
+    names = dict(model.lm_q.named_parameters())
+    for key in ("g::encoder.block.0.layer.0.SelfAttention.q.weight", "g::encoder.block.1.layer.1.DenseReluDense.wo.weight",
+                "g::encoder.block.0.layer.1.DenseReluDense.wi_1.weight", "g::encoder.final_layer_norm.weight"):
+        ref = torch.from_numpy(g[key]).flatten().double()
+        got = names[key[3:]].grad.cpu().flatten().double()
+        cos = torch.dot(ref, got) / (ref.norm() * got.norm())
+        assert cos > 0.99, (key, cos.item())
+    model = build("float32", 0.1)
+    l1 = model(query=q, passage=p).loss
+    l2 = model(query=q, passage=p).loss
+    assert torch.isfinite(l1) and torch.isfinite(l2) and l1.item() != l2.item()
+    l1.backward()
+    params = [p_ for p_ in list(model.lm_q.parameters()) + list(model.head_q.parameters()) if p_.grad is not None]
+    assert all(torch.isfinite(p_.grad).all() for p_ in params)
+    model.eval()
+    with torch.no_grad():
+        before = model(query=q, passage=p).loss.item()
+        for p_ in params:
+            p_.add_(p_.grad, alpha=-0.05)
+        after = model(query=q, passage=p).loss.item()
+    assert after < before, (before, after)
 
 
 def test_training_gradients_match_oracle_autograd_at_bert_width():
