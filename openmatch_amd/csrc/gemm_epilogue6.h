@@ -4,16 +4,14 @@
 //     acc[mi][ni][r]  =  C[ mrow0 + mi*32 + (lane & 31) ][ ncol0 + ni*32 + 8*(r>>2) + 4*(lane>>5) + (r&3) ]
 // That makes the LDS transposition cheap (tools/gemm_epilogue_probe.hip: the f32 `ds_write_b32`
 // staging of the column-per-lane layout cost ~7 k cycles per 256 x 256 tile before any store):
-//   * 16-bit output, no residual: pack to bf16 in registers, ds_write_b64 (4 columns), rows of 264 B
-//   * otherwise: ds_write_b128 of four f32, rows of 528 B; residual added in f32 after the read-back
-//     (a single rounding)
-//   * 16-bit output WITH residual: the residual patch (32 rows x 256 B) is brought into LDS by the same
-//     LDS-DMA the K loop uses (8 wave instructions per patch, chunk position XOR row so the
-//     row-per-lane read-back is 2-way instead of 32-way conflicted), one to two patches ahead, and added in
-//     f32 in registers BEFORE packing -- a single rounding and the cheap bf16 staging.  Loading the
-//     residual as 16-byte vectors into VGPRs after the read-back cost 20 k cycles per tile
-//     (tools/gemm_epilogue_probe.hip): HBM latency per patch, and `vmcnt` retiring in order ties those
-//     loads to the stores in front of them.
+//   * 16-bit output: add the residual (if any) in f32 in registers, pack to bf16, ds_write_b64 (4 columns),
+//     rows of 264 B.  The residual patch (32 rows x 256 B) comes in through the same LDS-DMA the K loop
+//     uses (8 wave instructions per patch, chunk position XOR row so the row-per-lane read-back is
+//     2-way instead of 32-way conflicted), one to two patches ahead -- a single rounding and the cheap
+//     bf16 staging.  Loading it as 16-byte vectors into VGPRs after the read-back cost 20 k cycles per
+//     tile (tools/gemm_epilogue_probe.hip): HBM latency per patch, and `vmcnt` retiring in order ties
+//     those loads to the stores in front of them.
+//   * f32 output: ds_write_b128 of four f32, rows of 528 B; residual (VGPR loads) added after the read-back
 // then whole 16-byte vectors are read back row-major and stored fully coalesced (a wave instruction
 // covers 4 (bf16) or 2 (f32) complete 256 / 512-byte row segments).
 // One patch = one mi block (32 rows x 128 columns).  With a single wave per SIMD nothing else hides
