@@ -92,6 +92,20 @@ class SimpleTrainPreProcessor:
         return state
 
 
+class SimpleCollectionPreProcessor:
+    """One collection line `id <sep> field <sep> field ...` -> `{"text_id", "text": [token ids]}` as a json string,
+    the fields joined by the tokenizer's separator token and cut to max_length (reference utils.py:104-124)."""
+
+    def __init__(self, tokenizer, separator="\t", max_length=128):
+        self.tokenizer, self.separator, self.max_length = tokenizer, separator, max_length
+
+    def process_line(self, line):
+        cells = line.strip().split(self.separator)
+        ids = self.tokenizer.encode(self.tokenizer.sep_token.join(cells[1:]), add_special_tokens=False,
+                                    max_length=self.max_length, truncation=True)
+        return json.dumps({"text_id": cells[0], "text": ids})
+
+
 def negatives_from_run(rank_file, relevance, n_sample, depth, rng=random):
     """(qid, positives, sampled hard negatives) per query of a TREC run file: the first `depth`
     non-relevant hits, shuffled, `n_sample` of them kept (build_hn.py:13-38)."""

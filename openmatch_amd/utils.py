@@ -130,8 +130,9 @@ def eval_ndcg(qrel, run, cutoff=10):
 
 
 def __getattr__(name):
-    # `from openmatch.utils import SimpleTrainPreProcessor` (reference utils.py:14) -- lives in preprocess.py
-    if name == "SimpleTrainPreProcessor":
-        from .preprocess import SimpleTrainPreProcessor
-        return SimpleTrainPreProcessor
+    # `from openmatch.utils import SimpleTrainPreProcessor / SimpleCollectionPreProcessor` (reference
+    # utils.py:14,104) -- they live in preprocess.py
+    if name in ("SimpleTrainPreProcessor", "SimpleCollectionPreProcessor"):
+        from . import preprocess
+        return getattr(preprocess, name)
     raise AttributeError(name)
