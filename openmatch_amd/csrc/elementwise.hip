@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const bf16_t* __restrict__
       const float w0 = bf16_to_f32((bf16_t)(w[e] & 0xffff)), w1 = bf16_to_f32((bf16_t)(w[e] >> 16));
       const bf16_t f0 = f32_to_bf16(w0 * gamma[k + 2 * e]), f1 = f32_to_bf16(w1 * gamma[k + 2 * e + 1]);
       s += bf16_to_f32(f0) + bf16_to_f32(f1);
-      t += w0 * beta[k + 2 * e] + w1 * beta[k + 2 * e + 1];
+      if (beta) t += w0 * beta[k + 2 * e] + w1 * beta[k + 2 * e + 1];
       o[e] = (uint32_t)f0 | ((uint32_t)f1 << 16);
     }
     *(uint4*)(Wf + (int64_t)n * K + k) = make_uint4(o[0], o[1], o[2], o[3]);

@@ -45,7 +45,7 @@ static EncWs carve(const OmEncoderConfig* c, int64_t B, int64_t L, char* base) {
   w.headout = (float*)take((size_t)B * (c->head_out > 0 ? c->head_out : 1) * 4);
   w.posbias = (float*)take(c->arch == OM_ARCH_T5 ? (size_t)c->n_heads * L * L * 4 : 0);
   w.lut = (int*)take(c->arch == OM_ARCH_T5 ? (size_t)(2 * L) * 4 : 0);
-  const bool fuse = c->arch == OM_ARCH_BERT && c->dtype == OM_BF16;
+  const bool fuse = c->dtype == OM_BF16;              // fused-norm path (BERT LayerNorm / T5 RMSNorm)
   const size_t wide = std::max((size_t)3 * H, F);
   w.wfold = take(fuse ? wide * H * es : 0);
   w.colsum = (float*)take(fuse ? wide * 4 : 0);
@@ -204,6 +204,52 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
     RUN(omk_t5_bias(w->rel_bias, ws.lut, ws.posbias, (int)L, nh, s));
     RUN(omk_embed(dt, input_ids, nullptr, w->word_emb, nullptr, nullptr, nullptr, nullptr, ws.x, M,
                   (int)L, H, c->vocab, 1, c->ln_eps, 0, s));
+    // RMSNorm fused across the GEMMs (bf16, >= 512 tokens), the pre-norm counterpart of the BERT path
+    // above: the GEMM that updates the residual stream x accumulates sum(x^2) per row; the GEMMs that
+    // consume rms(x) * g read x itself against the folded weight W * g and scale their rows by
+    // rsqrt(mean(x^2) + eps) in the epilogue.  Only the first and the final norm run as kernels.
+    const bool no_fuse_t5 = getenv("OM_ENCODER_FUSED_LN") && atoi(getenv("OM_ENCODER_FUSED_LN")) == 0;
+    // (gated feed-forward layers keep the kernels: two folded GEMMs per norm measured 1 % slower, tools/gtr_bench.py)
+    const bool fuse_t5 = !no_fuse_t5 && c->n_layers > 0 && !Ls[0].ffn1g_w && H % 8 == 0 && omk_gemm_ln_fusable(dt, M, H, H) &&
+                         omk_gemm_ln_fusable(dt, M, F, H) && omk_gemm_ln_fusable(dt, M, 3 * H, H) &&
+                         omk_gemm_ln_fusable(dt, M, H, F);
+    if (getenv("OM_ENCODER_DEBUG")) fprintf(stderr, "om_encoder_forward (t5): M=%ld fused_norm=%d\n", (long)M, (int)fuse_t5);
+    if (fuse_t5) {
+      const float inv_h = 1.0f / (float)H;
+      OM_HIP(hipMemsetAsync(ws.stats1, 0, (size_t)2 * c->n_layers * M * 8, s));
+      auto folded = [&](const void* A_, const void* W_, const float* g_, const float* stats_, void* C_, int N_, int act_,
+                        const void* res_, int64_t ldr_) -> int {
+        if (omk_ln_fold(W_, g_, nullptr, nullptr, ws.wfold, ws.colsum, ws.bfold, N_, H, s)) return 1;
+        GemmEpilogue e = {};
+        e.act = act_; e.resid = res_; e.ldr = ldr_;
+        e.ln_stats = stats_; e.ln_rms = 1; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+        return omk_gemm(dt, A_, H, ws.wfold, H, dt, C_, N_, M, N_, H, e, s);
+      };
+      for (int l = 0; l < c->n_layers; ++l) {
+        const OmLayerWeights& lw = Ls[l];
+        float* st1 = ws.stats1 + (size_t)l * M * 2;                     // sum(x1^2): input of the FFN norm
+        float* st2 = ws.stats2 + (size_t)l * M * 2;                     // sum(x'^2): input of the next layer's first norm
+        if (l == 0) {
+          RUN(omk_layernorm(dt, ws.x, H, ws.y, H, lw.ln1_g, nullptr, M, H, c->ln_eps, 1, s));
+          GEMM(ws.y, H, lw.qkv_w, H, ws.qkv, 3 * H, 3 * H, H, nullptr, nullptr, 0, OM_ACT_NONE);
+        } else {
+          RUN(folded(ws.x, lw.qkv_w, lw.ln1_g, ws.stats2 + (size_t)(l - 1) * M * 2, ws.qkv, 3 * H, OM_ACT_NONE, nullptr, 0));
+        }
+        RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, ws.posbias, B, (int)L, H, nh, 1.0f, 0.f, 0, s));
+        GemmEpilogue e = {};
+        e.resid = ws.x; e.ldr = H; e.stats_out = st1; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+        RUN(omk_gemm(dt, ws.ctx, H, lw.o_w, H, dt, ws.x, H, M, H, H, e, s));           // x += o(ctx), sum(x^2)
+        if (lw.ffn1g_w) {
+          RUN(folded(ws.x, lw.ffn1g_w, lw.ln2_g, st1, ws.ff2, F, OM_ACT_NONE, nullptr, 0));
+          RUN(folded(ws.x, lw.ffn1_w, lw.ln2_g, st1, ws.ff, F, c->act | OM_ACT_MUL_RESID, ws.ff2, F));
+        } else {
+          RUN(folded(ws.x, lw.ffn1_w, lw.ln2_g, st1, ws.ff, F, c->act, nullptr, 0));
+        }
+        e = GemmEpilogue{};
+        e.resid = ws.x; e.ldr = H; e.stats_out = st2; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+        RUN(omk_gemm(dt, ws.ff, F, lw.ffn2_w, F, dt, ws.x, H, M, H, F, e, s));         // x += wo(ff), sum(x^2)
+      }
+    } else
     for (int l = 0; l < c->n_layers; ++l) {
       const OmLayerWeights& lw = Ls[l];
       RUN(omk_layernorm(dt, ws.x, H, ws.y, H, lw.ln1_g, nullptr, M, H, c->ln_eps, 1, s));

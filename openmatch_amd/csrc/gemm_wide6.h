@@ -46,14 +46,15 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel6(
     }
     const int64_t n4 = nc + l31 * 4;                    // lanes 0-31: s, lanes 32-63: b'
     f32x4_t t = {0.f, 0.f, 0.f, 0.f};
-    if (n4 < N) t = *(const f32x4_t*)((half ? ep.bias : ep.ln_colsum) + n4);
+    const float* tsrc = half ? ep.bias : ep.ln_colsum;      // either may be absent (RMSNorm: no shift, no mean)
+    if (tsrc && n4 < N) t = *(const f32x4_t*)(tsrc + n4);
     if (tr && threadIdx.x == 0) tr[1] = clock64();
     g6_begin(pa, pb, nk, smem, wave);
     float* tab = &lntab[LNF == 1 ? wave : 0][0][0];
     *(f32x4_t*)(tab + half * 128 + l31 * 4) = t;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-      mu[mi] = st[mi].x * ep.ln_inv_h;
+      mu[mi] = ep.ln_rms ? 0.f : st[mi].x * ep.ln_inv_h;
       const float var = fmaxf(st[mi].y * ep.ln_inv_h - mu[mi] * mu[mi], 0.f) + ep.ln_eps;
       rs[mi] = rsqrtf(var);
       inv[mi] = sqrtf(var);

@@ -45,6 +45,7 @@ struct GemmEpilogue {
   const float* rln_b;
   float* stats_out;          // accumulate (sum, sum of squares) of every output row (the next LayerNorm's input)
   float ln_inv_h, ln_eps;
+  int ln_rms;                // 1: the statistics describe a T5 RMSNorm (no mean, no shift): only sum of squares is used
 };
 // true when omk_gemm will run [M,N] x K (16-bit) on the kernel that implements the ln_* / rln_* / stats_out fields
 bool omk_gemm_ln_fusable(int dtype, int64_t M, int64_t N, int64_t K);

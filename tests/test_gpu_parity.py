@@ -141,6 +141,44 @@ def test_fused_layernorm_path_matches_unfused_and_oracle(monkeypatch):
         assert not torch.equal(fused, plain)          # the two paths really are different code
 
 
+@pytest.mark.parametrize("gated", [False, True])
+def test_fused_rmsnorm_path_matches_unfused_and_oracle(monkeypatch, gated):
+    """The T5 counterpart: RMSNorm folded into the GEMMs (bf16, >= 512 tokens), GTR-style tail."""
+    from transformers import T5Config, T5EncoderModel
+    from openmatch.modeling import DRModelForInference, LinearHead
+    torch.manual_seed(12 + gated)
+    cfg = T5Config(d_model=256, d_ff=512, num_layers=3, num_heads=4, d_kv=64, vocab_size=600,
+                   feed_forward_proj="gated-gelu" if gated else "relu")
+    lm = T5EncoderModel(cfg).eval()
+    with torch.no_grad():
+        for name, p in lm.named_parameters():
+            if "layer_norm" in name:
+                p.copy_(1.0 + 0.3 * torch.randn_like(p))
+            elif "relative_attention_bias" in name:
+                p.copy_(0.5 * torch.randn_like(p))
+    head = LinearHead(256, 256)
+    sd = {k: v.clone() for k, v in lm.state_dict().items()}
+    hw = head.linear.weight.detach().clone()
+    model = DRModelForInference(lm_q=lm, lm_p=lm, pooling="mean", normalize=True, head_q=head, head_p=head,
+                                model_args=NS(encoder_only=True, dtype="bfloat16")).to(DEV).eval()
+    rng = np.random.default_rng(9)
+    for B, L in ((8, 64), (9, 77), (24, 128)):
+        ids, mask = synth_tokens(rng, B, L, vocab=600, lo_len=5, lo_id=3)
+        items = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
+        dev_items = {k: v.to(DEV) for k, v in items.items()}
+        _, ref = encoder_ref.encode(sd, cfg, "t5", items, "mean", hw, True)
+        monkeypatch.setenv("OM_ENCODER_FUSED_LN", "1")
+        _, fused = model.encode_passage(dev_items)
+        monkeypatch.setenv("OM_ENCODER_FUSED_LN", "0")
+        _, plain = model.encode_passage(dev_items)
+        fused, plain, ref = fused.float().cpu(), plain.float().cpu(), ref.float()
+        cos = lambda a, b: torch.nn.functional.cosine_similarity(a, b, dim=1).min().item()
+        assert cos(plain, ref) > 0.999, (B, L, cos(plain, ref))
+        assert cos(fused, ref) > 0.999, (B, L, cos(fused, ref))
+        assert cos(fused, plain) > 0.9995, (B, L, cos(fused, plain))
+        assert torch.equal(fused, plain) == gated      # gated layers keep the norm kernels (encoder.hip)
+
+
 # ------------------------------------------------------------------------------- search
 def _adjudicate(I_gpu, I_ref, P, Q, k):
     P64, Q64 = torch.from_numpy(P).double(), torch.from_numpy(Q).double()
