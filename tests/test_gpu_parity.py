@@ -104,14 +104,16 @@ def test_encoder_matches_oracle_on_ragged_batches():
         assert np.abs(got.cpu().numpy() - ref.numpy()).max() < 1e-4, (B, L)
 
 
-def test_fused_layernorm_path_matches_unfused_and_oracle(monkeypatch):
+@pytest.mark.parametrize("hidden,heads,ffn", [(256, 4, 512), (384, 6, 1536)])
+def test_fused_layernorm_path_matches_unfused_and_oracle(monkeypatch, hidden, heads, ffn):
     """bf16 batches of >= 512 tokens take the path where LayerNorm is folded into the GEMMs around it
     (encoder.hip): same embeddings as the launch-per-LayerNorm path and as the f32 oracle, incl. a
     ragged batch, a non-multiple-of-256 row count and non-trivial LayerNorm affines."""
     from transformers import BertConfig, BertModel
     from openmatch.modeling import DRModelForInference
     torch.manual_seed(11)
-    cfg = BertConfig(hidden_size=256, num_hidden_layers=3, num_attention_heads=4, intermediate_size=512,
+    # (384 columns = one full 256-wide tile + a half one: the column guards of the fused epilogues)
+    cfg = BertConfig(hidden_size=hidden, num_hidden_layers=3, num_attention_heads=heads, intermediate_size=ffn,
                      vocab_size=600, max_position_embeddings=128)
     lm = BertModel(cfg).eval()
     with torch.no_grad():                      # random-init LayerNorms are (1, 0): make the affines matter
