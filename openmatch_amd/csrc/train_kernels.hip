@@ -117,11 +117,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
   float* red = (float*)smem;                       // [2][4][H]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float gacc[NV][4], bacc[NV][4], gv[NV][4];
+  // MODE 1: every token adds into one of (usually) two token-type rows -- thousands of atomics per
+  // address if done per token (528 us per call at 8448 tokens).  Types 0 and 1 are summed in registers
+  // and flushed once per block; other type ids keep the per-token atomic.
+  float tacc[MODE == 1 ? 2 : 1][NV][4];
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int c = (lane + 64 * j) * 4;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { gacc[j][e] = 0.f; bacc[j][e] = 0.f; gv[j][e] = (c + e < H) ? g[c + e] : 0.f; }
+    for (int e = 0; e < 4; ++e) {
+      gacc[j][e] = 0.f; bacc[j][e] = 0.f; gv[j][e] = (c + e < H) ? g[c + e] : 0.f;
+      tacc[0][j][e] = 0.f;
+      if (MODE == 1) tacc[MODE == 1 ? 1 : 0][j][e] = 0.f;
+    }
   }
   for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < M; row += (int64_t)gridDim.x * 4) {
     float xv[NV][4], dv[NV][4];
@@ -187,7 +195,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
             ElemOps<T>::store(dx + row * H + c + e, v);
           } else {
             atomicAdd(dword + id * H + c + e, v);
-            atomicAdd(dtype_ + tt * H + c + e, v);
+            if (tt == 0) tacc[0][j][e] += v;
+            else if (tt == 1) tacc[MODE == 1 ? 1 : 0][j][e] += v;
+            else atomicAdd(dtype_ + tt * H + c + e, v);
             atomicAdd(dpos + (int64_t)t * H + c + e, v);
           }
         }
@@ -207,6 +217,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
   for (int c = threadIdx.x; c < H; c += 256) {
     atomicAdd(dg + c, (red[0 * H + c] + red[1 * H + c]) + (red[2 * H + c] + red[3 * H + c]));
     if (db) atomicAdd(db + c, (red[4 * H + c] + red[5 * H + c]) + (red[6 * H + c] + red[7 * H + c]));
+  }
+  if (MODE == 1) {                     // token-type rows 0 and 1: same block reduction, then one atomic per column
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (lane + 64 * j) * 4;
+      if (c < H) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[(0 * 4 + w) * H + c + e] = tacc[0][j][e]; red[(1 * 4 + w) * H + c + e] = tacc[MODE == 1 ? 1 : 0][j][e]; }
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) {
+      atomicAdd(dtype_ + c, (red[0 * H + c] + red[1 * H + c]) + (red[2 * H + c] + red[3 * H + c]));
+      if (type_vocab > 1) atomicAdd(dtype_ + H + c, (red[4 * H + c] + red[5 * H + c]) + (red[6 * H + c] + red[7 * H + c]));
+    }
   }
 }
 
