@@ -470,8 +470,11 @@ struct Scan {
     }
     while (done < N) {
       const int64_t list = std::max<unsigned>(f[1], 1u);
-      // expected survivors of a chunk ~ list * chunk / done ; aim at half the free slots
-      int64_t chunk = (int64_t)((double)done * (double)(SORT_CAP - list) / (2.0 * (double)list));
+      // expected survivors of a chunk ~ list * chunk / done.  The per-query sort pads its list to the next
+      // power of two, so aim just under 4096 keys (list + survivors) while the list is short enough --
+      // filling half the free slots lands at ~4700 and sorts 8192 every round -- else half the free slots.
+      const double want = list <= 2048 ? 3800.0 - (double)list : (double)(SORT_CAP - list) / 2.0;
+      int64_t chunk = (int64_t)((double)done * want / (double)list);
       chunk = std::max<int64_t>(chunk, DENSE_CHUNK);
       chunk = std::min<int64_t>(chunk, N - done);
       OM_HIP(hipMemsetAsync(ws.flag, 0, 64, s));
