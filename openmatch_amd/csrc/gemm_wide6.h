@@ -17,7 +17,7 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel6(
   g4_tile_coords(M, N, group_m, m0, n0);
   f32x16_t acc[4][4];
   unsigned long long* tr = ep.trace ? ep.trace + (size_t)blockIdx.x * 32 : nullptr;
-  if (tr && threadIdx.x == 0) tr[0] = clock64();
+  if (tr && threadIdx.x == 0) { tr[0] = clock64(); tr[30] = wall_clock64(); }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel6(
   const EpiScalars es(ep);
   char* region = smem + wave * G6E_REGION_BYTES;
   store_wave_tile6<OutT, ACT, TRAIN, RESID, LNF>(acc, mc, nc, C, ldc, M, N, ep, es, region, rs);
-  if (tr && threadIdx.x == 0) { tr[28] = clock64(); tr[29] = blockIdx.x; }
+  if (tr && threadIdx.x == 0) { tr[28] = clock64(); tr[29] = blockIdx.x; tr[31] = wall_clock64(); }
 }
 
 // A persistent form (one workgroup per CU walking tiles, the next tile's first two K steps issued

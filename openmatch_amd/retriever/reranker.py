@@ -20,24 +20,28 @@ logger = logging.getLogger(__name__)
 
 
 def encode_pair(tokenizer, item1, item2, max_len_1=32, max_len_2=128):
-    """Two token-id lists -> [CLS] q [SEP] d [SEP] padded to max_len_1 + max_len_2 + 2 (= 162) with
-    type ids 0/1 and a mask -- what the reference gets from `tokenizer.encode_plus(ids, ids,
-    truncation='longest_first', padding='max_length')` (reranker.py:23-29) under transformers 4.x.
-    transformers 5 has no id-list entry point any more, so the same rule is applied directly."""
+    """Query and document token-id lists -> ONE sequence, as the reference builds it
+    (reranker.py:23-29: `tokenizer.encode_plus(item1 + item2, truncation='longest_first',
+    padding='max_length', max_length=max_len_1 + max_len_2 + 2)`): the two id lists are CONCATENATED, so
+    the model sees [CLS] q d [SEP] (no separator between them), token_type_ids all 0, truncated from
+    the right, padded to 162 -- the same format `RRTrainDataset.create_one_example` trains on
+    (train_dataset.py:139-147).  transformers 5 has no id-list entry point any more, so the 4.x rule is
+    applied directly when `prepare_for_model` is missing."""
     n = max_len_1 + max_len_2 + 2
+    ids = list(item1) + list(item2)
     if hasattr(tokenizer, "prepare_for_model"):
-        return tokenizer.prepare_for_model(item1, item2, truncation="longest_first", padding="max_length", max_length=n)
-    a, b = list(item1), list(item2)
-    while len(a) + len(b) > n - 3:              # longest first; a tie shortens the second sequence
-        if len(a) > len(b):
-            a.pop()
-        else:
-            b.pop()
-    ids = [tokenizer.cls_token_id] + a + [tokenizer.sep_token_id] + b + [tokenizer.sep_token_id]
-    types = [0] * (len(a) + 2) + [1] * (len(b) + 1)
+        return tokenizer.prepare_for_model(ids, truncation="longest_first", padding="max_length", max_length=n)
+    cls_id, sep_id = getattr(tokenizer, "cls_token_id", None), getattr(tokenizer, "sep_token_id", None)
+    if cls_id is not None and sep_id is not None:
+        ids = [cls_id] + ids[:n - 2] + [sep_id]
+    else:                                      # T5-like vocabulary: ids </s>
+        ids = ids[:n - 1] + [tokenizer.eos_token_id]
     pad = n - len(ids)
-    return {"input_ids": ids + [tokenizer.pad_token_id] * pad, "token_type_ids": types + [0] * pad,
-            "attention_mask": [1] * len(ids) + [0] * pad}
+    pad_id = tokenizer.pad_token_id if tokenizer.pad_token_id is not None else 0
+    out = {"input_ids": ids + [pad_id] * pad, "attention_mask": [1] * len(ids) + [0] * pad}
+    if cls_id is not None and sep_id is not None:
+        out["token_type_ids"] = [0] * n
+    return out
 
 
 def add_to_result_dict(result_dicts, qids, dids, scores):

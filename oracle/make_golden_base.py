@@ -1,0 +1,213 @@
+"""Fixtures at the shapes that are actually BENCHMARKED (full-size models), produced by EXECUTING THE
+REFERENCE in the build container:  python oracle/make_golden_base.py   (needs /root/reference).
+
+  config1_bert_base.npz   BASELINE config 1 / SURVEY 8(d) row 1: seeded BertConfig() (12 x 768), 1 000 passages
+                          x 128 tok + 100 queries x 32 tok  ->  reference DRModelForInference  ->  reference
+                          Retriever.search (oracle.flatip injected as `faiss`)  ->  save_as_trec  ->  eval_mrr,
+                          once in fp32 and once under torch.autocast("cpu", bfloat16) -- the reference's own
+                          16-bit mode (its `--fp16` switch wraps the model call in autocast,
+                          retriever/dense_retriever.py:76) -- so that the HIP bf16 path is judged against what
+                          the REFERENCE loses in 16-bit arithmetic, not against an arbitrary threshold.
+  gtr_base.npz            GTR-base-sized T5 encoder (12 x 768, relu, mean pooling, 768->768 head, normalised):
+                          64 passages + 16 queries, fp32 and autocast.
+  bert_large_rr.npz       bert-large cross-encoder (24 x 1024) RRModel scores of 32 pairs x 162 tok, fp32 and autocast.
+
+Weights are re-created from the seed by the tests (HF is in the image); a checksum pins them.
+"""
+import os
+import pickle
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import make_golden as mg  # noqa: E402  (puts /root/reference/src first on sys.path, injects the faiss stub)
+from oracle import flatip  # noqa: E402
+
+from transformers import BertConfig, BertModel, T5Config, T5EncoderModel  # noqa: E402
+from openmatch.modeling import DRModelForInference  # noqa: E402  (the reference)
+from openmatch.modeling.linear import LinearHead  # noqa: E402
+from openmatch.modeling.reranking_model import RRModel  # noqa: E402
+from openmatch.retriever import Retriever  # noqa: E402
+from openmatch.utils import save_as_trec  # noqa: E402
+
+NS = mg.NS
+OUT = mg.OUT
+SEED = 20260925
+
+
+def checksum(model):
+    sd = model.state_dict()
+    return np.array([float(sum(v.double().sum() for v in sd.values())), float(sum(v.double().abs().sum() for v in sd.values()))])
+
+
+def lengths(mask):
+    return mask.sum(1).astype(np.int16)
+
+
+def encode_all(ref, which, ids, mask, bs, autocast, extra=None):
+    """The reference's batch loop (dense_retriever.py:70-83): model(passage=batch) / model(query=batch), optional
+    autocast, .cpu().numpy() per batch, concatenate."""
+    outs = []
+    t0 = time.time()
+    for s in range(0, ids.shape[0], bs):
+        batch = {"input_ids": torch.from_numpy(ids[s:s + bs]), "attention_mask": torch.from_numpy(mask[s:s + bs])}
+        if extra is not None:
+            batch.update({k: torch.from_numpy(v[s:s + bs]) for k, v in extra.items()})
+        with torch.no_grad():
+            if autocast:
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    o = ref(**{which: batch})
+            else:
+                o = ref(**{which: batch})
+        reps = o.p_reps if which == "passage" else o.q_reps
+        outs.append(reps.float().cpu().numpy())
+    print(f"    {which} x{ids.shape[0]} autocast={autocast}: {time.time() - t0:.1f} s", flush=True)
+    return np.concatenate(outs)
+
+
+def reference_search(P, Q, doc_ids, qry_ids, k):
+    """Reference Retriever.search over shard pickles (two corpus shards, two query shards)."""
+    n, nq = P.shape[0], Q.shape[0]
+    with tempfile.TemporaryDirectory() as tmp:
+        for r in range(2):
+            with open(os.path.join(tmp, f"embeddings.query.rank.{r}"), "wb") as f:
+                pickle.dump((Q[r * nq // 2:(r + 1) * nq // 2], qry_ids[r * nq // 2:(r + 1) * nq // 2]), f, protocol=4)
+        args = NS(device="cpu", output_dir=tmp, world_size=2, process_index=0, local_process_index=0)
+        r = Retriever(torch.nn.Linear(1, 1), None, args)
+        r.index = flatip.IndexFlatIP(P.shape[1])
+        r.doc_lookup = []
+        for rk in range(2):
+            r.index.add(P[rk * n // 2:(rk + 1) * n // 2])
+            r.doc_lookup.extend(doc_ids[rk * n // 2:(rk + 1) * n // 2])
+        run = r.search(k)
+        trec = os.path.join(tmp, "run.trec")
+        save_as_trec(run, trec)
+        text = open(trec).read()
+    return run, text
+
+
+def run_to_arrays(run, qry_ids, doc_ids):
+    pos = {d: i for i, d in enumerate(doc_ids)}
+    I = np.array([[pos[d] for d in run[q]] for q in qry_ids], np.int32)
+    D = np.array([[run[q][d] for d in run[q]] for q in qry_ids], np.float32)
+    return I, D
+
+
+def config1(rng):
+    torch.manual_seed(0)
+    cfg = BertConfig()
+    lm = BertModel(cfg).eval()
+    ref = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False))
+    n, nq = 1000, 100
+    p_ids, p_mask = mg.synth_batch(rng, n, 128, cfg.vocab_size, 16)
+    q_ids, q_mask = mg.synth_batch(rng, nq, 32, cfg.vocab_size, 4)
+    doc_ids = [f"D{7 * i + 3}" for i in range(n)]
+    qry_ids = [f"Q{i}" for i in range(nq)]
+    out = {"p_input_ids": p_ids.astype(np.uint16), "p_len": lengths(p_mask), "q_input_ids": q_ids.astype(np.uint16),
+           "q_len": lengths(q_mask), "doc_ids": np.array(doc_ids), "qry_ids": np.array(qry_ids), "weight_checksum": checksum(lm)}
+    eval_mrr = mg.reference_eval_mrr()
+    runs = {}
+    for tag, ac in (("f32", False), ("ac", True)):
+        P = encode_all(ref, "passage", p_ids, p_mask, 50, ac)
+        Q = encode_all(ref, "query", q_ids, q_mask, 50, ac)
+        run, trec = reference_search(P, Q, doc_ids, qry_ids, 100)
+        runs[tag] = run
+        I, D = run_to_arrays(run, qry_ids, doc_ids)
+        out[f"P_{tag}"] = P if tag == "f32" else P.astype(np.float16)
+        out[f"Q_{tag}"] = Q if tag == "f32" else Q.astype(np.float16)
+        out[f"I100_{tag}"], out[f"D100_{tag}"] = I, D
+        if tag == "f32":
+            out["trec_f32"] = np.array(trec)
+            # qrels: one relevant document per query at reference rank r ~ U{1..20}
+            qrel = {}
+            for qid in qry_ids:
+                ranked = sorted(run[qid].items(), key=lambda kv: kv[1], reverse=True)
+                qrel[qid] = {ranked[int(rng.integers(0, 20))][0]: 1}
+            out["qrel_docs"] = np.array([list(qrel[q])[0] for q in qry_ids])
+        out[f"mrr10_{tag}"] = np.array(eval_mrr(qrel, run, cutoff=10)["all"])
+    # how far the reference's own 16-bit mode is from its fp32 mode (the yardstick for the HIP bf16 path)
+    Pf, Pa = torch.from_numpy(out["P_f32"]).double(), torch.from_numpy(out["P_ac"].astype(np.float32)).double()
+    Qf, Qa = torch.from_numpy(out["Q_f32"]).double(), torch.from_numpy(out["Q_ac"].astype(np.float32)).double()
+    cos = torch.nn.functional.cosine_similarity(Pf, Pa, dim=1)
+    dd = ((Qa @ Pa.t()) - (Qf @ Pf.t())).abs()
+    ov = [len(set(a.tolist()) & set(b.tolist())) for a, b in zip(out["I100_f32"], out["I100_ac"])]
+    out["ac_vs_f32"] = np.array([float(cos.min()), float(cos.mean()), float(dd.max()), float(np.mean(ov)), float(np.min(ov))])
+    print("  reference autocast-bf16 vs reference fp32: min cos %.6f  mean cos %.6f  max|ddot| %.4f  top-100 overlap mean %.1f min %d"
+          % tuple(out["ac_vs_f32"]), " MRR@10 f32 %.4f  autocast %.4f" % (float(out["mrr10_f32"]), float(out["mrr10_ac"])))
+    np.savez_compressed(os.path.join(OUT, "config1_bert_base.npz"), **out)
+    print("wrote config1_bert_base.npz")
+
+
+def gtr_base(rng):
+    torch.manual_seed(1)
+    cfg = T5Config(d_model=768, d_ff=3072, num_layers=12, num_heads=12, d_kv=64, feed_forward_proj="relu")
+    lm = T5EncoderModel(cfg).eval()
+    head = LinearHead(768, 768)
+    ref = DRModelForInference(lm_q=lm, lm_p=lm, pooling="mean", head_q=head, head_p=head, normalize=True,
+                              model_args=NS(encoder_only=True))
+    p_ids, p_mask = mg.synth_batch(rng, 64, 128, cfg.vocab_size, 16, bert=False)
+    q_ids, q_mask = mg.synth_batch(rng, 16, 32, cfg.vocab_size, 4, bert=False)
+    out = {"p_input_ids": p_ids.astype(np.uint16), "p_len": lengths(p_mask), "q_input_ids": q_ids.astype(np.uint16),
+           "q_len": lengths(q_mask), "weight_checksum": checksum(lm),
+           "head_checksum": np.array([float(head.linear.weight.double().sum()), float(head.linear.weight.double().abs().sum())])}
+    for tag, ac in (("f32", False), ("ac", True)):
+        out[f"P_{tag}"] = encode_all(ref, "passage", p_ids, p_mask, 32, ac)
+        out[f"Q_{tag}"] = encode_all(ref, "query", q_ids, q_mask, 16, ac)
+    cos = torch.nn.functional.cosine_similarity(torch.from_numpy(out["P_f32"]).double(), torch.from_numpy(out["P_ac"]).double(), dim=1)
+    dd = np.abs(out["Q_ac"].astype(np.float64) @ out["P_ac"].astype(np.float64).T - out["Q_f32"].astype(np.float64) @ out["P_f32"].astype(np.float64).T)
+    out["ac_vs_f32"] = np.array([float(cos.min()), float(cos.mean()), float(dd.max())])
+    print("  GTR-base reference autocast vs fp32: min cos %.6f mean cos %.6f max|ddot| %.5f" % tuple(out["ac_vs_f32"]))
+    np.savez_compressed(os.path.join(OUT, "gtr_base.npz"), **out)
+    print("wrote gtr_base.npz")
+
+
+def bert_large_rr(rng):
+    torch.manual_seed(2)
+    cfg = BertConfig(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
+    lm = BertModel(cfg).eval()
+    head = LinearHead(1024, 1)
+    ref = RRModel(lm=lm, head=head, pooling="first", model_args=NS(encoder_only=False)).eval()
+    n, L = 32, 162
+    ids, mask = mg.synth_batch(rng, n, L, cfg.vocab_size, 40)
+    # the reference's pair format (retriever/reranker.py:23-29, encode_plus(item1 + item2)): ONE sequence
+    # [CLS] q d [SEP], token_type_ids all 0
+    tt = np.zeros_like(ids)
+    out = {"input_ids": ids.astype(np.uint16), "len": lengths(mask), "weight_checksum": checksum(lm),
+           "head_w": head.linear.weight.detach().numpy()}
+    for tag, ac in (("f32", False), ("ac", True)):
+        sc = []
+        t0 = time.time()
+        for s in range(0, n, 8):
+            batch = {"input_ids": torch.from_numpy(ids[s:s + 8]), "attention_mask": torch.from_numpy(mask[s:s + 8]),
+                     "token_type_ids": torch.from_numpy(tt[s:s + 8])}
+            with torch.no_grad():
+                if ac:
+                    with torch.autocast("cpu", dtype=torch.bfloat16):
+                        sc.append(ref.encode(batch).float().numpy())
+                else:
+                    sc.append(ref.encode(batch).float().numpy())
+        out[f"scores_{tag}"] = np.concatenate(sc)[:, 0]
+        print(f"    bert-large pairs autocast={ac}: {time.time() - t0:.1f} s", flush=True)
+    out["ac_vs_f32"] = np.array([float(np.abs(out["scores_ac"] - out["scores_f32"]).max()), float(np.abs(out["scores_f32"]).max())])
+    print("  bert-large RR reference autocast vs fp32: max|dscore| %.5f (|score| <= %.3f)" % tuple(out["ac_vs_f32"]))
+    np.savez_compressed(os.path.join(OUT, "bert_large_rr.npz"), **out)
+    print("wrote bert_large_rr.npz")
+
+
+def main():
+    torch.set_num_threads(os.cpu_count() or 1)
+    what = sys.argv[1:] or ["config1", "gtr", "large"]
+    if "config1" in what:
+        config1(np.random.default_rng(SEED + 11))
+    if "gtr" in what:
+        gtr_base(np.random.default_rng(SEED + 12))
+    if "large" in what:
+        bert_large_rr(np.random.default_rng(SEED + 13))
+
+
+if __name__ == "__main__":
+    main()

@@ -44,7 +44,12 @@ def v4_encode_plus(tok):
     def encode_plus(ids, truncation=None, max_length=None, padding=False, return_attention_mask=False,
                     return_token_type_ids=False):
         room = max_length - 2
-        return {"input_ids": [tok.cls_token_id] + list(ids)[:room] + [tok.sep_token_id]}
+        out = {"input_ids": [tok.cls_token_id] + list(ids)[:room] + [tok.sep_token_id]}
+        if padding == "max_length":      # the re-ranker's call (reranker.py:23-29): 4.x pads and returns all three
+            n = len(out["input_ids"])
+            out = {"input_ids": out["input_ids"] + [tok.pad_token_id] * (max_length - n),
+                   "token_type_ids": [0] * max_length, "attention_mask": [1] * n + [0] * (max_length - n)}
+        return out
     return encode_plus
 
 
@@ -126,6 +131,16 @@ def main():
                         it = iter(ds)
                     rows = [json.loads(json.dumps(dict(ex), default=lambda o: dict(o))) for ex in it]
                     golden["train"].append({"kind": name, "seed": seed, "flags": flags, "epoch": epoch, "examples": rows})
+    # the re-ranker's pair encoding: the reference's own encode_pair (retriever/reranker.py:23-29) on id lists
+    # short enough to pad and long enough to truncate
+    from openmatch.retriever.reranker import encode_pair
+    rng = np.random.default_rng(7)
+    golden["encode_pair"] = []
+    for nq, nd, m1, m2 in ((3, 5, 8, 24), (8, 24, 8, 24), (12, 40, 8, 24), (1, 1, 32, 128), (30, 200, 32, 128)):
+        q = [int(x) for x in rng.integers(5, 60, size=nq)]
+        d = [int(x) for x in rng.integers(5, 60, size=nd)]
+        golden["encode_pair"].append({"q": q, "d": d, "max_len_1": m1, "max_len_2": m2,
+                                      "out": plain(encode_pair(tok, q, d, m1, m2))})
     json.dump(golden, open(os.path.join(OUT, "reference_outputs.json"), "w"))
     print("wrote", OUT, {k: len(v) for k, v in golden.items()})
 

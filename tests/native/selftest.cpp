@@ -356,11 +356,12 @@ int main(int argc, char** argv) {
   }
   if (what == "trace") {    // per-block phase timelines of one GEMM launch (shader clocks)
     const int64_t N = argc > 2 ? atoi(argv[2]) : 768, K = argc > 3 ? atoi(argv[3]) : 768, M = argc > 4 ? atoll(argv[4]) : 32768;
-    const int64_t ld = argc > 5 ? atoll(argv[5]) : K;   // 0: every row aliases row 0 (operands always cache-hot)
+    const int64_t ld = (argc > 5 && atoll(argv[5]) > 0) ? atoll(argv[5]) : K;   // leading dimension (0 / absent: K)
+    const int warm = argc > 6 ? atoi(argv[6]) : 3;       // launches before the traced one (200: sustained clocks)
     char* A = dalloc<char>(M * K * 2); char* B = dalloc<char>(N * K * 2); char* C = dalloc<char>(M * N * 2);
     { auto t = to_bf16(randn(1 << 22)); for (size_t o = 0; o < (size_t)M * K; o += t.size()) CK(hipMemcpy(A + o * 2, t.data(), std::min(t.size(), (size_t)M * K - o) * 2, hipMemcpyHostToDevice)); auto tb = to_bf16(randn((size_t)N * K, 0.05f)); CK(hipMemcpy(B, tb.data(), tb.size() * 2, hipMemcpyHostToDevice)); }
     const size_t nblk = 8192; unsigned long long* tr = dalloc<unsigned long long>(nblk * 32);
-    for (int i = 0; i < 3; ++i) OMCK(om_gemm_nt(OM_BF16, A, ld, B, ld, OM_BF16, C, N, M, N, K, nullptr, nullptr, 0, 0, nullptr));
+    for (int i = 0; i < warm; ++i) OMCK(om_gemm_nt(OM_BF16, A, ld, B, ld, OM_BF16, C, N, M, N, K, nullptr, nullptr, 0, 0, nullptr));
     CK(hipMemset(tr, 0, nblk * 32 * 8)); om_debug_gemm_trace(tr);
     OMCK(om_gemm_nt(OM_BF16, A, ld, B, ld, OM_BF16, C, N, M, N, K, nullptr, nullptr, 0, 0, nullptr));
     CK(hipDeviceSynchronize()); om_debug_gemm_trace(nullptr);
@@ -375,6 +376,10 @@ int main(int argc, char** argv) {
         epi += (double)(h[b * 32 + 28] - h[b * 32 + 15]); tot += (double)(h[b * 32 + 28] - h[b * 32]); ++n;
       }
       if (n) printf("avg over %zu blocks: prologue %.0f  K-step %.0f  epilogue %.0f  whole tile %.0f (memtime ticks)\n", n, pro / n, step / n, epi / n, tot / n);
+      // effective shader clock: s_memtime ticks against the constant 100 MHz s_memrealtime counter, first start -> last end
+      unsigned long long c0 = ~0ull, c1 = 0, w0 = ~0ull, w1 = 0;
+      for (size_t b = 0; b < used; ++b) if (h[b * 32] && h[b * 32 + 28]) { c0 = std::min(c0, h[b * 32]); c1 = std::max(c1, h[b * 32 + 28]); w0 = std::min(w0, h[b * 32 + 30]); w1 = std::max(w1, h[b * 32 + 31]); }
+      if (w1 > w0) printf("kernel span: %llu shader ticks in %.1f us (100 MHz wall counter) -> %.3f GHz effective shader clock; tiles per CU %.2f\n", c1 - c0, (w1 - w0) / 100.0, (double)(c1 - c0) / ((w1 - w0) * 10.0), used / 256.0);
     }
     for (size_t b = 0; b < used; b += std::max<size_t>(1, used / 8)) {
       printf("blk %5zu:", b);

@@ -100,6 +100,24 @@ def test_train_datasets_match_reference(tok, golden):
         assert len(ds) == 7
 
 
+def test_encode_pair_matches_reference_and_training_format(tok, golden):
+    """The re-ranker's pair encoding against the reference's own encode_pair (reranker.py:23-29, recorded by
+    oracle/make_golden_text.py): ONE concatenated sequence [CLS] q d [SEP], type ids 0, right-truncated,
+    padded to max_len_1 + max_len_2 + 2 -- and the same token sequence RRTrainDataset trains on."""
+    from openmatch.retriever.reranker import encode_pair
+    from openmatch.dataset import RRTrainDataset
+    assert len(golden["encode_pair"]) == 5
+    for case in golden["encode_pair"]:
+        mine = encode_pair(tok, case["q"], case["d"], case["max_len_1"], case["max_len_2"])
+        assert {k: list(v) for k, v in dict(mine).items()} == case["out"]
+    ds = RRTrainDataset(tok, data_args(), trainer=None, shuffle_seed=None)
+    for case in golden["encode_pair"][:3]:            # q_max_len 8, p_max_len 24 -> 34 tokens
+        train = ds.create_one_example(case["q"], case["d"])["input_ids"]
+        infer = encode_pair(tok, case["q"], case["d"], 8, 24)
+        n = sum(infer["attention_mask"])
+        assert infer["input_ids"][:n] == train and set(infer["input_ids"][n:]) <= {tok.pad_token_id}
+
+
 def test_train_shuffle_is_a_seeded_permutation(tok):
     from openmatch.dataset import DRTrainDataset
     base = [as_plain(e) for e in DRTrainDataset(tok, data_args(negative_passage_no_shuffle=True, positive_passage_no_shuffle=True),
