@@ -73,6 +73,9 @@ int om_device_count(void);
 /* Debug hook: when `buf` is non-NULL every 256-row-tile GEMM workgroup writes 32 shader-clock
  * stamps (start, prologue, per-K-step, epilogue) to buf[32*block]; NULL switches it off. */
 void om_debug_gemm_trace(unsigned long long* buf);
+/* Debug hook: 0 = default tile-generation selection; 7 / 71 force the generation-7 K loop (128-byte K steps,
+ * gemm_core7.h) wherever it has a variant -- for A/B measurements inside one process. */
+void om_debug_gemm_gen(int gen);
 int om_kernel_timing_enable(int enable);
 int om_kernel_timing_read(int kernel_class, double* total_ms, int64_t* launches, double* flops);
 
@@ -265,6 +268,19 @@ int om_contrastive_fwd_bwd(const float* q, const float* p, int Qg, int Pg, int d
                            float loss_scale, int q_row0, int q_rows, int p_row0, int p_rows,
                            float* loss, float* scores, float* d_q, float* d_p, float* workspace,
                            void* stream);
+
+/* The same with the full call surface of `F.cross_entropy(logits, target, reduction=...)` that the reference's
+ * loss callables expose (loss.py:9-15: `target=None, reduction='mean'` are parameters of SimpleContrastiveLoss.__call__;
+ * :27-31 forwards them through DistributedContrastiveLoss):
+ *   target   int64 [Qg] class index per row, or NULL for the in-batch positive i*n_psg; -100 rows are ignored
+ *            (torch's ignore_index: loss 0, no gradient, not counted by the mean);
+ *   reduction 0 mean | 1 sum | 2 none (loss is then [Qg]; row_grad [Qg], or NULL for ones, is the upstream
+ *            gradient of each row's loss -- call once with d_q = d_p = NULL for the forward, again for the backward).
+ * workspace: (2*Qg*Pg + Qg + 1) floats. */
+int om_contrastive_fwd_bwd_ex(const float* q, const float* p, int Qg, int Pg, int d, const int64_t* target, int n_psg,
+                              int reduction, const float* row_grad, float loss_scale, int q_row0, int q_rows,
+                              int p_row0, int p_rows, float* loss, float* scores, float* d_q, float* d_p,
+                              float* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -116,6 +116,11 @@ bool omk_gemm_ln_fusable(int dtype, int64_t M, int64_t N, int64_t K) {
 
 static unsigned long long* g_trace = nullptr;
 extern "C" void om_debug_gemm_trace(unsigned long long* buf) { g_trace = buf; }
+static int g_debug_gen = 0;     // 0: default selection; 7 / 71: generation 7 stage A (gemm_wide7.hip) where it has a variant
+extern "C" void om_debug_gemm_gen(int gen) { g_debug_gen = gen; }
+bool omk_gemm_wide7a_has(int in_dtype, int out_dtype, int act, bool train, bool resid, int64_t K, const GemmEpilogue& ep);
+int omk_gemm_wide7a(int bpos, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                    int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s);
 
 int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int out_dtype,
              void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep_in,
@@ -157,6 +162,8 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
     const bool aligned = (((uintptr_t)ep.bias & 15) == 0) && (ep.ldp % 2 == 0) && (((uintptr_t)ep.pre_act & 3) == 0);
     if (!aligned && ln_fused) OM_FAIL("fused LayerNorm epilogue needs 16-byte aligned bias");
     if (!aligned) gen = 4;
+    else if ((g_debug_gen == 7 || g_debug_gen == 71) && omk_gemm_wide7a_has(in_dtype, out_dtype, act, train, resid, K, ep))
+      return omk_gemm_wide7a(g_debug_gen == 71, A, lda, B, ldb, C, ldc, M, N, K, ep, s);
     else if (omk_gemm_wide6_b16_has(in_dtype, out_dtype, act, train, resid))
       return omk_gemm_wide6_b16(in_dtype, A, lda, B, ldb, out_dtype, C, ldc, M, N, K, ep, s);
     else if (omk_gemm_wide6_f32_has(in_dtype, out_dtype, act, train, resid))

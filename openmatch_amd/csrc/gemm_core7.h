@@ -1,0 +1,150 @@
+// Seventh-generation NT GEMM main loop for gfx950 (16-bit inputs): the 256 x 256 tile / four waves of
+// 128 x 128 of gemm_core6.h, fed in 128-BYTE K steps (64 bf16) so that every LDS-DMA request is a
+// whole 128-byte cache line.
+//
+// Why (profiles/r02_gemm_v6_pmc_memory_path.txt, profiles/r02_vendor_gemm_reference.jsonl): with
+// 64-byte K steps a wave's DMA instruction covers 16 rows x 64 B, i.e. 16 HALF lines; the vector
+// L1 (TCP) sends one 64-byte request per half line (TCP_TCC_READ_REQ = bytes / 64), sits in
+// TCP_PENDING_STALL 41 % of the kernel with an average L2 latency of only 265-305 cycles, and the K
+// step takes 1320-1550 cycles on streamed operands against 1123 cache-hot: the per-CU miss queue,
+// not L2 bandwidth or latency, bounds the stream.  Whole-line requests carry twice the bytes per
+// queue entry.  (The vendor GEMM runs these K = 768 shapes at 1.13-1.20 PFLOP/s, v6 at 0.72-0.92.)
+//
+// LDS: five 32 KiB units, each one operand tile of one K step, [256 rows][128 B]; a row holds four
+// MFMA k sub-steps of two 16-byte chunks (k halves), chunk position XOR ((row >> 1) & 7) -- every
+// ds_read_b128 lane group then covers 16 distinct 16-byte slots of the 256-byte bank row, and the
+// eight lanes that fetch a row read one whole line (permuted).  Units rotate:
+//     step t computes from (A_cur, B_cur); (A_nxt, B_nxt) hold step t+1;
+//     A(t+2) is fetched into the spare unit during sub-steps 0-1 of step t,
+//     B(t+2) into A_cur once every wave has read its last A(t) fragment (the step's single barrier,
+//     between sub-steps 2 and 3, which also publishes step t+1), during sub-step 3.
+// Per wave and step: 64 MFMA (2048 cycles), 32 ds_read_b128, 16 global_load_lds_dwordx4, one
+// s_waitcnt vmcnt(8) + s_barrier.  Issue order is pinned by hand as in gemm_core6.h.
+#pragma once
+#include "gemm_core6.h"
+
+#define G7_ROW_BYTES 128
+#define G7_UNIT_BYTES (256 * G7_ROW_BYTES)     // 32 KiB
+#define G7_UNITS 5
+#define G7_LDS_BYTES (G7_UNITS * G7_UNIT_BYTES)   // 160 KiB: the whole LDS
+
+// DMA sources of tile (m0, n0): a wave-uniform 64-bit base per operand (the tile's first row, advanced by the
+// K offset in scalar registers) plus a 32-bit per-lane byte offset per instruction -- the saddr form of
+// global_load_lds, so the steady state spends no vector ALU on addresses.  Instruction i of this wave moves
+// tile rows (i*4 + wave)*8 .. +7: lane -> row (lane >> 3), physical chunk (lane & 7).  Rows past M / N are
+// clamped to the last valid row (their results are never stored).
+struct G7Src {
+  const char* a;        // A + m0 * lda   (wave-uniform)
+  const char* b;        // B + n0 * ldb
+  uint32_t oa[8], ob[8];
+};
+template <typename T>
+__device__ __forceinline__ void g7_point(G7Src& src, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
+                                         int64_t ldb, int64_t M, int64_t N, int64_t m0, int64_t n0, int wave, int lane) {
+  src.a = (const char*)(A + m0 * lda);
+  src.b = (const char*)(B + n0 * ldb);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = (i * 4 + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int64_t ra = r; if (m0 + ra > M - 1) ra = M - 1 - m0;
+    int64_t rb = r; if (n0 + rb > N - 1) rb = N - 1 - n0;
+    src.oa[i] = (uint32_t)(ra * lda * (int64_t)sizeof(T)) + c * 16;
+    src.ob[i] = (uint32_t)(rb * ldb * (int64_t)sizeof(T)) + c * 16;
+  }
+}
+
+// all eight DMA instructions of one operand unit (prologue only; the steady state spreads them)
+__device__ __forceinline__ void g7_fill(const char* base, const uint32_t (&off)[8], char* unit, int wave) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    __builtin_amdgcn_global_load_lds((gptr_t)(base + off[i]), (lptr_t)(unit + (i * 4 + wave) * 1024), 16, 0, 0);
+}
+
+// K steps 0 and 1 of a tile into units 0-3 (32 DMA instructions per wave).
+__device__ __forceinline__ void g7_begin(const G7Src& src, int nk, char* smem, int wave) {
+  g7_fill(src.a, src.oa, smem, wave);
+  g7_fill(src.b, src.ob, smem + G7_UNIT_BYTES, wave);
+  if (nk > 1) {
+    g7_fill(src.a + G7_ROW_BYTES, src.oa, smem + 2 * G7_UNIT_BYTES, wave);
+    g7_fill(src.b + G7_ROW_BYTES, src.ob, smem + 3 * G7_UNIT_BYTES, wave);
+  }
+}
+
+// The K loop of one tile whose steps 0 and 1 are in flight (g7_begin, nk >= 2).  acc as in gemm_core6.h:
+//   acc[mi][ni][r] = C[m0 + wm*128 + mi*32 + (lane&31)][n0 + wn*128 + ni*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)]
+// BPOS selects where sub-step 3 puts the eight B(t+2) DMA issues (A/B measurements): 0 = behind MFMAs 8-15,
+// 1 = behind the odd MFMAs 1,3,..,15 (sharing a gap with a fragment read in the first half).
+template <typename T, int BPOS = 0>
+__device__ inline void gemm_mainloop7_run(const G7Src& src, int nk, char* smem,
+                                          f32x16_t (&acc)[4][4], unsigned long long* tr = nullptr) {
+  typedef typename MmaOps<T>::frag_t frag_t;
+  static_assert(sizeof(T) == 2, "128-byte K steps: 16-bit operands only");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..3
+  const int wm = wave >> 1, wn = wave & 1;
+  const int key = (lane >> 1) & 7;           // == ((row >> 1) & 7) for row = 32*x + (lane & 31)
+  const int half = lane >> 5;
+  int slot[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) slot[kk] = (((kk << 1) | half) ^ key) << 4;
+  const int rowa = (wm * 128 + (lane & 31)) * G7_ROW_BYTES;
+  const int rowb = (wn * 128 + (lane & 31)) * G7_ROW_BYTES;
+
+  // steps 0 and 1 are in flight: step 0 has landed once only step 1's 16 instructions are outstanding
+  if (nk > 1) __builtin_amdgcn_s_waitcnt(0x4070);      // vmcnt(16) lgkmcnt(0)
+  else __builtin_amdgcn_s_waitcnt(0x0070);             // vmcnt(0)
+  __builtin_amdgcn_s_barrier();
+
+  int u_ac = 0, u_bc = G7_UNIT_BYTES, u_an = 2 * G7_UNIT_BYTES, u_bn = 3 * G7_UNIT_BYTES, u_sp = 4 * G7_UNIT_BYTES;
+  frag_t a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a0[i] = *(const frag_t*)(smem + u_ac + rowa + i * 32 * G7_ROW_BYTES + slot[0]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b0[i] = *(const frag_t*)(smem + u_bc + rowb + i * 32 * G7_ROW_BYTES + slot[0]);
+
+#define G7_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define G7_DMA(P, I, UNIT)                                                                               \
+  __builtin_amdgcn_global_load_lds((gptr_t)(src.P + (size_t)(t + 2) * G7_ROW_BYTES + src.o##P[I]),        \
+                                   (lptr_t)(smem + (UNIT) + ((I) * 4 + wave) * 1024), 16, 0, 0)
+  // one k sub-step: 16 MFMAs from (AF, BF); the first eight each cover one fragment read into (AN, BN) from
+  // (UA, UB) chunk SLOT; DMA issues of operand P into UNIT per DPOS: 1 = MFMAs 8,10,12,14 -> instructions
+  // DBASE..DBASE+3;  2 = MFMAs 8..15 -> 0..7;  3 = MFMAs 1,3,..,15 -> 0..7
+#define G7_SUB(AF, BF, AN, BN, UA, UB, SLOT, DO_READ, DPOS, P, UNIT, DBASE)                              \
+  _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                       \
+    MmaOps<T>::mma(BF[q & 3], AF[q >> 2], acc[q >> 2][q & 3]);                                           \
+    if (q < 8 && (DO_READ)) {                                                                            \
+      if (q < 4) AN[q] = *(const frag_t*)(smem + (UA) + rowa + q * 32 * G7_ROW_BYTES + (SLOT));          \
+      else BN[q - 4] = *(const frag_t*)(smem + (UB) + rowb + (q - 4) * 32 * G7_ROW_BYTES + (SLOT));      \
+    }                                                                                                    \
+    if ((DPOS) == 1 && q >= 8 && !(q & 1)) G7_DMA(P, (DBASE) + ((q - 8) >> 1), UNIT);                    \
+    if ((DPOS) == 2 && q >= 8) G7_DMA(P, q - 8, UNIT);                                                   \
+    if ((DPOS) == 3 && (q & 1)) G7_DMA(P, q >> 1, UNIT);                                                 \
+    G7_FENCE();                                                                                          \
+  }
+#define G7_STEP(ISSUE, NEXT)                                                                             \
+  do {                                                                                                   \
+    if (tr && tid == 0 && t < 12) tr[3 + t] = clock64();                                                 \
+    G7_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[1], true, (ISSUE) ? 1 : 0, a, u_sp, 0)                      \
+    G7_SUB(a1, b1, a0, b0, u_ac, u_bc, slot[2], true, (ISSUE) ? 1 : 0, a, u_sp, 4)                      \
+    G7_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[3], true, 0, a, u_sp, 0)                                    \
+    /* step t+1 has landed (only A(t+2) may be outstanding) and my reads of A(t), B(t) are done */       \
+    if (ISSUE) __builtin_amdgcn_s_waitcnt(0x0078); else __builtin_amdgcn_s_waitcnt(0x0070);             \
+    __builtin_amdgcn_s_barrier();                                                                        \
+    G7_FENCE();                                                                                          \
+    G7_SUB(a1, b1, a0, b0, u_an, u_bn, slot[0], NEXT, (ISSUE) ? (BPOS ? 3 : 2) : 0, b, u_ac, 0)         \
+    { const int o_ac = u_ac, o_bc = u_bc; u_ac = u_an; u_bc = u_bn; u_an = u_sp; u_bn = o_ac; u_sp = o_bc; } \
+  } while (0)
+
+  int t = 0;
+  for (; t + 2 < nk; ++t) G7_STEP(true, true);
+  if (t + 1 < nk) { G7_STEP(false, true); ++t; }
+  G7_STEP(false, false);
+#undef G7_STEP
+#undef G7_SUB
+#undef G7_DMA
+#undef G7_FENCE
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                             // everyone is done with the ring
+}

@@ -9,10 +9,10 @@ from .ops import contrastive_loss
 
 class SimpleContrastiveLoss:
     def __call__(self, x: Tensor, y: Tensor, target: Tensor = None, reduction: str = "mean"):
-        if target is not None or reduction != "mean":
-            raise NotImplementedError("only the default in-batch target with mean reduction has a HIP path")
+        """loss.py:9-15: `F.cross_entropy(x @ y.T, target, reduction=reduction)` with the in-batch target
+        arange(0, Q * (P // Q), P // Q) when none is given."""
         n_psg = y.size(0) // x.size(0)
-        loss, _ = contrastive_loss(x, y, n_psg, 1.0, x, 0, y, 0)
+        loss, _ = contrastive_loss(x, y, n_psg, 1.0, x, 0, y, 0, target=target, reduction=reduction)
         return loss
 
 
@@ -25,12 +25,13 @@ class DistributedContrastiveLoss(SimpleContrastiveLoss):
         self.scale_loss = scale_loss
 
     def __call__(self, x: Tensor, y: Tensor, **kwargs):
-        if kwargs.get("target") is not None or kwargs.get("reduction", "mean") != "mean":
-            raise NotImplementedError("only the default in-batch target with mean reduction has a HIP path")
+        """loss.py:27-31: gather x and y over the ranks (own slot keeps its autograd), the simple loss on the
+        gathered batch with the caller's `target=` / `reduction=`, times world_size when scale_loss."""
         gx, gy = self.gather_tensor(x), self.gather_tensor(y)
         n_psg = gy.size(0) // gx.size(0)
         scale = float(self.word_size) if self.scale_loss else 1.0
-        loss, _ = contrastive_loss(gx, gy, n_psg, scale, x, self.rank * x.size(0), y, self.rank * y.size(0))
+        loss, _ = contrastive_loss(gx, gy, n_psg, scale, x, self.rank * x.size(0), y, self.rank * y.size(0),
+                                   target=kwargs.get("target"), reduction=kwargs.get("reduction", "mean"))
         return loss
 
     def gather_tensor(self, t):

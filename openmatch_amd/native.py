@@ -61,6 +61,7 @@ _SIGNATURES = {
     "om_abi_version": (c_int, []),
     "om_device_count": (c_int, []),
     "om_debug_gemm_trace": (None, [c_void_p]),
+    "om_debug_gemm_gen": (None, [c_int]),
     "om_kernel_timing_enable": (c_int, [c_int]),
     "om_kernel_timing_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(c_int64), C.POINTER(C.c_double)]),
     "om_gemm_nt": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64,
@@ -89,6 +90,9 @@ _SIGNATURES = {
     "om_contrastive_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                        c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p]),
+    "om_contrastive_fwd_bwd_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
+                                          c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None
@@ -158,7 +162,8 @@ class Workspace:
     def get(cls, device, nbytes, tag="default"):
         key = (str(device), tag)
         buf = cls._pool.get(key)
-        if buf is None or buf.numel() < nbytes:
+        # the caller gets data_ptr() + off with off up to 255: a buffer is only reused when nbytes fit BEHIND that offset
+        if buf is None or buf.numel() - ((-buf.data_ptr()) % 256) < nbytes:
             buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
             cls._pool[key] = buf
         off = (-buf.data_ptr()) % 256

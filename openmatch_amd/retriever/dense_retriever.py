@@ -135,29 +135,32 @@ class Retriever:
         self._sharded = False
 
     def _init_sharded_index(self):
-        """Multi-rank path: every rank indexes only its own rows (resident tensor if this process
-        encoded them, else the partition files rank, rank+W, ...).  Collective."""
+        """Multi-rank path: every rank indexes only its own rows (the resident tensor if this process encoded them,
+        else a contiguous slice of the partition files in rank order -- counts need not divide evenly, a rank may
+        end up with no rows).  Collective."""
         W, r = self.args.world_size, self.args.process_index
         if self._resident_docs is not None:
             encoded, lookup = self._resident_docs
-            parts = [(encoded, lookup)]
+            parts = [(encoded, lookup)] if len(lookup) else []
         else:
             files = _corpus_partitions(self.args.output_dir)
-            if len(files) % W != 0:
-                raise ValueError(f"{len(files)} corpus partitions cannot be split evenly over {W} ranks")
+            lo, hi = (len(files) * r) // W, (len(files) * (r + 1)) // W
             parts = []
-            for path in files[r * (len(files) // W):(r + 1) * (len(files) // W)]:
+            for path in files[lo:hi]:
                 with open(path, "rb") as f:
                     parts.append(pickle.load(f))
         local_lookup = []
-        for i, (encoded, lookup) in enumerate(parts):
-            if i == 0:
-                self._initialize_faiss_index(encoded.shape[1])
-            self.index.add(encoded)
+        for encoded, lookup in parts:
             local_lookup.extend(lookup)
-        sizes = [None] * W
-        dist.all_gather_object(sizes, len(local_lookup))
-        self._shard_offset = int(sum(sizes[:r]))
+        dims = [None] * W
+        dist.all_gather_object(dims, (len(local_lookup), int(parts[0][0].shape[1]) if parts else 0))
+        dim = max(d for _, d in dims)
+        if dim == 0:
+            raise ValueError("no document embeddings on any rank")
+        self._initialize_faiss_index(dim)              # an empty shard still takes part in the collectives
+        for encoded, _ in parts:
+            self.index.add(encoded)
+        self._shard_offset = int(sum(n for n, _ in dims[:r]))
         gathered = [None] * W if r == 0 else None
         dist.gather_object(local_lookup, gathered, dst=0)
         self.doc_lookup = [x for part in gathered for x in part] if r == 0 else []

@@ -176,11 +176,13 @@ class DRTrainer:
     def _num_steps(self, loader):
         a = self.args
         accum = max(1, getattr(a, "gradient_accumulation_steps", 1))
-        if getattr(a, "max_steps", -1) and a.max_steps > 0:
-            return a.max_steps, None
-        try:
-            per_epoch = max(1, len(loader) // accum)
+        try:                                  # as HF Trainer: the epoch length is known whenever the loader has one,
+            per_epoch = max(1, len(loader) // accum)      # max_steps or not (it feeds the fractional state.epoch)
         except TypeError:
+            per_epoch = None
+        if getattr(a, "max_steps", -1) and a.max_steps > 0:
+            return a.max_steps, per_epoch
+        if per_epoch is None:
             raise ValueError("args.max_steps must be set for a dataset without a length")
         return int(math.ceil(a.num_train_epochs * per_epoch)), per_epoch
 
@@ -198,12 +200,20 @@ class DRTrainer:
         save_every = int(getattr(a, "save_steps", 0) or 0)
         running, micro, epoch = 0.0, 0, 0
         self.optimizer.zero_grad(set_to_none=True)
+        if resume_from_checkpoint:
+            logger.warning("resume_from_checkpoint=%r is not supported by this trainer (optimizer state is not "
+                           "checkpointed): training starts from the model's current weights", resume_from_checkpoint)
+        if self.eval_dataset is not None or str(getattr(a, "evaluation_strategy", getattr(a, "eval_strategy", "no"))).lower() not in ("no", "intervalstrategy.no"):
+            logger.warning("evaluation during training is not implemented: eval_dataset / evaluation_strategy are ignored")
         while self.state.global_step < total:
+            # the datasets read int(trainer.state.epoch) when their iterator is created (train_dataset.py:115-119):
+            # the epoch counter must already say `epoch` here, as HF Trainer's does, not after the first step
+            self.state.epoch = float(epoch)
             if hasattr(self.train_dataset, "set_epoch"):
                 self.train_dataset.set_epoch(epoch)
             if hasattr(getattr(loader, "sampler", None), "set_epoch"):
                 loader.sampler.set_epoch(epoch)
-            stepped = False
+            stepped, in_epoch = False, 0
             for batch in loader:
                 running += float(self.training_step(self.model, batch))
                 micro += 1
@@ -219,7 +229,9 @@ class DRTrainer:
                 self.optimizer.zero_grad(set_to_none=True)
                 self.state.global_step += 1
                 stepped = True
-                self.state.epoch = (self.state.global_step / per_epoch) if per_epoch else float(epoch)
+                in_epoch += 1
+                if per_epoch:                 # HF: epoch + (steps done in this epoch) / (steps per epoch)
+                    self.state.epoch = epoch + min(1.0, in_epoch / per_epoch)
                 if self.state.global_step % log_every == 0:
                     entry = {"loss": running / (log_every * accum), "learning_rate": self.lr_scheduler.get_last_lr()[0],
                              "epoch": self.state.epoch, "step": self.state.global_step}

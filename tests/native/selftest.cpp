@@ -305,6 +305,39 @@ static void bench_search(int mode, int64_t N, int Q, int d, int k) {
   hipFree(dP); hipFree(dQ); hipFree(dPb); hipFree(dstats); hipFree(ws); hipFree(dD); hipFree(dI);
 }
 
+// per-block phase timelines of one GEMM launch (shader clocks); `warm` launches first (200: sustained clocks)
+static void run_trace(int64_t N, int64_t K, int64_t M, int64_t ld, int warm, bool dump_blocks) {
+    char* A = dalloc<char>(M * K * 2); char* B = dalloc<char>(N * K * 2); char* C = dalloc<char>(M * N * 2);
+    { auto t = to_bf16(randn(1 << 22)); for (size_t o = 0; o < (size_t)M * K; o += t.size()) CK(hipMemcpy(A + o * 2, t.data(), std::min(t.size(), (size_t)M * K - o) * 2, hipMemcpyHostToDevice)); auto tb = to_bf16(randn((size_t)N * K, 0.05f)); CK(hipMemcpy(B, tb.data(), tb.size() * 2, hipMemcpyHostToDevice)); }
+    const size_t nblk = 8192; unsigned long long* tr = dalloc<unsigned long long>(nblk * 32);
+    for (int i = 0; i < warm; ++i) OMCK(om_gemm_nt(OM_BF16, A, ld, B, ld, OM_BF16, C, N, M, N, K, nullptr, nullptr, 0, 0, nullptr));
+    CK(hipMemset(tr, 0, nblk * 32 * 8)); om_debug_gemm_trace(tr);
+    OMCK(om_gemm_nt(OM_BF16, A, ld, B, ld, OM_BF16, C, N, M, N, K, nullptr, nullptr, 0, 0, nullptr));
+    CK(hipDeviceSynchronize()); om_debug_gemm_trace(nullptr);
+    auto h = download(tr, nblk * 32);
+    unsigned long long t0 = ~0ull; size_t used = 0;
+    for (size_t b = 0; b < nblk; ++b) if (h[b * 32]) { t0 = std::min(t0, h[b * 32]); used = b + 1; }
+    printf("trace M=%ld N=%ld K=%ld ld=%ld blocks=%zu (cycles since first block start)\n", (long)M, (long)N, (long)K, (long)ld, used);
+    {   // averages over all blocks: prologue [1]->[3], K loop [3]->[15] (ideal = K * 32 MFMA cycles per wave), epilogue [15]->[28]
+      double pro = 0, loop = 0, epi = 0, tot = 0; size_t n = 0;
+      for (size_t b = 0; b < used; ++b) if (h[b * 32] && h[b * 32 + 28] && h[b * 32 + 15] && h[b * 32 + 3]) {
+        pro += (double)(h[b * 32 + 3] - h[b * 32 + 1]); loop += (double)(h[b * 32 + 15] - h[b * 32 + 3]);
+        epi += (double)(h[b * 32 + 28] - h[b * 32 + 15]); tot += (double)(h[b * 32 + 28] - h[b * 32]); ++n;
+      }
+      if (n) printf("avg over %zu blocks: prologue %.0f  K loop %.0f (MFMA time %ld, x%.3f)  epilogue %.0f  whole tile %.0f (memtime ticks)\n", n, pro / n, loop / n, (long)(K * 32), loop / n / (K * 32.0), epi / n, tot / n);
+      // effective shader clock: s_memtime ticks against the constant 100 MHz s_memrealtime counter, first start -> last end
+      unsigned long long c0 = ~0ull, c1 = 0, w0 = ~0ull, w1 = 0;
+      for (size_t b = 0; b < used; ++b) if (h[b * 32] && h[b * 32 + 28]) { c0 = std::min(c0, h[b * 32]); c1 = std::max(c1, h[b * 32 + 28]); w0 = std::min(w0, h[b * 32 + 30]); w1 = std::max(w1, h[b * 32 + 31]); }
+      if (w1 > w0) printf("kernel span: %llu shader ticks in %.1f us (100 MHz wall counter) -> %.3f GHz effective shader clock; tiles per CU %.2f\n", c1 - c0, (w1 - w0) / 100.0, (double)(c1 - c0) / ((w1 - w0) * 10.0), used / 256.0);
+    }
+    if (dump_blocks) for (size_t b = 0; b < used; b += std::max<size_t>(1, used / 8)) {
+      printf("blk %5zu:", b);
+      for (int i = 0; i < 30; ++i) if (h[b * 32 + i] && i != 29) printf(" [%d]%llu", i, h[b * 32 + i] - t0);
+      printf("\n");
+    }
+    hipFree(A); hipFree(B); hipFree(C); hipFree(tr);
+}
+
 int main(int argc, char** argv) {
   std::string what = argc > 1 ? argv[1] : "quick";
   int ndev = om_device_count();
@@ -313,7 +346,7 @@ int main(int argc, char** argv) {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs=%d  clock=%d MHz  mem=%.1f GB  LDS/block=%zu\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000, prop.totalGlobalMem / 1e9, prop.sharedMemPerBlock);
 
-  if (what != "bench" && what != "prof" && what != "trace" && what != "shapes" && what != "layer") {
+  if (what != "bench" && what != "prof" && what != "trace" && what != "shapes" && what != "layer" && what != "gen7") {
     // GEMM: aligned, ragged M/N tails, every epilogue, both dtypes
     test_gemm(OM_F32, 128, 128, 32, false, false, OM_ACT_NONE, OM_F32);
     test_gemm(OM_BF16, 128, 128, 64, false, false, OM_ACT_NONE, OM_F32);
@@ -354,39 +387,42 @@ int main(int argc, char** argv) {
     test_merge();
     test_contrastive();
   }
-  if (what == "trace") {    // per-block phase timelines of one GEMM launch (shader clocks)
+  if (what == "trace") {
     const int64_t N = argc > 2 ? atoi(argv[2]) : 768, K = argc > 3 ? atoi(argv[3]) : 768, M = argc > 4 ? atoll(argv[4]) : 32768;
     const int64_t ld = (argc > 5 && atoll(argv[5]) > 0) ? atoll(argv[5]) : K;   // leading dimension (0 / absent: K)
-    const int warm = argc > 6 ? atoi(argv[6]) : 3;       // launches before the traced one (200: sustained clocks)
-    char* A = dalloc<char>(M * K * 2); char* B = dalloc<char>(N * K * 2); char* C = dalloc<char>(M * N * 2);
-    { auto t = to_bf16(randn(1 << 22)); for (size_t o = 0; o < (size_t)M * K; o += t.size()) CK(hipMemcpy(A + o * 2, t.data(), std::min(t.size(), (size_t)M * K - o) * 2, hipMemcpyHostToDevice)); auto tb = to_bf16(randn((size_t)N * K, 0.05f)); CK(hipMemcpy(B, tb.data(), tb.size() * 2, hipMemcpyHostToDevice)); }
-    const size_t nblk = 8192; unsigned long long* tr = dalloc<unsigned long long>(nblk * 32);
-    for (int i = 0; i < warm; ++i) OMCK(om_gemm_nt(OM_BF16, A, ld, B, ld, OM_BF16, C, N, M, N, K, nullptr, nullptr, 0, 0, nullptr));
-    CK(hipMemset(tr, 0, nblk * 32 * 8)); om_debug_gemm_trace(tr);
-    OMCK(om_gemm_nt(OM_BF16, A, ld, B, ld, OM_BF16, C, N, M, N, K, nullptr, nullptr, 0, 0, nullptr));
-    CK(hipDeviceSynchronize()); om_debug_gemm_trace(nullptr);
-    auto h = download(tr, nblk * 32);
-    unsigned long long t0 = ~0ull; size_t used = 0;
-    for (size_t b = 0; b < nblk; ++b) if (h[b * 32]) { t0 = std::min(t0, h[b * 32]); used = b + 1; }
-    printf("trace M=%ld N=%ld K=%ld ld=%ld blocks=%zu (cycles since first block start)\n", (long)M, (long)N, (long)K, (long)ld, used);
-    {   // averages over all blocks: prologue [1]->[3], first 11 K steps [3]->[14], epilogue [15]->[28]
-      double pro = 0, step = 0, epi = 0, tot = 0; size_t n = 0;
-      for (size_t b = 0; b < used; ++b) if (h[b * 32] && h[b * 32 + 28] && h[b * 32 + 14]) {
-        pro += (double)(h[b * 32 + 3] - h[b * 32 + 1]); step += (double)(h[b * 32 + 14] - h[b * 32 + 3]) / 11.0;
-        epi += (double)(h[b * 32 + 28] - h[b * 32 + 15]); tot += (double)(h[b * 32 + 28] - h[b * 32]); ++n;
-      }
-      if (n) printf("avg over %zu blocks: prologue %.0f  K-step %.0f  epilogue %.0f  whole tile %.0f (memtime ticks)\n", n, pro / n, step / n, epi / n, tot / n);
-      // effective shader clock: s_memtime ticks against the constant 100 MHz s_memrealtime counter, first start -> last end
-      unsigned long long c0 = ~0ull, c1 = 0, w0 = ~0ull, w1 = 0;
-      for (size_t b = 0; b < used; ++b) if (h[b * 32] && h[b * 32 + 28]) { c0 = std::min(c0, h[b * 32]); c1 = std::max(c1, h[b * 32 + 28]); w0 = std::min(w0, h[b * 32 + 30]); w1 = std::max(w1, h[b * 32 + 31]); }
-      if (w1 > w0) printf("kernel span: %llu shader ticks in %.1f us (100 MHz wall counter) -> %.3f GHz effective shader clock; tiles per CU %.2f\n", c1 - c0, (w1 - w0) / 100.0, (double)(c1 - c0) / ((w1 - w0) * 10.0), used / 256.0);
-    }
-    for (size_t b = 0; b < used; b += std::max<size_t>(1, used / 8)) {
-      printf("blk %5zu:", b);
-      for (int i = 0; i < 30; ++i) if (h[b * 32 + i] && i != 29) printf(" [%d]%llu", i, h[b * 32 + i] - t0);
-      printf("\n");
-    }
+    run_trace(N, K, M, ld, argc > 6 ? atoi(argv[6]) : 3, true);
     return 0;
+  }
+  if (what == "gen7") {     // generation-7 K loop (128-byte K steps) against generation 6: correctness, layer shapes, tile traces
+    for (int gen : {7, 71}) {
+      om_debug_gemm_gen(gen);
+      printf("-- generation %d\n", gen);
+      test_gemm(OM_BF16, 512, 256, 128, false, false, OM_ACT_NONE, OM_BF16);       // two K steps
+      test_gemm(OM_BF16, 512, 256, 64, true, false, OM_ACT_NONE, OM_BF16);         // a single K step
+      test_gemm(OM_BF16, 1000, 520, 192, true, true, OM_ACT_NONE, OM_BF16);        // three steps, ragged M and N tiles
+      test_gemm(OM_BF16, 4099, 768, 768, true, false, OM_ACT_GELU_ERF, OM_BF16);
+      test_gemm(OM_BF16, 2048, 768, 3072, true, true, OM_ACT_NONE, OM_BF16);       // 24 steps through the unit rotation
+    }
+    const int64_t M = argc > 2 ? atoll(argv[2]) : 131072;
+    for (int rep = 0; rep < 2; ++rep)
+      for (int gen : {0, 7, 71}) {
+        om_debug_gemm_gen(gen);
+        printf("-- generation %d (0 = default selection, v6)\n", gen);
+        bench_gemm(OM_BF16, M, 2304, 768, 0);
+        bench_gemm(OM_BF16, M, 768, 768, 0);
+        bench_gemm(OM_BF16, M, 3072, 768, OM_ACT_GELU_ERF);
+        bench_gemm(OM_BF16, M, 768, 3072, 0);
+        bench_gemm(OM_BF16, 8192, 8192, 8192, 0);
+      }
+    for (int gen : {0, 7}) {
+      om_debug_gemm_gen(gen);
+      printf("-- traces, generation %d\n", gen);
+      run_trace(3072, 768, M, 768, 50, false);
+      run_trace(768, 3072, M, 3072, 50, false);
+    }
+    om_debug_gemm_gen(0);
+    printf("%s: %d failure(s)\n", g_fail ? "SELFTEST FAILED" : "SELFTEST PASSED", g_fail);
+    return g_fail ? 1 : 0;
   }
   if (what == "shapes") {   // the encoder's own GEMM shapes at a small token count, every dtype
     for (int dt : {OM_F32, OM_BF16}) {

@@ -162,6 +162,43 @@ def test_trainer_schedule_param_groups_and_sharded_loader():
     assert [c["query"]["input_ids"].shape[0] for c in chunks] == [2, 2, 1]
 
 
+def test_trainer_epoch_is_advanced_before_each_epoch_iterator(tmp_path):
+    """TrainDataset.__iter__ reads int(trainer.state.epoch) when an epoch's iterator is created
+    (reference train_dataset.py:115-119); HF Trainer has advanced it by then.  With max_steps set, the k-th
+    pass over the data must see epoch k (round-1 bug: passes 0 and 1 both saw epoch 0)."""
+    from openmatch.trainer import DRTrainer
+
+    class Data(torch.utils.data.IterableDataset):
+        def __init__(self):
+            self.trainer, self.seen = None, []
+
+        def __iter__(self):
+            self.seen.append(int(self.trainer.state.epoch))
+            for i in range(4):
+                yield i
+
+        def __len__(self):
+            return 4
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(1))
+
+        def forward(self, query=None, passage=None):
+            return NS(loss=(self.w * query.float().mean()).sum())
+
+    data = Data()
+    args = NS(device="cpu", per_device_train_batch_size=2, max_steps=5, learning_rate=1e-3, output_dir=str(tmp_path),
+              num_train_epochs=1, world_size=1, process_index=0, dataloader_pin_memory=False, logging_steps=1)
+    trainer = DRTrainer(model=Model(), args=args, train_dataset=data,
+                        data_collator=lambda items: (torch.tensor(items), torch.tensor(items)))
+    data.trainer = trainer
+    trainer.train()
+    assert data.seen == [0, 1, 2]                      # 2 optimizer steps per pass, 5 steps
+    assert [round(e["epoch"], 2) for e in trainer.state.log_history] == [0.5, 1.0, 1.5, 2.0, 2.5]
+
+
 def test_no_kernel_spills_to_scratch():
     """Accumulators in scratch cost 5-7x (seen once with a lambda capture): keep every kernel of the
     library at private_segment_fixed_size == 0, except the two L<=256 attention variants."""
