@@ -73,9 +73,16 @@ int om_device_count(void);
 /* Debug hook: when `buf` is non-NULL every 256-row-tile GEMM workgroup writes 32 shader-clock
  * stamps (start, prologue, per-K-step, epilogue) to buf[32*block]; NULL switches it off. */
 void om_debug_gemm_trace(unsigned long long* buf);
-/* Debug hook: 0 = default tile-generation selection; 7 / 71 force the generation-7 K loop (128-byte K steps,
- * gemm_core7.h) wherever it has a variant -- for A/B measurements inside one process. */
+/* Debug hook for A/B measurements inside one process: 0 = default tile-generation selection; 6 = never the persistent
+ * generation 7 (gemm_wide7.h); 70 = generation 7 with one tile per workgroup (no cross-tile prefetch). */
 void om_debug_gemm_gen(int gen);
+/* Run-time switches for A/B measurements and tests (initialised from the environment variable of the same
+ * name on first use): OM_OPT_ENCODER_FUSED_LN 1 = LayerNorm / RMSNorm fused across the encoder GEMMs where the
+ * shapes allow (default), 0 = one normalisation kernel per site; OM_OPT_ENCODER_DEBUG 1 = log the path taken. */
+#define OM_OPT_ENCODER_FUSED_LN 0
+#define OM_OPT_ENCODER_DEBUG 1
+#define OM_OPT_COUNT 2
+int om_debug_option(int opt, int value);
 int om_kernel_timing_enable(int enable);
 int om_kernel_timing_read(int kernel_class, double* total_ms, int64_t* launches, double* flops);
 

@@ -64,3 +64,54 @@ extern "C" int om_kernel_timing_read(int c, double* total_ms, int64_t* launches,
   st.used = 0; st.flops = 0;
   return 0;
 }
+
+// ---- run-time switches (A/B measurements, tests) ------------------------------------------------
+// Read once from the environment, overridable through om_debug_option(); the hot paths read an atomic.
+#include <atomic>
+#include <map>
+#include <tuple>
+namespace {
+std::atomic<int> g_opt[OM_OPT_COUNT];
+std::atomic<bool> g_opt_init{false};
+std::mutex g_opt_mu;
+void opt_init() {
+  std::lock_guard<std::mutex> lk(g_opt_mu);
+  if (g_opt_init.load()) return;
+  const char* e = getenv("OM_ENCODER_FUSED_LN");
+  g_opt[OM_OPT_ENCODER_FUSED_LN] = e ? atoi(e) : 1;
+  g_opt[OM_OPT_ENCODER_DEBUG] = getenv("OM_ENCODER_DEBUG") ? 1 : 0;
+  g_opt_init.store(true);
+}
+}  // namespace
+int om_option(int opt) {
+  if (!g_opt_init.load(std::memory_order_acquire)) opt_init();
+  return g_opt[opt].load(std::memory_order_relaxed);
+}
+extern "C" int om_debug_option(int opt, int value) {
+  if (opt < 0 || opt >= OM_OPT_COUNT) { om_set_error("om_debug_option: unknown option"); return 1; }
+  if (!g_opt_init.load(std::memory_order_acquire)) opt_init();
+  g_opt[opt].store(value);
+  return 0;
+}
+
+// T5 relative-position bucket table of a sequence length, resident on the device: built and uploaded ONCE per
+// (device, L, buckets, max distance) -- no pageable copy and no stream synchronisation on later forwards.
+int om_t5_lut_device(int L, int buckets, int max_dist, const int** out) {
+  static std::mutex mu;
+  static std::map<std::tuple<int, int, int, int>, int*> cache;
+  int dev = 0;
+  OM_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  auto key = std::make_tuple(dev, L, buckets, max_dist);
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    std::vector<int> lut(2 * L);
+    for (int rel = -(L - 1); rel <= L - 1; ++rel) lut[rel + (L - 1)] = om_t5_relative_bucket(rel, buckets, max_dist);
+    int* d = nullptr;
+    OM_HIP(hipMalloc(&d, (size_t)(2 * L) * sizeof(int)));
+    OM_HIP(hipMemcpy(d, lut.data(), (size_t)(2 * L - 1) * sizeof(int), hipMemcpyHostToDevice));
+    it = cache.emplace(key, d).first;
+  }
+  *out = it->second;
+  return 0;
+}

@@ -156,7 +156,7 @@ static int launch_attn(const void* qkv, void* ctx, const int64_t* mask, const fl
                        hipStream_t s) {
   constexpr int LP = KT * 32 + 4;
   const int lds = KT * 32 * AttnGeom<T>::ROWB + 64 * LP * (int)sizeof(T) + KT * 32 * 4;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     OM_HIP(hipFuncSetAttribute((const void*)attention_kernel<T, KT>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));

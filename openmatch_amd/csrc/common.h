@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/openmatch_hip.h"
@@ -102,6 +103,10 @@ __device__ inline unsigned xcd_remap(unsigned bid, unsigned nwg) {
   unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + bid / nx;
 }
+
+// ---- run-time switches and caches (abi.cpp) -------------------------------------
+int om_option(int opt);                                                   // OM_OPT_* of include/openmatch_hip.h
+int om_t5_lut_device(int L, int buckets, int max_dist, const int** out);  // device-resident bucket table, built once
 
 // ---- optional per-launch timing (abi.cpp) ------------------------------------
 bool om_timing_on();

@@ -125,11 +125,11 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
     // rows in the epilogue; the GEMM that adds LN(y) as a residual normalises it on the fly
     // (kernels.h: GemmEpilogue::ln_*, rln_*, stats_out).  23 of the 25 LayerNorm passes over
     // [M,H] disappear (the embedding LayerNorm and the last one stay).
-    const bool no_fuse = getenv("OM_ENCODER_FUSED_LN") && atoi(getenv("OM_ENCODER_FUSED_LN")) == 0;   // A/B switch
+    const bool no_fuse = om_option(OM_OPT_ENCODER_FUSED_LN) == 0;   // A/B switch (om_debug_option)
     const bool fuse = !no_fuse && c->act == OM_ACT_GELU_ERF && c->n_layers > 0 && H % 8 == 0 &&
                       omk_gemm_ln_fusable(dt, M, H, H) && omk_gemm_ln_fusable(dt, M, F, H) &&
                       omk_gemm_ln_fusable(dt, M, 3 * H, H) && omk_gemm_ln_fusable(dt, M, H, F);
-    if (getenv("OM_ENCODER_DEBUG")) fprintf(stderr, "om_encoder_forward: M=%ld fused_ln=%d\n", (long)M, (int)fuse);
+    if (om_option(OM_OPT_ENCODER_DEBUG)) fprintf(stderr, "om_encoder_forward: M=%ld fused_ln=%d\n", (long)M, (int)fuse);
     if (fuse) {
       const float inv_h = 1.0f / (float)H;
       OM_HIP(hipMemsetAsync(ws.stats1, 0, (size_t)2 * c->n_layers * M * 8, s));
@@ -196,24 +196,21 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
   } else {
     // relative-position bias, shared by all layers (table lives in block 0)
     if (!w->rel_bias || !w->final_ln_g) OM_FAIL("T5 needs rel_bias and final_ln_g");
-    std::vector<int> lut(2 * L);
-    for (int rel = -(int)(L - 1); rel <= (int)(L - 1); ++rel)
-      lut[rel + (L - 1)] = om_t5_relative_bucket(rel, c->rel_buckets, c->rel_max_dist);
-    OM_HIP(hipMemcpyAsync(ws.lut, lut.data(), (2 * L - 1) * sizeof(int), hipMemcpyHostToDevice, s));
-    OM_HIP(hipStreamSynchronize(s));  // `lut` is a pageable host temporary
-    RUN(omk_t5_bias(w->rel_bias, ws.lut, ws.posbias, (int)L, nh, s));
+    const int* lut = nullptr;                    // device-resident, cached per (L, buckets, max distance): no copy, no sync
+    RUN(om_t5_lut_device((int)L, c->rel_buckets, c->rel_max_dist, &lut));
+    RUN(omk_t5_bias(w->rel_bias, lut, ws.posbias, (int)L, nh, s));
     RUN(omk_embed(dt, input_ids, nullptr, w->word_emb, nullptr, nullptr, nullptr, nullptr, ws.x, M,
                   (int)L, H, c->vocab, 1, c->ln_eps, 0, s));
     // RMSNorm fused across the GEMMs (bf16, >= 512 tokens), the pre-norm counterpart of the BERT path
     // above: the GEMM that updates the residual stream x accumulates sum(x^2) per row; the GEMMs that
     // consume rms(x) * g read x itself against the folded weight W * g and scale their rows by
     // rsqrt(mean(x^2) + eps) in the epilogue.  Only the first and the final norm run as kernels.
-    const bool no_fuse_t5 = getenv("OM_ENCODER_FUSED_LN") && atoi(getenv("OM_ENCODER_FUSED_LN")) == 0;
+    const bool no_fuse_t5 = om_option(OM_OPT_ENCODER_FUSED_LN) == 0;
     // (gated feed-forward layers keep the kernels: two folded GEMMs per norm measured 1 % slower, tools/gtr_bench.py)
     const bool fuse_t5 = !no_fuse_t5 && c->n_layers > 0 && !Ls[0].ffn1g_w && H % 8 == 0 && omk_gemm_ln_fusable(dt, M, H, H) &&
                          omk_gemm_ln_fusable(dt, M, F, H) && omk_gemm_ln_fusable(dt, M, 3 * H, H) &&
                          omk_gemm_ln_fusable(dt, M, H, F);
-    if (getenv("OM_ENCODER_DEBUG")) fprintf(stderr, "om_encoder_forward (t5): M=%ld fused_norm=%d\n", (long)M, (int)fuse_t5);
+    if (om_option(OM_OPT_ENCODER_DEBUG)) fprintf(stderr, "om_encoder_forward (t5): M=%ld fused_norm=%d\n", (long)M, (int)fuse_t5);
     if (fuse_t5) {
       const float inv_h = 1.0f / (float)H;
       OM_HIP(hipMemsetAsync(ws.stats1, 0, (size_t)2 * c->n_layers * M * 8, s));

@@ -116,11 +116,11 @@ bool omk_gemm_ln_fusable(int dtype, int64_t M, int64_t N, int64_t K) {
 
 static unsigned long long* g_trace = nullptr;
 extern "C" void om_debug_gemm_trace(unsigned long long* buf) { g_trace = buf; }
-static int g_debug_gen = 0;     // 0: default selection; 7 / 71: generation 7 stage A (gemm_wide7.hip) where it has a variant
+static int g_debug_gen = 0;     // 0: default selection; 6: never generation 7; 70: generation 7 with one tile per workgroup (A/B)
 extern "C" void om_debug_gemm_gen(int gen) { g_debug_gen = gen; }
-bool omk_gemm_wide7a_has(int in_dtype, int out_dtype, int act, bool train, bool resid, int64_t K, const GemmEpilogue& ep);
-int omk_gemm_wide7a(int bpos, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
-                    int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s);
+bool omk_gemm_wide7_has(int act, bool resid, int lnf);
+int omk_gemm_wide7(bool persist, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                   int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s);
 
 int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int out_dtype,
              void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep_in,
@@ -162,8 +162,11 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
     const bool aligned = (((uintptr_t)ep.bias & 15) == 0) && (ep.ldp % 2 == 0) && (((uintptr_t)ep.pre_act & 3) == 0);
     if (!aligned && ln_fused) OM_FAIL("fused LayerNorm epilogue needs 16-byte aligned bias");
     if (!aligned) gen = 4;
-    else if ((g_debug_gen == 7 || g_debug_gen == 71) && omk_gemm_wide7a_has(in_dtype, out_dtype, act, train, resid, K, ep))
-      return omk_gemm_wide7a(g_debug_gen == 71, A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    else if (g_debug_gen != 6 && gemm_variant() == 0 && in_dtype == OM_BF16 && out_dtype == OM_BF16 && !train && M % 256 == 0 &&
+             N % 256 == 0 && (K * 2) % 128 == 0 && !(ep.ln_stats && (ep.rln_stats || ep.stats_out)) &&
+             !((ep.rln_stats || ep.stats_out) && !ep.stats_out) && (!resid || (ep.ldr * 2) % 128 == 0) &&
+             omk_gemm_wide7_has(act, resid, ep.ln_stats ? 1 : ((ep.rln_stats || ep.stats_out) ? 2 : 0)))
+      return omk_gemm_wide7(g_debug_gen != 70, A, lda, B, ldb, C, ldc, M, N, K, ep, s);
     else if (omk_gemm_wide6_b16_has(in_dtype, out_dtype, act, train, resid))
       return omk_gemm_wide6_b16(in_dtype, A, lda, B, ldb, out_dtype, C, ldc, M, N, K, ep, s);
     else if (omk_gemm_wide6_f32_has(in_dtype, out_dtype, act, train, resid))
@@ -197,7 +200,7 @@ int omk_gemm_splitk(int in_dtype, const void* A, int64_t lda, const void* B, int
   if (slices > nk / 4) slices = nk / 4 > 0 ? nk / 4 : 1;   // but at least 4 K steps per slice
   const int per = (nk + slices - 1) / slices;
   slices = (nk + per - 1) / per;
-  static bool attr_bf16 = false, attr_f32 = false;
+  static std::atomic<bool> attr_bf16{false}, attr_f32{false};
   const bool timing = om_timing_on();
   const int tclass = es == 2 ? OM_TIMING_GEMM_BF16 : OM_TIMING_GEMM_F32;
   if (timing) om_timing_begin(tclass, s);

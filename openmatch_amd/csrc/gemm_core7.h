@@ -38,6 +38,17 @@ struct G7Src {
   const char* b;        // B + n0 * ldb
   uint32_t oa[8], ob[8];
 };
+// offsets of a tile whose rows all exist (every tile when M and N are multiples of 256): the same for every tile
+template <typename T>
+__device__ __forceinline__ void g7_offsets(G7Src& src, int64_t lda, int64_t ldb, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = (i * 4 + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    src.oa[i] = (uint32_t)(r * lda * (int64_t)sizeof(T)) + c * 16;
+    src.ob[i] = (uint32_t)(r * ldb * (int64_t)sizeof(T)) + c * 16;
+  }
+}
 template <typename T>
 __device__ __forceinline__ void g7_point(G7Src& src, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
                                          int64_t ldb, int64_t M, int64_t N, int64_t m0, int64_t n0, int wave, int lane) {
@@ -54,11 +65,26 @@ __device__ __forceinline__ void g7_point(G7Src& src, const T* __restrict__ A, in
   }
 }
 
+// One LDS-DMA instruction in its scalar-base form: 64 lanes x 16 bytes from (wave-uniform base + 32-bit lane offset)
+// to LDS bytes [lds, lds + 1024).  Inline assembly because the builtin only selects the 64-bit-VGPR-address form
+// (a 64-bit vector add per instruction and a register pair per pointer).  hipcc does not count these in its own
+// s_waitcnt bookkeeping: every wait for them in this generation is written by hand.  M0 carries the LDS address
+// (nothing else in these kernels uses M0); `s_nop 4` covers both the M0 write -> DMA wait state and a base that the
+// compiler produced with v_readfirstlane (VALU-written SGPR -> VMEM address: 5 wait states).
+__device__ __forceinline__ void g7_dma(const char* base, uint32_t lane_off, uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(lane_off), "s"(base) : "memory");
+}
+// the same with a full 64-bit address per lane (unrelated sources in one instruction)
+__device__ __forceinline__ void g7_dma_v(const void* lane_ptr, uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(lane_ptr) : "memory");
+}
+__device__ __forceinline__ uint32_t g7_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lptr_t)p; }
+
 // all eight DMA instructions of one operand unit (prologue only; the steady state spreads them)
 __device__ __forceinline__ void g7_fill(const char* base, const uint32_t (&off)[8], char* unit, int wave) {
+  const uint32_t lds = g7_lds_addr(unit) + wave * 1024;
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
-    __builtin_amdgcn_global_load_lds((gptr_t)(base + off[i]), (lptr_t)(unit + (i * 4 + wave) * 1024), 16, 0, 0);
+  for (int i = 0; i < 8; ++i) g7_dma(base, off[i], lds + i * 4096);
 }
 
 // K steps 0 and 1 of a tile into units 0-3 (32 DMA instructions per wave).
@@ -77,7 +103,8 @@ __device__ __forceinline__ void g7_begin(const G7Src& src, int nk, char* smem, i
 // 1 = behind the odd MFMAs 1,3,..,15 (sharing a gap with a fragment read in the first half).
 template <typename T, int BPOS = 0>
 __device__ inline void gemm_mainloop7_run(const G7Src& src, int nk, char* smem,
-                                          f32x16_t (&acc)[4][4], unsigned long long* tr = nullptr) {
+                                          f32x16_t (&acc)[4][4], unsigned long long* tr = nullptr,
+                                          bool stores_pending = false) {
   typedef typename MmaOps<T>::frag_t frag_t;
   static_assert(sizeof(T) == 2, "128-byte K steps: 16-bit operands only");
   const int tid = threadIdx.x;
@@ -92,11 +119,17 @@ __device__ inline void gemm_mainloop7_run(const G7Src& src, int nk, char* smem,
   const int rowa = (wm * 128 + (lane & 31)) * G7_ROW_BYTES;
   const int rowb = (wn * 128 + (lane & 31)) * G7_ROW_BYTES;
 
-  // steps 0 and 1 are in flight: step 0 has landed once only step 1's 16 instructions are outstanding
-  if (nk > 1) __builtin_amdgcn_s_waitcnt(0x4070);      // vmcnt(16) lgkmcnt(0)
-  else __builtin_amdgcn_s_waitcnt(0x0070);             // vmcnt(0)
+  // steps 0 and 1 are in flight: step 0 has landed once only step 1's 16 instructions are outstanding -- plus, in the
+  // persistent kernel, the 32 output stores of the previous tile's epilogue, issued between the two (vmcnt retires in
+  // order; the step-0 fetch is OLDER than those stores, so it must not wait for their acknowledgement)
+  if (stores_pending) { if (nk > 1) __builtin_amdgcn_s_waitcnt(0xC070); else __builtin_amdgcn_s_waitcnt(0x8070); }   // vmcnt(48) / vmcnt(32)
+  else if (nk > 1) __builtin_amdgcn_s_waitcnt(0x4070);      // vmcnt(16) lgkmcnt(0)
+  else __builtin_amdgcn_s_waitcnt(0x0070);                  // vmcnt(0)
   __builtin_amdgcn_s_barrier();
 
+  const uint32_t lds0 = g7_lds_addr(smem);
+  const char* ka = src.a + 2 * G7_ROW_BYTES;      // K offset of step t + 2 (scalar registers)
+  const char* kb = src.b + 2 * G7_ROW_BYTES;
   int u_ac = 0, u_bc = G7_UNIT_BYTES, u_an = 2 * G7_UNIT_BYTES, u_bn = 3 * G7_UNIT_BYTES, u_sp = 4 * G7_UNIT_BYTES;
   frag_t a0[4], b0[4], a1[4], b1[4];
 #pragma unroll
@@ -105,9 +138,7 @@ __device__ inline void gemm_mainloop7_run(const G7Src& src, int nk, char* smem,
   for (int i = 0; i < 4; ++i) b0[i] = *(const frag_t*)(smem + u_bc + rowb + i * 32 * G7_ROW_BYTES + slot[0]);
 
 #define G7_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define G7_DMA(P, I, UNIT)                                                                               \
-  __builtin_amdgcn_global_load_lds((gptr_t)(src.P + (size_t)(t + 2) * G7_ROW_BYTES + src.o##P[I]),        \
-                                   (lptr_t)(smem + (UNIT) + ((I) * 4 + wave) * 1024), 16, 0, 0)
+#define G7_DMA(P, I, UNIT) g7_dma(k##P, src.o##P[I], lds0 + (UNIT) + ((I) * 4 + wave) * 1024)
   // one k sub-step: 16 MFMAs from (AF, BF); the first eight each cover one fragment read into (AN, BN) from
   // (UA, UB) chunk SLOT; DMA issues of operand P into UNIT per DPOS: 1 = MFMAs 8,10,12,14 -> instructions
   // DBASE..DBASE+3;  2 = MFMAs 8..15 -> 0..7;  3 = MFMAs 1,3,..,15 -> 0..7
@@ -135,6 +166,7 @@ __device__ inline void gemm_mainloop7_run(const G7Src& src, int nk, char* smem,
     G7_FENCE();                                                                                          \
     G7_SUB(a1, b1, a0, b0, u_an, u_bn, slot[0], NEXT, (ISSUE) ? (BPOS ? 3 : 2) : 0, b, u_ac, 0)         \
     { const int o_ac = u_ac, o_bc = u_bc; u_ac = u_an; u_bc = u_bn; u_an = u_sp; u_bn = o_ac; u_sp = o_bc; } \
+    ka += G7_ROW_BYTES; kb += G7_ROW_BYTES;                                                              \
   } while (0)
 
   int t = 0;

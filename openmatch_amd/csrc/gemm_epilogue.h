@@ -210,7 +210,7 @@ __device__ __forceinline__ void store_direct(const f32x16_t a00, const f32x16_t 
                   int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {             \
     const int64_t nwg = ((M + BMV - 1) / BMV) * ((N + BNV - 1) / BNV);                                  \
     if (nwg > 0x7fffffffLL) OM_FAIL("grid too large");                                                  \
-    static bool attr_set = false;                                                                       \
+    static std::atomic<bool> attr_set{false};                                                                       \
     if (!attr_set) {                                                                                    \
       OM_HIP(hipFuncSetAttribute((const void*)KERNEL<T, OutT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
       attr_set = true;                                                                                  \

@@ -117,7 +117,7 @@ static int launch6(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   if (nwg > 0x7fffffffLL) OM_FAIL("grid too large");
   // 16-bit kernels with a residual keep three residual patches per wave in LDS next to the staging
   constexpr int lds_bytes = (RESID && sizeof(OutT) == 2 && G6E_RES_LDS_BYTES > G6_LDS_BYTES) ? G6E_RES_LDS_BYTES : G6_LDS_BYTES;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel6<T, OutT, ACT, TRAIN, RESID, LNF>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));

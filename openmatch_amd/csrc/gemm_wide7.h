@@ -1,0 +1,359 @@
+// Generation 7 of om_gemm_nt for 16-bit inputs and outputs (bf16 inference epilogues): the K loop of
+// gemm_core7.h inside a PERSISTENT kernel -- one workgroup per CU walks 256 x 256 tiles, and the first K
+// step of the next tile (64 KiB of operands, the ~5 k-cycle cold start of every tile in generation 6)
+// is fetched while the current tile's epilogue runs.
+//
+// Why this works now and did not in round 1 (gemm_wide6.h, "persistent form ... dropped twice"): vmcnt
+// retires in order, loads and stores alike.  The next tile's fetch is issued BEFORE the epilogue's
+// stores and every later wait is an exact count of the younger operations ("32 stores + 16 DMA may
+// still be outstanding"), so nothing ever waits for a store acknowledgement.  Exact counts need a
+// fixed instruction stream: this kernel only takes problems made of whole tiles (M, N multiples of
+// 256, K of 64 -- the encoder pads its token count) and issues every DMA unconditionally (a workgroup
+// without a next tile re-fetches its own).
+//
+// LDS (160 KiB, all dynamic; gemm_core7.h's five 32 KiB units U0..U4):
+//   K loop        U0-U4 rotate
+//   epilogue      U0, U1   step 0 of the next tile (in flight)
+//                 U2, U3   residual ring: 3 patches x 4 KiB per wave (48 KiB), then bf16 staging 4 KiB per wave
+//                 U4       [0, 8 KiB)   accumulator-init tables of the NEXT tile, 2 KiB per wave:
+//                                         s_n | b'_n (128 + 128 f32), LayerNorm statistics of the wave's 128 rows
+//                          [8, 16 KiB)  epilogue tables, 2 KiB per wave: gamma | beta, statistics of the residual rows
+//   A table of wave w occupies U4 + w KiB .. (first DMA instruction of the SAME wave in K step 0): another wave's
+//   step-0 DMA can only land there after the barrier that follows every wave's accumulator initialisation.
+// One patch = 32 rows x 64 columns (8 per wave tile): staged as packed bf16 (row = 128 B, 16-byte chunk XOR
+// (row & 7)), read back row-major, stored as whole 128-byte lines.
+#pragma once
+#include "gemm_core7.h"
+#include "gemm_epilogue6.h"
+
+#define G7E_RING_OFF (2 * G7_UNIT_BYTES)
+#define G7E_PATCH_BYTES 4096
+#define G7E_RES_DEPTH 3
+#define G7E_STAGE_OFF (G7E_RING_OFF + 4 * G7E_RES_DEPTH * G7E_PATCH_BYTES)
+#define G7_TAB_OFF (4 * G7_UNIT_BYTES)
+#define G7_ETAB_OFF (G7_TAB_OFF + 8192)
+
+#define G7_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+#define G7_FENCE_() __builtin_amdgcn_sched_barrier(0)
+
+// work id -> tile, XCD aware: the 32 workgroups of an XCD (block b runs on XCD b % 8) take 32 CONSECUTIVE tiles of the
+// grouped order (group_m row tiles sweeping the column tiles) in every round, so the panels they share stay in that L2.
+__device__ __forceinline__ bool g7_tile(int it, int64_t ntm, int64_t ntn, int group_m, int64_t& m0, int64_t& n0) {
+  const int64_t ntiles = ntm * ntn;
+  int64_t w;
+  if ((gridDim.x & 7) == 0) {
+    const int nslots = gridDim.x >> 3;
+    w = ((int64_t)it * 8 + (blockIdx.x & 7)) * nslots + (blockIdx.x >> 3);
+  } else {
+    w = (int64_t)it * gridDim.x + blockIdx.x;
+  }
+  if (w >= ntiles) return false;
+  const int64_t per_group = (int64_t)group_m * ntn;
+  const int64_t g = w / per_group;
+  const int64_t first_m = g * group_m;
+  const int64_t gsz = (ntm - first_m) < group_m ? (ntm - first_m) : group_m;
+  const int64_t in_g = w % per_group;
+  m0 = (first_m + in_g % gsz) * 256;
+  n0 = (in_g / gsz) * 256;
+  return true;
+}
+
+// one 1 KiB table by LDS-DMA: lanes 0-31 fetch 512 B from `lo`, lanes 32-63 from `hi` (16 bytes per lane)
+__device__ __forceinline__ void g7_table2(const float* lo, const float* hi, char* dst, int lane) {
+  g7_dma_v((lane < 32 ? lo : hi) + (lane & 31) * 4, g7_lds_addr(dst));
+}
+// 1 KiB of contiguous floats
+__device__ __forceinline__ void g7_table1(const float* src, char* dst, int lane) {
+  g7_dma((const char*)src, lane * 16, g7_lds_addr(dst));
+}
+
+// Accumulator-init tables of tile (mc, nc) for this wave (TI DMA instructions: 2 with LNF == 1, else 1).  Absent
+// vectors are fetched from a valid dummy and ignored by the reader.
+template <int LNF>
+__device__ __forceinline__ void g7_init_tables(const GemmEpilogue& ep, const void* dummy, char* smem, int64_t mc, int64_t nc,
+                                               int wave, int lane) {
+  char* tab = smem + G7_TAB_OFF + wave * 2048;
+  const float* d = (const float*)dummy;
+  const float* cs = (LNF == 1 && ep.ln_colsum) ? ep.ln_colsum + nc : d;
+  const float* bs = ep.bias ? ep.bias + nc : d;
+  g7_table2(cs, bs, tab, lane);
+  if (LNF == 1) g7_table1(ep.ln_stats + mc * 2, tab + 1024, lane);
+}
+
+template <typename T, int ACT, bool RESID, int LNF, bool PERSIST>
+__global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
+    const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, T* C, int64_t ldc,
+    int64_t M, int64_t N, int64_t K, GemmEpilogue ep, int group_m) {
+  typedef T OutT;
+  static_assert(sizeof(T) == 2, "16-bit in, 16-bit out");
+  static_assert(LNF != 2 || RESID, "the output-side LayerNorm variant adds a residual");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane0 = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t ntm = M / 256, ntn = N / 256;
+  const int nk = (int)((K * 2) / G7_ROW_BYTES);
+  const EpiScalars es(ep);
+  constexpr int R = RESID ? 4 : 0;             // DMA instructions per residual patch
+  constexpr int TI = LNF == 1 ? 2 : 1;         // ... of the next tile's init tables
+  constexpr int A2 = LNF == 2 ? 2 : 0;         // row-statistics atomics behind every second patch
+  constexpr int PF = 16;                       // ... of the next tile's first K step
+
+  int it = 0;
+  int64_t m0, n0;
+  if (!g7_tile(0, ntm, ntn, group_m, m0, n0)) return;
+  G7Src src;                                   // per-lane offsets once; only the two tile bases change
+  g7_offsets<T>(src, lda, ldb, wave, lane0);
+  src.a = (const char*)(A + m0 * lda);
+  src.b = (const char*)(B + n0 * ldb);
+  g7_init_tables<LNF>(ep, A, smem, m0 + wm * 128, n0 + wn * 128, wave, lane0);
+  g7_fill(src.a, src.oa, smem, wave);
+  g7_fill(src.b, src.ob, smem + G7_UNIT_BYTES, wave);
+  bool pending = false;                        // the previous epilogue's 32 stores may still be in flight
+
+  for (;;) {
+    const int64_t mc = m0 + wm * 128, nc = n0 + wn * 128;
+    unsigned long long* tr = nullptr;
+    if (ep.trace) {
+      const int64_t tile_id = (m0 / 256) * ntn + n0 / 256;
+      if (tile_id < 8192) tr = ep.trace + tile_id * 32;
+    }
+    if (tr && threadIdx.x == 0) { tr[0] = clock64(); tr[30] = wall_clock64(); }
+    // ---- tile start: K step 1 into U2, U3 (free once every wave has left the previous epilogue) --------------------
+    if (pending) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    if (nk > 1) {
+      g7_fill(src.a + G7_ROW_BYTES, src.oa, smem + 2 * G7_UNIT_BYTES, wave);
+      g7_fill(src.b + G7_ROW_BYTES, src.ob, smem + 3 * G7_UNIT_BYTES, wave);
+    }
+    // my tables (and K step 0) have landed: only K step 1 and the previous tile's stores are younger
+    if (pending) { if (nk > 1) G7_WAIT_VM(48); else G7_WAIT_VM(32); }
+    else { if (nk > 1) G7_WAIT_VM(16); else G7_WAIT_VM(0); }
+    if (tr && threadIdx.x == 0) tr[1] = clock64();
+    // ---- accumulators start at the bias, or at b'_n / rstd_m - mu_m s_n for a raw pre-LayerNorm A operand (gemm_wide6.h)
+    // (per-lane values of this section and of the epilogue derive from an OPAQUE copy of the lane id: otherwise the
+    // compiler hoists dozens of loop-invariant addresses out of the tile loop and spills them around the K loop)
+    f32x16_t acc[4][4];
+    float rs[4] = {1.f, 1.f, 1.f, 1.f};
+    {
+      int lane_i = lane0;
+      asm volatile("" : "+v"(lane_i));
+      const int l31 = lane_i & 31, half = lane_i >> 5;
+      const char* tab = smem + G7_TAB_OFF + wave * 2048;
+      const bool ln_in = LNF == 1 && ep.ln_stats != nullptr;
+      float mu[4] = {0.f, 0.f, 0.f, 0.f}, inv[4] = {1.f, 1.f, 1.f, 1.f};
+      if (ln_in) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const float2 st = *(const float2*)(tab + 1024 + (mi * 32 + l31) * 8);
+          mu[mi] = ep.ln_rms ? 0.f : st.x * ep.ln_inv_h;
+          const float var = fmaxf(st.y * ep.ln_inv_h - mu[mi] * mu[mi], 0.f) + ep.ln_eps;
+          rs[mi] = rsqrtf(var);
+          inv[mi] = sqrtf(var);
+        }
+      }
+      const bool has_cs = LNF == 1 && ep.ln_colsum != nullptr, has_b = ep.bias != nullptr;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4_t b4 = *(const f32x4_t*)(tab + 512 + (ni * 32 + 8 * j + 4 * half) * 4);
+          if (!has_b) b4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          if (ln_in) {
+            f32x4_t s4 = *(const f32x4_t*)(tab + (ni * 32 + 8 * j + 4 * half) * 4);
+            if (!has_cs) s4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[mi][ni][4 * j + e] = fmaf(-mu[mi], s4[e], b4[e] * inv[mi]);
+          } else {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[mi][ni][4 * j + e] = b4[e];
+          }
+          // a finished accumulator tile moves to its AGPRs now (otherwise all 256 initial values sit in VGPRs first)
+          if (j == 3) asm volatile("" : "+a"(acc[0][ni]), "+a"(acc[1][ni]), "+a"(acc[2][ni]), "+a"(acc[3][ni]));
+        }
+    }
+    gemm_mainloop7_run<T, 0>(src, nk, smem, acc, tr, pending);     // waits again (a no-op now), barrier, K loop, barrier
+    if (tr && threadIdx.x == 0) tr[15] = clock64();
+
+    // ---- next tile (a workgroup that has none re-fetches its own: the instruction stream stays fixed) -----------------
+    ++it;
+    int64_t m1 = m0, n1 = n0;
+    const bool has_next = PERSIST && g7_tile(it, ntm, ntn, group_m, m1, n1);
+    const char* const next_a = (const char*)(A + m1 * lda);
+    const char* const next_b = (const char*)(B + n1 * ldb);
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------------
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int l31 = lane & 31, half = lane >> 5;
+    size_t ldc2 = (size_t)ldc * sizeof(OutT), ldr2 = (size_t)ep.ldr * sizeof(OutT);
+    asm volatile("" : "+s"(ldc2), "+s"(ldr2));
+    const char* const rbase = RESID ? (const char*)((const OutT*)ep.resid + mc * ep.ldr + nc) : nullptr;   // wave-uniform
+    uint32_t roff[4];                                                    // row (lane >> 3) of an 8-row group, swizzled source chunk
+#pragma unroll
+    for (int k = 0; k < 4; ++k) roff[k] = (uint32_t)((lane >> 3) * ldr2) + (((lane & 7) ^ ((4 * k + (lane >> 4)) & 7)) << 4);
+    char* const ring = smem + G7E_RING_OFF + wave * (G7E_RES_DEPTH * G7E_PATCH_BYTES);
+    char* const stage = smem + G7E_STAGE_OFF + wave * G7E_PATCH_BYTES;
+    const char* const etab = smem + G7_ETAB_OFF + wave * 2048;
+    const bool res_ln = LNF == 2 && ep.rln_stats != nullptr;
+    // residual patch p = (mi, nh): 32 rows x 128 B, chunk position XOR ((row >> 1) & 7); 4 instructions of 8 rows
+#define G7E_RES_DMA(P_)                                                                                        \
+  do {                                                                                                         \
+    const uint32_t buf = g7_lds_addr(ring) + ((P_) % G7E_RES_DEPTH) * G7E_PATCH_BYTES;                         \
+    const char* const pbase = rbase + (size_t)(((P_) >> 1) * 32) * ldr2 + ((P_) & 1) * 128;                    \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) g7_dma(pbase + (size_t)(8 * k) * ldr2, roff[k], buf + k * 1024); \
+  } while (0)
+    if (LNF == 2) {        // gamma | beta of my 128 columns, statistics of my 128 residual rows (dummies when not normalised)
+      g7_table2(res_ln ? ep.rln_g + nc : (const float*)A, res_ln ? ep.rln_b + nc : (const float*)A, (char*)etab, lane);
+      g7_table1(res_ln ? ep.rln_stats + mc * 2 : (const float*)A, (char*)etab + 1024, lane);
+    }
+    if (RESID) { G7E_RES_DMA(0); G7E_RES_DMA(1); G7E_RES_DMA(2); }
+    g7_fill(next_a, src.oa, smem, wave);                                // K step 0 of the next tile: U0, U1
+    g7_fill(next_b, src.ob, smem + G7_UNIT_BYTES, wave);
+    g7_init_tables<LNF>(ep, A, smem, m1 + wm * 128, n1 + wn * 128, wave, lane);
+
+    G7_FENCE_();
+    float ra[4] = {1.f, 1.f, 1.f, 1.f}, rc[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x2_t ssum = {0.f, 0.f}, ssq = {0.f, 0.f};
+    const int skey = l31 & 7;
+    char* const st_wr = stage + l31 * 128 + 8 * half;
+    const char* const st_rd = stage + (lane >> 3) * 128;
+    char* const cbase = (char*)(C + mc * ldc + nc);                     // wave-uniform; the per-lane part is 32 bits
+    const uint32_t coff = (uint32_t)((lane >> 3) * ldc2) + (lane & 7) * 16;
+#define G7E_WRITE(P_)                                                                                          \
+  do {                                                                                                         \
+    constexpr int MI = (P_) >> 1, NH = (P_) & 1;                                                               \
+    /* the patch's two accumulator tiles stay in their AGPRs up to here: without the pin the compiler copies all   \
+       256 accumulators into VGPRs behind the K loop and spills everything that lives across the epilogue */      \
+    asm volatile("" : "+a"(acc[MI][NH * 2]), "+a"(acc[MI][NH * 2 + 1]));                                       \
+    const int64_t m = mc + MI * 32 + l31;                                                                      \
+    uint2 rpatch[2][4];                                                                                        \
+    if (RESID) {                                                                                               \
+      const char* buf = ring + ((P_) % G7E_RES_DEPTH) * G7E_PATCH_BYTES + l31 * 128 + 8 * half;                \
+      _Pragma("unroll") for (int nl = 0; nl < 2; ++nl)                                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                          \
+          rpatch[nl][j] = *(const uint2*)(buf + (((nl * 4 + j) ^ ((l31 >> 1) & 7)) << 4));                     \
+    }                                                                                                          \
+    _Pragma("unroll") for (int nl = 0; nl < 2; ++nl)                                                           \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                          \
+        const int ni = NH * 2 + nl;                                                                            \
+        const int64_t n = nc + ni * 32 + 8 * j + 4 * half;                                                     \
+        f32x2_t a_lo = {acc[MI][ni][4 * j], acc[MI][ni][4 * j + 1]}, a_hi = {acc[MI][ni][4 * j + 2], acc[MI][ni][4 * j + 3]}; \
+        if (LNF == 1) { a_lo *= rs[MI]; a_hi *= rs[MI]; }                                                      \
+        f32x2_t lo_ = epi_pair<ACT, false, OutT>(a_lo, m, n, M, N, ep, es);                                    \
+        f32x2_t hi_ = epi_pair<ACT, false, OutT>(a_hi, m, n + 2, M, N, ep, es);                                \
+        if (RESID) {                                                                                           \
+          const uint2 rr = rpatch[nl][j];                                                                      \
+          float r0 = bf16_to_f32((bf16_t)(rr.x & 0xffff)), r1 = bf16_to_f32((bf16_t)(rr.x >> 16));            \
+          float r2 = bf16_to_f32((bf16_t)(rr.y & 0xffff)), r3 = bf16_to_f32((bf16_t)(rr.y >> 16));            \
+          if (res_ln) {                                                                                        \
+            const f32x4_t g4 = *(const f32x4_t*)(etab + (ni * 32 + 8 * j + 4 * half) * 4);                     \
+            const f32x4_t b4 = *(const f32x4_t*)(etab + 512 + (ni * 32 + 8 * j + 4 * half) * 4);               \
+            r0 = fmaf(fmaf(r0, ra[MI], rc[MI]), g4[0], b4[0]); r1 = fmaf(fmaf(r1, ra[MI], rc[MI]), g4[1], b4[1]); \
+            r2 = fmaf(fmaf(r2, ra[MI], rc[MI]), g4[2], b4[2]); r3 = fmaf(fmaf(r3, ra[MI], rc[MI]), g4[3], b4[3]); \
+          }                                                                                                    \
+          if (es.mul) { lo_[0] *= r0; lo_[1] *= r1; hi_[0] *= r2; hi_[1] *= r3; }                              \
+          else {                                                                                               \
+            lo_[0] = epi_resid<ACT>(lo_[0], r0, false); lo_[1] = epi_resid<ACT>(lo_[1], r1, false);            \
+            hi_[0] = epi_resid<ACT>(hi_[0], r2, false); hi_[1] = epi_resid<ACT>(hi_[1], r3, false);            \
+          }                                                                                                    \
+        }                                                                                                      \
+        if (LNF == 2) {                                                                                        \
+          ssum += lo_ + hi_;                                                                                   \
+          ssq = __builtin_elementwise_fma(lo_, lo_, __builtin_elementwise_fma(hi_, hi_, ssq));                 \
+        }                                                                                                      \
+        *(uint2*)(st_wr + (((nl * 4 + j) ^ skey) << 4)) = make_uint2(pack_bf16x2(lo_[0], lo_[1]), pack_bf16x2(hi_[0], hi_[1])); \
+      }                                                                                                        \
+    if (LNF == 2 && NH == 1) {      /* both column halves of the row block done: one atomic pair per row */     \
+      float s1 = ssum[0] + ssum[1], s2 = ssq[0] + ssq[1];                                                      \
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);                                              \
+      if (half == 0) { atomicAdd(ep.stats_out + 2 * m, s1); atomicAdd(ep.stats_out + 2 * m + 1, s2); }        \
+      ssum = (f32x2_t){0.f, 0.f}; ssq = (f32x2_t){0.f, 0.f};                                                   \
+    }                                                                                                          \
+  } while (0)
+
+    // vmcnt retires in order: each wait names exactly the operations issued after the one it needs
+    if (RESID || LNF == 2) G7_WAIT_VM(2 * R + PF + TI);                 // residual patch 0 (and the epilogue tables)
+    if (res_ln) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const float2 st = *(const float2*)(etab + 1024 + (mi * 32 + l31) * 8);
+        const float mu = st.x * ep.ln_inv_h;
+        const float rstd = rsqrtf(fmaxf(st.y * ep.ln_inv_h - mu * mu, 0.f) + ep.ln_eps);
+        ra[mi] = rstd; rc[mi] = -mu * rstd;
+      }
+    }
+    if (tr && threadIdx.x == 0) tr[16] = clock64();
+    G7E_WRITE(0);
+    G7_FENCE_();
+#define G7E_RB(I4) (*(const uint4*)(st_rd + (I4) * 8 * 128 + (((lane & 7) ^ (((lane >> 3) + (I4) * 8) & 7)) << 4)))
+#define G7E_ST(PP, I4, V) *(uint4*)(cbase + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128 + coff) = V
+#define G7E_ITER(P_, YWAIT)                                                                                    \
+  do {                                                                                                         \
+    const uint4 stv0 = G7E_RB(0), stv1 = G7E_RB(1), stv2 = G7E_RB(2), stv3 = G7E_RB(3);                         \
+    G7_FENCE_();                                                                                               \
+    if ((P_) + 1 < 8) {                                                                                        \
+      if (RESID) {                                                                                             \
+        if ((P_) + 3 < 8) G7E_RES_DMA((P_) + 3);                                                               \
+        G7_WAIT_VM(YWAIT);                                                                                     \
+      }                                                                                                        \
+      G7E_WRITE((P_) + 1);                                                                                     \
+    }                                                                                                          \
+    G7_FENCE_();                                                                                               \
+    G7E_ST(P_, 0, stv0); G7E_ST(P_, 1, stv1); G7E_ST(P_, 2, stv2); G7E_ST(P_, 3, stv3);                                      \
+    G7_FENCE_();                                                                                               \
+  } while (0)
+    G7E_ITER(0, 2 * R + PF + TI);
+    G7E_ITER(1, 2 * R + PF + TI + A2 + 4);
+    G7E_ITER(2, 2 * R + 8 + A2);
+    G7E_ITER(3, 2 * R + 8 + A2);
+    G7E_ITER(4, 2 * R + 8 + A2);
+    G7E_ITER(5, R + 8 + A2);
+    G7E_ITER(6, 8 + A2);
+    G7E_ITER(7, 0);
+#undef G7E_ITER
+#undef G7E_RB
+#undef G7E_ST
+#undef G7E_WRITE
+#undef G7E_RES_DMA
+    if (tr && threadIdx.x == 0) { tr[28] = clock64(); tr[29] = blockIdx.x; tr[31] = wall_clock64(); }
+    if (!has_next) break;
+    src.a = next_a; src.b = next_b; m0 = m1; n0 = n1;
+    pending = true;
+  }
+  G7_WAIT_VM(0);      // the last (dummy) prefetch must not outlive the workgroup's LDS allocation
+}
+
+static int g7_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n = v;
+  }
+  return n;
+}
+
+template <typename T, int ACT, bool RESID, int LNF>
+static int launch7(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                   int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
+  const int64_t ntiles = (M / 256) * (N / 256);
+  int grid = g7_num_cus();
+  if (ntiles < grid) grid = (int)ntiles;
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set) {
+    OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel7<T, ACT, RESID, LNF, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
+    attr_set = true;
+  }
+  const bool timing = om_timing_on();
+  if (timing) om_timing_begin(OM_TIMING_GEMM_BF16, s);
+  hipLaunchKernelGGL((gemm_nt_kernel7<T, ACT, RESID, LNF, true>), dim3((unsigned)grid), dim3(G6_THREADS), G7_LDS_BYTES, s,
+                     (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, 8);
+  if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, 2.0 * (double)M * (double)N * (double)K);
+  OM_LAUNCH_CHECK();
+  return 0;
+}

@@ -337,7 +337,7 @@ extern "C" int om_topk_merge(const float* part_scores, const int64_t* part_ids, 
   if (n_queries <= 0 || k_out <= 0) return 0;
   if (W <= 0 || k_in <= 0) OM_FAIL("W and k_in must be positive");
   if ((int64_t)W * k_in > SORT_CAP) OM_FAIL("W*k_in exceeds the 8192-key merge capacity");
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     OM_HIP(hipFuncSetAttribute((const void*)merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                SORT_CAP * 8));
@@ -535,7 +535,7 @@ extern "C" int om_sim_topk(int mode, const float* queries, int64_t n_queries,
   sc.mode = mode; sc.q32 = queries; sc.idx32 = index_f32; sc.idx16 = (const f16_t*)index_f16;
   sc.nq = n_queries; sc.N = N; sc.d = d; sc.k = k; sc.s = s; sc.stats = stats;
 
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     OM_HIP(hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                SORT_CAP * 8 + 16));

@@ -118,10 +118,9 @@ inline uint64_t site_seed(uint64_t seed, int layer, int site) {
 int t5_bias_setup(const OmEncoderConfig* c, const OmEncoderWeights* w, const Dims& d, Ws& ws, hipStream_t s) {
   if (!w->rel_bias || !w->final_ln_g) OM_FAIL("T5 needs rel_bias and final_ln_g");
   const int L = (int)d.L;
-  std::vector<int> lut(2 * L);
-  for (int rel = -(L - 1); rel <= L - 1; ++rel) lut[rel + (L - 1)] = om_t5_relative_bucket(rel, c->rel_buckets, c->rel_max_dist);
-  OM_HIP(hipMemcpyAsync(ws.lut, lut.data(), (2 * L - 1) * sizeof(int), hipMemcpyHostToDevice, s));
-  OM_HIP(hipStreamSynchronize(s));      // `lut` is a pageable host temporary
+  const int* lut = nullptr;                      // device-resident, cached per (L, buckets, max distance)
+  if (om_t5_lut_device(L, c->rel_buckets, c->rel_max_dist, &lut)) return 1;
+  ws.lut = const_cast<int*>(lut);                // the backward reads it again (never written)
   return omk_t5_bias(w->rel_bias, ws.lut, ws.posbias, L, d.nh, s);
 }
 

@@ -607,7 +607,7 @@ static int launch_attn_bwd(const void* qkv, const void* dctx, void* dqkv, const 
                            uint64_t seed, const float* pos_bias, float* drel, hipStream_t s) {
   constexpr int LP = KT * 32 + 4;
   const int lds = 3 * 64 * LP * (int)sizeof(T) + 6 * KT * 32 * 4;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     OM_HIP(hipFuncSetAttribute((const void*)attention_bwd_kernel<T, KT>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));

@@ -62,6 +62,7 @@ _SIGNATURES = {
     "om_device_count": (c_int, []),
     "om_debug_gemm_trace": (None, [c_void_p]),
     "om_debug_gemm_gen": (None, [c_int]),
+    "om_debug_option": (c_int, [c_int, c_int]),
     "om_kernel_timing_enable": (c_int, [c_int]),
     "om_kernel_timing_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(c_int64), C.POINTER(C.c_double)]),
     "om_gemm_nt": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64,

@@ -393,30 +393,32 @@ int main(int argc, char** argv) {
     run_trace(N, K, M, ld, argc > 6 ? atoi(argv[6]) : 3, true);
     return 0;
   }
-  if (what == "gen7") {     // generation-7 K loop (128-byte K steps) against generation 6: correctness, layer shapes, tile traces
-    for (int gen : {7, 71}) {
+  if (what == "gen7") {     // generation 7 (persistent, 128-byte K steps) against generation 6: correctness, layer shapes, tile traces
+    for (int gen : {0, 70}) {
       om_debug_gemm_gen(gen);
-      printf("-- generation %d\n", gen);
-      test_gemm(OM_BF16, 512, 256, 128, false, false, OM_ACT_NONE, OM_BF16);       // two K steps
+      printf("-- generation 7%s\n", gen == 70 ? ", one tile per workgroup" : " (default selection)");
+      test_gemm(OM_BF16, 512, 256, 128, false, false, OM_ACT_NONE, OM_BF16);       // two K steps, two tiles
       test_gemm(OM_BF16, 512, 256, 64, true, false, OM_ACT_NONE, OM_BF16);         // a single K step
-      test_gemm(OM_BF16, 1000, 520, 192, true, true, OM_ACT_NONE, OM_BF16);        // three steps, ragged M and N tiles
-      test_gemm(OM_BF16, 4099, 768, 768, true, false, OM_ACT_GELU_ERF, OM_BF16);
+      test_gemm(OM_BF16, 1024, 512, 192, true, true, OM_ACT_NONE, OM_BF16);        // three steps, residual ring
+      test_gemm(OM_BF16, 4096, 768, 768, true, false, OM_ACT_GELU_ERF, OM_BF16);
       test_gemm(OM_BF16, 2048, 768, 3072, true, true, OM_ACT_NONE, OM_BF16);       // 24 steps through the unit rotation
+      test_gemm(OM_BF16, 70 * 256, 1024, 256, true, true, OM_ACT_NONE, OM_BF16);   // 280 tiles: more than one per workgroup
+      test_gemm(OM_BF16, 70 * 256, 768, 128, true, false, OM_ACT_RELU, OM_BF16);
     }
     const int64_t M = argc > 2 ? atoll(argv[2]) : 131072;
     for (int rep = 0; rep < 2; ++rep)
-      for (int gen : {0, 7, 71}) {
+      for (int gen : {6, 70, 0}) {
         om_debug_gemm_gen(gen);
-        printf("-- generation %d (0 = default selection, v6)\n", gen);
+        printf("-- %s\n", gen == 6 ? "generation 6" : (gen == 70 ? "generation 7, one tile per workgroup" : "generation 7 (persistent)"));
         bench_gemm(OM_BF16, M, 2304, 768, 0);
         bench_gemm(OM_BF16, M, 768, 768, 0);
         bench_gemm(OM_BF16, M, 3072, 768, OM_ACT_GELU_ERF);
         bench_gemm(OM_BF16, M, 768, 3072, 0);
         bench_gemm(OM_BF16, 8192, 8192, 8192, 0);
       }
-    for (int gen : {0, 7}) {
+    for (int gen : {6, 70, 0}) {
       om_debug_gemm_gen(gen);
-      printf("-- traces, generation %d\n", gen);
+      printf("-- traces, %s\n", gen == 6 ? "generation 6" : (gen == 70 ? "generation 7, one tile per workgroup" : "generation 7 (persistent)"));
       run_trace(3072, 768, M, 768, 50, false);
       run_trace(768, 3072, M, 3072, 50, false);
     }

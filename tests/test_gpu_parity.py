@@ -104,8 +104,18 @@ def test_encoder_matches_oracle_on_ragged_batches():
         assert np.abs(got.cpu().numpy() - ref.numpy()).max() < 1e-4, (B, L)
 
 
+def _encode_with_fused_ln(model, items, on):
+    """A/B switch of the encoder (include/openmatch_hip.h: om_debug_option(OM_OPT_ENCODER_FUSED_LN, .))."""
+    from openmatch_amd import native as N
+    N.check(N.lib().om_debug_option(0, int(on)))
+    try:
+        return model.encode_passage(items)
+    finally:
+        N.check(N.lib().om_debug_option(0, 1))
+
+
 @pytest.mark.parametrize("hidden,heads,ffn", [(256, 4, 512), (384, 6, 1536)])
-def test_fused_layernorm_path_matches_unfused_and_oracle(monkeypatch, hidden, heads, ffn):
+def test_fused_layernorm_path_matches_unfused_and_oracle(hidden, heads, ffn):
     """bf16 batches of >= 512 tokens take the path where LayerNorm is folded into the GEMMs around it
     (encoder.hip): same embeddings as the launch-per-LayerNorm path and as the f32 oracle, incl. a
     ragged batch, a non-multiple-of-256 row count and non-trivial LayerNorm affines."""
@@ -131,10 +141,8 @@ def test_fused_layernorm_path_matches_unfused_and_oracle(monkeypatch, hidden, he
         items = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
         dev_items = {k: v.to(DEV) for k, v in items.items()}
         _, ref = encoder_ref.encode(sd, cfg, "bert", items, "mean", None, True)
-        monkeypatch.setenv("OM_ENCODER_FUSED_LN", "1")
-        _, fused = model.encode_passage(dev_items)
-        monkeypatch.setenv("OM_ENCODER_FUSED_LN", "0")
-        _, plain = model.encode_passage(dev_items)
+        _, fused = _encode_with_fused_ln(model, dev_items, 1)
+        _, plain = _encode_with_fused_ln(model, dev_items, 0)
         fused, plain, ref = fused.float().cpu(), plain.float().cpu(), ref.float()
         cos = lambda a, b: torch.nn.functional.cosine_similarity(a, b, dim=1).min().item()
         assert cos(plain, ref) > 0.999, (B, L, cos(plain, ref))
@@ -144,7 +152,7 @@ def test_fused_layernorm_path_matches_unfused_and_oracle(monkeypatch, hidden, he
 
 
 @pytest.mark.parametrize("gated", [False, True])
-def test_fused_rmsnorm_path_matches_unfused_and_oracle(monkeypatch, gated):
+def test_fused_rmsnorm_path_matches_unfused_and_oracle(gated):
     """The T5 counterpart: RMSNorm folded into the GEMMs (bf16, >= 512 tokens), GTR-style tail."""
     from transformers import T5Config, T5EncoderModel
     from openmatch.modeling import DRModelForInference, LinearHead
@@ -169,10 +177,8 @@ def test_fused_rmsnorm_path_matches_unfused_and_oracle(monkeypatch, gated):
         items = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
         dev_items = {k: v.to(DEV) for k, v in items.items()}
         _, ref = encoder_ref.encode(sd, cfg, "t5", items, "mean", hw, True)
-        monkeypatch.setenv("OM_ENCODER_FUSED_LN", "1")
-        _, fused = model.encode_passage(dev_items)
-        monkeypatch.setenv("OM_ENCODER_FUSED_LN", "0")
-        _, plain = model.encode_passage(dev_items)
+        _, fused = _encode_with_fused_ln(model, dev_items, 1)
+        _, plain = _encode_with_fused_ln(model, dev_items, 0)
         fused, plain, ref = fused.float().cpu(), plain.float().cpu(), ref.float()
         cos = lambda a, b: torch.nn.functional.cosine_similarity(a, b, dim=1).min().item()
         assert cos(plain, ref) > 0.999, (B, L, cos(plain, ref))
@@ -305,6 +311,52 @@ def test_contrastive_loss_matches_reference_fixture(golden):
     lref, _ = retrieval_ref.contrastive_loss(qc, pc, int(g["n_psg"]))
     lref.backward()
     assert (q.grad.cpu() - qc.grad).abs().max() < 1e-6 and (p.grad.cpu() - pc.grad).abs().max() < 1e-6
+
+
+def test_loss_objects_full_call_surface(golden):
+    """SimpleContrastiveLoss / DistributedContrastiveLoss as OBJECTS with the reference's call surface (loss.py:7-38):
+    default in-batch target, an explicit `target=` (incl. torch's ignore_index), `reduction=` mean / sum / none --
+    values and gradients against F.cross_entropy on the CPU.  The distributed variant runs on a 1-rank group."""
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    from openmatch.loss import DistributedContrastiveLoss, SimpleContrastiveLoss
+    g = golden("train_bert_tiny")
+    q0, p0 = torch.from_numpy(g["q_reps"]), torch.from_numpy(g["p_reps"])          # [4,128], [8,128]
+    explicit = torch.tensor([1, 0, 7, -100])
+    weights = torch.tensor([0.5, -1.0, 2.0, 0.25])
+
+    def reference(target, reduction, scale=1.0):
+        q, p = q0.clone().requires_grad_(), p0.clone().requires_grad_()
+        tgt = torch.arange(0, 4 * 2, 2) if target is None else target
+        loss = F.cross_entropy(q @ p.t(), tgt, reduction=reduction) * scale
+        (loss * weights).sum().backward() if reduction == "none" else loss.backward()
+        return loss.detach(), q.grad, p.grad
+
+    def check(fn, scale=1.0):
+        for target in (None, explicit):
+            for reduction in ("mean", "sum", "none"):
+                q, p = q0.clone().to(DEV).requires_grad_(), p0.clone().to(DEV).requires_grad_()
+                kw = {}
+                if target is not None:
+                    kw["target"] = target.to(DEV)
+                if reduction != "mean":
+                    kw["reduction"] = reduction
+                loss = fn(q, p, **kw)
+                (loss * weights.to(DEV)).sum().backward() if reduction == "none" else loss.backward()
+                l_ref, gq, gp = reference(target, reduction, scale)
+                assert loss.shape == l_ref.shape
+                assert (loss.detach().cpu() - l_ref).abs().max() < 1e-5, (target, reduction)
+                assert (q.grad.cpu() - gq).abs().max() < 1e-6 and (p.grad.cpu() - gp).abs().max() < 1e-6, (target, reduction)
+    check(SimpleContrastiveLoss())
+    with pytest.raises(ValueError):
+        SimpleContrastiveLoss()(q0.to(DEV), p0.to(DEV), reduction="median")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        check(DistributedContrastiveLoss())                    # world size 1: gather is the identity, scale 1
+        check(DistributedContrastiveLoss(scale_loss=False))
+    finally:
+        dist.destroy_process_group()
 
 
 # ------------------------------------------------------------------------------- training

@@ -210,6 +210,40 @@ def test_drivers_end_to_end(tok, tmp_path):
         order = [doc_ids[i] for i in scores[j].argsort(descending=True).tolist()]
         assert len(run[q]) == 23 and max(run[q], key=run[q].get) == order[0]
         assert abs(run[q][order[0]] - float(scores[j].max())) < 1e-4
+    # out-of-core variant (reference driver/successive_retrieve.py, retriever/dense_retriever.py:209-236): the same
+    # corpus as three partition files searched one after the other and merged by score == one index over all rows
+    emb3 = tmp_path / "emb3"
+    emb3.mkdir()
+    for r, (lo, hi) in enumerate(((0, 9), (9, 10), (10, 23))):
+        with open(emb3 / f"embeddings.corpus.rank.{r}", "wb") as f:
+            pickle.dump((P[lo:hi], doc_ids[lo:hi]), f, protocol=4)
+    _run_driver("successive_retrieve", ["--model_name_or_path", ckpt, "--output_dir", emb3, "--per_device_eval_batch_size", 8]
+                + QUERY_FLAGS + ["--trec_save_path", tmp_path / "run3.trec"])
+    run3 = load_from_trec(str(tmp_path / "run3.trec"))
+    assert sorted(run3) == sorted(run)
+    for q in qry_ids:
+        assert sorted(run3[q], key=run3[q].get, reverse=True) == sorted(run[q], key=run[q].get, reverse=True)
+        assert max(abs(run3[q][d] - run[q][d]) for d in run[q]) < 1e-5
+    # ... and with a depth smaller than a partition, through the classes themselves (the merge has to truncate)
+    from types import SimpleNamespace
+    from transformers import BertModel
+    from openmatch.modeling import DRModelForInference
+    from openmatch.retriever import Retriever, SuccessiveRetriever
+    from openmatch.dataset import InferenceDataset
+    results = {}
+    for cls, d in ((Retriever, emb), (SuccessiveRetriever, emb3)):
+        margs = SimpleNamespace(encoder_only=False, dtype="float32")
+        lm = BertModel.from_pretrained(ckpt)
+        model = DRModelForInference(lm_q=lm, lm_p=lm, model_args=margs)
+        args = SimpleNamespace(device="cuda:0", output_dir=str(d), world_size=1, process_index=0, local_process_index=0, fp16=False,
+                               per_device_eval_batch_size=8, dataloader_num_workers=0, dataloader_pin_memory=False)
+        queries = InferenceDataset.load(tok, data_args(), is_query=True, final=True, stream=True, batch_size=8, num_processes=1, process_index=0)
+        results[cls.__name__] = cls.from_embeddings(model.to("cuda:0").eval(), args).retrieve(queries, topk=4)
+    a, b = results["Retriever"], results["SuccessiveRetriever"]
+    assert sorted(a) == sorted(b) == sorted(qry_ids)
+    for q in qry_ids:
+        assert len(a[q]) == len(b[q]) == 4 and set(a[q]) == set(b[q])
+        assert max(abs(a[q][d] - b[q][d]) for d in a[q]) < 1e-5
     out = tmp_path / "trained"
     _run_driver("train_dr", ["--model_name_or_path", ckpt, "--output_dir", out, "--do_train",
                              "--train_path", os.path.join(TEXT, "train.jsonl"), "--train_n_passages", 4,

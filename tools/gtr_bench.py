@@ -4,6 +4,7 @@
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from openmatch_amd import native as N
 from types import SimpleNamespace as NS
 
 
@@ -27,7 +28,7 @@ def main():
     items = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
     out = {}
     for fused in ("1", "0"):
-        os.environ["OM_ENCODER_FUSED_LN"] = fused
+        N.check(N.lib().om_debug_option(0, int(fused)))      # OM_OPT_ENCODER_FUSED_LN
         for _ in range(2):
             model(passage=items)
         torch.cuda.synchronize(); t0 = time.perf_counter()
