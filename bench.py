@@ -11,7 +11,7 @@ accumulation (the reference's documented `--fp16` mode), random-init bert-base w
 `value` = passages/s over all ranks (weak scaling: each rank encodes its own batches).
 The search leg (same process, after the encode leg) serves Q queries against an 8 841 823 x 768
 index sharded over the ranks: all-gather of query vectors -> per-shard filtered MFMA scan +
-top-1000 -> gather + merge on rank 0 (ids identical to the exact f32 scan).
+top-1000 -> candidates exchanged by query range (all-to-all) and merged per slice (ids identical to the exact f32 scan).
 """
 import argparse
 import ctypes as C
@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--topk", type=int, default=1000)
     ap.add_argument("--no-search", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the strided-subsample parity leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the f32 and training sub-objects")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     return ap.parse_args()
 
@@ -78,35 +80,74 @@ def max_over_ranks(x, world, device):
     return float(t.item())
 
 
-def cpu_baseline(no_search):
-    """The CPU oracle (a port of the reference's path: plain torch f32 restatement of HF BertModel +
-    DRModel.encode, oracle/encoder_ref.py) timed on this box's host cores on a bounded sample."""
-    from transformers import BertConfig, BertModel
-    from oracle import encoder_ref, flatip
-    cores = min(os.cpu_count() or 1, 64)     # beyond ~64 threads torch's CPU GEMMs stop scaling
-    torch.set_num_threads(cores)
-    torch.manual_seed(0)
-    cfg = BertConfig()
-    lm = BertModel(cfg).eval()
-    sd = lm.state_dict()
-    rng = np.random.default_rng(0)
+def cpu_baseline(no_search, sample_batches):
+    """The reference's own CPU path, timed on this box's host cores on a bounded sample.
 
-    def run(n, bs=16):
-        ids = torch.from_numpy(rng.integers(1000, 30522, size=(n, 128)))
-        items = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
-        t0 = time.perf_counter()
+    What the reference runs per batch (retriever/dense_retriever.py:60-92): DRModelForInference(passage=batch) ->
+    HF BertModel.forward -> CLS pooling -> `.cpu().numpy()`, then one faiss IndexFlatIP.search over the index
+    (:166-192).  When /root/reference is importable (the build container) exactly those classes are timed, kind
+    "reference".  On the GPU box the reference tree does not exist: the SAME loop is run over the SAME third-party
+    module the reference calls (HF BertModel, installed in the image) with the same ragged masks as the GPU
+    batches -- kind "port"; oracle.flatip stands in for faiss in both cases (faiss is not installable here)."""
+    import sys as _sys
+    from transformers import BertConfig, BertModel
+    from oracle import flatip
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)                      # torch's CPU GEMMs stop scaling beyond ~64 threads
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    lm = BertModel(BertConfig()).eval()
+    kind, model = "port", None
+    ref_src = "/root/reference/src"
+    if os.path.isdir(os.path.join(ref_src, "openmatch")):
+        try:
+            saved = list(_sys.path)
+            mods = {k: v for k, v in _sys.modules.items() if k == "openmatch" or k.startswith("openmatch.")}
+            for k in mods:
+                del _sys.modules[k]
+            _sys.path.insert(0, ref_src)
+            import types as _types
+            import datasets  # noqa: F401  (probes for a real faiss at import time: must precede the stub)
+            if "faiss" not in _sys.modules:
+                stub = _types.ModuleType("faiss"); stub.IndexFlatIP = flatip.IndexFlatIP; _sys.modules["faiss"] = stub
+            from openmatch.modeling import DRModelForInference as RefModel      # the reference's class
+            from types import SimpleNamespace as NS
+            model = RefModel(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False))
+            kind = "reference"
+        except Exception:
+            model = None
+        finally:
+            for k in [k for k in _sys.modules if k == "openmatch" or k.startswith("openmatch.")]:
+                del _sys.modules[k]
+            _sys.modules.update(mods)
+            _sys.path[:] = saved
+
+    def encode(batch):
         with torch.no_grad():
-            for s in range(0, n, bs):
-                encoder_ref.encode(sd, cfg, "bert", {k: v[s:s + bs] for k, v in items.items()}, "first")
+            if model is not None:
+                return model(passage=batch).p_reps.cpu().numpy()
+            return lm(**batch, return_dict=True).last_hidden_state[:, 0, :].cpu().numpy()     # DRModel.encode, pooling "first"
+
+    ids = torch.cat([b["input_ids"].cpu() for b in sample_batches])
+    msk = torch.cat([b["attention_mask"].cpu() for b in sample_batches])
+
+    def run(n, bs=64):
+        t0 = time.perf_counter()
+        for s0 in range(0, n, bs):
+            encode({"input_ids": ids[s0:s0 + bs], "attention_mask": msk[s0:s0 + bs]})
         return time.perf_counter() - t0
-    run(16)                                        # warm-up (thread pool, allocator)
-    probe = run(32)
-    n = int(min(4096, max(32, 16 * round(12.0 * 32 / max(probe, 1e-3) / 16))))    # ~12 s of CPU work
-    t = run(n) if n > 32 else probe
-    out = {"value": n / t, "unit": "passages/s", "cores": cores, "kind": "port",
-           "sample": f"{n} passages x 128 tok, bert-base f32, oracle/encoder_ref.py, torch {cores} threads"}
+    run(64)                                        # warm-up (thread pool, allocator)
+    probe = run(128)
+    n = int(min(ids.shape[0], max(128, 64 * round(15.0 * 128 / max(probe, 1e-3) / 64))))    # ~15 s of CPU work
+    t = run(n) if n > 128 else probe
+    out = {"value": round(n / t, 2), "unit": "passages/s", "cores": threads, "host_cores": cores, "kind": kind,
+           "sample": f"{n} passages x 128 tok (the GPU leg's ragged synthetic batches), bert-base fp32, batch 64, "
+                     + ("reference DRModelForInference loop" if kind == "reference" else
+                        "the reference's loop over HF BertModel (reference tree absent on this box)")
+                     + f", torch {threads} threads"}
     if not no_search:
-        d, rows, nq = 768, 500_000, 64
+        d, rows, nq = 768, 1_000_000, 64
+        rng = np.random.default_rng(0)
         P = rng.standard_normal((rows, d), dtype=np.float32)
         Q = rng.standard_normal((nq, d), dtype=np.float32)
         idx = flatip.IndexFlatIP(d)
@@ -114,9 +155,108 @@ def cpu_baseline(no_search):
         t0 = time.perf_counter()
         idx.search(Q, 1000)
         ts = time.perf_counter() - t0
-        out["search"] = {"value": nq / ts * rows / CORPUS_ROWS, "unit": "queries/s",
-                         "sample": f"{nq} queries x {rows} rows x 768 f32 top-1000 (oracle/flatip.py), "
+        out["search"] = {"value": round(nq / ts * rows / CORPUS_ROWS, 2), "unit": "queries/s",
+                         "sample": f"{nq} queries x {rows} rows x 768 fp32 top-1000 (oracle/flatip.py in place of faiss.IndexFlatIP), "
                                    f"scaled linearly to {CORPUS_ROWS} rows"}
+    return out
+
+
+def parity_leg(model_bf16, lm, batches, device, index=None, queries=None, topk=1000):
+    """parity of THIS run's configuration on a strided subsample against the CPU oracle.
+    Encode: every 16th passage of the first two timed batches through (a) the bf16 path as benchmarked (inside its
+    1024-passage batch) and (b) the exact-f32 path, against oracle/encoder_ref.py in fp32.  Search: a strided
+    65 536-row slice of the benchmark index x 256 queries, both scan modes against oracle/flatip.py with fp64
+    adjudication of boundary ties."""
+    from oracle import encoder_ref, flatip
+    from openmatch.modeling import DRModelForInference
+    from openmatch_amd.index import FlatIPIndex
+    from types import SimpleNamespace as NS
+    out = {}
+    stride = 16
+    sel = torch.arange(0, batches[0]["input_ids"].shape[0], stride)
+    ids = torch.cat([b["input_ids"][sel] for b in batches[:2]]).cpu()
+    msk = torch.cat([b["attention_mask"][sel] for b in batches[:2]]).cpu()
+    sd = {k: v.detach().cpu() for k, v in lm.state_dict().items()}
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        _, ref = encoder_ref.encode(sd, lm.config, "bert", {"input_ids": ids, "attention_mask": msk}, "first")
+    ref = ref.double()
+    got16 = torch.cat([model_bf16(passage=b).p_reps[sel] for b in batches[:2]]).double().cpu()
+    m32 = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype="float32")).to(device).eval()
+    got32 = m32(passage={"input_ids": ids.to(device), "attention_mask": msk.to(device)}).p_reps.double().cpu()
+    cos = torch.nn.functional.cosine_similarity(got16, ref, dim=1)
+    dots_ref = ref[:16] @ ref.t()
+    out["encode"] = {
+        "sample": f"{ids.shape[0]} passages (every {stride}th of two timed batches) vs oracle/encoder_ref.py fp32, {time.perf_counter() - t0:.1f} s of CPU",
+        "bf16_min_cosine": round(float(cos.min()), 6), "bf16_mean_cosine": round(float(cos.mean()), 6),
+        "bf16_max_abs_ddot": round(float(((got16[:16] @ got16.t()) - dots_ref).abs().max()), 4),
+        "f32_max_abs_emb_err": float((got32 - ref).abs().max()),
+        "f32_max_rel_ddot": float((((got32[:16] @ got32.t()) - dots_ref).abs() / dots_ref.abs().clamp_min(1.0)).max()),
+        "dot_scale": round(float(dots_ref.abs().max()), 1),
+    }
+    if index is not None:
+        n = index.ntotal
+        step = max(1, n // 65536)
+        rows = index._f32[:n][::step][:65536, :index.d].contiguous()
+        q = queries[:256].contiguous()
+        P, Q = rows.cpu().numpy(), q.cpu().numpy()
+        o = flatip.IndexFlatIP(index.d); o.add(P)
+        Dr, Ir = o.search(Q, topk)
+        P64, Q64 = torch.from_numpy(P).double(), torch.from_numpy(Q).double()
+
+        def full(qi, disputed):
+            sc = P64 @ Q64[qi]
+            return sc[torch.tensor(disputed)].numpy(), torch.topk(sc, topk).values[-1].item()
+        res = {"sample": f"{rows.shape[0]} index rows (stride {step}) x {q.shape[0]} queries, top-{topk}, vs oracle/flatip.py"}
+        for precision in ("f16_rescore", "f32"):
+            sub = FlatIPIndex(index.d, device=device, precision=precision)
+            sub.add(rows)
+            D, I = sub.search_device(q, topk)
+            n_exact, n_tie, n_bad, _ = flatip.topk_sets_equal(I.cpu().numpy(), Ir, full, rel_tol=2e-6)
+            res[precision] = {"id_sets_identical": n_exact, "fp64_near_tie_only": n_tie, "wrong": n_bad,
+                              "max_abs_score_err": float(np.abs(D.cpu().numpy() - Dr).max())}
+        out["search"] = res
+    return out
+
+
+def train_leg(device, steps=8):
+    """BASELINE config 3 per GPU: one contrastive training step (8 queries x 32 tok + 64 passages x 128 tok, bert-base,
+    dropout 0.1, forward + backward + AdamW) -- steps/s and algorithmic TFLOP/s (3 x forward FLOPs)."""
+    from transformers import BertConfig, BertModel
+    from openmatch.modeling import DRModel
+    from openmatch.trainer import DRTrainer
+    from types import SimpleNamespace as NS
+    torch.manual_seed(0)
+    lm = BertModel(BertConfig(hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1))
+    model = DRModel(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype="bfloat16"),
+                    data_args=NS(train_n_passages=8),
+                    train_args=NS(negatives_x_device=False, per_device_train_batch_size=8)).to(device)
+    g = torch.Generator().manual_seed(1)
+    mk = lambda n, L: {"input_ids": torch.randint(1000, 30000, (n, L), generator=g), "attention_mask": torch.ones(n, L, dtype=torch.long)}
+    batch = (mk(8, 32), mk(64, 128))
+    args = NS(device=device, world_size=1, process_index=0, per_device_train_batch_size=8, negatives_x_device=False,
+              learning_rate=5e-6, gradient_accumulation_steps=1, fp16=False, bf16=False)
+    trainer = DRTrainer(model=model, args=args)
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-6, fused=True)
+
+    def step():
+        loss = trainer.training_step(model, batch)
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step(); opt.zero_grad(set_to_none=True)
+        return loss
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    flop = 3 * (8 * 5.474e9 + 64 * GFLOP_PER_PASSAGE * 1e9)
+    out = {"metric": "contrastive training steps/s per GPU (8 q x 32 tok + 64 p x 128 tok, bert-base, fwd + bwd + AdamW, dropout 0.1)",
+           "value": round(1 / dt, 2), "unit": "steps/s", "ms_per_step": round(dt * 1e3, 2), "dtype": "bf16",
+           "algorithmic_tflops": round(flop / dt / 1e12, 1), "frac_of_mfma_peak": round(flop / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
+           "loss": float(loss)}
+    del model, trainer, opt
+    torch.cuda.empty_cache()
     return out
 
 
@@ -136,7 +276,7 @@ def main():
     from transformers import BertConfig, BertModel
     from openmatch.modeling import DRModelForInference
     from openmatch_amd import native as N
-    from openmatch_amd.index import FlatIPIndex, merge_topk
+    from openmatch_amd.index import FlatIPIndex, sharded_topk
     from types import SimpleNamespace as NS
 
     lib = N.lib()
@@ -174,18 +314,21 @@ def main():
     lib.om_kernel_timing_enable(0)
     gemm_tflops = flops.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
     peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else 157.3
-    traffic = None        # HBM bytes per launch of the dominant kernel, from the committed PMC passes
-    tpath = os.path.join(REPO, "profiles", "r01_hbm_traffic.json")
-    if a.precision == "bf16" and a.batch == 1024 and os.path.exists(tpath):
+    traffic, tsrc = None, None   # HBM bytes per launch of the dominant kernel: the round's committed rocprofv3 --pmc passes of this command
+    import glob
+    cand = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_traffic.json")))
+    if a.precision == "bf16" and a.batch == 1024 and cand:
         try:
-            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+            tj = json.load(open(cand[-1]))
+            traffic, tsrc = tj["hbm_bytes_per_launch"], "profiles/" + os.path.basename(cand[-1]) + ": " + tj.get("note", "")
         except Exception:
             traffic = None
     roofline = {
-        "kernel": "gemm_nt_kernel6<%s> (encoder QKV / out-proj / FFN contractions; three epilogue variants)" % a.precision,
+        "kernel": ("gemm_nt_kernel7<bf16> (persistent 256x256 tiles, 128-byte K steps; encoder QKV / out-proj / FFN contractions, "
+                   "three epilogue variants)" if a.precision == "bf16" else "gemm_nt_kernel6<f32> (exact-f32 MFMA)"),
         "bound": "mfma", "achieved": round(gemm_tflops, 1), "peak": peak, "unit": "TFLOP/s",
         "frac": round(gemm_tflops / peak, 4), "traffic": traffic,
-        "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH doubled per the gfx950 note)" if traffic else None,
+        "traffic_source": tsrc,
         "launches": int(n_launch.value), "avg_launch_us": round(ms.value * 1e3 / max(n_launch.value, 1), 2),
         "flops_per_launch": flops.value / max(n_launch.value, 1),
         "measured": "hipEvents around every launch of the kernel on its stream, second pass of the same K steps",
@@ -193,7 +336,7 @@ def main():
     }
 
     # ---------------- search leg -----------------------------------------------------------
-    search = None
+    search, parity = None, None
     if not a.no_search:
         rows = a.index_rows // world + (1 if rank < a.index_rows % world else 0)
         offset = rank * (a.index_rows // world) + min(rank, a.index_rows % world)
@@ -218,14 +361,10 @@ def main():
                 queries = torch.cat([allq[r * nmax:r * nmax + sizes[r]] for r in range(world)])
             else:
                 queries = q_local
-            D, I = index.search_device(queries, a.topk, id_offset=offset)
-            if world > 1:
-                pd = [torch.empty_like(D) for _ in range(world)] if rank == 0 else None
-                pi = [torch.empty_like(I) for _ in range(world)] if rank == 0 else None
-                dist.gather(D, pd, dst=0)
-                dist.gather(I, pi, dst=0)
-                if rank == 0:
-                    D, I = merge_topk(torch.stack(pd), torch.stack(pi), a.topk)
+            if world > 1:      # candidates exchanged by query range (all-to-all), merged per slice: openmatch_amd/index.py
+                D, I, _ = sharded_topk(index, queries, a.topk, offset)
+            else:
+                D, I = index.search_device(queries, a.topk, id_offset=offset)
             return D, I
 
         search_once()                                            # warm-up
@@ -257,12 +396,36 @@ def main():
                             "ms_per_search": round(sms.value / reps, 2), "launches_per_search": int(sl.value // reps),
                             "index_stream_GBps_if_read_once": round(scan_bytes / max(sms.value / reps, 1e-9) / 1e6, 1)},
         }
+        if rank == 0 and world == 1 and not a.no_parity and a.precision == "bf16":
+            parity = parity_leg(model, lm, batches, device, index, q_local, a.topk)
         del index
         torch.cuda.empty_cache()
+    if parity is None and rank == 0 and world == 1 and not a.no_parity and a.precision == "bf16":
+        parity = parity_leg(model, lm, batches, device)
+
+    # ---------------- exact-f32 mode and the training step (sub-objects; N = 1 only) ----------
+    f32_mode, train = None, None
+    if rank == 0 and world == 1 and not a.no_extra and a.precision == "bf16":
+        m32 = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first",
+                                  model_args=NS(encoder_only=False, dtype="float32")).to(device).eval()
+        sub = {k: v[:256] for k, v in batches[0].items()}
+        for _ in range(2):
+            m32(passage=sub)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3):
+            m32(passage=sub)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+        f32_mode = {"metric": "passages/s encode in the exact-f32 MFMA mode (the mode that meets the 1e-4 parity bar)",
+                    "value": round(256 / dt, 1), "unit": "passages/s", "passages_per_step": 256,
+                    "algorithmic_tflops": round(256 * GFLOP_PER_PASSAGE / 1e3 / dt, 1),
+                    "frac_of_f32_mfma_peak": round(256 * GFLOP_PER_PASSAGE / 1e3 / dt / 157.3, 4)}
+        del m32
+        torch.cuda.empty_cache()
+        train = train_leg(device)
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a.no_search)
+        cpu = cpu_baseline(a.no_search, batches)
 
     if rank == 0:
         line = {
@@ -275,7 +438,7 @@ def main():
                        "passages_per_step_per_gpu": a.batch, "seq_len": L, "global_batch": a.batch * world,
                        "index_rows": a.index_rows, "queries": a.queries, "topk": a.topk,
                        "weights": "random-init BertConfig() seed 0", "parallelism": f"shard{world}"},
-            "roofline": roofline, "search": search, "cpu_baseline": cpu,
+            "roofline": roofline, "search": search, "parity": parity, "f32": f32_mode, "train": train, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

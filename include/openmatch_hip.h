@@ -81,7 +81,8 @@ void om_debug_gemm_gen(int gen);
  * shapes allow (default), 0 = one normalisation kernel per site; OM_OPT_ENCODER_DEBUG 1 = log the path taken. */
 #define OM_OPT_ENCODER_FUSED_LN 0
 #define OM_OPT_ENCODER_DEBUG 1
-#define OM_OPT_COUNT 2
+#define OM_OPT_ATTENTION_FAST 2   /* 1 (default): bf16 inference attention on the low-instruction-count kernel; 0: the generic kernel */
+#define OM_OPT_COUNT 3
 int om_debug_option(int opt, int value);
 int om_kernel_timing_enable(int enable);
 int om_kernel_timing_read(int kernel_class, double* total_ms, int64_t* launches, double* flops);

@@ -80,6 +80,8 @@ void opt_init() {
   const char* e = getenv("OM_ENCODER_FUSED_LN");
   g_opt[OM_OPT_ENCODER_FUSED_LN] = e ? atoi(e) : 1;
   g_opt[OM_OPT_ENCODER_DEBUG] = getenv("OM_ENCODER_DEBUG") ? 1 : 0;
+  e = getenv("OM_ATTENTION_FAST");
+  g_opt[OM_OPT_ATTENTION_FAST] = e ? atoi(e) : 1;
   g_opt_init.store(true);
 }
 }  // namespace

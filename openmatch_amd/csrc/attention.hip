@@ -150,6 +150,198 @@ __global__ __launch_bounds__(64 * KT) void attention_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 inference kernel (no dropout): the same mathematics with ~2.5x fewer instructions per wave.  The kernel above
+// is ISSUE-bound at the encoder's shape (L = 128: ~1400 instructions per wave, 4 waves per SIMD -- profiles/
+// r01_bench_v8_kernel_stats.csv: 244 us per layer against a 146 us HBM floor): staging through VGPRs, V transposed
+// with 256 two-byte LDS stores per lane, the context transposed back through LDS.  Here
+//   * K and V go to LDS row-major by LDS-DMA (4 + 4 instructions per wave, swizzle on the source address);
+//   * V^T fragments are made by the matrix core: D = V_tile . I (two MFMAs per 32 x 32 block) leaves, in the
+//     accumulator layout, every lane with one d column and its 16 keys in registers -- exactly the k-slot order the
+//     probabilities have, so cvt_pk gives the A operand of  O^T = V^T P^T  directly (bf16 * 1.0 is exact);
+//   * O^T puts a query row in each lane: one v_permlane32_swap per dword pair makes 16 contiguous bytes, stored
+//     straight to global memory (no LDS round trip, no second barrier);
+//   * softmax in the log2 domain: v = fma(s, scale log2e, mask), exp2(v - max) -- five instructions per score.
+// Masked keys carry -1e30 (finite: a fully masked row stays uniform, as with HF's finfo.min), keys past L -inf.
+#include "gemm_core7.h"
+
+typedef __bf16 bf16x2_hw_a_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_a_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2_(float lo, float hi) {      // one v_cvt_pk_bf16_f32
+  const f32x2_a_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw_a_t));
+}
+
+template <int KT, bool BIAS>
+__global__ __launch_bounds__(64 * KT, KT <= 4 ? (BIAS ? 3 : 4) : 2) void attention_fwd16_kernel(
+    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, const int64_t* __restrict__ mask,
+    const float* __restrict__ pos_bias, int L, int H, int heads, float scale) {
+  typedef bf16x8_t frag_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sK = smem;
+  char* const sV = smem + KT * 32 * 128;
+  float* const sM = (float*)(smem + 2 * KT * 32 * 128);
+  const int h = blockIdx.x % heads;
+  const int64_t b = blockIdx.x / heads;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t ld2 = 6 * (int64_t)H;                       // row pitch of qkv in bytes
+  const char* const base = (const char*)(qkv + b * L * 3 * (int64_t)H + h * 64);
+
+  // K and V rows of this (batch, head): instruction i of wave w moves rows (i * KT + w) * 8 .. + 7, lane -> row
+  // (lane >> 3), physical 16-byte chunk (lane & 7) <- source chunk (lane & 7) ^ ((row >> 1) & 7).  Rows past L repeat
+  // row L - 1 (their scores are masked to -inf).
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (i * KT + wave) * 8 + (lane >> 3);
+    const int rr = r < L ? r : L - 1;
+    const uint32_t off = (uint32_t)(rr * ld2) + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+    const uint32_t dst = (uint32_t)((i * KT + wave) * 1024);
+    g7_dma(base + 2 * H, off, g7_lds_addr(sK) + dst);
+    g7_dma(base + 4 * H, off, g7_lds_addr(sV) + dst);
+  }
+  const float LOG2E = 1.4426950408889634f;
+  for (int k = tid; k < KT * 32; k += 64 * KT)
+    sM[k] = k < L ? (mask[b * L + k] != 0 ? 0.f : -1e30f) : -INFINITY;
+
+  const int q0 = wave * 32;
+  const int qrow = (q0 + l31) < L ? (q0 + l31) : (L - 1);
+  frag_t qf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const frag_t*)(base + (int64_t)qrow * ld2 + (kk * 2 + half) * 16);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the DMA above is not in hipcc's bookkeeping
+  __syncthreads();
+  if (q0 >= L) return;
+
+  // S^T = K Q^T : lane owns query l31, keys (r&3) + 8(r>>2) + 4 half of each 32-key tile
+  const int key = (l31 >> 1) & 7;
+  f32x16_t s[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+    const char* krow = sK + (t * 32 + l31) * 128;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const frag_t a = *(const frag_t*)(krow + (((kk * 2 + half) ^ key) << 4));
+      s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[kk], s[t], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const float c2 = scale * LOG2E;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int k0 = t * 32 + 8 * g + 4 * half;
+      const f32x4_t mb = *(const f32x4_t*)(sM + k0);
+      f32x4_t pb = {0.f, 0.f, 0.f, 0.f};
+      if (BIAS) {              // T5: bias[h][q][k], four consecutive keys per load (L % 4 == 0 is not required: clamp)
+        const float* pr = pos_bias + ((int64_t)h * L + qrow) * L;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pb[e] = pr[(k0 + e) < L ? (k0 + e) : (L - 1)] * LOG2E;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = fmaf(s[t][4 * g + e], c2, mb[e]) + pb[e];
+        s[t][4 * g + e] = v;
+        mx = fmaxf(mx, v);
+      }
+      __builtin_amdgcn_sched_barrier(0);      // keep the 16 mask vectors from being fetched all at once
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __builtin_amdgcn_exp2f(s[t][r] - mx);
+      s[t][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+
+  // identity fragments of the transposing MFMAs: lane j holds 1.0 at k == j of the 32-wide d block
+  frag_t idf[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const bool mine = (l31 >> 4) == kk && ((l31 >> 3) & 1) == half;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) idf[kk][e] = (mine && (l31 & 7) == e) ? (short)0x3F80 : (short)0;
+  }
+  f32x16_t o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    uint4 pa[2];      // probabilities of this key tile as two k slabs (k slot e of half h <-> register 8u + e)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      pa[u] = make_uint4(pack_bf16x2_(s[t][8 * u + 0], s[t][8 * u + 1]), pack_bf16x2_(s[t][8 * u + 2], s[t][8 * u + 3]),
+                         pack_bf16x2_(s[t][8 * u + 4], s[t][8 * u + 5]), pack_bf16x2_(s[t][8 * u + 6], s[t][8 * u + 7]));
+    const char* vrow = sV + (t * 32 + l31) * 128;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      f32x16_t vt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vt[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const frag_t a = *(const frag_t*)(vrow + (((dt * 4 + kk * 2 + half) ^ key) << 4));
+        vt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, idf[kk], vt, 0, 0, 0);       // vt[key][d]: lane = d, registers = keys
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint4 vb = make_uint4(pack_bf16x2_(vt[8 * u + 0], vt[8 * u + 1]), pack_bf16x2_(vt[8 * u + 2], vt[8 * u + 3]),
+                                    pack_bf16x2_(vt[8 * u + 4], vt[8 * u + 5]), pack_bf16x2_(vt[8 * u + 6], vt[8 * u + 7]));
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(frag_t, vb), __builtin_bit_cast(frag_t, pa[u]), o[dt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);      // one 32 x 32 block at a time: hoisting every V read costs 64 registers (occupancy)
+    }
+  }
+  // o[dt][r] = O[query l31][d = 32 dt + (r&3) + 8(r>>2) + 4 half]: scale by 1/sum, pack, pair up the two halves
+  if (q0 + l31 < L) {
+    char* const out = (char*)(ctx + (b * L + q0 + l31) * (int64_t)H + h * 64);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        uint32_t a0 = pack_bf16x2_(o[dt][8 * gp + 0] * inv, o[dt][8 * gp + 1] * inv), a1 = pack_bf16x2_(o[dt][8 * gp + 2] * inv, o[dt][8 * gp + 3] * inv);
+        uint32_t b0 = pack_bf16x2_(o[dt][8 * gp + 4] * inv, o[dt][8 * gp + 5] * inv), b1 = pack_bf16x2_(o[dt][8 * gp + 6] * inv, o[dt][8 * gp + 7] * inv);
+        // (a: d group 2gp, b: d group 2gp + 1) -- lanes 32-63 of a swap with lanes 0-31 of b
+        auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        // lanes 0-31: d = 32 dt + 16 gp + 0..7 ; lanes 32-63: d = 32 dt + 16 gp + 8..15
+        *(uint4*)(out + (32 * dt + 16 * gp + 8 * half) * 2) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+      }
+  }
+}
+
+template <int KT, bool BIAS>
+static int launch_attn16_(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias, int64_t B, int L, int H,
+                         int heads, float scale, hipStream_t s) {
+  const int lds = 2 * KT * 32 * 128 + KT * 32 * 4;
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set) {
+    OM_HIP(hipFuncSetAttribute((const void*)attention_fwd16_kernel<KT, BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attention_fwd16_kernel<KT, BIAS>), dim3((unsigned)(heads * B)), dim3(64 * KT), lds, s, (const bf16_t*)qkv,
+                     (bf16_t*)ctx, mask, pos_bias, L, H, heads, scale);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+template <int KT>
+static int launch_attn16(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias, int64_t B, int L, int H,
+                         int heads, float scale, hipStream_t s) {
+  if (pos_bias) return launch_attn16_<KT, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
+  return launch_attn16_<KT, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
+}
+
 template <typename T, int KT>
 static int launch_attn(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias,
                        int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
@@ -188,6 +380,13 @@ int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
   if (L < 1 || L > 256) OM_FAIL("sequence length must be in [1,256]");
   if (H != heads * 64) OM_FAIL("head_dim must be 64");
   if (B * heads > 0x7fffffffLL) OM_FAIL("batch too large for one launch");
+  if (dtype == OM_BF16 && drop_p == 0.f && om_option(OM_OPT_ATTENTION_FAST)) {        // inference: the low-instruction-count kernel
+    if (L <= 32) return launch_attn16<1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
+    if (L <= 64) return launch_attn16<2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
+    if (L <= 128) return launch_attn16<4>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
+    if (L <= 192) return launch_attn16<6>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
+    return launch_attn16<8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
+  }
   if (dtype == OM_BF16) return dispatch_attn<bf16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
   return dispatch_attn<float>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
 }

@@ -25,12 +25,17 @@ struct EncWs {
   // fused-LayerNorm path (bf16 BERT): folded weight, its column sums and bias, two statistics buffers
   char* wfold;
   float *colsum, *bfold, *stats1, *stats2;
+  int64_t Mp;       // row count the GEMMs run on: M rounded up to whole 256-row tiles (the buffers are that tall)
   size_t total;
 };
 
 static EncWs carve(const OmEncoderConfig* c, int64_t B, int64_t L, char* base) {
   const size_t es = c->dtype == OM_BF16 ? 2 : 4;
-  const size_t M = (size_t)B * L, H = c->hidden, F = c->ffn;
+  // 16-bit batches of >= 512 tokens are padded to whole 256-row tiles: the persistent GEMM generation
+  // (gemm_wide7.h) takes whole tiles only.  Rows are independent in every contraction, so whatever the pad rows
+  // hold stays in the pad rows; every other kernel (embedding, attention, normalisation, pooling) sees B*L rows.
+  const size_t Mreal = (size_t)B * L, H = c->hidden, F = c->ffn;
+  const size_t M = (c->dtype == OM_BF16 && Mreal >= 512) ? (Mreal + 255) / 256 * 256 : Mreal;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return base + o; };
   EncWs w;
@@ -53,6 +58,7 @@ static EncWs carve(const OmEncoderConfig* c, int64_t B, int64_t L, char* base) {
   // one (sum, sum of squares) buffer per LayerNorm site, all zeroed by ONE memset per forward
   w.stats1 = (float*)take(fuse ? (size_t)2 * c->n_layers * M * 8 : 0);
   w.stats2 = w.stats1 ? w.stats1 + (size_t)c->n_layers * M * 2 : nullptr;
+  w.Mp = (int64_t)M;
   w.total = off;
   return w;
 }
@@ -102,13 +108,14 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
   hipStream_t s = (hipStream_t)stream;
   const int dt = c->dtype, H = c->hidden, F = c->ffn, nh = c->n_heads;
   const int64_t M = B * L;
+  const int64_t Mg = ws.Mp;          // rows of the contractions (M padded to whole tiles for large 16-bit batches)
   const bool bert = c->arch == OM_ARCH_BERT;
   const OmLayerWeights* Ls = w->layers_host;
   if (!Ls) OM_FAIL("layers_host is null");
 
 #define GEMM(A_, lda_, W_, ldw_, C_, ldc_, N_, K_, bias_, res_, ldr_, act_)                      \
   do {                                                                                           \
-    if (om_gemm_nt(dt, A_, lda_, W_, ldw_, dt, C_, ldc_, M, N_, K_, bias_, res_, ldr_, act_, s)) \
+    if (om_gemm_nt(dt, A_, lda_, W_, ldw_, dt, C_, ldc_, Mg, N_, K_, bias_, res_, ldr_, act_, s)) \
       return 1;                                                                                  \
   } while (0)
 #define RUN(expr) do { if (expr) return 1; } while (0)
@@ -127,28 +134,28 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
     // [M,H] disappear (the embedding LayerNorm and the last one stay).
     const bool no_fuse = om_option(OM_OPT_ENCODER_FUSED_LN) == 0;   // A/B switch (om_debug_option)
     const bool fuse = !no_fuse && c->act == OM_ACT_GELU_ERF && c->n_layers > 0 && H % 8 == 0 &&
-                      omk_gemm_ln_fusable(dt, M, H, H) && omk_gemm_ln_fusable(dt, M, F, H) &&
-                      omk_gemm_ln_fusable(dt, M, 3 * H, H) && omk_gemm_ln_fusable(dt, M, H, F);
+                      omk_gemm_ln_fusable(dt, Mg, H, H) && omk_gemm_ln_fusable(dt, Mg, F, H) &&
+                      omk_gemm_ln_fusable(dt, Mg, 3 * H, H) && omk_gemm_ln_fusable(dt, Mg, H, F);
     if (om_option(OM_OPT_ENCODER_DEBUG)) fprintf(stderr, "om_encoder_forward: M=%ld fused_ln=%d\n", (long)M, (int)fuse);
     if (fuse) {
       const float inv_h = 1.0f / (float)H;
-      OM_HIP(hipMemsetAsync(ws.stats1, 0, (size_t)2 * c->n_layers * M * 8, s));
+      OM_HIP(hipMemsetAsync(ws.stats1, 0, (size_t)2 * c->n_layers * Mg * 8, s));
       // y1 lives in ws.y, y2 in ws.x1; ws.x is the embedding output (layer 0's input)
       for (int l = 0; l < c->n_layers; ++l) {
         const OmLayerWeights& lw = Ls[l];
-        float* st1 = ws.stats1 + (size_t)l * M * 2;                     // LN1 of this layer
-        float* st2 = ws.stats2 + (size_t)l * M * 2;                     // LN2 of this layer
-        const float* st2p = l ? ws.stats2 + (size_t)(l - 1) * M * 2 : nullptr;   // LN2 of the previous one
+        float* st1 = ws.stats1 + (size_t)l * Mg * 2;                     // LN1 of this layer
+        float* st2 = ws.stats2 + (size_t)l * Mg * 2;                     // LN2 of this layer
+        const float* st2p = l ? ws.stats2 + (size_t)(l - 1) * Mg * 2 : nullptr;   // LN2 of the previous one
         GemmEpilogue e = {};
         // ---- QKV: x0 for the first layer, LN2_{l-1}(y2) folded afterwards
         if (l == 0) {
           e.bias = lw.qkv_b;
-          RUN(omk_gemm(dt, ws.x, H, lw.qkv_w, H, dt, ws.qkv, 3 * H, M, 3 * H, H, e, s));
+          RUN(omk_gemm(dt, ws.x, H, lw.qkv_w, H, dt, ws.qkv, 3 * H, Mg, 3 * H, H, e, s));
         } else {
           const OmLayerWeights& pw = Ls[l - 1];
           RUN(omk_ln_fold(lw.qkv_w, pw.ln2_g, pw.ln2_b, lw.qkv_b, ws.wfold, ws.colsum, ws.bfold, 3 * H, H, s));
           e.bias = ws.bfold; e.ln_stats = st2p; e.ln_colsum = ws.colsum; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
-          RUN(omk_gemm(dt, ws.x1, H, ws.wfold, H, dt, ws.qkv, 3 * H, M, 3 * H, H, e, s));
+          RUN(omk_gemm(dt, ws.x1, H, ws.wfold, H, dt, ws.qkv, 3 * H, Mg, 3 * H, H, e, s));
         }
         RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, nullptr, B, (int)L, H, nh, scale, 0.f, 0, s));
         // ---- attention output + residual -> y1, statistics of LN1
@@ -160,17 +167,17 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
           const OmLayerWeights& pw = Ls[l - 1];
           e.resid = ws.x1; e.rln_stats = st2p; e.rln_g = pw.ln2_g; e.rln_b = pw.ln2_b;
         }
-        RUN(omk_gemm(dt, ws.ctx, H, lw.o_w, H, dt, ws.y, H, M, H, H, e, s));
+        RUN(omk_gemm(dt, ws.ctx, H, lw.o_w, H, dt, ws.y, H, Mg, H, H, e, s));
         // ---- FFN1 on LN1(y1), folded
         RUN(omk_ln_fold(lw.ffn1_w, lw.ln1_g, lw.ln1_b, lw.ffn1_b, ws.wfold, ws.colsum, ws.bfold, F, H, s));
         e = GemmEpilogue{};
         e.bias = ws.bfold; e.act = c->act; e.ln_stats = st1; e.ln_colsum = ws.colsum; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
-        RUN(omk_gemm(dt, ws.y, H, ws.wfold, H, dt, ws.ff, F, M, F, H, e, s));
+        RUN(omk_gemm(dt, ws.y, H, ws.wfold, H, dt, ws.ff, F, Mg, F, H, e, s));
         // ---- FFN2 + LN1(y1) as the residual -> y2, statistics of LN2
         e = GemmEpilogue{};
         e.bias = lw.ffn2_b; e.resid = ws.y; e.ldr = H; e.rln_stats = st1; e.rln_g = lw.ln1_g; e.rln_b = lw.ln1_b;
         e.stats_out = st2; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
-        RUN(omk_gemm(dt, ws.ff, F, lw.ffn2_w, F, dt, ws.x1, H, M, H, F, e, s));
+        RUN(omk_gemm(dt, ws.ff, F, lw.ffn2_w, F, dt, ws.x1, H, Mg, H, F, e, s));
       }
       const OmLayerWeights& last = Ls[c->n_layers - 1];
       void* dst = out_hidden ? out_hidden : (void*)ws.x;
@@ -207,35 +214,35 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
     // rsqrt(mean(x^2) + eps) in the epilogue.  Only the first and the final norm run as kernels.
     const bool no_fuse_t5 = om_option(OM_OPT_ENCODER_FUSED_LN) == 0;
     // (gated feed-forward layers keep the kernels: two folded GEMMs per norm measured 1 % slower, tools/gtr_bench.py)
-    const bool fuse_t5 = !no_fuse_t5 && c->n_layers > 0 && !Ls[0].ffn1g_w && H % 8 == 0 && omk_gemm_ln_fusable(dt, M, H, H) &&
-                         omk_gemm_ln_fusable(dt, M, F, H) && omk_gemm_ln_fusable(dt, M, 3 * H, H) &&
-                         omk_gemm_ln_fusable(dt, M, H, F);
+    const bool fuse_t5 = !no_fuse_t5 && c->n_layers > 0 && !Ls[0].ffn1g_w && H % 8 == 0 && omk_gemm_ln_fusable(dt, Mg, H, H) &&
+                         omk_gemm_ln_fusable(dt, Mg, F, H) && omk_gemm_ln_fusable(dt, Mg, 3 * H, H) &&
+                         omk_gemm_ln_fusable(dt, Mg, H, F);
     if (om_option(OM_OPT_ENCODER_DEBUG)) fprintf(stderr, "om_encoder_forward (t5): M=%ld fused_norm=%d\n", (long)M, (int)fuse_t5);
     if (fuse_t5) {
       const float inv_h = 1.0f / (float)H;
-      OM_HIP(hipMemsetAsync(ws.stats1, 0, (size_t)2 * c->n_layers * M * 8, s));
+      OM_HIP(hipMemsetAsync(ws.stats1, 0, (size_t)2 * c->n_layers * Mg * 8, s));
       auto folded = [&](const void* A_, const void* W_, const float* g_, const float* stats_, void* C_, int N_, int act_,
                         const void* res_, int64_t ldr_) -> int {
         if (omk_ln_fold(W_, g_, nullptr, nullptr, ws.wfold, ws.colsum, ws.bfold, N_, H, s)) return 1;
         GemmEpilogue e = {};
         e.act = act_; e.resid = res_; e.ldr = ldr_;
         e.ln_stats = stats_; e.ln_rms = 1; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
-        return omk_gemm(dt, A_, H, ws.wfold, H, dt, C_, N_, M, N_, H, e, s);
+        return omk_gemm(dt, A_, H, ws.wfold, H, dt, C_, N_, Mg, N_, H, e, s);
       };
       for (int l = 0; l < c->n_layers; ++l) {
         const OmLayerWeights& lw = Ls[l];
-        float* st1 = ws.stats1 + (size_t)l * M * 2;                     // sum(x1^2): input of the FFN norm
-        float* st2 = ws.stats2 + (size_t)l * M * 2;                     // sum(x'^2): input of the next layer's first norm
+        float* st1 = ws.stats1 + (size_t)l * Mg * 2;                     // sum(x1^2): input of the FFN norm
+        float* st2 = ws.stats2 + (size_t)l * Mg * 2;                     // sum(x'^2): input of the next layer's first norm
         if (l == 0) {
           RUN(omk_layernorm(dt, ws.x, H, ws.y, H, lw.ln1_g, nullptr, M, H, c->ln_eps, 1, s));
           GEMM(ws.y, H, lw.qkv_w, H, ws.qkv, 3 * H, 3 * H, H, nullptr, nullptr, 0, OM_ACT_NONE);
         } else {
-          RUN(folded(ws.x, lw.qkv_w, lw.ln1_g, ws.stats2 + (size_t)(l - 1) * M * 2, ws.qkv, 3 * H, OM_ACT_NONE, nullptr, 0));
+          RUN(folded(ws.x, lw.qkv_w, lw.ln1_g, ws.stats2 + (size_t)(l - 1) * Mg * 2, ws.qkv, 3 * H, OM_ACT_NONE, nullptr, 0));
         }
         RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, ws.posbias, B, (int)L, H, nh, 1.0f, 0.f, 0, s));
         GemmEpilogue e = {};
         e.resid = ws.x; e.ldr = H; e.stats_out = st1; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
-        RUN(omk_gemm(dt, ws.ctx, H, lw.o_w, H, dt, ws.x, H, M, H, H, e, s));           // x += o(ctx), sum(x^2)
+        RUN(omk_gemm(dt, ws.ctx, H, lw.o_w, H, dt, ws.x, H, Mg, H, H, e, s));           // x += o(ctx), sum(x^2)
         if (lw.ffn1g_w) {
           RUN(folded(ws.x, lw.ffn1g_w, lw.ln2_g, st1, ws.ff2, F, OM_ACT_NONE, nullptr, 0));
           RUN(folded(ws.x, lw.ffn1_w, lw.ln2_g, st1, ws.ff, F, c->act | OM_ACT_MUL_RESID, ws.ff2, F));
@@ -244,7 +251,7 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
         }
         e = GemmEpilogue{};
         e.resid = ws.x; e.ldr = H; e.stats_out = st2; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
-        RUN(omk_gemm(dt, ws.ff, F, lw.ffn2_w, F, dt, ws.x, H, M, H, F, e, s));         // x += wo(ff), sum(x^2)
+        RUN(omk_gemm(dt, ws.ff, F, lw.ffn2_w, F, dt, ws.x, H, Mg, H, F, e, s));         // x += wo(ff), sum(x^2)
       }
     } else
     for (int l = 0; l < c->n_layers; ++l) {

@@ -14,7 +14,7 @@
 // LDS (160 KiB, all dynamic; gemm_core7.h's five 32 KiB units U0..U4):
 //   K loop        U0-U4 rotate
 //   epilogue      U0, U1   step 0 of the next tile (in flight)
-//                 U2, U3   residual ring: 3 patches x 4 KiB per wave (48 KiB), then bf16 staging 4 KiB per wave
+//                 U2, U3   per wave 16 slices of 1 KiB (its own DMA targets): residual ring 3 x 4 KiB, bf16 staging 4 KiB
 //                 U4       [0, 8 KiB)   accumulator-init tables of the NEXT tile, 2 KiB per wave:
 //                                         s_n | b'_n (128 + 128 f32), LayerNorm statistics of the wave's 128 rows
 //                          [8, 16 KiB)  epilogue tables, 2 KiB per wave: gamma | beta, statistics of the residual rows
@@ -26,10 +26,14 @@
 #include "gemm_core7.h"
 #include "gemm_epilogue6.h"
 
-#define G7E_RING_OFF (2 * G7_UNIT_BYTES)
-#define G7E_PATCH_BYTES 4096
 #define G7E_RES_DEPTH 3
-#define G7E_STAGE_OFF (G7E_RING_OFF + 4 * G7E_RES_DEPTH * G7E_PATCH_BYTES)
+// Epilogue buffers of a wave live in the 1 KiB slices of U2 / U3 that the SAME wave's K-loop DMA instructions fill
+// (instruction i of wave w -> bytes [(4i + w) KiB, +1 KiB) of a unit): slice s = 0..15 of wave w.  A 4 KiB buffer
+// (32 rows x 128 B) takes four consecutive slices, row r at slice (r >> 3), byte (r & 7) * 128.  Slices 0-11: the
+// residual ring (3 patches); 12-15: the bf16 staging patch.  Because no wave ever touches another wave's slices
+// here, K step 1 of the next tile can be issued by each wave as soon as ITS epilogue is done -- no barrier.
+#define G7E_SLICE(S, WAVE) (2 * G7_UNIT_BYTES + ((S) >> 3) * G7_UNIT_BYTES + ((((S) & 7) * 4 + (WAVE)) * 1024))
+#define G7E_ROW(R) (((R) >> 3) * 4096 + ((R) & 7) * 128)
 #define G7_TAB_OFF (4 * G7_UNIT_BYTES)
 #define G7_ETAB_OFF (G7_TAB_OFF + 8192)
 
@@ -120,7 +124,8 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
     }
     if (tr && threadIdx.x == 0) { tr[0] = clock64(); tr[30] = wall_clock64(); }
     // ---- tile start: K step 1 into U2, U3 (free once every wave has left the previous epilogue) --------------------
-    if (pending) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    // (U2 / U3: this wave's epilogue buffers were exactly the slices its own DMA instructions fill -- no barrier)
+    if (pending) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (nk > 1) {
       g7_fill(src.a + G7_ROW_BYTES, src.oa, smem + 2 * G7_UNIT_BYTES, wave);
       g7_fill(src.b + G7_ROW_BYTES, src.ob, smem + 3 * G7_UNIT_BYTES, wave);
@@ -129,51 +134,58 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
     if (pending) { if (nk > 1) G7_WAIT_VM(48); else G7_WAIT_VM(32); }
     else { if (nk > 1) G7_WAIT_VM(16); else G7_WAIT_VM(0); }
     if (tr && threadIdx.x == 0) tr[1] = clock64();
-    // ---- accumulators start at the bias, or at b'_n / rstd_m - mu_m s_n for a raw pre-LayerNorm A operand (gemm_wide6.h)
-    // (per-lane values of this section and of the epilogue derive from an OPAQUE copy of the lane id: otherwise the
-    // compiler hoists dozens of loop-invariant addresses out of the tile loop and spills them around the K loop)
+    // ---- accumulators start at the bias, or at b'_n / rstd_m - mu_m s_n for a raw pre-LayerNorm A operand
+    // (gemm_wide6.h) -- written by ONE extra MFMA sub-step instead of 256 vector moves: the rank-2 product
+    //     u_m b_n + v_m s_n      (u = 1 or 1 / rstd_m, v = 0 or -mu_m)
+    // with every factor split into bf16 hi + lo, k slots (u_hi b_hi, u_lo b_hi, u_hi b_lo, v_hi s_hi, v_lo s_hi,
+    // v_hi s_lo): relative error 2^-16 of each term, far below the bf16 rounding of the output.  (Per-lane values of
+    // this section and of the epilogue derive from an OPAQUE copy of the lane id: otherwise the compiler hoists
+    // dozens of loop-invariant addresses out of the tile loop and spills them around the K loop.)
     f32x16_t acc[4][4];
     float rs[4] = {1.f, 1.f, 1.f, 1.f};
     {
+      typedef typename MmaOps<T>::frag_t frag_t;
       int lane_i = lane0;
       asm volatile("" : "+v"(lane_i));
       const int l31 = lane_i & 31, half = lane_i >> 5;
       const char* tab = smem + G7_TAB_OFF + wave * 2048;
       const bool ln_in = LNF == 1 && ep.ln_stats != nullptr;
-      float mu[4] = {0.f, 0.f, 0.f, 0.f}, inv[4] = {1.f, 1.f, 1.f, 1.f};
-      if (ln_in) {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-          const float2 st = *(const float2*)(tab + 1024 + (mi * 32 + l31) * 8);
-          mu[mi] = ep.ln_rms ? 0.f : st.x * ep.ln_inv_h;
-          const float var = fmaxf(st.y * ep.ln_inv_h - mu[mi] * mu[mi], 0.f) + ep.ln_eps;
-          rs[mi] = rsqrtf(var);
-          inv[mi] = sqrtf(var);
-        }
-      }
       const bool has_cs = LNF == 1 && ep.ln_colsum != nullptr, has_b = ep.bias != nullptr;
+      auto split = [](float x, uint32_t& hi, uint32_t& lo) {
+        const bf16_t h = f32_to_bf16(x);
+        hi = h; lo = f32_to_bf16(x - bf16_to_f32(h));
+      };
+      frag_t fa[4], fb[4];
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f32x4_t b4 = *(const f32x4_t*)(tab + 512 + (ni * 32 + 8 * j + 4 * half) * 4);
-          if (!has_b) b4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-          if (ln_in) {
-            f32x4_t s4 = *(const f32x4_t*)(tab + (ni * 32 + 8 * j + 4 * half) * 4);
-            if (!has_cs) s4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc[mi][ni][4 * j + e] = fmaf(-mu[mi], s4[e], b4[e] * inv[mi]);
-          } else {
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc[mi][ni][4 * j + e] = b4[e];
-          }
-          // a finished accumulator tile moves to its AGPRs now (otherwise all 256 initial values sit in VGPRs first)
-          if (j == 3) asm volatile("" : "+a"(acc[0][ni]), "+a"(acc[1][ni]), "+a"(acc[2][ni]), "+a"(acc[3][ni]));
+      for (int mi = 0; mi < 4; ++mi) {
+        float u = 1.f, v = 0.f;
+        if (ln_in) {
+          const float2 st = *(const float2*)(tab + 1024 + (mi * 32 + l31) * 8);
+          const float mu = ep.ln_rms ? 0.f : st.x * ep.ln_inv_h;
+          const float var = fmaxf(st.y * ep.ln_inv_h - mu * mu, 0.f) + ep.ln_eps;
+          rs[mi] = rsqrtf(var);
+          u = sqrtf(var); v = -mu;
         }
+        uint32_t uh, ul, vh, vl;
+        split(u, uh, ul); split(v, vh, vl);
+        uint4 w = make_uint4(uh | (ul << 16), uh | (vh << 16), vl | (vh << 16), 0u);     // k: u_hi u_lo u_hi v_hi v_lo v_hi 0 0
+        if (half) w = make_uint4(0u, 0u, 0u, 0u);
+        fa[mi] = __builtin_bit_cast(frag_t, w);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        float b = *(const float*)(tab + 512 + (ni * 32 + l31) * 4), sc = *(const float*)(tab + (ni * 32 + l31) * 4);
+        if (!has_b) b = 0.f;
+        if (!(ln_in && has_cs)) sc = 0.f;
+        uint32_t bh, bl, sh, sl;
+        split(b, bh, bl); split(sc, sh, sl);
+        uint4 w = make_uint4(bh | (bh << 16), bl | (sh << 16), sh | (sl << 16), 0u);     // k: b_hi b_hi b_lo s_hi s_hi s_lo 0 0
+        if (half) w = make_uint4(0u, 0u, 0u, 0u);
+        fb[ni] = __builtin_bit_cast(frag_t, w);
+      }
+      const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { acc[q >> 2][q & 3] = zero; MmaOps<T>::mma(fb[q & 3], fa[q >> 2], acc[q >> 2][q & 3]); }
     }
     gemm_mainloop7_run<T, 0>(src, nk, smem, acc, tr, pending);     // waits again (a no-op now), barrier, K loop, barrier
     if (tr && threadIdx.x == 0) tr[15] = clock64();
@@ -195,16 +207,15 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
     uint32_t roff[4];                                                    // row (lane >> 3) of an 8-row group, swizzled source chunk
 #pragma unroll
     for (int k = 0; k < 4; ++k) roff[k] = (uint32_t)((lane >> 3) * ldr2) + (((lane & 7) ^ ((4 * k + (lane >> 4)) & 7)) << 4);
-    char* const ring = smem + G7E_RING_OFF + wave * (G7E_RES_DEPTH * G7E_PATCH_BYTES);
-    char* const stage = smem + G7E_STAGE_OFF + wave * G7E_PATCH_BYTES;
+    char* const stage = smem + G7E_SLICE(12, wave);
     const char* const etab = smem + G7_ETAB_OFF + wave * 2048;
     const bool res_ln = LNF == 2 && ep.rln_stats != nullptr;
     // residual patch p = (mi, nh): 32 rows x 128 B, chunk position XOR ((row >> 1) & 7); 4 instructions of 8 rows
 #define G7E_RES_DMA(P_)                                                                                        \
   do {                                                                                                         \
-    const uint32_t buf = g7_lds_addr(ring) + ((P_) % G7E_RES_DEPTH) * G7E_PATCH_BYTES;                         \
+    const uint32_t buf = g7_lds_addr(smem) + G7E_SLICE(((P_) % G7E_RES_DEPTH) * 4, wave);                      \
     const char* const pbase = rbase + (size_t)(((P_) >> 1) * 32) * ldr2 + ((P_) & 1) * 128;                    \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k) g7_dma(pbase + (size_t)(8 * k) * ldr2, roff[k], buf + k * 1024); \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) g7_dma(pbase + (size_t)(8 * k) * ldr2, roff[k], buf + k * 4096); \
   } while (0)
     if (LNF == 2) {        // gamma | beta of my 128 columns, statistics of my 128 residual rows (dummies when not normalised)
       g7_table2(res_ln ? ep.rln_g + nc : (const float*)A, res_ln ? ep.rln_b + nc : (const float*)A, (char*)etab, lane);
@@ -219,8 +230,8 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
     float ra[4] = {1.f, 1.f, 1.f, 1.f}, rc[4] = {0.f, 0.f, 0.f, 0.f};
     f32x2_t ssum = {0.f, 0.f}, ssq = {0.f, 0.f};
     const int skey = l31 & 7;
-    char* const st_wr = stage + l31 * 128 + 8 * half;
-    const char* const st_rd = stage + (lane >> 3) * 128;
+    char* const st_wr = stage + G7E_ROW(l31) + 8 * half;
+    const char* const st_rd = stage + (lane >> 3) * 128;               // read-back pass i4 covers rows 8 i4 .. 8 i4 + 7 = slice i4
     char* const cbase = (char*)(C + mc * ldc + nc);                     // wave-uniform; the per-lane part is 32 bits
     const uint32_t coff = (uint32_t)((lane >> 3) * ldc2) + (lane & 7) * 16;
 #define G7E_WRITE(P_)                                                                                          \
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
     const int64_t m = mc + MI * 32 + l31;                                                                      \
     uint2 rpatch[2][4];                                                                                        \
     if (RESID) {                                                                                               \
-      const char* buf = ring + ((P_) % G7E_RES_DEPTH) * G7E_PATCH_BYTES + l31 * 128 + 8 * half;                \
+      const char* buf = smem + G7E_SLICE(((P_) % G7E_RES_DEPTH) * 4, wave) + G7E_ROW(l31) + 8 * half;          \
       _Pragma("unroll") for (int nl = 0; nl < 2; ++nl)                                                         \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                          \
           rpatch[nl][j] = *(const uint2*)(buf + (((nl * 4 + j) ^ ((l31 >> 1) & 7)) << 4));                     \
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
     if (tr && threadIdx.x == 0) tr[16] = clock64();
     G7E_WRITE(0);
     G7_FENCE_();
-#define G7E_RB(I4) (*(const uint4*)(st_rd + (I4) * 8 * 128 + (((lane & 7) ^ (((lane >> 3) + (I4) * 8) & 7)) << 4)))
+#define G7E_RB(I4) (*(const uint4*)(st_rd + (I4) * 4096 + (((lane & 7) ^ (((lane >> 3) + (I4) * 8) & 7)) << 4)))
 #define G7E_ST(PP, I4, V) *(uint4*)(cbase + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128 + coff) = V
 #define G7E_ITER(P_, YWAIT)                                                                                    \
   do {                                                                                                         \

@@ -124,3 +124,27 @@ def merge_topk(part_scores: torch.Tensor, part_ids: torch.Tensor, k_out: int):
         N.check(N.lib().om_topk_merge(N.ptr(ps), N.ptr(pi), W, Q, k_in, k_out, N.ptr(D), N.ptr(I),
                                       N.stream_ptr(ps.device)))
     return D, I
+
+
+def sharded_topk(index, queries: torch.Tensor, k: int, id_offset: int, merge=None):
+    """Exact top-k of `queries` (the SAME [Q,d] tensor on every rank) over an index row-sharded across the ranks of the
+    default process group: search the local shard, exchange candidates BY QUERY RANGE with one all-to-all (rank r
+    receives every shard's [Q/W, k] candidates for its slice -- point-to-point xGMI traffic, no rank collects W full
+    result sets), merge the W lists of the slice on the GPU.  Returns (D [blk,k], I [blk,k], blk): this rank's slice
+    rows [rank*blk, (rank+1)*blk) of the merged result (rows past Q are padding)."""
+    import torch.distributed as dist
+    W = dist.get_world_size()
+    dev = queries.device
+    Q = queries.shape[0]
+    D, I = index.search_device(queries, k, id_offset=id_offset)
+    D, I = D.to(dev), I.to(dev)
+    blk = (Q + W - 1) // W
+    pad = blk * W - Q
+    if pad:
+        D = torch.cat([D, torch.full((pad, k), -3.4028235e38, dtype=D.dtype, device=dev)])
+        I = torch.cat([I, torch.full((pad, k), -1, dtype=I.dtype, device=dev)])
+    recv_D, recv_I = torch.empty_like(D), torch.empty_like(I)
+    dist.all_to_all_single(recv_D, D.contiguous())              # block w of recv = shard w's candidates for MY queries
+    dist.all_to_all_single(recv_I, I.contiguous())
+    Dm, Im = (merge or merge_topk)(recv_D.view(W, blk, k), recv_I.view(W, blk, k), k)
+    return Dm.to(dev), Im.to(dev), blk

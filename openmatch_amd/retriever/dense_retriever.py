@@ -28,7 +28,7 @@ from tqdm import tqdm
 
 from ..arguments import InferenceArguments as EncodingArguments
 from ..dataset import DRInferenceCollator
-from ..index import FlatIPIndex, merge_topk
+from ..index import FlatIPIndex, merge_topk, sharded_topk
 from ..modeling import DRModelForInference, DROutput
 from ..utils import merge_retrieval_results_by_score
 
@@ -232,8 +232,11 @@ class Retriever:
         return result
 
     def _search_sharded(self, topk):
-        """Collective over all ranks: all-gather queries, search local shard, gather + merge on
-        rank 0.  Returns the result dict on rank 0 and {} elsewhere (as `retrieve` does)."""
+        """Collective over all ranks: all-gather the queries, search the local shard, then merge BY QUERY RANGE --
+        rank r receives every shard's candidates for its own slice of the queries (one all-to-all, (W-1)/W of
+        Q x k x 12 bytes per rank over point-to-point xGMI links instead of W-1 full result sets into rank 0),
+        merges them with the HIP top-k merge, and only the merged [Q/W, k] blocks travel to rank 0 for the result
+        dict.  Returns the dict on rank 0 and {} elsewhere (as `retrieve` does)."""
         W, r, dev = self.args.world_size, self.args.process_index, self.args.device
         if self._resident_queries is not None:
             q_local, ids_local = self._resident_queries
@@ -250,16 +253,17 @@ class Retriever:
         gathered = torch.empty(W * nmax, dim, dtype=torch.float32, device=dev)
         dist.all_gather_into_tensor(gathered, padded)
         queries = torch.cat([gathered[i * nmax:i * nmax + counts[i][0]] for i in range(W)])
-        D, I = self.index.search_device(queries, topk, id_offset=self._shard_offset)
-        parts_D = [torch.empty_like(D) for _ in range(W)] if r == 0 else None
-        parts_I = [torch.empty_like(I) for _ in range(W)] if r == 0 else None
-        dist.gather(D, parts_D, dst=0)
-        dist.gather(I, parts_I, dst=0)
+        Q = queries.shape[0]
+        Dm, Im, _blk = sharded_topk(self.index, queries, topk, self._shard_offset, merge=merge_topk)
+        parts_D = [torch.empty_like(Dm) for _ in range(W)] if r == 0 else None
+        parts_I = [torch.empty_like(Im) for _ in range(W)] if r == 0 else None
+        dist.gather(Dm.contiguous(), parts_D, dst=0)
+        dist.gather(Im.contiguous(), parts_I, dst=0)
         if r != 0:
             return {}
-        Dm, Im = merge_topk(torch.stack(parts_D), torch.stack(parts_I), topk)
+        Dall, Iall = torch.cat(parts_D)[:Q], torch.cat(parts_I)[:Q]
         self.query_lookup.extend(x for c in counts for x in c[1])
-        return self._hits_to_dict(Dm.cpu().numpy(), Im.cpu().numpy(), topk)
+        return self._hits_to_dict(Dall.cpu().numpy(), Iall.cpu().numpy(), topk)
 
     def retrieve(self, query_dataset: IterableDataset, topk: int = 100):
         self.query_embedding_inference(query_dataset)

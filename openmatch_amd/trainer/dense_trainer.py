@@ -48,25 +48,46 @@ def parameter_groups(model, weight_decay: float):
 
 def allreduce_mean_(params: List[torch.nn.Parameter], world_size: int, bucket_bytes: int = 256 << 20):
     """Gradient averaging across ranks = what DistributedDataParallel does for the reference.
-    Gradients are packed into few large flat buckets: xGMI is point-to-point, a ring all-reduce is
-    per-link bound, so per-call latency (not bandwidth) is what many small calls would waste."""
+
+    The HIP backward writes every parameter gradient of an encoder into ONE zero-initialised f32 arena and hands
+    autograd views of it (openmatch_amd/train.py), so `p.grad` of a whole model normally share one storage: that
+    storage span is all-reduced IN PLACE with a single collective -- no flatten copy, no copy back.  (xGMI is
+    point-to-point: a ring all-reduce is per-link bound, so one large call beats many small ones.)  Gradients that
+    live elsewhere (a head trained by plain autograd, CPU tests) go through flat copy buckets of `bucket_bytes`."""
     grads = [p.grad for p in params if p.grad is not None]
+
+    def reduce_(flat):
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(flat)
+            flat /= world_size
+
+    by_store = {}
+    for g in grads:
+        by_store.setdefault((g.untyped_storage().data_ptr(), g.dtype, g.device), []).append(g)
+    loose = []
+    for (_, dtype, _dev), gs in by_store.items():
+        lo = min(g.storage_offset() for g in gs)
+        hi = max(g.storage_offset() + g.numel() for g in gs)
+        dense = all(g.is_contiguous() for g in gs) and sum(g.numel() for g in gs) * 2 >= (hi - lo)
+        if len(gs) > 1 and dense:
+            span = torch.empty(0, dtype=dtype, device=gs[0].device).set_(gs[0].untyped_storage(), lo, (hi - lo,))
+            reduce_(span)                                   # the views in `gs` see the averaged values
+        else:
+            loose.extend(gs)
     bucket, size = [], 0
 
     def flush():
         if not bucket:
             return
         flat = torch.cat([g.reshape(-1) for g in bucket])
-        if dist.get_backend() == "nccl":
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG)
-        else:
-            dist.all_reduce(flat)
-            flat /= world_size
+        reduce_(flat)
         off = 0
         for g in bucket:
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
-    for g in grads:
+    for g in loose:
         bucket.append(g)
         size += g.numel() * g.element_size()
         if size >= bucket_bytes:

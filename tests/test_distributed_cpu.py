@@ -115,6 +115,22 @@ def _train_worker(rank, world, port, out_q):
     p = torch.nn.Parameter(torch.zeros(3)); p.grad = torch.full((3,), float(rank + 1))
     allreduce_mean_([p], world)
     assert torch.allclose(p.grad, torch.full((3,), 1.5))
+    # gradients that are views of ONE arena (what the HIP backward hands autograd): averaged in place with a single
+    # collective over the arena span -- the views keep their storage, padding between them stays zero
+    arena = torch.zeros(64)
+    shapes, views, off = [(3, 4), (5,), (2, 3)], [], 0
+    for shp in shapes:
+        n = int(np.prod(shp))
+        views.append(arena[off:off + n].view(*shp)); off += (n + 15) // 16 * 16
+    params = [torch.nn.Parameter(torch.zeros(*shp)) for shp in shapes]
+    for i, (q_, v) in enumerate(zip(params, views)):
+        v.fill_(float((rank + 1) * (i + 1))); q_.grad = v
+    ptr = arena.data_ptr()
+    allreduce_mean_(params, world)
+    for i, q_ in enumerate(params):
+        assert q_.grad.data_ptr() >= ptr and q_.grad.untyped_storage().data_ptr() == arena.untyped_storage().data_ptr()
+        assert torch.allclose(q_.grad, torch.full_like(q_.grad, 1.5 * (i + 1)))
+    assert float(arena[12:16].abs().sum()) == 0.0
     # loss convention: every rank computes world * mean-CE over the gathered batch; after the mean
     # all-reduce the parameter gradient equals that of the plain global mean-CE
     qs = [torch.randn(2, 8, generator=torch.Generator().manual_seed(10 + r)) for r in range(world)]

@@ -221,8 +221,8 @@ def test_drivers_end_to_end(tok, tmp_path):
                 + QUERY_FLAGS + ["--trec_save_path", tmp_path / "run3.trec"])
     run3 = load_from_trec(str(tmp_path / "run3.trec"))
     assert sorted(run3) == sorted(run)
-    for q in qry_ids:
-        assert sorted(run3[q], key=run3[q].get, reverse=True) == sorted(run[q], key=run[q].get, reverse=True)
+    for q in qry_ids:          # same documents, same scores (the order of near-equal scores may differ between two summation orders)
+        assert set(run3[q]) == set(run[q])
         assert max(abs(run3[q][d] - run[q][d]) for d in run[q]) < 1e-5
     # ... and with a depth smaller than a partition, through the classes themselves (the merge has to truncate)
     from types import SimpleNamespace
