@@ -82,7 +82,10 @@ void om_debug_gemm_gen(int gen);
 #define OM_OPT_ENCODER_FUSED_LN 0
 #define OM_OPT_ENCODER_DEBUG 1
 #define OM_OPT_ATTENTION_FAST 2   /* 1 (default): bf16 inference attention on the low-instruction-count kernel; 0: the generic kernel */
-#define OM_OPT_COUNT 3
+#define OM_OPT_SCAN_GEN7 3        /* 1 (default): f16 index scan of wide query batches on the persistent generation-7 kernel; 0: generation 6 */
+#define OM_OPT_SCAN_GROWTH 4      /* fast schedule of the index scan: rows scanned per round grow by this many percent of the rows already
+                                    * scanned (default 60; smaller = more rounds, tighter thresholds, fewer appends per tile) */
+#define OM_OPT_COUNT 5
 int om_debug_option(int opt, int value);
 int om_kernel_timing_enable(int enable);
 int om_kernel_timing_read(int kernel_class, double* total_ms, int64_t* launches, double* flops);
@@ -289,6 +292,29 @@ int om_contrastive_fwd_bwd_ex(const float* q, const float* p, int Qg, int Pg, in
                               int reduction, const float* row_grad, float loss_scale, int q_row0, int q_rows,
                               int p_row0, int p_rows, float* loss, float* scores, float* d_q, float* d_p,
                               float* workspace, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Multi-GPU collectives over RCCL / xGMI (one process per GPU).  What the reference does through torch.distributed
+ * + NCCL and faiss-GPU, behind plain pointers:
+ *   om_allgather_rows   DRModel.dist_gather_tensor (modeling/dense_retrieval_model.py:247-258; loss.py:33-38):
+ *                       recv[w*rows:(w+1)*rows] = rank w's rows, rank-major
+ *   om_allreduce_grads  the gradient averaging DistributedDataParallel does under HF Trainer
+ *                       (trainer/dense_trainer.py:27-108): in place over one flat f32 buffer
+ *   om_exchange_topk    the shard-merge traffic of the faiss-GPU index (retriever/dense_retriever.py:43-58),
+ *                       re-cut by query range: block w of this shard's [world][q_block][k] candidates goes to rank w
+ *                       (follow with om_topk_merge on the received [world][q_block][k])
+ * A communicator is created from a 128-byte unique id: rank 0 calls om_comm_unique_id, the host layer broadcasts it
+ * over whatever rendezvous it has (openmatch_amd: the torch.distributed store), every rank calls om_comm_init with
+ * its HIP device current.  RCCL is bound at run time; all calls are asynchronous on `stream`.
+ * ------------------------------------------------------------------------ */
+#define OM_COMM_ID_BYTES 128
+int om_comm_unique_id(void* id128);
+int om_comm_init(const void* id128, int world, int rank, void** comm);
+int om_comm_destroy(void* comm);
+int om_allgather_rows(void* comm, const void* send, void* recv, int64_t rows, int64_t row_bytes, void* stream);
+int om_allreduce_grads(void* comm, float* buf, int64_t n, int average, void* stream);
+int om_exchange_topk(void* comm, int world, const float* D, const int64_t* I, int64_t q_block, int k, float* recvD,
+                     int64_t* recvI, void* stream);
 
 #ifdef __cplusplus
 }

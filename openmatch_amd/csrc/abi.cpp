@@ -82,6 +82,10 @@ void opt_init() {
   g_opt[OM_OPT_ENCODER_DEBUG] = getenv("OM_ENCODER_DEBUG") ? 1 : 0;
   e = getenv("OM_ATTENTION_FAST");
   g_opt[OM_OPT_ATTENTION_FAST] = e ? atoi(e) : 1;
+  e = getenv("OM_SCAN_GEN7");
+  g_opt[OM_OPT_SCAN_GEN7] = e ? atoi(e) : 1;
+  e = getenv("OM_SCAN_GROWTH");
+  g_opt[OM_OPT_SCAN_GROWTH] = e ? atoi(e) : 60;
   g_opt_init.store(true);
 }
 }  // namespace

@@ -30,6 +30,7 @@ void om_set_error(const std::string& msg);
     hipError_t _e = (expr);                                                 \
     if (_e != hipSuccess) {                                                 \
       om_set_error(std::string(__func__) + ": " #expr " -> " + hipGetErrorString(_e)); \
+      (void)hipGetLastError(); /* reported here: do not leave it sticky for the host framework's next check */ \
       return 1;                                                             \
     }                                                                       \
   } while (0)

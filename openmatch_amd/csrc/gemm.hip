@@ -116,6 +116,7 @@ bool omk_gemm_ln_fusable(int dtype, int64_t M, int64_t N, int64_t K) {
 
 static unsigned long long* g_trace = nullptr;
 extern "C" void om_debug_gemm_trace(unsigned long long* buf) { g_trace = buf; }
+unsigned long long* omk_debug_trace() { return g_trace; }      // the scan kernel of search.hip stamps into the same buffer
 static int g_debug_gen = 0;     // 0: default selection; 6: never generation 7; 70: generation 7 with one tile per workgroup (A/B)
 extern "C" void om_debug_gemm_gen(int gen) { g_debug_gen = gen; }
 bool omk_gemm_wide7_has(int act, bool resid, int lnf);

@@ -43,22 +43,26 @@
 // work id -> tile, XCD aware: the 32 workgroups of an XCD (block b runs on XCD b % 8) take 32 CONSECUTIVE tiles of the
 // grouped order (group_m row tiles sweeping the column tiles) in every round, so the panels they share stay in that L2.
 __device__ __forceinline__ bool g7_tile(int it, int64_t ntm, int64_t ntn, int group_m, int64_t& m0, int64_t& n0) {
-  const int64_t ntiles = ntm * ntn;
-  int64_t w;
+  // 32-bit arithmetic throughout (the launchers refuse ntm * ntn >= 2^31): the 64-bit divisions of the first version
+  // were ~700 dependent scalar instructions per tile on the only wave of each SIMD
+  const uint32_t tm = (uint32_t)ntm, tn = (uint32_t)ntn, gm = (uint32_t)group_m;
+  const uint32_t ntiles = tm * tn;
+  uint32_t w;
   if ((gridDim.x & 7) == 0) {
-    const int nslots = gridDim.x >> 3;
-    w = ((int64_t)it * 8 + (blockIdx.x & 7)) * nslots + (blockIdx.x >> 3);
+    const uint32_t nslots = gridDim.x >> 3;
+    w = ((uint32_t)it * 8 + (blockIdx.x & 7)) * nslots + (blockIdx.x >> 3);
   } else {
-    w = (int64_t)it * gridDim.x + blockIdx.x;
+    w = (uint32_t)it * gridDim.x + blockIdx.x;
   }
   if (w >= ntiles) return false;
-  const int64_t per_group = (int64_t)group_m * ntn;
-  const int64_t g = w / per_group;
-  const int64_t first_m = g * group_m;
-  const int64_t gsz = (ntm - first_m) < group_m ? (ntm - first_m) : group_m;
-  const int64_t in_g = w % per_group;
-  m0 = (first_m + in_g % gsz) * 256;
-  n0 = (in_g / gsz) * 256;
+  const uint32_t per_group = gm * tn;
+  const uint32_t g = w / per_group;
+  const uint32_t first_m = g * gm;
+  const uint32_t gsz = (tm - first_m) < gm ? (tm - first_m) : gm;
+  const uint32_t in_g = w - g * per_group;
+  const uint32_t col = in_g / gsz;
+  m0 = (int64_t)(first_m + (in_g - col * gsz)) * 256;
+  n0 = (int64_t)col * 256;
   return true;
 }
 
@@ -298,33 +302,39 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
       }
     }
     if (tr && threadIdx.x == 0) tr[16] = clock64();
+    // Software pipeline over the 8 patches: WRITE(p+1) -> read-back of p+1 ISSUED at once (its data is only needed one
+    // iteration later, behind the next patch's conversion work) -> stores of patch p from the registers read one
+    // iteration ago.  A wave's LDS operations execute in order, so the single staging buffer needs no waits.
     G7E_WRITE(0);
     G7_FENCE_();
 #define G7E_RB(I4) (*(const uint4*)(st_rd + (I4) * 4096 + (((lane & 7) ^ (((lane >> 3) + (I4) * 8) & 7)) << 4)))
 #define G7E_ST(PP, I4, V) *(uint4*)(cbase + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128 + coff) = V
-#define G7E_ITER(P_, YWAIT)                                                                                    \
+    uint4 sa0 = G7E_RB(0), sa1 = G7E_RB(1), sa2 = G7E_RB(2), sa3 = G7E_RB(3), sb0, sb1, sb2, sb3;
+    G7_FENCE_();
+    // CUR / NXT: the register sets holding patch P_ (read last iteration) and patch P_ + 1 (read now)
+#define G7E_ITER(P_, YWAIT, C0, C1, C2, C3, N0, N1, N2, N3)                                                    \
   do {                                                                                                         \
-    const uint4 stv0 = G7E_RB(0), stv1 = G7E_RB(1), stv2 = G7E_RB(2), stv3 = G7E_RB(3);                         \
-    G7_FENCE_();                                                                                               \
     if ((P_) + 1 < 8) {                                                                                        \
       if (RESID) {                                                                                             \
         if ((P_) + 3 < 8) G7E_RES_DMA((P_) + 3);                                                               \
         G7_WAIT_VM(YWAIT);                                                                                     \
       }                                                                                                        \
       G7E_WRITE((P_) + 1);                                                                                     \
+      G7_FENCE_();                                                                                             \
+      N0 = G7E_RB(0); N1 = G7E_RB(1); N2 = G7E_RB(2); N3 = G7E_RB(3);                                          \
     }                                                                                                          \
     G7_FENCE_();                                                                                               \
-    G7E_ST(P_, 0, stv0); G7E_ST(P_, 1, stv1); G7E_ST(P_, 2, stv2); G7E_ST(P_, 3, stv3);                                      \
+    G7E_ST(P_, 0, C0); G7E_ST(P_, 1, C1); G7E_ST(P_, 2, C2); G7E_ST(P_, 3, C3);                                 \
     G7_FENCE_();                                                                                               \
   } while (0)
-    G7E_ITER(0, 2 * R + PF + TI);
-    G7E_ITER(1, 2 * R + PF + TI + A2 + 4);
-    G7E_ITER(2, 2 * R + 8 + A2);
-    G7E_ITER(3, 2 * R + 8 + A2);
-    G7E_ITER(4, 2 * R + 8 + A2);
-    G7E_ITER(5, R + 8 + A2);
-    G7E_ITER(6, 8 + A2);
-    G7E_ITER(7, 0);
+    G7E_ITER(0, 2 * R + PF + TI, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
+    G7E_ITER(1, 2 * R + PF + TI + A2 + 4, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+    G7E_ITER(2, 2 * R + 8 + A2, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
+    G7E_ITER(3, 2 * R + 8 + A2, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+    G7E_ITER(4, 2 * R + 8 + A2, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
+    G7E_ITER(5, R + 8 + A2, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+    G7E_ITER(6, 8 + A2, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
+    G7E_ITER(7, 0, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
 #undef G7E_ITER
 #undef G7E_RB
 #undef G7E_ST
@@ -352,6 +362,7 @@ template <typename T, int ACT, bool RESID, int LNF>
 static int launch7(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                    int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
   const int64_t ntiles = (M / 256) * (N / 256);
+  if (ntiles >= 0x7fff0000LL) OM_FAIL("gemm: more than 2^31 output tiles");      // g7_tile works in 32 bits
   int grid = g7_num_cus();
   if (ntiles < grid) grid = (int)ntiles;
   static std::atomic<bool> attr_set{false};

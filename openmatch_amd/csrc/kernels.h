@@ -49,6 +49,7 @@ struct GemmEpilogue {
 };
 // true when omk_gemm will run [M,N] x K (16-bit) on the kernel that implements the ln_* / rln_* / stats_out fields
 bool omk_gemm_ln_fusable(int dtype, int64_t M, int64_t N, int64_t K);
+unsigned long long* omk_debug_trace();      // om_debug_gemm_trace buffer (NULL: off)
 // wide-tile generations, one translation unit each (gemm_wide4.hip / gemm_wide6_*.hip); omk_gemm dispatches
 int omk_gemm_wide4(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int out_dtype,
                    void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s);

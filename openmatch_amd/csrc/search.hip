@@ -24,6 +24,7 @@
 
 #include "gemm_core2.h"
 #include "gemm_core6.h"
+#include "gemm_wide7.h"
 #include "kernels.h"
 
 #define SORT_CAP 8192      // keys one workgroup sorts in LDS (64 KiB)
@@ -131,6 +132,147 @@ __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel6(
   }
 }
 
+// Survivors of the generation-7 scan.  A score passes its list's threshold about once in a thousand, but with 1024
+// scores per 32 x 32 block most blocks hold one: appending from inside the block walk (returning atomic on the list
+// counter -> wait -> store, per survivor, as generation 6 does) serialises ~7 L2 round trips per wave and tile
+// (profiles/r02_scan_trace_v0.log: 11.2k cycles of a 44.9k-cycle tile).  Instead the walk only STAGES survivors in
+// wave-private LDS -- position from the wave's ballot, no atomics -- and one flush per tile appends them with all lanes
+// in parallel: a single round trip.  Staging: keys in the wave's OWN DMA slices of units 2 and 3 (only this wave ever
+// writes them, and not before its next tile starts), 2048 of them; their query numbers in unit 4 behind the threshold
+// tables.  A block adds at most 1024 records, so one capacity check per block suffices.
+#define SC7_STAGE_CAP 2048
+#define SC7_QIDX_OFF (G7_TAB_OFF + 4096)
+__device__ __forceinline__ char* sc7_key_slot(char* smem, int wave, unsigned pos) {
+  return smem + (2 + (pos >> 10)) * G7_UNIT_BYTES + wave * 1024 + ((pos >> 7) & 7) * 4096 + (pos & 127) * 8;
+}
+__device__ __forceinline__ void sc7_flush(char* smem, int wave, unsigned& wcount, int lane, int64_t q0,
+                                          u64* __restrict__ keys, unsigned* __restrict__ cnt) {
+  for (unsigned i = (unsigned)lane; i < wcount; i += 64) {
+    const u64 key = *(const u64*)sc7_key_slot(smem, wave, i);
+    const int64_t q = q0 + *(const uint16_t*)(smem + SC7_QIDX_OFF + wave * (SC7_STAGE_CAP * 2) + i * 2);
+    const unsigned pos = atomicAdd(cnt + q, 1u);
+    if (pos < SORT_CAP) keys[q * SORT_CAP + pos] = key;
+  }
+  wcount = 0;
+}
+// whole tiles only: every row of the tile exists
+__device__ __forceinline__ void sc7_filter(f32x16_t (&acc)[4][4], const float (&th)[4], uint32_t id0, uint32_t ql0,
+                                           int lane, char* smem, int wave, unsigned& wcount, int64_t q0,
+                                           u64* __restrict__ keys, unsigned* __restrict__ cnt) {
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      asm volatile("" : "+a"(acc[mi][ni]));            // stays in its AGPRs until this point
+      const f32x16_t a = acc[mi][ni];
+      float mx = fmaxf(fmaxf(a[0], a[1]), a[2]);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, a[r]), a[r + 1]);
+      mx = fmaxf(mx, a[15]);
+      if (__builtin_amdgcn_ballot_w64(mx >= th[mi]) != 0) {          // wave-uniform: some lane holds a survivor
+        if (wcount > SC7_STAGE_CAP - 1024) sc7_flush(smem, wave, wcount, lane, q0, keys, cnt);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t off = (uint32_t)(ni * 32 + (r & 3) + 8 * (r >> 2));
+          const bool pass = a[r] >= th[mi];
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+          if (m != 0) {
+            if (pass) {
+              const unsigned pos = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+              *(u64*)sc7_key_slot(smem, wave, pos) = pack_key(a[r], id0 + off);
+              *(uint16_t*)(smem + SC7_QIDX_OFF + wave * (SC7_STAGE_CAP * 2) + pos * 2) = (uint16_t)(ql0 + mi * 32);
+            }
+            wcount += (unsigned)__builtin_popcountll(m);
+          }
+        }
+      }
+      G7_FENCE_();
+    }
+  }
+}
+
+// The same scan on generation 7 (gemm_core7.h / gemm_wide7.h): 128-byte K steps (whole-line LDS-DMA requests) in a
+// PERSISTENT kernel -- one workgroup per CU walks (query tile, row tile) pairs, the first K step of the next pair and its
+// 256 thresholds are fetched while the current pair is filtered.  The filter issues no regular stores (appends are rare
+// by construction of theta), so the only wait at a tile start is vmcnt(16): K step 1 may be outstanding, everything
+// older -- the prefetch, and an occasional append -- has landed.  16-bit inputs only (the f32 scan stays on generation 6).
+// `thr` must be readable up to round_up(nq, 256) + 256 entries (+inf beyond nq: carve_search / init_lists_kernel).
+template <typename T>
+__global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7(
+    const T* __restrict__ rows, int64_t nrows, uint32_t row_base, const T* __restrict__ queries,
+    int64_t nq, int64_t d, const float* __restrict__ thr, u64* __restrict__ keys,
+    unsigned* __restrict__ cnt, int group_m, unsigned long long* __restrict__ trace) {
+  typedef typename MmaOps<T>::frag_t frag_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane0 = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t ntr = (nrows + 255) / 256, ntq = (nq + 255) / 256;
+  const int nk = (int)((d * 2) / G7_ROW_BYTES);
+  int it = 0;
+  unsigned wcount = 0;                     // records in this wave's staging area (wave-uniform)
+  int64_t r0, q0;
+  if (!g7_tile(0, ntr, ntq, group_m, r0, q0)) return;      // `group_m` row tiles stay in L2 while the query tiles sweep them
+  G7Src src;
+  g7_point<T>(src, queries, d, rows, d, nq, nrows, q0, r0, wave, lane0);
+  g7_dma((const char*)(thr + q0 + wm * 128), lane0 * 16, g7_lds_addr(smem + G7_TAB_OFF + wave * 1024));
+  g7_fill(src.a, src.oa, smem, wave);
+  g7_fill(src.b, src.ob, smem + G7_UNIT_BYTES, wave);
+  for (;;) {
+    unsigned long long* tr = nullptr;          // debug: phase stamps of the first 8192 tiles (om_debug_gemm_trace)
+    if (trace) {
+      const int64_t tile_id = (r0 / 256) * ntq + q0 / 256;
+      if (tile_id < 8192) tr = trace + tile_id * 32;
+    }
+    if (tr && threadIdx.x == 0) { tr[0] = clock64(); tr[30] = wall_clock64(); }
+    if (nk > 1) {
+      g7_fill(src.a + G7_ROW_BYTES, src.oa, smem + 2 * G7_UNIT_BYTES, wave);
+      g7_fill(src.b + G7_ROW_BYTES, src.ob, smem + 3 * G7_UNIT_BYTES, wave);
+      G7_WAIT_VM(16);
+    } else {
+      G7_WAIT_VM(0);
+    }
+    if (tr && threadIdx.x == 0) tr[1] = clock64();
+    float th[4];
+    f32x16_t acc[4][4];
+    {
+      int lane_i = lane0;
+      asm volatile("" : "+v"(lane_i));
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) th[mi] = *(const float*)(smem + G7_TAB_OFF + wave * 1024 + (mi * 32 + (lane_i & 31)) * 4);
+      const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+      const frag_t zf = __builtin_bit_cast(frag_t, z4);
+      const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { acc[q >> 2][q & 3] = zero; MmaOps<T>::mma(zf, zf, acc[q >> 2][q & 3]); }   // zero by the matrix core
+    }
+    gemm_mainloop7_run<T, 0>(src, nk, smem, acc, tr, false);
+    if (tr && threadIdx.x == 0) tr[15] = clock64();
+    // next pair: its first K step and its thresholds are fetched under the filter below
+    ++it;
+    int64_t r1 = r0, q1 = q0;
+    const bool has_next = g7_tile(it, ntr, ntq, group_m, r1, q1);
+    G7Src nsrc;
+    g7_point<T>(nsrc, queries, d, rows, d, nq, nrows, q1, r1, wave, lane0);
+    g7_dma((const char*)(thr + q1 + wm * 128), lane0 * 16, g7_lds_addr(smem + G7_TAB_OFF + wave * 1024));
+    g7_fill(nsrc.a, nsrc.oa, smem, wave);
+    g7_fill(nsrc.b, nsrc.ob, smem + G7_UNIT_BYTES, wave);
+    G7_FENCE_();
+    {
+      int lane = lane0;
+      asm volatile("" : "+v"(lane));
+      const uint32_t id0 = row_base + (uint32_t)r0 + (uint32_t)(wn * 128 + 4 * (lane >> 5));    // row id of (ni = 0, r = 0)
+      const uint32_t ql0 = (uint32_t)(wm * 128 + (lane & 31));
+      sc7_filter(acc, th, id0, ql0, lane, smem, wave, wcount, q0, keys, cnt);
+      if (wcount) sc7_flush(smem, wave, wcount, lane, q0, keys, cnt);
+    }
+    if (tr && threadIdx.x == 0) { tr[28] = clock64(); tr[29] = blockIdx.x; tr[31] = wall_clock64(); }
+    if (!has_next) break;
+    src = nsrc; r0 = r1; q0 = q1;
+  }
+  G7_WAIT_VM(0);
+}
+
 // append a dense score block S[q, 0:n] (rows row_base..) to every list
 __global__ void append_dense_kernel(const float* __restrict__ S, int64_t ldS, int n,
                                     uint32_t row_base, u64* __restrict__ keys,
@@ -221,6 +363,90 @@ __global__ __launch_bounds__(SORT_THREADS) void select_kernel(
   }
 }
 
+// The per-round selection WITHOUT a sort: a round only needs the new threshold (the k-th best score so far) and the
+// list cut down to what can still matter; order is irrelevant until the very end.  Radix select over the 32 score bits
+// of the keys (4 passes of a 256-bin histogram in LDS, suffix sums by wave shuffles), then an unordered compaction of
+// everything >= the cut (exact mode: the k-th score, ties included; certified mode: k-th - 2 margin).  ~30x cheaper
+// than the 8192-key bitonic sort it replaces between rounds (profiles/r01_bench_v8_kernel_stats.csv: 8 x 2.3 ms).
+__global__ __launch_bounds__(256) void select_radix_kernel(
+    u64* __restrict__ keys, unsigned* __restrict__ cnt, float* __restrict__ thr, const float* __restrict__ margin,
+    int k, unsigned* __restrict__ flag) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u64* s = (u64*)smem;
+  unsigned* hist = (unsigned*)(smem + SORT_CAP * 8);          // 256 bins
+  unsigned* misc = hist + 256;                                // [0] bucket, [1] remaining, [2] keep counter, [4..7] wave totals
+  const int64_t q = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned n = cnt[q];
+  if (n > SORT_CAP) n = SORT_CAP;                            // (overflow is flagged by check_overflow_kernel)
+  u64* list = keys + q * SORT_CAP;
+  for (unsigned i = tid; i < n; i += 256) s[i] = list[i];
+  if (tid == 0) misc[2] = 0;
+  __syncthreads();
+  if (n <= (unsigned)k) {                                     // nothing to cut: keep everything
+    float mn = INFINITY;
+    for (unsigned i = tid; i < n; i += 256) mn = fminf(mn, key_score(s[i]));
+    mn = -wave_max(-mn);
+    float* wmin = (float*)(misc + 4);
+    if (lane == 0) wmin[wave] = mn;
+    __syncthreads();
+    if (tid == 0) {
+      float th = -INFINITY;                                   // fewer than k candidates so far: no threshold yet
+      if (n == (unsigned)k) {                                 // exactly k: the k-th best is the minimum
+        const float m4 = fminf(fminf(wmin[0], wmin[1]), fminf(wmin[2], wmin[3]));
+        th = margin ? m4 - 2.0f * margin[q] : m4;
+      }
+      thr[q] = th;
+      atomicMax(flag + 1, n);
+    }
+    return;
+  }
+  uint32_t prefix = 0, mask = 0;
+  unsigned remaining = (unsigned)k;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hist[tid] = 0;
+    __syncthreads();
+    for (unsigned i = tid; i < n; i += 256) {
+      const uint32_t v = (uint32_t)(s[i] >> 32);
+      if ((v & mask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    // suffix sums S[t] = sum_{b >= t} hist[b]: inside each wave by shuffles, across waves through misc[4..7]
+    const unsigned c = hist[tid];
+    unsigned suf = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned up = __shfl_down(suf, o, 64);
+      if (lane + o < 64) suf += up;
+    }
+    if (lane == 0) misc[4 + wave] = suf;                      // total of this wave's 64 bins
+    __syncthreads();
+    unsigned above = 0;                                       // bins of higher waves
+    for (int w = wave + 1; w < 4; ++w) above += misc[4 + w];
+    const unsigned S = suf + above, Snext = S - c;            // S[t] and S[t+1]
+    if (S >= remaining && Snext < remaining) { misc[0] = (unsigned)tid; misc[1] = remaining - Snext; }
+    __syncthreads();
+    prefix |= misc[0] << shift;
+    mask |= 255u << shift;
+    remaining = misc[1];
+    __syncthreads();
+  }
+  const float kth = orderable_f32(prefix);
+  const float cut = margin ? kth - 2.0f * margin[q] : kth;
+  for (unsigned i = tid; i < n; i += 256) {
+    const u64 key = s[i];
+    if (key_score(key) >= cut) list[atomicAdd(&misc[2], 1u)] = key;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned keep = misc[2];
+    cnt[q] = keep;
+    thr[q] = cut;
+    atomicMax(flag + 1, keep);
+    if (margin && keep > LIST_MAX) atomicOr(flag + 2, 1u);
+  }
+}
+
 // per-query certified margin and bf16 copy of the queries
 __global__ __launch_bounds__(256) void query_prep_kernel(const float* __restrict__ q,
                                                          f16_t* __restrict__ qb,
@@ -292,6 +518,7 @@ __global__ void emit_kernel(const u64* __restrict__ keys, const unsigned* __rest
 __global__ void init_lists_kernel(unsigned* cnt, unsigned* cnt_prev, float* thr, int64_t nq) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q < nq) { cnt[q] = 0; cnt_prev[q] = 0; thr[q] = -INFINITY; }
+  else if (q < (nq + 255) / 256 * 256 + 256) thr[q] = INFINITY;       // queries that do not exist never have survivors
 }
 
 // ---- K14: merge W sorted partial lists per query ------------------------------------------
@@ -363,7 +590,7 @@ static SearchWs carve_search(int64_t nq, int d, char* base) {
   w.cnt = (unsigned*)take((size_t)nq * 4);
   w.cnt_prev = (unsigned*)take((size_t)nq * 4);
   w.flag = (unsigned*)take(64);
-  w.thr = (float*)take((size_t)nq * 4);
+  w.thr = (float*)take(((size_t)(nq + 255) / 256 * 256 + 256) * 4);      // +inf beyond nq: the generation-7 scan reads whole tiles of thresholds
   w.margin = (float*)take((size_t)nq * 4);
   w.dense = (float*)take((size_t)nq * DENSE_CHUNK * 4);
   w.qb = (f16_t*)take((size_t)nq * d * 2);
@@ -390,6 +617,12 @@ struct Scan {
     hipLaunchKernelGGL(select_kernel, dim3((unsigned)nq), dim3(SORT_THREADS), SORT_CAP * 8 + 16, s,
                        ws.keys, ws.cnt, ws.cnt_prev, ws.thr, certified ? ws.margin : nullptr, k,
                        ws.flag);
+    OM_LAUNCH_CHECK();
+    return 0;
+  }
+  int select_radix(bool certified) {
+    hipLaunchKernelGGL(select_radix_kernel, dim3((unsigned)nq), dim3(256), SORT_CAP * 8 + 1024 + 64, s,
+                       ws.keys, ws.cnt, ws.thr, certified ? ws.margin : nullptr, k, ws.flag);
     OM_LAUNCH_CHECK();
     return 0;
   }
@@ -423,7 +656,20 @@ struct Scan {
   hipLaunchKernelGGL((KERNEL<TT>), grid, dim3(THREADS), LDS, s, ROWS + r0 * d, n, (uint32_t)r0, QUERIES, \
                      nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8)
     if (bf16) {
-      if (wide) SCAN(sim_filter_kernel6, G6_THREADS, G6_LDS_BYTES, f16_t, idx16, ws.qb);
+      if (wide && om_option(OM_OPT_SCAN_GEN7)) {
+        // generation 7 takes the whole 256-row tiles, generation 6 the ragged tail of the chunk (if any)
+        const int64_t whole = n & ~(int64_t)255;
+        if (whole) {
+          int ncu = g7_num_cus();
+          const int64_t tiles = (whole / 256) * ntn;
+          if (tiles < ncu) ncu = (int)tiles;
+          hipLaunchKernelGGL((sim_filter_kernel7<f16_t>), dim3((unsigned)ncu), dim3(G6_THREADS), G7_LDS_BYTES, s, idx16 + r0 * d, whole,
+                             (uint32_t)r0, ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8, omk_debug_trace());
+        }
+        if (n > whole)
+          hipLaunchKernelGGL((sim_filter_kernel6<f16_t>), dim3((unsigned)ntn), dim3(G6_THREADS), G6_LDS_BYTES, s, idx16 + (r0 + whole) * d,
+                             n - whole, (uint32_t)(r0 + whole), ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8);
+      } else if (wide) SCAN(sim_filter_kernel6, G6_THREADS, G6_LDS_BYTES, f16_t, idx16, ws.qb);
       else SCAN(sim_filter_kernel, G2_THREADS, G2_LDS_BYTES, f16_t, idx16, ws.qb);
     } else {
       if (wide) SCAN(sim_filter_kernel6, G6_THREADS, G6_LDS_BYTES, float, idx32, q32);
@@ -449,7 +695,7 @@ struct Scan {
   // returns 0 ok, 1 error, 2 certified margin too wide (caller retries in f32)
   int run(bool bf16) {
     OM_HIP(hipMemsetAsync(ws.flag, 0, 64, s));
-    hipLaunchKernelGGL(init_lists_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(init_lists_kernel, dim3((unsigned)((nq + 255) / 256 + 2)), dim3(256), 0, s,
                        ws.cnt, ws.cnt_prev, ws.thr, nq);
     OM_LAUNCH_CHECK();
     if (bf16) {
@@ -459,6 +705,7 @@ struct Scan {
     }
     int64_t done = 0;
     unsigned f[4];
+    bool unsorted = false;
     // bootstrap
     {
       const int n = (int)std::min<int64_t>(N, DENSE_CHUNK);
@@ -467,6 +714,51 @@ struct Scan {
       if (read_flags(f)) return 1;
       trace("boot", 0, n, f);
       if (f[2]) return 2;
+    }
+    // Fast schedule (default): the list length after a selection hardly moves (k plus ties / the certified margin),
+    // so the chunk sizes are fixed on the host from the bootstrap's list length and the rounds run back to back with
+    // NO host synchronisation: filtered scan -> overflow check (sticky flag) -> radix selection.  One read of the flags at
+    // the end; an overflow or a too-wide margin anywhere (adversarial row order) falls back to the step-by-step loop
+    // below from scratch, which is always exact.
+    if (om_option(OM_OPT_SCAN_GEN7) && N > done) {
+      const int64_t list = std::max<unsigned>(f[1], 1u);
+      const double growth = (double)std::max(5, om_option(OM_OPT_SCAN_GROWTH));
+      OM_HIP(hipMemsetAsync(ws.flag, 0, 64, s));
+      int64_t at = done;
+      while (at < N) {
+        // expected survivors of a chunk ~ list * chunk / at: `growth` percent keeps that many appends per list and round.
+        // The radix selection costs ~0.3 ms, an append costs the scan a serialised slow path, so MANY short rounds with
+        // tight thresholds beat few long ones (profiles/r02_scan_trace_*.log); the room left in the list caps it.
+        const double room = list <= 2048 ? 3800.0 - (double)list : (double)(SORT_CAP - list) / 2.0;
+        const double want = std::min(room, (double)list * growth / 100.0);
+        int64_t chunk = (int64_t)((double)at * want / (double)list);
+        chunk = std::max<int64_t>(chunk, DENSE_CHUNK) & ~(int64_t)255;      // whole tiles (DENSE_CHUNK is one)
+        chunk = std::min<int64_t>(chunk, N - at);
+        if (N - at - chunk < chunk / 4) chunk = N - at;           // no sliver of a last round
+        if (filter_step(at, chunk, bf16)) return 1;
+        if (select_radix(bf16)) return 1;
+        g_info[1]++;
+        at += chunk;
+      }
+      unsigned g[4];
+      if (read_flags(g)) return 1;
+      if (g[1] > (unsigned)g_info[3]) g_info[3] = g[1];
+      if (!g[0] && !g[2]) {
+        done = N;
+        f[1] = g[1];
+        unsorted = true;                         // the lists are cut but not ordered: one sort at the very end
+      } else {                                   // rare: start over on the careful path
+        g_info[2]++;
+        OM_HIP(hipMemsetAsync(ws.flag, 0, 64, s));
+        hipLaunchKernelGGL(init_lists_kernel, dim3((unsigned)((nq + 255) / 256 + 2)), dim3(256), 0, s,
+                           ws.cnt, ws.cnt_prev, ws.thr, nq);
+        OM_LAUNCH_CHECK();
+        const int n = (int)std::min<int64_t>(N, DENSE_CHUNK);
+        if (dense_step(0, n, bf16)) return 1;
+        done = n;
+        if (read_flags(f)) return 1;
+        if (f[2]) return 2;
+      }
     }
     while (done < N) {
       const int64_t list = std::max<unsigned>(f[1], 1u);
@@ -509,6 +801,8 @@ struct Scan {
                          idx32, ws.keys, ws.cnt, d);
       OM_LAUNCH_CHECK();
       if (select(false)) return 1;
+    } else if (unsorted) {
+      if (select(false)) return 1;               // exact mode after the radix rounds: best k, in order
     }
     return 0;
   }
@@ -547,6 +841,10 @@ extern "C" int om_sim_topk(int mode, const float* queries, int64_t n_queries,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES));
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel6<f16_t>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES));
+    OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel7<f16_t>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
+    OM_HIP(hipFuncSetAttribute((const void*)select_radix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               SORT_CAP * 8 + 1024 + 64));
     attr_set = true;
   }
   for (auto& v : g_info) v = 0;

@@ -99,7 +99,8 @@ int check_train_cfg(const OmEncoderConfig* c, int64_t L) {
   if (c->arch != OM_ARCH_BERT && c->arch != OM_ARCH_T5) OM_FAIL("unknown arch");
   if (c->dtype != OM_F32 && c->dtype != OM_BF16) OM_FAIL("dtype must be OM_F32 or OM_BF16");
   if (c->head_dim != 64 || c->n_heads * 64 != c->hidden) OM_FAIL("head_dim must be 64");
-  if (L < 1 || L > 128) OM_FAIL("training supports sequence lengths up to 128");
+  if (L < 1 || L > 256) OM_FAIL("training supports sequence lengths up to 256");
+  if (c->dtype != OM_BF16 && L > 192) OM_FAIL("float32 training supports sequence lengths up to 192 (bfloat16: 256)");
   if (c->arch == OM_ARCH_BERT && c->act != OM_ACT_GELU_ERF) OM_FAIL("BERT training supports the erf-GELU FFN");
   if (c->arch == OM_ARCH_T5 && (c->act & 0xff) != OM_ACT_RELU && (c->act & 0xff) != OM_ACT_GELU_TANH)
     OM_FAIL("T5 training supports relu and gated gelu_new feed-forward layers");

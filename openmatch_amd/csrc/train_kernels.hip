@@ -368,7 +368,8 @@ int omk_small_tn(const float* A, const float* Bm, float* C, int I, int J, int Cc
 }
 
 // ---------------------------------------------------------------------------------------
-// Attention backward for one (batch, head) per workgroup, L <= 128 (KT <= 4 key/query tiles).
+// Attention backward for one (batch, head) per workgroup, L <= 256 (KT <= 8 key/query tiles; KT = 6, 8 serve the
+// cross-encoder's 162-token pairs and long passages at one wave per SIMD).
 //   P = softmax(scale QK^T + mask), Pd = dropout(P), O = Pd V           (forward, recomputed)
 //   dPd = dO V^T ; dP = dropout'(dPd) ; dS = P o (dP - rowsum(P o dP)) * scale
 //   dQ = dS K ; dK = dS^T Q ; dV = Pd^T dO
@@ -630,13 +631,17 @@ int omk_attention_bwd_bias(int dtype, const void* qkv, const void* dctx, void* d
                            int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
                            const float* pos_bias, float* drel, hipStream_t s) {
   if (B <= 0) return 0;
-  if (L < 1 || L > 128) OM_FAIL("training supports sequence lengths up to 128");
+  if (L < 1 || L > 256) OM_FAIL("training supports sequence lengths up to 256");
+  // the three transposed [64][L + 4] images of the backward kernel must fit the 160 KiB of LDS: 256 keys in 16 bits, 192 in f32
+  if (dtype != OM_BF16 && L > 192) OM_FAIL("float32 training supports sequence lengths up to 192 (bfloat16: 256)");
   if (H != heads * 64) OM_FAIL("head_dim must be 64");
 #define AB(TT)                                                                                       \
   do {                                                                                               \
     if (L <= 32) return launch_attn_bwd<TT, 1>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s); \
     if (L <= 64) return launch_attn_bwd<TT, 2>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s); \
-    return launch_attn_bwd<TT, 4>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s);    \
+    if (L <= 128) return launch_attn_bwd<TT, 4>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s); \
+    if (L <= 192) return launch_attn_bwd<TT, 6>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s); \
+    return launch_attn_bwd<TT, 8>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s);    \
   } while (0)
   if (dtype == OM_BF16) AB(bf16_t);
   AB(float);

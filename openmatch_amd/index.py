@@ -143,8 +143,13 @@ def sharded_topk(index, queries: torch.Tensor, k: int, id_offset: int, merge=Non
     if pad:
         D = torch.cat([D, torch.full((pad, k), -3.4028235e38, dtype=D.dtype, device=dev)])
         I = torch.cat([I, torch.full((pad, k), -1, dtype=I.dtype, device=dev)])
-    recv_D, recv_I = torch.empty_like(D), torch.empty_like(I)
-    dist.all_to_all_single(recv_D, D.contiguous())              # block w of recv = shard w's candidates for MY queries
-    dist.all_to_all_single(recv_I, I.contiguous())
+    from .comm import native_comm
+    comm = native_comm(dev) if D.is_cuda else None
+    if comm is not None:                         # OPENMATCH_AMD_COMM=native: om_exchange_topk behind the C ABI
+        recv_D, recv_I = comm.exchange_topk(D, I)
+    else:
+        recv_D, recv_I = torch.empty_like(D), torch.empty_like(I)
+        dist.all_to_all_single(recv_D, D.contiguous())          # block w of recv = shard w's candidates for MY queries
+        dist.all_to_all_single(recv_I, I.contiguous())
     Dm, Im = (merge or merge_topk)(recv_D.view(W, blk, k), recv_I.view(W, blk, k), k)
     return Dm.to(dev), Im.to(dev), blk

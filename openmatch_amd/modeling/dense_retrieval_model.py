@@ -194,9 +194,14 @@ class DRModel(nn.Module):
         if t is None:
             return None
         t = t.contiguous()
-        out = torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype,
-                          device=t.device)
-        dist.all_gather_into_tensor(out, t.detach())
+        from ..comm import native_comm
+        comm = native_comm(t.device) if t.is_cuda else None
+        if comm is not None:                     # OPENMATCH_AMD_COMM=native: om_allgather_rows behind the C ABI
+            out = comm.allgather_rows(t.detach())
+        else:
+            out = torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype,
+                              device=t.device)
+            dist.all_gather_into_tensor(out, t.detach())
         if t.requires_grad:
             parts = list(out.split(t.shape[0], dim=0))
             parts[self.process_rank] = t

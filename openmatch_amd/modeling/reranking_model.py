@@ -4,7 +4,7 @@ pair -> CLS / mean pooling -> `LinearHead(H, 1)`.  The whole scoring path is ONE
 `om_encoder_forward` call (head_out = 1); BASELINE config 5 (bert-large, L = 162) runs the same
 kernels as the bi-encoder at H = 1024.  The monoT5 encoder-decoder branch (:110-114) needs a T5
 decoder step, which has no HIP path: it raises.  Training is supported for sequence lengths the
-HIP backward covers (L <= 128)."""
+HIP backward covers (L <= 256 in bfloat16, <= 192 in float32; the default pair length is 162)."""
 import json
 import logging
 import os

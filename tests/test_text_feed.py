@@ -214,16 +214,21 @@ def test_drivers_end_to_end(tok, tmp_path):
     # corpus as three partition files searched one after the other and merged by score == one index over all rows
     emb3 = tmp_path / "emb3"
     emb3.mkdir()
-    for r, (lo, hi) in enumerate(((0, 9), (9, 10), (10, 23))):
+    for r, (lo, hi) in enumerate(((0, 9), (9, 15), (15, 23))):
         with open(emb3 / f"embeddings.corpus.rank.{r}", "wb") as f:
             pickle.dump((P[lo:hi], doc_ids[lo:hi]), f, protocol=4)
     _run_driver("successive_retrieve", ["--model_name_or_path", ckpt, "--output_dir", emb3, "--per_device_eval_batch_size", 8]
                 + QUERY_FLAGS + ["--trec_save_path", tmp_path / "run3.trec"])
     run3 = load_from_trec(str(tmp_path / "run3.trec"))
     assert sorted(run3) == sorted(run)
-    for q in qry_ids:          # same documents, same scores (the order of near-equal scores may differ between two summation orders)
+    # same documents, same scores.  (With fewer rows than the depth of 100, faiss pads with id -1 / -FLT_MAX, and the reference's
+    # `doc_lookup[I]` turns -1 into the LAST document of whatever index was searched (retriever/dense_retriever.py:184-188):
+    # that document's score is overwritten by the pad -- per partition here, once in the single-index run.  Kept, as the
+    # reference does it; the comparison skips those entries.)
+    for q in qry_ids:
         assert set(run3[q]) == set(run[q])
-        assert max(abs(run3[q][d] - run[q][d]) for d in run[q]) < 1e-5
+        real = [d for d in run[q] if run[q][d] > -1e30 and run3[q][d] > -1e30]
+        assert len(real) >= 20 and max(abs(run3[q][d] - run[q][d]) for d in real) < 1e-5
     # ... and with a depth smaller than a partition, through the classes themselves (the merge has to truncate)
     from types import SimpleNamespace
     from transformers import BertModel
