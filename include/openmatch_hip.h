@@ -103,6 +103,17 @@ int om_gemm_nt(int in_dtype, const void* A, int64_t lda, const void* B, int64_t 
                const float* bias, const void* resid, int64_t ldr, int act, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Weight-gradient contraction  C[N,K] += A[M,N]^T · B[M,K],  bias[N] += column sums of A
+ * (A = dY, B = X, both row-major bf16 as the backward pass holds them; C, bias f32,
+ * ACCUMULATED into -- zero them first for a plain product).  Replaces autograd's
+ * dW = dY^T X / db = sum(dY) of every nn.Linear under DRModel.forward + backward
+ * (modeling/dense_retrieval_model.py:89-131).  Requires N % 128 == 0, K % 128 == 0,
+ * lda / ldb multiples of 8, 16-byte aligned operands; bias may be NULL.
+ * ------------------------------------------------------------------------ */
+int om_gemm_tn_acc(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb,
+                   float* C, int64_t ldc, float* bias, int64_t M, int64_t N, int64_t K, void* stream);
+
+/* ------------------------------------------------------------------------
  * Encoder forward:  ids -> hidden [B,L,H] -> pooled/head/normalised reps [B,D]
  * Replaces  lm(**items) + pooling + head + F.normalize  in
  * modeling/dense_retrieval_model.py:133-155 (DRModel.encode), i.e. the whole

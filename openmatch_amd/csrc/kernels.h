@@ -49,7 +49,11 @@ struct GemmEpilogue {
 };
 // true when omk_gemm will run [M,N] x K (16-bit) on the kernel that implements the ln_* / rln_* / stats_out fields
 bool omk_gemm_ln_fusable(int dtype, int64_t M, int64_t N, int64_t K);
-unsigned long long* omk_debug_trace();      // om_debug_gemm_trace buffer (NULL: off)
+unsigned long long* omk_debug_trace();
+// C[N,K] += A[M,N]^T B[M,K] (+ bias[N] += colsum A) on row-major bf16 operands (gemm_tn.hip); _ok: shapes it takes
+bool omk_gemm_tn_ok(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb);
+int omk_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* bias,
+                int64_t M, int64_t N, int64_t K, hipStream_t s);      // om_debug_gemm_trace buffer (NULL: off)
 // wide-tile generations, one translation unit each (gemm_wide4.hip / gemm_wide6_*.hip); omk_gemm dispatches
 int omk_gemm_wide4(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int out_dtype,
                    void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s);

@@ -35,6 +35,7 @@ struct Tape {
   char* x;                 // [(nl+1)][M,H] layer inputs / final output
   char *qkv, *ctx, *y1, *x1, *f, *y2;   // per layer, strided by their per-layer size
   char* f2;                // T5 gated FFN: the gate projection (per layer, stride sf)
+  char* g;                 // BERT: gelu(f), the FFN2 input (per layer, stride sf) -- the weight gradient reads it as is
   float *pooled, *headout;             // [B,H], [B,D] (pre-normalise)
   size_t total;
   size_t sx, sqkv, sf;     // per-layer strides in bytes
@@ -54,6 +55,7 @@ Tape carve_tape(const Dims& d, char* base) {
   t.f = take(t.sf * d.nl);
   t.y2 = take(d.t5 ? 0 : t.sx * d.nl);
   t.f2 = take(d.gated ? t.sf * d.nl : 0);
+  t.g = take(d.t5 ? 0 : t.sf * d.nl);
   t.pooled = (float*)take((size_t)d.B * d.H * 4);
   t.headout = (float*)take((size_t)d.B * d.D * 4);
   t.total = off;
@@ -93,6 +95,18 @@ Ws carve_ws(const Dims& d, char* base) {
   w.lut = (int*)take(d.t5 ? (size_t)(2 * d.L) * 4 : 0);
   w.total = off;
   return w;
+}
+
+// Weight and bias gradients of one nn.Linear: dW[N,K] += dY^T X, db[N] += column sums of dY (db may be NULL), f32
+// atomics into the caller-zeroed buffers.  16-bit runs read dY and X as they lie (gemm_tn.hip: transposing LDS reads,
+// the bias sums on the matrix core); f32 runs -- and widths that are not multiples of 128 -- transpose both operands
+// and use the NT split-K kernel.
+int wgrad(int dt, const void* dY, int N, const void* X, int K, float* dW, float* db, const Dims& d, Ws& ws, hipStream_t s) {
+  if (omk_gemm_tn_ok(dt, d.M, N, K, N, K)) return omk_gemm_tn(dt, dY, N, X, K, dW, K, db, d.M, N, K, s);
+  if (db && omk_colsum(dt, dY, N, d.M, N, db, s)) return 1;
+  if (omk_transpose(dt, dY, N, d.M, N, ws.tl, d.Mp, d.Mp, 0, s)) return 1;
+  if (omk_transpose(dt, X, K, d.M, K, ws.tr, d.Mp, d.Mp, 0, s)) return 1;
+  return omk_gemm_splitk(dt, ws.tl, d.Mp, ws.tr, d.Mp, dW, K, N, K, d.Mp, s);
 }
 
 int check_train_cfg(const OmEncoderConfig* c, int64_t L) {
@@ -185,8 +199,7 @@ int t5_train_backward(const OmEncoderConfig* c, const OmEncoderWeights* w, const
   if (!g->final_ln_g || !g->rel_bias) OM_FAIL("T5 gradients need final_ln_g and rel_bias buffers");
   RUN(t5_bias_setup(c, w, d, ws, s));
   OM_HIP(hipMemsetAsync(ws.drel, 0, (size_t)d.nh * (2 * d.L) * 4, s));
-#define WGRAD(left, right, rows_out, cols_in, dst) \
-  RUN(omk_gemm_splitk(dt, left, Mp, right, Mp, dst, cols_in, rows_out, cols_in, Mp, s))
+#define WGRAD(dY_, N_, X_, K_, dW_) RUN(wgrad(dt, dY_, N_, X_, K_, dW_, nullptr, d, ws, s))
   // final dropout + RMSNorm
   if (hd > 0.f) RUN(omk_dropout(dt, dx, dx, M * H, hd, site_seed(seed, d.nl, 1), s));
   RUN(omk_norm_bwd(dt, dx, t.x + t.sx * d.nl, w->final_ln_g, dx_other, g->final_ln_g, nullptr, M, H, c->ln_eps, 1, nullptr, s));
@@ -206,22 +219,17 @@ int t5_train_backward(const OmEncoderConfig* c, const OmEncoderWeights* w, const
     if (hd > 0.f) { RUN(omk_dropout(dt, dx, ws.dd, M * H, hd, site_seed(seed, l, 4), s)); dO = ws.dd; }
     RUN(omk_t5_act_fwd(dt, f, f2, ws.g, M * F, kind, s));                     // g = act(f) [* f2]
     if (hd > 0.f) RUN(omk_dropout(dt, ws.g, ws.g, M * F, hd, site_seed(seed, l, 5), s));
-    RUN(omk_transpose(dt, dO, H, M, H, ws.tl, Mp, Mp, 0, s));
-    RUN(omk_transpose(dt, ws.g, F, M, F, ws.tr, Mp, Mp, 0, s));
-    WGRAD(ws.tl, ws.tr, H, F, lg.ffn2_w);                                     // dWo2 [H,F]
+    WGRAD(dO, H, ws.g, F, lg.ffn2_w);                                         // dWo2 [H,F]
     RUN(omk_transpose(dt, lw.ffn2_w, F, H, F, ws.wt, H, H, 0, s));            // Wo2^T [F,H]
     GemmEpilogue e = {};
     RUN(omk_gemm(dt, dO, H, ws.wt, H, dt, ws.df, F, M, F, H, e, s));          // dg = dO Wo2
     if (hd > 0.f) RUN(omk_dropout(dt, ws.df, ws.df, M * F, hd, site_seed(seed, l, 5), s));
     RUN(omk_t5_act_bwd(dt, ws.df, f, f2, ws.df, ws.df2, M * F, kind, s));     // df (in place), df2
     RUN(omk_layernorm(dt, x1, H, ws.nbuf, H, lw.ln2_g, nullptr, M, H, c->ln_eps, 1, s));   // n2 again
-    RUN(omk_transpose(dt, ws.nbuf, H, M, H, ws.tr, Mp, Mp, 0, s));            // n2^T [H,Mp]
-    RUN(omk_transpose(dt, ws.df, F, M, F, ws.tl, Mp, Mp, 0, s));
-    WGRAD(ws.tl, ws.tr, F, H, lg.ffn1_w);                                     // dWi (wi / wi_0) [F,H]
+    WGRAD(ws.df, F, ws.nbuf, H, lg.ffn1_w);                                   // dWi (wi / wi_0) [F,H]
     if (d.gated) {
       if (!lg.ffn1g_w) OM_FAIL("gated T5 gradients need ffn1g_w");
-      RUN(omk_transpose(dt, ws.df2, F, M, F, ws.tl, Mp, Mp, 0, s));
-      WGRAD(ws.tl, ws.tr, F, H, lg.ffn1g_w);                                  // dWi_1 [F,H]
+      WGRAD(ws.df2, F, ws.nbuf, H, lg.ffn1g_w);                               // dWi_1 [F,H]
     }
     RUN(omk_transpose(dt, lw.ffn1_w, H, F, H, ws.wt, F, F, 0, s));            // Wi^T [H,F]
     e = GemmEpilogue{};
@@ -236,18 +244,14 @@ int t5_train_backward(const OmEncoderConfig* c, const OmEncoderWeights* w, const
     // ---- attention branch (dx_other now holds d/d x1)
     const char* dA = dx_other;
     if (hd > 0.f) { RUN(omk_dropout(dt, dx_other, ws.dd, M * H, hd, site_seed(seed, l, 3), s)); dA = ws.dd; }
-    RUN(omk_transpose(dt, dA, H, M, H, ws.tl, Mp, Mp, 0, s));
-    RUN(omk_transpose(dt, ctx, H, M, H, ws.tr, Mp, Mp, 0, s));
-    WGRAD(ws.tl, ws.tr, H, H, lg.o_w);
+    WGRAD(dA, H, ctx, H, lg.o_w);
     RUN(omk_transpose(dt, lw.o_w, H, H, H, ws.wt, H, H, 0, s));
     e = GemmEpilogue{};
     RUN(omk_gemm(dt, dA, H, ws.wt, H, dt, ws.dctx, H, M, H, H, e, s));        // dctx = dA Wo
     RUN(omk_attention_bwd_bias(dt, qkv, ws.dctx, ws.dqkv, attention_mask, d.B, (int)d.L, H, d.nh, 1.0f, ad,
                                site_seed(seed, l, 2), ws.posbias, ws.drel, s));
     RUN(omk_layernorm(dt, x, H, ws.nbuf, H, lw.ln1_g, nullptr, M, H, c->ln_eps, 1, s));    // n1 again
-    RUN(omk_transpose(dt, ws.dqkv, 3 * H, M, 3 * H, ws.tl, Mp, Mp, 0, s));
-    RUN(omk_transpose(dt, ws.nbuf, H, M, H, ws.tr, Mp, Mp, 0, s));
-    WGRAD(ws.tl, ws.tr, 3 * H, H, lg.qkv_w);
+    WGRAD(ws.dqkv, 3 * H, ws.nbuf, H, lg.qkv_w);
     RUN(omk_transpose(dt, lw.qkv_w, H, 3 * H, H, ws.wt, 3 * H, 3 * H, 0, s));
     e = GemmEpilogue{};
     RUN(omk_gemm(dt, ws.dqkv, 3 * H, ws.wt, 3 * H, dt, ws.dy, H, M, H, 3 * H, e, s));   // dn1
@@ -333,11 +337,12 @@ extern "C" int om_encoder_train_forward(const OmEncoderConfig* c, const OmEncode
     RUN(omk_gemm(dt, ctx, H, lw.o_w, H, dt, y1, H, M, H, H, ep, s));
     RUN(omk_layernorm(dt, y1, H, x1, H, lw.ln1_g, lw.ln1_b, M, H, c->ln_eps, 0, s));
     ep = GemmEpilogue{};
+    char* gl = t.g + t.sf * l;
     ep.bias = lw.ffn1_b; ep.act = OM_ACT_GELU_ERF; ep.pre_act = f; ep.ldp = F;
-    RUN(omk_gemm(dt, x1, H, lw.ffn1_w, H, dt, ws.g, F, M, F, H, ep, s));
+    RUN(omk_gemm(dt, x1, H, lw.ffn1_w, H, dt, gl, F, M, F, H, ep, s));
     ep = GemmEpilogue{};
     ep.bias = lw.ffn2_b; ep.resid = x1; ep.ldr = H; ep.drop_p = hidden_dropout; ep.seed = site_seed(seed, l, 4);
-    RUN(omk_gemm(dt, ws.g, F, lw.ffn2_w, F, dt, y2, H, M, H, F, ep, s));
+    RUN(omk_gemm(dt, gl, F, lw.ffn2_w, F, dt, y2, H, M, H, F, ep, s));
     RUN(omk_layernorm(dt, y2, H, t.x + t.sx * (l + 1), H, lw.ln2_g, lw.ln2_b, M, H, c->ln_eps, 0, s));
   }
   const char* xf = t.x + t.sx * d.nl;
@@ -396,9 +401,7 @@ extern "C" int om_encoder_train_backward(const OmEncoderConfig* c, const OmEncod
     return t5_train_backward(c, w, input_ids, attention_mask, d, t, ws, hidden_dropout, attn_dropout, seed, dx,
                              dx_prev, g, s);
 
-  // weight gradients: split-K over the token axis, f32 atomics into the caller-zeroed buffers
-#define WGRAD(left, right, rows_out, cols_in, dst) \
-  RUN(omk_gemm_splitk(dt, left, Mp, right, Mp, dst, cols_in, rows_out, cols_in, Mp, s))
+#define WGRAD(dY_, N_, X_, K_, dW_, db_) RUN(wgrad(dt, dY_, N_, X_, K_, dW_, db_, d, ws, s))
 
   for (int l = d.nl - 1; l >= 0; --l) {
     const OmLayerWeights& lw = Ls[l];
@@ -409,6 +412,7 @@ extern "C" int om_encoder_train_backward(const OmEncoderConfig* c, const OmEncod
     const char* y1 = t.y1 + t.sx * l;
     const char* x1 = t.x1 + t.sx * l;
     const char* f = t.f + t.sf * l;
+    const char* gl = t.g + t.sf * l;
     const char* y2 = t.y2 + t.sx * l;
 
     // LN2 backward: dy2 = d(loss)/d(y2)
@@ -416,20 +420,14 @@ extern "C" int om_encoder_train_backward(const OmEncoderConfig* c, const OmEncod
     // FFN output branch (dropout after the dense, before the residual add)
     const char* dO = ws.dy;
     if (hidden_dropout > 0.f) { RUN(omk_dropout(dt, ws.dy, ws.dd, M * H, hidden_dropout, site_seed(seed, l, 4), s)); dO = ws.dd; }
-    RUN(omk_colsum(dt, dO, H, M, H, lg.ffn2_b, s));
-    RUN(omk_transpose(dt, dO, H, M, H, ws.tl, Mp, Mp, 0, s));       // dO^T   [H, Mp]
-    RUN(omk_transpose(dt, f, F, M, F, ws.tr, Mp, Mp, 1, s));        // gelu(f)^T [F, Mp]
-    WGRAD(ws.tl, ws.tr, H, F, lg.ffn2_w);                           // dW2 [H,F]
+    WGRAD(dO, H, gl, F, lg.ffn2_w, lg.ffn2_b);                      // dW2 [H,F], db2
     RUN(omk_transpose(dt, lw.ffn2_w, F, H, F, ws.wt, H, H, 0, s));  // W2^T [F,H]
     {
       GemmEpilogue e1 = {};
       e1.act = OM_ACT_GELU_ERF_GRAD; e1.resid = f; e1.ldr = F;      // df = (dO W2) * gelu'(f)
       RUN(omk_gemm(dt, dO, H, ws.wt, H, dt, ws.df, F, M, F, H, e1, s));
     }
-    RUN(omk_colsum(dt, ws.df, F, M, F, lg.ffn1_b, s));
-    RUN(omk_transpose(dt, ws.df, F, M, F, ws.tl, Mp, Mp, 0, s));    // df^T [F, Mp]
-    RUN(omk_transpose(dt, x1, H, M, H, ws.tr, Mp, Mp, 0, s));       // x1^T [H, Mp]
-    WGRAD(ws.tl, ws.tr, F, H, lg.ffn1_w);                           // dW1 [F,H]
+    WGRAD(ws.df, F, x1, H, lg.ffn1_w, lg.ffn1_b);                   // dW1 [F,H], db1
     RUN(omk_transpose(dt, lw.ffn1_w, H, F, H, ws.wt, F, F, 0, s));  // W1^T [H,F]
     {
       GemmEpilogue e2 = {};
@@ -440,10 +438,7 @@ extern "C" int om_encoder_train_backward(const OmEncoderConfig* c, const OmEncod
     RUN(omk_ln_bwd(dt, ws.dctx, y1, lw.ln1_g, ws.dy, lg.ln1_g, lg.ln1_b, M, H, c->ln_eps, s));
     const char* dA = ws.dy;
     if (hidden_dropout > 0.f) { RUN(omk_dropout(dt, ws.dy, ws.dd, M * H, hidden_dropout, site_seed(seed, l, 3), s)); dA = ws.dd; }
-    RUN(omk_colsum(dt, dA, H, M, H, lg.o_b, s));
-    RUN(omk_transpose(dt, dA, H, M, H, ws.tl, Mp, Mp, 0, s));
-    RUN(omk_transpose(dt, ctx, H, M, H, ws.tr, Mp, Mp, 0, s));
-    WGRAD(ws.tl, ws.tr, H, H, lg.o_w);                              // dWo [H,H]
+    WGRAD(dA, H, ctx, H, lg.o_w, lg.o_b);                           // dWo [H,H], dbo
     RUN(omk_transpose(dt, lw.o_w, H, H, H, ws.wt, H, H, 0, s));     // Wo^T
     {
       GemmEpilogue e3 = {};
@@ -451,10 +446,7 @@ extern "C" int om_encoder_train_backward(const OmEncoderConfig* c, const OmEncod
     }
     RUN(omk_attention_bwd(dt, qkv, ws.dctx, ws.dqkv, attention_mask, B, (int)L, H, d.nh, scale,
                           attn_dropout, site_seed(seed, l, 2), s));
-    RUN(omk_colsum(dt, ws.dqkv, 3 * H, M, 3 * H, lg.qkv_b, s));
-    RUN(omk_transpose(dt, ws.dqkv, 3 * H, M, 3 * H, ws.tl, Mp, Mp, 0, s));
-    RUN(omk_transpose(dt, x, H, M, H, ws.tr, Mp, Mp, 0, s));
-    WGRAD(ws.tl, ws.tr, 3 * H, H, lg.qkv_w);                        // dWqkv [3H,H]
+    WGRAD(ws.dqkv, 3 * H, x, H, lg.qkv_w, lg.qkv_b);                // dWqkv [3H,H], dbqkv
     RUN(omk_transpose(dt, lw.qkv_w, H, 3 * H, H, ws.wt, 3 * H, 3 * H, 0, s));   // Wqkv^T [H,3H]
     {
       GemmEpilogue e4 = {};

@@ -77,8 +77,11 @@ class DRModel(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, query: Dict[str, Tensor] = None, passage: Dict[str, Tensor] = None):
-        _, q_reps = self.encode_query(query)
-        _, p_reps = self.encode_passage(passage)
+        if self._one_pass_ok(query, passage):
+            q_reps, p_reps = self._encode_one_pass(query, passage)
+        else:
+            _, q_reps = self.encode_query(query)
+            _, p_reps = self.encode_passage(passage)
         if q_reps is None or p_reps is None:
             return DROutput(q_reps=q_reps, p_reps=p_reps)
 
@@ -123,6 +126,37 @@ class DRModel(nn.Module):
 
     def encode_query(self, qry):
         return self.encode(qry, self.lm_q, self.head_q)
+
+    # A tied bi-encoder runs the SAME weights over the queries and the passages (reference :89-93: two calls of one
+    # module).  In a training step the query batch is a few short rows -- 8 x 32 tokens beside 64 x 128 -- and a second
+    # forward + backward over it costs a full set of launches for 3 % of the tokens, plus a second gradient arena that
+    # autograd then adds to the first, parameter by parameter.  So the training forward pads the queries to the passage
+    # length (mask 0) and encodes both in ONE pass; rows are independent and padded keys are masked, so the
+    # representations are the two-call ones (up to the order of floating-point sums inside attention).
+    def _one_pass_ok(self, query, passage):
+        if query is None or passage is None or not self.training or not torch.is_grad_enabled():
+            return False
+        if self.lm_q is not self.lm_p or self.head_q is not self.head_p:
+            return False
+        if set(query.keys()) != set(passage.keys()) or "input_ids" not in query:
+            return False
+        (bq, lq), (bp, lp) = query["input_ids"].shape, passage["input_ids"].shape
+        return lq <= lp and 4 * bq <= bp          # padding adds at most a quarter of the passage tokens
+
+    def _encode_one_pass(self, query, passage):
+        bq, lq = query["input_ids"].shape
+        lp = passage["input_ids"].shape[1]
+        pad_id = getattr(getattr(self.lm_p, "config", None), "pad_token_id", None) or 0
+        merged = {}
+        for key, q in query.items():
+            p_ = passage[key]
+            q = q.to(p_.device)
+            if q.dim() == 2 and q.shape[1] == lq and lq < lp:
+                fill = pad_id if key == "input_ids" else 0
+                q = torch.nn.functional.pad(q, (0, lp - lq), value=fill)
+            merged[key] = torch.cat([q.to(p_.dtype), p_], dim=0)
+        _, reps = self.encode(merged, self.lm_p, self.head_p)
+        return reps[:bq], reps[bq:]
 
     # ------------------------------------------------------------------ build / save
     @classmethod

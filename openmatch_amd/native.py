@@ -67,6 +67,8 @@ _SIGNATURES = {
     "om_kernel_timing_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(c_int64), C.POINTER(C.c_double)]),
     "om_gemm_nt": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64,
                            c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "om_gemm_tn_acc": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                               c_int64, c_int64, c_int64, c_void_p]),
     "om_encoder_workspace_bytes": (c_size_t, [C.POINTER(OmEncoderConfig), c_int64, c_int64]),
     "om_t5_relative_bucket": (c_int, [c_int, c_int, c_int]),
     "om_encoder_forward": (c_int, [C.POINTER(OmEncoderConfig), C.POINTER(OmEncoderWeights), c_void_p,

@@ -5,6 +5,7 @@ Tolerances (north_star): f32 path — embeddings / dot products within 1e-4, top
 identical (fp64-adjudicated boundary near-ties reported, not counted), MRR@10 within 1e-4.
 bf16 path (the reference's `--fp16` autocast analogue) — looser, stated per test.
 """
+import math
 import numpy as np
 import pytest
 import torch
@@ -631,6 +632,63 @@ def test_training_gradients_beyond_128_tokens(L, dtype):
         elif p.grad.norm() > 1e-6:                     # 16-bit compute: direction of every gradient tensor
             cos = (torch.dot(gg.flatten().double(), p.grad.flatten().double()) / (gg.norm().double() * p.grad.norm().double())).item()
             assert cos > 0.98, (L, name, cos)
+
+
+@pytest.mark.parametrize("M,N,K,with_bias", [(8192, 768, 768, True), (9216, 768, 3072, True), (1000, 256, 128, True),
+                                              (77, 128, 384, False), (4099, 2304, 768, True)])
+def test_weight_gradient_contraction_matches_torch(M, N, K, with_bias):
+    """om_gemm_tn_acc (gemm_tn.hip): C[N,K] += A[M,N]^T B[M,K], bias[N] += column sums of A on row-major bf16 operands
+    -- the contraction behind every dW / db of the training backward -- against a float64 product of the same bf16
+    values.  Random (asymmetric) operands, token counts that are not multiples of the 64-row step, accumulation into a
+    non-zero C: any operand / output transposition or a wrong transposing-read lane mapping shows up as O(1) error."""
+    from openmatch_amd import native as N_
+    gen = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, N, generator=gen).to(torch.bfloat16)
+    B = (torch.randn(M, K, generator=gen) * 0.5 + 0.1).to(torch.bfloat16)
+    C0 = torch.randn(N, K, generator=gen)
+    b0 = torch.randn(N, generator=gen)
+    ref = C0.double() + A.double().t() @ B.double()
+    ref_b = b0.double() + A.double().sum(0)
+    Ad, Bd, Cd, bd = A.to(DEV), B.to(DEV), C0.to(DEV).contiguous(), b0.to(DEV).contiguous()
+    with torch.cuda.device(DEV):
+        N_.check(N_.lib().om_gemm_tn_acc(1, N_.ptr(Ad), N, N_.ptr(Bd), K, N_.ptr(Cd), K, N_.ptr(bd) if with_bias else None,
+                                         M, N, K, N_.stream_ptr(Cd.device)))
+    torch.cuda.synchronize()
+    scale = math.sqrt(M)
+    err = (Cd.cpu().double() - ref).abs().max().item()
+    assert err < 2e-5 * scale * 8, (err, scale)                    # f32 accumulation of exact bf16 products
+    if with_bias:
+        assert (bd.cpu().double() - ref_b).abs().max().item() < 2e-5 * scale * 8
+    else:
+        assert torch.equal(bd.cpu(), b0)
+
+
+def test_tied_training_forward_in_one_pass_equals_two_calls(golden):
+    """A tied DRModel in training mode pads the queries to the passage length and encodes both batches in one pass
+    (modeling/dense_retrieval_model.py: _encode_one_pass); the reference calls the shared module twice (:89-93).  Same
+    loss, scores and parameter gradients as the two-call path (taken in eval mode: dropout is 0 in both)."""
+    g = golden("train_bert_tiny")
+    q, p = _train_batch(g)
+    p2 = {k: torch.cat([v, v.flip(0)], 0) for k, v in p.items()}          # 4 x as many passages as queries: one pass
+    results = []
+    for one_pass in (True, False):
+        model = _train_model(g)
+        model.data_args = NS(train_n_passages=2 * int(g["n_psg"]))
+        if not one_pass:
+            model.eval()
+        assert model._one_pass_ok(q, p2) == one_pass
+        out = model(query=q, passage=p2)
+        out.loss.backward()
+        results.append((out.loss.item(), out.scores.detach().cpu(),
+                        {n: t.grad.detach().cpu().clone() for n, t in model.lm_q.named_parameters() if t.grad is not None},
+                        model.head_q.linear.weight.grad.detach().cpu().clone()))
+    (l1, s1, g1, h1), (l2, s2, g2, h2) = results
+    assert abs(l1 - l2) < 1e-5 and (s1 - s2).abs().max().item() < 1e-5
+    assert g1.keys() == g2.keys()
+    for n in g1:
+        rel = ((g1[n] - g2[n]).norm() / (g2[n].norm() + 1e-20)).item()
+        assert rel < 1e-4 or (g1[n] - g2[n]).abs().max().item() < 1e-7, (n, rel)
+    assert ((h1 - h2).norm() / h2.norm()).item() < 1e-4
 
 
 def test_float32_training_rejects_more_than_192_tokens():
