@@ -85,7 +85,9 @@ void om_debug_gemm_gen(int gen);
 #define OM_OPT_SCAN_GEN7 3        /* 1 (default): f16 index scan of wide query batches on the persistent generation-7 kernel; 0: generation 6 */
 #define OM_OPT_SCAN_GROWTH 4      /* fast schedule of the index scan: rows scanned per round grow by this many percent of the rows already
                                     * scanned (default 60; smaller = more rounds, tighter thresholds, fewer appends per tile) */
-#define OM_OPT_COUNT 5
+#define OM_OPT_WGRAD_DEBUG 5     /* 0 (default); timing experiments on the weight-gradient kernel: bit 1 plain stores, bit 2 one step
+                                   * (both break the result), value >> 4 = workgroups aimed at / 64 */
+#define OM_OPT_COUNT 6
 int om_debug_option(int opt, int value);
 int om_kernel_timing_enable(int enable);
 int om_kernel_timing_read(int kernel_class, double* total_ms, int64_t* launches, double* flops);

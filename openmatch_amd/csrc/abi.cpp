@@ -86,6 +86,7 @@ void opt_init() {
   g_opt[OM_OPT_SCAN_GEN7] = e ? atoi(e) : 1;
   e = getenv("OM_SCAN_GROWTH");
   g_opt[OM_OPT_SCAN_GROWTH] = e ? atoi(e) : 60;
+  g_opt[OM_OPT_WGRAD_DEBUG] = 0;
   g_opt_init.store(true);
 }
 }  // namespace

@@ -37,9 +37,23 @@ __device__ __forceinline__ float act_apply(float x) {
   return x;
 }
 
-// d/dx of the erf GELU
+// d/dx of the erf GELU:  Phi(x) + x phi(x)
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+// The same for 16-bit outputs, ~20 instructions instead of ~90 (libm erff + expf made the epilogue of the GELU-backward
+// contraction longer than its K = 768 main loop: 138 us per launch, profiles/r02_train_kernel_stats_v2.csv):
+// Phi(x) = 0.5 + xc Q(xc^2) with the degree-8 fit of gemm_epilogue6.h's forward (|error| <= 7.4e-6, xc = clamp(x, +-4.2)),
+// phi by the hardware exp2 (1 ulp).  |error| < 1e-5 against an output rounded to 2^-9.
+__device__ __forceinline__ float gelu_erf_grad_fast(float x) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -4.2f, 4.2f);
+  const float t = xc * xc;
+  float q = 5.998145036e-11f;
+  q = fmaf(q, t, -5.633389311e-09f); q = fmaf(q, t, 2.343703613e-07f); q = fmaf(q, t, -5.760840850e-06f);
+  q = fmaf(q, t, 9.457556007e-05f); q = fmaf(q, t, -1.114161685e-03f); q = fmaf(q, t, 9.830250405e-03f);
+  q = fmaf(q, t, -6.636118144e-02f); q = fmaf(q, t, 3.989123106e-01f);
+  const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.7213475204444817f * x * x);
+  return fmaf(x, pdf, fmaf(xc, q, 0.5f));
 }
 
 // value of one output element before the residual: v = dropout(act(acc + bias))
@@ -58,9 +72,9 @@ __device__ __forceinline__ float epi_value(float v, int64_t m, int64_t n, int64_
   return v;
 }
 
-template <int ACT>
+template <int ACT, bool FAST = false>      // FAST: the output is rounded to 16 bits
 __device__ __forceinline__ float epi_resid(float v, float r, bool mul) {
-  if (ACT == OM_ACT_GELU_ERF_GRAD) return v * gelu_erf_grad(r);
+  if (ACT == OM_ACT_GELU_ERF_GRAD) return v * (FAST ? gelu_erf_grad_fast(r) : gelu_erf_grad(r));
   return mul ? v * r : v + r;
 }
 
@@ -166,7 +180,7 @@ __device__ __forceinline__ void store_patch(const f32x16_t acc0, const f32x16_t 
         float rv[VEC];
         OutVec<OutT>::unpack(*(const uint4*)(resid + m * ep.ldr + n), rv);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) xv[e] = epi_resid<ACT>(xv[e], rv[e], es.mul);
+        for (int e = 0; e < VEC; ++e) xv[e] = epi_resid<ACT, sizeof(OutT) == 2>(xv[e], rv[e], es.mul);
       }
       *(uint4*)(C + m * ldc + n) = OutVec<OutT>::pack(xv);
     }
@@ -196,7 +210,7 @@ __device__ __forceinline__ void store_direct(const f32x16_t a00, const f32x16_t 
         if (m >= M) continue;
         const float a = mi == 0 ? (ni == 0 ? a00[r] : a01[r]) : (ni == 0 ? a10[r] : a11[r]);
         float v = epi_value<ACT, TRAIN, OutT>(a + bv, m, n, M, N, ep, es.drop_thresh, es.drop_scale);
-        if (resid) v = epi_resid<ACT>(v, ElemOps<OutT>::load(resid + m * ep.ldr + n), es.mul);
+        if (resid) v = epi_resid<ACT, sizeof(OutT) == 2>(v, ElemOps<OutT>::load(resid + m * ep.ldr + n), es.mul);
         ElemOps<OutT>::store(C + m * ldc + n, v);
       }
     }

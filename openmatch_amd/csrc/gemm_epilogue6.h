@@ -155,8 +155,8 @@ __device__ __forceinline__ void store_wave_tile6(f32x16_t (&acc)[4][4], int64_t 
           }                                                                                                \
           if (es.mul) { lo_[0] *= r0; lo_[1] *= r1; hi_[0] *= r2; hi_[1] *= r3; }                          \
           else {                                                                                           \
-            lo_[0] = epi_resid<ACT>(lo_[0], r0, false); lo_[1] = epi_resid<ACT>(lo_[1], r1, false);        \
-            hi_[0] = epi_resid<ACT>(hi_[0], r2, false); hi_[1] = epi_resid<ACT>(hi_[1], r3, false);        \
+            lo_[0] = epi_resid<ACT, sizeof(OutT) == 2>(lo_[0], r0, false); lo_[1] = epi_resid<ACT, sizeof(OutT) == 2>(lo_[1], r1, false);        \
+            hi_[0] = epi_resid<ACT, sizeof(OutT) == 2>(hi_[0], r2, false); hi_[1] = epi_resid<ACT, sizeof(OutT) == 2>(hi_[1], r3, false);        \
           }                                                                                                \
         }                                                                                                  \
         if (stats_out && n < N) {                                                                          \
@@ -245,7 +245,7 @@ __device__ __forceinline__ void store_wave_tile6(f32x16_t (&acc)[4][4], int64_t 
               for (int e = 0; e < VEC; ++e) xv[e] *= rv[e];
             } else {
 #pragma unroll
-              for (int e = 0; e < VEC; ++e) xv[e] = epi_resid<ACT>(xv[e], rv[e], false);
+              for (int e = 0; e < VEC; ++e) xv[e] = epi_resid<ACT, sizeof(OutT) == 2>(xv[e], rv[e], false);
             }
           }
           packed = OutVec<OutT>::pack(xv);

@@ -14,8 +14,8 @@
 //
 // Workgroup: 128 (n) x 128 (k) output tile, four waves of 64 x 64, over one slice of the token axis (split-M, f32
 // atomics into the caller-zeroed / caller-accumulated C); register-staged double buffer, one barrier per 64 tokens.
-// The bias column sums ride on the matrix core too (one extra MFMA per A fragment against a fragment of ones) in the
-// workgroups of k tile 0.
+// The bias column sums are taken from the A fragments themselves (eight tokens of one column per lane) by the vector ALU
+// under the MFMAs, in the waves that own k columns 0..WT-1 of k tile 0.
 #include <atomic>
 
 #include "gemm_core.h"
@@ -24,8 +24,8 @@
 namespace {
 constexpr int TN_BM = 64;                       // tokens per step
 constexpr int TN_SUB = TN_BM * 32 + 128;        // bytes per [64][16] sub-tile, padded
-constexpr int TN_TILE = 8 * TN_SUB;             // one operand tile
-constexpr int TN_LDS = 4 * TN_TILE;             // A, B double-buffered: 69 632 bytes
+constexpr int TN_OPER = 8 * TN_SUB;             // one operand tile (64 tokens x 128 columns)
+constexpr int TN_LDS = 4 * TN_OPER;             // A, B double-buffered: 69 632 bytes, two workgroups per CU
 constexpr int TN_THREADS = 256;
 
 typedef short v4s __attribute__((ext_vector_type(4)));
@@ -33,97 +33,125 @@ __device__ __forceinline__ v4s tn_read(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p));
 }
 
+// Measured on the way here (profiles/r02_gemm_tn_variants.log, M = 9216):
+//  * the f32 atomics of the split-M flush execute at the memory side, ~0.35 M/us: 16 384 per workgroup, so the number of
+//    WORKGROUPS sets that cost -- ~320 of them (one wave of two per CU) instead of ~1000 took 104 -> 77 us at 768 x 3072;
+//  * a 256 x 256 tile (one workgroup per CU, 65 536 atomics each) was slower than 128 x 128 at every shape;
+//  * with one step of prefetch the token loop ran at ~30 % of the MFMA rate, parked on the global loads (SQ_WAIT_ANY
+//    42 %, no LDS bank conflicts): the loads of step t + 2 are now issued before step t is computed (two register sets).
 __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, float* __restrict__ C,
-    int64_t ldc, float* __restrict__ bias, int64_t M, int N, int K, int rows_per_slice) {
+    int64_t ldc, float* __restrict__ bias, int64_t M, int N, int K, int rows_per_slice, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wk = wave & 1;
   const int ntk = K / 128;
   const int n0 = (blockIdx.x / ntk) * 128, k0 = (blockIdx.x % ntk) * 128;
   const int64_t m_begin = (int64_t)blockIdx.y * rows_per_slice;
-  const int64_t m_end = m_begin + rows_per_slice < M ? m_begin + rows_per_slice : M;
+  int64_t m_end = m_begin + rows_per_slice < M ? m_begin + rows_per_slice : M;
   if (m_begin >= m_end) return;
-  const bool do_bias = bias != nullptr && k0 == 0;
+  if (dbg & 4) m_end = m_begin + 1;          // measurement only: one step of the token loop
+  const int nsteps = (int)((m_end - m_begin + TN_BM - 1) / TN_BM);
+  const bool do_bias = bias != nullptr && k0 == 0 && wk == 0;
 
-  // staging: wave instruction j = wave * 4 + i covers rows (j >> 1) * 8 .. + 7 and column blocks (j & 1) * 4 .. + 3;
-  // lane -> (half h of the 32-byte row, row r8, column block cbl): 16 lanes write 256 contiguous bytes of one sub-tile
+  // staging: wave instruction j = wave * 4 + i covers rows (j >> 1) * 8 .. + 7 and column blocks (j & 1) * 4 .. + 3
+  // (64 columns = one 128-byte line of each row); lane -> (half h of the 32-byte sub-tile row, row r8, column block
+  // cbl): 16 lanes write 256 contiguous LDS bytes.  Addresses = one per-lane 32-bit part + a wave-uniform part.
   const int h = lane & 1, r8 = (lane >> 1) & 7, cbl = lane >> 4;
-  int s_row[4], s_lds[4];
-  const bf16_t* pa[4];
-  const bf16_t* pb[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int j = wave * 4 + i;
-    const int m = (j >> 1) * 8 + r8, cb = (j & 1) * 4 + cbl;
-    s_row[i] = m;
-    s_lds[i] = cb * TN_SUB + m * 32 + h * 16;
-    pa[i] = A + (m_begin + m) * lda + n0 + cb * 16 + h * 8;
-    pb[i] = B + (m_begin + m) * ldb + k0 + cb * 16 + h * 8;
+  const int row0 = wave * 16 + r8;                    // + (i >> 1) * 8
+  const uint32_t a_lane = (uint32_t)((row0 * lda + cbl * 16 + h * 8) * 2);
+  const uint32_t b_lane = (uint32_t)((row0 * ldb + cbl * 16 + h * 8) * 2);
+  const int lds_lane = cbl * TN_SUB + row0 * 32 + h * 16;
+  const uint32_t col_lane = (uint32_t)((cbl * 16 + h * 8) * 2);   // row 0 of the step: the stand-in for rows past m_end
+  const char* const a_base = (const char*)(A + m_begin * lda + n0);      // wave-uniform
+  const char* const b_base = (const char*)(B + m_begin * ldb + k0);
+  const size_t a_step = (size_t)TN_BM * lda * 2, b_step = (size_t)TN_BM * ldb * 2;
+  // two register sets (X, Y) of 4 + 4 x 16 bytes: named registers, not arrays -- hipcc leaves a uint4 array that lives
+  // across the barrier in scratch, and a conditionally filled one too (hence the clamped, unconditional fetches)
+  uint4 raX0, raX1, raX2, raX3, rbX0, rbX1, rbX2, rbX3, raY0, raY1, raY2, raY3, rbY0, rbY1, rbY2, rbY3;
+  // rows past the end of the slice: no branches -- the load goes to row 0 of the step (always valid) and the A value is
+  // zeroed on its way into LDS (0 x finite = 0; the B stand-in is real data)
+#define TN_FETCH1(S, I, STEP)                                                                          \
+  {                                                                                                    \
+    const bool ok = m_begin + (int64_t)(STEP) * TN_BM + row0 + ((I) >> 1) * 8 < m_end;                  \
+    const uint32_t ua = (uint32_t)(((I) >> 1) * 8 * lda * 2), ub = (uint32_t)(((I) >> 1) * 8 * ldb * 2); \
+    ra##S##I = *(const uint4*)(a_base + (STEP) * a_step + ((I) & 1) * 128 + (ok ? a_lane + ua : col_lane)); \
+    rb##S##I = *(const uint4*)(b_base + (STEP) * b_step + ((I) & 1) * 128 + (ok ? b_lane + ub : col_lane)); \
   }
-  uint4 ra[4], rb[4];
-  auto fetch = [&](int64_t m_at) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool ok = m_at + s_row[i] < m_end;
-      ra[i] = ok ? *(const uint4*)(pa[i] + (m_at - m_begin) * lda) : make_uint4(0u, 0u, 0u, 0u);
-      rb[i] = ok ? *(const uint4*)(pb[i] + (m_at - m_begin) * ldb) : make_uint4(0u, 0u, 0u, 0u);
-    }
-  };
-  auto stash = [&](char* buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *(uint4*)(buf + s_lds[i]) = ra[i];
-      *(uint4*)(buf + TN_TILE + s_lds[i]) = rb[i];
-    }
-  };
+#define TN_FETCH(S, STEP_)                                                                             \
+  do {                                                                                                 \
+    const int st_ = (STEP_) < nsteps ? (STEP_) : nsteps - 1;      /* past the end: re-fetch the last tile, never used */ \
+    TN_FETCH1(S, 0, st_) TN_FETCH1(S, 1, st_) TN_FETCH1(S, 2, st_) TN_FETCH1(S, 3, st_)                \
+  } while (0)
+#define TN_STASH1(S, I, BUF, STEP)                                                                     \
+  {                                                                                                    \
+    const bool ok = m_begin + (int64_t)(STEP) * TN_BM + row0 + ((I) >> 1) * 8 < m_end;                  \
+    const int off = ((I) & 1) * 4 * TN_SUB + ((I) >> 1) * 8 * 32;                                      \
+    uint4 va = ra##S##I;                                                                               \
+    if (!ok) va = make_uint4(0u, 0u, 0u, 0u);                                                          \
+    *(uint4*)((BUF) + lds_lane + off) = va;                                                            \
+    *(uint4*)((BUF) + TN_OPER + lds_lane + off) = rb##S##I;                                            \
+  }
+#define TN_STASH(S, BUF, STEP)                                                                         \
+  do { TN_STASH1(S, 0, BUF, STEP) TN_STASH1(S, 1, BUF, STEP) TN_STASH1(S, 2, BUF, STEP) TN_STASH1(S, 3, BUF, STEP) } while (0)
 
   // fragment reads: 16-lane group g -> column block (g & 1) of the 32-column fragment, m half (g >> 1) of the k16 step
   const int g = lane >> 4;
   const int frag_off = (g & 1) * TN_SUB + (g >> 1) * 8 * 32 + (lane & 15) * 8;
   f32x16_t acc[2][2];
-  f32x16_t accb[2];
+  float bsum[2] = {0.f, 0.f};               // bias: this lane's share of the column sum of A column (i*32 + lane&31)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; accb[i][r] = 0.f; }
-  }
-  const short one = (short)0x3f80;
-  const bf16x8_t ones = {one, one, one, one, one, one, one, one};
+    for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; }
 
-  fetch(m_begin);
-  stash(smem);
+  // one 64-token step from LDS buffer CUR: fragments of k16 step ks + 1 are read while the MFMAs of step ks run
+#define TN_READ(KS, SET)                                                                               \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+    const v4s a0 = tn_read(ia + i * 2 * TN_SUB + (KS) * 512), a1 = tn_read(ia + i * 2 * TN_SUB + (KS) * 512 + 128); \
+    const v4s b0 = tn_read(ib + i * 2 * TN_SUB + (KS) * 512), b1 = tn_read(ib + i * 2 * TN_SUB + (KS) * 512 + 128); \
+    fa[SET][i] = (bf16x8_t){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};                   \
+    fb[SET][i] = (bf16x8_t){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};                   \
+  }
+  // acc[i][j][r]: n = n0 + wn*64 + i*32 + 8*(r>>2) + 4*(lane>>5) + (r&3),  k = k0 + wk*64 + j*32 + (lane & 31)
+  // (k, the contiguous index of C, runs along the lanes: every atomic instruction of the flush covers whole 128-byte rows)
+#define TN_COMPUTE(CUR)                                                                                \
+  do {                                                                                                 \
+    const char* ia = smem + (CUR) * 2 * TN_OPER + (wn * 4) * TN_SUB + frag_off;                        \
+    const char* ib = smem + (CUR) * 2 * TN_OPER + TN_OPER + (wk * 4) * TN_SUB + frag_off;              \
+    bf16x8_t fa[2][2], fb[2][2];                                                                       \
+    TN_READ(0, 0)                                                                                      \
+    _Pragma("unroll") for (int ks = 0; ks < TN_BM / 16; ++ks) {                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+      if (ks + 1 < TN_BM / 16) { TN_READ(ks + 1, (ks + 1) & 1) }                                       \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                  \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) MmaOps<bf16_t>::mma(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]); \
+        if (do_bias) {      /* the fragment holds 8 tokens of column (lane & 31): add them up under the MFMAs */ \
+          const uint4 w = __builtin_bit_cast(uint4, fa[ks & 1][i]);                                    \
+          bsum[i] += (__uint_as_float(w.x << 16) + __uint_as_float(w.x & 0xffff0000u)) + (__uint_as_float(w.y << 16) + __uint_as_float(w.y & 0xffff0000u)) + \
+                     (__uint_as_float(w.z << 16) + __uint_as_float(w.z & 0xffff0000u)) + (__uint_as_float(w.w << 16) + __uint_as_float(w.w & 0xffff0000u)); \
+        }                                                                                              \
+      }                                                                                                \
+    }                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+  } while (0)
+
+  // pipeline: LDS holds step t, set Y holds step t + 1 (in flight), set X receives step t + 2 -- and the roles swap
+  TN_FETCH(X, 0);
+  TN_FETCH(Y, 1);
+  TN_STASH(X, smem, 0);
   __syncthreads();
-  int cur = 0;
-  for (int64_t m_at = m_begin; m_at < m_end; m_at += TN_BM) {
-    const bool more = m_at + TN_BM < m_end;
-    if (more) fetch(m_at + TN_BM);
-    const char* ia = smem + cur * 2 * TN_TILE + (wn * 4) * TN_SUB + frag_off;
-    const char* ib = smem + cur * 2 * TN_TILE + TN_TILE + (wk * 4) * TN_SUB + frag_off;
-#pragma unroll
-    for (int ks = 0; ks < TN_BM / 16; ++ks) {
-      bf16x8_t fa[2], fb[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const v4s a0 = tn_read(ia + i * 2 * TN_SUB + ks * 512), a1 = tn_read(ia + i * 2 * TN_SUB + ks * 512 + 128);
-        const v4s b0 = tn_read(ib + i * 2 * TN_SUB + ks * 512), b1 = tn_read(ib + i * 2 * TN_SUB + ks * 512 + 128);
-        fa[i] = (bf16x8_t){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        fb[i] = (bf16x8_t){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-      }
-      // acc[i][j][r]: n = n0 + wn*64 + i*32 + 8*(r>>2) + 4*(lane>>5) + (r&3),  k = k0 + wk*64 + j*32 + (lane & 31)
-      // (k, the contiguous index of C, runs along the lanes: every atomic instruction below covers whole 128-byte rows)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) MmaOps<bf16_t>::mma(fa[i], fb[j], acc[i][j]);
-        if (do_bias && wk == 0) MmaOps<bf16_t>::mma(fa[i], ones, accb[i]);
-      }
-    }
-    if (more) {
-      stash(smem + (cur ^ 1) * 2 * TN_TILE);
-      __syncthreads();
-      cur ^= 1;
-    }
+  for (int t = 0; t < nsteps; t += 2) {
+    TN_FETCH(X, t + 2);
+    TN_COMPUTE(0);
+    if (t + 1 >= nsteps) break;
+    TN_STASH(Y, smem + 2 * TN_OPER, t + 1);
+    __syncthreads();
+    TN_FETCH(Y, t + 3);
+    TN_COMPUTE(1);
+    if (t + 2 >= nsteps) break;
+    TN_STASH(X, smem, t + 2);
+    __syncthreads();
   }
 
   const int kcol = k0 + wk * 64 + (lane & 31);
@@ -134,9 +162,12 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(
     for (int r = 0; r < 16; ++r) {
       const int n = nbase + 8 * (r >> 2) + (r & 3);
       float* crow = C + (int64_t)n * ldc + kcol;
-      atomicAdd(crow, acc[i][0][r]);
-      atomicAdd(crow + 32, acc[i][1][r]);
-      if (do_bias && wk == 0 && (lane & 31) == 0) atomicAdd(bias + n, accb[i][r]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { if (dbg & 2) crow[j * 32] = acc[i][j][r]; else atomicAdd(crow + j * 32, acc[i][j][r]); }   // (dbg 2: measurement only)
+    }
+    if (do_bias) {                          // lanes l and l + 32 hold the two token halves of column (l & 31)
+      const float t = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+      if (lane < 32) atomicAdd(bias + n0 + wn * 64 + i * 32 + lane, t);
     }
   }
 }
@@ -150,10 +181,12 @@ int omk_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, int64_t ld
                 int64_t M, int64_t N, int64_t K, hipStream_t s) {
   if (!omk_gemm_tn_ok(dtype, M, N, K, lda, ldb)) OM_FAIL("gemm_tn: bf16 operands with N and K multiples of 128 only");
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) OM_FAIL("gemm_tn: operands must be 16-byte aligned");
+  const int dbg = om_option(OM_OPT_WGRAD_DEBUG);
   const int64_t tiles = (N / 128) * (K / 128);
   const int64_t steps = (M + TN_BM - 1) / TN_BM;
-  int64_t slices = (1024 + tiles - 1) / tiles;            // ~4 workgroups per CU (two are resident at a time)
-  if (slices > steps / 4) slices = steps / 4 > 0 ? steps / 4 : 1;     // at least 256 tokens per slice
+  const int64_t want = (dbg >> 4) ? (dbg >> 4) * 64 : 320;             // workgroups: one round of two per CU, and no more --
+  int64_t slices = (want + tiles - 1) / tiles;                          // every workgroup flushes 16 384 memory-side atomics
+  if (slices > steps / 4) slices = steps / 4 > 0 ? steps / 4 : 1;       // at least 256 tokens per slice
   const int64_t per = (steps + slices - 1) / slices;
   slices = (steps + per - 1) / per;
   static std::atomic<bool> attr{false};
@@ -164,7 +197,7 @@ int omk_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, int64_t ld
   const bool timing = om_timing_on();
   if (timing) om_timing_begin(OM_TIMING_GEMM_BF16, s);
   hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)tiles, (unsigned)slices), dim3(TN_THREADS), TN_LDS, s, (const bf16_t*)A, lda,
-                     (const bf16_t*)B, ldb, C, ldc, bias, M, (int)N, (int)K, (int)(per * TN_BM));
+                     (const bf16_t*)B, ldb, C, ldc, bias, M, (int)N, (int)K, (int)(per * TN_BM), dbg);
   if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, 2.0 * (double)M * (double)N * (double)K);
   OM_LAUNCH_CHECK();
   return 0;

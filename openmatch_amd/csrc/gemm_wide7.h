@@ -272,8 +272,8 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
           }                                                                                                    \
           if (es.mul) { lo_[0] *= r0; lo_[1] *= r1; hi_[0] *= r2; hi_[1] *= r3; }                              \
           else {                                                                                               \
-            lo_[0] = epi_resid<ACT>(lo_[0], r0, false); lo_[1] = epi_resid<ACT>(lo_[1], r1, false);            \
-            hi_[0] = epi_resid<ACT>(hi_[0], r2, false); hi_[1] = epi_resid<ACT>(hi_[1], r3, false);            \
+            lo_[0] = epi_resid<ACT, sizeof(OutT) == 2>(lo_[0], r0, false); lo_[1] = epi_resid<ACT, sizeof(OutT) == 2>(lo_[1], r1, false);            \
+            hi_[0] = epi_resid<ACT, sizeof(OutT) == 2>(hi_[0], r2, false); hi_[1] = epi_resid<ACT, sizeof(OutT) == 2>(hi_[1], r3, false);            \
           }                                                                                                    \
         }                                                                                                      \
         if (LNF == 2) {                                                                                        \

@@ -66,7 +66,8 @@ Tape carve_tape(const Dims& d, char* base) {
 struct Ws {
   char *g;                          // fwd: GELU output [M,F]
   char *dxa, *dxb, *dy, *dd, *df, *dqkv, *dctx;   // bwd activation gradients
-  char *tl, *tr, *wt;               // transposed operands / transposed weight
+  char *tl, *tr, *wt;               // transposed operands (f32 / odd widths only) / every layer's transposed weights
+  size_t swt;                       // bytes of one layer's transposed weights
   float *dhead, *dpooled;
   // T5 extras: normed-input scratch, gate gradient, bias [nh,L,L], its LUT and per-offset gradient
   char *nbuf, *df2;
@@ -85,7 +86,8 @@ Ws carve_ws(const Dims& d, char* base) {
   w.df = take(mf); w.dqkv = take(3 * mh); w.dctx = take(mh);
   w.tl = take(wide * d.Mp * d.es);
   w.tr = take(wide * d.Mp * d.es);
-  w.wt = take(wide * (size_t)std::max(d.H, d.F) * d.es);
+  w.swt = align_up(((size_t)4 * d.H * d.H + (size_t)(d.gated ? 3 : 2) * d.F * d.H) * d.es, 256);
+  w.wt = take(w.swt * d.nl);
   w.dhead = (float*)take((size_t)d.B * d.D * 4);
   w.dpooled = (float*)take((size_t)d.B * d.H * 4);
   w.nbuf = take(d.t5 ? mh : 0);
@@ -95,6 +97,32 @@ Ws carve_ws(const Dims& d, char* base) {
   w.lut = (int*)take(d.t5 ? (size_t)(2 * d.L) * 4 : 0);
   w.total = off;
   return w;
+}
+
+// W^T of every dense weight of the encoder, all layers in one launch: layer l at ws.wt + l * ws.swt holds
+// [Wqkv^T (H x 3H) | Wo^T (H x H) | W1^T (H x F) | W2^T (F x H) | gated T5: W1g^T (H x F)]
+struct WtView { const char *qkv, *o, *f1, *f2, *f1g; };
+WtView wt_of(const Dims& d, const Ws& ws, int l) {
+  const char* p = ws.wt + ws.swt * l;
+  WtView v;
+  v.qkv = p; p += (size_t)3 * d.H * d.H * d.es;
+  v.o = p; p += (size_t)d.H * d.H * d.es;
+  v.f1 = p; p += (size_t)d.F * d.H * d.es;
+  v.f2 = p; p += (size_t)d.F * d.H * d.es;
+  v.f1g = p;
+  return v;
+}
+int transpose_weights(int dt, const OmLayerWeights* Ls, const Dims& d, Ws& ws, hipStream_t s) {
+  std::vector<const void*> in; std::vector<void*> out; std::vector<int> R, C;
+  for (int l = 0; l < d.nl; ++l) {
+    const WtView v = wt_of(d, ws, l);
+    in.push_back(Ls[l].qkv_w); out.push_back((void*)v.qkv); R.push_back(3 * d.H); C.push_back(d.H);
+    in.push_back(Ls[l].o_w); out.push_back((void*)v.o); R.push_back(d.H); C.push_back(d.H);
+    in.push_back(Ls[l].ffn1_w); out.push_back((void*)v.f1); R.push_back(d.F); C.push_back(d.H);
+    in.push_back(Ls[l].ffn2_w); out.push_back((void*)v.f2); R.push_back(d.H); C.push_back(d.F);
+    if (d.gated) { in.push_back(Ls[l].ffn1g_w); out.push_back((void*)v.f1g); R.push_back(d.F); C.push_back(d.H); }
+  }
+  return omk_transpose_batch(dt, in.data(), out.data(), R.data(), C.data(), (int)in.size(), s);
 }
 
 // Weight and bias gradients of one nn.Linear: dW[N,K] += dY^T X, db[N] += column sums of dY (db may be NULL), f32
@@ -200,6 +228,7 @@ int t5_train_backward(const OmEncoderConfig* c, const OmEncoderWeights* w, const
   RUN(t5_bias_setup(c, w, d, ws, s));
   OM_HIP(hipMemsetAsync(ws.drel, 0, (size_t)d.nh * (2 * d.L) * 4, s));
 #define WGRAD(dY_, N_, X_, K_, dW_) RUN(wgrad(dt, dY_, N_, X_, K_, dW_, nullptr, d, ws, s))
+  RUN(transpose_weights(dt, Ls, d, ws, s));
   // final dropout + RMSNorm
   if (hd > 0.f) RUN(omk_dropout(dt, dx, dx, M * H, hd, site_seed(seed, d.nl, 1), s));
   RUN(omk_norm_bwd(dt, dx, t.x + t.sx * d.nl, w->final_ln_g, dx_other, g->final_ln_g, nullptr, M, H, c->ln_eps, 1, nullptr, s));
@@ -214,15 +243,15 @@ int t5_train_backward(const OmEncoderConfig* c, const OmEncoderWeights* w, const
     const char* x1 = t.x1 + t.sx * l;
     const char* f = t.f + t.sf * l;
     const char* f2 = d.gated ? t.f2 + t.sf * l : nullptr;
+    const WtView wt = wt_of(d, ws, l);
     // ---- feed-forward branch
     const char* dO = dx;
     if (hd > 0.f) { RUN(omk_dropout(dt, dx, ws.dd, M * H, hd, site_seed(seed, l, 4), s)); dO = ws.dd; }
     RUN(omk_t5_act_fwd(dt, f, f2, ws.g, M * F, kind, s));                     // g = act(f) [* f2]
     if (hd > 0.f) RUN(omk_dropout(dt, ws.g, ws.g, M * F, hd, site_seed(seed, l, 5), s));
     WGRAD(dO, H, ws.g, F, lg.ffn2_w);                                         // dWo2 [H,F]
-    RUN(omk_transpose(dt, lw.ffn2_w, F, H, F, ws.wt, H, H, 0, s));            // Wo2^T [F,H]
     GemmEpilogue e = {};
-    RUN(omk_gemm(dt, dO, H, ws.wt, H, dt, ws.df, F, M, F, H, e, s));          // dg = dO Wo2
+    RUN(omk_gemm(dt, dO, H, wt.f2, H, dt, ws.df, F, M, F, H, e, s));          // dg = dO Wo2;  Wo2^T [F,H]
     if (hd > 0.f) RUN(omk_dropout(dt, ws.df, ws.df, M * F, hd, site_seed(seed, l, 5), s));
     RUN(omk_t5_act_bwd(dt, ws.df, f, f2, ws.df, ws.df2, M * F, kind, s));     // df (in place), df2
     RUN(omk_layernorm(dt, x1, H, ws.nbuf, H, lw.ln2_g, nullptr, M, H, c->ln_eps, 1, s));   // n2 again
@@ -231,30 +260,26 @@ int t5_train_backward(const OmEncoderConfig* c, const OmEncoderWeights* w, const
       if (!lg.ffn1g_w) OM_FAIL("gated T5 gradients need ffn1g_w");
       WGRAD(ws.df2, F, ws.nbuf, H, lg.ffn1g_w);                               // dWi_1 [F,H]
     }
-    RUN(omk_transpose(dt, lw.ffn1_w, H, F, H, ws.wt, F, F, 0, s));            // Wi^T [H,F]
     e = GemmEpilogue{};
-    RUN(omk_gemm(dt, ws.df, F, ws.wt, F, dt, ws.dy, H, M, H, F, e, s));       // dn2 = df Wi
+    RUN(omk_gemm(dt, ws.df, F, wt.f1, F, dt, ws.dy, H, M, H, F, e, s));       // dn2 = df Wi;  Wi^T [H,F]
     if (d.gated) {
-      RUN(omk_transpose(dt, lw.ffn1g_w, H, F, H, ws.wt, F, F, 0, s));
       e = GemmEpilogue{};
       e.resid = ws.dy; e.ldr = H;
-      RUN(omk_gemm(dt, ws.df2, F, ws.wt, F, dt, ws.dy, H, M, H, F, e, s));    // += df2 Wi_1
+      RUN(omk_gemm(dt, ws.df2, F, wt.f1g, F, dt, ws.dy, H, M, H, F, e, s));   // += df2 Wi_1
     }
     RUN(omk_norm_bwd(dt, ws.dy, x1, lw.ln2_g, dx_other, lg.ln2_g, nullptr, M, H, c->ln_eps, 1, dx, s));   // dx1
     // ---- attention branch (dx_other now holds d/d x1)
     const char* dA = dx_other;
     if (hd > 0.f) { RUN(omk_dropout(dt, dx_other, ws.dd, M * H, hd, site_seed(seed, l, 3), s)); dA = ws.dd; }
     WGRAD(dA, H, ctx, H, lg.o_w);
-    RUN(omk_transpose(dt, lw.o_w, H, H, H, ws.wt, H, H, 0, s));
     e = GemmEpilogue{};
-    RUN(omk_gemm(dt, dA, H, ws.wt, H, dt, ws.dctx, H, M, H, H, e, s));        // dctx = dA Wo
+    RUN(omk_gemm(dt, dA, H, wt.o, H, dt, ws.dctx, H, M, H, H, e, s));         // dctx = dA Wo
     RUN(omk_attention_bwd_bias(dt, qkv, ws.dctx, ws.dqkv, attention_mask, d.B, (int)d.L, H, d.nh, 1.0f, ad,
                                site_seed(seed, l, 2), ws.posbias, ws.drel, s));
     RUN(omk_layernorm(dt, x, H, ws.nbuf, H, lw.ln1_g, nullptr, M, H, c->ln_eps, 1, s));    // n1 again
     WGRAD(ws.dqkv, 3 * H, ws.nbuf, H, lg.qkv_w);
-    RUN(omk_transpose(dt, lw.qkv_w, H, 3 * H, H, ws.wt, 3 * H, 3 * H, 0, s));
     e = GemmEpilogue{};
-    RUN(omk_gemm(dt, ws.dqkv, 3 * H, ws.wt, 3 * H, dt, ws.dy, H, M, H, 3 * H, e, s));   // dn1
+    RUN(omk_gemm(dt, ws.dqkv, 3 * H, wt.qkv, 3 * H, dt, ws.dy, H, M, H, 3 * H, e, s));  // dn1
     RUN(omk_norm_bwd(dt, ws.dy, x, lw.ln1_g, dx, lg.ln1_g, nullptr, M, H, c->ln_eps, 1, dx_other, s));   // dx of layer input
   }
 #undef WGRAD
@@ -402,6 +427,7 @@ extern "C" int om_encoder_train_backward(const OmEncoderConfig* c, const OmEncod
                              dx_prev, g, s);
 
 #define WGRAD(dY_, N_, X_, K_, dW_, db_) RUN(wgrad(dt, dY_, N_, X_, K_, dW_, db_, d, ws, s))
+  RUN(transpose_weights(dt, Ls, d, ws, s));
 
   for (int l = d.nl - 1; l >= 0; --l) {
     const OmLayerWeights& lw = Ls[l];
@@ -414,44 +440,39 @@ extern "C" int om_encoder_train_backward(const OmEncoderConfig* c, const OmEncod
     const char* f = t.f + t.sf * l;
     const char* gl = t.g + t.sf * l;
     const char* y2 = t.y2 + t.sx * l;
+    const WtView wt = wt_of(d, ws, l);
 
     // LN2 backward: dy2 = d(loss)/d(y2)
-    RUN(omk_ln_bwd(dt, dx, y2, lw.ln2_g, ws.dy, lg.ln2_g, lg.ln2_b, M, H, c->ln_eps, s));
-    // FFN output branch (dropout after the dense, before the residual add)
-    const char* dO = ws.dy;
-    if (hidden_dropout > 0.f) { RUN(omk_dropout(dt, ws.dy, ws.dd, M * H, hidden_dropout, site_seed(seed, l, 4), s)); dO = ws.dd; }
+    // (+ the FFN output branch's dropout, which sits after the dense and before the residual add, in the same pass)
+    RUN(omk_ln_bwd_drop(dt, dx, y2, lw.ln2_g, ws.dy, ws.dd, hidden_dropout, site_seed(seed, l, 4), lg.ln2_g, lg.ln2_b, M, H, c->ln_eps, s));
+    const char* dO = hidden_dropout > 0.f ? ws.dd : ws.dy;
     WGRAD(dO, H, gl, F, lg.ffn2_w, lg.ffn2_b);                      // dW2 [H,F], db2
-    RUN(omk_transpose(dt, lw.ffn2_w, F, H, F, ws.wt, H, H, 0, s));  // W2^T [F,H]
     {
       GemmEpilogue e1 = {};
-      e1.act = OM_ACT_GELU_ERF_GRAD; e1.resid = f; e1.ldr = F;      // df = (dO W2) * gelu'(f)
-      RUN(omk_gemm(dt, dO, H, ws.wt, H, dt, ws.df, F, M, F, H, e1, s));
+      e1.act = OM_ACT_GELU_ERF_GRAD; e1.resid = f; e1.ldr = F;      // df = (dO W2) * gelu'(f);  W2^T [F,H]
+      RUN(omk_gemm(dt, dO, H, wt.f2, H, dt, ws.df, F, M, F, H, e1, s));
     }
     WGRAD(ws.df, F, x1, H, lg.ffn1_w, lg.ffn1_b);                   // dW1 [F,H], db1
-    RUN(omk_transpose(dt, lw.ffn1_w, H, F, H, ws.wt, F, F, 0, s));  // W1^T [H,F]
     {
       GemmEpilogue e2 = {};
-      e2.resid = ws.dy; e2.ldr = H;                                 // dx1 = df W1 + dy2 (residual path)
-      RUN(omk_gemm(dt, ws.df, F, ws.wt, F, dt, ws.dctx, H, M, H, F, e2, s));
+      e2.resid = ws.dy; e2.ldr = H;                                 // dx1 = df W1 + dy2 (residual path);  W1^T [H,F]
+      RUN(omk_gemm(dt, ws.df, F, wt.f1, F, dt, ws.dctx, H, M, H, F, e2, s));
     }
     // LN1 backward (ws.dctx holds d/d(x1) for now)
-    RUN(omk_ln_bwd(dt, ws.dctx, y1, lw.ln1_g, ws.dy, lg.ln1_g, lg.ln1_b, M, H, c->ln_eps, s));
-    const char* dA = ws.dy;
-    if (hidden_dropout > 0.f) { RUN(omk_dropout(dt, ws.dy, ws.dd, M * H, hidden_dropout, site_seed(seed, l, 3), s)); dA = ws.dd; }
+    RUN(omk_ln_bwd_drop(dt, ws.dctx, y1, lw.ln1_g, ws.dy, ws.dd, hidden_dropout, site_seed(seed, l, 3), lg.ln1_g, lg.ln1_b, M, H, c->ln_eps, s));
+    const char* dA = hidden_dropout > 0.f ? ws.dd : ws.dy;
     WGRAD(dA, H, ctx, H, lg.o_w, lg.o_b);                           // dWo [H,H], dbo
-    RUN(omk_transpose(dt, lw.o_w, H, H, H, ws.wt, H, H, 0, s));     // Wo^T
     {
       GemmEpilogue e3 = {};
-      RUN(omk_gemm(dt, dA, H, ws.wt, H, dt, ws.dctx, H, M, H, H, e3, s));   // dctx = dA Wo
+      RUN(omk_gemm(dt, dA, H, wt.o, H, dt, ws.dctx, H, M, H, H, e3, s));    // dctx = dA Wo
     }
     RUN(omk_attention_bwd(dt, qkv, ws.dctx, ws.dqkv, attention_mask, B, (int)L, H, d.nh, scale,
                           attn_dropout, site_seed(seed, l, 2), s));
     WGRAD(ws.dqkv, 3 * H, x, H, lg.qkv_w, lg.qkv_b);                // dWqkv [3H,H], dbqkv
-    RUN(omk_transpose(dt, lw.qkv_w, H, 3 * H, H, ws.wt, 3 * H, 3 * H, 0, s));   // Wqkv^T [H,3H]
     {
       GemmEpilogue e4 = {};
-      e4.resid = ws.dy; e4.ldr = H;                                 // dx = dqkv Wqkv + dy1
-      RUN(omk_gemm(dt, ws.dqkv, 3 * H, ws.wt, 3 * H, dt, dx_prev, H, M, H, 3 * H, e4, s));
+      e4.resid = ws.dy; e4.ldr = H;                                 // dx = dqkv Wqkv + dy1;  Wqkv^T [H,3H]
+      RUN(omk_gemm(dt, ws.dqkv, 3 * H, wt.qkv, 3 * H, dt, dx_prev, H, M, H, 3 * H, e4, s));
     }
     char* tmp = dx; dx = dx_prev; dx_prev = tmp;
   }

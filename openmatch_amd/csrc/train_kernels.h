@@ -4,10 +4,15 @@
 
 int omk_transpose(int dtype, const void* in, int64_t ldi, int64_t R, int C, void* out, int64_t ldo,
                   int64_t Rp, int op, hipStream_t s);
+// n dense transposes out[i][c][r] = in[i][r][c] (R[i] x C[i]) in one launch per 40 matrices
+int omk_transpose_batch(int dtype, const void* const* in, void* const* out, const int* R, const int* C, int n, hipStream_t s);
 int omk_colsum(int dtype, const void* x, int64_t ld, int64_t M, int N, float* out, hipStream_t s);
 int omk_dropout(int dtype, const void* x, void* y, int64_t n, float p, uint64_t seed, hipStream_t s);
 int omk_ln_bwd(int dtype, const void* dy, const void* x, const float* g, void* dx, float* dg,
                float* db, int64_t M, int H, float eps, hipStream_t s);
+// LayerNorm backward that also writes dx_drop = dropout(dx) (mask of the forward: seed, element index) when drop_p > 0
+int omk_ln_bwd_drop(int dtype, const void* dy, const void* x, const float* g, void* dx, void* dx_drop, float drop_p,
+                    uint64_t drop_seed, float* dg, float* db, int64_t M, int H, float eps, hipStream_t s);
 // LayerNorm (rms = 0) or T5 RMSNorm (rms = 1) backward; `add` (optional, same shape) is added to dx
 int omk_norm_bwd(int dtype, const void* dy, const void* x, const float* g, void* dx, float* dg,
                  float* db, int64_t M, int H, float eps, int rms, const void* add, hipStream_t s);

@@ -49,6 +49,52 @@ int omk_transpose(int dtype, const void* in, int64_t ldi, int64_t R, int C, void
   return 0;
 }
 
+// Many small transposes in one launch (every weight matrix of the encoder, once per backward: the dgrad GEMMs read W^T).
+// 48 separate launches of ~10 us each were 0.5 ms of a 15 ms training step (profiles/r02_train_kernel_stats_v3.csv).
+struct TransposeJob { const void* in; void* out; int R, C; int tile0; };     // out[c][r] = in[r][c], both dense
+struct TransposeBatch { TransposeJob job[40]; int n; };
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch b) {
+  __shared__ float tile[64][65];
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.job[j + 1].tile0) ++j;
+  const TransposeJob& jb = b.job[j];
+  const int t = blockIdx.x - jb.tile0, tc = (jb.C + 63) / 64;
+  const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+  const T* in = (const T*)jb.in;
+  T* out = (T*)jb.out;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty + 4 * i, c = c0 + tx;
+    tile[ty + 4 * i][tx] = (r < jb.R && c < jb.C) ? ElemOps<T>::load(in + (int64_t)r * jb.C + c) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i, r = r0 + tx;
+    if (c < jb.C && r < jb.R) ElemOps<T>::store(out + (int64_t)c * jb.R + r, tile[tx][ty + 4 * i]);
+  }
+}
+
+int omk_transpose_batch(int dtype, const void* const* in, void* const* out, const int* R, const int* C, int n, hipStream_t s) {
+  for (int at = 0; at < n;) {
+    TransposeBatch b;
+    int tiles = 0;
+    b.n = 0;
+    while (at < n && b.n < 40) {
+      b.job[b.n] = TransposeJob{in[at], out[at], R[at], C[at], tiles};
+      tiles += ((R[at] + 63) / 64) * ((C[at] + 63) / 64);
+      ++b.n; ++at;
+    }
+    if (!tiles) continue;
+    if (dtype == OM_BF16) hipLaunchKernelGGL((transpose_batch_kernel<bf16_t>), dim3((unsigned)tiles), dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((transpose_batch_kernel<float>), dim3((unsigned)tiles), dim3(256), 0, s, b);
+    OM_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 // out[c] += sum_r x[r][c]      (out is f32 and zero-initialised by the caller)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t ld, int64_t M,
@@ -95,6 +141,26 @@ int omk_dropout(int dtype, const void* x, void* y, int64_t n, float p, uint64_t 
   return 0;
 }
 
+// four consecutive elements as one 8-byte (bf16) / 16-byte (f32) access: p must be that aligned
+template <typename T> __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float (&v)[4]) {
+  const uint2 w = *(const uint2*)p;
+  v[0] = __uint_as_float(w.x << 16); v[1] = __uint_as_float(w.x & 0xffff0000u);
+  v[2] = __uint_as_float(w.y << 16); v[3] = __uint_as_float(w.y & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
+  const float4 w = *(const float4*)p;
+  v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w;
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4]) {
+  *(uint2*)p = make_uint2((uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16),
+                          (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16));
+}
+template <> __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4]) {
+  *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // ---------------------------------------------------------------------------------------
 // LayerNorm backward.  One wavefront per row, 4 rows per block pass, grid-stride over rows;
 // d_gamma / d_beta are accumulated per lane in registers and flushed once per block.
@@ -103,18 +169,24 @@ int omk_dropout(int dtype, const void* x, void* y, int64_t n, float p, uint64_t 
 // MODE 0: x is read from memory (the saved pre-LN sum).
 // MODE 1: x = word[id] + type[tt] + pos[t] is recomputed and dx is scattered into the three
 //         embedding-table gradients (BERT embeddings backward).
+// Eight waves per block and at most one block per CU: every block ends with one f32 atomic per column into d_gamma /
+// d_beta, and 1024 blocks adding into the same 96 cache lines serialised at the memory side (41 us per call at
+// 9216 x 768, profiles/r02_train_kernel_stats_v3.csv) -- the block count, not the bytes, set the time.
+constexpr int LNB_WAVES = 8;
 template <typename T, int NV, int MODE>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ g,
     T* __restrict__ dx, float* __restrict__ dg, float* __restrict__ db, int64_t M, int H, float eps,
     const int64_t* __restrict__ ids, const int64_t* __restrict__ type_ids,
     const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
     float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype_, int L, int vocab,
-    int type_vocab, int rms, const T* __restrict__ add) {
+    int type_vocab, int rms, const T* __restrict__ add, T* __restrict__ dx_drop, float drop_p, uint64_t drop_seed) {
+  // dx_drop != NULL: also writes dropout(dx) with the forward's mask (seed, element index) -- the gradient entering the
+  // dense layer in front of the residual add -- so that no separate dropout pass re-reads dx.
   // rms != 0: T5LayerNorm (no mean, no bias): xhat = x * rstd, rstd = rsqrt(mean(x^2) + eps).
   // add != NULL: dx = (this backward) + add  (the residual stream's gradient, pre-norm stacks).
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = (float*)smem;                       // [2][4][H]
+  float* red = (float*)smem;                       // [2][LNB_WAVES][H]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float gacc[NV][4], bacc[NV][4], gv[NV][4];
   // MODE 1: every token adds into one of (usually) two token-type rows -- thousands of atomics per
@@ -131,7 +203,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
       if (MODE == 1) tacc[MODE == 1 ? 1 : 0][j][e] = 0.f;
     }
   }
-  for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < M; row += (int64_t)gridDim.x * 4) {
+  for (int64_t row = (int64_t)blockIdx.x * LNB_WAVES + w; row < M; row += (int64_t)gridDim.x * LNB_WAVES) {
     float xv[NV][4], dv[NV][4];
     int64_t id = 0, tt = 0;
     int t = 0;
@@ -146,14 +218,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
       const int c = (lane + 64 * j) * 4;
       if (c < H) {
         if (MODE == 0) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) xv[j][e] = ElemOps<T>::load(x + row * H + c + e);
+          load4<T>(x + row * H + c, xv[j]);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) xv[j][e] = (word[id * H + c + e] + type[tt * H + c + e]) + pos[(int64_t)t * H + c + e];
         }
+        load4<T>(dy + row * H + c, dv[j]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { dv[j][e] = ElemOps<T>::load(dy + row * H + c + e); s1 += xv[j][e]; }
+        for (int e = 0; e < 4; ++e) s1 += xv[j][e];
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { xv[j][e] = 0.f; dv[j][e] = 0.f; }
@@ -183,17 +255,36 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
         }
       }
     m1 = rms ? 0.f : wave_sum(m1) / (float)H; m2 = wave_sum(m2) / (float)H;
+    const uint32_t drop_thresh = (MODE == 0 && dx_drop) ? (uint32_t)(drop_p * 4294967296.0) : 0u;
+    const float drop_scale = 1.0f / (1.0f - drop_p);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int c = (lane + 64 * j) * 4;
       if (c < H) {
+        float out[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = rstd * (dv[j][e] * gv[j][e] - m1 - xv[j][e] * m2);
-          if (MODE == 0) {
-            if (add) v += ElemOps<T>::load(add + row * H + c + e);
-            ElemOps<T>::store(dx + row * H + c + e, v);
-          } else {
+        for (int e = 0; e < 4; ++e) out[e] = rstd * (dv[j][e] * gv[j][e] - m1 - xv[j][e] * m2);
+        if (MODE == 0) {
+          if (add) {
+            float av[4];
+            load4<T>(add + row * H + c, av);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[e] += av[e];
+          }
+          store4<T>(dx + row * H + c, out);
+          if (dx_drop) {               // dropout of the value as stored (rounded to T), like the separate pass it replaces
+            float dr[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float vb = sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(out[e])) : out[e];
+              dr[e] = dropout_keep(drop_seed, (uint64_t)(row * H + c + e), drop_thresh) ? vb * drop_scale : 0.f;
+            }
+            store4<T>(dx_drop + row * H + c, dr);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = out[e];
             atomicAdd(dword + id * H + c + e, v);
             if (tt == 0) tacc[0][j][e] += v;
             else if (tt == 1) tacc[MODE == 1 ? 1 : 0][j][e] += v;
@@ -210,13 +301,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const int c = (lane + 64 * j) * 4;
     if (c < H) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { red[(0 * 4 + w) * H + c + e] = gacc[j][e]; red[(1 * 4 + w) * H + c + e] = bacc[j][e]; }
+      for (int e = 0; e < 4; ++e) { red[(0 * LNB_WAVES + w) * H + c + e] = gacc[j][e]; red[(1 * LNB_WAVES + w) * H + c + e] = bacc[j][e]; }
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < H; c += 256) {
-    atomicAdd(dg + c, (red[0 * H + c] + red[1 * H + c]) + (red[2 * H + c] + red[3 * H + c]));
-    if (db) atomicAdd(db + c, (red[4 * H + c] + red[5 * H + c]) + (red[6 * H + c] + red[7 * H + c]));
+  for (int c = threadIdx.x; c < H; c += 64 * LNB_WAVES) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < LNB_WAVES; ++k) { sg += red[k * H + c]; sb += red[(LNB_WAVES + k) * H + c]; }
+    atomicAdd(dg + c, sg);
+    if (db) atomicAdd(db + c, sb);
   }
   if (MODE == 1) {                     // token-type rows 0 and 1: same block reduction, then one atomic per column
     __syncthreads();
@@ -225,13 +319,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
       const int c = (lane + 64 * j) * 4;
       if (c < H) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { red[(0 * 4 + w) * H + c + e] = tacc[0][j][e]; red[(1 * 4 + w) * H + c + e] = tacc[MODE == 1 ? 1 : 0][j][e]; }
+        for (int e = 0; e < 4; ++e) { red[(0 * LNB_WAVES + w) * H + c + e] = tacc[0][j][e]; red[(1 * LNB_WAVES + w) * H + c + e] = tacc[MODE == 1 ? 1 : 0][j][e]; }
       }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < H; c += 256) {
-      atomicAdd(dtype_ + c, (red[0 * H + c] + red[1 * H + c]) + (red[2 * H + c] + red[3 * H + c]));
-      if (type_vocab > 1) atomicAdd(dtype_ + H + c, (red[4 * H + c] + red[5 * H + c]) + (red[6 * H + c] + red[7 * H + c]));
+    for (int c = threadIdx.x; c < H; c += 64 * LNB_WAVES) {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < LNB_WAVES; ++k) { s0 += red[k * H + c]; s1 += red[(LNB_WAVES + k) * H + c]; }
+      atomicAdd(dtype_ + c, s0);
+      if (type_vocab > 1) atomicAdd(dtype_ + H + c, s1);
     }
   }
 }
@@ -241,10 +338,18 @@ static int launch_ln_bwd(const void* dy, const void* x, const float* g, void* dx
                          int64_t M, int H, float eps, const int64_t* ids, const int64_t* tt,
                          const float* word, const float* pos, const float* type, float* dword,
                          float* dpos, float* dtype_, int L, int vocab, int type_vocab, hipStream_t s,
-                         int rms = 0, const void* add = nullptr) {
-  const unsigned grid = (unsigned)((M + 3) / 4 > 1024 ? 1024 : (M + 3) / 4);
-  const size_t lds = (size_t)8 * H * sizeof(float);
-#define LNB(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, MODE>), dim3(grid), dim3(256), lds, s, (const T*)dy, (const T*)x, g, (T*)dx, dg, db, M, H, eps, ids, tt, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, rms, (const T*)add)
+                         int rms = 0, const void* add = nullptr, void* dx_drop = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0) {
+  const int64_t want = (M + LNB_WAVES - 1) / LNB_WAVES;
+  const unsigned grid = (unsigned)(want > 256 ? 256 : want);
+  const size_t lds = (size_t)2 * LNB_WAVES * H * sizeof(float);
+  if (lds > 64 * 1024) {
+    static std::atomic<bool> attr{false};
+    if (!attr) {
+      OM_HIP(hipFuncSetAttribute((const void*)ln_bwd_kernel<T, 8, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LNB_WAVES * 2048 * 4));
+      attr = true;
+    }
+  }
+#define LNB(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, MODE>), dim3(grid), dim3(64 * LNB_WAVES), lds, s, (const T*)dy, (const T*)x, g, (T*)dx, dg, db, M, H, eps, ids, tt, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, rms, (const T*)add, (T*)dx_drop, drop_p, drop_seed)
   if (H <= 1024) LNB(4); else LNB(8);
 #undef LNB
   OM_LAUNCH_CHECK();
@@ -254,6 +359,16 @@ static int launch_ln_bwd(const void* dy, const void* x, const float* g, void* dx
 int omk_ln_bwd(int dtype, const void* dy, const void* x, const float* g, void* dx, float* dg,
                float* db, int64_t M, int H, float eps, hipStream_t s) {
   return omk_norm_bwd(dtype, dy, x, g, dx, dg, db, M, H, eps, 0, nullptr, s);
+}
+
+int omk_ln_bwd_drop(int dtype, const void* dy, const void* x, const float* g, void* dx, void* dx_drop, float drop_p,
+                    uint64_t drop_seed, float* dg, float* db, int64_t M, int H, float eps, hipStream_t s) {
+  if (M <= 0) return 0;
+  if (H % 4 || H > 2048) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
+  if (drop_p <= 0.f) dx_drop = nullptr;
+  if (dtype == OM_BF16)
+    return launch_ln_bwd<bf16_t, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, 0, nullptr, dx_drop, drop_p, drop_seed);
+  return launch_ln_bwd<float, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, 0, nullptr, dx_drop, drop_p, drop_seed);
 }
 
 int omk_norm_bwd(int dtype, const void* dy, const void* x, const float* g, void* dx, float* dg,

@@ -346,7 +346,7 @@ int main(int argc, char** argv) {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs=%d  clock=%d MHz  mem=%.1f GB  LDS/block=%zu\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000, prop.totalGlobalMem / 1e9, prop.sharedMemPerBlock);
 
-  if (what != "bench" && what != "prof" && what != "trace" && what != "shapes" && what != "layer" && what != "gen7" && what != "scantrace") {
+  if (what != "bench" && what != "prof" && what != "trace" && what != "shapes" && what != "layer" && what != "gen7" && what != "scantrace" && what != "tn") {
     // GEMM: aligned, ragged M/N tails, every epilogue, both dtypes
     test_gemm(OM_F32, 128, 128, 32, false, false, OM_ACT_NONE, OM_F32);
     test_gemm(OM_BF16, 128, 128, 64, false, false, OM_ACT_NONE, OM_F32);
@@ -425,6 +425,34 @@ int main(int argc, char** argv) {
     om_debug_gemm_gen(0);
     printf("%s: %d failure(s)\n", g_fail ? "SELFTEST FAILED" : "SELFTEST PASSED", g_fail);
     return g_fail ? 1 : 0;
+  }
+  if (what == "tn") {       // weight-gradient contraction: time per shape under the debug variants of OM_OPT_WGRAD_DEBUG
+    const int64_t M = argc > 2 ? atoll(argv[2]) : 9216;
+    const int shapes[4][2] = {{768, 768}, {768, 3072}, {3072, 768}, {2304, 768}};
+    for (auto& sh : shapes) {
+      const int N = sh[0], K = sh[1];
+      bf16* dA = upload(to_bf16(randn((size_t)M * N, 1.f)));
+      bf16* dB = upload(to_bf16(randn((size_t)M * K, 1.f)));
+      float* dC = dalloc<float>((size_t)N * K); float* db = dalloc<float>(N);
+      std::vector<int> variants = {0, 4 << 4, 8 << 4, 2, 4};
+      if (argc > 3) { variants.clear(); for (int a = 3; a < argc; ++a) variants.push_back(atoi(argv[a])); }
+      for (int variant : variants) {
+        om_debug_option(OM_OPT_WGRAD_DEBUG, variant);
+        CK(hipMemset(dC, 0, (size_t)N * K * 4)); CK(hipMemset(db, 0, N * 4));
+        for (int r = 0; r < 3; ++r) OMCK(om_gemm_tn_acc(OM_BF16, dA, N, dB, K, dC, K, db, M, N, K, nullptr));
+        CK(hipDeviceSynchronize());
+        auto t0 = std::chrono::steady_clock::now();
+        const int reps = 20;
+        for (int r = 0; r < reps; ++r) OMCK(om_gemm_tn_acc(OM_BF16, dA, N, dB, K, dC, K, db, M, N, K, nullptr));
+        CK(hipDeviceSynchronize());
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+        printf("[BENCH] gemm_tn M=%ld N=%d K=%d variant=%d (%s%s%s, ~%d workgroups): %.1f us  %.1f TFLOP/s\n", (long)M, N, K, variant, "128x128",
+               (variant & 2) ? ", plain stores" : "", (variant & 4) ? ", one step" : "", (variant >> 4) * 64, us, 2.0 * M * N * K / us * 1e-6);
+      }
+      om_debug_option(OM_OPT_WGRAD_DEBUG, 0);
+      CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(db));
+    }
+    return 0;
   }
   if (what == "scantrace") {     // tile phase timeline of the generation-7 index scan (first 8192 tiles of the last round)
     const int64_t N = argc > 2 ? atoll(argv[2]) : 2000000; const int Q = argc > 3 ? atoi(argv[3]) : 6980, d = 768, k = 1000;
