@@ -172,15 +172,16 @@ template <> __device__ __forceinline__ void store4<float>(float* p, const float 
 // Eight waves per block and at most one block per CU: every block ends with one f32 atomic per column into d_gamma /
 // d_beta, and 1024 blocks adding into the same 96 cache lines serialised at the memory side (41 us per call at
 // 9216 x 768, profiles/r02_train_kernel_stats_v3.csv) -- the block count, not the bytes, set the time.
-constexpr int LNB_WAVES = 8;
+// (Four waves for hidden sizes above 1024: the wider per-lane state needs the 256-register budget.)
 template <typename T, int NV, int MODE>
-__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(
+__global__ __launch_bounds__(NV == 8 ? 256 : 512) void ln_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ g,
     T* __restrict__ dx, float* __restrict__ dg, float* __restrict__ db, int64_t M, int H, float eps,
     const int64_t* __restrict__ ids, const int64_t* __restrict__ type_ids,
     const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
     float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype_, int L, int vocab,
     int type_vocab, int rms, const T* __restrict__ add, T* __restrict__ dx_drop, float drop_p, uint64_t drop_seed) {
+  constexpr int LNB_WAVES = NV == 8 ? 4 : 8;
   // dx_drop != NULL: also writes dropout(dx) with the forward's mask (seed, element index) -- the gradient entering the
   // dense layer in front of the residual add -- so that no separate dropout pass re-reads dx.
   // rms != 0: T5LayerNorm (no mean, no bias): xhat = x * rstd, rstd = rsqrt(mean(x^2) + eps).
@@ -339,17 +340,11 @@ static int launch_ln_bwd(const void* dy, const void* x, const float* g, void* dx
                          const float* word, const float* pos, const float* type, float* dword,
                          float* dpos, float* dtype_, int L, int vocab, int type_vocab, hipStream_t s,
                          int rms = 0, const void* add = nullptr, void* dx_drop = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0) {
-  const int64_t want = (M + LNB_WAVES - 1) / LNB_WAVES;
+  const int waves = H <= 1024 ? 8 : 4;
+  const int64_t want = (M + waves - 1) / waves;
   const unsigned grid = (unsigned)(want > 256 ? 256 : want);
-  const size_t lds = (size_t)2 * LNB_WAVES * H * sizeof(float);
-  if (lds > 64 * 1024) {
-    static std::atomic<bool> attr{false};
-    if (!attr) {
-      OM_HIP(hipFuncSetAttribute((const void*)ln_bwd_kernel<T, 8, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LNB_WAVES * 2048 * 4));
-      attr = true;
-    }
-  }
-#define LNB(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, MODE>), dim3(grid), dim3(64 * LNB_WAVES), lds, s, (const T*)dy, (const T*)x, g, (T*)dx, dg, db, M, H, eps, ids, tt, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, rms, (const T*)add, (T*)dx_drop, drop_p, drop_seed)
+  const size_t lds = (size_t)2 * waves * H * sizeof(float);       // <= 64 KiB for both shapes
+#define LNB(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, MODE>), dim3(grid), dim3(64 * waves), lds, s, (const T*)dy, (const T*)x, g, (T*)dx, dg, db, M, H, eps, ids, tt, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, rms, (const T*)add, (T*)dx_drop, drop_p, drop_seed)
   if (H <= 1024) LNB(4); else LNB(8);
 #undef LNB
   OM_LAUNCH_CHECK();
