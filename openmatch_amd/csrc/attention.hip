@@ -107,15 +107,15 @@ __global__ __launch_bounds__(64 * KT) void attention_kernel(
   for (int t = 0; t < KT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[t][r] *= inv;
-  if (drop_p > 0.f) {      // training: attention_probs dropout, mask regenerated in the backward
-    const uint32_t thresh = (uint32_t)(drop_p * 4294967296.0);
-    const float keep_scale = 1.0f / (1.0f - drop_p);
+  if (drop_p > 0.f) {      // training: attention_probs dropout, mask regenerated in the backward (attn_common.h)
+    const AttnDrop dr(drop_p);
 #pragma unroll
     for (int t = 0; t < KT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        s[t][r] = dropout_keep(seed, attn_drop_idx(b, h, heads, L, q0 + l31, key), thresh) ? s[t][r] * keep_scale : 0.f;
+      for (int g = 0; g < 4; ++g) {
+        const uint64_t bits = attn_drop_bits(seed, b, h, heads, L, q0 + l31, (t * 32 + 8 * g + 4 * half) >> 2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[t][4 * g + e] = attn_drop_keep(bits, e, dr.thresh) ? s[t][4 * g + e] * dr.keep_scale : 0.f;
       }
   }
 

@@ -517,8 +517,9 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
   const T* base = qkv + b * L * ld + h * 64;
   const T* dob = dctx + b * L * H + h * 64;
   T* dbase = dqkv + b * L * ld + h * 64;
-  const uint32_t thresh = drop_p > 0.f ? (uint32_t)(drop_p * 4294967296.0) : 0u;
-  const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  const AttnDrop dr_(drop_p);
+  const uint32_t thresh = dr_.thresh;
+  const float keep_scale = dr_.keep_scale;
 
   for (int idx = tid; idx < KT * 32 * G::CPR; idx += nthr) {
     const int row = idx / G::CPR, c = idx % G::CPR;
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
         float dpp = dp[t][r];
         if (thresh) {
           const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          dpp = dropout_keep(seed, attn_drop_idx(b, h, heads, L, blk0 + l31, key), thresh) ? dpp * keep_scale : 0.f;
+          dpp = attn_drop_keep1(seed, b, h, heads, L, blk0 + l31, key, thresh) ? dpp * keep_scale : 0.f;
         }
         s[t][r] = p; dp[t][r] = dpp;
         delta += p * dpp;
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
             p = G::exp_(lg - m4[e]) * i4[e];
             pd = p; dpp = dpb[4 * g + e];
             if (thresh) {
-              const bool keep = dropout_keep(seed, attn_drop_idx(b, h, heads, L, q, blk0 + l31), thresh);
+              const bool keep = attn_drop_keep1(seed, b, h, heads, L, q, blk0 + l31, thresh);
               pd = keep ? p * keep_scale : 0.f;
               dpp = keep ? dpp * keep_scale : 0.f;
             }
@@ -741,6 +742,8 @@ int omk_attention_bwd_bias(int dtype, const void* qkv, const void* dctx, void* d
                            int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
                            const float* pos_bias, float* drel, hipStream_t s) {
   if (B <= 0) return 0;
+  if (!pos_bias && omk_attention_bwd16_ok(dtype, L, H, heads))
+    return omk_attention_bwd16(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s);
   if (L < 1 || L > 256) OM_FAIL("training supports sequence lengths up to 256");
   // the three transposed [64][L + 4] images of the backward kernel must fit the 160 KiB of LDS: 256 keys in 16 bits, 192 in f32
   if (dtype != OM_BF16 && L > 192) OM_FAIL("float32 training supports sequence lengths up to 192 (bfloat16: 256)");

@@ -691,6 +691,52 @@ def test_tied_training_forward_in_one_pass_equals_two_calls(golden):
     assert ((h1 - h2).norm() / h2.norm()).item() < 1e-4
 
 
+@pytest.mark.parametrize("L,p_drop", [(128, 0.0), (128, 0.1), (80, 0.1), (40, 0.1), (20, 0.0)])
+def test_bf16_attention_backward_kernels_agree(L, p_drop):
+    """The bf16 training backward has two attention kernels: the transposing-read one (attention_bwd16.hip, L <= 128) and
+    the generic one (train_kernels.hip; OM_OPT_ATTENTION_FAST = 0 selects it).  Same model, batch and dropout seed ->
+    the same masks (both regenerate them from the seed) and the same gradients up to bf16 rounding of intermediates,
+    for full and partially filled 32-token tiles and ragged attention masks."""
+    from transformers import BertConfig, BertModel
+    from openmatch.modeling import DRModel
+    from openmatch_amd import native as N_
+    cfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=600,
+                     max_position_embeddings=128, hidden_dropout_prob=p_drop, attention_probs_dropout_prob=p_drop)
+    torch.manual_seed(21)
+    lm = BertModel(cfg)
+    rng = np.random.default_rng(L)
+    p_ids, p_mask = synth_tokens(rng, 12, L, vocab=600, lo_len=max(3, L // 3), lo_id=300)
+    q_ids, q_mask = synth_tokens(rng, 3, L, vocab=600, lo_len=3, lo_id=300)
+    tens = lambda a: torch.from_numpy(a).to(DEV)
+    grads = []
+    for fast in (1, 0):
+        model = DRModel(lm_q=lm, lm_p=lm, pooling="mean", model_args=NS(encoder_only=False, dtype="bfloat16"),
+                        data_args=NS(train_n_passages=4),
+                        train_args=NS(negatives_x_device=False, per_device_train_batch_size=3)).to(DEV).train()
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(77)                                # the dropout seed of the step is drawn from torch's generator
+        N_.check(N_.lib().om_debug_option(2, fast))
+        try:
+            out = model(query={"input_ids": tens(q_ids), "attention_mask": tens(q_mask)},
+                        passage={"input_ids": tens(p_ids), "attention_mask": tens(p_mask)})
+            out.loss.backward()
+        finally:
+            N_.check(N_.lib().om_debug_option(2, 1))
+        grads.append((out.loss.item(), {n: t.grad.detach().float().cpu().clone() for n, t in lm.named_parameters() if t.grad is not None}))
+    (l1, g1), (l2, g2) = grads
+    assert abs(l1 - l2) < 1e-3 * max(1.0, abs(l2))           # (without dropout the switch also changes the forward attention kernel)
+    worst = ("", 1.0)
+    for n in g2:
+        a, b_ = g1[n].flatten().double(), g2[n].flatten().double()
+        if b_.norm() < 1e-9 or n.endswith("attention.self.key.bias"):
+            continue      # (d loss / d key bias is identically zero -- softmax ignores a per-query shift of the scores: noise only)
+        cos = (torch.dot(a, b_) / (a.norm() * b_.norm())).item()
+        rel = ((a - b_).norm() / b_.norm()).item()
+        worst = min(worst, (n, cos), key=lambda t: t[1])
+        assert cos > 0.999 and rel < 3e-2, (L, p_drop, n, cos, rel)
+    print(f"\n[attention backward, L={L}, p={p_drop}] least aligned gradient tensor: {worst}")
+
+
 def test_float32_training_rejects_more_than_192_tokens():
     """The float32 backward attention kernel holds three [64][L + 4] f32 images in LDS: 192 keys is what 160 KiB takes.
     Longer float32 batches must fail with a message, not a HIP error (and leave no sticky error behind)."""
