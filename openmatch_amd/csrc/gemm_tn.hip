@@ -18,7 +18,7 @@
 // under the MFMAs, in the waves that own k columns 0..WT-1 of k tile 0.
 #include <atomic>
 
-#include "gemm_core.h"
+#include "gemm_core7.h"
 #include "kernels.h"
 
 namespace {
@@ -171,17 +171,128 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(
     }
   }
 }
+
+// ---- the same contraction with the tiles brought in by LDS-DMA --------------------------------------------------------
+// The register-staged kernel above is bound by its own LDS writes: 8 ds_write_b128 per wave and step at ~13 LDS cycles
+// each (MI355X_MICROARCH.md: 79 B/clk/CU) is 830 cycles per two resident workgroups against 512 cycles of MFMA.
+// global_load_lds writes LDS without passing through registers.  Its destination is lane-linear (64 x 16 bytes
+// contiguous), so the image is made of 1 KiB REGIONS, one per (32-column fragment f, 16-token k step ks), laid out as
+// the transposing reads want them:  [read 0 | read 1][16-lane group g = (token half, column block)][4 tokens][16 columns]
+//     DMA lane l = r*32 + g*8 + tl*2 + h  ->  token ks*16 + (g>>1)*8 + r*4 + tl,  columns f*32 + (g&1)*16 + h*8 .. + 7
+//     read  r of lane l : region + r*512 + l*8   (each half-wave reads 256 contiguous bytes: no bank conflicts)
+// Two stages of 32 KiB (A + B), two workgroups per CU; whole 64-token steps only (the launcher gives a ragged tail to
+// the register-staged kernel, which can zero-fill).  vmcnt is counted by hand: the DMA is inline assembly.
+constexpr int TD_STAGE = 32768;
+__global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_dma_kernel(
+    const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, float* __restrict__ C,
+    int64_t ldc, float* __restrict__ bias, int N, int K, int steps_per_slice, int total_steps, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  int lane = tid & 63;
+  asm volatile("" : "+v"(lane));
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int ntk = K / 128;
+  const int n0 = (blockIdx.x / ntk) * 128, k0 = (blockIdx.x % ntk) * 128;
+  const int s_begin = blockIdx.y * steps_per_slice;
+  int nsteps = total_steps - s_begin < steps_per_slice ? total_steps - s_begin : steps_per_slice;
+  if (nsteps <= 0) return;
+  if (dbg & 4) nsteps = 1;
+  const bool do_bias = bias != nullptr && k0 == 0 && wk == 0;
+
+  // DMA: instruction i of this wave fills region (f = i, ks = wave) of each operand
+  const int dr = lane >> 5, dg = (lane >> 3) & 3, dtl = (lane >> 1) & 3, dh = lane & 1;
+  const int drow = wave * 16 + (dg >> 1) * 8 + dr * 4 + dtl;
+  const uint32_t a_off = (uint32_t)((drow * lda + (dg & 1) * 16 + dh * 8) * 2);
+  const uint32_t b_off = (uint32_t)((drow * ldb + (dg & 1) * 16 + dh * 8) * 2);
+  const char* a_at = (const char*)(A + (int64_t)s_begin * TN_BM * lda + n0);       // wave-uniform, advanced per step issued
+  const char* b_at = (const char*)(B + (int64_t)s_begin * TN_BM * ldb + k0);
+  const size_t a_step = (size_t)TN_BM * lda * 2, b_step = (size_t)TN_BM * ldb * 2;
+  const uint32_t lds0 = g7_lds_addr(smem);
+#define TD_ISSUE(STAGE)                                                                               \
+  do {                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+      g7_dma(a_at + i * 64, a_off, lds0 + (STAGE) * TD_STAGE + (i * 4 + wave) * 1024);                \
+      g7_dma(b_at + i * 64, b_off, lds0 + (STAGE) * TD_STAGE + 16384 + (i * 4 + wave) * 1024);        \
+    }                                                                                                 \
+    a_at += a_step; b_at += b_step;                                                                   \
+  } while (0)
+
+  f32x16_t acc[2][2];
+  float bsum[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; }
+
+#define TD_READ(KS, SET)                                                                               \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+    const char* pa_ = st + ((wn * 2 + i) * 4 + (KS)) * 1024 + lane * 8;                                \
+    const char* pb_ = st + 16384 + ((wk * 2 + i) * 4 + (KS)) * 1024 + lane * 8;                        \
+    fa[SET][i] = frag2(tn_read(pa_), tn_read(pa_ + 512));                                              \
+    fb[SET][i] = frag2(tn_read(pb_), tn_read(pb_ + 512));                                              \
+  }
+  auto frag2 = [](v4s a, v4s b) { return (bf16x8_t){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; };
+
+  TD_ISSUE(0);
+  if (nsteps > 1) TD_ISSUE(1);
+  for (int t = 0; t < nsteps; ++t) {
+    if (t + 1 < nsteps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // step t has landed; step t + 1 may be in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const char* st = smem + (t & 1) * TD_STAGE;
+    bf16x8_t fa[2][2], fb[2][2];
+    TD_READ(0, 0)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 1 < 4) { TD_READ(ks + 1, (ks + 1) & 1) }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) MmaOps<bf16_t>::mma(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+        if (do_bias) {
+          const uint4 w = __builtin_bit_cast(uint4, fa[ks & 1][i]);
+          bsum[i] += (__uint_as_float(w.x << 16) + __uint_as_float(w.x & 0xffff0000u)) + (__uint_as_float(w.y << 16) + __uint_as_float(w.y & 0xffff0000u)) +
+                     (__uint_as_float(w.z << 16) + __uint_as_float(w.z & 0xffff0000u)) + (__uint_as_float(w.w << 16) + __uint_as_float(w.w & 0xffff0000u));
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < nsteps) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __syncthreads();                        // every wave has read stage t & 1
+      TD_ISSUE(t & 1);
+    }
+  }
+#undef TD_READ
+#undef TD_ISSUE
+
+  const int kcol = k0 + wk * 64 + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int nbase = n0 + wn * 64 + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = nbase + 8 * (r >> 2) + (r & 3);
+      float* crow = C + (int64_t)n * ldc + kcol;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { if (dbg & 2) crow[j * 32] = acc[i][j][r]; else atomicAdd(crow + j * 32, acc[i][j][r]); }
+    }
+    if (do_bias) {
+      const float t = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+      if (lane < 32) atomicAdd(bias + n0 + wn * 64 + i * 32 + lane, t);
+    }
+  }
+}
 }  // namespace
 
 bool omk_gemm_tn_ok(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {
   return dtype == OM_BF16 && M > 0 && N % 128 == 0 && K % 128 == 0 && lda % 8 == 0 && ldb % 8 == 0 && N <= (1 << 20) && K <= (1 << 20);
 }
 
-int omk_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* bias,
-                int64_t M, int64_t N, int64_t K, hipStream_t s) {
-  if (!omk_gemm_tn_ok(dtype, M, N, K, lda, ldb)) OM_FAIL("gemm_tn: bf16 operands with N and K multiples of 128 only");
-  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) OM_FAIL("gemm_tn: operands must be 16-byte aligned");
-  const int dbg = om_option(OM_OPT_WGRAD_DEBUG);
+static int launch_tn_regs(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* bias, int64_t M,
+                          int64_t N, int64_t K, int dbg, hipStream_t s) {
   const int64_t tiles = (N / 128) * (K / 128);
   const int64_t steps = (M + TN_BM - 1) / TN_BM;
   const int64_t want = (dbg >> 4) ? (dbg >> 4) * 64 : 320;             // workgroups: one round of two per CU, and no more --
@@ -194,12 +305,41 @@ int omk_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, int64_t ld
     OM_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS));
     attr = true;
   }
-  const bool timing = om_timing_on();
-  if (timing) om_timing_begin(OM_TIMING_GEMM_BF16, s);
   hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)tiles, (unsigned)slices), dim3(TN_THREADS), TN_LDS, s, (const bf16_t*)A, lda,
                      (const bf16_t*)B, ldb, C, ldc, bias, M, (int)N, (int)K, (int)(per * TN_BM), dbg);
-  if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, 2.0 * (double)M * (double)N * (double)K);
   OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int omk_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* bias,
+                int64_t M, int64_t N, int64_t K, hipStream_t s) {
+  if (!omk_gemm_tn_ok(dtype, M, N, K, lda, ldb)) OM_FAIL("gemm_tn: bf16 operands with N and K multiples of 128 only");
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) OM_FAIL("gemm_tn: operands must be 16-byte aligned");
+  const int dbg = om_option(OM_OPT_WGRAD_DEBUG);
+  const bool timing = om_timing_on();
+  if (timing) om_timing_begin(OM_TIMING_GEMM_BF16, s);
+  const int64_t whole = (dbg & 8) ? 0 : M / TN_BM;             // (dbg 8: the register-staged kernel for everything)
+  if (whole >= 8 && 64 * lda * 2 < (1ll << 31) && 64 * ldb * 2 < (1ll << 31)) {
+    const int64_t tiles = (N / 128) * (K / 128);
+    const int64_t want = (dbg >> 4) ? (dbg >> 4) * 64 : 320;
+    int64_t slices = (want + tiles - 1) / tiles;
+    if (slices > whole / 4) slices = whole / 4 > 0 ? whole / 4 : 1;
+    const int64_t per = (whole + slices - 1) / slices;
+    slices = (whole + per - 1) / per;
+    static std::atomic<bool> attr{false};
+    if (!attr) {
+      OM_HIP(hipFuncSetAttribute((const void*)gemm_tn_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TD_STAGE));
+      attr = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_dma_kernel, dim3((unsigned)tiles, (unsigned)slices), dim3(TN_THREADS), 2 * TD_STAGE, s, (const bf16_t*)A, lda,
+                       (const bf16_t*)B, ldb, C, ldc, bias, (int)N, (int)K, (int)per, (int)whole, dbg);
+    OM_LAUNCH_CHECK();
+    const int64_t done = whole * TN_BM;
+    if (M > done && launch_tn_regs((const bf16_t*)A + done * lda, lda, (const bf16_t*)B + done * ldb, ldb, C, ldc, bias, M - done, N, K, dbg, s)) return 1;
+  } else if (launch_tn_regs(A, lda, B, ldb, C, ldc, bias, M, N, K, dbg, s)) {
+    return 1;
+  }
+  if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, 2.0 * (double)M * (double)N * (double)K);
   return 0;
 }
 

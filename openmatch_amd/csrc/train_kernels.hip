@@ -174,14 +174,14 @@ template <> __device__ __forceinline__ void store4<float>(float* p, const float 
 // 9216 x 768, profiles/r02_train_kernel_stats_v3.csv) -- the block count, not the bytes, set the time.
 // (Four waves for hidden sizes above 1024: the wider per-lane state needs the 256-register budget.)
 template <typename T, int NV, int MODE>
-__global__ __launch_bounds__(NV == 8 ? 256 : 512) void ln_bwd_kernel(
+__global__ __launch_bounds__((NV == 8 || MODE == 1) ? 256 : 512) void ln_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ g,
     T* __restrict__ dx, float* __restrict__ dg, float* __restrict__ db, int64_t M, int H, float eps,
     const int64_t* __restrict__ ids, const int64_t* __restrict__ type_ids,
     const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
     float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype_, int L, int vocab,
     int type_vocab, int rms, const T* __restrict__ add, T* __restrict__ dx_drop, float drop_p, uint64_t drop_seed) {
-  constexpr int LNB_WAVES = NV == 8 ? 4 : 8;
+  constexpr int LNB_WAVES = (NV == 8 || MODE == 1) ? 4 : 8;
   // dx_drop != NULL: also writes dropout(dx) with the forward's mask (seed, element index) -- the gradient entering the
   // dense layer in front of the residual add -- so that no separate dropout pass re-reads dx.
   // rms != 0: T5LayerNorm (no mean, no bias): xhat = x * rstd, rstd = rsqrt(mean(x^2) + eps).
@@ -194,6 +194,10 @@ __global__ __launch_bounds__(NV == 8 ? 256 : 512) void ln_bwd_kernel(
   // address if done per token (528 us per call at 8448 tokens).  Types 0 and 1 are summed in registers
   // and flushed once per block; other type ids keep the per-token atomic.
   float tacc[MODE == 1 ? 2 : 1][NV][4];
+  // MODE 1, position table: a block takes ONE position t (all sequences, or a share of them), sums d x over its rows in
+  // registers and adds the total once -- instead of one atomic per token and element into 128 x H addresses
+  // (7 M contended atomics, 283 us per call at 72 x 128 tokens: profiles/r02_train_kernel_stats_v4.csv).
+  float pacc[MODE == 1 ? NV : 1][4];
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int c = (lane + 64 * j) * 4;
@@ -201,10 +205,21 @@ __global__ __launch_bounds__(NV == 8 ? 256 : 512) void ln_bwd_kernel(
     for (int e = 0; e < 4; ++e) {
       gacc[j][e] = 0.f; bacc[j][e] = 0.f; gv[j][e] = (c + e < H) ? g[c + e] : 0.f;
       tacc[0][j][e] = 0.f;
-      if (MODE == 1) tacc[MODE == 1 ? 1 : 0][j][e] = 0.f;
+      if (MODE == 1) { tacc[MODE == 1 ? 1 : 0][j][e] = 0.f; pacc[MODE == 1 ? j : 0][e] = 0.f; }
     }
   }
-  for (int64_t row = (int64_t)blockIdx.x * LNB_WAVES + w; row < M; row += (int64_t)gridDim.x * LNB_WAVES) {
+  // rows of this wave: MODE 0 grid-stride over all rows; MODE 1 rows b * L + t of the block's position t
+  int64_t row_first = (int64_t)blockIdx.x * LNB_WAVES + w, row_step = (int64_t)gridDim.x * LNB_WAVES, row_end = M;
+  int my_t = 0;
+  if (MODE == 1) {
+    const int parts = (int)gridDim.x / L > 0 ? (int)gridDim.x / L : 1;        // blocks per position (grid >= L is the launcher's job)
+    my_t = blockIdx.x % L;
+    const int part = blockIdx.x / L;
+    row_first = ((int64_t)part * LNB_WAVES + w) * L + my_t;
+    row_step = (int64_t)parts * LNB_WAVES * L;
+    if (part >= parts) row_end = 0;
+  }
+  for (int64_t row = row_first; row < row_end; row += row_step) {
     float xv[NV][4], dv[NV][4];
     int64_t id = 0, tt = 0;
     int t = 0;
@@ -290,7 +305,7 @@ __global__ __launch_bounds__(NV == 8 ? 256 : 512) void ln_bwd_kernel(
             if (tt == 0) tacc[0][j][e] += v;
             else if (tt == 1) tacc[MODE == 1 ? 1 : 0][j][e] += v;
             else atomicAdd(dtype_ + tt * H + c + e, v);
-            atomicAdd(dpos + (int64_t)t * H + c + e, v);
+            pacc[MODE == 1 ? j : 0][e] += v;
           }
         }
       }
@@ -331,6 +346,22 @@ __global__ __launch_bounds__(NV == 8 ? 256 : 512) void ln_bwd_kernel(
       atomicAdd(dtype_ + c, s0);
       if (type_vocab > 1) atomicAdd(dtype_ + H + c, s1);
     }
+    __syncthreads();                   // the block's position row
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (lane + 64 * j) * 4;
+      if (c < H) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[w * H + c + e] = pacc[MODE == 1 ? j : 0][e];
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 64 * LNB_WAVES) {
+      float s0 = 0.f;
+#pragma unroll
+      for (int k = 0; k < LNB_WAVES; ++k) s0 += red[k * H + c];
+      atomicAdd(dpos + (int64_t)my_t * H + c, s0);
+    }
   }
 }
 
@@ -340,9 +371,14 @@ static int launch_ln_bwd(const void* dy, const void* x, const float* g, void* dx
                          const float* word, const float* pos, const float* type, float* dword,
                          float* dpos, float* dtype_, int L, int vocab, int type_vocab, hipStream_t s,
                          int rms = 0, const void* add = nullptr, void* dx_drop = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0) {
-  const int waves = H <= 1024 ? 8 : 4;
+  const int waves = (H <= 1024 && MODE == 0) ? 8 : 4;
   const int64_t want = (M + waves - 1) / waves;
-  const unsigned grid = (unsigned)(want > 256 ? 256 : want);
+  unsigned grid = (unsigned)(want > 256 ? 256 : want);
+  if (MODE == 1) {                     // one position per block, 256 / L blocks per position (kernel comment)
+    if (L < 1 || M % L) OM_FAIL("embedding backward: M must be B * L");
+    const int parts = 256 / L > 0 ? 256 / L : 1;
+    grid = (unsigned)(L * parts);
+  }
   const size_t lds = (size_t)2 * waves * H * sizeof(float);       // <= 64 KiB for both shapes
 #define LNB(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, MODE>), dim3(grid), dim3(64 * waves), lds, s, (const T*)dy, (const T*)x, g, (T*)dx, dg, db, M, H, eps, ids, tt, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, rms, (const T*)add, (T*)dx_drop, drop_p, drop_seed)
   if (H <= 1024) LNB(4); else LNB(8);
@@ -388,29 +424,47 @@ int omk_embed_bwd(int dtype, const void* dy, const int64_t* ids, const int64_t* 
 
 // ---------------------------------------------------------------------------------------
 // pooling backward: d_hidden[b,t,:] from d_pooled[b,:]
+// grid (B, parts): block (b, part) writes rows part, part + parts, .. of sequence b, four elements per thread and access
+// (one block per sequence took 97 us for 72 x 128 x 768 outputs; H % 4 == 0 is checked by the callers of the encoder)
 template <typename T>
-__global__ void pool_bwd_kernel(const float* __restrict__ dp, const int64_t* __restrict__ mask,
-                                T* __restrict__ dh, int L, int H, int mode) {
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dp, const int64_t* __restrict__ mask,
+                                                       T* __restrict__ dh, int L, int H, int mode) {
   const int64_t b = blockIdx.x;
-  float cnt = 0.f;
+  __shared__ float cnt_s;
   if (mode == OM_POOL_MEAN) {
-    for (int t = 0; t < L; ++t) cnt += (float)mask[b * L + t];
-    cnt = fmaxf(cnt, 1e-9f);
+    if (threadIdx.x < 64) {
+      float c = 0.f;
+      for (int t = threadIdx.x; t < L; t += 64) c += (float)mask[b * L + t];
+      c = wave_sum(c);
+      if (threadIdx.x == 0) cnt_s = fmaxf(c, 1e-9f);
+    }
+    __syncthreads();
   }
-  for (int64_t i = threadIdx.x; i < (int64_t)L * H; i += blockDim.x) {
-    const int t = (int)(i / H), c = (int)(i % H);
-    float v;
-    if (mode == OM_POOL_FIRST) v = t == 0 ? dp[b * H + c] : 0.f;
-    else v = dp[b * H + c] * (float)mask[b * L + t] / cnt;
-    ElemOps<T>::store(dh + (b * L + t) * H + c, v);
+  const float cnt = mode == OM_POOL_MEAN ? cnt_s : 1.f;
+  const int h4 = H >> 2;
+  for (int t = blockIdx.y; t < L; t += gridDim.y) {
+    const float wgt = mode == OM_POOL_FIRST ? (t == 0 ? 1.f : 0.f) : (float)mask[b * L + t] / cnt;
+    for (int c4 = threadIdx.x; c4 < h4; c4 += 256) {
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (wgt != 0.f) {
+        const float4 d = *(const float4*)(dp + b * H + c4 * 4);
+        if (mode == OM_POOL_FIRST) { v[0] = d.x; v[1] = d.y; v[2] = d.z; v[3] = d.w; }
+        else { v[0] = d.x * (float)mask[b * L + t] / cnt; v[1] = d.y * (float)mask[b * L + t] / cnt; v[2] = d.z * (float)mask[b * L + t] / cnt; v[3] = d.w * (float)mask[b * L + t] / cnt; }
+      }
+      store4<T>(dh + (b * L + t) * H + c4 * 4, v);
+    }
   }
 }
 
 int omk_pool_bwd(int dtype, const float* dp, const int64_t* mask, void* dh, int64_t B, int L, int H,
                  int mode, hipStream_t s) {
   if (B <= 0) return 0;
-  if (dtype == OM_BF16) hipLaunchKernelGGL((pool_bwd_kernel<bf16_t>), dim3((unsigned)B), dim3(256), 0, s, dp, mask, (bf16_t*)dh, L, H, mode);
-  else hipLaunchKernelGGL((pool_bwd_kernel<float>), dim3((unsigned)B), dim3(256), 0, s, dp, mask, (float*)dh, L, H, mode);
+  if (H % 4) OM_FAIL("hidden size must be a multiple of 4");
+  int parts = (int)(2048 / B);
+  parts = parts < 1 ? 1 : (parts > L ? L : parts);
+  const dim3 grid((unsigned)B, (unsigned)parts);
+  if (dtype == OM_BF16) hipLaunchKernelGGL((pool_bwd_kernel<bf16_t>), grid, dim3(256), 0, s, dp, mask, (bf16_t*)dh, L, H, mode);
+  else hipLaunchKernelGGL((pool_bwd_kernel<float>), grid, dim3(256), 0, s, dp, mask, (float*)dh, L, H, mode);
   OM_LAUNCH_CHECK();
   return 0;
 }

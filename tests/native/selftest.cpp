@@ -434,7 +434,7 @@ int main(int argc, char** argv) {
       bf16* dA = upload(to_bf16(randn((size_t)M * N, 1.f)));
       bf16* dB = upload(to_bf16(randn((size_t)M * K, 1.f)));
       float* dC = dalloc<float>((size_t)N * K); float* db = dalloc<float>(N);
-      std::vector<int> variants = {0, 4 << 4, 8 << 4, 2, 4};
+      std::vector<int> variants = {0, 8, 2, 4};      // DMA-fed (default), register-staged, plain stores, one step
       if (argc > 3) { variants.clear(); for (int a = 3; a < argc; ++a) variants.push_back(atoi(argv[a])); }
       for (int variant : variants) {
         om_debug_option(OM_OPT_WGRAD_DEBUG, variant);
