@@ -273,6 +273,113 @@ __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7(
   G7_WAIT_VM(0);
 }
 
+// Small query batches (<= 32 queries): the scan is a pass over the whole f16 index (13.6 GB at 8.8 M x 768) that has to
+// run at HBM speed.  The generic 128-query tile spends 1.7 PFLOP of matrix-core time on padding at Q = 1 (3.99 ms per
+// search in round 1, profiles/r01_search_shapes.jsonl) -- this kernel keeps ONE 32-query column block, resident in LDS for
+// the whole kernel ([K step][32 queries][128 B], 48 KiB at d = 768), and streams 256-row x 128-byte units of the index
+// through a three-slot LDS-DMA ring (the generation-7 unit layout and swizzle): 8 MFMAs per wave and unit against
+// 32 KiB of HBM traffic, two units (64 KiB per CU) in flight, one barrier per unit.  Persistent: one workgroup per CU
+// walks row tiles blockIdx, blockIdx + grid, ...  Whole 256-row tiles only (the host gives the tail to the generic kernel).
+#define SS_RING 3
+#define SS_QOFF (SS_RING * G7_UNIT_BYTES)
+template <typename T>
+__global__ __launch_bounds__(G6_THREADS) void sim_stream_kernel(
+    const T* __restrict__ rows, int64_t nrows, uint32_t row_base, const T* __restrict__ queries, int64_t nq, int64_t d,
+    const float* __restrict__ thr, u64* __restrict__ keys, unsigned* __restrict__ cnt) {
+  typedef typename MmaOps<T>::frag_t frag_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int lane = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nk = (int)((d * 2) / G7_ROW_BYTES);
+  const int64_t ntiles = nrows / 256;
+  const int my_tiles = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+  if (my_tiles <= 0) return;
+  const int units = my_tiles * nk;
+  const uint32_t lds0 = g7_lds_addr(smem);
+
+  // DMA offsets of a 256-row unit: instruction i of this wave moves rows (i*4 + wave)*8 .. +7, lane -> row (lane >> 3),
+  // physical chunk (lane & 7) <- source chunk (lane & 7) ^ ((row >> 1) & 7)
+  uint32_t off[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = (i * 4 + wave) * 8 + (lane >> 3);
+    off[i] = (uint32_t)(r * d * 2) + ((((lane & 7) ^ ((r >> 1) & 7))) << 4);
+  }
+  // the queries: K step ks, rows (queries) 8 j .. 8 j + 7 per instruction; wave w takes K steps w, w + 4, ...
+  {
+    uint32_t qoff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = j * 8 + (lane >> 3);
+      const int rr = r < nq ? r : (int)nq - 1;                // padding rows repeat the last query (their threshold is +inf)
+      qoff[j] = (uint32_t)(rr * d * 2) + ((((lane & 7) ^ ((r >> 1) & 7))) << 4);
+    }
+    for (int ks = wave; ks < nk; ks += 4)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g7_dma((const char*)queries + ks * G7_ROW_BYTES, qoff[j], lds0 + SS_QOFF + ks * 4096 + j * 1024);
+  }
+  const float th = thr[lane & 31];
+  auto issue = [&](int u) {
+    const int64_t tile = blockIdx.x + (int64_t)(u / nk) * gridDim.x;
+    const char* base = (const char*)(rows + tile * 256 * d) + (u % nk) * G7_ROW_BYTES;
+    const uint32_t dst = lds0 + (u % SS_RING) * G7_UNIT_BYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g7_dma(base, off[i], dst + i * 4096);
+  };
+  issue(0);
+  if (units > 1) issue(1);
+
+  const int half = lane >> 5, l31 = lane & 31, key = (l31 >> 1) & 7;
+  const int arow = (wave * 64 + l31) * G7_ROW_BYTES;          // + rt * 32 rows
+  const int brow = l31 * G7_ROW_BYTES;
+  f32x16_t acc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+  int ks = 0;
+  int64_t tile = blockIdx.x;
+  for (int u = 0; u < units; ++u) {
+    if (u + 1 < units) G7_WAIT_VM(8); else G7_WAIT_VM(0);      // unit u (and the queries) landed; unit u + 1 may be in flight
+    __builtin_amdgcn_s_barrier();                              // ... for every wave; and unit u - 1 has been read by all
+    if (u + 2 < units) issue(u + 2);
+    const char* ua = smem + (u % SS_RING) * G7_UNIT_BYTES + arow;
+    const char* ub = smem + SS_QOFF + ks * 4096 + brow;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int slot = (((kk << 1) | half) ^ key) << 4;
+      const frag_t b = *(const frag_t*)(ub + slot);
+      const frag_t a0 = *(const frag_t*)(ua + slot);
+      const frag_t a1 = *(const frag_t*)(ua + 32 * G7_ROW_BYTES + slot);
+      MmaOps<T>::mma(a0, b, acc[0]);            // acc[rt][r]: row 8(r>>2) + 4 half + (r&3) of the 32-row block, query l31
+      MmaOps<T>::mma(a1, b, acc[1]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (++ks == nk) {
+      ks = 0;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const f32x16_t a = acc[rt];
+        float mx = fmaxf(fmaxf(a[0], a[1]), a[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, a[r]), a[r + 1]);
+        mx = fmaxf(mx, a[15]);
+        if (mx >= th) {                                          // rare by construction of the thresholds
+          const uint32_t id0 = row_base + (uint32_t)(tile * 256) + wave * 64 + rt * 32 + 4 * half;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (a[r] >= th) {
+              const unsigned pos = atomicAdd(cnt + l31, 1u);
+              if (pos < SORT_CAP) keys[(int64_t)l31 * SORT_CAP + pos] = pack_key(a[r], id0 + (r & 3) + 8 * (r >> 2));
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+      }
+      tile += gridDim.x;
+    }
+  }
+}
+
 // append a dense score block S[q, 0:n] (rows row_base..) to every list
 __global__ void append_dense_kernel(const float* __restrict__ S, int64_t ldS, int n,
                                     uint32_t row_base, u64* __restrict__ keys,
@@ -632,7 +739,7 @@ struct Scan {
     return 0;
   }
   // dense-score rows [r0, r0+n) and merge them into the lists (always exact, HBM heavy)
-  int dense_step(int64_t r0, int n, bool bf16) {
+  int dense_gemm_append(int64_t r0, int n, bool bf16) {
     if (bf16) {
       if (om_gemm_nt(OM_F16, ws.qb, d, idx16 + r0 * d, d, OM_F32, ws.dense, DENSE_CHUNK, nq, n, d,
                      nullptr, nullptr, 0, OM_ACT_NONE, s)) return 1;
@@ -643,6 +750,10 @@ struct Scan {
     hipLaunchKernelGGL(append_dense_kernel, dim3((unsigned)nq), dim3(256), 0, s, ws.dense,
                        (int64_t)DENSE_CHUNK, n, (uint32_t)r0, ws.keys, ws.cnt);
     OM_LAUNCH_CHECK();
+    return 0;
+  }
+  int dense_step(int64_t r0, int n, bool bf16) {
+    if (dense_gemm_append(r0, n, bf16)) return 1;
     return select(bf16);
   }
   int filter_step(int64_t r0, int64_t n, bool bf16) {
@@ -670,7 +781,19 @@ struct Scan {
           hipLaunchKernelGGL((sim_filter_kernel6<f16_t>), dim3((unsigned)ntn), dim3(G6_THREADS), G6_LDS_BYTES, s, idx16 + (r0 + whole) * d,
                              n - whole, (uint32_t)(r0 + whole), ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8);
       } else if (wide) SCAN(sim_filter_kernel6, G6_THREADS, G6_LDS_BYTES, f16_t, idx16, ws.qb);
-      else SCAN(sim_filter_kernel, G2_THREADS, G2_LDS_BYTES, f16_t, idx16, ws.qb);
+      else if (nq <= 32 && (d * 2) / G7_ROW_BYTES <= 12 && om_option(OM_OPT_SCAN_GEN7)) {
+        // the HBM-speed pass for small batches over the whole tiles; the generic kernel takes the ragged tail
+        const int64_t whole = n & ~(int64_t)255;
+        if (whole) {
+          int ncu = g7_num_cus();
+          if (whole / 256 < ncu) ncu = (int)(whole / 256);
+          hipLaunchKernelGGL((sim_stream_kernel<f16_t>), dim3((unsigned)ncu), dim3(G6_THREADS), SS_QOFF + 12 * 4096, s, idx16 + r0 * d, whole,
+                             (uint32_t)r0, ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt);
+        }
+        if (n > whole)
+          hipLaunchKernelGGL((sim_filter_kernel<f16_t>), dim3(1), dim3(G2_THREADS), G2_LDS_BYTES, s, idx16 + (r0 + whole) * d, n - whole,
+                             (uint32_t)(r0 + whole), ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8);
+      } else SCAN(sim_filter_kernel, G2_THREADS, G2_LDS_BYTES, f16_t, idx16, ws.qb);
     } else {
       if (wide) SCAN(sim_filter_kernel6, G6_THREADS, G6_LDS_BYTES, float, idx32, q32);
       else SCAN(sim_filter_kernel, G2_THREADS, G2_LDS_BYTES, float, idx32, q32);
@@ -704,33 +827,27 @@ struct Scan {
       OM_LAUNCH_CHECK();
     }
     int64_t done = 0;
-    unsigned f[4];
+    unsigned f[4] = {0, 0, 0, 0};
     bool unsorted = false;
-    // bootstrap
-    {
-      const int n = (int)std::min<int64_t>(N, DENSE_CHUNK);
-      if (dense_step(0, n, bf16)) return 1;
-      done = n;
-      if (read_flags(f)) return 1;
-      trace("boot", 0, n, f);
-      if (f[2]) return 2;
-    }
-    // Fast schedule (default): the list length after a selection hardly moves (k plus ties / the certified margin),
-    // so the chunk sizes are fixed on the host from the bootstrap's list length and the rounds run back to back with
-    // NO host synchronisation: filtered scan -> overflow check (sticky flag) -> radix selection.  One read of the flags at
-    // the end; an overflow or a too-wide margin anywhere (adversarial row order) falls back to the step-by-step loop
-    // below from scratch, which is always exact.
-    if (om_option(OM_OPT_SCAN_GEN7) && N > done) {
-      const int64_t list = std::max<unsigned>(f[1], 1u);
-      const double growth = (double)std::max(5, om_option(OM_OPT_SCAN_GROWTH));
-      OM_HIP(hipMemsetAsync(ws.flag, 0, 64, s));
-      int64_t at = done;
+    // Fast schedule (default): bootstrap on a dense-scored chunk, then filtered scan -> overflow check (sticky flag) ->
+    // radix selection per round, back to back with NO host synchronisation at all -- the list length after a selection
+    // hardly moves (k plus ties / the certified margin), so the chunk sizes are fixed on the host from an ESTIMATE of
+    // it.  One read of the flags at the very end; an overflow or a too-wide margin anywhere (adversarial row order,
+    // heavily duplicated rows) falls back to the step-by-step loop below from scratch, which is always exact.
+    bool careful = true;
+    if (om_option(OM_OPT_SCAN_GEN7) && N > DENSE_CHUNK) {
+      if (dense_gemm_append(0, DENSE_CHUNK, bf16)) return 1;
+      if (select_radix(bf16)) return 1;
+      g_info[1]++;
+      const int64_t list = bf16 ? (int64_t)k * 13 / 10 + 64 : (int64_t)k + 16;       // estimate (certified: + the margin's ties)
+      // few queries: the scan is one HBM pass whatever the thresholds, the per-round launches are what costs -- few, long
+      // rounds; many queries: an append costs the scan a slow path, the selection ~0.3 ms -- many short rounds with
+      // tight thresholds (profiles/r02_scan_trace_*.log).  Expected survivors of a chunk ~ list * chunk / at.
+      const double growth = nq <= 32 ? 400.0 : (double)std::max(5, om_option(OM_OPT_SCAN_GROWTH));
+      const double room = 0.75 * (double)(SORT_CAP - list);
+      const double want = std::min(room, (double)list * growth / 100.0);
+      int64_t at = DENSE_CHUNK;
       while (at < N) {
-        // expected survivors of a chunk ~ list * chunk / at: `growth` percent keeps that many appends per list and round.
-        // The radix selection costs ~0.3 ms, an append costs the scan a serialised slow path, so MANY short rounds with
-        // tight thresholds beat few long ones (profiles/r02_scan_trace_*.log); the room left in the list caps it.
-        const double room = list <= 2048 ? 3800.0 - (double)list : (double)(SORT_CAP - list) / 2.0;
-        const double want = std::min(room, (double)list * growth / 100.0);
         int64_t chunk = (int64_t)((double)at * want / (double)list);
         chunk = std::max<int64_t>(chunk, DENSE_CHUNK) & ~(int64_t)255;      // whole tiles (DENSE_CHUNK is one)
         chunk = std::min<int64_t>(chunk, N - at);
@@ -747,18 +864,22 @@ struct Scan {
         done = N;
         f[1] = g[1];
         unsorted = true;                         // the lists are cut but not ordered: one sort at the very end
+        careful = false;
       } else {                                   // rare: start over on the careful path
         g_info[2]++;
         OM_HIP(hipMemsetAsync(ws.flag, 0, 64, s));
         hipLaunchKernelGGL(init_lists_kernel, dim3((unsigned)((nq + 255) / 256 + 2)), dim3(256), 0, s,
                            ws.cnt, ws.cnt_prev, ws.thr, nq);
         OM_LAUNCH_CHECK();
-        const int n = (int)std::min<int64_t>(N, DENSE_CHUNK);
-        if (dense_step(0, n, bf16)) return 1;
-        done = n;
-        if (read_flags(f)) return 1;
-        if (f[2]) return 2;
       }
+    }
+    if (careful) {                               // bootstrap of the step-by-step loop
+      const int n = (int)std::min<int64_t>(N, DENSE_CHUNK);
+      if (dense_step(0, n, bf16)) return 1;
+      done = n;
+      if (read_flags(f)) return 1;
+      trace("boot", 0, n, f);
+      if (f[2]) return 2;
     }
     while (done < N) {
       const int64_t list = std::max<unsigned>(f[1], 1u);
@@ -841,6 +962,7 @@ extern "C" int om_sim_topk(int mode, const float* queries, int64_t n_queries,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES));
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel6<f16_t>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES));
+    OM_HIP(hipFuncSetAttribute((const void*)sim_stream_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, SS_QOFF + 12 * 4096));
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel7<f16_t>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
     OM_HIP(hipFuncSetAttribute((const void*)select_radix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

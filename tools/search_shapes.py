@@ -11,6 +11,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=8841823)
     ap.add_argument("--topk", type=int, default=1000)
+    ap.add_argument("--queries", type=int, nargs="*", default=[1, 8, 64, 256, 1024, 6980])
     a = ap.parse_args()
     from openmatch_amd.index import FlatIPIndex
     dev = torch.device("cuda:0")
@@ -21,7 +22,7 @@ def main():
     for s in range(0, a.rows, 1 << 20):
         n = min(1 << 20, a.rows - s)
         index.add(torch.randn(n, 768, device=dev, generator=g) * 0.05 + shared * 0.05)
-    for nq in (1, 8, 64, 256, 1024, 6980):
+    for nq in a.queries:
         q = torch.randn(nq, 768, device=dev, generator=g) * 0.05 + shared * 0.05
         index.search_device(q, a.topk)
         torch.cuda.synchronize(); t0 = time.perf_counter()
