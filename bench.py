@@ -396,6 +396,19 @@ def main():
                             "ms_per_search": round(sms.value / reps, 2), "launches_per_search": int(sl.value // reps),
                             "index_stream_GBps_if_read_once": round(scan_bytes / max(sms.value / reps, 1e-9) / 1e6, 1)},
         }
+        if world == 1 and not a.no_extra:
+            # small batches: the scan is one pass over the f16 index -- latency and the implied HBM stream rate
+            small = {}
+            for nq_s in (1, 64):
+                qs = q_local[:nq_s]
+                index.search_device(qs, a.topk)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                for _ in range(3):
+                    index.search_device(qs, a.topk)
+                torch.cuda.synchronize(); dt_s = (time.perf_counter() - t1) / 3
+                small["q%d" % nq_s] = {"ms": round(dt_s * 1e3, 2), "index_stream_TBps": round(scan_bytes / dt_s / 1e12, 2),
+                                       "frac_of_hbm_peak": round(scan_bytes / dt_s / 1e9 / PEAK_HBM_GBS, 3)}
+            search["small_batch_latency"] = small
         if rank == 0 and world == 1 and not a.no_parity and a.precision == "bf16":
             parity = parity_leg(model, lm, batches, device, index, q_local, a.topk)
         del index
