@@ -190,6 +190,40 @@ int om_encoder_forward(const OmEncoderConfig* cfg, const OmEncoderWeights* w,
                        size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * One decoder position of a T5 encoder-decoder over the encoder's output (inference):
+ * what the reference computes for T5 backbones that are not --encoder_only --
+ * DRModel.encode modeling/dense_retrieval_model.py:137-141 (decoder_input_ids = zeros([B,1]),
+ * reps = decoder last_hidden_state[:, 0]) and the monoT5 scores of RRModel.encode
+ * modeling/reranking_model.py:110-114 (two columns of the LM head over that state).
+ * cfg: the ENCODER's config (hidden, heads, ffn, act, ln_eps, dtype); matrices in cfg->dtype,
+ * [out,in] row-major, no biases (T5).  Self-attention over a single position needs only Wv, Wo.
+ * enc_hidden: [B,L,H] in cfg->dtype = om_encoder_forward's out_hidden (after the final norm).
+ * out_hidden: f32 [B,H], the decoder stack's output after its final RMSNorm. */
+typedef struct OmT5DecoderLayer {
+  const void* sa_v_w;    /* [H,H] layer[0].SelfAttention.v                                   */
+  const void* sa_o_w;    /* [H,H] layer[0].SelfAttention.o                                   */
+  const float* sa_ln_g;  /* layer[0].layer_norm                                              */
+  const void* ca_q_w;    /* [H,H] layer[1].EncDecAttention.q                                 */
+  const void* ca_kv_w;   /* [2H,H] rows: EncDecAttention.k | EncDecAttention.v               */
+  const void* ca_o_w;    /* [H,H] layer[1].EncDecAttention.o                                 */
+  const float* ca_ln_g;  /* layer[1].layer_norm                                              */
+  const void* ffn1_w;    /* [F,H] wi (wi_0 if gated)                                         */
+  const void* ffn1g_w;   /* [F,H] wi_1 or NULL                                               */
+  const void* ffn2_w;    /* [H,F] wo                                                         */
+  const float* ffn_ln_g; /* layer[2].layer_norm                                              */
+} OmT5DecoderLayer;
+typedef struct OmT5DecoderWeights {
+  const float* start_emb;   /* [H] f32: shared.weight[decoder_start_token_id]                */
+  const float* final_ln_g;  /* decoder.final_layer_norm.weight                               */
+  const OmT5DecoderLayer* layers_host; /* HOST array [n_layers] of device pointers           */
+  int n_layers;
+} OmT5DecoderWeights;
+size_t om_t5_decoder_workspace_bytes(const OmEncoderConfig* cfg, int64_t B, int64_t L);
+int om_t5_decoder_step(const OmEncoderConfig* cfg, const OmT5DecoderWeights* w, const void* enc_hidden,
+                       const int64_t* attention_mask, int64_t B, int64_t L, float* out_hidden,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
  * Encoder forward + backward for training (BERT; sequence length <= 128).
  * Replaces the autograd graph HF builds under DRModel.forward in train mode
  * (modeling/dense_retrieval_model.py:89-131 -> HF BertModel with dropout) and

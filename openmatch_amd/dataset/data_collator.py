@@ -2,6 +2,7 @@
 from dataclasses import dataclass
 
 from transformers import DataCollatorWithPadding, DefaultDataCollator
+from ..feed import pack_token_batch
 
 
 def _flatten(groups):
@@ -42,7 +43,7 @@ class DRInferenceCollator(DefaultDataCollator):
 
     def __call__(self, features):
         text_ids = [f["text_id"] for f in features]
-        return text_ids, super().__call__(features)
+        return text_ids, pack_token_batch(super().__call__(features))      # compact wire format (feed.py)
 
 
 @dataclass
@@ -53,4 +54,4 @@ class RRInferenceCollator(DefaultDataCollator):
         query_ids = [f["query_id"] for f in features]
         doc_ids = [f["doc_id"] for f in features]
         keep = [{k: v for k, v in f.items() if k not in ("query_id", "doc_id")} for f in features]
-        return query_ids, doc_ids, super().__call__(keep)
+        return query_ids, doc_ids, pack_token_batch(super().__call__(keep))

@@ -49,8 +49,22 @@ def _arch_of(model):
         return "t5"
     if name.startswith("Bert") or "Bert" in name and "Roberta" not in name:
         return "bert"
+    if "Roberta" in name:          # RobertaModel, XLMRobertaModel: the BERT stack behind offset position ids
+        return "bert"
     raise NotImplementedError(
-        f"openmatch_amd has HIP encoders for BERT and T5-encoder backbones; got {name}")
+        f"openmatch_amd has HIP encoders for BERT / RoBERTa and T5-encoder backbones; got {name}")
+
+
+def position_offset(model):
+    """RoBERTa-family models number positions from padding_idx + 1 (HF:models/roberta/modeling_roberta.py
+    create_position_ids_from_input_ids: cumsum over non-pad tokens + padding_idx): token t of a right-padded sequence
+    reads row t + padding_idx + 1 of the position table.  The kernels index positions from 0, so the table (and its
+    gradient) is handed over starting at that row.  Padded positions read other rows than HF's (row padding_idx) -- they
+    are masked out of attention and pooling, so no output depends on them.  0 for BERT."""
+    if "Roberta" in type(model).__name__:
+        pad = getattr(model.config, "pad_token_id", None)
+        return (1 if pad is None else int(pad)) + 1
+    return 0
 
 
 def _pack_bert(model, code, device):
@@ -63,7 +77,8 @@ def _pack_bert(model, code, device):
     emb = model.embeddings
     w = pk.weights
     w.word_emb = pk.dev(emb.word_embeddings.weight, f32, device)
-    w.pos_emb = pk.dev(emb.position_embeddings.weight, f32, device)
+    off = position_offset(model)
+    w.pos_emb = pk.dev(emb.position_embeddings.weight, f32, device) + off * cfg.hidden_size * 4
     w.type_emb = pk.dev(emb.token_type_embeddings.weight, f32, device)
     w.emb_ln_g = pk.dev(emb.LayerNorm.weight, f32, device)
     w.emb_ln_b = pk.dev(emb.LayerNorm.bias, f32, device)
@@ -91,7 +106,7 @@ def _pack_bert(model, code, device):
         raise NotImplementedError(f"activation {act!r} has no HIP epilogue")
     pk.cfg = dict(arch=N.ARCH_BERT, dtype=code, hidden=cfg.hidden_size, n_layers=cfg.num_hidden_layers,
                   n_heads=cfg.num_attention_heads, head_dim=cfg.hidden_size // cfg.num_attention_heads,
-                  ffn=cfg.intermediate_size, vocab=cfg.vocab_size, max_pos=cfg.max_position_embeddings,
+                  ffn=cfg.intermediate_size, vocab=cfg.vocab_size, max_pos=cfg.max_position_embeddings - off,
                   type_vocab=cfg.type_vocab_size, act=_ACT[act], ln_eps=float(cfg.layer_norm_eps),
                   rel_buckets=0, rel_max_dist=0)
     return pk
@@ -133,6 +148,44 @@ def _pack_t5(model, code, device):
                   max_pos=0, type_vocab=0, act=_ACT[act], ln_eps=float(cfg.layer_norm_epsilon),
                   rel_buckets=cfg.relative_attention_num_buckets,
                   rel_max_dist=cfg.relative_attention_max_distance)
+    return pk
+
+
+def _pack_t5_decoder(model, code, device):
+    """Decoder-side weights of a T5Model / T5ForConditionalGeneration for om_t5_decoder_step (one decoder position:
+    self-attention needs only v, o; cross-attention k | v fused to [2H, H])."""
+    cfg = model.config
+    wd = torch.bfloat16 if code == N.OM_BF16 else torch.float32
+    f32 = torch.float32
+    pk = _Packed()
+    dec = model.decoder
+    # the reference feeds decoder_input_ids = zeros([B, 1]) (dense_retrieval_model.py:138): token 0, whatever the
+    # config's decoder_start_token_id says
+    w = N.OmT5DecoderWeights()
+    w.start_emb = pk.dev(dec.embed_tokens.weight[0], f32, device)
+    w.final_ln_g = pk.dev(dec.final_layer_norm.weight, f32, device)
+    layers = (N.OmT5DecoderLayer * len(dec.block))()
+    gated = bool(getattr(cfg, "is_gated_act", False))
+    for i, block in enumerate(dec.block):
+        sa, ca, ff, lw = block.layer[0].SelfAttention, block.layer[1].EncDecAttention, block.layer[2].DenseReluDense, layers[i]
+        lw.sa_v_w = pk.dev(sa.v.weight, wd, device)
+        lw.sa_o_w = pk.dev(sa.o.weight, wd, device)
+        lw.sa_ln_g = pk.dev(block.layer[0].layer_norm.weight, f32, device)
+        lw.ca_q_w = pk.dev(ca.q.weight, wd, device)
+        lw.ca_kv_w = pk.dev(torch.cat([ca.k.weight, ca.v.weight], 0), wd, device)
+        lw.ca_o_w = pk.dev(ca.o.weight, wd, device)
+        lw.ca_ln_g = pk.dev(block.layer[1].layer_norm.weight, f32, device)
+        if gated:
+            lw.ffn1_w = pk.dev(ff.wi_0.weight, wd, device)
+            lw.ffn1g_w = pk.dev(ff.wi_1.weight, wd, device)
+        else:
+            lw.ffn1_w = pk.dev(ff.wi.weight, wd, device)
+        lw.ffn2_w = pk.dev(ff.wo.weight, wd, device)
+        lw.ffn_ln_g = pk.dev(block.layer[2].layer_norm.weight, f32, device)
+    pk.layers = layers
+    w.layers_host = C.cast(layers, C.POINTER(N.OmT5DecoderLayer))
+    w.n_layers = len(dec.block)
+    pk.weights = w
     return pk
 
 
@@ -200,3 +253,44 @@ def hip_encode(model, items, pooling, head, normalize, code, want_hidden=True):
                                        N.ptr(tti), B, L, N.ptr(hidden), N.ptr(reps),
                                        C.c_void_p(ws_ptr), nbytes, N.stream_ptr(device)))
     return hidden, reps
+
+
+def hip_t5_decoder_step(model, items, code):
+    """Decoder hidden state [B, H] (f32) of a T5 encoder-decoder after ONE decoder position fed token 0 -- the
+    reference's `model(**items, decoder_input_ids=zeros([B, 1])).last_hidden_state[:, 0]`
+    (modeling/dense_retrieval_model.py:137-141).  Encoder through om_encoder_forward, decoder through om_t5_decoder_step."""
+    if not hasattr(model, "decoder") or not hasattr(model, "encoder"):
+        raise ValueError("an encoder-decoder T5 model is required")
+    enc_hidden, _ = hip_encode(model, items, None, None, False, code, want_hidden=True)
+    device = enc_hidden.device
+    mask = items["attention_mask"].to(device=device, dtype=torch.int64).contiguous()
+    cache = model.__dict__.setdefault(_PACK_CACHE_ATTR + "_dec", {})
+    key = (code, str(device))
+    ver = _version_key(model, None)
+    hit = cache.get(key)
+    if hit is None or hit[0] != ver:
+        hit = (ver, _pack_t5_decoder(model, code, device))
+        cache[key] = hit
+    dpk = hit[1]
+    epk = packed_weights(model, None, code, device)
+    cfg = N.OmEncoderConfig(pooling=N.POOL_NONE, normalize=0, **epk.cfg)
+    B, L = mask.shape
+    lib = N.lib()
+    with torch.cuda.device(device):
+        nbytes = lib.om_t5_decoder_workspace_bytes(C.byref(cfg), B, L)
+        _buf, ws_ptr = N.Workspace.get(device, nbytes, "decoder")
+        out = torch.empty(B, cfg.hidden, device=device, dtype=torch.float32)
+        N.check(lib.om_t5_decoder_step(C.byref(cfg), C.byref(dpk.weights), N.ptr(enc_hidden), N.ptr(mask), B, L,
+                                       N.ptr(out), C.c_void_p(ws_ptr), nbytes, N.stream_ptr(device)))
+    return out
+
+
+def hip_linear_f32(x, weight):
+    """x [B, K] f32 @ weight[N, K]^T on the device through om_gemm_nt (LinearHead / LM-head columns)."""
+    x = x.to(torch.float32).contiguous()
+    w = weight.detach().to(device=x.device, dtype=torch.float32).contiguous()
+    out = torch.empty(x.shape[0], w.shape[0], device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        N.check(N.lib().om_gemm_nt(N.OM_F32, N.ptr(x), x.shape[1], N.ptr(w), w.shape[1], N.OM_F32, N.ptr(out), w.shape[0],
+                                   x.shape[0], w.shape[0], x.shape[1], None, None, 0, 0, N.stream_ptr(x.device)))
+    return out

@@ -103,9 +103,7 @@ class DRModel(nn.Module):
             return None, None
         items = BatchEncoding(items)
         if "T5" in type(model).__name__ and not self.model_args.encoder_only:
-            raise NotImplementedError(
-                "T5 encoder-decoder pooling (decoder step) has no HIP path yet; use "
-                "--encoder_only (T5EncoderModel), which is what GTR/sentence-T5 checkpoints need.")
+            return self._encode_t5_decoder(items, model, head)
         if self.feature != "last_hidden_state":
             raise NotImplementedError("only feature='last_hidden_state' is produced by the HIP encoder")
         if self.pooling not in ("first", "mean"):
@@ -120,6 +118,22 @@ class DRModel(nn.Module):
             return encode_with_grad(model, head, items, self.pooling, self.normalize, code,
                                     self.training)
         return hip_encode(model, items, self.pooling, head, self.normalize, code)
+
+    def _encode_t5_decoder(self, items, model, head):
+        """T5 encoder-decoder pooling (reference :137-141): one decoder position fed token 0, reps = its hidden state,
+        then head / normalize.  Inference only: the decoder step has no backward on the HIP path."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()):
+            raise NotImplementedError(
+                "training through the T5 decoder step has no HIP backward; train with --encoder_only "
+                "(T5EncoderModel, what GTR / sentence-T5 checkpoints use) or wrap inference in torch.no_grad()")
+        from ..encoder import hip_linear_f32, hip_t5_decoder_step
+        reps = hip_t5_decoder_step(model, items, compute_dtype_code(self.model_args))
+        hidden = reps.unsqueeze(1)                       # [B, 1, H]: the decoder's last_hidden_state
+        if head is not None:
+            reps = hip_linear_f32(reps, head.linear.weight)
+        if self.normalize:
+            reps = torch.nn.functional.normalize(reps, dim=1)
+        return hidden, reps
 
     def encode_passage(self, psg):
         return self.encode(psg, self.lm_p, self.head_p)

@@ -2,8 +2,9 @@
 (src/openmatch/modeling/reranking_model.py:34-181): encoder over the concatenated (query, doc)
 pair -> CLS / mean pooling -> `LinearHead(H, 1)`.  The whole scoring path is ONE
 `om_encoder_forward` call (head_out = 1); BASELINE config 5 (bert-large, L = 162) runs the same
-kernels as the bi-encoder at H = 1024.  The monoT5 encoder-decoder branch (:110-114) needs a T5
-decoder step, which has no HIP path: it raises.  Training is supported for sequence lengths the
+kernels as the bi-encoder at H = 1024.  The monoT5 encoder-decoder branch (:110-114) runs the encoder and one T5
+decoder position (`om_t5_decoder_step`) and reads two columns of the LM head: inference only.  Training is supported
+for encoder-only backbones at sequence lengths the
 HIP backward covers (L <= 256 in bfloat16, <= 192 in float32; the default pair length is 162)."""
 import json
 import logging
@@ -61,8 +62,7 @@ class RRModel(nn.Module):
             return None, None
         items = BatchEncoding(items)
         if "T5" in type(self.lm).__name__ and not self.model_args.encoder_only:
-            raise NotImplementedError("monoT5 scoring needs a T5 decoder step, which has no HIP path; "
-                                      "use an encoder-only backbone")
+            return self._encode_mono_t5(items)
         if self.pooling not in ("first", "mean"):
             raise ValueError("Unknown pooling type: {}".format(self.pooling))
         code = compute_dtype_code(self.model_args)
@@ -70,10 +70,36 @@ class RRModel(nn.Module):
             return encode_with_grad(self.lm, self.head, items, self.pooling, False, code, self.training)[1]
         return hip_encode(self.lm, items, self.pooling, self.head, False, code, want_hidden=False)[1]   # [B,1]
 
+    def _encode_mono_t5(self, items):
+        """monoT5 (reference :110-114): logits[:, 0, [neg_token, pos_token]] of a T5ForConditionalGeneration after one
+        decoder position fed token 0 -> [B, 2]; the Reranker takes log_softmax(...)[:, 1].  Inference only."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.lm.parameters()):
+            raise NotImplementedError("training monoT5 through the decoder step has no HIP backward; "
+                                      "score under torch.no_grad() or train an encoder-only cross-encoder")
+        if self.pos_token_id is None or self.neg_token_id is None:
+            raise ValueError("monoT5 scoring needs pos_token and neg_token")
+        if not hasattr(self.lm, "lm_head"):
+            raise ValueError("monoT5 scoring needs a T5ForConditionalGeneration (lm_head) model")
+        from ..encoder import hip_linear_f32, hip_t5_decoder_step
+        state = hip_t5_decoder_step(self.lm, items, compute_dtype_code(self.model_args))      # [B, H] f32
+        cfg = self.lm.config      # HF T5ForConditionalGeneration.forward: original T5 scales the state, v1.1 does not
+        scale = cfg.scale_decoder_outputs if hasattr(cfg, "scale_decoder_outputs") else getattr(cfg, "tie_word_embeddings", True)
+        if scale:                 # (transformers >= 5 keeps that bit in `scale_decoder_outputs`, 4.x in `tie_word_embeddings`)
+            state = state * (cfg.d_model ** -0.5)
+        cols = self.lm.lm_head.weight[[self.neg_token_id, self.pos_token_id]]
+        return hip_linear_f32(state, cols)                             # [B, 2]
+
     @classmethod
     def build(cls, model_args, data_args=None, train_args=None, tokenizer=None, **hf_kwargs):
         path = model_args.model_name_or_path
-        model_class = T5EncoderModel if model_args.encoder_only else AutoModel
+        # (reference :139-146: encoder-only T5 -> T5EncoderModel, any other T5 checkpoint -> T5ForConditionalGeneration
+        #  (monoT5 reads its LM head), everything else -> AutoModel)
+        if model_args.encoder_only:
+            model_class = T5EncoderModel
+        else:
+            from transformers import AutoConfig, T5ForConditionalGeneration
+            archs = getattr(AutoConfig.from_pretrained(path, **hf_kwargs), "architectures", None) or [""]
+            model_class = T5ForConditionalGeneration if "T5" in archs[0] else AutoModel
         config = None
         if os.path.exists(os.path.join(path, "openmatch_config.json")):
             with open(os.path.join(path, "openmatch_config.json")) as f:

@@ -43,6 +43,16 @@ class OmEncoderWeights(C.Structure):
                 ("rel_bias", c_void_p), ("head_w", c_void_p)]
 
 
+class OmT5DecoderLayer(C.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "sa_v_w", "sa_o_w", "sa_ln_g", "ca_q_w", "ca_kv_w", "ca_o_w", "ca_ln_g", "ffn1_w", "ffn1g_w", "ffn2_w", "ffn_ln_g")]
+
+
+class OmT5DecoderWeights(C.Structure):
+    _fields_ = [("start_emb", c_void_p), ("final_ln_g", c_void_p),
+                ("layers_host", C.POINTER(OmT5DecoderLayer)), ("n_layers", c_int)]
+
+
 class OmLayerGrads(C.Structure):
     _fields_ = [(n, c_void_p) for n in (
         "qkv_w", "qkv_b", "o_w", "o_b", "ln1_g", "ln1_b", "ffn1_w", "ffn1_b", "ffn2_w", "ffn2_b",
@@ -70,6 +80,9 @@ _SIGNATURES = {
     "om_gemm_tn_acc": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                c_int64, c_int64, c_int64, c_void_p]),
     "om_encoder_workspace_bytes": (c_size_t, [C.POINTER(OmEncoderConfig), c_int64, c_int64]),
+    "om_t5_decoder_workspace_bytes": (c_size_t, [C.POINTER(OmEncoderConfig), c_int64, c_int64]),
+    "om_t5_decoder_step": (c_int, [C.POINTER(OmEncoderConfig), C.POINTER(OmT5DecoderWeights), c_void_p, c_void_p,
+                                   c_int64, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "om_t5_relative_bucket": (c_int, [c_int, c_int, c_int]),
     "om_encoder_forward": (c_int, [C.POINTER(OmEncoderConfig), C.POINTER(OmEncoderWeights), c_void_p,
                                    c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,

@@ -15,6 +15,7 @@ from transformers.trainer_pt_utils import IterableDatasetShard
 
 from ..dataset.data_collator import RRInferenceCollator
 from ..utils import load_from_trec, merge_retrieval_results_by_score, save_as_trec
+from ..feed import unpack_token_batch
 
 logger = logging.getLogger(__name__)
 
@@ -86,7 +87,7 @@ class Reranker:
         with torch.no_grad():
             for qids, dids, batch in tqdm(loader, desc="Reranking", disable=a.local_process_index > 0):
                 with cast:
-                    batch = {k: v.to(a.device, non_blocking=True) for k, v in batch.items()}
+                    batch = unpack_token_batch(batch, a.device)
                     out = self.model.encode(batch)
                 if out.dim() == 2 and out.shape[1] == 2:
                     out = F.log_softmax(out, dim=1)[:, 1]

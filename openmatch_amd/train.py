@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import native as N
-from .encoder import _POOL, _arch_of, packed_weights
+from .encoder import _POOL, _arch_of, packed_weights, position_offset
 
 
 def _bert_params(model, head):
@@ -116,6 +116,7 @@ class _EncoderTrain(torch.autograd.Function):
         else:
             gw = buf(g, "word_emb", *emb.word_embeddings.weight.shape)
             gp = buf(g, "pos_emb", *emb.position_embeddings.weight.shape)
+            g.pos_emb = gp[position_offset(model):].data_ptr()        # RoBERTa: positions start at padding_idx + 1
             gt = buf(g, "type_emb", *emb.token_type_embeddings.weight.shape)
             gg = buf(g, "emb_ln_g", H)
             gb = buf(g, "emb_ln_b", H)

@@ -737,6 +737,134 @@ def test_bf16_attention_backward_kernels_agree(L, p_drop):
     print(f"\n[attention backward, L={L}, p={p_drop}] least aligned gradient tensor: {worst}")
 
 
+def test_roberta_backbone_matches_hf_forward_and_autograd():
+    """`AutoModel.from_pretrained` (reference modeling/dense_retrieval_model.py:173) may hand DRModel a RoBERTa-family
+    checkpoint: the BERT stack behind position ids that start at padding_idx + 1 (HF create_position_ids_from_input_ids).
+    f32 HIP path vs HF RobertaModel on the CPU, right-padded ragged batches: embeddings within 1e-4, and loss + every
+    parameter gradient of a contrastive training step vs torch autograd through the HF module (incl. the shifted rows
+    of the position table)."""
+    from transformers import RobertaConfig, RobertaModel
+    from openmatch.modeling import DRModel, DRModelForInference
+    torch.manual_seed(31)
+    cfg = RobertaConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=600,
+                        max_position_embeddings=140, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    lm = RobertaModel(cfg)
+    ref_lm = RobertaModel(cfg); ref_lm.load_state_dict(lm.state_dict())
+    pad = cfg.pad_token_id
+    rng = np.random.default_rng(3)
+
+    def batch(n, L, lo):
+        ids, mask = synth_tokens(rng, n, L, vocab=600, lo_len=lo, lo_id=300)
+        ids[mask == 0] = pad                                  # HF derives the positions from input_ids != pad
+        return torch.from_numpy(ids), torch.from_numpy(mask)
+    p_ids, p_mask = batch(6, 128, 40)
+    q_ids, q_mask = batch(3, 32, 5)
+
+    def ref_mean(ids, mask):
+        h = ref_lm(input_ids=ids, attention_mask=mask).last_hidden_state
+        m = mask.unsqueeze(-1).float()
+        return (h * m).sum(1) / m.sum(1).clamp(min=1e-9)
+    # inference
+    inf = DRModelForInference(lm_q=lm, lm_p=lm, pooling="mean", model_args=NS(encoder_only=False, dtype="float32")).to(DEV).eval()
+    with torch.no_grad():
+        want = ref_mean(p_ids, p_mask)
+        _, got = inf.encode_passage({"input_ids": p_ids.to(DEV), "attention_mask": p_mask.to(DEV)})
+    assert (got.cpu() - want).abs().max().item() < 1e-4
+    # training step
+    hq, hp = ref_mean(q_ids, q_mask), ref_mean(p_ids, p_mask)
+    loss_ref, _ = retrieval_ref.contrastive_loss(hq, hp, 2)
+    loss_ref.backward()
+    model = DRModel(lm_q=lm, lm_p=lm, pooling="mean", model_args=NS(encoder_only=False, dtype="float32"),
+                    data_args=NS(train_n_passages=2),
+                    train_args=NS(negatives_x_device=False, per_device_train_batch_size=3)).to(DEV).train()
+    out = model(query={"input_ids": q_ids.to(DEV), "attention_mask": q_mask.to(DEV)},
+                passage={"input_ids": p_ids.to(DEV), "attention_mask": p_mask.to(DEV)})
+    assert abs(out.loss.item() - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item()))
+    out.loss.backward()
+    got_g = dict(lm.named_parameters())
+    checked = 0
+    for name, p in ref_lm.named_parameters():
+        if p.grad is None or "pooler" in name:
+            continue
+        gg = got_g[name].grad.cpu()
+        if name == "embeddings.position_embeddings.weight":   # rows of padded positions: HF adds them to row `pad`, masked here
+            rows = slice(pad + 1, pad + 1 + 128)
+            gg, ref_g = gg[rows], p.grad[rows]
+        elif name == "embeddings.word_embeddings.weight":
+            keep = torch.ones(cfg.vocab_size, dtype=torch.bool); keep[pad] = False
+            gg, ref_g = gg[keep], p.grad[keep]
+        else:
+            ref_g = p.grad
+        rel = ((gg - ref_g).norm() / (ref_g.norm() + 1e-20)).item()
+        assert rel < 2e-3 or (gg - ref_g).abs().max().item() < 1e-7, (name, rel)
+        checked += 1
+    assert checked >= 30
+
+
+@pytest.mark.parametrize("gated", [False, True])
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_t5_encoder_decoder_pooling_and_monot5_match_hf(gated, dtype):
+    """T5 backbones that are NOT --encoder_only: the reference feeds decoder_input_ids = zeros([B, 1]) and takes the
+    decoder's hidden state as the representation (modeling/dense_retrieval_model.py:137-141), or -- monoT5 -- the LM
+    head's logits of two tokens there (modeling/reranking_model.py:110-114, + log_softmax in retriever/reranker.py:115).
+    HIP path (om_encoder_forward + om_t5_decoder_step) vs HF T5ForConditionalGeneration on the CPU in f32."""
+    from transformers import T5Config, T5ForConditionalGeneration
+    from openmatch.modeling import DRModelForInference, LinearHead, RRModel
+    torch.manual_seed(41 + gated)
+    cfg = T5Config(d_model=128, d_ff=256, num_layers=2, num_decoder_layers=3, num_heads=2, d_kv=64, vocab_size=600,
+                   feed_forward_proj="gated-gelu" if gated else "relu", tie_word_embeddings=not gated,
+                   decoder_start_token_id=0)
+    lm = T5ForConditionalGeneration(cfg).eval()
+    with torch.no_grad():                                   # random init leaves the norms at 1: make them matter
+        for name, p in lm.named_parameters():
+            if "layer_norm" in name:
+                p.copy_(1.0 + 0.3 * torch.randn_like(p))
+    rng = np.random.default_rng(9)
+    ids, mask = synth_tokens(rng, 7, 96, vocab=600, lo_len=20, lo_id=300)
+    ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
+    with torch.no_grad():
+        out = lm(input_ids=ids_t, attention_mask=mask_t, decoder_input_ids=torch.zeros(7, 1, dtype=torch.long),
+                 output_hidden_states=True, return_dict=True)
+        want_state = out.decoder_hidden_states[-1][:, 0, :]             # after the decoder's final norm
+        want_logits = out.logits[:, 0, [17, 23]]
+    items = {"input_ids": ids_t.to(DEV), "attention_mask": mask_t.to(DEV)}
+    exact = dtype == "float32"
+    # --- bi-encoder pooling: DRModel.encode -> (hidden [B,1,H], reps)
+    head = LinearHead(128, 64)
+    dr = DRModelForInference(lm_q=lm, lm_p=lm, head_q=head, head_p=head, normalize=True,
+                             model_args=NS(encoder_only=False, dtype=dtype)).to(DEV).eval()
+    hidden, reps = dr.encode_passage(items)
+    assert hidden.shape == (7, 1, 128) and reps.shape == (7, 64)
+    got_state = hidden[:, 0, :].float().cpu()
+    want_reps = torch.nn.functional.normalize(want_state @ head.linear.weight.detach().cpu().t(), dim=1)
+    if exact:
+        assert (got_state - want_state).abs().max().item() < 1e-4 * max(1.0, want_state.abs().max().item())
+        assert (reps.cpu() - want_reps).abs().max().item() < 1e-4
+    else:
+        cos = torch.nn.functional.cosine_similarity(got_state, want_state, dim=1).min().item()
+        assert cos > 0.999, cos
+    # --- monoT5: RRModel.encode -> [B, 2] logits of (neg_token, pos_token)
+    class Tok:                                               # RRModel only asks the tokenizer for the two token ids
+        def encode(self, t, add_special_tokens=False):
+            return [{"true": 23, "false": 17}[t]]
+    rr = RRModel(lm=lm, head=LinearHead(128, 1), pos_token="true", neg_token="false", tokenizer=Tok(),
+                 model_args=NS(encoder_only=False, dtype=dtype)).to(DEV).eval()
+    with torch.no_grad():
+        got_logits = rr.encode(items).cpu()
+    assert got_logits.shape == (7, 2)
+    if exact:
+        assert (got_logits - want_logits).abs().max().item() < 1e-4 * max(1.0, want_logits.abs().max().item())
+    else:
+        want_s = torch.log_softmax(want_logits, dim=1)[:, 1]
+        got_s = torch.log_softmax(got_logits, dim=1)[:, 1]
+        assert (got_s - want_s).abs().max().item() < 3e-2 * max(1.0, want_logits.abs().max().item())      # bf16: relative to the logits' size
+    # training through the decoder step is refused with a message
+    dr_t = type(dr).__mro__[1](lm_q=lm, lm_p=lm, model_args=NS(encoder_only=False, dtype=dtype),
+                               data_args=NS(train_n_passages=1), train_args=NS(negatives_x_device=False)).to(DEV).train()
+    with pytest.raises(NotImplementedError, match="decoder"):
+        dr_t.encode_passage(items)
+
+
 def test_float32_training_rejects_more_than_192_tokens():
     """The float32 backward attention kernel holds three [64][L + 4] f32 images in LDS: 192 keys is what 160 KiB takes.
     Longer float32 batches must fail with a message, not a HIP error (and leave no sticky error behind)."""

@@ -245,3 +245,36 @@ def test_no_kernel_spills_to_scratch():
         return False
     bad = {k: v for k, v in kernels.items() if v > 0 and not allowed(k, v)}
     assert not bad, bad
+
+
+def test_packed_token_transport_round_trip():
+    """openmatch_amd/feed.py: the collators' compact wire format (16-bit ids, one length per right-padded row, no token
+    types when they are all zero) rebuilds exactly the int64 tensors the reference's collators would have sent
+    (dataset/data_collator.py:78-91), and falls back to the plain batch whenever something does not fit."""
+    import torch
+    from openmatch_amd.feed import is_packed, pack_token_batch, packed_nbytes, unpack_token_batch
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, 65536, (7, 33), generator=g)
+    lens = torch.randint(1, 34, (7,), generator=g)
+    mask = (torch.arange(33)[None, :] < lens[:, None]).long()
+    for tti in (None, torch.zeros_like(ids), (torch.arange(33)[None, :] >= 10).long().expand(7, 33).contiguous()):
+        batch = {"input_ids": ids, "attention_mask": mask}
+        if tti is not None:
+            batch["token_type_ids"] = tti
+        packed = pack_token_batch(dict(batch))
+        assert is_packed(packed)
+        assert packed_nbytes(packed) * 4 < sum(v.numel() * 8 for v in batch.values())     # > 4x smaller (12x at [B,128] with no types)
+        back = unpack_token_batch(packed, "cpu")
+        assert back.keys() == batch.keys()
+        for k in batch:
+            assert back[k].dtype == torch.int64 and torch.equal(back[k], batch[k]), k
+    # a mask with a hole travels as bytes; ids beyond 16 bits, negative ids or extra keys are not packed at all
+    holed = mask.clone(); holed[0, 0] = 0
+    back = unpack_token_batch(pack_token_batch({"input_ids": ids, "attention_mask": holed}), "cpu")
+    assert torch.equal(back["attention_mask"], holed)
+    assert not is_packed(pack_token_batch({"input_ids": ids + 70000, "attention_mask": mask}))
+    neg = ids.clone(); neg[0, 0] = -1
+    assert not is_packed(pack_token_batch({"input_ids": neg, "attention_mask": mask}))
+    assert not is_packed(pack_token_batch({"input_ids": ids, "attention_mask": mask, "labels": ids}))
+    plain = unpack_token_batch({"input_ids": ids, "attention_mask": mask}, "cpu")
+    assert torch.equal(plain["input_ids"], ids)
