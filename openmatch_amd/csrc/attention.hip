@@ -342,6 +342,167 @@ static int launch_attn16(const void* qkv, void* ctx, const int64_t* mask, const 
   return launch_attn16_<KT, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Long sequences (256 < L <= 1024, inference): the kernels above keep a whole score row per lane (L / 2 registers) and
+// all of K, V in LDS, which stops at 256 keys.  Document corpora are encoded at 512 tokens (the reference accepts anything
+// up to max_position_embeddings).  Here a workgroup owns 128 QUERIES of one (batch, head) -- four waves of 32 -- and walks
+// the keys in chunks of 128 with the online softmax: running maximum m and sum l per query, O rescaled by
+// exp(m_old - m_new) per chunk.  K chunk row-major (swizzled), V chunk transposed, as in attention_kernel<T, 4>; the
+// accumulators O[query][d] keep queries in REGISTERS and d in lanes (SlabMma), so the per-query factors travel through a
+// 32-float LDS table per wave.  Constant registers and LDS for any L; K / V are re-read once per 128 queries (L2).
+template <typename T>
+__global__ __launch_bounds__(256) void attention_long_kernel(
+    const T* __restrict__ qkv, T* __restrict__ ctx, const int64_t* __restrict__ mask,
+    const float* __restrict__ pos_bias, int L, int H, int heads, float scale) {
+  typedef AttnGeom<T> G;
+  typedef typename MmaOps<T>::frag_t frag_t;
+  constexpr int LP = 128 + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  T* sVt = (T*)(smem + 128 * G::ROWB);
+  float* sM = (float*)(smem + 128 * G::ROWB + 64 * LP * (int)sizeof(T));
+  float* sF = sM + 128;                                     // [4 waves][32] per-query factors
+
+  const int h = blockIdx.x % heads;
+  const int64_t b = blockIdx.x / heads;
+  const int qb = blockIdx.y * 128;
+  const int tid = threadIdx.x;
+  const int64_t ld = 3 * (int64_t)H;
+  const T* base = qkv + b * L * ld + h * 64;
+  const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int q0 = qb + wave * 32;
+  const int qrow = (q0 + l31) < L ? (q0 + l31) : (L - 1);
+  frag_t qf[G::NKK];
+#pragma unroll
+  for (int kk = 0; kk < G::NKK; ++kk) qf[kk] = *(const frag_t*)(base + (int64_t)qrow * ld + (kk * 2 + half) * G::EPC);
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16_t o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+
+  for (int kc = 0; kc < L; kc += 128) {
+    __syncthreads();                                         // the previous chunk has been consumed by every wave
+    for (int idx = tid; idx < 128 * G::CPR; idx += 256) {
+      const int row = idx / G::CPR, c = idx % G::CPR;
+      uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+      if (kc + row < L) {
+        kv = *(const uint4*)(base + (int64_t)(kc + row) * ld + H + c * G::EPC);
+        vv = *(const uint4*)(base + (int64_t)(kc + row) * ld + 2 * H + c * G::EPC);
+      }
+      *(uint4*)(sK + row * G::ROWB + ((c ^ G::key(row)) << 4)) = kv;
+      const T* ve = (const T*)&vv;
+#pragma unroll
+      for (int e = 0; e < G::EPC; ++e) sVt[(c * G::EPC + e) * LP + row] = ve[e];
+    }
+    if (tid < 128) sM[tid] = (kc + tid) < L ? (mask[b * L + kc + tid] != 0 ? 0.f : -3.4028235e38f) : -INFINITY;
+    __syncthreads();
+
+    f32x16_t s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+      const int row = t * 32 + l31;
+      const char* krow = sK + row * G::ROWB;
+      const int key = G::key(row);
+#pragma unroll
+      for (int kk = 0; kk < G::NKK; ++kk) {
+        const frag_t a = *(const frag_t*)(krow + (((kk * 2 + half) ^ key) << 4));
+        MmaOps<T>::mma(a, qf[kk], s[t]);
+      }
+    }
+    float mx = m_run;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int k0 = t * 32 + 8 * g + 4 * half;
+        const f32x4_t mb = *(const f32x4_t*)(sM + k0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = s[t][4 * g + e] * scale;
+          if (pos_bias) {
+            const int kcol = (kc + k0 + e) < L ? (kc + k0 + e) : (L - 1);
+            v += pos_bias[((int64_t)h * L + qrow) * L + kcol];
+          }
+          v += mb[e];
+          s[t][4 * g + e] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // the first chunk always holds key 0 (unmasked [CLS] or finfo.min, finite): mx is finite from here on
+    const float alpha = G::exp_(m_run - mx);                 // exp(-inf) = 0 on the first chunk
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = G::exp_(s[t][r] - mx);
+        s[t][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    l_run = l_run * alpha + sum;
+    m_run = mx;
+    // rescale O: the factor of query q lives in lane q; O holds queries in registers -> through the wave's table
+    if (half == 0) sF[wave * 32 + l31] = alpha;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (same wave: LDS operations execute in order)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4_t a4 = *(const f32x4_t*)(sF + wave * 32 + 8 * g + 4 * half);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[0][4 * g + e] *= a4[e]; o[1][4 * g + e] *= a4[e]; }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) SlabMma<T>::run(s[t], sVt + l31 * LP + t * 32 + 4 * half, LP, o);
+  }
+  // O / l, parked in the wave's own K rows, stored as whole 16-byte vectors
+  __syncthreads();
+  if (half == 0) sF[wave * 32 + l31] = 1.0f / l_run;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  T* so = (T*)(sK + (size_t)(wave * 32) * G::ROWB);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4_t i4 = *(const f32x4_t*)(sF + wave * 32 + 8 * g + 4 * half);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = 8 * g + 4 * half + e;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) ElemOps<T>::store(so + q * 64 + dt * 32 + l31, o[dt][4 * g + e] * i4[e]);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (q0 < L) {
+    T* out = ctx + (b * L + q0) * H + h * 64;
+    constexpr int VPR = G::ROWB / 16;
+#pragma unroll
+    for (int it = 0; it < 32 * VPR / 64; ++it) {
+      const int idx = it * 64 + lane, row = idx / VPR, c = idx % VPR;
+      const uint4 v = *(const uint4*)((const char*)so + row * G::ROWB + c * 16);
+      if (q0 + row < L) *(uint4*)((char*)(out + (int64_t)row * H) + c * 16) = v;
+    }
+  }
+}
+
+template <typename T>
+static int launch_attn_long(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias, int64_t B, int L, int H,
+                            int heads, float scale, hipStream_t s) {
+  const int lds = 128 * AttnGeom<T>::ROWB + 64 * 132 * (int)sizeof(T) + 128 * 4 + 128 * 4;
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set) {
+    OM_HIP(hipFuncSetAttribute((const void*)attention_long_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attention_long_kernel<T>), dim3((unsigned)(heads * B), (unsigned)((L + 127) / 128)), dim3(256), lds, s,
+                     (const T*)qkv, (T*)ctx, mask, pos_bias, L, H, heads, scale);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T, int KT>
 static int launch_attn(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias,
                        int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
@@ -377,9 +538,14 @@ int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
                   const float* pos_bias, int64_t B, int L, int H, int heads, float scale,
                   float drop_p, uint64_t seed, hipStream_t s) {
   if (B <= 0) return 0;
-  if (L < 1 || L > 256) OM_FAIL("sequence length must be in [1,256]");
+  if (L < 1 || L > 1024) OM_FAIL("sequence length must be in [1,1024]");
+  if (L > 256 && drop_p > 0.f) OM_FAIL("training supports sequence lengths up to 256");
   if (H != heads * 64) OM_FAIL("head_dim must be 64");
   if (B * heads > 0x7fffffffLL) OM_FAIL("batch too large for one launch");
+  if (L > 256) {                                              // online-softmax kernel, any dtype
+    if (dtype == OM_BF16) return launch_attn_long<bf16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
+    return launch_attn_long<float>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
+  }
   if (dtype == OM_BF16 && drop_p == 0.f && om_option(OM_OPT_ATTENTION_FAST)) {        // inference: the low-instruction-count kernel
     if (L <= 32) return launch_attn16<1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
     if (L <= 64) return launch_attn16<2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);

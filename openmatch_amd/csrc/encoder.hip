@@ -100,7 +100,7 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
   if (!c || !w || !input_ids || !attention_mask) OM_FAIL("null argument");
   if (check_cfg(c)) return 1;
   if (B <= 0) return 0;
-  if (L < 1 || L > 256) OM_FAIL("sequence length must be in [1,256]");
+  if (L < 1 || L > 1024) OM_FAIL("sequence length must be in [1,1024]");
   if (!workspace || ((uintptr_t)workspace & 255)) OM_FAIL("workspace must be 256-byte aligned");
   EncWs ws = carve(c, B, L, (char*)workspace);
   if (ws.total > workspace_bytes) OM_FAIL("workspace too small");

@@ -865,6 +865,45 @@ def test_t5_encoder_decoder_pooling_and_monot5_match_hf(gated, dtype):
         dr_t.encode_passage(items)
 
 
+@pytest.mark.parametrize("arch,L,dtype", [("bert", 384, "float32"), ("bert", 512, "float32"), ("bert", 512, "bfloat16"),
+                                          ("t5", 320, "float32"), ("t5", 512, "bfloat16")])
+def test_long_sequences_match_oracle(arch, L, dtype):
+    """Document-length inputs (the reference accepts anything up to max_position_embeddings; its document recipes use
+    512): above 256 tokens attention runs on the key-chunked online-softmax kernel (attention.hip:
+    attention_long_kernel).  Ragged batches whose lengths straddle the 128-key chunks, against the CPU oracle."""
+    from openmatch.modeling import DRModelForInference
+    torch.manual_seed(L)
+    if arch == "bert":
+        from transformers import BertConfig, BertModel
+        cfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=600,
+                         max_position_embeddings=512)
+        lm = BertModel(cfg).eval()
+        encoder_only = False
+    else:
+        from transformers import T5Config, T5EncoderModel
+        cfg = T5Config(d_model=128, d_ff=256, num_layers=2, num_heads=2, d_kv=64, vocab_size=600)
+        lm = T5EncoderModel(cfg).eval()
+        with torch.no_grad():
+            for name, p in lm.named_parameters():
+                if "relative_attention_bias" in name:
+                    p.copy_(0.5 * torch.randn_like(p))
+        encoder_only = True
+    rng = np.random.default_rng(L)
+    ids, mask = synth_tokens(rng, 5, L, vocab=600, lo_len=L // 4, lo_id=300)
+    ids[0, :], mask[0, :] = rng.integers(300, 600, L), 1          # one full-length row
+    tens = lambda a: torch.from_numpy(a)
+    sd = dict(lm.named_parameters()); sd.update({k: v for k, v in lm.named_buffers()})
+    with torch.no_grad():
+        ref = encoder_ref.encode(sd, cfg, arch, {"input_ids": tens(ids), "attention_mask": tens(mask)}, "mean")[1]
+    model = DRModelForInference(lm_q=lm, lm_p=lm, pooling="mean", model_args=NS(encoder_only=encoder_only, dtype=dtype)).to(DEV).eval()
+    _, got = model.encode_passage({"input_ids": tens(ids).to(DEV), "attention_mask": tens(mask).to(DEV)})
+    got = got.float().cpu()
+    if dtype == "float32":
+        assert (got - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+    else:
+        assert torch.nn.functional.cosine_similarity(got, ref, dim=1).min().item() > 0.999
+
+
 def test_float32_training_rejects_more_than_192_tokens():
     """The float32 backward attention kernel holds three [64][L + 4] f32 images in LDS: 192 keys is what 160 KiB takes.
     Longer float32 batches must fail with a message, not a HIP error (and leave no sticky error behind)."""
