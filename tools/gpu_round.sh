@@ -1,9 +1,7 @@
 #!/bin/bash
-R=$PWD; O=$R/gpurun_out/call6; mkdir -p $O
+R=$PWD; O=$R/gpurun_out/round; mkdir -p $O
 export LD_LIBRARY_PATH=$R/openmatch_amd/csrc:$LD_LIBRARY_PATH
 timeout 300 $R/build/selftest full > $O/full.log 2>&1; echo "selftest rc=$?" >> $O/full.log
-timeout 200 $R/build/selftest scantrace > $O/scantrace.log 2>&1; echo "rc=$?" >> $O/scantrace.log
-timeout 200 $R/build/selftest scantrace 8841823 6980 >> $O/scantrace.log 2>&1; echo "rc=$?" >> $O/scantrace.log
 timeout 1200 python -m pytest tests -m gpu -q -s > $O/pytest.log 2>&1; echo "rc=$?" >> $O/pytest.log
 timeout 900 python bench.py > $O/bench.json 2>$O/bench.err
 cd /tmp; export TMPDIR=/tmp
@@ -12,6 +10,5 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --no-search --no-cpu-baseline --no-extra --no-parity > $O/pmc_write.log 2>&1
 cd $R
 python tools/summarize_pmc.py $O > $O/pmc_summary.txt 2>&1
-grep "FAIL\|SELFTEST\|rc=" $O/full.log | tail -12; cat $O/scantrace.log; grep -v "^$" $O/pytest.log | grep "^\[\|passed\|failed\|Error\|error\|rc=\|FAIL" | tail -20; cat $O/bench.json
 f=$(find $O/prof_stats -name "*kernel_stats.csv" | head -1); head -12 "$f" | cut -c1-150
 grep -A3 "gemm_nt_kernel7" $O/pmc_summary.txt | head -40
