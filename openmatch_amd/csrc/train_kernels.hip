@@ -298,10 +298,12 @@ __global__ __launch_bounds__((NV == 8 || MODE == 1) ? 256 : 512) void ln_bwd_ker
             store4<T>(dx_drop + row * H + c, dr);
           }
         } else {
+          // the word-table scatter leaves through a wave-private LDS row so that every atomic instruction covers 64
+          // CONSECUTIVE columns (the registers hold 4 consecutive columns per lane: 16 cache lines per instruction)
+          *(float4*)(red + w * H + c) = make_float4(out[0], out[1], out[2], out[3]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float v = out[e];
-            atomicAdd(dword + id * H + c + e, v);
             if (tt == 0) tacc[0][j][e] += v;
             else if (tt == 1) tacc[MODE == 1 ? 1 : 0][j][e] += v;
             else atomicAdd(dtype_ + tt * H + c + e, v);
@@ -310,7 +312,13 @@ __global__ __launch_bounds__((NV == 8 || MODE == 1) ? 256 : 512) void ln_bwd_ker
         }
       }
     }
+    if (MODE == 1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its LDS operations execute in order)
+      for (int cc = lane; cc < H; cc += 64) atomicAdd(dword + id * H + cc, red[w * H + cc]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // read before the next row overwrites it
+    }
   }
+  if (MODE == 1) __syncthreads();          // `red` is the block-reduction buffer from here on
   // block reduction of the parameter gradients
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
@@ -373,7 +381,9 @@ static int launch_ln_bwd(const void* dy, const void* x, const float* g, void* dx
                          int rms = 0, const void* add = nullptr, void* dx_drop = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0) {
   const int waves = (H <= 1024 && MODE == 0) ? 8 : 4;
   const int64_t want = (M + waves - 1) / waves;
-  unsigned grid = (unsigned)(want > 256 ? 256 : want);
+  // two blocks per CU: ~12 MB of loads in flight (one row per wave at a time), what ~5 TB/s x ~2 us of latency needs;
+  // more blocks only add same-address atomics on d_gamma / d_beta (1024 blocks: 41 us, 256: 30 us per call)
+  unsigned grid = (unsigned)(want > 512 ? 512 : want);
   if (MODE == 1) {                     // one position per block, 256 / L blocks per position (kernel comment)
     if (L < 1 || M % L) OM_FAIL("embedding backward: M must be B * L");
     const int parts = 256 / L > 0 ? 256 / L : 1;
