@@ -172,10 +172,10 @@ __device__ __forceinline__ uint32_t pack_bf16x2_(float lo, float hi) {      // o
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw_a_t));
 }
 
-template <int KT, bool BIAS>
-__global__ __launch_bounds__(64 * KT, KT <= 4 ? (BIAS ? 3 : 4) : 2) void attention_fwd16_kernel(
+template <int KT, bool BIAS, bool DROP>
+__global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) void attention_fwd16_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, const int64_t* __restrict__ mask,
-    const float* __restrict__ pos_bias, int L, int H, int heads, float scale) {
+    const float* __restrict__ pos_bias, int L, int H, int heads, float scale, float drop_p, uint64_t seed) {
   typedef bf16x8_t frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sK = smem;
@@ -261,7 +261,21 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? (BIAS ? 3 : 4) : 2) void attenti
       sum += e;
     }
   sum += __shfl_xor(sum, 32, 64);
-  const float inv = 1.0f / sum;
+  float inv = 1.0f / sum;
+  if (DROP) {       // training forward: attention_probs dropout on the (still unnormalised) probabilities; the mask is
+                    // regenerated by the backward from (seed, b, h, q, key group) -- attn_common.h
+    const AttnDrop dr(drop_p);
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint64_t bits = attn_drop_bits(seed, b, h, heads, L, q0 + l31, (t * 32 + 8 * g + 4 * half) >> 2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[t][4 * g + e] = attn_drop_keep(bits, e, dr.thresh) ? s[t][4 * g + e] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    inv *= dr.keep_scale;
+  }
 
   // identity fragments of the transposing MFMAs: lane j holds 1.0 at k == j of the 32-wide d block
   frag_t idf[2];
@@ -321,25 +335,29 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? (BIAS ? 3 : 4) : 2) void attenti
   }
 }
 
-template <int KT, bool BIAS>
+template <int KT, bool BIAS, bool DROP>
 static int launch_attn16_(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias, int64_t B, int L, int H,
-                         int heads, float scale, hipStream_t s) {
+                         int heads, float scale, float drop_p, uint64_t seed, hipStream_t s) {
   const int lds = 2 * KT * 32 * 128 + KT * 32 * 4;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
-    OM_HIP(hipFuncSetAttribute((const void*)attention_fwd16_kernel<KT, BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    OM_HIP(hipFuncSetAttribute((const void*)attention_fwd16_kernel<KT, BIAS, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((attention_fwd16_kernel<KT, BIAS>), dim3((unsigned)(heads * B)), dim3(64 * KT), lds, s, (const bf16_t*)qkv,
-                     (bf16_t*)ctx, mask, pos_bias, L, H, heads, scale);
+  hipLaunchKernelGGL((attention_fwd16_kernel<KT, BIAS, DROP>), dim3((unsigned)(heads * B)), dim3(64 * KT), lds, s, (const bf16_t*)qkv,
+                     (bf16_t*)ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed);
   OM_LAUNCH_CHECK();
   return 0;
 }
 template <int KT>
 static int launch_attn16(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias, int64_t B, int L, int H,
-                         int heads, float scale, hipStream_t s) {
-  if (pos_bias) return launch_attn16_<KT, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
-  return launch_attn16_<KT, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
+                         int heads, float scale, float drop_p, uint64_t seed, hipStream_t s) {
+  if (drop_p > 0.f) {
+    if (pos_bias) return launch_attn16_<KT, true, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
+    return launch_attn16_<KT, false, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
+  }
+  if (pos_bias) return launch_attn16_<KT, true, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s);
+  return launch_attn16_<KT, false, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -546,12 +564,12 @@ int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
     if (dtype == OM_BF16) return launch_attn_long<bf16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
     return launch_attn_long<float>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
   }
-  if (dtype == OM_BF16 && drop_p == 0.f && om_option(OM_OPT_ATTENTION_FAST)) {        // inference: the low-instruction-count kernel
-    if (L <= 32) return launch_attn16<1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
-    if (L <= 64) return launch_attn16<2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
-    if (L <= 128) return launch_attn16<4>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
-    if (L <= 192) return launch_attn16<6>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
-    return launch_attn16<8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
+  if (dtype == OM_BF16 && om_option(OM_OPT_ATTENTION_FAST)) {        // the low-instruction-count kernel (inference, and training with dropout)
+    if (L <= 32) return launch_attn16<1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
+    if (L <= 64) return launch_attn16<2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
+    if (L <= 128) return launch_attn16<4>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
+    if (L <= 192) return launch_attn16<6>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
+    return launch_attn16<8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
   }
   if (dtype == OM_BF16) return dispatch_attn<bf16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
   return dispatch_attn<float>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
