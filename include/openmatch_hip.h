@@ -87,7 +87,9 @@ void om_debug_gemm_gen(int gen);
                                     * scanned (default 60; smaller = more rounds, tighter thresholds, fewer appends per tile) */
 #define OM_OPT_WGRAD_DEBUG 5     /* 0 (default); timing experiments on the weight-gradient kernel: bit 1 plain stores, bit 2 one step
                                    * (both break the result), value >> 4 = workgroups aimed at / 64 */
-#define OM_OPT_COUNT 6
+#define OM_OPT_GEMM_GROUP_M 6     /* row tiles per group of the persistent GEMM's tile walk (default 8): the group's A panels stay in an
+                                   * XCD's L2 while its column tiles are swept */
+#define OM_OPT_COUNT 7
 int om_debug_option(int opt, int value);
 int om_kernel_timing_enable(int enable);
 int om_kernel_timing_read(int kernel_class, double* total_ms, int64_t* launches, double* flops);

@@ -374,7 +374,7 @@ static int launch7(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   const bool timing = om_timing_on();
   if (timing) om_timing_begin(OM_TIMING_GEMM_BF16, s);
   hipLaunchKernelGGL((gemm_nt_kernel7<T, ACT, RESID, LNF, true>), dim3((unsigned)grid), dim3(G6_THREADS), G7_LDS_BYTES, s,
-                     (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, 8);
+                     (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, std::max(1, om_option(OM_OPT_GEMM_GROUP_M)));
   if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, 2.0 * (double)M * (double)N * (double)K);
   OM_LAUNCH_CHECK();
   return 0;

@@ -346,7 +346,7 @@ int main(int argc, char** argv) {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs=%d  clock=%d MHz  mem=%.1f GB  LDS/block=%zu\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000, prop.totalGlobalMem / 1e9, prop.sharedMemPerBlock);
 
-  if (what != "bench" && what != "prof" && what != "trace" && what != "shapes" && what != "layer" && what != "gen7" && what != "scantrace" && what != "tn") {
+  if (what != "bench" && what != "prof" && what != "trace" && what != "shapes" && what != "layer" && what != "gen7" && what != "scantrace" && what != "tn" && what != "groupm") {
     // GEMM: aligned, ragged M/N tails, every epilogue, both dtypes
     test_gemm(OM_F32, 128, 128, 32, false, false, OM_ACT_NONE, OM_F32);
     test_gemm(OM_BF16, 128, 128, 64, false, false, OM_ACT_NONE, OM_F32);
@@ -452,6 +452,19 @@ int main(int argc, char** argv) {
       om_debug_option(OM_OPT_WGRAD_DEBUG, 0);
       CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(db));
     }
+    return 0;
+  }
+  if (what == "groupm") {      // persistent GEMM: tile-walk group size vs throughput on the encoder's shapes
+    const int64_t M = 131072;
+    for (int gm : {8, 1, 2, 4, 16, 32}) {
+      om_debug_option(OM_OPT_GEMM_GROUP_M, gm);
+      printf("-- group_m = %d\n", gm);
+      bench_gemm(OM_BF16, M, 2304, 768, 0);
+      bench_gemm(OM_BF16, M, 768, 768, 0);
+      bench_gemm(OM_BF16, M, 3072, 768, OM_ACT_GELU_ERF);
+      bench_gemm(OM_BF16, M, 768, 3072, 0);
+    }
+    om_debug_option(OM_OPT_GEMM_GROUP_M, 8);
     return 0;
   }
   if (what == "scantrace") {     // tile phase timeline of the generation-7 index scan (first 8192 tiles of the last round)
