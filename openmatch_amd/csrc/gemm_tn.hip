@@ -13,9 +13,10 @@
 // 32-byte rows, sub-tile stride 2048 + 128 bytes (the two column blocks a half-wave reads land on disjoint banks).
 //
 // Workgroup: 128 (n) x 128 (k) output tile, four waves of 64 x 64, over one slice of the token axis (split-M, f32
-// atomics into the caller-zeroed / caller-accumulated C); register-staged double buffer, one barrier per 64 tokens.
-// The bias column sums are taken from the A fragments themselves (eight tokens of one column per lane) by the vector ALU
-// under the MFMAs, in the waves that own k columns 0..WT-1 of k tile 0.
+// atomics into the caller-zeroed / caller-accumulated C).  Two kernels share that shape: `gemm_tn_dma_kernel` (whole
+// 64-token steps brought in by LDS-DMA, the default) and `gemm_tn_kernel` (register-staged, zero-fills: ragged tails and
+// short token axes).  The bias column sums are taken from the A fragments themselves (eight tokens of one column per
+// lane) by the vector ALU under the MFMAs, in the waves that own k columns 0..63 of k tile 0.
 #include <atomic>
 
 #include "gemm_core7.h"
