@@ -18,8 +18,8 @@
 //                 U4       [0, 8 KiB)   accumulator-init tables of the NEXT tile, 2 KiB per wave:
 //                                         s_n | b'_n (128 + 128 f32), LayerNorm statistics of the wave's 128 rows
 //                          [8, 16 KiB)  epilogue tables, 2 KiB per wave: gamma | beta, statistics of the residual rows
-//   A table of wave w occupies U4 + w KiB .. (first DMA instruction of the SAME wave in K step 0): another wave's
-//   step-0 DMA can only land there after the barrier that follows every wave's accumulator initialisation.
+//   The tables are consumed (accumulator initialisation) before the K loop's first barrier; the K loop's own DMA into U4
+//   (the spare unit, A of step 2) is issued after that barrier, so it cannot overwrite a table that is still needed.
 // One patch = 32 rows x 64 columns (8 per wave tile): staged as packed bf16 (row = 128 B, 16-byte chunk XOR
 // (row & 7)), read back row-major, stored as whole 128-byte lines.
 #pragma once
