@@ -278,3 +278,43 @@ def test_packed_token_transport_round_trip():
     assert not is_packed(pack_token_batch({"input_ids": ids, "attention_mask": mask, "labels": ids}))
     plain = unpack_token_batch({"input_ids": ids, "attention_mask": mask}, "cpu")
     assert torch.equal(plain["input_ids"], ids)
+
+
+def test_backbone_dispatch_and_position_offset():
+    """openmatch_amd/encoder.py: BERT and RoBERTa-family modules map to the BERT stack (RoBERTa with its position table
+    handed over from row padding_idx + 1, HF create_position_ids_from_input_ids), T5 to the T5 stack, anything else is
+    refused by name -- the reference builds backbones with AutoModel (modeling/dense_retrieval_model.py:173)."""
+    import pytest
+    from transformers import BertConfig, BertModel, GPT2Config, GPT2Model, RobertaConfig, RobertaModel, T5Config, T5EncoderModel
+    from openmatch_amd.encoder import _arch_of, position_offset
+    tiny = dict(hidden_size=32, num_hidden_layers=1, num_attention_heads=1, intermediate_size=64, vocab_size=50)
+    bert, rob = BertModel(BertConfig(**tiny)), RobertaModel(RobertaConfig(max_position_embeddings=40, **tiny))
+    t5 = T5EncoderModel(T5Config(d_model=64, d_ff=64, num_layers=1, num_heads=1, d_kv=64, vocab_size=50))
+    assert _arch_of(bert) == "bert" and position_offset(bert) == 0
+    assert _arch_of(rob) == "bert" and position_offset(rob) == rob.config.pad_token_id + 1 == 2
+    assert _arch_of(t5) == "t5" and position_offset(t5) == 0
+    with pytest.raises(NotImplementedError, match="GPT2Model"):
+        _arch_of(GPT2Model(GPT2Config(n_embd=32, n_layer=1, n_head=1, vocab_size=50)))
+
+
+def test_one_pass_rule_for_tied_training_batches():
+    """DRModel._one_pass_ok: queries ride along with the passages only for a TIED encoder in training mode with autograd
+    on, equal key sets, queries no longer than passages and at most a quarter as many rows."""
+    import torch
+    from types import SimpleNamespace as NS
+    from transformers import BertConfig, BertModel
+    from openmatch_amd.modeling import DRModel
+    lm = BertModel(BertConfig(hidden_size=32, num_hidden_layers=1, num_attention_heads=1, intermediate_size=64, vocab_size=50))
+    other = BertModel(lm.config)
+    mk = lambda n, L, **extra: dict({"input_ids": torch.zeros(n, L, dtype=torch.long), "attention_mask": torch.ones(n, L, dtype=torch.long)}, **extra)
+    args = dict(model_args=NS(encoder_only=False), data_args=NS(train_n_passages=8), train_args=NS(negatives_x_device=False))
+    tied = DRModel(lm_q=lm, lm_p=lm, **args).train()
+    assert tied._one_pass_ok(mk(8, 32), mk(64, 128))
+    assert not tied._one_pass_ok(mk(8, 32), mk(16, 128))            # padding would add more than a quarter
+    assert not tied._one_pass_ok(mk(8, 160), mk(64, 128))           # queries longer than passages
+    assert not tied._one_pass_ok(mk(8, 32, token_type_ids=torch.zeros(8, 32, dtype=torch.long)), mk(64, 128))
+    assert not tied._one_pass_ok(None, mk(64, 128))
+    with torch.no_grad():
+        assert not tied._one_pass_ok(mk(8, 32), mk(64, 128))
+    assert not tied.eval()._one_pass_ok(mk(8, 32), mk(64, 128))
+    assert not DRModel(lm_q=lm, lm_p=other, tied=False, **args).train()._one_pass_ok(mk(8, 32), mk(64, 128))
