@@ -3,6 +3,7 @@ R=$PWD; O=$R/gpurun_out/round; mkdir -p $O
 export LD_LIBRARY_PATH=$R/openmatch_amd/csrc:$LD_LIBRARY_PATH
 timeout 300 $R/build/selftest full > $O/full.log 2>&1; echo "selftest rc=$?" >> $O/full.log
 timeout 1200 python -m pytest tests -m gpu -q -s > $O/pytest.log 2>&1; echo "rc=$?" >> $O/pytest.log
+timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 timeout 900 python bench.py > $O/bench.json 2>$O/bench.err
 cd /tmp; export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-parity > $O/prof_stats.log 2>&1
