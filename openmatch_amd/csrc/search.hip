@@ -191,6 +191,30 @@ __device__ __forceinline__ void sc7_filter(f32x16_t (&acc)[4][4], const float (&
   }
 }
 
+// Work id -> (row tile, query tile) of the generation-7 scan.  With the GEMM's walk (g7_tile: groups of row tiles swept by
+// ALL query tiles, 32 consecutive tiles per XCD and round) every XCD touches 4 query panels and 8 row panels per
+// round and hops to another group next round: nothing is reused across rounds, and the L2 -> fabric traffic of one
+// 6980-query search measured 441 GB, 32x the 13.6 GB index (FETCH_SIZE, profiles/r02_hbm_traffic_search.json) -- 4.7 TB/s,
+// close to what the memory system delivers at all.  Here every XCD OWNS a group of at most 8 query tiles (<= 3 MiB of
+// query panels, resident in its 4 MiB L2 for the whole launch) and a share of the row tiles, and walks its rows with
+// the query tile running fastest: a row panel is fetched once per query GROUP instead of once per 4 query tiles.
+__device__ __forceinline__ bool sc7_tile(int it, int64_t ntr, int64_t ntq, int group_m, int qgroup, int64_t& r0, int64_t& q0) {
+  if ((gridDim.x & 7) != 0 || ntq > 8 * qgroup) return g7_tile(it, ntr, ntq, group_m, r0, q0);
+  const uint32_t x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const uint32_t tq = (uint32_t)ntq, tr = (uint32_t)ntr;
+  uint32_t ng = 1;                                        // query groups: 1, 2, 4 or 8 -- at most 8 query tiles each
+  while (ng < 8 && (tq + ng - 1) / ng > (uint32_t)qgroup) ng <<= 1;
+  const uint32_t g = x % ng, part = x / ng, nparts = 8 / ng;
+  const uint32_t q_lo = g * tq / ng, qn = (g + 1) * tq / ng - q_lo;
+  const uint32_t r_lo = (uint32_t)((uint64_t)part * tr / nparts), rn = (uint32_t)((uint64_t)(part + 1) * tr / nparts) - r_lo;
+  const uint64_t w = (uint64_t)it * nslots + slot;
+  if (qn == 0 || w >= (uint64_t)rn * qn) return false;
+  const uint32_t row = (uint32_t)(w / qn);
+  r0 = (int64_t)(r_lo + row) * 256;
+  q0 = (int64_t)(q_lo + (uint32_t)(w - (uint64_t)row * qn)) * 256;
+  return true;
+}
+
 // The same scan on generation 7 (gemm_core7.h / gemm_wide7.h): 128-byte K steps (whole-line LDS-DMA requests) in a
 // PERSISTENT kernel -- one workgroup per CU walks (query tile, row tile) pairs, the first K step of the next pair and its
 // 256 thresholds are fetched while the current pair is filtered.  The filter issues no regular stores (appends are rare
@@ -212,7 +236,9 @@ __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7(
   int it = 0;
   unsigned wcount = 0;                     // records in this wave's staging area (wave-uniform)
   int64_t r0, q0;
-  if (!g7_tile(0, ntr, ntq, group_m, r0, q0)) return;      // `group_m` row tiles stay in L2 while the query tiles sweep them
+  const int qgroup = group_m >> 8;                 // (the host packs both walk parameters into one argument)
+  group_m &= 255;
+  if (!sc7_tile(0, ntr, ntq, group_m, qgroup, r0, q0)) return;
   G7Src src;
   g7_point<T>(src, queries, d, rows, d, nq, nrows, q0, r0, wave, lane0);
   g7_dma((const char*)(thr + q0 + wm * 128), lane0 * 16, g7_lds_addr(smem + G7_TAB_OFF + wave * 1024));
@@ -251,7 +277,7 @@ __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7(
     // next pair: its first K step and its thresholds are fetched under the filter below
     ++it;
     int64_t r1 = r0, q1 = q0;
-    const bool has_next = g7_tile(it, ntr, ntq, group_m, r1, q1);
+    const bool has_next = sc7_tile(it, ntr, ntq, group_m, qgroup, r1, q1);
     G7Src nsrc;
     g7_point<T>(nsrc, queries, d, rows, d, nq, nrows, q1, r1, wave, lane0);
     g7_dma((const char*)(thr + q1 + wm * 128), lane0 * 16, g7_lds_addr(smem + G7_TAB_OFF + wave * 1024));
@@ -775,7 +801,7 @@ struct Scan {
           const int64_t tiles = (whole / 256) * ntn;
           if (tiles < ncu) ncu = (int)tiles;
           hipLaunchKernelGGL((sim_filter_kernel7<f16_t>), dim3((unsigned)ncu), dim3(G6_THREADS), G7_LDS_BYTES, s, idx16 + r0 * d, whole,
-                             (uint32_t)r0, ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8, omk_debug_trace());
+                             (uint32_t)r0, ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8 | (std::max(1, om_option(OM_OPT_SCAN_QGROUP)) << 8), omk_debug_trace());
         }
         if (n > whole)
           hipLaunchKernelGGL((sim_filter_kernel6<f16_t>), dim3((unsigned)ntn), dim3(G6_THREADS), G6_LDS_BYTES, s, idx16 + (r0 + whole) * d,
