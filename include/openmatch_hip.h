@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OM_ABI_VERSION 2
+#define OM_ABI_VERSION 3
 
 /* element types */
 #define OM_F32 0

@@ -17,7 +17,7 @@ ACT_MUL_RESID = 0x100
 ARCH_BERT, ARCH_T5 = 0, 1
 POOL_NONE, POOL_FIRST, POOL_MEAN = 0, 1, 2
 SEARCH_F32, SEARCH_F16_RESCORE = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_void_p, c_int, c_int64, c_float, c_size_t = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
