@@ -90,8 +90,12 @@ void om_debug_gemm_gen(int gen);
 #define OM_OPT_GEMM_GROUP_M 6     /* row tiles per group of the persistent GEMM's tile walk (default 8): the group's A panels stay in an
                                    * XCD's L2 while its column tiles are swept */
 #define OM_OPT_SCAN_QGROUP 7      /* query tiles (256 queries each) an XCD keeps resident in its L2 during the index scan (default 8) */
-#define OM_OPT_COUNT 8
+#define OM_OPT_FOLD_CACHE 8       /* 1: LayerNorm-folded weights are computed once per weight version and cached in library-owned
+                                   * buffers (call om_invalidate_folded_weights() after ANY change of encoder weights); 0 (default for
+                                   * raw C-ABI callers): folded per forward */
+#define OM_OPT_COUNT 9
 int om_debug_option(int opt, int value);
+void om_invalidate_folded_weights(void);   /* see OM_OPT_FOLD_CACHE */
 int om_kernel_timing_enable(int enable);
 int om_kernel_timing_read(int kernel_class, double* total_ms, int64_t* launches, double* flops);
 

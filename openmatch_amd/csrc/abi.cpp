@@ -87,6 +87,8 @@ void opt_init() {
   e = getenv("OM_SCAN_GROWTH");
   g_opt[OM_OPT_SCAN_GROWTH] = e ? atoi(e) : 60;
   g_opt[OM_OPT_WGRAD_DEBUG] = 0;
+  e = getenv("OM_FOLD_CACHE");
+  g_opt[OM_OPT_FOLD_CACHE] = e ? atoi(e) : 0;
   e = getenv("OM_SCAN_QGROUP");
   g_opt[OM_OPT_SCAN_QGROUP] = e ? atoi(e) : 8;
   e = getenv("OM_GEMM_GROUP_M");

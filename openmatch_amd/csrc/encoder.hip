@@ -18,6 +18,62 @@
 
 #include "kernels.h"
 
+// Folded LayerNorm weights (W * gamma, its row sums, the folded bias) depend on the weights alone.  With
+// OM_OPT_FOLD_CACHE on they are computed once per weight version and kept in device buffers owned by the library,
+// instead of 23 ln_fold launches per forward; om_invalidate_folded_weights() (called by the host whenever it repacks
+// a model's weights) marks every entry stale.  Off by default for raw C-ABI callers, who may update weights in place.
+#include <map>
+#include <mutex>
+#include <tuple>
+namespace {
+struct FoldEntry { void* wf = nullptr; float* colsum = nullptr; float* bf = nullptr; unsigned long long epoch = 0; hipStream_t stream = nullptr; hipEvent_t ev = nullptr; };
+typedef std::tuple<const void*, const void*, const void*, const void*, int, int, int> FoldKey;
+std::map<FoldKey, FoldEntry> g_folds;
+std::mutex g_fold_mu;
+unsigned long long g_fold_epoch = 1;
+}  // namespace
+extern "C" void om_invalidate_folded_weights(void) {
+  std::lock_guard<std::mutex> lk(g_fold_mu);
+  ++g_fold_epoch;
+  if (g_folds.size() > 160) {          // stale entries keep their buffers for re-use under the same key; bound the pool
+    for (auto& kv : g_folds) {          // (weights that keep moving to new addresses would otherwise grow it without limit)
+      if (kv.second.wf) (void)hipFree(kv.second.wf);
+      if (kv.second.colsum) (void)hipFree(kv.second.colsum);
+      if (kv.second.bf) (void)hipFree(kv.second.bf);
+      if (kv.second.ev) (void)hipEventDestroy(kv.second.ev);
+    }
+    g_folds.clear();
+  }
+}
+// Wf / colsum / bf of (W, gamma, beta, b): from the cache, or computed into the caller's scratch (cache off)
+static int folded_weights(const void* W, const float* g, const float* beta, const float* b, int N, int K, void* scratch_w,
+                          float* scratch_cs, float* scratch_bf, hipStream_t s, const void** Wf, const float** cs, const float** bf) {
+  if (!om_option(OM_OPT_FOLD_CACHE)) {
+    if (omk_ln_fold(W, g, beta, b, scratch_w, scratch_cs, scratch_bf, N, K, s)) return 1;
+    *Wf = scratch_w; *cs = scratch_cs; *bf = scratch_bf;
+    return 0;
+  }
+  int dev = 0;
+  OM_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_fold_mu);
+  FoldEntry& e = g_folds[FoldKey(W, g, beta, b, N, K, dev)];
+  if (!e.wf) {
+    OM_HIP(hipMalloc(&e.wf, (size_t)N * K * 2));
+    OM_HIP(hipMalloc((void**)&e.colsum, (size_t)N * 4));
+    OM_HIP(hipMalloc((void**)&e.bf, (size_t)N * 4));
+    OM_HIP(hipEventCreateWithFlags(&e.ev, hipEventDisableTiming));
+  }
+  if (e.epoch != g_fold_epoch) {
+    if (omk_ln_fold(W, g, beta, b, e.wf, e.colsum, e.bf, N, K, s)) return 1;
+    OM_HIP(hipEventRecord(e.ev, s));
+    e.epoch = g_fold_epoch; e.stream = s;
+  } else if (e.stream != s) {
+    OM_HIP(hipStreamWaitEvent(s, e.ev, 0));              // folded on another stream: order after it
+  }
+  *Wf = e.wf; *cs = e.colsum; *bf = e.bf;
+  return 0;
+}
+
 struct EncWs {
   char *x, *y, *x1, *qkv, *ctx, *ff, *ff2;
   float *pooled, *headout, *posbias;
@@ -153,9 +209,10 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
           RUN(omk_gemm(dt, ws.x, H, lw.qkv_w, H, dt, ws.qkv, 3 * H, Mg, 3 * H, H, e, s));
         } else {
           const OmLayerWeights& pw = Ls[l - 1];
-          RUN(omk_ln_fold(lw.qkv_w, pw.ln2_g, pw.ln2_b, lw.qkv_b, ws.wfold, ws.colsum, ws.bfold, 3 * H, H, s));
-          e.bias = ws.bfold; e.ln_stats = st2p; e.ln_colsum = ws.colsum; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
-          RUN(omk_gemm(dt, ws.x1, H, ws.wfold, H, dt, ws.qkv, 3 * H, Mg, 3 * H, H, e, s));
+          const void* wf; const float *cs, *bfp;
+          RUN(folded_weights(lw.qkv_w, pw.ln2_g, pw.ln2_b, lw.qkv_b, 3 * H, H, ws.wfold, ws.colsum, ws.bfold, s, &wf, &cs, &bfp));
+          e.bias = bfp; e.ln_stats = st2p; e.ln_colsum = cs; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+          RUN(omk_gemm(dt, ws.x1, H, wf, H, dt, ws.qkv, 3 * H, Mg, 3 * H, H, e, s));
         }
         RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, nullptr, B, (int)L, H, nh, scale, 0.f, 0, s));
         // ---- attention output + residual -> y1, statistics of LN1
@@ -169,10 +226,11 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
         }
         RUN(omk_gemm(dt, ws.ctx, H, lw.o_w, H, dt, ws.y, H, Mg, H, H, e, s));
         // ---- FFN1 on LN1(y1), folded
-        RUN(omk_ln_fold(lw.ffn1_w, lw.ln1_g, lw.ln1_b, lw.ffn1_b, ws.wfold, ws.colsum, ws.bfold, F, H, s));
+        const void* wf1; const float *cs1, *bf1;
+        RUN(folded_weights(lw.ffn1_w, lw.ln1_g, lw.ln1_b, lw.ffn1_b, F, H, ws.wfold, ws.colsum, ws.bfold, s, &wf1, &cs1, &bf1));
         e = GemmEpilogue{};
-        e.bias = ws.bfold; e.act = c->act; e.ln_stats = st1; e.ln_colsum = ws.colsum; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
-        RUN(omk_gemm(dt, ws.y, H, ws.wfold, H, dt, ws.ff, F, Mg, F, H, e, s));
+        e.bias = bf1; e.act = c->act; e.ln_stats = st1; e.ln_colsum = cs1; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+        RUN(omk_gemm(dt, ws.y, H, wf1, H, dt, ws.ff, F, Mg, F, H, e, s));
         // ---- FFN2 + LN1(y1) as the residual -> y2, statistics of LN2
         e = GemmEpilogue{};
         e.bias = lw.ffn2_b; e.resid = ws.y; e.ldr = H; e.rln_stats = st1; e.rln_g = lw.ln1_g; e.rln_b = lw.ln1_b;
@@ -223,11 +281,13 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
       OM_HIP(hipMemsetAsync(ws.stats1, 0, (size_t)2 * c->n_layers * Mg * 8, s));
       auto folded = [&](const void* A_, const void* W_, const float* g_, const float* stats_, void* C_, int N_, int act_,
                         const void* res_, int64_t ldr_) -> int {
-        if (omk_ln_fold(W_, g_, nullptr, nullptr, ws.wfold, ws.colsum, ws.bfold, N_, H, s)) return 1;
+        const void* wf; const float *cs, *bfp;
+        if (folded_weights(W_, g_, nullptr, nullptr, N_, H, ws.wfold, ws.colsum, ws.bfold, s, &wf, &cs, &bfp)) return 1;
+        (void)cs; (void)bfp;            // RMSNorm: no mean, no shift -- only the folded weight is used
         GemmEpilogue e = {};
         e.act = act_; e.resid = res_; e.ldr = ldr_;
         e.ln_stats = stats_; e.ln_rms = 1; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
-        return omk_gemm(dt, A_, H, ws.wfold, H, dt, C_, N_, Mg, N_, H, e, s);
+        return omk_gemm(dt, A_, H, wf, H, dt, C_, N_, Mg, N_, H, e, s);
       };
       for (int l = 0; l < c->n_layers; ++l) {
         const OmLayerWeights& lw = Ls[l];

@@ -206,6 +206,7 @@ def packed_weights(model, head, code, device):
     if hit is not None and hit[0] == ver:
         return hit[1]
     pk = _pack_bert(model, code, device) if _arch_of(model) == "bert" else _pack_t5(model, code, device)
+    N.lib().om_invalidate_folded_weights()      # new device copies (possibly at recycled addresses): drop cached folds
     if head is not None:
         lin = head.linear
         pk.weights.head_w = pk.dev(lin.weight, torch.float32, device)
