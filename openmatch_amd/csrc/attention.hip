@@ -156,9 +156,10 @@ __global__ __launch_bounds__(64 * KT) void attention_kernel(
 // r01_bench_v8_kernel_stats.csv: 244 us per layer against a 146 us HBM floor): staging through VGPRs, V transposed
 // with 256 two-byte LDS stores per lane, the context transposed back through LDS.  Here
 //   * K and V go to LDS row-major by LDS-DMA (4 + 4 instructions per wave, swizzle on the source address);
-//   * V^T fragments are made by the matrix core: D = V_tile . I (two MFMAs per 32 x 32 block) leaves, in the
-//     accumulator layout, every lane with one d column and its 16 keys in registers -- exactly the k-slot order the
-//     probabilities have, so cvt_pk gives the A operand of  O^T = V^T P^T  directly (bf16 * 1.0 is exact);
+//   * V^T fragments come from transposing LDS reads (ds_read_b64_tr_b16) of the row-major V image: two reads hand a
+//     lane its d column's eight keys in exactly the k-slot order the probabilities' registers have, so they are the
+//     A operand of  O^T = V^T P^T  as read (the first version transposed V on the matrix core: D = V_tile . I, two
+//     MFMAs + eight cvt_pk per fragment pair -- a third of the kernel's MFMAs and ~15 % of its instructions);
 //   * O^T puts a query row in each lane: one v_permlane32_swap per dword pair makes 16 contiguous bytes, stored
 //     straight to global memory (no LDS round trip, no second barrier);
 //   * softmax in the log2 domain: v = fma(s, scale log2e, mask), exp2(v - max) -- five instructions per score.
@@ -171,6 +172,12 @@ __device__ __forceinline__ uint32_t pack_bf16x2_(float lo, float hi) {      // o
   const f32x2_a_t v = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw_a_t));
 }
+
+typedef short v4s_a_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4s_a_t vtrd(const char* p) {           // ds_read_b64_tr_b16
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_a_t __attribute__((address_space(3)))*)(p));
+}
+__device__ __forceinline__ bf16x8_t vfrag_of(v4s_a_t a, v4s_a_t b) { return (bf16x8_t){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 
 template <int KT, bool BIAS, bool DROP>
 __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) void attention_fwd16_kernel(
@@ -189,16 +196,18 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
   const char* const base = (const char*)(qkv + b * L * 3 * (int64_t)H + h * 64);
 
   // K and V rows of this (batch, head): instruction i of wave w moves rows (i * KT + w) * 8 .. + 7, lane -> row
-  // (lane >> 3), physical 16-byte chunk (lane & 7) <- source chunk (lane & 7) ^ ((row >> 1) & 7).  Rows past L repeat
-  // row L - 1 (their scores are masked to -inf).
+  // (lane >> 3), physical 16-byte chunk (lane & 7) <- source chunk (lane & 7) ^ ((row >> 1) & 7) for K (row-per-lane
+  // 16-byte reads), ^ 4 ((row >> 1) & 1) for V: the four rows of a transposing read then sit in the four 64-byte
+  // quarters of the bank cycle.  Rows past L repeat row L - 1 (their scores are masked to -inf).
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = (i * KT + wave) * 8 + (lane >> 3);
     const int rr = r < L ? r : L - 1;
     const uint32_t off = (uint32_t)(rr * ld2) + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+    const uint32_t offv = (uint32_t)(rr * ld2) + (((lane & 7) ^ (((r >> 1) & 1) << 2)) << 4);
     const uint32_t dst = (uint32_t)((i * KT + wave) * 1024);
     g7_dma(base + 2 * H, off, g7_lds_addr(sK) + dst);
-    g7_dma(base + 4 * H, off, g7_lds_addr(sV) + dst);
+    g7_dma(base + 4 * H, offv, g7_lds_addr(sV) + dst);
   }
   const float LOG2E = 1.4426950408889634f;
   for (int k = tid; k < KT * 32; k += 64 * KT)
@@ -277,14 +286,12 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
     inv *= dr.keep_scale;
   }
 
-  // identity fragments of the transposing MFMAs: lane j holds 1.0 at k == j of the 32-wide d block
-  frag_t idf[2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    const bool mine = (l31 >> 4) == kk && ((l31 >> 3) & 1) == half;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) idf[kk][e] = (mine && (l31 & 7) == e) ? (short)0x3F80 : (short)0;
-  }
+  // V^T fragments by transposing LDS reads: lane (i = lane & 15, gg = lane bit 4, half) names 8-byte chunk i of the
+  // [4 keys][16 d] block (keys 4 half .. + 3 of a 16-key step, d block 16 gg) and receives its d column's four keys --
+  // two reads are the eight k slots of a fragment in the order the probabilities' registers have.
+  const int i16 = lane & 15;
+  const char* const vt0 = sV + (4 * half + (i16 >> 2)) * 128 + 32 * ((lane >> 4) & 1) + 8 * (i16 & 3);
+  const int vsw = (i16 >> 3) & 1;               // the row's swizzle bit: (row >> 1) & 1 with row = 8 n + 4 half + (i16 >> 2)
   f32x16_t o[2];
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -297,25 +304,16 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
     for (int u = 0; u < 2; ++u)
       pa[u] = make_uint4(pack_bf16x2_(s[t][8 * u + 0], s[t][8 * u + 1]), pack_bf16x2_(s[t][8 * u + 2], s[t][8 * u + 3]),
                          pack_bf16x2_(s[t][8 * u + 4], s[t][8 * u + 5]), pack_bf16x2_(s[t][8 * u + 6], s[t][8 * u + 7]));
-    const char* vrow = sV + (t * 32 + l31) * 128;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      f32x16_t vt;
+    for (int u = 0; u < 2; ++u) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) vt[r] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const frag_t a = *(const frag_t*)(vrow + (((dt * 4 + kk * 2 + half) ^ key) << 4));
-        vt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, idf[kk], vt, 0, 0, 0);       // vt[key][d]: lane = d, registers = keys
+      for (int dt = 0; dt < 2; ++dt) {
+        const char* p = vt0 + (t * 32 + 16 * u) * 128 + ((dt ^ vsw) << 6);
+        const frag_t vf = vfrag_of(vtrd(p), vtrd(p + 8 * 128));
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(frag_t, pa[u]), o[dt], 0, 0, 0);
       }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const uint4 vb = make_uint4(pack_bf16x2_(vt[8 * u + 0], vt[8 * u + 1]), pack_bf16x2_(vt[8 * u + 2], vt[8 * u + 3]),
-                                    pack_bf16x2_(vt[8 * u + 4], vt[8 * u + 5]), pack_bf16x2_(vt[8 * u + 6], vt[8 * u + 7]));
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(frag_t, vb), __builtin_bit_cast(frag_t, pa[u]), o[dt], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);      // one 32 x 32 block at a time: hoisting every V read costs 64 registers (occupancy)
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
   // o[dt][r] = O[query l31][d = 32 dt + (r&3) + 8(r>>2) + 4 half]: scale by 1/sum, pack, pair up the two halves
   if (q0 + l31 < L) {

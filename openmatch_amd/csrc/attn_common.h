@@ -63,26 +63,11 @@ template <> struct SlabMma<float> {
 // accumulator group in the lane-per-query orientation of the forward and of the backward's first phase, so those
 // kernels pay ~10 instead of ~35 integer instructions per probability (the three 64-bit multiplies of the hash were the
 // largest single cost of the attention backward).  p is resolved to 2^-16; keep_scale uses the same rounded value.
-__host__ __device__ inline uint64_t om_hash64(uint64_t seed, uint64_t idx) {
-  uint64_t x = idx * 0x9E3779B97F4A7C15ull + seed;
-  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32;
-  return x;
-}
-struct AttnDrop {
-  uint32_t thresh;        // 0: no dropout
-  float keep_scale;
-  __host__ __device__ explicit AttnDrop(float p) {
-    thresh = p > 0.f ? (uint32_t)(p * 65536.0f + 0.5f) : 0u;
-    if (thresh > 65535u) thresh = 65535u;
-    keep_scale = 65536.0f / (float)(65536u - thresh);
-  }
-};
+using AttnDrop = DropCfg;   // kernels.h: 16-bit fields of one 64-bit hash per four elements
 __device__ inline uint64_t attn_drop_bits(uint64_t seed, int64_t b, int h, int heads, int L, int q, int kg) {
   return om_hash64(seed, (((uint64_t)b * heads + h) * (uint64_t)L + q) * (uint64_t)((L + 3) >> 2) + kg);
 }
-__device__ inline bool attn_drop_keep(uint64_t bits, int e, uint32_t thresh) { return ((uint32_t)(bits >> (16 * e)) & 0xffffu) >= thresh; }
+__device__ inline bool attn_drop_keep(uint64_t bits, int e, uint32_t thresh) { return dropout_field(bits, e, thresh); }
 // one probability (the lane-per-key orientation): the group's hash, this element's field
 __device__ inline bool attn_drop_keep1(uint64_t seed, int64_t b, int h, int heads, int L, int q, int key, uint32_t thresh) {
   return attn_drop_keep(attn_drop_bits(seed, b, h, heads, L, q, key >> 2), key & 3, thresh);

@@ -130,8 +130,8 @@ template <> struct OutVec<bf16_t> {
 struct EpiScalars {
   uint32_t drop_thresh; float drop_scale; bool train, mul; int act;
   __device__ __forceinline__ explicit EpiScalars(const GemmEpilogue& ep) {
-    drop_thresh = ep.drop_p > 0.f ? (uint32_t)(ep.drop_p * 4294967296.0) : 0u;
-    drop_scale = ep.drop_p > 0.f ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
+    const DropCfg dc(ep.drop_p);
+    drop_thresh = dc.thresh; drop_scale = dc.keep_scale;
     train = ep.pre_act != nullptr || ep.drop_p > 0.f;
     mul = (ep.act & OM_ACT_MUL_RESID) != 0;
     act = ep.act & 0xff;

@@ -39,9 +39,10 @@ __device__ __forceinline__ f32x2_t gelu_erf_poly2(f32x2_t x) {
 }
 
 // two adjacent output elements (columns n, n+1 of row m) before the residual
+// dbits: the dropout hash of the four-column group holding (m, n) (dropout_bits; N % 4 == 0), e0 = n & 3 (0 or 2)
 template <int ACT, bool TRAIN, typename OutT>
 __device__ __forceinline__ f32x2_t epi_pair(f32x2_t v, int64_t m, int64_t n, int64_t M, int64_t N,
-                                           const GemmEpilogue& ep, const EpiScalars& es) {
+                                           const GemmEpilogue& ep, const EpiScalars& es, uint64_t dbits, int e0) {
   if (ACT == OM_ACT_GELU_ERF && sizeof(OutT) == 2) {
     if (TRAIN) {
       if (ep.pre_act && m < M && n < N)
@@ -50,14 +51,21 @@ __device__ __forceinline__ f32x2_t epi_pair(f32x2_t v, int64_t m, int64_t n, int
     v = gelu_erf_poly2(v);
     if (TRAIN) {
       if (es.drop_thresh) {
-        v[0] = dropout_keep(ep.seed, (uint64_t)m * (uint64_t)N + (uint64_t)n, es.drop_thresh) ? v[0] * es.drop_scale : 0.f;
-        v[1] = dropout_keep(ep.seed, (uint64_t)m * (uint64_t)N + (uint64_t)n + 1, es.drop_thresh) ? v[1] * es.drop_scale : 0.f;
+        v[0] = dropout_field(dbits, e0, es.drop_thresh) ? v[0] * es.drop_scale : 0.f;
+        v[1] = dropout_field(dbits, e0 + 1, es.drop_thresh) ? v[1] * es.drop_scale : 0.f;
       }
     }
     return v;
   }
-  return (f32x2_t){epi_value<ACT, TRAIN, OutT>(v[0], m, n, M, N, ep, es.drop_thresh, es.drop_scale),
-                   epi_value<ACT, TRAIN, OutT>(v[1], m, n + 1, M, N, ep, es.drop_thresh, es.drop_scale)};
+  f32x2_t o = {epi_value<ACT, TRAIN, OutT>(v[0], m, n, M, N, ep, 0u, 1.f),
+               epi_value<ACT, TRAIN, OutT>(v[1], m, n + 1, M, N, ep, 0u, 1.f)};
+  if (TRAIN && ACT != OM_ACT_GELU_ERF_GRAD) {
+    if (es.drop_thresh) {
+      o[0] = dropout_field(dbits, e0, es.drop_thresh) ? o[0] * es.drop_scale : 0.f;
+      o[1] = dropout_field(dbits, e0 + 1, es.drop_thresh) ? o[1] * es.drop_scale : 0.f;
+    }
+  }
+  return o;
 }
 
 #define G6E_STRIDE16 264      // bf16 staging row: 128 columns x 2 B + 8 (ds_write_b64 / ds_read_b64 conflict-free)
@@ -140,8 +148,10 @@ __device__ __forceinline__ void store_wave_tile6(f32x16_t (&acc)[4][4], int64_t 
         const int64_t n = ncol0 + ni * 32 + 8 * j + 4 * half;                                              \
         f32x2_t a_lo = {acc[MI][ni][4 * j], acc[MI][ni][4 * j + 1]}, a_hi = {acc[MI][ni][4 * j + 2], acc[MI][ni][4 * j + 3]};  \
         if (ln_in) { a_lo *= rs[MI]; a_hi *= rs[MI]; }                                                     \
-        const f32x2_t lo = epi_pair<ACT, TRAIN, OutT>(a_lo, m, n, M, N, ep, es);                           \
-        const f32x2_t hi = epi_pair<ACT, TRAIN, OutT>(a_hi, m, n + 2, M, N, ep, es);                       \
+        uint64_t dbits = 0;            /* n % 4 == 0, N % 8 == 0: one hash for the four columns */        \
+        if (TRAIN) { if (es.drop_thresh) dbits = dropout_bits(ep.seed, ((uint64_t)m * (uint64_t)N + (uint64_t)n) >> 2); } \
+        const f32x2_t lo = epi_pair<ACT, TRAIN, OutT>(a_lo, m, n, M, N, ep, es, dbits, 0);                 \
+        const f32x2_t hi = epi_pair<ACT, TRAIN, OutT>(a_hi, m, n + 2, M, N, ep, es, dbits, 2);             \
         f32x2_t lo_ = lo, hi_ = hi;                                                                        \
         if (RES_DMA) {                                                                                     \
           const uint2 rr = rpatch[ni][j];                                                                  \

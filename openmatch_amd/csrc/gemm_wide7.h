@@ -258,8 +258,8 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
         const int64_t n = nc + ni * 32 + 8 * j + 4 * half;                                                     \
         f32x2_t a_lo = {acc[MI][ni][4 * j], acc[MI][ni][4 * j + 1]}, a_hi = {acc[MI][ni][4 * j + 2], acc[MI][ni][4 * j + 3]}; \
         if (LNF == 1) { a_lo *= rs[MI]; a_hi *= rs[MI]; }                                                      \
-        f32x2_t lo_ = epi_pair<ACT, false, OutT>(a_lo, m, n, M, N, ep, es);                                    \
-        f32x2_t hi_ = epi_pair<ACT, false, OutT>(a_hi, m, n + 2, M, N, ep, es);                                \
+        f32x2_t lo_ = epi_pair<ACT, false, OutT>(a_lo, m, n, M, N, ep, es, 0, 0);                                    \
+        f32x2_t hi_ = epi_pair<ACT, false, OutT>(a_hi, m, n + 2, M, N, ep, es, 0, 0);                                \
         if (RESID) {                                                                                           \
           const uint2 rr = rpatch[nl][j];                                                                      \
           float r0 = bf16_to_f32((bf16_t)(rr.x & 0xffff)), r1 = bf16_to_f32((bf16_t)(rr.x >> 16));            \

@@ -71,15 +71,31 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
 int omk_gemm_splitk(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C,
                     int64_t ldc, int64_t M, int64_t N, int64_t K, hipStream_t s);
 
-// Stateless counter-based dropout: element `idx` of stream `seed` is kept iff hash >= p * 2^32.
-// Forward and backward regenerate the same mask from (seed, idx); nothing is stored.
-__host__ __device__ inline uint32_t om_hash32(uint64_t seed, uint64_t idx) {
+// Stateless counter-based dropout.  Forward and backward regenerate the same mask from (seed, idx); nothing is stored.
+// One 64-bit hash serves FOUR consecutive elements (idx >> 2 names the group): bits 16 e .. 16 e + 15 decide element
+// idx & 3 == e, kept iff the field >= p * 2^16.  The three 64-bit multiplies of the hash cost ~30 integer instructions;
+// a lane that holds four consecutive elements (every vectorised kernel here) pays them once, not four times.  p is
+// resolved to 2^-16 and the keep scale uses the same rounded value, so E[mask * scale] is exactly 1.
+__host__ __device__ inline uint64_t om_hash64(uint64_t seed, uint64_t idx) {
   uint64_t x = idx * 0x9E3779B97F4A7C15ull + seed;
   x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
   x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
   x ^= x >> 32;
-  return (uint32_t)x;
+  return x;
+}
+struct DropCfg {
+  uint32_t thresh;        // 0: no dropout
+  float keep_scale;
+  __host__ __device__ explicit DropCfg(float p) {
+    thresh = p > 0.f ? (uint32_t)(p * 65536.0f + 0.5f) : 0u;
+    if (thresh > 65535u) thresh = 65535u;
+    keep_scale = 65536.0f / (float)(65536u - thresh);
+  }
+};
+__host__ __device__ inline uint64_t dropout_bits(uint64_t seed, uint64_t group) { return om_hash64(seed, group); }
+__host__ __device__ inline bool dropout_field(uint64_t bits, int e, uint32_t thresh) {
+  return ((uint32_t)(bits >> (16 * e)) & 0xffffu) >= thresh;
 }
 __host__ __device__ inline bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
-  return om_hash32(seed, idx) >= thresh;
+  return dropout_field(dropout_bits(seed, idx >> 2), (int)(idx & 3), thresh);
 }

@@ -126,8 +126,9 @@ int omk_colsum(int dtype, const void* x, int64_t ld, int64_t M, int N, float* ou
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p,
                                uint64_t seed) {
-  const uint32_t thresh = (uint32_t)(p * 4294967296.0);
-  const float scale = 1.0f / (1.0f - p);
+  const DropCfg dc(p);
+  const uint32_t thresh = dc.thresh;
+  const float scale = dc.keep_scale;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     ElemOps<T>::store(y + i, dropout_keep(seed, (uint64_t)i, thresh) ? ElemOps<T>::load(x + i) * scale : 0.f);
 }
@@ -271,8 +272,9 @@ __global__ __launch_bounds__((NV == 8 || MODE == 1) ? 256 : 512) void ln_bwd_ker
         }
       }
     m1 = rms ? 0.f : wave_sum(m1) / (float)H; m2 = wave_sum(m2) / (float)H;
-    const uint32_t drop_thresh = (MODE == 0 && dx_drop) ? (uint32_t)(drop_p * 4294967296.0) : 0u;
-    const float drop_scale = 1.0f / (1.0f - drop_p);
+    const DropCfg dc((MODE == 0 && dx_drop) ? drop_p : 0.f);
+    const uint32_t drop_thresh = dc.thresh;
+    const float drop_scale = dc.keep_scale;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int c = (lane + 64 * j) * 4;
@@ -290,10 +292,11 @@ __global__ __launch_bounds__((NV == 8 || MODE == 1) ? 256 : 512) void ln_bwd_ker
           store4<T>(dx + row * H + c, out);
           if (dx_drop) {               // dropout of the value as stored (rounded to T), like the separate pass it replaces
             float dr[4];
+            const uint64_t bits = dropout_bits(drop_seed, (uint64_t)(row * H + c) >> 2);   // H % 4 == 0: one group
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float vb = sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(out[e])) : out[e];
-              dr[e] = dropout_keep(drop_seed, (uint64_t)(row * H + c + e), drop_thresh) ? vb * drop_scale : 0.f;
+              dr[e] = dropout_field(bits, e, drop_thresh) ? vb * drop_scale : 0.f;
             }
             store4<T>(dx_drop + row * H + c, dr);
           }
