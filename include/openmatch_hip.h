@@ -93,8 +93,14 @@ void om_debug_gemm_gen(int gen);
 #define OM_OPT_FOLD_CACHE 8       /* 1: LayerNorm-folded weights are computed once per weight version and cached in library-owned
                                    * buffers (call om_invalidate_folded_weights() after ANY change of encoder weights); 0 (default for
                                    * raw C-ABI callers): folded per forward */
-#define OM_OPT_COUNT 9
+#define OM_OPT_ATTENTION_DEBUG 9  /* 0 (default); timing experiments on the bf16 attention kernel at L in (64, 128]: bit 0 no K / V fetch,
+                                   * bit 1 no arithmetic, bit 2 no stores (results are garbage) */
+#define OM_OPT_ENCODER_PINGPONG 10 /* 1 (default): the fused bf16 encoder's kernels alternate their walk direction over the token rows so
+                                   * each starts on the rows its producer wrote last (memory-side cache hits); 0: always first to last */
+#define OM_OPT_COUNT 11
 int om_debug_option(int opt, int value);
+/* the attention kernel alone (bf16 qkv [B*L, 3H] -> ctx [B*L, H]; mask [B, L] int64), for timing: csrc/kernels.h omk_attention */
+int om_debug_attention(const void* qkv, void* ctx, const int64_t* mask, int64_t B, int L, int H, int heads, void* stream);
 void om_invalidate_folded_weights(void);   /* see OM_OPT_FOLD_CACHE */
 int om_kernel_timing_enable(int enable);
 int om_kernel_timing_read(int kernel_class, double* total_ms, int64_t* launches, double* flops);

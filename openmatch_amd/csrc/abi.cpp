@@ -87,6 +87,9 @@ void opt_init() {
   e = getenv("OM_SCAN_GROWTH");
   g_opt[OM_OPT_SCAN_GROWTH] = e ? atoi(e) : 60;
   g_opt[OM_OPT_WGRAD_DEBUG] = 0;
+  g_opt[OM_OPT_ATTENTION_DEBUG] = 0;
+  e = getenv("OM_ENCODER_PINGPONG");
+  g_opt[OM_OPT_ENCODER_PINGPONG] = e ? atoi(e) : 1;
   e = getenv("OM_FOLD_CACHE");
   g_opt[OM_OPT_FOLD_CACHE] = e ? atoi(e) : 0;
   e = getenv("OM_SCAN_QGROUP");

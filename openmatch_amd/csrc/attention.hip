@@ -160,8 +160,8 @@ __global__ __launch_bounds__(64 * KT) void attention_kernel(
 //     lane its d column's eight keys in exactly the k-slot order the probabilities' registers have, so they are the
 //     A operand of  O^T = V^T P^T  as read (the first version transposed V on the matrix core: D = V_tile . I, two
 //     MFMAs + eight cvt_pk per fragment pair -- a third of the kernel's MFMAs and ~15 % of its instructions);
-//   * O^T puts a query row in each lane: one v_permlane32_swap per dword pair makes 16 contiguous bytes, stored
-//     straight to global memory (no LDS round trip, no second barrier);
+//   * O^T puts a query row in each lane: one v_permlane32_swap per dword pair makes 16 contiguous bytes, parked in the
+//     wave's own K rows and written out as whole 128-byte lines;
 //   * softmax in the log2 domain: v = fma(s, scale log2e, mask), exp2(v - max) -- five instructions per score.
 // Masked keys carry -1e30 (finite: a fully masked row stays uniform, as with HF's finfo.min), keys past L -inf.
 #include "gemm_core7.h"
@@ -179,17 +179,20 @@ __device__ __forceinline__ v4s_a_t vtrd(const char* p) {           // ds_read_b6
 }
 __device__ __forceinline__ bf16x8_t vfrag_of(v4s_a_t a, v4s_a_t b) { return (bf16x8_t){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 
-template <int KT, bool BIAS, bool DROP>
+// DBG (timing experiments, OM_OPT_ATTENTION_DEBUG): bit 0 no K / V fetch, bit 1 no arithmetic, bit 2 no stores
+template <int KT, bool BIAS, bool DROP, int DBG = 0>
 __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) void attention_fwd16_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, const int64_t* __restrict__ mask,
-    const float* __restrict__ pos_bias, int L, int H, int heads, float scale, float drop_p, uint64_t seed) {
+    const float* __restrict__ pos_bias, int L, int H, int heads, float scale, float drop_p, uint64_t seed, int rev) {
   typedef bf16x8_t frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sK = smem;
   char* const sV = smem + KT * 32 * 128;
   float* const sM = (float*)(smem + 2 * KT * 32 * 128);
   const int h = blockIdx.x % heads;
-  const int64_t b = blockIdx.x / heads;
+  // rev: batch rows last to first (workgroups start in blockIdx order) -- the rows the QKV projection wrote last are
+  // still in the memory-side cache, and the output projection then starts on the context rows written last
+  const int64_t b = rev ? (int64_t)(gridDim.x / heads) - 1 - blockIdx.x / heads : blockIdx.x / heads;
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t ld2 = 6 * (int64_t)H;                       // row pitch of qkv in bytes
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
   // (lane >> 3), physical 16-byte chunk (lane & 7) <- source chunk (lane & 7) ^ ((row >> 1) & 7) for K (row-per-lane
   // 16-byte reads), ^ 4 ((row >> 1) & 1) for V: the four rows of a transposing read then sit in the four 64-byte
   // quarters of the bank cycle.  Rows past L repeat row L - 1 (their scores are masked to -inf).
+  if (!(DBG & 1))
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = (i * KT + wave) * 8 + (lane >> 3);
@@ -222,11 +226,12 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
   __syncthreads();
   if (q0 >= L) return;
 
+  constexpr int KTC = (DBG & 2) ? 0 : KT;          // key tiles the arithmetic walks
   // S^T = K Q^T : lane owns query l31, keys (r&3) + 8(r>>2) + 4 half of each 32-key tile
   const int key = (l31 >> 1) & 7;
   f32x16_t s[KT];
 #pragma unroll
-  for (int t = 0; t < KT; ++t) {
+  for (int t = 0; t < KTC; ++t) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
     const char* krow = sK + (t * 32 + l31) * 128;
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
   const float c2 = scale * LOG2E;
   float mx = -INFINITY;
 #pragma unroll
-  for (int t = 0; t < KT; ++t)
+  for (int t = 0; t < KTC; ++t)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int k0 = t * 32 + 8 * g + 4 * half;
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float sum = 0.f;
 #pragma unroll
-  for (int t = 0; t < KT; ++t)
+  for (int t = 0; t < KTC; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float e = __builtin_amdgcn_exp2f(s[t][r] - mx);
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
                     // regenerated by the backward from (seed, b, h, q, key group) -- attn_common.h
     const AttnDrop dr(drop_p);
 #pragma unroll
-    for (int t = 0; t < KT; ++t)
+    for (int t = 0; t < KTC; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const uint64_t bits = attn_drop_bits(seed, b, h, heads, L, q0 + l31, (t * 32 + 8 * g + 4 * half) >> 2);
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
 #pragma unroll
-  for (int t = 0; t < KT; ++t) {
+  for (int t = 0; t < KTC; ++t) {
     uint4 pa[2];      // probabilities of this key tile as two k slabs (k slot e of half h <-> register 8u + e)
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -315,47 +320,74 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  // o[dt][r] = O[query l31][d = 32 dt + (r&3) + 8(r>>2) + 4 half]: scale by 1/sum, pack, pair up the two halves
-  if (q0 + l31 < L) {
-    char* const out = (char*)(ctx + (b * L + q0 + l31) * (int64_t)H + h * 64);
+  if (DBG & 2) {                                    // keep the Q loads alive
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int kk = 0; kk < 4; ++kk) o[0][kk] = (float)qf[kk][0];
+  }
+  // o[dt][r] = O[query l31][d = 32 dt + (r&3) + 8(r>>2) + 4 half]: scale by 1/sum, pack to bf16 -- 16 bytes per
+  // (dt, register group of 8) after pairing the two halves' dwords.  Stored straight from this layout an instruction
+  // writes 32 bytes to each of 32 rows: the PMC pass counted 2x the context bytes leaving L2 (partial lines,
+  // profiles/r02_hbm_traffic.json).  So the block goes through the wave's own K rows (all waves are past K and V after
+  // the barrier; waves without queries have exited and do not count) and leaves as whole 128-byte rows, 8 per
+  // instruction.  16-byte chunk c of row r sits at chunk c ^ (r & 7): writes and reads are both conflict-free.
+  __syncthreads();
+  char* const so = sK + q0 * 128;
 #pragma unroll
-      for (int gp = 0; gp < 2; ++gp) {
-        uint32_t a0 = pack_bf16x2_(o[dt][8 * gp + 0] * inv, o[dt][8 * gp + 1] * inv), a1 = pack_bf16x2_(o[dt][8 * gp + 2] * inv, o[dt][8 * gp + 3] * inv);
-        uint32_t b0 = pack_bf16x2_(o[dt][8 * gp + 4] * inv, o[dt][8 * gp + 5] * inv), b1 = pack_bf16x2_(o[dt][8 * gp + 6] * inv, o[dt][8 * gp + 7] * inv);
-        // (a: d group 2gp, b: d group 2gp + 1) -- lanes 32-63 of a swap with lanes 0-31 of b
-        auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-        auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-        // lanes 0-31: d = 32 dt + 16 gp + 0..7 ; lanes 32-63: d = 32 dt + 16 gp + 8..15
-        *(uint4*)(out + (32 * dt + 16 * gp + 8 * half) * 2) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-      }
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      uint32_t a0 = pack_bf16x2_(o[dt][8 * gp + 0] * inv, o[dt][8 * gp + 1] * inv), a1 = pack_bf16x2_(o[dt][8 * gp + 2] * inv, o[dt][8 * gp + 3] * inv);
+      uint32_t b0 = pack_bf16x2_(o[dt][8 * gp + 4] * inv, o[dt][8 * gp + 5] * inv), b1 = pack_bf16x2_(o[dt][8 * gp + 6] * inv, o[dt][8 * gp + 7] * inv);
+      // (a: d group 2gp, b: d group 2gp + 1) -- lanes 32-63 of a swap with lanes 0-31 of b
+      auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+      auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+      // lanes 0-31: d = 32 dt + 16 gp + 0..7 ; lanes 32-63: d = 32 dt + 16 gp + 8..15   (chunk 4 dt + 2 gp + half)
+      *(uint4*)(so + l31 * 128 + (((4 * dt + 2 * gp + half) ^ (l31 & 7)) << 4)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    }
+  char* const out = (char*)(ctx + (b * L + q0) * (int64_t)H + h * 64);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + (lane >> 3), c = lane & 7;
+    const uint4 v = *(const uint4*)(so + row * 128 + ((c ^ (row & 7)) << 4));
+    if (!(DBG & 4) || v.x == 0x12345u) { if (q0 + row < L) *(uint4*)(out + (int64_t)row * H * 2 + c * 16) = v; }
   }
 }
 
 template <int KT, bool BIAS, bool DROP>
 static int launch_attn16_(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias, int64_t B, int L, int H,
-                         int heads, float scale, float drop_p, uint64_t seed, hipStream_t s) {
+                         int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, int rev) {
   const int lds = 2 * KT * 32 * 128 + KT * 32 * 4;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     OM_HIP(hipFuncSetAttribute((const void*)attention_fwd16_kernel<KT, BIAS, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
+  const int dbg = (KT == 4 && !BIAS && !DROP) ? om_option(OM_OPT_ATTENTION_DEBUG) : 0;
+  if (dbg) {
+#define OM_ATTN_DBG(D)                                                                                                        \
+  case D:                                                                                                                     \
+    hipLaunchKernelGGL((attention_fwd16_kernel<4, false, false, D>), dim3((unsigned)(heads * B)), dim3(256), lds, s,          \
+                       (const bf16_t*)qkv, (bf16_t*)ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed, rev);               \
+    break;
+    switch (dbg) { OM_ATTN_DBG(1) OM_ATTN_DBG(2) OM_ATTN_DBG(3) OM_ATTN_DBG(4) OM_ATTN_DBG(5) OM_ATTN_DBG(6) OM_ATTN_DBG(7) default: break; }
+#undef OM_ATTN_DBG
+    OM_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL((attention_fwd16_kernel<KT, BIAS, DROP>), dim3((unsigned)(heads * B)), dim3(64 * KT), lds, s, (const bf16_t*)qkv,
-                     (bf16_t*)ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed);
+                     (bf16_t*)ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed, rev);
   OM_LAUNCH_CHECK();
   return 0;
 }
 template <int KT>
 static int launch_attn16(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias, int64_t B, int L, int H,
-                         int heads, float scale, float drop_p, uint64_t seed, hipStream_t s) {
+                         int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, int rev) {
   if (drop_p > 0.f) {
-    if (pos_bias) return launch_attn16_<KT, true, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
-    return launch_attn16_<KT, false, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
+    if (pos_bias) return launch_attn16_<KT, true, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, rev);
+    return launch_attn16_<KT, false, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, rev);
   }
-  if (pos_bias) return launch_attn16_<KT, true, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s);
-  return launch_attn16_<KT, false, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s);
+  if (pos_bias) return launch_attn16_<KT, true, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev);
+  return launch_attn16_<KT, false, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -552,7 +584,7 @@ static int dispatch_attn(const void* qkv, void* ctx, const int64_t* mask, const 
 
 int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
                   const float* pos_bias, int64_t B, int L, int H, int heads, float scale,
-                  float drop_p, uint64_t seed, hipStream_t s) {
+                  float drop_p, uint64_t seed, hipStream_t s, int reverse) {
   if (B <= 0) return 0;
   if (L < 1 || L > 1024) OM_FAIL("sequence length must be in [1,1024]");
   if (L > 256 && drop_p > 0.f) OM_FAIL("training supports sequence lengths up to 256");
@@ -563,12 +595,17 @@ int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
     return launch_attn_long<float>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
   }
   if (dtype == OM_BF16 && om_option(OM_OPT_ATTENTION_FAST)) {        // the low-instruction-count kernel (inference, and training with dropout)
-    if (L <= 32) return launch_attn16<1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
-    if (L <= 64) return launch_attn16<2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
-    if (L <= 128) return launch_attn16<4>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
-    if (L <= 192) return launch_attn16<6>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
-    return launch_attn16<8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
+    if (L <= 32) return launch_attn16<1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
+    if (L <= 64) return launch_attn16<2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
+    if (L <= 128) return launch_attn16<4>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
+    if (L <= 192) return launch_attn16<6>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
+    return launch_attn16<8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
   }
   if (dtype == OM_BF16) return dispatch_attn<bf16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
   return dispatch_attn<float>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
+}
+
+extern "C" int om_debug_attention(const void* qkv, void* ctx, const int64_t* mask, int64_t B, int L, int H, int heads, void* stream) {
+  if (!qkv || !ctx || !mask) OM_FAIL("null argument");
+  return omk_attention(OM_BF16, qkv, ctx, mask, nullptr, B, L, H, heads, 0.125f, 0.f, 0, (hipStream_t)stream);
 }

@@ -197,6 +197,12 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
       const float inv_h = 1.0f / (float)H;
       OM_HIP(hipMemsetAsync(ws.stats1, 0, (size_t)2 * c->n_layers * Mg * 8, s));
       // y1 lives in ws.y, y2 in ws.x1; ws.x is the embedding output (layer 0's input)
+      // Ping-pong walk: every kernel of the chain starts on the rows its producer wrote last (reverse = 1 on every second
+      // launch), so the head of each activation tensor (200-800 MB, far beyond the 32 MB of L2) is found in the 256 MB
+      // memory-side cache instead of HBM.  OM_OPT_ENCODER_PINGPONG = 0 walks every kernel first row to last.
+      const bool pingpong = om_option(OM_OPT_ENCODER_PINGPONG) != 0;
+      int walk = 1;               // the embedding kernel wrote first row to last
+#define OM_WALK() (pingpong ? (walk ^= 1, walk ^ 1) : 0)
       for (int l = 0; l < c->n_layers; ++l) {
         const OmLayerWeights& lw = Ls[l];
         float* st1 = ws.stats1 + (size_t)l * Mg * 2;                     // LN1 of this layer
@@ -205,16 +211,16 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
         GemmEpilogue e = {};
         // ---- QKV: x0 for the first layer, LN2_{l-1}(y2) folded afterwards
         if (l == 0) {
-          e.bias = lw.qkv_b;
+          e.bias = lw.qkv_b; e.reverse = OM_WALK();
           RUN(omk_gemm(dt, ws.x, H, lw.qkv_w, H, dt, ws.qkv, 3 * H, Mg, 3 * H, H, e, s));
         } else {
           const OmLayerWeights& pw = Ls[l - 1];
           const void* wf; const float *cs, *bfp;
           RUN(folded_weights(lw.qkv_w, pw.ln2_g, pw.ln2_b, lw.qkv_b, 3 * H, H, ws.wfold, ws.colsum, ws.bfold, s, &wf, &cs, &bfp));
-          e.bias = bfp; e.ln_stats = st2p; e.ln_colsum = cs; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+          e.bias = bfp; e.ln_stats = st2p; e.ln_colsum = cs; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps; e.reverse = OM_WALK();
           RUN(omk_gemm(dt, ws.x1, H, wf, H, dt, ws.qkv, 3 * H, Mg, 3 * H, H, e, s));
         }
-        RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, nullptr, B, (int)L, H, nh, scale, 0.f, 0, s));
+        RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, nullptr, B, (int)L, H, nh, scale, 0.f, 0, s, OM_WALK()));
         // ---- attention output + residual -> y1, statistics of LN1
         e = GemmEpilogue{};
         e.bias = lw.o_b; e.ldr = H; e.stats_out = st1; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
@@ -224,19 +230,23 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
           const OmLayerWeights& pw = Ls[l - 1];
           e.resid = ws.x1; e.rln_stats = st2p; e.rln_g = pw.ln2_g; e.rln_b = pw.ln2_b;
         }
+        e.reverse = OM_WALK();
         RUN(omk_gemm(dt, ws.ctx, H, lw.o_w, H, dt, ws.y, H, Mg, H, H, e, s));
         // ---- FFN1 on LN1(y1), folded
         const void* wf1; const float *cs1, *bf1;
         RUN(folded_weights(lw.ffn1_w, lw.ln1_g, lw.ln1_b, lw.ffn1_b, F, H, ws.wfold, ws.colsum, ws.bfold, s, &wf1, &cs1, &bf1));
         e = GemmEpilogue{};
         e.bias = bf1; e.act = c->act; e.ln_stats = st1; e.ln_colsum = cs1; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+        e.reverse = OM_WALK();
         RUN(omk_gemm(dt, ws.y, H, wf1, H, dt, ws.ff, F, Mg, F, H, e, s));
         // ---- FFN2 + LN1(y1) as the residual -> y2, statistics of LN2
         e = GemmEpilogue{};
         e.bias = lw.ffn2_b; e.resid = ws.y; e.ldr = H; e.rln_stats = st1; e.rln_g = lw.ln1_g; e.rln_b = lw.ln1_b;
         e.stats_out = st2; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+        e.reverse = OM_WALK();
         RUN(omk_gemm(dt, ws.ff, F, lw.ffn2_w, F, dt, ws.x1, H, Mg, H, F, e, s));
       }
+#undef OM_WALK
       const OmLayerWeights& last = Ls[c->n_layers - 1];
       void* dst = out_hidden ? out_hidden : (void*)ws.x;
       if (!out_hidden && c->pooling == OM_POOL_FIRST)      // only the [CLS] rows are ever read

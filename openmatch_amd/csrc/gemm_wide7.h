@@ -45,7 +45,7 @@
 __device__ __forceinline__ bool g7_tile(int it, int64_t ntm, int64_t ntn, int group_m, int64_t& m0, int64_t& n0) {
   // 32-bit arithmetic throughout (the launchers refuse ntm * ntn >= 2^31): the 64-bit divisions of the first version
   // were ~700 dependent scalar instructions per tile on the only wave of each SIMD
-  const uint32_t tm = (uint32_t)ntm, tn = (uint32_t)ntn, gm = (uint32_t)group_m;
+  const uint32_t tm = (uint32_t)ntm, tn = (uint32_t)ntn, gm = (uint32_t)group_m & 0xffffu;   // bit 16: reversed walk
   const uint32_t ntiles = tm * tn;
   uint32_t w;
   if ((gridDim.x & 7) == 0) {
@@ -55,6 +55,7 @@ __device__ __forceinline__ bool g7_tile(int it, int64_t ntm, int64_t ntn, int gr
     w = (uint32_t)it * gridDim.x + blockIdx.x;
   }
   if (w >= ntiles) return false;
+  if (group_m >> 16) w = ntiles - 1 - w;
   const uint32_t per_group = gm * tn;
   const uint32_t g = w / per_group;
   const uint32_t first_m = g * gm;
@@ -374,7 +375,7 @@ static int launch7(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   const bool timing = om_timing_on();
   if (timing) om_timing_begin(OM_TIMING_GEMM_BF16, s);
   hipLaunchKernelGGL((gemm_nt_kernel7<T, ACT, RESID, LNF, true>), dim3((unsigned)grid), dim3(G6_THREADS), G7_LDS_BYTES, s,
-                     (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, std::max(1, om_option(OM_OPT_GEMM_GROUP_M)));
+                     (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, std::max(1, om_option(OM_OPT_GEMM_GROUP_M)) | (ep.reverse ? 1 << 16 : 0));
   if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, 2.0 * (double)M * (double)N * (double)K);
   OM_LAUNCH_CHECK();
   return 0;

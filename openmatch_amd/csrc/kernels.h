@@ -20,7 +20,7 @@ int omk_t5_bias(const float* table, const int* lut, float* out, int L, int heads
 // projection output [B*L, 3H] (q | k | v), ctx is [B*L, H].  L <= 256, head_dim == 64.
 int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
                   const float* pos_bias, int64_t B, int L, int H, int heads, float scale,
-                  float drop_p, uint64_t seed, hipStream_t s);
+                  float drop_p, uint64_t seed, hipStream_t s, int reverse = 0 /* batch rows last to first */);
 
 // ---- extended GEMM epilogue (training) ---------------------------------------------------
 // order: v = acc + bias ; [pre_act <- v] ; v = act(v) ; v = dropout(v) ; v = v (+|*) resid
@@ -46,6 +46,9 @@ struct GemmEpilogue {
   float* stats_out;          // accumulate (sum, sum of squares) of every output row (the next LayerNorm's input)
   float ln_inv_h, ln_eps;
   int ln_rms;                // 1: the statistics describe a T5 RMSNorm (no mean, no shift): only sum of squares is used
+  int reverse;               // 1: walk the output tiles from the last row block to the first (persistent 16-bit kernel only).
+                             //   A consumer that starts where its producer finished finds those rows in the memory-side cache
+                             //   (256 MB; the encoder's activations are 200-800 MB per tensor) -- encoder.hip alternates.
 };
 // true when omk_gemm will run [M,N] x K (16-bit) on the kernel that implements the ln_* / rln_* / stats_out fields
 bool omk_gemm_ln_fusable(int dtype, int64_t M, int64_t N, int64_t K);

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "om_debug_gemm_trace": (None, [c_void_p]),
     "om_debug_gemm_gen": (None, [c_int]),
     "om_debug_option": (c_int, [c_int, c_int]),
+    "om_debug_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "om_invalidate_folded_weights": (None, []),
     "om_kernel_timing_enable": (c_int, [c_int]),
     "om_kernel_timing_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(c_int64), C.POINTER(C.c_double)]),

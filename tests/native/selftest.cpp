@@ -454,6 +454,28 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (what == "attn") {        // bf16 attention kernel alone under the OM_OPT_ATTENTION_DEBUG variants
+    const int64_t B = argc > 2 ? atoll(argv[2]) : 1024; const int L = argc > 3 ? atoi(argv[3]) : 128, H = 768, heads = 12;
+    bf16* dqkv = upload(to_bf16(randn((size_t)B * L * 3 * H, 1.f)));
+    bf16* dctx = dalloc<bf16>((size_t)B * L * H);
+    std::vector<int64_t> hm((size_t)B * L, 1);
+    int64_t* dmask = upload(hm);
+    for (int variant : {0, 1, 2, 3, 4, 5, 6, 7, 0}) {
+      om_debug_option(OM_OPT_ATTENTION_DEBUG, variant);
+      for (int r = 0; r < 3; ++r) OMCK(om_debug_attention(dqkv, dctx, dmask, B, L, H, heads, nullptr));
+      CK(hipDeviceSynchronize());
+      auto t0 = std::chrono::steady_clock::now();
+      const int reps = 20;
+      for (int r = 0; r < reps; ++r) OMCK(om_debug_attention(dqkv, dctx, dmask, B, L, H, heads, nullptr));
+      CK(hipDeviceSynchronize());
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+      printf("[BENCH] attention B=%ld L=%d heads=%d variant=%d (%s%s%s): %.1f us  %.2f TB/s of qkv + ctx\n", (long)B, L, heads, variant,
+             (variant & 1) ? "no K/V fetch " : "", (variant & 2) ? "no arithmetic " : "", (variant & 4) ? "no stores" : "", us,
+             (double)B * L * H * 2 * 4 / us * 1e-6);
+    }
+    om_debug_option(OM_OPT_ATTENTION_DEBUG, 0);
+    return 0;
+  }
   if (what == "groupm") {      // persistent GEMM: tile-walk group size vs throughput on the encoder's shapes
     const int64_t M = 131072;
     for (int gm : {8, 1, 2, 4, 16, 32}) {
