@@ -326,10 +326,11 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
   }
   // o[dt][r] = O[query l31][d = 32 dt + (r&3) + 8(r>>2) + 4 half]: scale by 1/sum, pack to bf16 -- 16 bytes per
   // (dt, register group of 8) after pairing the two halves' dwords.  Stored straight from this layout an instruction
-  // writes 32 bytes to each of 32 rows: the PMC pass counted 2x the context bytes leaving L2 (partial lines,
-  // profiles/r02_hbm_traffic.json).  So the block goes through the wave's own K rows (all waves are past K and V after
-  // the barrier; waves without queries have exited and do not count) and leaves as whole 128-byte rows, 8 per
+  // writes 32 bytes to each of 32 rows; instead the block goes through the wave's own K rows (all waves are past K and
+  // V after the barrier; waves without queries have exited and do not count) and leaves as whole 128-byte rows, 8 per
   // instruction.  16-byte chunk c of row r sits at chunk c ^ (r & 7): writes and reads are both conflict-free.
+  // (Either way L2 writes exactly the context bytes -- WRITE_SIZE 201 MB per launch, profiles/r02_hbm_traffic.json -- and
+  // the kernel runs at the memory system's pace: 805 MB per layer at ~5.2 TB/s, profiles/r02_attention_variants.log.)
   __syncthreads();
   char* const so = sK + q0 * 128;
 #pragma unroll

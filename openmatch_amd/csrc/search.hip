@@ -390,12 +390,19 @@ __global__ __launch_bounds__(G6_THREADS) void sim_stream_kernel(
         for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, a[r]), a[r + 1]);
         mx = fmaxf(mx, a[15]);
         if (mx >= th) {                                          // rare by construction of the thresholds
+          // one atomic per lane and block, not per survivor: with one query every append of the round lands on the
+          // same counter, and the first rounds keep a third of their rows (~5 k same-address atomics were ~50 us of a
+          // 57 us round -- profiles/r02_search_q1_timeline.log)
           const uint32_t id0 = row_base + (uint32_t)(tile * 256) + wave * 64 + rt * 32 + 4 * half;
+          unsigned n = 0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) n += a[r] >= th ? 1u : 0u;
+          unsigned pos = atomicAdd(cnt + l31, n);
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             if (a[r] >= th) {
-              const unsigned pos = atomicAdd(cnt + l31, 1u);
               if (pos < SORT_CAP) keys[(int64_t)l31 * SORT_CAP + pos] = pack_key(a[r], id0 + (r & 3) + 8 * (r >> 2));
+              ++pos;
             }
         }
 #pragma unroll
@@ -511,7 +518,10 @@ __global__ __launch_bounds__(256) void select_radix_kernel(
   const int64_t q = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned n = cnt[q];
-  if (n > SORT_CAP) n = SORT_CAP;                            // (overflow is flagged by check_overflow_kernel)
+  if (n > SORT_CAP) {                                        // appends beyond the capacity were dropped: the round is void
+    if (tid == 0) atomicOr(flag, 1u);                        // (sticky; the step-by-step loop uses check_overflow_kernel)
+    n = SORT_CAP;
+  }
   u64* list = keys + q * SORT_CAP;
   for (unsigned i = tid; i < n; i += 256) s[i] = list[i];
   if (tid == 0) misc[2] = 0;
@@ -648,8 +658,9 @@ __global__ void emit_kernel(const u64* __restrict__ keys, const unsigned* __rest
   }
 }
 
-__global__ void init_lists_kernel(unsigned* cnt, unsigned* cnt_prev, float* thr, int64_t nq) {
+__global__ void init_lists_kernel(unsigned* cnt, unsigned* cnt_prev, float* thr, int64_t nq, unsigned* flag) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < 16) flag[q] = 0;                                            // the 64-byte flag block (one launch less than a memset)
   if (q < nq) { cnt[q] = 0; cnt_prev[q] = 0; thr[q] = -INFINITY; }
   else if (q < (nq + 255) / 256 * 256 + 256) thr[q] = INFINITY;       // queries that do not exist never have survivors
 }
@@ -760,8 +771,17 @@ struct Scan {
     return 0;
   }
   int read_flags(unsigned (&f)[4]) {
-    OM_HIP(hipMemcpyAsync(f, ws.flag, sizeof(f), hipMemcpyDeviceToHost, s));
+    static thread_local unsigned* pinned = nullptr;        // page-locked: the copy is one DMA, no staging through the runtime
+    if (!pinned) OM_HIP(hipHostMalloc((void**)&pinned, 64, hipHostMallocDefault));
+    OM_HIP(hipMemcpyAsync(pinned, ws.flag, sizeof(f), hipMemcpyDeviceToHost, s));
     OM_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < 4; ++i) f[i] = pinned[i];
+    return 0;
+  }
+  int rescore(unsigned maxlist) {
+    hipLaunchKernelGGL(rescore_kernel, dim3((maxlist + 3) / 4, (unsigned)nq), dim3(256), 0, s, q32,
+                       idx32, ws.keys, ws.cnt, d);
+    OM_LAUNCH_CHECK();
     return 0;
   }
   // dense-score rows [r0, r0+n) and merge them into the lists (always exact, HBM heavy)
@@ -782,7 +802,7 @@ struct Scan {
     if (dense_gemm_append(r0, n, bf16)) return 1;
     return select(bf16);
   }
-  int filter_step(int64_t r0, int64_t n, bool bf16) {
+  int filter_step(int64_t r0, int64_t n, bool bf16, bool check = true /* false: the selection that follows flags overflows */) {
     const bool wide = nq > 128;
     const int64_t ntm = (n + 255) / 256, ntn = wide ? (nq + G4_BM - 1) / G4_BM : (nq + G2_BN - 1) / G2_BN;
     if (ntm * ntn > 0x7fffffffLL) OM_FAIL("scan grid too large");
@@ -827,6 +847,7 @@ struct Scan {
 #undef SCAN
     if (timing) om_timing_end(OM_TIMING_SCAN, s, 2.0 * (double)n * (double)nq * (double)d);
     OM_LAUNCH_CHECK();
+    if (!check) return 0;
     hipLaunchKernelGGL(check_overflow_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s,
                        ws.cnt, nq, ws.flag);
     OM_LAUNCH_CHECK();
@@ -843,9 +864,8 @@ struct Scan {
 
   // returns 0 ok, 1 error, 2 certified margin too wide (caller retries in f32)
   int run(bool bf16) {
-    OM_HIP(hipMemsetAsync(ws.flag, 0, 64, s));
     hipLaunchKernelGGL(init_lists_kernel, dim3((unsigned)((nq + 255) / 256 + 2)), dim3(256), 0, s,
-                       ws.cnt, ws.cnt_prev, ws.thr, nq);
+                       ws.cnt, ws.cnt_prev, ws.thr, nq, ws.flag);
     OM_LAUNCH_CHECK();
     if (bf16) {
       hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, q32,
@@ -878,24 +898,33 @@ struct Scan {
         chunk = std::max<int64_t>(chunk, DENSE_CHUNK) & ~(int64_t)255;      // whole tiles (DENSE_CHUNK is one)
         chunk = std::min<int64_t>(chunk, N - at);
         if (N - at - chunk < chunk / 4) chunk = N - at;           // no sliver of a last round
-        if (filter_step(at, chunk, bf16)) return 1;
+        if (filter_step(at, chunk, bf16, false)) return 1;
         if (select_radix(bf16)) return 1;
         g_info[1]++;
         at += chunk;
       }
+      // Few queries: the exact re-score and the final sort are queued BEHIND the last round before the flags are read, so
+      // the host's wake-up overlaps them instead of idling the device (a 34 us hole per search at one query).  They
+      // cover lists up to twice the estimate; a longer list (never seen) counts as a failed fast schedule.
+      const bool spec = bf16 && nq <= 32;
+      const unsigned spec_cover = (unsigned)std::min<int64_t>(2 * list, SORT_CAP);
+      if (spec) {
+        if (rescore(spec_cover)) return 1;
+        if (select(false)) return 1;
+      }
       unsigned g[4];
       if (read_flags(g)) return 1;
       if (g[1] > (unsigned)g_info[3]) g_info[3] = g[1];
-      if (!g[0] && !g[2]) {
+      if (!g[0] && !g[2] && !(spec && g[1] > spec_cover)) {
+        if (spec) return 0;                      // everything is done
         done = N;
         f[1] = g[1];
         unsorted = true;                         // the lists are cut but not ordered: one sort at the very end
         careful = false;
       } else {                                   // rare: start over on the careful path
         g_info[2]++;
-        OM_HIP(hipMemsetAsync(ws.flag, 0, 64, s));
         hipLaunchKernelGGL(init_lists_kernel, dim3((unsigned)((nq + 255) / 256 + 2)), dim3(256), 0, s,
-                           ws.cnt, ws.cnt_prev, ws.thr, nq);
+                           ws.cnt, ws.cnt_prev, ws.thr, nq, ws.flag);
         OM_LAUNCH_CHECK();
       }
     }
@@ -943,10 +972,7 @@ struct Scan {
     }
     if (bf16) {
       // exact f32 re-score of the certified candidate set, then the true top-k
-      const unsigned maxlist = std::max<unsigned>(f[1], 1u);
-      hipLaunchKernelGGL(rescore_kernel, dim3((maxlist + 3) / 4, (unsigned)nq), dim3(256), 0, s, q32,
-                         idx32, ws.keys, ws.cnt, d);
-      OM_LAUNCH_CHECK();
+      if (rescore(std::max<unsigned>(f[1], 1u))) return 1;
       if (select(false)) return 1;
     } else if (unsorted) {
       if (select(false)) return 1;               // exact mode after the radix rounds: best k, in order
@@ -1012,7 +1038,7 @@ extern "C" int om_sim_topk(int mode, const float* queries, int64_t n_queries,
     }
   } else {
     hipLaunchKernelGGL(init_lists_kernel, dim3((unsigned)((n_queries + 255) / 256)), dim3(256), 0, s,
-                       sc.ws.cnt, sc.ws.cnt_prev, sc.ws.thr, n_queries);
+                       sc.ws.cnt, sc.ws.cnt_prev, sc.ws.thr, n_queries, sc.ws.flag);
     OM_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(emit_kernel, dim3((unsigned)n_queries), dim3(256), 0, s, sc.ws.keys, sc.ws.cnt, k,

@@ -74,8 +74,12 @@ class FlatIPIndex:
         """Local-shard search on device tensors: returns (D [Q,k] f32, I [Q,k] int64) on the GPU."""
         if queries.dim() != 2 or queries.shape[1] != self.d:
             raise ValueError(f"expected [q,{self.d}] queries")
-        q = torch.zeros(queries.shape[0], self.dpad, dtype=torch.float32, device=self.device)
-        q[:, :self.d].copy_(queries.to(device=self.device, dtype=torch.float32))
+        q = queries.to(device=self.device, dtype=torch.float32)
+        if self.dpad != self.d:            # zero-padded to the kernels' K step
+            qp = torch.zeros(q.shape[0], self.dpad, dtype=torch.float32, device=self.device)
+            qp[:, :self.d].copy_(q)
+            q = qp
+        q = q.contiguous()
         nq = q.shape[0]
         D = torch.empty(nq, k, dtype=torch.float32, device=self.device)
         I = torch.empty(nq, k, dtype=torch.int64, device=self.device)

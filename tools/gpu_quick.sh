@@ -8,4 +8,4 @@ cd /tmp; export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python $R/bench.py --steps 5 --warmup 2 --no-search --no-cpu-baseline --no-extra --no-parity > $O/prof_stats.log 2>&1
 cd $R
 tail -3 $O/pytest.log; cat $O/bench.json | cut -c1-600
-f=$(find $O/prof_stats -name "*kernel_stats.csv" | head -1); head -8 "$f" | cut -c1-200
+f=$(ls -t $(find $O/prof_stats -name "*kernel_stats.csv") | head -1); head -8 "$f" | cut -c1-200

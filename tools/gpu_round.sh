@@ -11,5 +11,5 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --no-search --no-cpu-baseline --no-extra --no-parity > $O/pmc_write.log 2>&1
 cd $R
 python tools/summarize_pmc.py $O > $O/pmc_summary.txt 2>&1
-f=$(find $O/prof_stats -name "*kernel_stats.csv" | head -1); head -12 "$f" | cut -c1-150
+f=$(ls -t $(find $O/prof_stats -name "*kernel_stats.csv") | head -1); head -12 "$f" | cut -c1-150
 grep -A3 "gemm_nt_kernel7" $O/pmc_summary.txt | head -40
