@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the strided-subsample parity leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the f32 and training sub-objects")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32"])
     return ap.parse_args()
 
 
@@ -184,12 +184,19 @@ def parity_leg(model_bf16, lm, batches, device, index=None, queries=None, topk=1
     got16 = torch.cat([model_bf16(passage=b).p_reps[sel] for b in batches[:2]]).double().cpu()
     m32 = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype="float32")).to(device).eval()
     got32 = m32(passage={"input_ids": ids.to(device), "attention_mask": msk.to(device)}).p_reps.double().cpu()
+    mf16 = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype="float16")).to(device).eval()
+    gotf16 = torch.cat([mf16(passage=b).p_reps[sel] for b in batches[:2]]).double().cpu()
+    del mf16
     cos = torch.nn.functional.cosine_similarity(got16, ref, dim=1)
+    cosf = torch.nn.functional.cosine_similarity(gotf16, ref, dim=1)
     dots_ref = ref[:16] @ ref.t()
     out["encode"] = {
         "sample": f"{ids.shape[0]} passages (every {stride}th of two timed batches) vs oracle/encoder_ref.py fp32, {time.perf_counter() - t0:.1f} s of CPU",
         "bf16_min_cosine": round(float(cos.min()), 6), "bf16_mean_cosine": round(float(cos.mean()), 6),
         "bf16_max_abs_ddot": round(float(((got16[:16] @ got16.t()) - dots_ref).abs().max()), 4),
+        "f16_min_cosine": round(float(cosf.min()), 8), "f16_mean_cosine": round(float(cosf.mean()), 8),
+        "f16_max_abs_ddot": round(float(((gotf16[:16] @ gotf16.t()) - dots_ref).abs().max()), 4),
+        "f16_max_rel_ddot": float((((gotf16[:16] @ gotf16.t()) - dots_ref).abs() / dots_ref.abs().clamp_min(1.0)).max()),
         "f32_max_abs_emb_err": float((got32 - ref).abs().max()),
         "f32_max_rel_ddot": float((((got32[:16] @ got32.t()) - dots_ref).abs() / dots_ref.abs().clamp_min(1.0)).max()),
         "dot_scale": round(float(dots_ref.abs().max()), 1),
@@ -282,7 +289,8 @@ def main():
     lib = N.lib()
     torch.manual_seed(0)
     lm = BertModel(BertConfig()).eval()
-    dtype_name = "bfloat16" if a.precision == "bf16" else "float32"
+    half = a.precision in ("bf16", "f16")
+    dtype_name = {"bf16": "bfloat16", "f16": "float16"}.get(a.precision, "float32")
     model = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first",
                                 model_args=NS(encoder_only=False, dtype=dtype_name)).to(device).eval()
     L = 128
@@ -309,15 +317,15 @@ def main():
         step(i)
     torch.cuda.synchronize()
     ms, n_launch, flops = C.c_double(), C.c_int64(), C.c_double()
-    cls = 0 if a.precision == "bf16" else 1
+    cls = 0 if half else 1
     N.check(lib.om_kernel_timing_read(cls, C.byref(ms), C.byref(n_launch), C.byref(flops)))
     lib.om_kernel_timing_enable(0)
     gemm_tflops = flops.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-    peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else 157.3
+    peak = PEAK_BF16_TFLOPS if half else 157.3
     traffic, tsrc = None, None   # HBM bytes per launch of the dominant kernel: the round's committed rocprofv3 --pmc passes of this command
     import glob
     cand = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_traffic.json")))
-    if a.precision == "bf16" and a.batch == 1024 and cand:
+    if half and a.batch == 1024 and cand:
         try:
             tj = json.load(open(cand[-1]))
             traffic, tsrc = tj["hbm_bytes_per_launch"], "profiles/" + os.path.basename(cand[-1]) + ": " + tj.get("note", "")
@@ -325,7 +333,7 @@ def main():
             traffic = None
     roofline = {
         "kernel": ("gemm_nt_kernel7<bf16> (persistent 256x256 tiles, 128-byte K steps; encoder QKV / out-proj / FFN contractions, "
-                   "three epilogue variants)" if a.precision == "bf16" else "gemm_nt_kernel6<f32> (exact-f32 MFMA)"),
+                   "three epilogue variants)" if half else "gemm_nt_kernel6<f32> (exact-f32 MFMA)"),
         "bound": "mfma", "achieved": round(gemm_tflops, 1), "peak": peak, "unit": "TFLOP/s",
         "frac": round(gemm_tflops / peak, 4), "traffic": traffic,
         "traffic_source": tsrc,
@@ -340,7 +348,7 @@ def main():
     if not a.no_search:
         rows = a.index_rows // world + (1 if rank < a.index_rows % world else 0)
         offset = rank * (a.index_rows // world) + min(rank, a.index_rows % world)
-        index = FlatIPIndex(768, device=device, precision="f16_rescore" if a.precision == "bf16" else "f32")
+        index = FlatIPIndex(768, device=device, precision="f16_rescore" if half else "f32")
         g = torch.Generator(device=device).manual_seed(77 + rank)
         shared = torch.randn(1, 768, device=device, generator=torch.Generator(device=device).manual_seed(5))
         index._reserve(rows)
@@ -381,14 +389,14 @@ def main():
         lib.om_kernel_timing_read(0, None, None, None)
         lib.om_kernel_timing_read(1, None, None, None)
         lib.om_kernel_timing_enable(0)
-        es = 2 if a.precision == "bf16" else 4
+        es = 2 if half else 4
         scan_bytes = rows * 768 * es
         search = {
             "metric": "queries/sec exact top-%d over %d x 768" % (a.topk, a.index_rows),
             "value": round(a.queries / t_s, 1), "unit": "queries/s", "queries": a.queries,
             "seconds_per_batch": round(t_s, 4),
             "scaling": "strong (index rows fixed, sharded by rank)" if world > 1 else "single shard",
-            "precision": ("f16 MFMA candidate scan (certified margin) + exact f32 re-score; ids == f32 scan" if a.precision == "bf16" else "exact f32 MFMA scan"),
+            "precision": ("f16 MFMA candidate scan (certified margin) + exact f32 re-score; ids == f32 scan" if half else "exact f32 MFMA scan"),
             "scan_info": index.last_search_info,
             "algorithmic_tflops": round(2.0 * a.index_rows * 768 * a.queries / t_s / 1e12, 1),
             "frac_of_mfma_peak": round(2.0 * a.index_rows * 768 * a.queries / t_s / 1e12 / (peak * world), 4),
@@ -417,8 +425,24 @@ def main():
         parity = parity_leg(model, lm, batches, device)
 
     # ---------------- exact-f32 mode and the training step (sub-objects; N = 1 only) ----------
-    f32_mode, train = None, None
+    f32_mode, train, f16_mode = None, None, None
     if rank == 0 and world == 1 and not a.no_extra and a.precision == "bf16":
+        # the float16 mode on the SAME timed batches: same kernels and MFMA rate, 11-bit mantissa activations
+        m16 = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first",
+                                  model_args=NS(encoder_only=False, dtype="float16")).to(device).eval()
+        for i in range(a.warmup):
+            m16(passage=batches[i % len(batches)])
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(a.steps):
+            m16(passage=batches[i % len(batches)])
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
+        f16_mode = {"metric": "passages/s encode in the float16 MFMA mode (the reference's --fp16 format; same kernels as bf16, "
+                              "three more mantissa bits per stored activation; parity in `parity.encode.f16_*`)",
+                    "value": round(a.batch / dt, 1), "unit": "passages/s", "ms_per_step": round(dt * 1e3, 3),
+                    "algorithmic_tflops": round(a.batch * GFLOP_PER_PASSAGE / 1e3 / dt, 1),
+                    "frac_of_mfma_peak": round(a.batch * GFLOP_PER_PASSAGE / 1e3 / dt / PEAK_BF16_TFLOPS, 4)}
+        del m16
+        torch.cuda.empty_cache()
         m32 = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first",
                                   model_args=NS(encoder_only=False, dtype="float32")).to(device).eval()
         sub = {k: v[:256] for k, v in batches[0].items()}
@@ -451,7 +475,7 @@ def main():
                        "passages_per_step_per_gpu": a.batch, "seq_len": L, "global_batch": a.batch * world,
                        "index_rows": a.index_rows, "queries": a.queries, "topk": a.topk,
                        "weights": "random-init BertConfig() seed 0", "parallelism": f"shard{world}"},
-            "roofline": roofline, "search": search, "parity": parity, "f32": f32_mode, "train": train, "cpu_baseline": cpu,
+            "roofline": roofline, "search": search, "parity": parity, "f16": f16_mode, "f32": f32_mode, "train": train, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -34,7 +34,7 @@ extern "C" {
 /* element types */
 #define OM_F32 0
 #define OM_BF16 1
-#define OM_F16 2 /* IEEE half: search shadow index only */
+#define OM_F16 2 /* IEEE half: the search shadow index; the inference encoder's float16 mode (OmEncoderConfig.dtype) */
 
 /* GEMM epilogue activation */
 #define OM_ACT_NONE 0
@@ -109,8 +109,8 @@ int om_kernel_timing_read(int kernel_class, double* total_ms, int64_t* launches,
  * Dense contraction  C[M,N] = act(A[M,K] · B[N,K]^T + bias[N]) + resid[M,N]
  * (torch.nn.Linear layout: B is the [out,in] weight).  Replaces the ATen/BLAS
  * GEMMs under every nn.Linear of HF BertLayer / T5Block and linear.py:22-23.
- * in_dtype: OM_F32 (exact f32 MFMA, k-ordered fmaf chain) or OM_BF16
- * (bf16 MFMA, f32 accumulate).  bias (f32) and resid (out_dtype) may be NULL.
+ * in_dtype: OM_F32 (exact f32 MFMA, k-ordered fmaf chain), OM_BF16 or OM_F16 (16-bit MFMA, f32 accumulate;
+ * OM_F16 with out_dtype OM_F16 or OM_F32, inference epilogues only).  bias (f32) and resid (out_dtype) may be NULL.
  * Requires K * sizeof(in) % 128 == 0.
  * ------------------------------------------------------------------------ */
 int om_gemm_nt(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb,
@@ -136,7 +136,7 @@ int om_gemm_tn_acc(int in_dtype, const void* A, int64_t lda, const void* B, int6
  * T5Stack.forward (HF:models/t5/modeling_t5.py) in eval mode.
  * ------------------------------------------------------------------------ */
 typedef struct OmLayerWeights {
-  /* matrices: compute dtype (OM_F32 / OM_BF16), [out,in] row-major */
+  /* matrices: compute dtype (OM_F32 / OM_BF16 / OM_F16), [out,in] row-major */
   const void* qkv_w;   /* [3H,H]  rows: query | key | value                       */
   const float* qkv_b;  /* [3H] or NULL (T5)                                       */
   const void* o_w;     /* [H,H]                                                   */
@@ -154,7 +154,9 @@ typedef struct OmLayerWeights {
 
 typedef struct OmEncoderConfig {
   int arch;          /* OM_ARCH_*                                                 */
-  int dtype;         /* compute dtype of matrices/activations: OM_F32 | OM_BF16   */
+  int dtype;         /* compute dtype of matrices/activations: OM_F32 | OM_BF16 | OM_F16 (OM_F16: om_encoder_forward only,
+                      * BERT-family erf-GELU encoders, sequences up to 256 tokens -- the reference's `--fp16` is torch.cuda.amp
+                      * float16, retriever/dense_retriever.py:76; same kernels and MFMA rate as OM_BF16, 11-bit mantissas) */
   int hidden;        /* H                                                         */
   int n_layers;
   int n_heads;

@@ -8,6 +8,8 @@
 // the 32x32 accumulator map (col = lane&31, rows in registers) every lane then owns ONE query
 // row and 16 keys per key tile, so the softmax is lane-local plus one exchange with lane^32,
 // and the probabilities already sit in the A-operand layout of the P·V MFMA.
+#include <type_traits>
+
 #include "attn_common.h"
 
 template <typename T, int KT>
@@ -166,25 +168,20 @@ __global__ __launch_bounds__(64 * KT) void attention_kernel(
 // Masked keys carry -1e30 (finite: a fully masked row stays uniform, as with HF's finfo.min), keys past L -inf.
 #include "gemm_core7.h"
 
-typedef __bf16 bf16x2_hw_a_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_a_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pack_bf16x2_(float lo, float hi) {      // one v_cvt_pk_bf16_f32
-  const f32x2_a_t v = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw_a_t));
-}
-
 typedef short v4s_a_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v4s_a_t vtrd(const char* p) {           // ds_read_b64_tr_b16
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_a_t __attribute__((address_space(3)))*)(p));
 }
-__device__ __forceinline__ bf16x8_t vfrag_of(v4s_a_t a, v4s_a_t b) { return (bf16x8_t){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+template <typename F>
+__device__ __forceinline__ F vfrag_of(v4s_a_t a, v4s_a_t b) { return __builtin_bit_cast(F, (bf16x8_t){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}); }
 
 // DBG (timing experiments, OM_OPT_ATTENTION_DEBUG): bit 0 no K / V fetch, bit 1 no arithmetic, bit 2 no stores
-template <int KT, bool BIAS, bool DROP, int DBG = 0>
+// T: bf16_t or f16_t (the float16 inference mode) -- same instruction stream, the other MFMA / conversion opcodes
+template <typename T, int KT, bool BIAS, bool DROP, int DBG = 0>
 __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) void attention_fwd16_kernel(
-    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, const int64_t* __restrict__ mask,
+    const T* __restrict__ qkv, T* __restrict__ ctx, const int64_t* __restrict__ mask,
     const float* __restrict__ pos_bias, int L, int H, int heads, float scale, float drop_p, uint64_t seed, int rev) {
-  typedef bf16x8_t frag_t;
+  typedef typename MmaOps<T>::frag_t frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sK = smem;
   char* const sV = smem + KT * 32 * 128;
@@ -238,7 +235,7 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const frag_t a = *(const frag_t*)(krow + (((kk * 2 + half) ^ key) << 4));
-      s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[kk], s[t], 0, 0, 0);
+      MmaOps<T>::mma(a, qf[kk], s[t]);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -307,15 +304,15 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
     uint4 pa[2];      // probabilities of this key tile as two k slabs (k slot e of half h <-> register 8u + e)
 #pragma unroll
     for (int u = 0; u < 2; ++u)
-      pa[u] = make_uint4(pack_bf16x2_(s[t][8 * u + 0], s[t][8 * u + 1]), pack_bf16x2_(s[t][8 * u + 2], s[t][8 * u + 3]),
-                         pack_bf16x2_(s[t][8 * u + 4], s[t][8 * u + 5]), pack_bf16x2_(s[t][8 * u + 6], s[t][8 * u + 7]));
+      pa[u] = make_uint4(Half16<T>::pack2(s[t][8 * u + 0], s[t][8 * u + 1]), Half16<T>::pack2(s[t][8 * u + 2], s[t][8 * u + 3]),
+                         Half16<T>::pack2(s[t][8 * u + 4], s[t][8 * u + 5]), Half16<T>::pack2(s[t][8 * u + 6], s[t][8 * u + 7]));
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const char* p = vt0 + (t * 32 + 16 * u) * 128 + ((dt ^ vsw) << 6);
-        const frag_t vf = vfrag_of(vtrd(p), vtrd(p + 8 * 128));
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(frag_t, pa[u]), o[dt], 0, 0, 0);
+        const frag_t vf = vfrag_of<frag_t>(vtrd(p), vtrd(p + 8 * 128));
+        MmaOps<T>::mma(vf, __builtin_bit_cast(frag_t, pa[u]), o[dt]);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -337,8 +334,8 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int gp = 0; gp < 2; ++gp) {
-      uint32_t a0 = pack_bf16x2_(o[dt][8 * gp + 0] * inv, o[dt][8 * gp + 1] * inv), a1 = pack_bf16x2_(o[dt][8 * gp + 2] * inv, o[dt][8 * gp + 3] * inv);
-      uint32_t b0 = pack_bf16x2_(o[dt][8 * gp + 4] * inv, o[dt][8 * gp + 5] * inv), b1 = pack_bf16x2_(o[dt][8 * gp + 6] * inv, o[dt][8 * gp + 7] * inv);
+      uint32_t a0 = Half16<T>::pack2(o[dt][8 * gp + 0] * inv, o[dt][8 * gp + 1] * inv), a1 = Half16<T>::pack2(o[dt][8 * gp + 2] * inv, o[dt][8 * gp + 3] * inv);
+      uint32_t b0 = Half16<T>::pack2(o[dt][8 * gp + 4] * inv, o[dt][8 * gp + 5] * inv), b1 = Half16<T>::pack2(o[dt][8 * gp + 6] * inv, o[dt][8 * gp + 7] * inv);
       // (a: d group 2gp, b: d group 2gp + 1) -- lanes 32-63 of a swap with lanes 0-31 of b
       auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
       auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
@@ -354,20 +351,20 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
   }
 }
 
-template <int KT, bool BIAS, bool DROP>
+template <typename T, int KT, bool BIAS, bool DROP>
 static int launch_attn16_(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias, int64_t B, int L, int H,
                          int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, int rev) {
   const int lds = 2 * KT * 32 * 128 + KT * 32 * 4;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
-    OM_HIP(hipFuncSetAttribute((const void*)attention_fwd16_kernel<KT, BIAS, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    OM_HIP(hipFuncSetAttribute((const void*)attention_fwd16_kernel<T, KT, BIAS, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  const int dbg = (KT == 4 && !BIAS && !DROP) ? om_option(OM_OPT_ATTENTION_DEBUG) : 0;
+  const int dbg = (sizeof(T) == 2 && std::is_same<T, bf16_t>::value && KT == 4 && !BIAS && !DROP) ? om_option(OM_OPT_ATTENTION_DEBUG) : 0;
   if (dbg) {
 #define OM_ATTN_DBG(D)                                                                                                        \
   case D:                                                                                                                     \
-    hipLaunchKernelGGL((attention_fwd16_kernel<4, false, false, D>), dim3((unsigned)(heads * B)), dim3(256), lds, s,          \
+    hipLaunchKernelGGL((attention_fwd16_kernel<bf16_t, 4, false, false, D>), dim3((unsigned)(heads * B)), dim3(256), lds, s,          \
                        (const bf16_t*)qkv, (bf16_t*)ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed, rev);               \
     break;
     switch (dbg) { OM_ATTN_DBG(1) OM_ATTN_DBG(2) OM_ATTN_DBG(3) OM_ATTN_DBG(4) OM_ATTN_DBG(5) OM_ATTN_DBG(6) OM_ATTN_DBG(7) default: break; }
@@ -375,20 +372,24 @@ static int launch_attn16_(const void* qkv, void* ctx, const int64_t* mask, const
     OM_LAUNCH_CHECK();
     return 0;
   }
-  hipLaunchKernelGGL((attention_fwd16_kernel<KT, BIAS, DROP>), dim3((unsigned)(heads * B)), dim3(64 * KT), lds, s, (const bf16_t*)qkv,
-                     (bf16_t*)ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed, rev);
+  hipLaunchKernelGGL((attention_fwd16_kernel<T, KT, BIAS, DROP>), dim3((unsigned)(heads * B)), dim3(64 * KT), lds, s, (const T*)qkv,
+                     (T*)ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed, rev);
   OM_LAUNCH_CHECK();
   return 0;
 }
-template <int KT>
+template <typename T, int KT>
 static int launch_attn16(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias, int64_t B, int L, int H,
                          int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, int rev) {
-  if (drop_p > 0.f) {
-    if (pos_bias) return launch_attn16_<KT, true, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, rev);
-    return launch_attn16_<KT, false, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, rev);
+  if (std::is_same<T, f16_t>::value) {            // float16: BERT-family inference only (no bias table, no dropout)
+    if (drop_p > 0.f || pos_bias) OM_FAIL("float16 attention: inference without a position-bias table only");
+    return launch_attn16_<T, KT, false, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev);
   }
-  if (pos_bias) return launch_attn16_<KT, true, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev);
-  return launch_attn16_<KT, false, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev);
+  if (drop_p > 0.f) {
+    if (pos_bias) return launch_attn16_<bf16_t, KT, true, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, rev);
+    return launch_attn16_<bf16_t, KT, false, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, rev);
+  }
+  if (pos_bias) return launch_attn16_<bf16_t, KT, true, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev);
+  return launch_attn16_<bf16_t, KT, false, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -591,16 +592,24 @@ int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
   if (L > 256 && drop_p > 0.f) OM_FAIL("training supports sequence lengths up to 256");
   if (H != heads * 64) OM_FAIL("head_dim must be 64");
   if (B * heads > 0x7fffffffLL) OM_FAIL("batch too large for one launch");
+  if (dtype == OM_F16) {                                      // float16 inference mode: the fast kernel only
+    if (L > 256) OM_FAIL("float16 mode supports sequences up to 256 tokens");
+    if (L <= 32) return launch_attn16<f16_t, 1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
+    if (L <= 64) return launch_attn16<f16_t, 2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
+    if (L <= 128) return launch_attn16<f16_t, 4>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
+    if (L <= 192) return launch_attn16<f16_t, 6>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
+    return launch_attn16<f16_t, 8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
+  }
   if (L > 256) {                                              // online-softmax kernel, any dtype
     if (dtype == OM_BF16) return launch_attn_long<bf16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
     return launch_attn_long<float>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
   }
   if (dtype == OM_BF16 && om_option(OM_OPT_ATTENTION_FAST)) {        // the low-instruction-count kernel (inference, and training with dropout)
-    if (L <= 32) return launch_attn16<1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
-    if (L <= 64) return launch_attn16<2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
-    if (L <= 128) return launch_attn16<4>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
-    if (L <= 192) return launch_attn16<6>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
-    return launch_attn16<8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
+    if (L <= 32) return launch_attn16<bf16_t, 1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
+    if (L <= 64) return launch_attn16<bf16_t, 2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
+    if (L <= 128) return launch_attn16<bf16_t, 4>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
+    if (L <= 192) return launch_attn16<bf16_t, 6>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
+    return launch_attn16<bf16_t, 8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
   }
   if (dtype == OM_BF16) return dispatch_attn<bf16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
   return dispatch_attn<float>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);

@@ -72,6 +72,43 @@ template <> struct ElemOps<bf16_t> {
   __device__ static inline void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
+// ---- packed pairs of the 16-bit formats: one dword <-> two floats ------------------------------
+// The 16-bit kernels (GEMM epilogues, attention, LayerNorm) are written once for both storage formats: bfloat16
+// (bf16_t, raw bits) and IEEE half (f16_t).  pack2 rounds to nearest even (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32).
+#if defined(__HIPCC__)
+typedef __bf16 om_bf16x2_hw_t __attribute__((ext_vector_type(2)));
+typedef _Float16 om_f16x2_hw_t __attribute__((ext_vector_type(2)));
+typedef float om_f32x2_t __attribute__((ext_vector_type(2)));
+template <typename T> struct Half16;
+template <> struct Half16<bf16_t> {
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) {
+    const om_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, om_bf16x2_hw_t));
+  }
+  __device__ static __forceinline__ float lo(uint32_t w) { return __uint_as_float(w << 16); }
+  __device__ static __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+  __device__ static __forceinline__ uint32_t bits(float v) { return f32_to_bf16(v); }          // one value -> its 16 bits
+  __device__ static __forceinline__ float value(uint32_t b) { return __uint_as_float(b << 16); }
+};
+template <> struct Half16<f16_t> {
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) {
+    const om_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, om_f16x2_hw_t));
+  }
+  __device__ static __forceinline__ float lo(uint32_t w) { return (float)__builtin_bit_cast(om_f16x2_hw_t, w)[0]; }
+  __device__ static __forceinline__ float hi(uint32_t w) { return (float)__builtin_bit_cast(om_f16x2_hw_t, w)[1]; }
+  __device__ static __forceinline__ uint32_t bits(float v) { return __builtin_bit_cast(unsigned short, (f16_t)v); }
+  __device__ static __forceinline__ float value(uint32_t b) { return (float)__builtin_bit_cast(f16_t, (unsigned short)b); }
+};
+template <> struct Half16<float> {     // never executed: lets `if (sizeof(OutT) == 2)` branches of f32 instantiations compile
+  __device__ static __forceinline__ uint32_t pack2(float lo, float) { return __float_as_uint(lo); }
+  __device__ static __forceinline__ float lo(uint32_t w) { return __uint_as_float(w); }
+  __device__ static __forceinline__ float hi(uint32_t w) { return __uint_as_float(w); }
+  __device__ static __forceinline__ uint32_t bits(float v) { return __float_as_uint(v); }
+  __device__ static __forceinline__ float value(uint32_t b) { return __uint_as_float(b); }
+};
+#endif
+
 // ---- wave reductions (64 lanes) ---------------------------------------------
 __device__ inline float wave_sum(float v) {
 #pragma unroll

@@ -31,6 +31,17 @@ template <> struct Vec4<bf16_t> {
   }
 };
 
+template <> struct Vec4<f16_t> {
+  __device__ static inline void load(const f16_t* p, float (&v)[4]) {
+    const uint2 t = *(const uint2*)p;
+    v[0] = Half16<f16_t>::lo(t.x); v[1] = Half16<f16_t>::hi(t.x);
+    v[2] = Half16<f16_t>::lo(t.y); v[3] = Half16<f16_t>::hi(t.y);
+  }
+  __device__ static inline void store(f16_t* p, const float (&v)[4]) {
+    *(uint2*)p = make_uint2(Half16<f16_t>::pack2(v[0], v[1]), Half16<f16_t>::pack2(v[2], v[3]));
+  }
+};
+
 // Normalise the row held in x[][] (nv vectors per lane) and write it out.
 // LayerNorm: two-pass mean / biased variance in f32 (torch.nn.LayerNorm);
 // RMSNorm (T5LayerNorm, HF:models/t5/modeling_t5.py:59-72): x * rsqrt(mean(x^2)+eps) * g.
@@ -161,9 +172,10 @@ __global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(
 // Fold a LayerNorm into the bf16 weight that consumes its output (kernels.h, GemmEpilogue::ln_*):
 //   W'[n,k] = bf16(W[n,k] gamma[k]),  s[n] = sum_k W'[n,k],  b'[n] = b[n] + sum_k beta[k] W[n,k]
 // so that LN(y) W^T + b = rstd (y W'^T - mu s) + b'.  One wave per output row.
-__global__ __launch_bounds__(256) void ln_fold_kernel(const bf16_t* __restrict__ W, const float* __restrict__ gamma,
+template <typename T>          // bf16_t or f16_t
+__global__ __launch_bounds__(256) void ln_fold_kernel(const T* __restrict__ W, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, const float* __restrict__ b,
-                                                      bf16_t* __restrict__ Wf, float* __restrict__ colsum,
+                                                      T* __restrict__ Wf, float* __restrict__ colsum,
                                                       float* __restrict__ bf, int N, int K) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -175,11 +187,10 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const bf16_t* __restrict__
     uint32_t o[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float w0 = bf16_to_f32((bf16_t)(w[e] & 0xffff)), w1 = bf16_to_f32((bf16_t)(w[e] >> 16));
-      const bf16_t f0 = f32_to_bf16(w0 * gamma[k + 2 * e]), f1 = f32_to_bf16(w1 * gamma[k + 2 * e + 1]);
-      s += bf16_to_f32(f0) + bf16_to_f32(f1);
+      const float w0 = Half16<T>::lo(w[e]), w1 = Half16<T>::hi(w[e]);
+      o[e] = Half16<T>::pack2(w0 * gamma[k + 2 * e], w1 * gamma[k + 2 * e + 1]);
+      s += Half16<T>::lo(o[e]) + Half16<T>::hi(o[e]);        // the column sum of what the GEMM will actually multiply
       if (beta) t += w0 * beta[k + 2 * e] + w1 * beta[k + 2 * e + 1];
-      o[e] = (uint32_t)f0 | ((uint32_t)f1 << 16);
     }
     *(uint4*)(Wf + (int64_t)n * K + k) = make_uint4(o[0], o[1], o[2], o[3]);
   }
@@ -187,11 +198,15 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const bf16_t* __restrict__
   if (lane == 0) { colsum[n] = s; bf[n] = (b ? b[n] : 0.f) + t; }
 }
 
-int omk_ln_fold(const void* W, const float* gamma, const float* beta, const float* b, void* Wf,
+int omk_ln_fold(int dtype, const void* W, const float* gamma, const float* beta, const float* b, void* Wf,
                 float* colsum, float* bf, int N, int K, hipStream_t s) {
   if (K % 8 != 0) OM_FAIL("K must be a multiple of 8");
-  hipLaunchKernelGGL(ln_fold_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, (const bf16_t*)W, gamma, beta, b,
-                     (bf16_t*)Wf, colsum, bf, N, K);
+  if (dtype == OM_F16)
+    hipLaunchKernelGGL((ln_fold_kernel<f16_t>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, (const f16_t*)W, gamma, beta, b,
+                       (f16_t*)Wf, colsum, bf, N, K);
+  else
+    hipLaunchKernelGGL((ln_fold_kernel<bf16_t>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, (const bf16_t*)W, gamma, beta, b,
+                       (bf16_t*)Wf, colsum, bf, N, K);
   OM_LAUNCH_CHECK();
   return 0;
 }
@@ -349,6 +364,7 @@ int omk_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, c
     return 0;
   }
   if (dtype == OM_BF16) return launch_ln<bf16_t, bf16_t>(x, ldx, y, ldy, g, b, M, H, eps, rms, s);
+  if (dtype == OM_F16) return launch_ln<f16_t, f16_t>(x, ldx, y, ldy, g, b, M, H, eps, rms, s);
   return launch_ln<float, float>(x, ldx, y, ldy, g, b, M, H, eps, rms, s);
 }
 
@@ -364,6 +380,8 @@ int omk_embed(int dtype, const int64_t* ids, const int64_t* type_ids, const floa
                      type_ids, word, pos, type, g, b, (TT*)out, M, L, H, vocab, type_vocab, eps, bert)
   if (dtype == OM_BF16) {
     if (H <= 1024) EMBED_LAUNCH(bf16_t, 4); else EMBED_LAUNCH(bf16_t, 8);
+  } else if (dtype == OM_F16) {
+    if (H <= 1024) EMBED_LAUNCH(f16_t, 4); else EMBED_LAUNCH(f16_t, 8);
   } else {
     if (H <= 1024) EMBED_LAUNCH(float, 4); else EMBED_LAUNCH(float, 8);
   }
@@ -378,6 +396,9 @@ int omk_pool(int dtype, const void* x, const int64_t* mask, float* out, int64_t 
   if (H % 4 != 0) OM_FAIL("hidden size must be a multiple of 4");
   if (dtype == OM_BF16)
     hipLaunchKernelGGL((pool_kernel<bf16_t>), dim3((unsigned)B), dim3(256), 0, s, (const bf16_t*)x,
+                       mask, out, L, H, mode);
+  else if (dtype == OM_F16)
+    hipLaunchKernelGGL((pool_kernel<f16_t>), dim3((unsigned)B), dim3(256), 0, s, (const f16_t*)x,
                        mask, out, L, H, mode);
   else
     hipLaunchKernelGGL((pool_kernel<float>), dim3((unsigned)B), dim3(256), 0, s, (const float*)x,

@@ -46,10 +46,10 @@ extern "C" void om_invalidate_folded_weights(void) {
   }
 }
 // Wf / colsum / bf of (W, gamma, beta, b): from the cache, or computed into the caller's scratch (cache off)
-static int folded_weights(const void* W, const float* g, const float* beta, const float* b, int N, int K, void* scratch_w,
+static int folded_weights(int dt, const void* W, const float* g, const float* beta, const float* b, int N, int K, void* scratch_w,
                           float* scratch_cs, float* scratch_bf, hipStream_t s, const void** Wf, const float** cs, const float** bf) {
   if (!om_option(OM_OPT_FOLD_CACHE)) {
-    if (omk_ln_fold(W, g, beta, b, scratch_w, scratch_cs, scratch_bf, N, K, s)) return 1;
+    if (omk_ln_fold(dt, W, g, beta, b, scratch_w, scratch_cs, scratch_bf, N, K, s)) return 1;
     *Wf = scratch_w; *cs = scratch_cs; *bf = scratch_bf;
     return 0;
   }
@@ -64,7 +64,7 @@ static int folded_weights(const void* W, const float* g, const float* beta, cons
     OM_HIP(hipEventCreateWithFlags(&e.ev, hipEventDisableTiming));
   }
   if (e.epoch != g_fold_epoch) {
-    if (omk_ln_fold(W, g, beta, b, e.wf, e.colsum, e.bf, N, K, s)) return 1;
+    if (omk_ln_fold(dt, W, g, beta, b, e.wf, e.colsum, e.bf, N, K, s)) return 1;
     OM_HIP(hipEventRecord(e.ev, s));
     e.epoch = g_fold_epoch; e.stream = s;
   } else if (e.stream != s) {
@@ -86,12 +86,13 @@ struct EncWs {
 };
 
 static EncWs carve(const OmEncoderConfig* c, int64_t B, int64_t L, char* base) {
-  const size_t es = c->dtype == OM_BF16 ? 2 : 4;
+  const bool half = c->dtype == OM_BF16 || c->dtype == OM_F16;
+  const size_t es = half ? 2 : 4;
   // 16-bit batches of >= 512 tokens are padded to whole 256-row tiles: the persistent GEMM generation
   // (gemm_wide7.h) takes whole tiles only.  Rows are independent in every contraction, so whatever the pad rows
   // hold stays in the pad rows; every other kernel (embedding, attention, normalisation, pooling) sees B*L rows.
   const size_t Mreal = (size_t)B * L, H = c->hidden, F = c->ffn;
-  const size_t M = (c->dtype == OM_BF16 && Mreal >= 512) ? (Mreal + 255) / 256 * 256 : Mreal;
+  const size_t M = (half && Mreal >= 512) ? (Mreal + 255) / 256 * 256 : Mreal;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return base + o; };
   EncWs w;
@@ -106,7 +107,7 @@ static EncWs carve(const OmEncoderConfig* c, int64_t B, int64_t L, char* base) {
   w.headout = (float*)take((size_t)B * (c->head_out > 0 ? c->head_out : 1) * 4);
   w.posbias = (float*)take(c->arch == OM_ARCH_T5 ? (size_t)c->n_heads * L * L * 4 : 0);
   w.lut = (int*)take(c->arch == OM_ARCH_T5 ? (size_t)(2 * L) * 4 : 0);
-  const bool fuse = c->dtype == OM_BF16;              // fused-norm path (BERT LayerNorm / T5 RMSNorm)
+  const bool fuse = half;                             // fused-norm path (BERT LayerNorm / T5 RMSNorm)
   const size_t wide = std::max((size_t)3 * H, F);
   w.wfold = take(fuse ? wide * H * es : 0);
   w.colsum = (float*)take(fuse ? wide * 4 : 0);
@@ -138,11 +139,14 @@ extern "C" int om_t5_relative_bucket(int relative_position, int num_buckets, int
 }
 
 static int check_cfg(const OmEncoderConfig* c) {
-  if (c->dtype != OM_F32 && c->dtype != OM_BF16) OM_FAIL("dtype must be OM_F32 or OM_BF16");
+  if (c->dtype != OM_F32 && c->dtype != OM_BF16 && c->dtype != OM_F16) OM_FAIL("dtype must be OM_F32, OM_BF16 or OM_F16");
+  if (c->dtype == OM_F16 && c->arch != OM_ARCH_BERT)
+    OM_FAIL("float16 mode serves BERT-family encoders (T5 activations leave the float16 range; use OM_BF16)");
+  if (c->dtype == OM_F16 && c->act != OM_ACT_GELU_ERF) OM_FAIL("float16 mode: erf-GELU encoders only");
   if (c->arch != OM_ARCH_BERT && c->arch != OM_ARCH_T5) OM_FAIL("unknown arch");
   if (c->head_dim != 64 || c->n_heads * 64 != c->hidden)
     OM_FAIL("only head_dim 64 with n_heads*64 == hidden is supported");
-  const int es = c->dtype == OM_BF16 ? 2 : 4;
+  const int es = c->dtype == OM_F32 ? 4 : 2;
   if ((c->hidden * es) % 128 || (c->ffn * es) % 128) OM_FAIL("hidden/ffn rows must be multiples of 128 bytes");
   if (c->head_in > 0 && ((c->head_in * 4) % 128 || c->head_in != c->hidden)) OM_FAIL("head_in must equal hidden");
   return 0;
@@ -216,7 +220,7 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
         } else {
           const OmLayerWeights& pw = Ls[l - 1];
           const void* wf; const float *cs, *bfp;
-          RUN(folded_weights(lw.qkv_w, pw.ln2_g, pw.ln2_b, lw.qkv_b, 3 * H, H, ws.wfold, ws.colsum, ws.bfold, s, &wf, &cs, &bfp));
+          RUN(folded_weights(dt, lw.qkv_w, pw.ln2_g, pw.ln2_b, lw.qkv_b, 3 * H, H, ws.wfold, ws.colsum, ws.bfold, s, &wf, &cs, &bfp));
           e.bias = bfp; e.ln_stats = st2p; e.ln_colsum = cs; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps; e.reverse = OM_WALK();
           RUN(omk_gemm(dt, ws.x1, H, wf, H, dt, ws.qkv, 3 * H, Mg, 3 * H, H, e, s));
         }
@@ -234,7 +238,7 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
         RUN(omk_gemm(dt, ws.ctx, H, lw.o_w, H, dt, ws.y, H, Mg, H, H, e, s));
         // ---- FFN1 on LN1(y1), folded
         const void* wf1; const float *cs1, *bf1;
-        RUN(folded_weights(lw.ffn1_w, lw.ln1_g, lw.ln1_b, lw.ffn1_b, F, H, ws.wfold, ws.colsum, ws.bfold, s, &wf1, &cs1, &bf1));
+        RUN(folded_weights(dt, lw.ffn1_w, lw.ln1_g, lw.ln1_b, lw.ffn1_b, F, H, ws.wfold, ws.colsum, ws.bfold, s, &wf1, &cs1, &bf1));
         e = GemmEpilogue{};
         e.bias = bf1; e.act = c->act; e.ln_stats = st1; e.ln_colsum = cs1; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
         e.reverse = OM_WALK();
@@ -292,7 +296,7 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
       auto folded = [&](const void* A_, const void* W_, const float* g_, const float* stats_, void* C_, int N_, int act_,
                         const void* res_, int64_t ldr_) -> int {
         const void* wf; const float *cs, *bfp;
-        if (folded_weights(W_, g_, nullptr, nullptr, N_, H, ws.wfold, ws.colsum, ws.bfold, s, &wf, &cs, &bfp)) return 1;
+        if (folded_weights(dt, W_, g_, nullptr, nullptr, N_, H, ws.wfold, ws.colsum, ws.bfold, s, &wf, &cs, &bfp)) return 1;
         (void)cs; (void)bfp;            // RMSNorm: no mean, no shift -- only the folded weight is used
         GemmEpilogue e = {};
         e.act = act_; e.resid = res_; e.ldr = ldr_;

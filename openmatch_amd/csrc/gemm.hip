@@ -110,6 +110,8 @@ static bool wide_ok(int out_dtype, const void* C, int64_t ldc, int64_t M, int64_
 }
 
 bool omk_gemm_ln_fusable(int dtype, int64_t M, int64_t N, int64_t K) {
+  // float16 has the persistent generation only: whole 256 x 256 tiles (the encoder pads its token rows)
+  if (dtype == OM_F16) return M >= 512 && M % 256 == 0 && N % 256 == 0 && (K * 2) % 128 == 0 && gemm_variant() == 0;
   return dtype == OM_BF16 && M >= 512 && N >= 256 && N % 8 == 0 && (K * 2) % 128 == 0 && gemm_variant() != 1 &&
          gemm_variant() != 2 && gemm_variant() != 4;
 }
@@ -120,6 +122,9 @@ unsigned long long* omk_debug_trace() { return g_trace; }      // the scan kerne
 static int g_debug_gen = 0;     // 0: default selection; 6: never generation 7; 70: generation 7 with one tile per workgroup (A/B)
 extern "C" void om_debug_gemm_gen(int gen) { g_debug_gen = gen; }
 bool omk_gemm_wide7_has(int act, bool resid, int lnf);
+bool omk_gemm_wide7_f16_has(int act, bool resid, int lnf);
+int omk_gemm_wide7_f16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                       int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s);
 int omk_gemm_wide7(bool persist, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                    int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s);
 
@@ -153,6 +158,22 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
     if (gemm_variant() == 4 || gemm_variant() == 6) gen = N >= 256 ? gemm_variant() : 2;
   }
   const bool ln_fused = ep.ln_stats || ep.rln_stats || ep.stats_out;
+  if (in_dtype == OM_F16 && out_dtype == OM_F16) {
+    // float16 -> float16 (the inference encoder's float16 mode): the persistent 256 x 256 kernel where the problem is
+    // made of whole tiles, else the generic 128 / 256-row tiles; no training epilogues
+    const int act = ep.act & 0xff;
+    const bool resid = ep.resid != nullptr;
+    if (ep.pre_act != nullptr || ep.drop_p > 0.f) OM_FAIL("float16 is an inference format: no training epilogue");
+    const int lnf = ep.ln_stats ? 1 : ((ep.rln_stats || ep.stats_out) ? 2 : 0);
+    const bool g7 = wide && gemm_variant() == 0 && M % 256 == 0 && N % 256 == 0 && (K * 2) % 128 == 0 &&
+                    (((uintptr_t)ep.bias & 15) == 0) && !(ep.ln_stats && (ep.rln_stats || ep.stats_out)) &&
+                    !(lnf == 2 && !ep.stats_out) && (!resid || (ep.ldr * 2) % 128 == 0) && !(ep.act & OM_ACT_MUL_RESID) &&
+                    omk_gemm_wide7_f16_has(act, resid, lnf);
+    if (g7) return omk_gemm_wide7_f16(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    if (ln_fused) OM_FAIL("float16: the fused LayerNorm epilogues need whole 256 x 256 tiles");
+    if (wide && gen != 1) return launch_gemm2<f16_t, f16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    return launch_gemm<f16_t, f16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+  }
   if (ln_fused && !(wide && in_dtype == OM_BF16 && out_dtype == OM_BF16 && N >= 256)) OM_FAIL("fused LayerNorm epilogue needs the 256x256 bf16 kernel");
   if (ln_fused) gen = 6;
   if (gen == 6) {

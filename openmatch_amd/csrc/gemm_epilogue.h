@@ -127,6 +127,21 @@ template <> struct OutVec<bf16_t> {
   }
 };
 
+template <> struct OutVec<f16_t> {
+  static constexpr int VEC = 8;
+  __device__ static inline void unpack(const uint4& u, float (&v)[8]) {
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = Half16<f16_t>::lo(w[i]); v[2 * i + 1] = Half16<f16_t>::hi(w[i]); }
+  }
+  __device__ static inline uint4 pack(const float (&v)[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = Half16<f16_t>::pack2(v[2 * i], v[2 * i + 1]);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
 struct EpiScalars {
   uint32_t drop_thresh; float drop_scale; bool train, mul; int act;
   __device__ __forceinline__ explicit EpiScalars(const GemmEpilogue& ep) {

@@ -46,7 +46,7 @@ __device__ __forceinline__ f32x2_t epi_pair(f32x2_t v, int64_t m, int64_t n, int
   if (ACT == OM_ACT_GELU_ERF && sizeof(OutT) == 2) {
     if (TRAIN) {
       if (ep.pre_act && m < M && n < N)
-        *(uint32_t*)((OutT*)ep.pre_act + m * ep.ldp + n) = pack_bf16x2(v[0], v[1]);
+        *(uint32_t*)((OutT*)ep.pre_act + m * ep.ldp + n) = Half16<OutT>::pack2(v[0], v[1]);
     }
     v = gelu_erf_poly2(v);
     if (TRAIN) {
@@ -155,8 +155,8 @@ __device__ __forceinline__ void store_wave_tile6(f32x16_t (&acc)[4][4], int64_t 
         f32x2_t lo_ = lo, hi_ = hi;                                                                        \
         if (RES_DMA) {                                                                                     \
           const uint2 rr = rpatch[ni][j];                                                                  \
-          float r0 = bf16_to_f32((bf16_t)(rr.x & 0xffff)), r1 = bf16_to_f32((bf16_t)(rr.x >> 16));        \
-          float r2 = bf16_to_f32((bf16_t)(rr.y & 0xffff)), r3 = bf16_to_f32((bf16_t)(rr.y >> 16));        \
+          float r0 = Half16<OutT>::lo(rr.x), r1 = Half16<OutT>::hi(rr.x);                                  \
+          float r2 = Half16<OutT>::lo(rr.y), r3 = Half16<OutT>::hi(rr.y);                                  \
           if (res_ln) {                                                                                    \
             const f32x4_t g4 = *(const f32x4_t*)&gbtab[LNF == 2 ? wave_ : 0][0][ni * 32 + 8 * j + 4 * half];              \
             const f32x4_t b4 = *(const f32x4_t*)&gbtab[LNF == 2 ? wave_ : 0][1][ni * 32 + 8 * j + 4 * half];              \
@@ -175,7 +175,7 @@ __device__ __forceinline__ void store_wave_tile6(f32x16_t (&acc)[4][4], int64_t 
         }                                                                                                  \
         char* dst = lds_wr + (ni * 32 + 8 * j) * SB;                                                       \
         if (PROBE & 1) { asm volatile("" :: "v"(lo_), "v"(hi_)); }                                         \
-        else if (STAGE16) *(uint2*)dst = make_uint2(pack_bf16x2(lo_[0], lo_[1]), pack_bf16x2(hi_[0], hi_[1])); \
+        else if (STAGE16) *(uint2*)dst = make_uint2(Half16<OutT>::pack2(lo_[0], lo_[1]), Half16<OutT>::pack2(hi_[0], hi_[1])); \
         else *(f32x4_t*)dst = (f32x4_t){lo_[0], lo_[1], hi_[0], hi_[1]};                                   \
       }                                                                                                    \
     if (stats_out) {          /* the other half of the row sits in lane ^ 32; one atomic pair per row */  \

@@ -157,8 +157,7 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
       const bool ln_in = LNF == 1 && ep.ln_stats != nullptr;
       const bool has_cs = LNF == 1 && ep.ln_colsum != nullptr, has_b = ep.bias != nullptr;
       auto split = [](float x, uint32_t& hi, uint32_t& lo) {
-        const bf16_t h = f32_to_bf16(x);
-        hi = h; lo = f32_to_bf16(x - bf16_to_f32(h));
+        hi = Half16<T>::bits(x); lo = Half16<T>::bits(x - Half16<T>::value(hi));
       };
       frag_t fa[4], fb[4];
 #pragma unroll
@@ -263,8 +262,8 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
         f32x2_t hi_ = epi_pair<ACT, false, OutT>(a_hi, m, n + 2, M, N, ep, es, 0, 0);                                \
         if (RESID) {                                                                                           \
           const uint2 rr = rpatch[nl][j];                                                                      \
-          float r0 = bf16_to_f32((bf16_t)(rr.x & 0xffff)), r1 = bf16_to_f32((bf16_t)(rr.x >> 16));            \
-          float r2 = bf16_to_f32((bf16_t)(rr.y & 0xffff)), r3 = bf16_to_f32((bf16_t)(rr.y >> 16));            \
+          float r0 = Half16<OutT>::lo(rr.x), r1 = Half16<OutT>::hi(rr.x);                                      \
+          float r2 = Half16<OutT>::lo(rr.y), r3 = Half16<OutT>::hi(rr.y);                                      \
           if (res_ln) {                                                                                        \
             const f32x4_t g4 = *(const f32x4_t*)(etab + (ni * 32 + 8 * j + 4 * half) * 4);                     \
             const f32x4_t b4 = *(const f32x4_t*)(etab + 512 + (ni * 32 + 8 * j + 4 * half) * 4);               \
@@ -281,7 +280,7 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
           ssum += lo_ + hi_;                                                                                   \
           ssq = __builtin_elementwise_fma(lo_, lo_, __builtin_elementwise_fma(hi_, hi_, ssq));                 \
         }                                                                                                      \
-        *(uint2*)(st_wr + (((nl * 4 + j) ^ skey) << 4)) = make_uint2(pack_bf16x2(lo_[0], lo_[1]), pack_bf16x2(hi_[0], hi_[1])); \
+        *(uint2*)(st_wr + (((nl * 4 + j) ^ skey) << 4)) = make_uint2(Half16<OutT>::pack2(lo_[0], lo_[1]), Half16<OutT>::pack2(hi_[0], hi_[1])); \
       }                                                                                                        \
     if (LNF == 2 && NH == 1) {      /* both column halves of the row block done: one atomic pair per row */     \
       float s1 = ssum[0] + ssum[1], s2 = ssq[0] + ssq[1];                                                      \

@@ -3,7 +3,7 @@
 #include "common.h"
 
 // LayerNorm folded into the consuming bf16 weight (elementwise.hip)
-int omk_ln_fold(const void* W, const float* gamma, const float* beta, const float* b, void* Wf,
+int omk_ln_fold(int dtype /* OM_BF16 | OM_F16 */, const void* W, const float* gamma, const float* beta, const float* b, void* Wf,
                 float* colsum, float* bf, int N, int K, hipStream_t s);
 int omk_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* g,
                   const float* b, int64_t M, int H, float eps, int rms, hipStream_t s);

@@ -17,15 +17,38 @@ _ACT = {"gelu": N.ACT_GELU_ERF, "relu": N.ACT_RELU, "gelu_new": N.ACT_GELU_TANH,
 
 
 def compute_dtype_code(model_args=None):
-    """bf16 MFMA when the caller asked for 16-bit compute the way the reference does
-    (`--fp16` -> torch autocast in retriever/dense_retriever.py:76, or ModelArguments.dtype),
-    exact f32 MFMA otherwise."""
+    """The compute format the caller asked for, the way the reference asks: `--fp16` -> torch autocast in
+    retriever/dense_retriever.py:76 (float16 on a GPU), or ModelArguments.dtype.  float16 and bfloat16 both run on the
+    16-bit MFMA path at the same rate; float32 on the exact f32 MFMA path."""
     if torch.is_autocast_enabled():
-        return N.OM_BF16
+        return N.OM_F16 if torch.get_autocast_dtype("cuda") == torch.float16 else N.OM_BF16
     dt = getattr(model_args, "dtype", None) if model_args is not None else None
-    if dt in ("bfloat16", "float16", "bf16", "fp16"):
+    if dt in ("float16", "fp16"):
+        return N.OM_F16
+    if dt in ("bfloat16", "bf16"):
         return N.OM_BF16
     return N.OM_F32
+
+
+def torch_dtype_of(code):
+    return {N.OM_BF16: torch.bfloat16, N.OM_F16: torch.float16}.get(code, torch.float32)
+
+
+def inference_code(model, code, seq_len):
+    """float16 is served where it is safe and built: BERT-family encoders with erf-GELU, up to 256 tokens (three more
+    mantissa bits than bfloat16 in every stored activation, same speed).  Everywhere else -- T5 (activations leave the
+    float16 range), other activations, longer sequences -- a 16-bit request means bfloat16."""
+    if code != N.OM_F16:
+        return code
+    cfg = getattr(model, "config", None)
+    if _arch_of(model) != "bert" or _ACT.get(getattr(cfg, "hidden_act", None)) != N.ACT_GELU_ERF or seq_len > 256:
+        return N.OM_BF16
+    return code
+
+
+def training_code(code):
+    """Training runs in bfloat16 or float32 (float16 would need loss scaling; the backward kernels are bfloat16)."""
+    return N.OM_BF16 if code == N.OM_F16 else code
 
 
 class _Packed:
@@ -71,7 +94,7 @@ def _pack_bert(model, code, device):
     cfg = model.config
     if getattr(cfg, "position_embedding_type", "absolute") != "absolute":
         raise NotImplementedError("only absolute position embeddings are supported")
-    wd = torch.bfloat16 if code == N.OM_BF16 else torch.float32
+    wd = torch_dtype_of(code)
     f32 = torch.float32
     pk = _Packed()
     emb = model.embeddings
@@ -116,7 +139,7 @@ def _pack_t5(model, code, device):
     cfg = model.config
     if cfg.num_heads * cfg.d_kv != cfg.d_model:
         raise NotImplementedError("T5 with inner_dim != d_model is not supported")
-    wd = torch.bfloat16 if code == N.OM_BF16 else torch.float32
+    wd = torch_dtype_of(code)
     f32 = torch.float32
     pk = _Packed()
     enc = model.encoder
@@ -155,7 +178,7 @@ def _pack_t5_decoder(model, code, device):
     """Decoder-side weights of a T5Model / T5ForConditionalGeneration for om_t5_decoder_step (one decoder position:
     self-attention needs only v, o; cross-attention k | v fused to [2H, H])."""
     cfg = model.config
-    wd = torch.bfloat16 if code == N.OM_BF16 else torch.float32
+    wd = torch_dtype_of(code)
     f32 = torch.float32
     pk = _Packed()
     dec = model.decoder
@@ -236,6 +259,7 @@ def hip_encode(model, items, pooling, head, normalize, code, want_hidden=True):
         tti = tti.to(device=ids.device, dtype=torch.int64).contiguous()
     N.require_device(ids, mask, tti)
     device = ids.device
+    code = inference_code(model, code, ids.shape[1])
     pk = packed_weights(model, head, code, device)
     cfg = N.OmEncoderConfig(pooling=_POOL[pooling], normalize=int(bool(normalize)), **pk.cfg)
     B, L = ids.shape
@@ -248,7 +272,7 @@ def hip_encode(model, items, pooling, head, normalize, code, want_hidden=True):
         hidden = None
         if want_hidden:
             hidden = torch.empty(B, L, H, device=device,
-                                 dtype=torch.bfloat16 if code == N.OM_BF16 else torch.float32)
+                                 dtype=torch_dtype_of(code))
         reps = torch.empty(B, D, device=device, dtype=torch.float32) if pooling is not None else None
         N.check(lib.om_encoder_forward(C.byref(cfg), C.byref(pk.weights), N.ptr(ids), N.ptr(mask),
                                        N.ptr(tti), B, L, N.ptr(hidden), N.ptr(reps),
@@ -262,6 +286,7 @@ def hip_t5_decoder_step(model, items, code):
     (modeling/dense_retrieval_model.py:137-141).  Encoder through om_encoder_forward, decoder through om_t5_decoder_step."""
     if not hasattr(model, "decoder") or not hasattr(model, "encoder"):
         raise ValueError("an encoder-decoder T5 model is required")
+    code = training_code(code)             # T5: a 16-bit request means bfloat16 (inference_code)
     enc_hidden, _ = hip_encode(model, items, None, None, False, code, want_hidden=True)
     device = enc_hidden.device
     mask = items["attention_mask"].to(device=device, dtype=torch.int64).contiguous()

@@ -66,7 +66,7 @@ class Retriever:
 
     # ------------------------------------------------------------------ encoding
     def _autocast(self):
-        return torch.autocast("cuda", dtype=torch.bfloat16) if getattr(self.args, "fp16", False) else nullcontext()
+        return torch.autocast("cuda", dtype=torch.float16) if getattr(self.args, "fp16", False) else nullcontext()
 
     def _encode_loop(self, dataset, is_query):
         loader = DataLoader(

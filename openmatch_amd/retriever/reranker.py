@@ -83,7 +83,7 @@ class Reranker:
                                            num_processes=a.world_size, process_index=a.process_index)
         loader = DataLoader(dataset, batch_size=a.eval_batch_size, collate_fn=RRInferenceCollator(),
                             num_workers=a.dataloader_num_workers, pin_memory=a.dataloader_pin_memory)
-        cast = torch.autocast("cuda", dtype=torch.bfloat16) if getattr(a, "fp16", False) else nullcontext()
+        cast = torch.autocast("cuda", dtype=torch.float16) if getattr(a, "fp16", False) else nullcontext()
         with torch.no_grad():
             for qids, dids, batch in tqdm(loader, desc="Reranking", disable=a.local_process_index > 0):
                 with cast:

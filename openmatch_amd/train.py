@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import native as N
-from .encoder import _POOL, _arch_of, packed_weights, position_offset
+from .encoder import _POOL, _arch_of, packed_weights, position_offset, training_code
 
 
 def _bert_params(model, head):
@@ -162,6 +162,7 @@ class _EncoderTrain(torch.autograd.Function):
 def encode_train(model, head, items, pooling, normalize, code, training):
     """(None, reps) with an autograd edge from `reps` to every encoder / head parameter.
     Dropout follows the HF config only in training mode (model.train())."""
+    code = training_code(code)
     ids = items["input_ids"].to(torch.int64).contiguous()
     mask = items["attention_mask"].to(device=ids.device, dtype=torch.int64).contiguous()
     tti = items.get("token_type_ids") if hasattr(items, "get") else None

@@ -62,6 +62,41 @@ def test_encoder_bf16_close_to_reference_fixture(golden, name, arch, gated):
         assert cos.min() > 0.999, cos
 
 
+@pytest.mark.parametrize("name,arch,gated", [c for c in CASES if c[1] == "bert"][:3])
+def test_encoder_f16_close_to_reference_fixture(golden, name, arch, gated):
+    """float16 MFMA mode (the reference's `--fp16` is torch.cuda.amp float16) vs the f32 reference: 11 mantissa bits in
+    every stored activation -- cosine >= 0.99999 per embedding on the small fixtures (generic GEMM tiles, unfused
+    LayerNorm: these batches are below the persistent kernel's whole-tile shapes)."""
+    g = golden(name)
+    model = build_drmodel(g, arch, gated, dtype="float16")
+    for kind in ("p", "q"):
+        hidden, reps = model.encode_passage(items_from_golden(g, kind, DEV))
+        assert hidden.dtype == torch.float16
+        a, b = reps.cpu().double(), torch.from_numpy(g[kind + "_reps"]).double()
+        cos = torch.nn.functional.cosine_similarity(a, b, dim=1)
+        assert cos.min() > 0.99999, cos
+        assert (a - b).abs().max() < 2e-2 * b.abs().max(), (a - b).abs().max()
+
+
+def test_float16_request_on_t5_runs_bfloat16(golden):
+    """T5 activations leave the float16 range: a float16 request is served by the bfloat16 kernels there."""
+    name, arch, gated = [c for c in CASES if c[1] == "t5"][0]
+    g = golden(name)
+    model = build_drmodel(g, arch, gated, dtype="float16")
+    hidden, reps = model.encode_passage(items_from_golden(g, "p", DEV))
+    assert hidden.dtype == torch.bfloat16
+    cos = torch.nn.functional.cosine_similarity(reps.cpu().double(), torch.from_numpy(g["p_reps"]).double(), dim=1)
+    assert cos.min() > 0.999
+
+
+def test_autocast_float16_selects_f16_path(golden):
+    g = golden("bert_tiny_first")
+    model = build_drmodel(g, "bert", False)
+    with torch.autocast("cuda", dtype=torch.float16):
+        hidden, _ = model.encode_query(items_from_golden(g, "q", DEV))
+    assert hidden.dtype == torch.float16
+
+
 def test_autocast_selects_bf16_path(golden):
     g = golden("bert_tiny_first")
     model = build_drmodel(g, "bert", False)

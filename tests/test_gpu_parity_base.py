@@ -152,6 +152,27 @@ def test_config1_bf16_chain_within_reference_16bit_envelope(golden, tmp_path):
     assert d_mrr <= max(0.03, 4.0 * r_d_mrr), (mrr, float(g["mrr10_f32"]))
 
 
+def test_config1_f16_chain_beats_reference_16bit_envelope(golden, tmp_path):
+    """The float16 mode at the benchmarked shapes (float16 MFMA, LayerNorm fused into the GEMMs, bert-base, 512 x 128-token
+    batches): same kernels and speed as bfloat16, three more mantissa bits per stored activation.  It has to land INSIDE
+    the reference's own autocast deviation from fp32, by a wide margin (CPU emulation of the rounding points: 1 - cos
+    6e-7 against 1.6e-5 for the reference's bf16 autocast and 4.2e-5 for the bf16 path)."""
+    g = golden("config1_bert_base")
+    P, Q, I, run, mrr, _ = _chain(g, tmp_path, "float16", fp16=False)
+    cmin, cmean, ddot = _stats(P, Q, g["P_f32"], g["Q_f32"])
+    r_cmin, r_cmean, r_ddot, r_ov_mean, r_ov_min = (float(x) for x in g["ac_vs_f32"])
+    ov = [len(set(a.tolist()) & set(b.tolist())) for a, b in zip(I, g["I100_f32"])]
+    d_mrr, r_d_mrr = abs(mrr - float(g["mrr10_f32"])), abs(float(g["mrr10_ac"]) - float(g["mrr10_f32"]))
+    scale = float(np.abs(g["Q_f32"] @ g["P_f32"].T).max())
+    print(f"\n[config 1, f16 fused path] vs reference fp32: min cos {cmin:.8f} (reference autocast {r_cmin:.6f}), mean cos {cmean:.8f} ({r_cmean:.6f}), "
+          f"max|ddot| {ddot:.4f} = {ddot / scale:.2e} relative ({r_ddot:.4f}), top-100 overlap mean {np.mean(ov):.1f} min {min(ov)} ({r_ov_mean:.1f} / {r_ov_min:.0f}), "
+          f"|dMRR@10| {d_mrr:.4f} ({r_d_mrr:.4f})")
+    assert 1.0 - cmin <= 0.25 * (1.0 - r_cmin), (cmin, r_cmin)
+    assert ddot <= 2e-4 * scale, (ddot, scale)             # dot products within 2e-4 relative
+    assert np.mean(ov) >= r_ov_mean and min(ov) >= r_ov_min, (np.mean(ov), min(ov))
+    assert d_mrr <= max(0.01, r_d_mrr), (mrr, float(g["mrr10_f32"]))
+
+
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
 def test_gtr_base_sized_t5_matches_reference(golden, dtype):
     """BASELINE config 4's model: T5 encoder 12 x 768 (relu), mean pooling, 768 -> 768 head, L2-normalised."""
@@ -179,7 +200,7 @@ def test_gtr_base_sized_t5_matches_reference(golden, dtype):
         assert 1.0 - cmin <= 4.0 * (1.0 - r_cmin) and ddot <= 4.0 * r_ddot
 
 
-@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
 def test_bert_large_cross_encoder_matches_reference(golden, dtype):
     """BASELINE config 5's model: bert-large (24 x 1024) RRModel, 162-token pairs in the reference's
     single-sequence format, LinearHead(1024, 1)."""
@@ -203,5 +224,7 @@ def test_bert_large_cross_encoder_matches_reference(golden, dtype):
     print(f"\n[bert-large RR, {dtype}] max|dscore| {err:.2e} (reference autocast {r_err:.2e}, |score| <= {scale:.2f}); rank order agreement {order_same:.2f}")
     if dtype == "float32":
         assert err < 1e-4
+    elif dtype == "float16":
+        assert err <= 0.5 * r_err                  # inside the reference's own 16-bit deviation
     else:
         assert err <= 4.0 * r_err

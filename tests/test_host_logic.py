@@ -318,3 +318,24 @@ def test_one_pass_rule_for_tied_training_batches():
         assert not tied._one_pass_ok(mk(8, 32), mk(64, 128))
     assert not tied.eval()._one_pass_ok(mk(8, 32), mk(64, 128))
     assert not DRModel(lm_q=lm, lm_p=other, tied=False, **args).train()._one_pass_ok(mk(8, 32), mk(64, 128))
+
+
+def test_compute_format_resolution():
+    """float16 requests: served as float16 for BERT-family erf-GELU encoders up to 256 tokens, as bfloat16 elsewhere
+    (T5, other activations, longer sequences, every training path)."""
+    from types import SimpleNamespace as NS
+    from transformers import BertConfig, BertModel, T5Config, T5EncoderModel
+    from openmatch_amd import native as N
+    from openmatch_amd.encoder import compute_dtype_code, inference_code, training_code, torch_dtype_of
+    assert compute_dtype_code(NS(dtype="float16")) == N.OM_F16 and compute_dtype_code(NS(dtype="fp16")) == N.OM_F16
+    assert compute_dtype_code(NS(dtype="bfloat16")) == N.OM_BF16 and compute_dtype_code(NS(dtype="float32")) == N.OM_F32
+    assert compute_dtype_code(None) == N.OM_F32
+    bert = BertModel(BertConfig(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128))
+    relu = BertModel(BertConfig(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128, hidden_act="relu"))
+    t5 = T5EncoderModel(T5Config(d_model=64, d_ff=128, num_layers=1, num_heads=1, d_kv=64))
+    assert inference_code(bert, N.OM_F16, 128) == N.OM_F16 and inference_code(bert, N.OM_F16, 256) == N.OM_F16
+    assert inference_code(bert, N.OM_F16, 384) == N.OM_BF16
+    assert inference_code(relu, N.OM_F16, 128) == N.OM_BF16 and inference_code(t5, N.OM_F16, 128) == N.OM_BF16
+    assert inference_code(t5, N.OM_BF16, 128) == N.OM_BF16 and inference_code(bert, N.OM_F32, 512) == N.OM_F32
+    assert training_code(N.OM_F16) == N.OM_BF16 and training_code(N.OM_F32) == N.OM_F32
+    assert torch_dtype_of(N.OM_F16) == torch.float16 and torch_dtype_of(N.OM_BF16) == torch.bfloat16 and torch_dtype_of(N.OM_F32) == torch.float32
