@@ -78,6 +78,43 @@ def test_encoder_f16_close_to_reference_fixture(golden, name, arch, gated):
         assert (a - b).abs().max() < 2e-2 * b.abs().max(), (a - b).abs().max()
 
 
+@pytest.mark.parametrize("L,n", [(24, 40), (48, 24), (128, 8), (200, 6), (256, 4)])
+def test_f16_fused_path_tracks_f32_path_across_lengths(L, n):
+    """float16 mode on whole-tile shapes (hidden 256: the persistent GEMM with the fused-LayerNorm epilogues and every
+    key-tile count of the attention kernel) against the exact-f32 HIP path (itself pinned to the reference fixtures):
+    ragged batches, cosine and relative error of the pooled embeddings; the same inputs in bfloat16 for scale."""
+    from transformers import BertConfig, BertModel
+    from openmatch.modeling import DRModelForInference
+    torch.manual_seed(7 + L)
+    cfg = BertConfig(hidden_size=256, num_hidden_layers=3, num_attention_heads=4, intermediate_size=1024, vocab_size=600,
+                     max_position_embeddings=256)
+    lm = BertModel(cfg).eval()
+    with torch.no_grad():                      # trained-checkpoint-like LayerNorm affines and biases, not the 1 / 0 of an init
+        for name, p in lm.named_parameters():
+            if "LayerNorm.weight" in name:
+                p.copy_(1.0 + 0.3 * torch.randn_like(p))
+            elif "bias" in name:
+                p.copy_(0.1 * torch.randn_like(p))
+    rng = np.random.default_rng(L)
+    ids, mask = synth_tokens(rng, n, L, vocab=600, lo_len=max(2, L // 3), lo_id=300)
+    ids[0, :], mask[0, :] = rng.integers(300, 600, L), 1
+    items = {"input_ids": torch.from_numpy(ids).to(DEV), "attention_mask": torch.from_numpy(mask).to(DEV)}
+    outs = {}
+    for dtype in ("float32", "float16", "bfloat16"):
+        model = DRModelForInference(lm_q=lm, lm_p=lm, pooling="mean", model_args=NS(encoder_only=False, dtype=dtype)).to(DEV).eval()
+        hidden, reps = model.encode_passage(items)
+        assert hidden.dtype == {"float32": torch.float32, "float16": torch.float16, "bfloat16": torch.bfloat16}[dtype]
+        outs[dtype] = reps.double().cpu()
+    ref = outs["float32"]
+    cos16 = torch.nn.functional.cosine_similarity(outs["float16"], ref, dim=1).min().item()
+    cosb = torch.nn.functional.cosine_similarity(outs["bfloat16"], ref, dim=1).min().item()
+    rel16 = ((outs["float16"] - ref).abs().max() / ref.abs().max()).item()
+    relb = ((outs["bfloat16"] - ref).abs().max() / ref.abs().max()).item()
+    print(f"\n[f16 vs f32 path, L={L}, {n * L} tokens] 1 - cos {1 - cos16:.2e} (bf16 {1 - cosb:.2e}); max rel err {rel16:.2e} (bf16 {relb:.2e})")
+    assert 1 - cos16 < 5e-6 and rel16 < 5e-3, (cos16, rel16)
+    assert (1 - cos16) < 0.25 * (1 - cosb) + 1e-7, (cos16, cosb)
+
+
 def test_float16_request_on_t5_runs_bfloat16(golden):
     """T5 activations leave the float16 range: a float16 request is served by the bfloat16 kernels there."""
     name, arch, gated = [c for c in CASES if c[1] == "t5"][0]
