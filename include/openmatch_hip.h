@@ -155,7 +155,7 @@ typedef struct OmLayerWeights {
 typedef struct OmEncoderConfig {
   int arch;          /* OM_ARCH_*                                                 */
   int dtype;         /* compute dtype of matrices/activations: OM_F32 | OM_BF16 | OM_F16 (OM_F16: om_encoder_forward only,
-                      * BERT-family erf-GELU encoders, sequences up to 256 tokens -- the reference's `--fp16` is torch.cuda.amp
+                      * BERT-family erf-GELU encoders -- the reference's `--fp16` is torch.cuda.amp
                       * float16, retriever/dense_retriever.py:76; same kernels and MFMA rate as OM_BF16, 11-bit mantissas) */
   int hidden;        /* H                                                         */
   int n_layers;

@@ -593,7 +593,10 @@ int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
   if (H != heads * 64) OM_FAIL("head_dim must be 64");
   if (B * heads > 0x7fffffffLL) OM_FAIL("batch too large for one launch");
   if (dtype == OM_F16) {                                      // float16 inference mode: the fast kernel only
-    if (L > 256) OM_FAIL("float16 mode supports sequences up to 256 tokens");
+    if (L > 256) {
+      if (drop_p > 0.f || pos_bias) OM_FAIL("float16 attention: inference without a position-bias table only");
+      return launch_attn_long<f16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
+    }
     if (L <= 32) return launch_attn16<f16_t, 1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
     if (L <= 64) return launch_attn16<f16_t, 2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
     if (L <= 128) return launch_attn16<f16_t, 4>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);

@@ -9,6 +9,11 @@ template <> struct AttnGeom<bf16_t> {
   __device__ static inline int key(int row) { return (row >> 1) & 7; }
   __device__ static inline float exp_(float x) { return __expf(x); }
 };
+template <> struct AttnGeom<f16_t> {              // IEEE half: the same geometry as bfloat16
+  static constexpr int ROWB = 128, CPR = 8, EPC = 8, NKK = 4;
+  __device__ static inline int key(int row) { return (row >> 1) & 7; }
+  __device__ static inline float exp_(float x) { return __expf(x); }
+};
 template <> struct AttnGeom<float> {
   static constexpr int ROWB = 256, CPR = 16, EPC = 4, NKK = 8;
   __device__ static inline int key(int row) { return row & 15; }
@@ -40,6 +45,28 @@ template <> struct SlabMma<bf16_t> {
         vb[0] = v0[0]; vb[1] = v0[1]; vb[2] = v0[2]; vb[3] = v0[3];
         vb[4] = v1[0]; vb[5] = v1[1]; vb[6] = v1[2]; vb[7] = v1[3];
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[u], vb, o[dt], 0, 0, 0);
+      }
+  }
+};
+template <> struct SlabMma<f16_t> {
+  __device__ static inline void run(const f32x16_t& a, const f16_t* bt, int LP, f32x16_t (&o)[2]) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+    f16x8_t pa[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pa[u][j] = (f16_t)a[8 * u + j];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f16_t* p = bt + dt * 32 * LP + 16 * u;
+        const f16x4_t v0 = *(const f16x4_t*)p;
+        const f16x4_t v1 = *(const f16x4_t*)(p + 8);
+        f16x8_t vb;
+        vb[0] = v0[0]; vb[1] = v0[1]; vb[2] = v0[2]; vb[3] = v0[3];
+        vb[4] = v1[0]; vb[5] = v1[1]; vb[6] = v1[2]; vb[7] = v1[3];
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[u], vb, o[dt], 0, 0, 0);
       }
   }
 };

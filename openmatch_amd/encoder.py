@@ -35,13 +35,13 @@ def torch_dtype_of(code):
 
 
 def inference_code(model, code, seq_len):
-    """float16 is served where it is safe and built: BERT-family encoders with erf-GELU, up to 256 tokens (three more
-    mantissa bits than bfloat16 in every stored activation, same speed).  Everywhere else -- T5 (activations leave the
-    float16 range), other activations, longer sequences -- a 16-bit request means bfloat16."""
+    """float16 is served where it is safe and built: BERT-family encoders with erf-GELU (three more mantissa bits than
+    bfloat16 in every stored activation, same speed).  Everywhere else -- T5 (activations leave the float16 range),
+    other activations -- a 16-bit request means bfloat16."""
     if code != N.OM_F16:
         return code
     cfg = getattr(model, "config", None)
-    if _arch_of(model) != "bert" or _ACT.get(getattr(cfg, "hidden_act", None)) != N.ACT_GELU_ERF or seq_len > 256:
+    if _arch_of(model) != "bert" or _ACT.get(getattr(cfg, "hidden_act", None)) != N.ACT_GELU_ERF:
         return N.OM_BF16
     return code
 

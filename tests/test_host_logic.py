@@ -321,8 +321,8 @@ def test_one_pass_rule_for_tied_training_batches():
 
 
 def test_compute_format_resolution():
-    """float16 requests: served as float16 for BERT-family erf-GELU encoders up to 256 tokens, as bfloat16 elsewhere
-    (T5, other activations, longer sequences, every training path)."""
+    """float16 requests: served as float16 for BERT-family erf-GELU encoders, as bfloat16 elsewhere (T5, other
+    activations, every training path)."""
     from types import SimpleNamespace as NS
     from transformers import BertConfig, BertModel, T5Config, T5EncoderModel
     from openmatch_amd import native as N
@@ -334,7 +334,7 @@ def test_compute_format_resolution():
     relu = BertModel(BertConfig(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128, hidden_act="relu"))
     t5 = T5EncoderModel(T5Config(d_model=64, d_ff=128, num_layers=1, num_heads=1, d_kv=64))
     assert inference_code(bert, N.OM_F16, 128) == N.OM_F16 and inference_code(bert, N.OM_F16, 256) == N.OM_F16
-    assert inference_code(bert, N.OM_F16, 384) == N.OM_BF16
+    assert inference_code(bert, N.OM_F16, 512) == N.OM_F16
     assert inference_code(relu, N.OM_F16, 128) == N.OM_BF16 and inference_code(t5, N.OM_F16, 128) == N.OM_BF16
     assert inference_code(t5, N.OM_BF16, 128) == N.OM_BF16 and inference_code(bert, N.OM_F32, 512) == N.OM_F32
     assert training_code(N.OM_F16) == N.OM_BF16 and training_code(N.OM_F32) == N.OM_F32
