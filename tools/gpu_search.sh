@@ -4,7 +4,7 @@ R=$PWD; O=$R/gpurun_out/search; mkdir -p $O
 export LD_LIBRARY_PATH=$R/openmatch_amd/csrc:$LD_LIBRARY_PATH
 timeout 300 $R/build/selftest full > $O/full.log 2>&1; echo "selftest rc=$?" >> $O/full.log
 timeout 600 python -m pytest tests -m gpu -q -k "search or topk or index or retriev or drivers" > $O/pytest_search.log 2>&1; echo "rc=$?" >> $O/pytest_search.log
-timeout 600 python tools/search_shapes.py --queries 256 1024 6980 > $O/search_shapes.jsonl 2>$O/search_shapes.err
+timeout 600 python tools/search_shapes.py --queries 1 8 32 64 256 1024 6980 > $O/search_shapes.jsonl 2>$O/search_shapes.err
 cd /tmp; export TMPDIR=/tmp
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/tools/search_shapes.py --queries 6980 > $O/fetch.log 2>&1
 cd $R
