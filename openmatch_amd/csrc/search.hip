@@ -510,10 +510,12 @@ __global__ __launch_bounds__(SORT_THREADS) void select_kernel(
 // than the 8192-key bitonic sort it replaces between rounds (profiles/r01_bench_v8_kernel_stats.csv: 8 x 2.3 ms).
 __global__ __launch_bounds__(256) void select_radix_kernel(
     u64* __restrict__ keys, unsigned* __restrict__ cnt, float* __restrict__ thr, const float* __restrict__ margin,
-    int k, unsigned* __restrict__ flag) {
+    int k, unsigned* __restrict__ flag, int cap) {
+  // cap: keys the LDS copy holds (SORT_CAP, or less when the host expects short lists: 64 KiB of LDS per workgroup
+  // leaves two workgroups per CU, 32 KiB four -- this kernel is a chain of barriers and wants the occupancy)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u64* s = (u64*)smem;
-  unsigned* hist = (unsigned*)(smem + SORT_CAP * 8);          // 256 bins
+  unsigned* hist = (unsigned*)(smem + (size_t)cap * 8);       // 256 bins
   unsigned* misc = hist + 256;                                // [0] bucket, [1] remaining, [2] keep counter, [4..7] wave totals
   const int64_t q = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -523,12 +525,17 @@ __global__ __launch_bounds__(256) void select_radix_kernel(
     n = SORT_CAP;
   }
   u64* list = keys + q * SORT_CAP;
-  for (unsigned i = tid; i < n; i += 256) s[i] = list[i];
+  // a list longer than the LDS copy (rare: the host sizes `cap` with a 2x margin) is read from global memory in every
+  // pass (64 KiB, L2-resident) and only the survivors are staged
+  const bool staged = n <= (unsigned)cap;
+  const u64* src = staged ? (const u64*)s : (const u64*)list;
+  if (staged)
+    for (unsigned i = tid; i < n; i += 256) s[i] = list[i];
   if (tid == 0) misc[2] = 0;
   __syncthreads();
   if (n <= (unsigned)k) {                                     // nothing to cut: keep everything
     float mn = INFINITY;
-    for (unsigned i = tid; i < n; i += 256) mn = fminf(mn, key_score(s[i]));
+    for (unsigned i = tid; i < n; i += 256) mn = fminf(mn, key_score(src[i]));
     mn = -wave_max(-mn);
     float* wmin = (float*)(misc + 4);
     if (lane == 0) wmin[wave] = mn;
@@ -550,7 +557,7 @@ __global__ __launch_bounds__(256) void select_radix_kernel(
     hist[tid] = 0;
     __syncthreads();
     for (unsigned i = tid; i < n; i += 256) {
-      const uint32_t v = (uint32_t)(s[i] >> 32);
+      const uint32_t v = (uint32_t)(src[i] >> 32);
       if ((v & mask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
     }
     __syncthreads();
@@ -576,11 +583,28 @@ __global__ __launch_bounds__(256) void select_radix_kernel(
   }
   const float kth = orderable_f32(prefix);
   const float cut = margin ? kth - 2.0f * margin[q] : kth;
-  for (unsigned i = tid; i < n; i += 256) {
-    const u64 key = s[i];
-    if (key_score(key) >= cut) list[atomicAdd(&misc[2], 1u)] = key;
+  if (staged) {
+    for (unsigned i = tid; i < n; i += 256) {
+      const u64 key = s[i];
+      if (key_score(key) >= cut) list[atomicAdd(&misc[2], 1u)] = key;
+    }
+    __syncthreads();
+  } else {                                                    // in place is not safe without the copy: survivors via LDS
+    for (unsigned i = tid; i < n; i += 256) {
+      const u64 key = list[i];
+      if (key_score(key) >= cut) {
+        const unsigned pos = atomicAdd(&misc[2], 1u);
+        if (pos < (unsigned)cap) s[pos] = key;
+      }
+    }
+    __syncthreads();
+    if (misc[2] > (unsigned)cap) {                            // cannot happen below LIST_MAX ties; treated as an overflow
+      if (tid == 0) { atomicOr(flag, 1u); misc[2] = (unsigned)cap; }
+      __syncthreads();
+    }
+    for (unsigned i = tid; i < misc[2]; i += 256) list[i] = s[i];
+    __syncthreads();
   }
-  __syncthreads();
   if (tid == 0) {
     const unsigned keep = misc[2];
     cnt[q] = keep;
@@ -764,15 +788,15 @@ struct Scan {
     OM_LAUNCH_CHECK();
     return 0;
   }
-  int select_radix(bool certified) {
-    hipLaunchKernelGGL(select_radix_kernel, dim3((unsigned)nq), dim3(256), SORT_CAP * 8 + 1024 + 64, s,
-                       ws.keys, ws.cnt, ws.thr, certified ? ws.margin : nullptr, k, ws.flag);
+  int select_radix(bool certified, int cap = SORT_CAP) {
+    hipLaunchKernelGGL(select_radix_kernel, dim3((unsigned)nq), dim3(256), (size_t)cap * 8 + 1024 + 64, s,
+                       ws.keys, ws.cnt, ws.thr, certified ? ws.margin : nullptr, k, ws.flag, cap);
     OM_LAUNCH_CHECK();
     return 0;
   }
   int read_flags(unsigned (&f)[4]) {
     static thread_local unsigned* pinned = nullptr;        // page-locked: the copy is one DMA, no staging through the runtime
-    if (!pinned) OM_HIP(hipHostMalloc((void**)&pinned, 64, hipHostMallocDefault));
+    if (!pinned) OM_HIP(hipHostMalloc((void**)&pinned, 64, hipHostMallocPortable));
     OM_HIP(hipMemcpyAsync(pinned, ws.flag, sizeof(f), hipMemcpyDeviceToHost, s));
     OM_HIP(hipStreamSynchronize(s));
     for (int i = 0; i < 4; ++i) f[i] = pinned[i];
@@ -883,7 +907,7 @@ struct Scan {
     bool careful = true;
     if (om_option(OM_OPT_SCAN_GEN7) && N > DENSE_CHUNK) {
       if (dense_gemm_append(0, DENSE_CHUNK, bf16)) return 1;
-      if (select_radix(bf16)) return 1;
+      if (select_radix(bf16, DENSE_CHUNK <= 4096 ? 4096 : SORT_CAP)) return 1;
       g_info[1]++;
       const int64_t list = bf16 ? (int64_t)k * 13 / 10 + 64 : (int64_t)k + 16;       // estimate (certified: + the margin's ties)
       // few queries: the scan is one HBM pass whatever the thresholds, the per-round launches are what costs -- few, long
@@ -892,6 +916,9 @@ struct Scan {
       const double growth = nq <= 32 ? 400.0 : (double)std::max(5, om_option(OM_OPT_SCAN_GROWTH));
       const double room = 0.75 * (double)(SORT_CAP - list);
       const double want = std::min(room, (double)list * growth / 100.0);
+      // selection launches of the rounds: lists are ~list + want keys long; when twice that margin fits 4096 keys the
+      // LDS copy is sized for 4096 (four workgroups per CU instead of two); a longer list is read from global memory
+      const int sel_cap = (double)list + 2.0 * want + 256.0 < 4096.0 ? 4096 : SORT_CAP;
       int64_t at = DENSE_CHUNK;
       while (at < N) {
         int64_t chunk = (int64_t)((double)at * want / (double)list);
@@ -899,7 +926,7 @@ struct Scan {
         chunk = std::min<int64_t>(chunk, N - at);
         if (N - at - chunk < chunk / 4) chunk = N - at;           // no sliver of a last round
         if (filter_step(at, chunk, bf16, false)) return 1;
-        if (select_radix(bf16)) return 1;
+        if (select_radix(bf16, sel_cap)) return 1;
         g_info[1]++;
         at += chunk;
       }
