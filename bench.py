@@ -332,8 +332,8 @@ def main():
         except Exception:
             traffic = None
     roofline = {
-        "kernel": ("gemm_nt_kernel7<bf16> (persistent 256x256 tiles, 128-byte K steps; encoder QKV / out-proj / FFN contractions, "
-                   "three epilogue variants)" if half else "gemm_nt_kernel6<f32> (exact-f32 MFMA)"),
+        "kernel": ("gemm_nt_kernel7<%s> (persistent 256x256 tiles, 128-byte K steps; encoder QKV / out-proj / FFN contractions, "
+                   "three epilogue variants)" % a.precision if half else "gemm_nt_kernel6<f32> (exact-f32 MFMA)"),
         "bound": "mfma", "achieved": round(gemm_tflops, 1), "peak": peak, "unit": "TFLOP/s",
         "frac": round(gemm_tflops / peak, 4), "traffic": traffic,
         "traffic_source": tsrc,
