@@ -598,12 +598,14 @@ __global__ __launch_bounds__(256) void select_radix_kernel(
       }
     }
     __syncthreads();
-    if (misc[2] > (unsigned)cap) {                            // cannot happen below LIST_MAX ties; treated as an overflow
-      if (tid == 0) { atomicOr(flag, 1u); misc[2] = (unsigned)cap; }
-      __syncthreads();
+    unsigned kept = misc[2];                                  // one value for the whole workgroup (no writer until the barrier below)
+    if (kept > (unsigned)cap) {                               // masses of ties (duplicated rows): treated as an overflow
+      if (tid == 0) atomicOr(flag, 1u);
+      kept = (unsigned)cap;
     }
-    for (unsigned i = tid; i < misc[2]; i += 256) list[i] = s[i];
+    for (unsigned i = tid; i < kept; i += 256) list[i] = s[i];
     __syncthreads();
+    if (tid == 0) misc[2] = kept;                             // read back by this same thread below
   }
   if (tid == 0) {
     const unsigned keep = misc[2];

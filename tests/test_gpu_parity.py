@@ -301,6 +301,32 @@ def test_flat_ip_search_matches_oracle(precision, n, nq, k, clustered):
     assert np.abs(D[:, :kk] - exact).max() < 1e-4 * max(1.0, np.abs(exact).max())
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16_rescore"])
+@pytest.mark.parametrize("nq", [4, 64])
+def test_flat_ip_search_with_heavily_duplicated_rows(precision, nq):
+    """Collisions: 60 000 rows that are 40 distinct vectors, 1 500 shuffled copies each.  Every score level is a 1 500-way
+    exact tie, so the filtered scan's candidate lists fill with ties (longer than the selection kernel's LDS copy, then
+    past the list capacity) and the fast schedule has to hand over to the step-by-step path.  The result must still be
+    exact: scores equal to the oracle's, ids any members of the tied groups (fp64-adjudicated)."""
+    from openmatch_amd.index import FlatIPIndex
+    rng = np.random.default_rng(11 + nq)
+    d, groups, copies, k = 768, 40, 1500, 1000
+    base = rng.standard_normal((groups, d)).astype(np.float32)
+    P = np.repeat(base, copies, axis=0)[rng.permutation(groups * copies)]
+    Q = (base[rng.integers(0, groups, nq)] + 0.5 * rng.standard_normal((nq, d))).astype(np.float32)
+    idx = FlatIPIndex(d, device=DEV, precision=precision)
+    idx.add(P)
+    D, I = idx.search(Q, k)
+    ref = flatip.IndexFlatIP(d); ref.add(P)
+    Dr, Ir = ref.search(Q, k)
+    assert (np.diff(D, axis=1) <= 0).all()
+    assert np.abs(D - Dr).max() <= 1e-4 * np.abs(Dr).max(), np.abs(D - Dr).max()
+    n_exact, n_tie, n_bad, detail = _adjudicate(I, Ir, P, Q, k)
+    print(f"[{precision}, duplicated rows, Q={nq}] id sets identical for {n_exact}/{nq}, tie-only {n_tie}, wrong {n_bad}; {idx.last_search_info}")
+    assert n_bad == 0, detail
+    assert all(len(set(row.tolist())) == k for row in I)          # no id returned twice
+
+
 def test_search_properties_at_scale():
     """Size-independent properties on a 1M x 768 shard (too big for the CPU oracle in seconds):
     every row retrieves itself first; results are sorted; both precisions return the same ids."""
