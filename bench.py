@@ -301,6 +301,21 @@ def main():
         return model(passage=batches[i % len(batches)]).p_reps
 
     # ---------------- encode leg: W warm-up, K timed steps -------------------------------
+    # Time-based pre-warm ahead of the counted warm-up: the first pass of a process carries the
+    # one-off work (weight packing, folded-LayerNorm cache, workspace allocation) and a fresh box may still be raising
+    # its clocks -- encode until three consecutive step times agree within 2 % (at least 0.3 s, capped at 3 s).
+    # profiles/r03_cold_step_series.json: on a fresh box only the first pass differs (40 ms, then 24.1-24.3 ms).
+    prewarm_ms = []
+    t_pw = time.perf_counter()
+    while True:
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        step(len(prewarm_ms))
+        torch.cuda.synchronize()
+        prewarm_ms.append((time.perf_counter() - t1) * 1e3)
+        spent = time.perf_counter() - t_pw
+        last = prewarm_ms[-3:]
+        if spent >= 3.0 or (spent >= 0.3 and len(last) == 3 and max(last) <= 1.02 * min(last)):
+            break
     for i in range(a.warmup):
         step(i)
     barrier_sync(world)
@@ -469,7 +484,11 @@ def main():
             "metric": "passages/sec encode (bert-base DPR bi-encoder, 128 tok -> 768-d) "
                       "[+ queries/sec exact top-1000 over 8.8M x 768 in `search`]",
             "value": round(passages_per_s, 1), "unit": "passages/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(t_enc / a.steps * 1e3, 3), "higher_is_better": True,
+            "warmup": a.warmup, "ms_per_step": round(t_enc / a.steps * 1e3, 3),
+            "cold_first_pass_ms": round(prewarm_ms[0], 2),
+            "prewarm": {"passes": len(prewarm_ms), "seconds": round(sum(prewarm_ms) / 1e3, 3), "last_ms": round(prewarm_ms[-1], 3),
+                        "rule": "untimed passes until 3 consecutive agree within 2 % (>= 0.3 s, <= 3 s), before the W counted warm-up steps"},
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": "bert-base DPR bi-encoder encode+search, MS MARCO 8.8M x 128-tok -> 768-d (BASELINE configs[1])",
                        "passages_per_step_per_gpu": a.batch, "seq_len": L, "global_batch": a.batch * world,
