@@ -223,6 +223,22 @@ def parity_leg(model_bf16, lm, batches, device, index=None, queries=None, topk=1
             res[precision] = {"id_sets_identical": n_exact, "fp64_near_tie_only": n_tie, "wrong": n_bad,
                               "max_abs_score_err": float(np.abs(D.cpu().numpy() - Dr).max())}
         out["search"] = res
+        # the benchmark's OWN index and k: om_sim_topk over all rows for 256 queries against an independent device-side
+        # check (chunked torch fp32 matmul + topk, fp64 adjudication of differing sets: oracle/device_check.py)
+        from oracle import device_check
+        t0 = time.perf_counter()
+        qf = queries[:256].contiguous()
+        rows_all = index._f32[:n, :index.d]
+        D, I = index.search_device(qf, topk)
+        info = dict(index.last_search_info)
+        Dr, Ir = device_check.reference_topk(rows_all, qf, topk)
+        n_exact, n_tie, n_bad, detail = device_check.adjudicate(rows_all, qf, I, Ir, topk)
+        torch.cuda.synchronize()
+        out["search_full"] = {"rows": int(n), "queries": int(qf.shape[0]), "k": int(topk), "precision": index.precision,
+                              "id_sets_identical": n_exact, "fp64_near_tie_only": n_tie, "wrong": n_bad,
+                              "max_abs_score_err": float((D - Dr).abs().max()), "scan_info": info,
+                              "checker": "chunked torch.matmul fp32 + torch.topk on the device, fp64 adjudication of differing id sets "
+                                         "(oracle/device_check.py); %.1f s" % (time.perf_counter() - t0)}
     return out
 
 

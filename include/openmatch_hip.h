@@ -97,7 +97,10 @@ void om_debug_gemm_gen(int gen);
                                    * bit 1 no arithmetic, bit 2 no stores (results are garbage) */
 #define OM_OPT_ENCODER_PINGPONG 10 /* 1 (default): the fused bf16 encoder's kernels alternate their walk direction over the token rows so
                                    * each starts on the rows its producer wrote last (memory-side cache hits); 0: always first to last */
-#define OM_OPT_COUNT 11
+#define OM_OPT_ENCODER_TWO_PLANE 11 /* 1 (default): the fused bfloat16 BERT encoder keeps its pre-LayerNorm residual stream in TWO 16-bit
+                                   * planes (value = hi + lo; the reference's autocast keeps it in f32) -- 1 - cos against the fp32 chain
+                                   * 1e-5 instead of 4.8e-5 for +2 bytes per element at the two residual sites of a layer; 0: one plane */
+#define OM_OPT_COUNT 12
 int om_debug_option(int opt, int value);
 /* the attention kernel alone (bf16 qkv [B*L, 3H] -> ctx [B*L, H]; mask [B, L] int64), for timing: csrc/kernels.h omk_attention */
 int om_debug_attention(const void* qkv, void* ctx, const int64_t* mask, int64_t B, int L, int H, int heads, void* stream);

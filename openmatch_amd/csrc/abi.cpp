@@ -96,6 +96,8 @@ void opt_init() {
   g_opt[OM_OPT_SCAN_QGROUP] = e ? atoi(e) : 8;
   e = getenv("OM_GEMM_GROUP_M");
   g_opt[OM_OPT_GEMM_GROUP_M] = e ? atoi(e) : 8;
+  e = getenv("OM_ENCODER_TWO_PLANE");
+  g_opt[OM_OPT_ENCODER_TWO_PLANE] = e ? atoi(e) : 1;
   g_opt_init.store(true);
 }
 }  // namespace

@@ -105,10 +105,11 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_kernel(
 // bf16 rows with 16-byte accesses: 32 lanes own one row (two rows per wave), every lane holds NV
 // vectors of 8 elements.  The 8-byte accesses of the generic kernel reach ~4.1 TB/s on
 // [131072, 768]; 16-byte ones are what the memory path is built for (MI355X_MICROARCH.md).
-template <int NV>
-__global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(
-    const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ y, int64_t ldy,
-    const float* __restrict__ g, const float* __restrict__ b, int64_t M, int H, float eps, int rms) {
+template <int NV, typename TOut = bf16_t>      // TOut = float: the LAST normalisation before pooling (the reference's autocast
+__global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(     // runs layer_norm in fp32 and returns fp32)
+    const bf16_t* __restrict__ x, int64_t ldx, TOut* __restrict__ y, int64_t ldy,
+    const float* __restrict__ g, const float* __restrict__ b, int64_t M, int H, float eps, int rms,
+    const bf16_t* __restrict__ x_lo) {        // x_lo: second plane of a two-plane residual stream (value = x + x_lo), or NULL
   const int lane = threadIdx.x & 31;
   const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
   if (row >= M) return;
@@ -122,6 +123,12 @@ __global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(
       const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[j][2 * e] = bf16_to_f32((bf16_t)(w[e] & 0xffff)); v[j][2 * e + 1] = bf16_to_f32((bf16_t)(w[e] >> 16)); }
+      if (x_lo) {
+        const uint4 t2 = *(const uint4*)(x_lo + row * ldx + c * 8);
+        const uint32_t w2[4] = {t2.x, t2.y, t2.z, t2.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[j][2 * e] += bf16_to_f32((bf16_t)(w2[e] & 0xffff)); v[j][2 * e + 1] += bf16_to_f32((bf16_t)(w2[e] >> 16)); }
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
@@ -158,13 +165,20 @@ __global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(
       Vec4<float>::load(g + c * 8 + 4, *(float(*)[4])&gv[4]);
       if (b) { Vec4<float>::load(b + c * 8, *(float(*)[4])&bv[0]); Vec4<float>::load(b + c * 8 + 4, *(float(*)[4])&bv[4]); }
       uint32_t w[4];
+      float o[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float y0 = (v[j][2 * e] - mean) * rstd * gv[2 * e], y1 = (v[j][2 * e + 1] - mean) * rstd * gv[2 * e + 1];
         if (b) { y0 += bv[2 * e]; y1 += bv[2 * e + 1]; }
+        o[2 * e] = y0; o[2 * e + 1] = y1;
         w[e] = (uint32_t)f32_to_bf16(y0) | ((uint32_t)f32_to_bf16(y1) << 16);
       }
-      *(uint4*)(y + row * ldy + c * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+      if (sizeof(TOut) == 4) {
+        Vec4<float>::store((float*)y + row * ldy + c * 8, *(float(*)[4])&o[0]);
+        Vec4<float>::store((float*)y + row * ldy + c * 8 + 4, *(float(*)[4])&o[4]);
+      } else {
+        *(uint4*)(y + row * ldy + c * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
     }
   }
 }
@@ -348,16 +362,57 @@ static int launch_ln(const void* x, int64_t ldx, void* y, int64_t ldy, const flo
   return 0;
 }
 
-int omk_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* g,
-                  const float* b, int64_t M, int H, float eps, int rms, hipStream_t s) {
+// Row statistics from the slot partials a GEMM epilogue left (GemmEpilogue::stats_out): one thread per row adds the
+// slots in slot order -- the same result whatever order the tiles ran in (round 2 accumulated with f32 atomics).
+__global__ __launch_bounds__(256) void ln_stats_reduce_kernel(const float2* __restrict__ slots, int nslots, int64_t M, float2* __restrict__ out) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < nslots; ++k) { const float2 v = slots[(int64_t)k * M + m]; s1 += v.x; s2 += v.y; }
+  out[m] = make_float2(s1, s2);
+}
+int omk_ln_stats_reduce(const float* slots, int nslots, int64_t M, float* out, hipStream_t s) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(ln_stats_reduce_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, (const float2*)slots, nslots, M, (float2*)out);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+// x in the compute format (optionally two planes, bf16) -> y in f32
+int omk_layernorm_f32out(int dtype, const void* x, int64_t ldx, float* y, int64_t ldy, const float* g, const float* b,
+                         int64_t M, int H, float eps, int rms, hipStream_t s, const void* x_lo) {
   if (H % 4 != 0 || H > 64 * 4 * MAX_VEC_LIMIT) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
   if (M <= 0) return 0;
+  if (dtype == OM_BF16 && H % 8 == 0 && H <= 1024 && ldx % 8 == 0 && ldy % 4 == 0 &&
+      !(((uintptr_t)x | (uintptr_t)y | (uintptr_t)x_lo) & 15) && !(((uintptr_t)g | (uintptr_t)b) & 15)) {
+    const unsigned grid = (unsigned)((M + 7) / 8);
+    const int nv = (H / 8 + 31) / 32;
+#define LN8F(NV) hipLaunchKernelGGL((layernorm_bf16x8_kernel<NV, float>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ldx, \
+                                    y, ldy, g, b, M, H, eps, rms, (const bf16_t*)x_lo)
+    if (nv <= 1) LN8F(1); else if (nv == 2) LN8F(2); else if (nv == 3) LN8F(3); else LN8F(4);
+#undef LN8F
+    OM_LAUNCH_CHECK();
+    return 0;
+  }
+  if (x_lo) OM_FAIL("two-plane LayerNorm input: bf16 rows of whole 16-byte vectors only");
+  if (dtype == OM_BF16) return launch_ln<bf16_t, float>(x, ldx, y, ldy, g, b, M, H, eps, rms, s);
+  if (dtype == OM_F16) return launch_ln<f16_t, float>(x, ldx, y, ldy, g, b, M, H, eps, rms, s);
+  return launch_ln<float, float>(x, ldx, y, ldy, g, b, M, H, eps, rms, s);
+}
+
+int omk_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* g,
+                  const float* b, int64_t M, int H, float eps, int rms, hipStream_t s, const void* x_lo) {
+  if (H % 4 != 0 || H > 64 * 4 * MAX_VEC_LIMIT) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
+  if (M <= 0) return 0;
+  if (x_lo && !(dtype == OM_BF16 && H % 8 == 0 && H <= 1024 && ldx % 8 == 0 && ldy % 8 == 0 &&
+                !(((uintptr_t)x | (uintptr_t)y | (uintptr_t)x_lo) & 15) && !(((uintptr_t)g | (uintptr_t)b) & 15)))
+    OM_FAIL("two-plane LayerNorm input: bf16 rows of whole 16-byte vectors only");
   if (dtype == OM_BF16 && H % 8 == 0 && H <= 1024 && ldx % 8 == 0 && ldy % 8 == 0 &&
       !(((uintptr_t)x | (uintptr_t)y) & 15) && !(((uintptr_t)g | (uintptr_t)b) & 15)) {
     const unsigned grid = (unsigned)((M + 7) / 8);
     const int nv = (H / 8 + 31) / 32;
 #define LN8(NV) hipLaunchKernelGGL((layernorm_bf16x8_kernel<NV>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ldx, \
-                                   (bf16_t*)y, ldy, g, b, M, H, eps, rms)
+                                   (bf16_t*)y, ldy, g, b, M, H, eps, rms, (const bf16_t*)x_lo)
     if (nv <= 1) LN8(1); else if (nv == 2) LN8(2); else if (nv == 3) LN8(3); else LN8(4);
 #undef LN8
     OM_LAUNCH_CHECK();

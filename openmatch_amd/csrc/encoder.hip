@@ -77,10 +77,13 @@ static int folded_weights(int dt, const void* W, const float* g, const float* be
 struct EncWs {
   char *x, *y, *x1, *qkv, *ctx, *ff, *ff2;
   float *pooled, *headout, *posbias;
+  float* final32;   // 16-bit runs: the last normalisation's output in f32 for the pooling tail (CLS rows, or all rows for mean pooling)
   int* lut;
-  // fused-LayerNorm path (bf16 BERT): folded weight, its column sums and bias, two statistics buffers
+  // fused-LayerNorm path (16-bit): folded weight, its column sums and bias, two statistics buffers per layer, the slot
+  // partials one GEMM leaves (kernels.h: GemmEpilogue::stats_out), and the second plane of the two residual tensors
   char* wfold;
-  float *colsum, *bfold, *stats1, *stats2;
+  float *colsum, *bfold, *stats1, *stats2, *slots;
+  char *y_lo, *x1_lo;
   int64_t Mp;       // row count the GEMMs run on: M rounded up to whole 256-row tiles (the buffers are that tall)
   size_t total;
 };
@@ -107,14 +110,19 @@ static EncWs carve(const OmEncoderConfig* c, int64_t B, int64_t L, char* base) {
   w.headout = (float*)take((size_t)B * (c->head_out > 0 ? c->head_out : 1) * 4);
   w.posbias = (float*)take(c->arch == OM_ARCH_T5 ? (size_t)c->n_heads * L * L * 4 : 0);
   w.lut = (int*)take(c->arch == OM_ARCH_T5 ? (size_t)(2 * L) * 4 : 0);
+  w.final32 = (float*)take(half && c->pooling != OM_POOL_NONE ? (c->pooling == OM_POOL_FIRST ? (size_t)B : Mreal) * H * 4 : 0);
   const bool fuse = half;                             // fused-norm path (BERT LayerNorm / T5 RMSNorm)
   const size_t wide = std::max((size_t)3 * H, F);
   w.wfold = take(fuse ? wide * H * es : 0);
   w.colsum = (float*)take(fuse ? wide * 4 : 0);
   w.bfold = (float*)take(fuse ? wide * 4 : 0);
-  // one (sum, sum of squares) buffer per LayerNorm site, all zeroed by ONE memset per forward
+  // one (sum, sum of squares) buffer per LayerNorm site (written whole by omk_ln_stats_reduce: nothing to zero)
   w.stats1 = (float*)take(fuse ? (size_t)2 * c->n_layers * M * 8 : 0);
   w.stats2 = w.stats1 ? w.stats1 + (size_t)c->n_layers * M * 2 : nullptr;
+  w.slots = (float*)take(fuse ? (size_t)2 * ((H + 255) / 256) * M * 8 : 0);
+  const bool two = fuse && c->dtype == OM_BF16 && c->arch == OM_ARCH_BERT;
+  w.y_lo = take(two ? M * H * es : 0);
+  w.x1_lo = take(two ? M * H * es : 0);
   w.Mp = (int64_t)M;
   w.total = off;
   return w;
@@ -181,6 +189,9 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
 #define RUN(expr) do { if (expr) return 1; } while (0)
 
   char* final_hidden = nullptr;
+  // 16-bit runs that only return representations: the LAST normalisation writes f32 (the reference's autocast runs
+  // layer_norm in fp32), into ws.final32 -- B CLS rows (pooling "first": already the pooled vectors) or all M rows
+  int64_t final32_rows = 0;
   if (bert) {
     if (L > c->max_pos) OM_FAIL("sequence longer than the position table");
     RUN(omk_embed(dt, input_ids, token_type_ids, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g,
@@ -199,7 +210,10 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
     if (om_option(OM_OPT_ENCODER_DEBUG)) fprintf(stderr, "om_encoder_forward: M=%ld fused_ln=%d\n", (long)M, (int)fuse);
     if (fuse) {
       const float inv_h = 1.0f / (float)H;
-      OM_HIP(hipMemsetAsync(ws.stats1, 0, (size_t)2 * c->n_layers * Mg * 8, s));
+      // Two-plane residual stream (bfloat16): y1 = ws.y + ws.y_lo, y2 = ws.x1 + ws.x1_lo; the GEMMs that consume LN(y)
+      // as their A operand read the first plane, the residual adds and the final LayerNorm read both.
+      const bool two = dt == OM_BF16 && om_option(OM_OPT_ENCODER_TWO_PLANE) != 0;
+      const int nslots = 2 * (H / 256);
       // y1 lives in ws.y, y2 in ws.x1; ws.x is the embedding output (layer 0's input)
       // Ping-pong walk: every kernel of the chain starts on the rows its producer wrote last (reverse = 1 on every second
       // launch), so the head of each activation tensor (200-800 MB, far beyond the 32 MB of L2) is found in the 256 MB
@@ -227,15 +241,18 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
         RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, nullptr, B, (int)L, H, nh, scale, 0.f, 0, s, OM_WALK()));
         // ---- attention output + residual -> y1, statistics of LN1
         e = GemmEpilogue{};
-        e.bias = lw.o_b; e.ldr = H; e.stats_out = st1; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+        e.bias = lw.o_b; e.ldr = H; e.stats_out = ws.slots; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+        if (two) e.out_lo = ws.y_lo;
         if (l == 0) {
-          e.resid = ws.x;
+          e.resid = ws.x;                    // the embedding output: one plane
         } else {
           const OmLayerWeights& pw = Ls[l - 1];
           e.resid = ws.x1; e.rln_stats = st2p; e.rln_g = pw.ln2_g; e.rln_b = pw.ln2_b;
+          if (two) e.resid_lo = ws.x1_lo;
         }
         e.reverse = OM_WALK();
         RUN(omk_gemm(dt, ws.ctx, H, lw.o_w, H, dt, ws.y, H, Mg, H, H, e, s));
+        RUN(omk_ln_stats_reduce(ws.slots, nslots, Mg, st1, s));
         // ---- FFN1 on LN1(y1), folded
         const void* wf1; const float *cs1, *bf1;
         RUN(folded_weights(dt, lw.ffn1_w, lw.ln1_g, lw.ln1_b, lw.ffn1_b, F, H, ws.wfold, ws.colsum, ws.bfold, s, &wf1, &cs1, &bf1));
@@ -246,18 +263,26 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
         // ---- FFN2 + LN1(y1) as the residual -> y2, statistics of LN2
         e = GemmEpilogue{};
         e.bias = lw.ffn2_b; e.resid = ws.y; e.ldr = H; e.rln_stats = st1; e.rln_g = lw.ln1_g; e.rln_b = lw.ln1_b;
-        e.stats_out = st2; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+        e.stats_out = ws.slots; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+        if (two) { e.resid_lo = ws.y_lo; e.out_lo = ws.x1_lo; }
         e.reverse = OM_WALK();
         RUN(omk_gemm(dt, ws.ff, F, lw.ffn2_w, F, dt, ws.x1, H, Mg, H, F, e, s));
+        RUN(omk_ln_stats_reduce(ws.slots, nslots, Mg, st2, s));
       }
 #undef OM_WALK
       const OmLayerWeights& last = Ls[c->n_layers - 1];
-      void* dst = out_hidden ? out_hidden : (void*)ws.x;
-      if (!out_hidden && c->pooling == OM_POOL_FIRST)      // only the [CLS] rows are ever read
-        RUN(omk_layernorm(dt, ws.x1, L * H, dst, L * H, last.ln2_g, last.ln2_b, B, H, c->ln_eps, 0, s));
-      else
-        RUN(omk_layernorm(dt, ws.x1, H, dst, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, 0, s));
-      final_hidden = (char*)dst;
+      const void* lo = two ? ws.x1_lo : nullptr;
+      if (!out_hidden && c->pooling == OM_POOL_FIRST) {    // only the [CLS] rows are ever read: normalised straight into f32
+        RUN(omk_layernorm_f32out(dt, ws.x1, L * H, ws.final32, H, last.ln2_g, last.ln2_b, B, H, c->ln_eps, 0, s, lo));
+        final32_rows = B;
+      } else if (!out_hidden && c->pooling != OM_POOL_NONE) {
+        RUN(omk_layernorm_f32out(dt, ws.x1, H, ws.final32, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, 0, s, lo));
+        final32_rows = M;
+      } else {
+        void* dst = out_hidden ? out_hidden : (void*)ws.x;
+        RUN(omk_layernorm(dt, ws.x1, H, dst, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, 0, s, lo));
+        final_hidden = (char*)dst;
+      }
     } else
     for (int l = 0; l < c->n_layers; ++l) {
       const OmLayerWeights& lw = Ls[l];
@@ -267,9 +292,18 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
       RUN(omk_layernorm(dt, ws.y, H, ws.x1, H, lw.ln1_g, lw.ln1_b, M, H, c->ln_eps, 0, s));
       GEMM(ws.x1, H, lw.ffn1_w, H, ws.ff, F, F, H, lw.ffn1_b, nullptr, 0, c->act);
       GEMM(ws.ff, F, lw.ffn2_w, F, ws.y, H, H, F, lw.ffn2_b, ws.x1, H, OM_ACT_NONE);
-      void* dst = (l == c->n_layers - 1 && out_hidden) ? out_hidden : (void*)ws.x;
-      RUN(omk_layernorm(dt, ws.y, H, dst, H, lw.ln2_g, lw.ln2_b, M, H, c->ln_eps, 0, s));
-      final_hidden = (char*)dst;
+      const bool half16 = dt != OM_F32;
+      if (l == c->n_layers - 1 && half16 && !out_hidden && c->pooling == OM_POOL_FIRST) {
+        RUN(omk_layernorm_f32out(dt, ws.y, L * H, ws.final32, H, lw.ln2_g, lw.ln2_b, B, H, c->ln_eps, 0, s));
+        final32_rows = B;
+      } else if (l == c->n_layers - 1 && half16 && !out_hidden && c->pooling != OM_POOL_NONE) {
+        RUN(omk_layernorm_f32out(dt, ws.y, H, ws.final32, H, lw.ln2_g, lw.ln2_b, M, H, c->ln_eps, 0, s));
+        final32_rows = M;
+      } else {
+        void* dst = (l == c->n_layers - 1 && out_hidden) ? out_hidden : (void*)ws.x;
+        RUN(omk_layernorm(dt, ws.y, H, dst, H, lw.ln2_g, lw.ln2_b, M, H, c->ln_eps, 0, s));
+        final_hidden = (char*)dst;
+      }
     }
     if (c->n_layers == 0) final_hidden = ws.x;
   } else {
@@ -292,7 +326,7 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
     if (om_option(OM_OPT_ENCODER_DEBUG)) fprintf(stderr, "om_encoder_forward (t5): M=%ld fused_norm=%d\n", (long)M, (int)fuse_t5);
     if (fuse_t5) {
       const float inv_h = 1.0f / (float)H;
-      OM_HIP(hipMemsetAsync(ws.stats1, 0, (size_t)2 * c->n_layers * Mg * 8, s));
+      const int nslots = 2 * (H / 256);
       auto folded = [&](const void* A_, const void* W_, const float* g_, const float* stats_, void* C_, int N_, int act_,
                         const void* res_, int64_t ldr_) -> int {
         const void* wf; const float *cs, *bfp;
@@ -315,8 +349,9 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
         }
         RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, ws.posbias, B, (int)L, H, nh, 1.0f, 0.f, 0, s));
         GemmEpilogue e = {};
-        e.resid = ws.x; e.ldr = H; e.stats_out = st1; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+        e.resid = ws.x; e.ldr = H; e.stats_out = ws.slots; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
         RUN(omk_gemm(dt, ws.ctx, H, lw.o_w, H, dt, ws.x, H, Mg, H, H, e, s));           // x += o(ctx), sum(x^2)
+        RUN(omk_ln_stats_reduce(ws.slots, nslots, Mg, st1, s));
         if (lw.ffn1g_w) {
           RUN(folded(ws.x, lw.ffn1g_w, lw.ln2_g, st1, ws.ff2, F, OM_ACT_NONE, nullptr, 0));
           RUN(folded(ws.x, lw.ffn1_w, lw.ln2_g, st1, ws.ff, F, c->act | OM_ACT_MUL_RESID, ws.ff2, F));
@@ -324,8 +359,9 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
           RUN(folded(ws.x, lw.ffn1_w, lw.ln2_g, st1, ws.ff, F, c->act, nullptr, 0));
         }
         e = GemmEpilogue{};
-        e.resid = ws.x; e.ldr = H; e.stats_out = st2; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
+        e.resid = ws.x; e.ldr = H; e.stats_out = ws.slots; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
         RUN(omk_gemm(dt, ws.ff, F, lw.ffn2_w, F, dt, ws.x, H, Mg, H, F, e, s));         // x += wo(ff), sum(x^2)
+        RUN(omk_ln_stats_reduce(ws.slots, nslots, Mg, st2, s));
       }
     } else
     for (int l = 0; l < c->n_layers; ++l) {
@@ -343,15 +379,28 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
       }
       GEMM(ws.ff, F, lw.ffn2_w, F, ws.x, H, H, F, nullptr, ws.x, H, OM_ACT_NONE);  // x += wo(ff)
     }
-    void* dst = out_hidden ? out_hidden : (void*)ws.y;
-    RUN(omk_layernorm(dt, ws.x, H, dst, H, w->final_ln_g, nullptr, M, H, c->ln_eps, 1, s));
-    final_hidden = (char*)dst;
+    if (dt != OM_F32 && !out_hidden && c->pooling == OM_POOL_FIRST) {
+      RUN(omk_layernorm_f32out(dt, ws.x, L * H, ws.final32, H, w->final_ln_g, nullptr, B, H, c->ln_eps, 1, s));
+      final32_rows = B;
+    } else if (dt != OM_F32 && !out_hidden && c->pooling != OM_POOL_NONE) {
+      RUN(omk_layernorm_f32out(dt, ws.x, H, ws.final32, H, w->final_ln_g, nullptr, M, H, c->ln_eps, 1, s));
+      final32_rows = M;
+    } else {
+      void* dst = out_hidden ? out_hidden : (void*)ws.y;
+      RUN(omk_layernorm(dt, ws.x, H, dst, H, w->final_ln_g, nullptr, M, H, c->ln_eps, 1, s));
+      final_hidden = (char*)dst;
+    }
   }
 
   if (c->pooling != OM_POOL_NONE) {
     const bool head = c->head_in > 0 && w->head_w;
     float* pooled = head ? ws.pooled : out_reps;
-    RUN(omk_pool(dt, final_hidden, attention_mask, pooled, B, (int)L, H, c->pooling, s));
+    if (final32_rows == B && c->pooling == OM_POOL_FIRST)
+      OM_HIP(hipMemcpyAsync(pooled, ws.final32, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));
+    else if (final32_rows == M)
+      RUN(omk_pool(OM_F32, ws.final32, attention_mask, pooled, B, (int)L, H, c->pooling, s));
+    else
+      RUN(omk_pool(dt, final_hidden, attention_mask, pooled, B, (int)L, H, c->pooling, s));
     int D = H;
     if (head) {
       D = c->head_out;

@@ -109,11 +109,13 @@ static bool wide_ok(int out_dtype, const void* C, int64_t ldc, int64_t M, int64_
   return true;
 }
 
+static int g_debug_gen_value();
 bool omk_gemm_ln_fusable(int dtype, int64_t M, int64_t N, int64_t K) {
   // float16 has the persistent generation only: whole 256 x 256 tiles (the encoder pads its token rows)
   if (dtype == OM_F16) return M >= 512 && M % 256 == 0 && N % 256 == 0 && (K * 2) % 128 == 0 && gemm_variant() == 0;
-  return dtype == OM_BF16 && M >= 512 && N >= 256 && N % 8 == 0 && (K * 2) % 128 == 0 && gemm_variant() != 1 &&
-         gemm_variant() != 2 && gemm_variant() != 4;
+  // bfloat16 likewise since round 3: the fused-LayerNorm epilogues (slot statistics, two-plane residual) exist in
+  // generation 7 only
+  return dtype == OM_BF16 && M >= 512 && M % 256 == 0 && N % 256 == 0 && (K * 2) % 128 == 0 && gemm_variant() == 0 && g_debug_gen_value() != 6;
 }
 
 static unsigned long long* g_trace = nullptr;
@@ -121,6 +123,7 @@ extern "C" void om_debug_gemm_trace(unsigned long long* buf) { g_trace = buf; }
 unsigned long long* omk_debug_trace() { return g_trace; }      // the scan kernel of search.hip stamps into the same buffer
 static int g_debug_gen = 0;     // 0: default selection; 6: never generation 7; 70: generation 7 with one tile per workgroup (A/B)
 extern "C" void om_debug_gemm_gen(int gen) { g_debug_gen = gen; }
+static int g_debug_gen_value() { return g_debug_gen; }
 bool omk_gemm_wide7_has(int act, bool resid, int lnf);
 bool omk_gemm_wide7_f16_has(int act, bool resid, int lnf);
 int omk_gemm_wide7_f16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
@@ -165,6 +168,7 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
     const bool resid = ep.resid != nullptr;
     if (ep.pre_act != nullptr || ep.drop_p > 0.f) OM_FAIL("float16 is an inference format: no training epilogue");
     const int lnf = ep.ln_stats ? 1 : ((ep.rln_stats || ep.stats_out) ? 2 : 0);
+    if (ep.out_lo || ep.resid_lo) OM_FAIL("float16: the two-plane residual stream is a bfloat16 feature");
     const bool g7 = wide && gemm_variant() == 0 && M % 256 == 0 && N % 256 == 0 && (K * 2) % 128 == 0 &&
                     (((uintptr_t)ep.bias & 15) == 0) && !(ep.ln_stats && (ep.rln_stats || ep.stats_out)) &&
                     !(lnf == 2 && !ep.stats_out) && (!resid || (ep.ldr * 2) % 128 == 0) && !(ep.act & OM_ACT_MUL_RESID) &&
@@ -187,8 +191,9 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
     else if (g_debug_gen != 6 && gemm_variant() == 0 && in_dtype == OM_BF16 && out_dtype == OM_BF16 && !train && M % 256 == 0 &&
              N % 256 == 0 && (K * 2) % 128 == 0 && !(ep.ln_stats && (ep.rln_stats || ep.stats_out)) &&
              !((ep.rln_stats || ep.stats_out) && !ep.stats_out) && (!resid || (ep.ldr * 2) % 128 == 0) &&
-             omk_gemm_wide7_has(act, resid, ep.ln_stats ? 1 : ((ep.rln_stats || ep.stats_out) ? 2 : 0)))
+             omk_gemm_wide7_has(act, resid, ep.ln_stats ? 1 : ((ep.rln_stats || ep.stats_out) ? (ep.out_lo ? 3 : 2) : 0)))
       return omk_gemm_wide7(g_debug_gen != 70, A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    else if (ln_fused) OM_FAIL("fused LayerNorm epilogue: whole 256 x 256 tiles of bf16, inference only (generation 7)");
     else if (omk_gemm_wide6_b16_has(in_dtype, out_dtype, act, train, resid))
       return omk_gemm_wide6_b16(in_dtype, A, lda, B, ldb, out_dtype, C, ldc, M, N, K, ep, s);
     else if (omk_gemm_wide6_f32_has(in_dtype, out_dtype, act, train, resid))

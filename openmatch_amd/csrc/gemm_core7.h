@@ -24,6 +24,12 @@
 #include "gemm_core6.h"
 
 #define G7_ROW_BYTES 128
+// Developer probe (tools/gemm7_probe.hip only; 0 in the product): switches parts of the tile off to attribute its cycles.
+//   1 no output stores   2 no epilogue LDS staging   4 no epilogue at all   8 no K-loop DMA   16 no fragment reads
+//   32 no MFMA   64 no K-loop barrier
+#ifndef G7_ABL
+#define G7_ABL 0
+#endif
 #define G7_UNIT_BYTES (256 * G7_ROW_BYTES)     // 32 KiB
 #define G7_UNITS 5
 #define G7_LDS_BYTES (G7_UNITS * G7_UNIT_BYTES)   // 160 KiB: the whole LDS
@@ -87,6 +93,40 @@ __device__ __forceinline__ void g7_fill(const char* base, const uint32_t (&off)[
   for (int i = 0; i < 8; ++i) g7_dma(base, off[i], lds + i * 4096);
 }
 
+// Whole tiles only (the persistent GEMM: M, N multiples of 256): instruction i's lane offset is instruction 0's plus
+// i * 32 rows -- the swizzle term ((r >> 1) & 7) does not depend on i -- so ONE VGPR per operand and a scalar stride
+// replace the eight offsets of G7Src (14 VGPRs that the deferred output vectors of gemm_wide7.h need).
+struct G7SrcU {
+  const char* a;
+  const char* b;
+  uint32_t oa0, ob0;    // per lane: row ((wave * 8) + (lane >> 3)), swizzled chunk
+  uint32_t sa, sb;      // 32 rows of A / B in bytes (wave-uniform)
+};
+template <typename T>
+__device__ __forceinline__ void g7_offsets_u(G7SrcU& src, int64_t lda, int64_t ldb, int wave, int lane) {
+  const int r = wave * 8 + (lane >> 3);
+  const int c = (lane & 7) ^ ((r >> 1) & 7);
+  src.oa0 = (uint32_t)(r * lda * (int64_t)sizeof(T)) + c * 16;
+  src.ob0 = (uint32_t)(r * ldb * (int64_t)sizeof(T)) + c * 16;
+  src.sa = (uint32_t)(32 * lda * (int64_t)sizeof(T));
+  src.sb = (uint32_t)(32 * ldb * (int64_t)sizeof(T));
+}
+__device__ __forceinline__ void g7_issue_a(const G7Src& s, const char* base, int i, uint32_t lds) { g7_dma(base, s.oa[i], lds); }
+__device__ __forceinline__ void g7_issue_b(const G7Src& s, const char* base, int i, uint32_t lds) { g7_dma(base, s.ob[i], lds); }
+__device__ __forceinline__ void g7_issue_a(const G7SrcU& s, const char* base, int i, uint32_t lds) { g7_dma(base + (size_t)((uint32_t)i * s.sa), s.oa0, lds); }
+__device__ __forceinline__ void g7_issue_b(const G7SrcU& s, const char* base, int i, uint32_t lds) { g7_dma(base + (size_t)((uint32_t)i * s.sb), s.ob0, lds); }
+// all eight DMA instructions of one operand unit from a compact descriptor
+__device__ __forceinline__ void g7_fill_a(const G7SrcU& s, const char* base, char* unit, int wave) {
+  const uint32_t lds = g7_lds_addr(unit) + wave * 1024;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) g7_issue_a(s, base, i, lds + i * 4096);
+}
+__device__ __forceinline__ void g7_fill_b(const G7SrcU& s, const char* base, char* unit, int wave) {
+  const uint32_t lds = g7_lds_addr(unit) + wave * 1024;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) g7_issue_b(s, base, i, lds + i * 4096);
+}
+
 // K steps 0 and 1 of a tile into units 0-3 (32 DMA instructions per wave).
 __device__ __forceinline__ void g7_begin(const G7Src& src, int nk, char* smem, int wave) {
   g7_fill(src.a, src.oa, smem, wave);
@@ -99,10 +139,8 @@ __device__ __forceinline__ void g7_begin(const G7Src& src, int nk, char* smem, i
 
 // The K loop of one tile whose steps 0 and 1 are in flight (g7_begin, nk >= 2).  acc as in gemm_core6.h:
 //   acc[mi][ni][r] = C[m0 + wm*128 + mi*32 + (lane&31)][n0 + wn*128 + ni*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)]
-// BPOS selects where sub-step 3 puts the eight B(t+2) DMA issues (A/B measurements): 0 = behind MFMAs 8-15,
-// 1 = behind the odd MFMAs 1,3,..,15 (sharing a gap with a fragment read in the first half).
-template <typename T, int BPOS = 0>
-__device__ inline void gemm_mainloop7_run(const G7Src& src, int nk, char* smem,
+template <typename T, typename SRC = G7Src>
+__device__ __forceinline__ void gemm_mainloop7_run(const SRC& src, int nk, char* smem,
                                           f32x16_t (&acc)[4][4], unsigned long long* tr = nullptr,
                                           bool stores_pending = false) {
   typedef typename MmaOps<T>::frag_t frag_t;
@@ -138,41 +176,51 @@ __device__ inline void gemm_mainloop7_run(const G7Src& src, int nk, char* smem,
   for (int i = 0; i < 4; ++i) b0[i] = *(const frag_t*)(smem + u_bc + rowb + i * 32 * G7_ROW_BYTES + slot[0]);
 
 #define G7_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define G7_DMA(P, I, UNIT) g7_dma(k##P, src.o##P[I], lds0 + (UNIT) + ((I) * 4 + wave) * 1024)
+#define G7_DMA(P, I, UNIT) do { if (!(G7_ABL & 8)) g7_issue_##P(src, k##P, I, lds0 + (UNIT) + ((I) * 4 + wave) * 1024); } while (0)
   // one k sub-step: 16 MFMAs from (AF, BF); the first eight each cover one fragment read into (AN, BN) from
-  // (UA, UB) chunk SLOT; DMA issues of operand P into UNIT per DPOS: 1 = MFMAs 8,10,12,14 -> instructions
-  // DBASE..DBASE+3;  2 = MFMAs 8..15 -> 0..7;  3 = MFMAs 1,3,..,15 -> 0..7
-#define G7_SUB(AF, BF, AN, BN, UA, UB, SLOT, DO_READ, DPOS, P, UNIT, DBASE)                              \
+  // (UA, UB) chunk SLOT; MFMAs 8, 10, 12, 14 each cover one DMA issue of operand P into UNIT (instructions
+  // DBASE .. DBASE + 3) when the wave-uniform COND holds
+#define G7_SUB(AF, BF, AN, BN, UA, UB, SLOT, DO_READ, DPOS, P, UNIT, DBASE, COND)                        \
   _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                       \
-    MmaOps<T>::mma(BF[q & 3], AF[q >> 2], acc[q >> 2][q & 3]);                                           \
-    if (q < 8 && (DO_READ)) {                                                                            \
+    if (!(G7_ABL & 32)) MmaOps<T>::mma(BF[q & 3], AF[q >> 2], acc[q >> 2][q & 3]);                       \
+    if (q < 8 && (DO_READ) && !(G7_ABL & 16)) {                                                          \
       if (q < 4) AN[q] = *(const frag_t*)(smem + (UA) + rowa + q * 32 * G7_ROW_BYTES + (SLOT));          \
       else BN[q - 4] = *(const frag_t*)(smem + (UB) + rowb + (q - 4) * 32 * G7_ROW_BYTES + (SLOT));      \
     }                                                                                                    \
-    if ((DPOS) == 1 && q >= 8 && !(q & 1)) G7_DMA(P, (DBASE) + ((q - 8) >> 1), UNIT);                    \
-    if ((DPOS) == 2 && q >= 8) G7_DMA(P, q - 8, UNIT);                                                   \
-    if ((DPOS) == 3 && (q & 1)) G7_DMA(P, q >> 1, UNIT);                                                 \
+    if ((DPOS) == 1 && q >= 8 && !(q & 1)) { if (COND) G7_DMA(P, (DBASE) + ((q - 8) >> 1), UNIT); }      \
     G7_FENCE();                                                                                          \
   }
-#define G7_STEP(ISSUE, NEXT)                                                                             \
+  // Even schedule (round 3): FOUR issues behind every sub-step (round 2: eight back-to-back B issues in sub-step 3):
+  //     sub-step 0   B(t+1) instructions 4-7 -> B_nxt   (the half the previous step's sub-step 3 left out)
+  //     sub-step 1   A(t+2) instructions 0-3 -> spare
+  //     sub-step 2   A(t+2) instructions 4-7 -> spare
+  //     barrier      vmcnt(8): everything but A(t+2) has landed -- B(t+1)'s second half is >= 2 sub-steps old
+  //     sub-step 3   B(t+2) instructions 0-3 -> A_cur
+  // ONE step body for the whole loop: whether a step still issues (t + 2 < nk) and whether the previous step issued the
+  // first half of B(t+1) are wave-uniform run-time flags (a scalar branch around each DMA), and the last step reads
+  // "next" fragments nobody uses.  Peeled first / last steps cost 7 KiB of code each, and kernels past ~40 KiB ran three to
+  // four times slower (instruction cache; profiles/r03_gemm7_ablation_v0.log vs the peeled build).
+#define G7_STEP(ISSUE, B2H)                                                                              \
   do {                                                                                                   \
     if (tr && tid == 0 && t < 12) tr[3 + t] = clock64();                                                 \
-    G7_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[1], true, (ISSUE) ? 1 : 0, a, u_sp, 0)                      \
-    G7_SUB(a1, b1, a0, b0, u_ac, u_bc, slot[2], true, (ISSUE) ? 1 : 0, a, u_sp, 4)                      \
-    G7_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[3], true, 0, a, u_sp, 0)                                    \
-    /* step t+1 has landed (only A(t+2) may be outstanding) and my reads of A(t), B(t) are done */       \
+    { const char* const kb_cur = kb; kb -= G7_ROW_BYTES;                                                 \
+      G7_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[1], true, 1, b, u_bn, 4, B2H)                              \
+      kb = kb_cur; }                                                                                     \
+    G7_SUB(a1, b1, a0, b0, u_ac, u_bc, slot[2], true, 1, a, u_sp, 0, ISSUE)                              \
+    G7_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[3], true, 1, a, u_sp, 4, ISSUE)                              \
     if (ISSUE) __builtin_amdgcn_s_waitcnt(0x0078); else __builtin_amdgcn_s_waitcnt(0x0070);             \
-    __builtin_amdgcn_s_barrier();                                                                        \
+    if (!(G7_ABL & 64)) __builtin_amdgcn_s_barrier();                                                    \
     G7_FENCE();                                                                                          \
-    G7_SUB(a1, b1, a0, b0, u_an, u_bn, slot[0], NEXT, (ISSUE) ? (BPOS ? 3 : 2) : 0, b, u_ac, 0)         \
+    G7_SUB(a1, b1, a0, b0, u_an, u_bn, slot[0], true, 1, b, u_ac, 0, ISSUE)                              \
     { const int o_ac = u_ac, o_bc = u_bc; u_ac = u_an; u_bc = u_bn; u_an = u_sp; u_bn = o_ac; u_sp = o_bc; } \
     ka += G7_ROW_BYTES; kb += G7_ROW_BYTES;                                                              \
   } while (0)
 
-  int t = 0;
-  for (; t + 2 < nk; ++t) G7_STEP(true, true);
-  if (t + 1 < nk) { G7_STEP(false, true); ++t; }
-  G7_STEP(false, false);
+  for (int t = 0; t < nk; ++t) {
+    const bool issue = t + 2 < nk;
+    const bool b2h = t > 0 && t + 1 < nk;
+    G7_STEP(issue, b2h);
+  }
 #undef G7_STEP
 #undef G7_SUB
 #undef G7_DMA

@@ -22,6 +22,15 @@
 //   (the spare unit, A of step 2) is issued after that barrier, so it cannot overwrite a table that is still needed.
 // One patch = 32 rows x 64 columns (8 per wave tile): staged as packed bf16 (row = 128 B, 16-byte chunk XOR
 // (row & 7)), read back row-major, stored as whole 128-byte lines.
+//
+// LNF == 3 (round 3): the LNF == 2 epilogue on a TWO-PLANE residual stream.  The pre-LayerNorm sums y are stored as
+// y_hi = round16(y) (the plane the next GEMM reads as its A operand) and y_lo = round16(y - y_hi) (ep.out_lo); the
+// residual is read as r_hi + r_lo (ep.resid_lo).  The reference's autocast keeps that stream in f32
+// (HF:models/bert/modeling_bert.py:289-293,347-351 under torch.autocast); one 16-bit plane was the single reason the
+// fused path sat at 1 - cos 4.8e-5 against the reference's own 1.8e-5 (tools/emulate_16bit_dataflow.py: 1.1e-5 with the
+// second plane).  LDS of this variant: residual ring of TWO entries, each 4 KiB hi + 4 KiB lo, in the wave's 16 slices
+// of U2 / U3; the staging patch moves to the upper half of U4 (4 KiB per wave at 16 KiB + wave * 4 KiB, plain rows of
+// 128 B) and is used twice per patch (hi, then lo -- a wave's LDS operations execute in order).
 #pragma once
 #include "gemm_core7.h"
 #include "gemm_epilogue6.h"
@@ -95,7 +104,9 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
     int64_t M, int64_t N, int64_t K, GemmEpilogue ep, int group_m) {
   typedef T OutT;
   static_assert(sizeof(T) == 2, "16-bit in, 16-bit out");
-  static_assert(LNF != 2 || RESID, "the output-side LayerNorm variant adds a residual");
+  static_assert(LNF < 2 || RESID, "the output-side LayerNorm variants add a residual");
+  constexpr bool LNO = LNF >= 2;               // output side: normalised residual + row statistics of the output
+  constexpr bool TWO = LNF == 3;               // ... on a two-plane (hi + lo) residual stream
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -103,21 +114,21 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
   const int64_t ntm = M / 256, ntn = N / 256;
   const int nk = (int)((K * 2) / G7_ROW_BYTES);
   const EpiScalars es(ep);
-  constexpr int R = RESID ? 4 : 0;             // DMA instructions per residual patch
+  constexpr int R = RESID ? (TWO ? 8 : 4) : 0; // DMA instructions per residual patch
   constexpr int TI = LNF == 1 ? 2 : 1;         // ... of the next tile's init tables
-  constexpr int A2 = LNF == 2 ? 2 : 0;         // row-statistics atomics behind every second patch
+  constexpr int A2 = LNO ? 1 : 0;              // one row-statistics store behind every second patch
   constexpr int PF = 16;                       // ... of the next tile's first K step
 
   int it = 0;
   int64_t m0, n0;
   if (!g7_tile(0, ntm, ntn, group_m, m0, n0)) return;
-  G7Src src;                                   // per-lane offsets once; only the two tile bases change
-  g7_offsets<T>(src, lda, ldb, wave, lane0);
+  G7SrcU src;                                  // per-lane offsets once; only the two tile bases change
+  g7_offsets_u<T>(src, lda, ldb, wave, lane0);
   src.a = (const char*)(A + m0 * lda);
   src.b = (const char*)(B + n0 * ldb);
   g7_init_tables<LNF>(ep, A, smem, m0 + wm * 128, n0 + wn * 128, wave, lane0);
-  g7_fill(src.a, src.oa, smem, wave);
-  g7_fill(src.b, src.ob, smem + G7_UNIT_BYTES, wave);
+  g7_fill_a(src, src.a, smem, wave);
+  g7_fill_b(src, src.b, smem + G7_UNIT_BYTES, wave);
   bool pending = false;                        // the previous epilogue's 32 stores may still be in flight
 
   for (;;) {
@@ -132,8 +143,8 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
     // (U2 / U3: this wave's epilogue buffers were exactly the slices its own DMA instructions fill -- no barrier)
     if (pending) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (nk > 1) {
-      g7_fill(src.a + G7_ROW_BYTES, src.oa, smem + 2 * G7_UNIT_BYTES, wave);
-      g7_fill(src.b + G7_ROW_BYTES, src.ob, smem + 3 * G7_UNIT_BYTES, wave);
+      g7_fill_a(src, src.a + G7_ROW_BYTES, smem + 2 * G7_UNIT_BYTES, wave);
+      g7_fill_b(src, src.b + G7_ROW_BYTES, smem + 3 * G7_UNIT_BYTES, wave);
     }
     // my tables (and K step 0) have landed: only K step 1 and the previous tile's stores are younger
     if (pending) { if (nk > 1) G7_WAIT_VM(48); else G7_WAIT_VM(32); }
@@ -191,7 +202,7 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
 #pragma unroll
       for (int q = 0; q < 16; ++q) { acc[q >> 2][q & 3] = zero; MmaOps<T>::mma(fb[q & 3], fa[q >> 2], acc[q >> 2][q & 3]); }
     }
-    gemm_mainloop7_run<T, 0>(src, nk, smem, acc, tr, pending);     // waits again (a no-op now), barrier, K loop, barrier
+    gemm_mainloop7_run<T, G7SrcU>(src, nk, smem, acc, tr, pending);     // waits again (a no-op now), barrier, K loop, barrier
     if (tr && threadIdx.x == 0) tr[15] = clock64();
 
     // ---- next tile (a workgroup that has none re-fetches its own: the instruction stream stays fixed) -----------------
@@ -208,36 +219,57 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
     size_t ldc2 = (size_t)ldc * sizeof(OutT), ldr2 = (size_t)ep.ldr * sizeof(OutT);
     asm volatile("" : "+s"(ldc2), "+s"(ldr2));
     const char* const rbase = RESID ? (const char*)((const OutT*)ep.resid + mc * ep.ldr + nc) : nullptr;   // wave-uniform
+    // second plane of the residual; absent (layer 0 adds the one-plane embedding output): fetched from the first and scaled by 0
+    const char* const rlo_base = (TWO && ep.resid_lo) ? (const char*)((const OutT*)ep.resid_lo + mc * ep.ldr + nc) : rbase;
+    const float rlo_scale = (TWO && ep.resid_lo) ? 1.f : 0.f;
     uint32_t roff[4];                                                    // row (lane >> 3) of an 8-row group, swizzled source chunk
 #pragma unroll
     for (int k = 0; k < 4; ++k) roff[k] = (uint32_t)((lane >> 3) * ldr2) + (((lane & 7) ^ ((4 * k + (lane >> 4)) & 7)) << 4);
-    char* const stage = smem + G7E_SLICE(12, wave);
+    // staging patch: the wave's slices 12-15 of U2 / U3 (8 rows per 1 KiB slice, slices 4 KiB apart) -- or, two planes, a
+    // contiguous 4 KiB in the upper half of U4
+    char* const stage = TWO ? smem + G7_TAB_OFF + 16384 + wave * 4096 : smem + G7E_SLICE(12, wave);
+#define G7E_SROW(R_) (TWO ? (R_) * 128 : G7E_ROW(R_))
+#define G7E_SPASS (TWO ? 1024 : 4096)
     const char* const etab = smem + G7_ETAB_OFF + wave * 2048;
-    const bool res_ln = LNF == 2 && ep.rln_stats != nullptr;
-    // residual patch p = (mi, nh): 32 rows x 128 B, chunk position XOR ((row >> 1) & 7); 4 instructions of 8 rows
+    const bool res_ln = LNO && ep.rln_stats != nullptr;
+    // residual patch p = (mi, nh): 32 rows x 128 B, chunk position XOR ((row >> 1) & 7); 4 instructions of 8 rows per plane.
+    // One plane: ring of three patches (slices 0-11).  Two planes: ring of two entries of 8 slices (hi 0-3, lo 4-7).
+#define G7E_RES_SLICE(P_) (TWO ? ((P_) & 1) * 8 : ((P_) % G7E_RES_DEPTH) * 4)
 #define G7E_RES_DMA(P_)                                                                                        \
   do {                                                                                                         \
-    const uint32_t buf = g7_lds_addr(smem) + G7E_SLICE(((P_) % G7E_RES_DEPTH) * 4, wave);                      \
-    const char* const pbase = rbase + (size_t)(((P_) >> 1) * 32) * ldr2 + ((P_) & 1) * 128;                    \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k) g7_dma(pbase + (size_t)(8 * k) * ldr2, roff[k], buf + k * 4096); \
+    const size_t poff = (size_t)(((P_) >> 1) * 32) * ldr2 + ((P_) & 1) * 128;                                  \
+    const uint32_t buf = g7_lds_addr(smem) + G7E_SLICE(G7E_RES_SLICE(P_), wave);                               \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) g7_dma(rbase + poff + (size_t)(8 * k) * ldr2, roff[k], buf + k * 4096); \
+    if (TWO) {                                                                                                 \
+      const uint32_t buf2 = g7_lds_addr(smem) + G7E_SLICE(G7E_RES_SLICE(P_) + 4, wave);                        \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) g7_dma(rlo_base + poff + (size_t)(8 * k) * ldr2, roff[k], buf2 + k * 4096); \
+    }                                                                                                          \
   } while (0)
-    if (LNF == 2) {        // gamma | beta of my 128 columns, statistics of my 128 residual rows (dummies when not normalised)
+    if (LNO) {             // gamma | beta of my 128 columns, statistics of my 128 residual rows (dummies when not normalised)
       g7_table2(res_ln ? ep.rln_g + nc : (const float*)A, res_ln ? ep.rln_b + nc : (const float*)A, (char*)etab, lane);
       g7_table1(res_ln ? ep.rln_stats + mc * 2 : (const float*)A, (char*)etab + 1024, lane);
     }
-    if (RESID) { G7E_RES_DMA(0); G7E_RES_DMA(1); G7E_RES_DMA(2); }
-    g7_fill(next_a, src.oa, smem, wave);                                // K step 0 of the next tile: U0, U1
-    g7_fill(next_b, src.ob, smem + G7_UNIT_BYTES, wave);
+    if (RESID && !(G7_ABL & 4)) { G7E_RES_DMA(0); G7E_RES_DMA(1); if (!TWO) G7E_RES_DMA(2); }
+    g7_fill_a(src, next_a, smem, wave);                                 // K step 0 of the next tile: U0, U1
+    g7_fill_b(src, next_b, smem + G7_UNIT_BYTES, wave);
     g7_init_tables<LNF>(ep, A, smem, m1 + wm * 128, n1 + wn * 128, wave, lane);
 
     G7_FENCE_();
+    if (!(G7_ABL & 4)) {
     float ra[4] = {1.f, 1.f, 1.f, 1.f}, rc[4] = {0.f, 0.f, 0.f, 0.f};
     f32x2_t ssum = {0.f, 0.f}, ssq = {0.f, 0.f};
     const int skey = l31 & 7;
-    char* const st_wr = stage + G7E_ROW(l31) + 8 * half;
-    const char* const st_rd = stage + (lane >> 3) * 128;               // read-back pass i4 covers rows 8 i4 .. 8 i4 + 7 = slice i4
+    char* const st_wr = stage + G7E_SROW(l31) + 8 * half;
+    const char* const st_rd = stage + (lane >> 3) * 128;               // read-back pass i4 covers rows 8 i4 .. 8 i4 + 7
     char* const cbase = (char*)(C + mc * ldc + nc);                     // wave-uniform; the per-lane part is 32 bits
+    char* const cbase_lo = TWO ? (char*)((OutT*)ep.out_lo + mc * ldc + nc) : nullptr;
     const uint32_t coff = (uint32_t)((lane >> 3) * ldc2) + (lane & 7) * 16;
+    // row statistics of this launch's output: slot (column tile, wave column) of ep.stats_out, [slots][M] pairs (sum, sum
+    // of squares) written with PLAIN stores -- one writer per (slot, row); omk_ln_stats_reduce adds the slots in a fixed
+    // order.  (Round 2 added into one pair per row with f32 atomics: the last bits depended on the arrival order.)
+    float2* const stat_slot = LNO ? (float2*)ep.stats_out + ((n0 >> 8) * 2 + wn) * M : nullptr;
+    uint2 plo[8];                                                       // two planes: the patch's remainder words until the hi plane is read back
+    // WRITE(p): residual + conversion of patch p, staged as packed 16-bit (two planes: the hi plane; the lo words wait in plo)
 #define G7E_WRITE(P_)                                                                                          \
   do {                                                                                                         \
     constexpr int MI = (P_) >> 1, NH = (P_) & 1;                                                               \
@@ -245,12 +277,18 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
        256 accumulators into VGPRs behind the K loop and spills everything that lives across the epilogue */      \
     asm volatile("" : "+a"(acc[MI][NH * 2]), "+a"(acc[MI][NH * 2 + 1]));                                       \
     const int64_t m = mc + MI * 32 + l31;                                                                      \
-    uint2 rpatch[2][4];                                                                                        \
+    uint2 rpatch[2][4], rplo[2][4];                                                                            \
     if (RESID) {                                                                                               \
-      const char* buf = smem + G7E_SLICE(((P_) % G7E_RES_DEPTH) * 4, wave) + G7E_ROW(l31) + 8 * half;          \
+      const char* buf = smem + G7E_SLICE(G7E_RES_SLICE(P_), wave) + G7E_ROW(l31) + 8 * half;                   \
       _Pragma("unroll") for (int nl = 0; nl < 2; ++nl)                                                         \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                          \
           rpatch[nl][j] = *(const uint2*)(buf + (((nl * 4 + j) ^ ((l31 >> 1) & 7)) << 4));                     \
+      if (TWO) {                                                                                               \
+        const char* buf2 = smem + G7E_SLICE(G7E_RES_SLICE(P_) + 4, wave) + G7E_ROW(l31) + 8 * half;            \
+        _Pragma("unroll") for (int nl = 0; nl < 2; ++nl)                                                       \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+            rplo[nl][j] = *(const uint2*)(buf2 + (((nl * 4 + j) ^ ((l31 >> 1) & 7)) << 4));                    \
+      }                                                                                                        \
     }                                                                                                          \
     _Pragma("unroll") for (int nl = 0; nl < 2; ++nl)                                                           \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                          \
@@ -264,6 +302,11 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
           const uint2 rr = rpatch[nl][j];                                                                      \
           float r0 = Half16<OutT>::lo(rr.x), r1 = Half16<OutT>::hi(rr.x);                                      \
           float r2 = Half16<OutT>::lo(rr.y), r3 = Half16<OutT>::hi(rr.y);                                      \
+          if (TWO) {                                                                                           \
+            const uint2 rl = rplo[nl][j];                                                                      \
+            r0 = fmaf(Half16<OutT>::lo(rl.x), rlo_scale, r0); r1 = fmaf(Half16<OutT>::hi(rl.x), rlo_scale, r1); \
+            r2 = fmaf(Half16<OutT>::lo(rl.y), rlo_scale, r2); r3 = fmaf(Half16<OutT>::hi(rl.y), rlo_scale, r3); \
+          }                                                                                                    \
           if (res_ln) {                                                                                        \
             const f32x4_t g4 = *(const f32x4_t*)(etab + (ni * 32 + 8 * j + 4 * half) * 4);                     \
             const f32x4_t b4 = *(const f32x4_t*)(etab + 512 + (ni * 32 + 8 * j + 4 * half) * 4);               \
@@ -276,22 +319,32 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
             hi_[0] = epi_resid<ACT, sizeof(OutT) == 2>(hi_[0], r2, false); hi_[1] = epi_resid<ACT, sizeof(OutT) == 2>(hi_[1], r3, false);            \
           }                                                                                                    \
         }                                                                                                      \
-        if (LNF == 2) {                                                                                        \
+        if (LNO) {                                                                                             \
           ssum += lo_ + hi_;                                                                                   \
           ssq = __builtin_elementwise_fma(lo_, lo_, __builtin_elementwise_fma(hi_, hi_, ssq));                 \
         }                                                                                                      \
-        *(uint2*)(st_wr + (((nl * 4 + j) ^ skey) << 4)) = make_uint2(Half16<OutT>::pack2(lo_[0], lo_[1]), Half16<OutT>::pack2(hi_[0], hi_[1])); \
+        { const uint2 pk_ = make_uint2(Half16<OutT>::pack2(lo_[0], lo_[1]), Half16<OutT>::pack2(hi_[0], hi_[1]));       \
+          if (TWO)          /* what the 16-bit word dropped, rounded once more: y = hi + lo to ~2^-17 */        \
+            plo[nl * 4 + j] = make_uint2(Half16<OutT>::pack2(lo_[0] - Half16<OutT>::lo(pk_.x), lo_[1] - Half16<OutT>::hi(pk_.x)), \
+                                         Half16<OutT>::pack2(hi_[0] - Half16<OutT>::lo(pk_.y), hi_[1] - Half16<OutT>::hi(pk_.y))); \
+          if (G7_ABL & 2) asm volatile("" ::"v"(pk_)); else *(uint2*)(st_wr + (((nl * 4 + j) ^ skey) << 4)) = pk_; }  \
       }                                                                                                        \
-    if (LNF == 2 && NH == 1) {      /* both column halves of the row block done: one atomic pair per row */     \
+    if (LNO && NH == 1) {           /* both column halves of the row block done: this wave's partial sums of the row */ \
       float s1 = ssum[0] + ssum[1], s2 = ssq[0] + ssq[1];                                                      \
       s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);                                              \
-      if (half == 0) { atomicAdd(ep.stats_out + 2 * m, s1); atomicAdd(ep.stats_out + 2 * m + 1, s2); }        \
+      if (half == 0) stat_slot[m] = make_float2(s1, s2);                                                       \
       ssum = (f32x2_t){0.f, 0.f}; ssq = (f32x2_t){0.f, 0.f};                                                   \
     }                                                                                                          \
   } while (0)
+    // two planes: the remainder words of the patch just converted go through the same staging patch, behind the read-back
+    // of its hi plane (a wave's LDS operations execute in order)
+#define G7E_WRITE_LO()                                                                                         \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) *(uint2*)(st_wr + ((c ^ skey) << 4)) = plo[c];                \
+  } while (0)
 
-    // vmcnt retires in order: each wait names exactly the operations issued after the one it needs
-    if (RESID || LNF == 2) G7_WAIT_VM(2 * R + PF + TI);                 // residual patch 0 (and the epilogue tables)
+    // vmcnt retires in order: each wait names (at most) the operations issued after the one it needs
+    if (RESID || LNO) G7_WAIT_VM((TWO ? R : 2 * R) + PF + TI);          // residual patch 0 (and the epilogue tables)
     if (res_ln) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
@@ -302,13 +355,15 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
       }
     }
     if (tr && threadIdx.x == 0) tr[16] = clock64();
+#define G7E_RB(I4) ((G7_ABL & 2) ? make_uint4(0u, 0u, 0u, 0u) : *(const uint4*)(st_rd + (I4) * G7E_SPASS + (((lane & 7) ^ (((lane >> 3) + (I4) * 8) & 7)) << 4)))
+#define G7E_ST_(BASE, PP, I4, V) do { if (G7_ABL & 1) asm volatile("" ::"v"((V).x), "v"((V).y), "v"((V).z), "v"((V).w)); else *(uint4*)((BASE) + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128 + coff) = V; } while (0)
+#define G7E_ST(PP, I4, V) G7E_ST_(cbase, PP, I4, V)
+    if (!TWO) {
     // Software pipeline over the 8 patches: WRITE(p+1) -> read-back of p+1 ISSUED at once (its data is only needed one
     // iteration later, behind the next patch's conversion work) -> stores of patch p from the registers read one
     // iteration ago.  A wave's LDS operations execute in order, so the single staging buffer needs no waits.
     G7E_WRITE(0);
     G7_FENCE_();
-#define G7E_RB(I4) (*(const uint4*)(st_rd + (I4) * 4096 + (((lane & 7) ^ (((lane >> 3) + (I4) * 8) & 7)) << 4)))
-#define G7E_ST(PP, I4, V) *(uint4*)(cbase + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128 + coff) = V
     uint4 sa0 = G7E_RB(0), sa1 = G7E_RB(1), sa2 = G7E_RB(2), sa3 = G7E_RB(3), sb0, sb1, sb2, sb3;
     G7_FENCE_();
     // CUR / NXT: the register sets holding patch P_ (read last iteration) and patch P_ + 1 (read now)
@@ -336,14 +391,71 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
     G7E_ITER(6, 8 + A2, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
     G7E_ITER(7, 0, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
 #undef G7E_ITER
+    } else {
+    // Two planes: the same pipeline with a ring of two residual entries (patch p + 2 is fetched into the entry patch p
+    // was read from one iteration ago) and eight stores per patch.  Per iteration: WRITE(p + 1) (hi staged, lo words in
+    // registers) -> read back hi -> stage lo -> read back lo -> stores of patch p.  Operations issued after
+    // RES_DMA(q) when iteration p = q - 1 waits for it:  [p = 0] K step 0 of the next tile, its tables, RES_DMA(2);
+    // [p >= 1] the statistics store behind an odd patch, 8 stores, RES_DMA(q + 1) if any.
+    G7E_WRITE(0);
+    G7_FENCE_();
+    uint4 ha0 = G7E_RB(0), ha1 = G7E_RB(1), ha2 = G7E_RB(2), ha3 = G7E_RB(3), hb0, hb1, hb2, hb3;
+    G7_FENCE_();
+    G7E_WRITE_LO();
+    G7_FENCE_();
+    uint4 la0 = G7E_RB(0), la1 = G7E_RB(1), la2 = G7E_RB(2), la3 = G7E_RB(3), lb0, lb1, lb2, lb3;
+    G7_FENCE_();
+#define G7E_ITER2(P_, YWAIT, CH0, CH1, CH2, CH3, CL0, CL1, CL2, CL3, NH0, NH1, NH2, NH3, NL0, NL1, NL2, NL3)      \
+  do {                                                                                                         \
+    if ((P_) + 1 < 8) {                                                                                        \
+      if ((P_) + 2 < 8) G7E_RES_DMA((P_) + 2);                                                                 \
+      G7_WAIT_VM(YWAIT);                                                                                       \
+      G7E_WRITE((P_) + 1);                                                                                     \
+      G7_FENCE_();                                                                                             \
+      NH0 = G7E_RB(0); NH1 = G7E_RB(1); NH2 = G7E_RB(2); NH3 = G7E_RB(3);                                      \
+      G7_FENCE_();                                                                                             \
+      G7E_WRITE_LO();                                                                                          \
+      G7_FENCE_();                                                                                             \
+      NL0 = G7E_RB(0); NL1 = G7E_RB(1); NL2 = G7E_RB(2); NL3 = G7E_RB(3);                                      \
+    }                                                                                                          \
+    G7_FENCE_();                                                                                               \
+    G7E_ST(P_, 0, CH0); G7E_ST(P_, 1, CH1); G7E_ST(P_, 2, CH2); G7E_ST(P_, 3, CH3);                             \
+    G7E_ST_(cbase_lo, P_, 0, CL0); G7E_ST_(cbase_lo, P_, 1, CL1); G7E_ST_(cbase_lo, P_, 2, CL2); G7E_ST_(cbase_lo, P_, 3, CL3); \
+    G7_FENCE_();                                                                                               \
+  } while (0)
+#define G7E_ITER2_(...) G7E_ITER2(__VA_ARGS__)
+#define G7E_A ha0, ha1, ha2, ha3, la0, la1, la2, la3
+#define G7E_B hb0, hb1, hb2, hb3, lb0, lb1, lb2, lb3
+    G7E_ITER2_(0, PF + TI + R, G7E_A, G7E_B);
+    G7E_ITER2_(1, 16 + A2, G7E_B, G7E_A);
+    G7E_ITER2_(2, 16, G7E_A, G7E_B);
+    G7E_ITER2_(3, 16 + A2, G7E_B, G7E_A);
+    G7E_ITER2_(4, 16, G7E_A, G7E_B);
+    G7E_ITER2_(5, 16 + A2, G7E_B, G7E_A);
+    G7E_ITER2_(6, 8, G7E_A, G7E_B);
+    G7E_ITER2_(7, 0, G7E_B, G7E_A);
+#undef G7E_A
+#undef G7E_B
+#undef G7E_ITER2
+#undef G7E_ITER2_
+    }
 #undef G7E_RB
 #undef G7E_ST
+#undef G7E_ST_
 #undef G7E_WRITE
+#undef G7E_WRITE_LO
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) asm volatile("" : "+a"(acc[q >> 2][q & 3]));
+    }
 #undef G7E_RES_DMA
+#undef G7E_RES_SLICE
+#undef G7E_SROW
+#undef G7E_SPASS
     if (tr && threadIdx.x == 0) { tr[28] = clock64(); tr[29] = blockIdx.x; tr[31] = wall_clock64(); }
     if (!has_next) break;
     src.a = next_a; src.b = next_b; m0 = m1; n0 = n1;
-    pending = true;
+    pending = !(G7_ABL & 5);        // (probe builds without stores: the tile-start waits count no stores)
   }
   G7_WAIT_VM(0);      // the last (dummy) prefetch must not outlive the workgroup's LDS allocation
 }

@@ -2,7 +2,7 @@
 #include "gemm_wide7.h"
 
 bool omk_gemm_wide7_has(int act, bool resid, int lnf) {
-  if (lnf == 2) return act == OM_ACT_NONE && resid;
+  if (lnf == 2 || lnf == 3) return act == OM_ACT_NONE && resid;
   switch (act) {
     case OM_ACT_NONE: return lnf == 0 || !resid;
     case OM_ACT_GELU_TANH: return true;
@@ -19,9 +19,10 @@ int omk_gemm_wide7(bool persist, const void* A, int64_t lda, const void* B, int6
                    int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
   const int act = ep.act & 0xff;
   const bool resid = ep.resid != nullptr;
-  const int lnf = ep.ln_stats ? 1 : ((ep.rln_stats || ep.stats_out) ? 2 : 0);
+  const int lnf = ep.ln_stats ? 1 : ((ep.rln_stats || ep.stats_out) ? (ep.out_lo ? 3 : 2) : 0);
   if (M % 256 || N % 256 || (K * 2) % G7_ROW_BYTES) OM_FAIL("generation 7 takes whole 256 x 256 tiles and 128-byte K steps");
-  if (lnf == 2 && !ep.stats_out) OM_FAIL("the output-side LayerNorm variant accumulates row statistics: stats_out is null");
+  if (lnf >= 2 && !ep.stats_out) OM_FAIL("the output-side LayerNorm variant writes row statistics: stats_out is null");
+  if ((ep.out_lo || ep.resid_lo) && lnf != 3) OM_FAIL("two-plane residual stream: only with the output-side LayerNorm epilogue");
   if (ep.ln_stats && (ep.rln_stats || ep.stats_out)) OM_FAIL("fused LayerNorm: either the A side or the output side");
   if (lnf) return omk_gemm_wide7_ln(act, resid, lnf, A, lda, B, ldb, C, ldc, M, N, K, ep, s);
   if (!persist) {

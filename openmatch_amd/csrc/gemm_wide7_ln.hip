@@ -13,6 +13,8 @@ int omk_gemm_wide7_ln(int act, bool resid, int lnf, const void* A, int64_t lda, 
     if (act == OM_ACT_GELU_TANH && resid) OM_L7(OM_ACT_GELU_TANH, true, 1);         // T5 gated: act(.) * gate
   } else if (lnf == 2) {
     if (act == OM_ACT_NONE && resid) OM_L7(OM_ACT_NONE, true, 2);
+  } else if (lnf == 3) {                     // two-plane residual stream (GemmEpilogue::out_lo / resid_lo)
+    if (act == OM_ACT_NONE && resid) OM_L7(OM_ACT_NONE, true, 3);
   }
 #undef OM_L7
   OM_FAIL("no generation-7 kernel for this fused-LayerNorm epilogue");

@@ -6,7 +6,10 @@
 int omk_ln_fold(int dtype /* OM_BF16 | OM_F16 */, const void* W, const float* gamma, const float* beta, const float* b, void* Wf,
                 float* colsum, float* bf, int N, int K, hipStream_t s);
 int omk_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* g,
-                  const float* b, int64_t M, int H, float eps, int rms, hipStream_t s);
+                  const float* b, int64_t M, int H, float eps, int rms, hipStream_t s,
+                  const void* x_lo = nullptr /* second plane of a two-plane input: normalises x + x_lo */);
+int omk_layernorm_f32out(int dtype, const void* x, int64_t ldx, float* y, int64_t ldy, const float* g, const float* b,
+                         int64_t M, int H, float eps, int rms, hipStream_t s, const void* x_lo = nullptr);
 int omk_embed(int dtype, const int64_t* ids, const int64_t* type_ids, const float* word,
               const float* pos, const float* type, const float* g, const float* b, void* out,
               int64_t M, int L, int H, int vocab, int type_vocab, float eps, int bert,
@@ -43,13 +46,19 @@ struct GemmEpilogue {
   const float* rln_stats;    // the residual is a RAW pre-LayerNorm tensor: add LN(resid) with these statistics
   const float* rln_g;        //   and this affine (per output column)
   const float* rln_b;
-  float* stats_out;          // accumulate (sum, sum of squares) of every output row (the next LayerNorm's input)
+  float* stats_out;          // row statistics of the output (the next LayerNorm's input): PARTIAL (sum, sum of squares) pairs,
+                             //   [2 * N / 256 slots][M] float2 -- slot = (column tile, wave column), one plain store per (slot, row);
+                             //   omk_ln_stats_reduce adds the slots in a fixed order into the [M][2] array the consumers read
+  const void* resid_lo;      // two-plane residual stream (bf16 BERT inference): the residual is resid + resid_lo (NULL: one plane)
+  void* out_lo;              //   and the output is written as C = round16(y), out_lo = round16(y - C); selects the LNF == 3 kernel
   float ln_inv_h, ln_eps;
   int ln_rms;                // 1: the statistics describe a T5 RMSNorm (no mean, no shift): only sum of squares is used
   int reverse;               // 1: walk the output tiles from the last row block to the first (persistent 16-bit kernel only).
                              //   A consumer that starts where its producer finished finds those rows in the memory-side cache
                              //   (256 MB; the encoder's activations are 200-800 MB per tensor) -- encoder.hip alternates.
 };
+// (sum, sum of squares) per row from the slot partials a GEMM with stats_out left: out[m] = sum over slots, in slot order
+int omk_ln_stats_reduce(const float* slots, int nslots, int64_t M, float* out, hipStream_t s);
 // true when omk_gemm will run [M,N] x K (16-bit) on the kernel that implements the ln_* / rln_* / stats_out fields
 bool omk_gemm_ln_fusable(int dtype, int64_t M, int64_t N, int64_t K);
 unsigned long long* omk_debug_trace();

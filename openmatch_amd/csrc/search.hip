@@ -272,7 +272,7 @@ __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7(
 #pragma unroll
       for (int q = 0; q < 16; ++q) { acc[q >> 2][q & 3] = zero; MmaOps<T>::mma(zf, zf, acc[q >> 2][q & 3]); }   // zero by the matrix core
     }
-    gemm_mainloop7_run<T, 0>(src, nk, smem, acc, tr, false);
+    gemm_mainloop7_run<T>(src, nk, smem, acc, tr, false);
     if (tr && threadIdx.x == 0) tr[15] = clock64();
     // next pair: its first K step and its thresholds are fetched under the filter below
     ++it;

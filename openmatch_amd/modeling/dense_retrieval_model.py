@@ -80,8 +80,8 @@ class DRModel(nn.Module):
         if self._one_pass_ok(query, passage):
             q_reps, p_reps = self._encode_one_pass(query, passage)
         else:
-            _, q_reps = self.encode_query(query)
-            _, p_reps = self.encode_passage(passage)
+            _, q_reps = self.encode(query, self.lm_q, self.head_q, want_hidden=False)
+            _, p_reps = self.encode(passage, self.lm_p, self.head_p, want_hidden=False)
         if q_reps is None or p_reps is None:
             return DROutput(q_reps=q_reps, p_reps=p_reps)
 
@@ -98,7 +98,10 @@ class DRModel(nn.Module):
         return DROutput(loss=loss, scores=scores, q_reps=q_all, p_reps=p_all)
 
     # ------------------------------------------------------------------ encode
-    def encode(self, items, model, head):
+    def encode(self, items, model, head, want_hidden=True):
+        """(hidden, reps) as the reference's encode.  `want_hidden=False` (what forward() passes: it only uses the
+        representations) skips materialising the [B, L, H] hidden states -- reps are then pooled from an f32 final
+        LayerNorm of just the rows pooling needs, and hidden is None."""
         if items is None:
             return None, None
         items = BatchEncoding(items)
@@ -117,7 +120,7 @@ class DRModel(nn.Module):
         if needs_grad or has_dropout:      # train-mode forward (dropout), also under no_grad (GradCache)
             return encode_with_grad(model, head, items, self.pooling, self.normalize, code,
                                     self.training)
-        return hip_encode(model, items, self.pooling, head, self.normalize, code)
+        return hip_encode(model, items, self.pooling, head, self.normalize, code, want_hidden=want_hidden)
 
     def _encode_t5_decoder(self, items, model, head):
         """T5 encoder-decoder pooling (reference :137-141): one decoder position fed token 0, reps = its hidden state,
@@ -268,7 +271,8 @@ class DRModelForInference(DRModel):
     def encode_query(self, qry):
         return super().encode_query(qry)
 
+    @torch.no_grad()
     def forward(self, query: Dict[str, Tensor] = None, passage: Dict[str, Tensor] = None):
-        _, q_reps = self.encode_query(query)
-        _, p_reps = self.encode_passage(passage)
+        _, q_reps = self.encode(query, self.lm_q, self.head_q, want_hidden=False)
+        _, p_reps = self.encode(passage, self.lm_p, self.head_p, want_hidden=False)
         return DROutput(q_reps=q_reps, p_reps=p_reps)

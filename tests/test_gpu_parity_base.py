@@ -140,16 +140,39 @@ def test_config1_bf16_chain_within_reference_16bit_envelope(golden, tmp_path):
     print(f"\n[config 1, bf16 fused path] vs reference fp32: min cos {cmin:.6f} (reference autocast {r_cmin:.6f}), mean cos {cmean:.6f} ({r_cmean:.6f}), "
           f"max|ddot| {ddot:.4f} ({r_ddot:.4f}), top-100 overlap mean {np.mean(ov):.1f} min {min(ov)} ({r_ov_mean:.1f} / {r_ov_min:.0f}), "
           f"|dMRR@10| {d_mrr:.4f} ({r_d_mrr:.4f}); vs reference autocast: min cos {a_cmin:.6f}, max|ddot| {a_ddot:.4f}, overlap mean {np.mean(ov_ac):.1f}")
-    # Measured (profiles/r02_parity_base_v0.log): 1 - cos 4.8e-5 vs the reference's autocast 1.8e-5, max|ddot| 0.82 vs 0.33 on
-    # dots of ~760, top-100 overlap 91.2 (min 84) vs 97.4 (95), |dMRR@10| 0.0065 vs 0.0035.  This path keeps the residual
-    # stream in bf16 between sub-layers (autocast keeps it in fp32 and rounds only the matmul operands), hence ~2.5x the
-    # reference's own 16-bit deviation; the bounds below are that envelope with headroom, not a claim of equality.
-    assert 1.0 - cmin <= 4.0 * (1.0 - r_cmin), (cmin, r_cmin)
-    assert ddot <= 4.0 * r_ddot, (ddot, r_ddot)
-    assert np.mean(ov) >= r_ov_mean - 9.0 and min(ov) >= r_ov_min - 15, (np.mean(ov), min(ov))
-    # MRR@10 over 100 queries moves in steps of a few 1e-3 per flipped rank, and the LayerNorm statistics are summed with
-    # float atomics (order varies run to run): 0.0065 .. 0.0205 over six runs of this test (profiles/r02_parity_base_v*.log)
-    assert d_mrr <= max(0.03, 4.0 * r_d_mrr), (mrr, float(g["mrr10_f32"]))
+    # Round 3: the pre-LayerNorm residual stream is kept in two 16-bit planes (gemm_wide7.h LNF == 3; the reference's
+    # autocast keeps it in fp32), and the LayerNorm statistics are added in a fixed order.  The path has to land INSIDE the
+    # reference's own 16-bit envelope -- factor 1.0 on every measure, no floors (round 2, one plane: 1 - cos 4.8e-5 vs
+    # 1.8e-5, max|ddot| 0.82 vs 0.33, overlap 91.2 (min 84) vs 97.4 (95), |dMRR@10| 0.0065-0.0205 vs 0.0035).
+    assert 1.0 - cmin <= 1.0 * (1.0 - r_cmin), (cmin, r_cmin)
+    assert ddot <= 1.0 * r_ddot, (ddot, r_ddot)
+    assert np.mean(ov) >= r_ov_mean - 0.5 and min(ov) >= r_ov_min - 1, (np.mean(ov), min(ov), r_ov_mean, r_ov_min)
+    assert d_mrr <= r_d_mrr + 1e-9, (mrr, float(g["mrr10_f32"]), r_d_mrr)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_benchmark_batch_is_bit_identical_run_to_run(dtype):
+    """The 16-bit fused path on the benchmark's own batch (1024 x 128 ragged tokens, bert-base): two runs give the same
+    bits.  (Round 2 summed the LayerNorm statistics with f32 atomics: the last bits, and with them MRR@10, moved run to
+    run.  The reference is deterministic.)"""
+    from openmatch.modeling import DRModelForInference
+    lm = _bert_base()
+    model = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype=dtype)).to(DEV).eval()
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(1000, 30522, (1024, 128), generator=g)
+    lens = torch.randint(16, 129, (1024,), generator=g)
+    mask = (torch.arange(128)[None, :] < lens[:, None]).long()
+    ids = ids * mask
+    ids[:, 0] = 101
+    batch = {"input_ids": ids.to(DEV), "attention_mask": mask.to(DEV)}
+    a = model(passage=batch).p_reps.clone()
+    other = model(passage={"input_ids": batch["input_ids"].flip(0).contiguous(), "attention_mask": batch["attention_mask"].flip(0).contiguous()}).p_reps
+    b = model(passage=batch).p_reps.clone()
+    c = model(passage=batch).p_reps.clone()
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b) and torch.equal(a, c)
+    # and a row's embedding does not depend on where in the batch it sits (rows are independent in every kernel)
+    assert torch.equal(other.flip(0), a)
 
 
 def test_config1_f16_chain_beats_reference_16bit_envelope(golden, tmp_path):
@@ -170,9 +193,7 @@ def test_config1_f16_chain_beats_reference_16bit_envelope(golden, tmp_path):
     assert 1.0 - cmin <= 0.25 * (1.0 - r_cmin), (cmin, r_cmin)
     assert ddot <= 2e-4 * scale, (ddot, scale)             # dot products within 2e-4 relative
     assert np.mean(ov) >= r_ov_mean and min(ov) >= r_ov_min, (np.mean(ov), min(ov))
-    # MRR@10 over 100 queries moves 0.005 when ONE query's top two near-tied documents swap (seen: 0.0003 and 0.0035 on two
-    # runs -- the LayerNorm statistics are summed with float atomics, so the last bits vary run to run)
-    assert d_mrr <= max(0.02, r_d_mrr), (mrr, float(g["mrr10_f32"]))
+    assert d_mrr <= r_d_mrr + 1e-9, (mrr, float(g["mrr10_f32"]), r_d_mrr)     # deterministic since round 3: no floor
 
 
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])

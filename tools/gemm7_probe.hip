@@ -1,0 +1,117 @@
+// Developer tool: times the generation-7 persistent GEMM (gemm_wide7.h) on the encoder's four shapes with parts of
+// the tile compiled out (-DG7_ABL=<bits>, gemm_core7.h), on random operands, hipEvents around 20 launches.
+//   for a in 0 1 2 4 8 16 32 64 ...; do hipcc -O3 -std=c++17 --offload-arch=gfx950 -DG7_ABL=$a tools/gemm7_probe.hip -o build/g7probe_$a; done
+#include <stdio.h>
+#include <stdlib.h>
+#include <string>
+#include <vector>
+#include <atomic>
+#include <algorithm>
+#include "../openmatch_amd/csrc/gemm_wide7.h"
+
+void om_set_error(const std::string& s) { fprintf(stderr, "error: %s\n", s.c_str()); }
+bool om_timing_on() { return false; }
+void om_timing_begin(int, hipStream_t) {}
+void om_timing_end(int, hipStream_t, double) {}
+int om_option(int) { return 8; }      // OM_OPT_GEMM_GROUP_M default
+
+static void fill_bf16(bf16_t* d, size_t n, float scale, unsigned long long seed) {
+  const size_t chunk = std::min<size_t>(n, (size_t)1 << 22);      // 4 M random values, repeated (rows differ: 4 M is not a multiple of any row)
+  std::vector<bf16_t> h(chunk + 37);
+  unsigned long long x = 88172645463325252ull ^ seed;
+  for (auto& v : h) {
+    float acc = 0;
+    for (int i = 0; i < 4; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; acc += (float)(x & 0xffff) / 65536.0f - 0.5f; }
+    v = f32_to_bf16(acc * 1.7f * scale);
+  }
+  for (size_t o = 0; o < n; o += chunk + 37) hipMemcpy(d + o, h.data(), std::min(chunk + 37, n - o) * 2, hipMemcpyHostToDevice);
+}
+static void fill_f32(float* d, size_t n, float a, float b) {
+  std::vector<float> h(n);
+  unsigned long long x = 1234567ull;
+  for (auto& v : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = a + (b - a) * (float)(x & 0xffff) / 65536.0f; }
+  hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice);
+}
+
+static bool g_zero = false;
+template <int ACT, bool RESID, int LNF>
+static void run(const char* what, int64_t M, int64_t N, int64_t K, const bf16_t* A, const bf16_t* B, bf16_t* C, const bf16_t* R,
+                const float* vecs, float* stats_in, float* stats_out) {
+  GemmEpilogue ep = {};
+  ep.bias = vecs;
+  ep.act = ACT;
+  ep.ln_inv_h = 1.0f / 768.0f; ep.ln_eps = 1e-12f;
+  if (LNF == 1) { ep.ln_stats = stats_in; ep.ln_colsum = vecs + 4096; }
+  if (RESID) { ep.resid = R; ep.ldr = N; }
+  if (LNF == 2) { ep.rln_stats = stats_in; ep.rln_g = vecs + 8192; ep.rln_b = vecs + 12288; ep.stats_out = stats_out; }
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) launch7<bf16_t, ACT, RESID, LNF>(A, K, B, K, C, N, M, N, K, ep, 0);
+  const int reps = 20;
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < reps; ++i) { ep.reverse = i & 1; launch7<bf16_t, ACT, RESID, LNF>(A, K, B, K, C, N, M, N, K, ep, 0); }
+  hipEventRecord(e1, 0);
+  hipDeviceSynchronize();
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+  ms /= reps;
+  const double tiles_per_cu = (double)(M / 256) * (N / 256) / 256.0;
+  printf("D%dk%d%s ABL=%-3d %-28s M=%ld N=%ld K=%ld : %8.1f us  %7.1f TFLOP/s  %7.2f us per tile-slot (%.0f tiles/CU)\n", G7_DEFER_STORES, G7_SKEW, g_zero ? "z" : "", G7_ABL, what, (long)M,
+         (long)N, (long)K, ms * 1e3, 2.0 * M * N * K / (ms * 1e9), ms * 1e3 / tiles_per_cu, tiles_per_cu);
+}
+
+// spot check of the plain variant (bias only): 512 sampled outputs against a host dot product in double
+static void check_plain(int64_t M, int64_t N, int64_t K, const bf16_t* A, const bf16_t* B, bf16_t* C, const float* vecs) {
+  GemmEpilogue ep = {};
+  ep.bias = vecs;
+  hipMemset(C, 0xff, (size_t)M * N * 2);
+  launch7<bf16_t, OM_ACT_NONE, false, 0>(A, K, B, K, C, N, M, N, K, ep, 0);
+  hipDeviceSynchronize();
+  std::vector<bf16_t> a(K), b(K); std::vector<float> bias(N);
+  hipMemcpy(bias.data(), vecs, N * 4, hipMemcpyDeviceToHost);
+  double worst = 0; int bad = 0;
+  unsigned long long x = 99;
+  for (int i = 0; i < 512; ++i) {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    const int64_t m = (i < 8) ? (i & 1 ? M - 1 - i : i) : (int64_t)(x % (unsigned long long)M);
+    const int64_t n = (int64_t)((x >> 32) % (unsigned long long)N);
+    hipMemcpy(a.data(), A + m * K, K * 2, hipMemcpyDeviceToHost);
+    hipMemcpy(b.data(), B + n * K, K * 2, hipMemcpyDeviceToHost);
+    bf16_t c; hipMemcpy(&c, C + m * N + n, 2, hipMemcpyDeviceToHost);
+    double ref = bias[n];
+    for (int64_t k = 0; k < K; ++k) ref += (double)bf16_to_f32(a[k]) * (double)bf16_to_f32(b[k]);
+    const double err = fabs((double)bf16_to_f32(c) - ref), tol = 0.01 * fabs(ref) + 0.02;
+    if (!(err <= tol)) ++bad;
+    worst = std::max(worst, err);
+  }
+  printf("CHECK sched=%d ABL=%d M=%ld N=%ld K=%ld: %s (max |err| %.4f over 512 samples)\n", G7_SCHED, G7_ABL, (long)M, (long)N, (long)K,
+         bad ? "FAILED" : "ok", worst);
+}
+
+int main(int argc, char** argv) {
+  const int64_t M = 131072;
+  bf16_t *A, *B, *C, *R; float *vecs, *st_in, *st_out;
+  hipMalloc(&A, (size_t)M * 3072 * 2); hipMalloc(&B, (size_t)3072 * 3072 * 2); hipMalloc(&C, (size_t)M * 3072 * 2); hipMalloc(&R, (size_t)M * 768 * 2);
+  hipMalloc(&vecs, 16384 * 4); hipMalloc(&st_in, (size_t)M * 8); hipMalloc(&st_out, (size_t)M * 8);
+  const bool zero = argc > 1; g_zero = zero;          // any argument: zero-filled operands (how much of the rate is the power limit?)
+  if (zero) { hipMemset(A, 0, (size_t)M * 3072 * 2); hipMemset(B, 0, (size_t)3072 * 3072 * 2); hipMemset(R, 0, (size_t)M * 768 * 2); printf("operands: zeros\n"); }
+  else { fill_bf16(A, (size_t)M * 3072, 1.0f, 1); fill_bf16(B, (size_t)3072 * 3072, 0.05f, 2); fill_bf16(R, (size_t)M * 768, 1.0f, 3); }
+  fill_f32(vecs, 16384, -0.5f, 0.5f);
+  {  // plausible (sum, sum of squares) of 768 N(0,1) values
+    std::vector<float> h((size_t)M * 2);
+    for (size_t i = 0; i < (size_t)M; ++i) { h[2 * i] = (float)((i * 37) % 23) - 11.f; h[2 * i + 1] = 700.f + (float)((i * 13) % 101); }
+    hipMemcpy(st_in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  }
+  hipMemset(st_out, 0, (size_t)M * 8);
+  if (!(G7_ABL)) {
+    check_plain(4096, 768, 768, A, B, C, vecs); check_plain(2048, 2304, 768, A, B, C, vecs); check_plain(2048, 768, 3072, A, B, C, vecs);
+    check_plain(512, 512, 128, A, B, C, vecs); check_plain(512, 256, 64, A, B, C, vecs); check_plain(65536, 768, 192, A, B, C, vecs);
+  }
+  for (int round = 0; round < 2; ++round) {
+    run<OM_ACT_NONE, false, 1>("qkv (ln-folded A)", M, 2304, 768, A, B, C, R, vecs, st_in, st_out);
+    run<OM_ACT_NONE, true, 2>("out-proj (+LN resid, stats)", M, 768, 768, A, B, C, R, vecs, st_in, st_out);
+    run<OM_ACT_GELU_ERF, false, 1>("ffn1 + gelu (ln-folded A)", M, 3072, 768, A, B, C, R, vecs, st_in, st_out);
+    run<OM_ACT_NONE, false, 1>("ffn1 shape, no gelu", M, 3072, 768, A, B, C, R, vecs, st_in, st_out);
+    run<OM_ACT_NONE, true, 2>("ffn2 (+LN resid, stats)", M, 768, 3072, A, B, C, R, vecs, st_in, st_out);
+    run<OM_ACT_NONE, false, 0>("plain", 32768, 3072, 3072, A, B, C, R, vecs, st_in, st_out);
+  }
+  return 0;
+}
