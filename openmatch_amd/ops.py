@@ -40,6 +40,11 @@ class _ContrastiveLoss(torch.autograd.Function):
             target = target.to(device=q_all.device, dtype=torch.int64).contiguous()
             if target.shape != (q_all.shape[0],):
                 raise ValueError("target must hold one class index per query row")
+            # F.cross_entropy (reference loss.py:15 / modeling :122) raises on a class index outside [0, C) other than
+            # ignore_index; the kernel indexes the score row with it, so check here (one host read, caller-supplied targets only)
+            bad = (target != -100) & ((target < 0) | (target >= p_all.shape[0]))
+            if bool(bad.any()):
+                raise IndexError("Target {} is out of bounds.".format(int(target[bad][0])))
         need_grad = q_local.requires_grad or p_local.requires_grad
         fused = need_grad and reduction != 2
         loss, scores, dq, dp = _contrastive_call(q_all, p_all, target, n_psg, reduction, None, scale, q_local, q_row0,

@@ -164,6 +164,60 @@ class DRTrainer:
                                                                       seed=getattr(self.args, "seed", 42))
         return DataLoader(ds, batch_size=per_dev, sampler=sampler, shuffle=sampler is None, **common)
 
+    def get_eval_dataloader(self, eval_dataset=None) -> DataLoader:
+        ds = eval_dataset if eval_dataset is not None else self.eval_dataset
+        if ds is None:
+            raise ValueError("Trainer: evaluation requires an eval_dataset.")
+        W, r = self._world()
+        per_dev = getattr(self.args, "per_device_eval_batch_size", None) or self.args.per_device_train_batch_size
+        common = dict(collate_fn=self.data_collator, drop_last=False,
+                      num_workers=getattr(self.args, "dataloader_num_workers", 0),
+                      pin_memory=getattr(self.args, "dataloader_pin_memory", True))
+        if isinstance(ds, IterableDataset):
+            if W > 1:
+                ds = IterableDatasetShard(ds, batch_size=per_dev, drop_last=False, num_processes=W, process_index=r)
+            return DataLoader(ds, batch_size=per_dev, **common)
+        sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=W, rank=r, shuffle=False) if W > 1 else None
+        return DataLoader(ds, batch_size=per_dev, sampler=sampler, shuffle=False, **common)
+
+    def evaluate(self, eval_dataset=None, ignore_keys=None, metric_key_prefix: str = "eval") -> Dict[str, float]:
+        """Validation loss, what the reference's evaluation is (docs/dr-msmarco-passage.md:85: "evaluation is just
+        calculating the loss on the validation set"; driver/train_dr.py:84-97 hands `eval_dataset` to the HF Trainer,
+        whose evaluate() averages compute_loss over the eval batches, each weighted by its size, across all ranks).
+        The model runs in eval mode (no dropout, no x world_size on the loss: modeling :124-125) without gradients."""
+        loader = self.get_eval_dataloader(eval_dataset)
+        W, _ = self._world()
+        was_training = self.model.training
+        self.model.eval()
+        tot = torch.zeros(2, dtype=torch.float64, device=self.args.device)       # (sum of loss * queries, queries)
+        try:
+            with torch.no_grad():
+                for batch in loader:
+                    inputs = self._prepare_inputs(batch)
+                    with self._autocast():
+                        loss = self.compute_loss(self.model, inputs)
+                    n = next(iter(inputs[0].values())).shape[0] if isinstance(inputs[0], dict) else inputs[0].shape[0]
+                    tot[0] += loss.detach().double() * n
+                    tot[1] += n
+        finally:
+            self.model.train(was_training)
+        if W > 1:
+            dist.all_reduce(tot)
+        n_all = float(tot[1])
+        metrics = {f"{metric_key_prefix}_loss": float(tot[0]) / n_all if n_all else float("nan"),
+                   f"{metric_key_prefix}_samples": int(n_all), "epoch": self.state.epoch, "step": self.state.global_step}
+        self.state.log_history.append(metrics)
+        if self.is_world_process_zero():
+            logger.info("%s", metrics)
+        for cb in self.callbacks:                       # HF callbacks that implement on_evaluate (TensorBoardCallback logs via on_log)
+            fn = getattr(cb, "on_evaluate", None)
+            if callable(fn):
+                try:
+                    fn(self.args, self.state, None, metrics=metrics)
+                except Exception as e:                  # a callback written against HF's TrainerControl must not stop training
+                    logger.debug("callback %r.on_evaluate failed: %s", cb, e)
+        return metrics
+
     # ------------------------------------------------------------------ one step
     def compute_loss(self, model, inputs, return_outputs=False, **_unused):
         query, passage = inputs
@@ -228,8 +282,12 @@ class DRTrainer:
         if resume_from_checkpoint:
             logger.warning("resume_from_checkpoint=%r is not supported by this trainer (optimizer state is not "
                            "checkpointed): training starts from the model's current weights", resume_from_checkpoint)
-        if self.eval_dataset is not None or str(getattr(a, "evaluation_strategy", getattr(a, "eval_strategy", "no"))).lower() not in ("no", "intervalstrategy.no"):
-            logger.warning("evaluation during training is not implemented: eval_dataset / evaluation_strategy are ignored")
+        # --evaluation_strategy steps|epoch with --eval_steps (docs/dr-msmarco-passage.md:71-85); HF renamed the field to eval_strategy
+        strategy = str(getattr(a, "evaluation_strategy", None) or getattr(a, "eval_strategy", "no")).lower().split(".")[-1]
+        eval_every = int(getattr(a, "eval_steps", 0) or 0) or log_every
+        do_eval = self.eval_dataset is not None and strategy in ("steps", "epoch")
+        if strategy in ("steps", "epoch") and self.eval_dataset is None:
+            raise ValueError("Trainer: evaluation requires an eval_dataset.")
         while self.state.global_step < total:
             # the datasets read int(trainer.state.epoch) when their iterator is created (train_dataset.py:115-119):
             # the epoch counter must already say `epoch` here, as HF Trainer's does, not after the first step
@@ -264,10 +322,14 @@ class DRTrainer:
                     if self.is_world_process_zero():
                         logger.info("%s", entry)
                     running = 0.0
+                if do_eval and strategy == "steps" and self.state.global_step % eval_every == 0:
+                    self.evaluate()
                 if save_every and self.state.global_step % save_every == 0 and self.is_world_process_zero():
                     self._save(os.path.join(a.output_dir, f"checkpoint-{self.state.global_step}"))
                 if self.state.global_step >= total:
                     break
+            if do_eval and strategy == "epoch" and stepped:
+                self.evaluate()
             epoch += 1
             if not stepped:
                 raise ValueError("the training dataloader produced no batches")

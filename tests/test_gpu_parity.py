@@ -457,6 +457,10 @@ def test_loss_objects_full_call_surface(golden):
     check(SimpleContrastiveLoss())
     with pytest.raises(ValueError):
         SimpleContrastiveLoss()(q0.to(DEV), p0.to(DEV), reduction="median")
+    for bad in (p0.shape[0], -1):                        # F.cross_entropy raises on a class index outside [0, C)
+        t_bad = torch.zeros(q0.shape[0], dtype=torch.int64); t_bad[1] = bad
+        with pytest.raises(IndexError):
+            SimpleContrastiveLoss()(q0.to(DEV), p0.to(DEV), target=t_bad)
     if not dist.is_initialized():
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=torch.device(DEV))
     try:
