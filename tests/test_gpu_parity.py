@@ -1063,10 +1063,17 @@ def test_drtrainer_loop_reduces_loss_and_saves(golden, tmp_path):
     from openmatch.trainer import DRTrainer
     g = golden("train_bert_tiny")
     model = _train_model(g)
-    args = _trainer_args(tmp_path)
-    trainer = DRTrainer(model=model, args=args, train_dataset=_pair_dataset(g), data_collator=lambda b: b[0])
+    # with validation loss during training (reference driver/train_dr.py:84-97, docs/dr-msmarco-passage.md:71-85)
+    args = _trainer_args(tmp_path, evaluation_strategy="steps", eval_steps=6, per_device_eval_batch_size=1)
+    trainer = DRTrainer(model=model, args=args, train_dataset=_pair_dataset(g), eval_dataset=_pair_dataset(g, 3),
+                        data_collator=lambda b: b[0])
+    before = trainer.evaluate()
+    assert abs(before["eval_loss"] - float(g["loss"])) < 1e-4 and before["eval_samples"] == 3 * g["q_input_ids"].shape[0]
     trainer.train()
-    hist = trainer.state.log_history
+    assert model.training                                                      # evaluate() restores the mode it found
+    evals = [h for h in trainer.state.log_history if "eval_loss" in h]
+    assert [h["step"] for h in evals] == [0, 6, 12] and evals[-1]["eval_loss"] < evals[1]["eval_loss"] < evals[0]["eval_loss"]
+    hist = [h for h in trainer.state.log_history if "loss" in h]
     assert trainer.state.global_step == 12 and len(hist) == 3
     assert hist[-1]["loss"] < hist[0]["loss"] < float(g["loss"]) + 0.05       # same batch every step: it must fit
     trainer.save_model()
