@@ -66,6 +66,13 @@ def synth_ids(batch, L, device, seed):
     return ids.contiguous(), mask.contiguous()
 
 
+def shard_range(total, world, rank):
+    """Contiguous near-even split of `total` items over the ranks (the first total % world ranks take one more):
+    (count, offset) of rank's share.  8 841 823 rows over 8 ranks: 7 shards of 1 105 228 and one of 1 105 227."""
+    base, rem = divmod(total, world)
+    return base + (1 if rank < rem else 0), rank * base + min(rank, rem)
+
+
 def barrier_sync(world):
     if world > 1:
         dist.barrier()
@@ -293,6 +300,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    rccl_ranks = None
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
@@ -303,6 +311,11 @@ def main():
     from types import SimpleNamespace as NS
 
     lib = N.lib()
+    if world > 1:      # ranks as RCCL itself counts them (ncclCommCount on a communicator built from this rendezvous)
+        from openmatch_amd.comm import RcclComm
+        comm = RcclComm.from_torch_distributed(device)
+        rccl_ranks = comm.count()
+        comm.close()
     torch.manual_seed(0)
     lm = BertModel(BertConfig()).eval()
     half = a.precision in ("bf16", "f16")
@@ -377,8 +390,7 @@ def main():
     # ---------------- search leg -----------------------------------------------------------
     search, parity = None, None
     if not a.no_search:
-        rows = a.index_rows // world + (1 if rank < a.index_rows % world else 0)
-        offset = rank * (a.index_rows // world) + min(rank, a.index_rows % world)
+        rows, offset = shard_range(a.index_rows, world, rank)
         index = FlatIPIndex(768, device=device, precision="f16_rescore" if half else "f32")
         g = torch.Generator(device=device).manual_seed(77 + rank)
         shared = torch.randn(1, 768, device=device, generator=torch.Generator(device=device).manual_seed(5))
@@ -386,7 +398,7 @@ def main():
         for s in range(0, rows, 1 << 20):                         # anisotropic, CLS-like: mean + noise
             n = min(1 << 20, rows - s)
             index.add(torch.randn(n, 768, device=device, generator=g) * 0.05 + shared * 0.05)
-        nq_local = a.queries // world + (1 if rank < a.queries % world else 0)
+        nq_local, _ = shard_range(a.queries, world, rank)
         q_local = torch.randn(nq_local, 768, device=device, generator=g) * 0.05 + shared * 0.05
 
         def search_once():
@@ -396,7 +408,7 @@ def main():
                 pad[:nq_local] = q_local
                 allq = torch.empty(world * nmax, 768, device=device)
                 dist.all_gather_into_tensor(allq, pad)
-                sizes = [a.queries // world + (1 if r < a.queries % world else 0) for r in range(world)]
+                sizes = [shard_range(a.queries, world, r)[0] for r in range(world)]
                 queries = torch.cat([allq[r * nmax:r * nmax + sizes[r]] for r in range(world)])
             else:
                 queries = q_local
@@ -499,7 +511,7 @@ def main():
         line = {
             "metric": "passages/sec encode (bert-base DPR bi-encoder, 128 tok -> 768-d) "
                       "[+ queries/sec exact top-1000 over 8.8M x 768 in `search`]",
-            "value": round(passages_per_s, 1), "unit": "passages/s", "n_gpus": world, "steps": a.steps,
+            "value": round(passages_per_s, 1), "unit": "passages/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(t_enc / a.steps * 1e3, 3),
             "cold_first_pass_ms": round(prewarm_ms[0], 2),
             "prewarm": {"passes": len(prewarm_ms), "seconds": round(sum(prewarm_ms) / 1e3, 3), "last_ms": round(prewarm_ms[-1], 3),

@@ -376,6 +376,7 @@ int om_contrastive_fwd_bwd_ex(const float* q, const float* p, int Qg, int Pg, in
 int om_comm_unique_id(void* id128);
 int om_comm_init(const void* id128, int world, int rank, void** comm);
 int om_comm_destroy(void* comm);
+int om_comm_count(void* comm, int* count);   /* ranks of the communicator as RCCL reports them (ncclCommCount) */
 int om_allgather_rows(void* comm, const void* send, void* recv, int64_t rows, int64_t row_bytes, void* stream);
 int om_allreduce_grads(void* comm, float* buf, int64_t n, int average, void* stream);
 int om_exchange_topk(void* comm, int world, const float* D, const int64_t* I, int64_t q_block, int k, float* recvD,

@@ -36,6 +36,12 @@ class RcclComm:
         dist.broadcast_object_list(box, src=0)
         return cls(world, rank, device, box[0])
 
+    def count(self) -> int:
+        """Ranks of the communicator as RCCL reports them (ncclCommCount)."""
+        n = C.c_int(0)
+        N.check(N.lib().om_comm_count(self._h, C.byref(n)))
+        return int(n.value)
+
     def close(self):
         if self._h:
             N.check(N.lib().om_comm_destroy(self._h))

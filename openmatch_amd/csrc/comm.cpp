@@ -19,6 +19,7 @@ struct Api {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*);
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
   ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*CommCount)(const ncclComm_t, int*);
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
@@ -44,7 +45,7 @@ void bind() {
 #define OM_SYM(F)                                                                    \
   g_api.F = (decltype(g_api.F))dlsym(h, "nccl" #F);                                  \
   if (!g_api.F) { g_api.why = "RCCL symbol nccl" #F " missing"; return; }
-  OM_SYM(GetUniqueId) OM_SYM(CommInitRank) OM_SYM(CommDestroy) OM_SYM(AllGather) OM_SYM(AllReduce) OM_SYM(Send)
+  OM_SYM(GetUniqueId) OM_SYM(CommInitRank) OM_SYM(CommDestroy) OM_SYM(CommCount) OM_SYM(AllGather) OM_SYM(AllReduce) OM_SYM(Send)
   OM_SYM(Recv) OM_SYM(GroupStart) OM_SYM(GroupEnd) OM_SYM(GetErrorString)
 #undef OM_SYM
   g_api.ok = true;
@@ -85,6 +86,14 @@ extern "C" int om_comm_destroy(void* comm) {
   if (!comm) return 0;
   if (api()) return 1;
   OM_RCCL(g_api.CommDestroy((ncclComm_t)comm));
+  return 0;
+}
+
+// number of ranks of the communicator, as RCCL itself reports it (ncclCommCount)
+extern "C" int om_comm_count(void* comm, int* count) {
+  if (!comm || !count) OM_FAIL("null argument");
+  if (api()) return 1;
+  OM_RCCL(g_api.CommCount((ncclComm_t)comm, count));
   return 0;
 }
 

@@ -145,7 +145,7 @@ def sharded_topk(index, queries: torch.Tensor, k: int, id_offset: int, merge=Non
     blk = (Q + W - 1) // W
     pad = blk * W - Q
     if pad:
-        D = torch.cat([D, torch.full((pad, k), -3.4028235e38, dtype=D.dtype, device=dev)])
+        D = torch.cat([D, torch.full((pad, k), torch.finfo(torch.float32).min, dtype=D.dtype, device=dev)])
         I = torch.cat([I, torch.full((pad, k), -1, dtype=I.dtype, device=dev)])
     from .comm import native_comm
     comm = native_comm(dev) if D.is_cuda else None

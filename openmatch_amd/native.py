@@ -112,6 +112,7 @@ _SIGNATURES = {
     "om_comm_unique_id": (c_int, [c_void_p]),
     "om_comm_init": (c_int, [c_void_p, c_int, c_int, C.POINTER(c_void_p)]),
     "om_comm_destroy": (c_int, [c_void_p]),
+    "om_comm_count": (c_int, [c_void_p, C.POINTER(c_int)]),
     "om_allgather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "om_allreduce_grads": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "om_exchange_topk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),

@@ -160,3 +160,67 @@ def test_cross_device_negatives_and_gradient_averaging():
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert got[0] == pytest.approx(got[1], abs=1e-6)                         # identical loss on every rank
+
+
+def _uneven_worker(rank, world, port, n_rows, n_q, k, out_q):
+    """bench.py's multi-rank search branch on CPU: rows and queries split by bench.shard_range (uneven: the benchmark's
+    8 841 823 rows leave 7 over 8 ranks, its 6 980 queries 4), query all-gather with padding, per-shard search, candidates
+    exchanged by query range (all-to-all) and merged per slice."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from openmatch_amd.index import sharded_topk
+    d = 32
+    rng = np.random.default_rng(123)
+    P = rng.standard_normal((n_rows, d)).astype(np.float32)
+    Q = rng.standard_normal((n_q, d)).astype(np.float32)
+    rows, offset = bench.shard_range(n_rows, world, rank)
+    nq_local, q_off = bench.shard_range(n_q, world, rank)
+    shard = _OracleShard(d)
+    shard.add(P[offset:offset + rows])
+    # the query all-gather of bench.search_once (padded to the largest share, then trimmed)
+    nmax = (n_q + world - 1) // world
+    pad = torch.zeros(nmax, d)
+    pad[:nq_local] = torch.from_numpy(Q[q_off:q_off + nq_local])
+    allq = torch.empty(world * nmax, d)
+    dist.all_gather_into_tensor(allq, pad)
+    sizes = [bench.shard_range(n_q, world, r)[0] for r in range(world)]
+    queries = torch.cat([allq[r * nmax:r * nmax + sizes[r]] for r in range(world)])
+    assert torch.equal(queries, torch.from_numpy(Q))
+    Dm, Im, blk = sharded_topk(shard, queries, k, offset, merge=_merge_cpu)
+    lo, hi = rank * blk, min((rank + 1) * blk, n_q)
+    out_q.put((rank, rows, offset, lo, hi, Dm[:max(hi - lo, 0)].numpy(), Im[:max(hi - lo, 0)].numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_uneven_shards_equal_single_index():
+    """World size 8 with the benchmark's remainders in miniature: rows % 8 == 7, queries % 8 == 4 (8 841 823 and 6 980),
+    and a k larger than the smallest shard's useful rows for some queries.  Union of the rank slices == one index."""
+    from oracle import flatip
+    import bench
+    world, n_rows, n_q, k = 8, 8 * 53 + 7, 8 * 5 + 4, 60
+    assert 8_841_823 % 8 == n_rows % 8 and 6_980 % 8 == n_q % 8
+    assert sum(bench.shard_range(8_841_823, 8, r)[0] for r in range(8)) == 8_841_823
+    assert [bench.shard_range(8_841_823, 8, r)[1] for r in range(1, 8)] == [sum(bench.shard_range(8_841_823, 8, q)[0] for q in range(r)) for r in range(1, 8)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, n_rows, n_q, k, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert sorted(t[1] for t in got) == [53] * 1 + [54] * 7 and sum(t[1] for t in got) == n_rows
+    rng = np.random.default_rng(123)
+    P = rng.standard_normal((n_rows, 32)).astype(np.float32)
+    Q = rng.standard_normal((n_q, 32)).astype(np.float32)
+    single = flatip.IndexFlatIP(32); single.add(P)
+    D, I = single.search(Q, k)
+    covered = 0
+    for rank, rows, offset, lo, hi, Dm, Im in got:
+        if hi > lo:
+            assert np.array_equal(Im, I[lo:hi]), rank
+            assert np.allclose(Dm, D[lo:hi], atol=1e-6)
+            covered += hi - lo
+    assert covered == n_q

@@ -25,3 +25,25 @@ def test_two_ranks_over_rccl():
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(HERE, "mgpu_worker.py")],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "MGPU-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_bench_multi_rank_branches_on_two_gpus():
+    """bench.py's N > 1 branches (weak-scaling encode leg, query all-gather + sharded search + by-range merge, the
+    max-over-ranks timing and rank 0's JSON line) on tiny sizes, launched exactly as the driver launches it."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    repo = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(repo, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64", "--index-rows", "40001",
+                        "--queries", "37", "--topk", "100", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=repo)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["search"]["value"] > 0 and line["search"]["queries"] == 37
