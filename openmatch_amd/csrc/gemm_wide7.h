@@ -313,7 +313,7 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
             r0 = fmaf(fmaf(r0, ra[MI], rc[MI]), g4[0], b4[0]); r1 = fmaf(fmaf(r1, ra[MI], rc[MI]), g4[1], b4[1]); \
             r2 = fmaf(fmaf(r2, ra[MI], rc[MI]), g4[2], b4[2]); r3 = fmaf(fmaf(r3, ra[MI], rc[MI]), g4[3], b4[3]); \
           }                                                                                                    \
-          if (es.mul) { lo_[0] *= r0; lo_[1] *= r1; hi_[0] *= r2; hi_[1] *= r3; }                              \
+          if (!LNO && es.mul) { lo_[0] *= r0; lo_[1] *= r1; hi_[0] *= r2; hi_[1] *= r3; }   /* T5 gated act(.) * gate: never with LNO */ \
           else {                                                                                               \
             lo_[0] = epi_resid<ACT, sizeof(OutT) == 2>(lo_[0], r0, false); lo_[1] = epi_resid<ACT, sizeof(OutT) == 2>(lo_[1], r1, false);            \
             hi_[0] = epi_resid<ACT, sizeof(OutT) == 2>(hi_[0], r2, false); hi_[1] = epi_resid<ACT, sizeof(OutT) == 2>(hi_[1], r3, false);            \

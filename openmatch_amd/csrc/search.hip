@@ -299,115 +299,149 @@ __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7(
   G7_WAIT_VM(0);
 }
 
-// Small query batches (<= 32 queries): the scan is a pass over the whole f16 index (13.6 GB at 8.8 M x 768) that has to
+// Small query batches (<= 64 queries): the scan is a pass over the whole f16 index (13.6 GB at 8.8 M x 768) that has to
 // run at HBM speed.  The generic 128-query tile spends 1.7 PFLOP of matrix-core time on padding at Q = 1 (3.99 ms per
-// search in round 1, profiles/r01_search_shapes.jsonl) -- this kernel keeps ONE 32-query column block, resident in LDS for
-// the whole kernel ([K step][32 queries][128 B], 48 KiB at d = 768), and streams 256-row x 128-byte units of the index
-// through a three-slot LDS-DMA ring (the generation-7 unit layout and swizzle): 8 MFMAs per wave and unit against
-// 32 KiB of HBM traffic, two units (64 KiB per CU) in flight, one barrier per unit.  Persistent: one workgroup per CU
-// walks row tiles blockIdx, blockIdx + grid, ...  Whole 256-row tiles only (the host gives the tail to the generic kernel).
-#define SS_RING 3
-#define SS_QOFF (SS_RING * G7_UNIT_BYTES)
-template <typename T>
+// search in round 1, profiles/r01_search_shapes.jsonl) -- this kernel keeps NB 32-query column blocks resident in LDS for
+// the whole kernel ([block][K step][32 queries][128 B], 48 KiB per block at d = 768) and streams units of the index
+// through an LDS-DMA ring (the generation-7 unit layout and swizzle), one barrier per unit:
+//     NB = 1 (Q <= 32)   256-row units (32 KiB), three slots: two units (64 KiB per CU) in flight, 8 MFMAs per wave and unit
+//     NB = 2 (Q <= 64)   128-row units (16 KiB), four slots: three units (48 KiB per CU) in flight, 8 MFMAs per wave and unit
+//                        (round 3: batches of 33-64 fell onto the generation-2 filter kernel at 4.33 ms per search -- 0.39 of
+//                        the HBM rate -- although their 0.9 TFLOP of MFMA work is nothing; now one index pass as well)
+// Persistent: one workgroup per CU walks row tiles blockIdx, blockIdx + grid, ...  Whole 256-row tiles only (the host gives
+// the tail to the generic kernel).  LDS: ring | query blocks = 96 + 48 KiB or 64 + 96 KiB.
+#define SS_RING(NB) ((NB) == 1 ? 3 : 4)
+#define SS_UROWS(NB) ((NB) == 1 ? 256 : 128)
+#define SS_UBYTES(NB) (SS_UROWS(NB) * G7_ROW_BYTES)
+#define SS_QOFF(NB) (SS_RING(NB) * SS_UBYTES(NB))
+#define SS_LDS(NB) (SS_QOFF(NB) + (NB) * 12 * 4096)
+template <typename T, int NB>
 __global__ __launch_bounds__(G6_THREADS) void sim_stream_kernel(
     const T* __restrict__ rows, int64_t nrows, uint32_t row_base, const T* __restrict__ queries, int64_t nq, int64_t d,
     const float* __restrict__ thr, u64* __restrict__ keys, unsigned* __restrict__ cnt) {
   typedef typename MmaOps<T>::frag_t frag_t;
+  constexpr int RING = SS_RING(NB), UROWS = SS_UROWS(NB), UBYTES = SS_UBYTES(NB);
+  constexpr int IPU = UROWS / 32;                // DMA instructions per wave and unit
+  constexpr int RB = UROWS / 128;                // 32-row blocks per wave and unit
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int lane = threadIdx.x & 63;
   asm volatile("" : "+v"(lane));
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nk = (int)((d * 2) / G7_ROW_BYTES);
-  const int64_t ntiles = nrows / 256;
+  const int64_t ntiles = nrows / UROWS;
   const int my_tiles = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
   if (my_tiles <= 0) return;
   const int units = my_tiles * nk;
   const uint32_t lds0 = g7_lds_addr(smem);
 
-  // DMA offsets of a 256-row unit: instruction i of this wave moves rows (i*4 + wave)*8 .. +7, lane -> row (lane >> 3),
+  // DMA offsets of a unit: instruction i of this wave moves rows (i*4 + wave)*8 .. +7, lane -> row (lane >> 3),
   // physical chunk (lane & 7) <- source chunk (lane & 7) ^ ((row >> 1) & 7)
-  uint32_t off[8];
+  uint32_t off[IPU];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < IPU; ++i) {
     const int r = (i * 4 + wave) * 8 + (lane >> 3);
     off[i] = (uint32_t)(r * d * 2) + ((((lane & 7) ^ ((r >> 1) & 7))) << 4);
   }
-  // the queries: K step ks, rows (queries) 8 j .. 8 j + 7 per instruction; wave w takes K steps w, w + 4, ...
+  // the queries: block nb, K step ks, rows (queries) 8 j .. 8 j + 7 per instruction; wave w takes K steps w, w + 4, ...
   {
-    uint32_t qoff[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = j * 8 + (lane >> 3);
-      const int rr = r < nq ? r : (int)nq - 1;                // padding rows repeat the last query (their threshold is +inf)
-      qoff[j] = (uint32_t)(rr * d * 2) + ((((lane & 7) ^ ((r >> 1) & 7))) << 4);
+    for (int nb = 0; nb < NB; ++nb) {
+      uint32_t qoff[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = j * 8 + (lane >> 3);
+        const int qr = nb * 32 + r;
+        const int rr = qr < nq ? qr : (int)nq - 1;              // padding rows repeat the last query (their threshold is +inf)
+        qoff[j] = (uint32_t)(rr * d * 2) + ((((lane & 7) ^ ((r >> 1) & 7))) << 4);
+      }
+      for (int ks = wave; ks < nk; ks += 4)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          g7_dma((const char*)queries + ks * G7_ROW_BYTES, qoff[j], lds0 + SS_QOFF(NB) + (nb * 12 + ks) * 4096 + j * 1024);
     }
-    for (int ks = wave; ks < nk; ks += 4)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) g7_dma((const char*)queries + ks * G7_ROW_BYTES, qoff[j], lds0 + SS_QOFF + ks * 4096 + j * 1024);
   }
-  const float th = thr[lane & 31];
+  float th[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) th[nb] = thr[nb * 32 + (lane & 31)];
   auto issue = [&](int u) {
     const int64_t tile = blockIdx.x + (int64_t)(u / nk) * gridDim.x;
-    const char* base = (const char*)(rows + tile * 256 * d) + (u % nk) * G7_ROW_BYTES;
-    const uint32_t dst = lds0 + (u % SS_RING) * G7_UNIT_BYTES + wave * 1024;
+    const char* base = (const char*)(rows + tile * UROWS * d) + (u % nk) * G7_ROW_BYTES;
+    const uint32_t dst = lds0 + (u % RING) * UBYTES + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) g7_dma(base, off[i], dst + i * 4096);
+    for (int i = 0; i < IPU; ++i) g7_dma(base, off[i], dst + i * 4096);
   };
-  issue(0);
-  if (units > 1) issue(1);
+#pragma unroll
+  for (int u = 0; u < RING - 1; ++u)
+    if (u < units) issue(u);
 
   const int half = lane >> 5, l31 = lane & 31, key = (l31 >> 1) & 7;
-  const int arow = (wave * 64 + l31) * G7_ROW_BYTES;          // + rt * 32 rows
+  const int arow = (wave * (UROWS / 4) + l31) * G7_ROW_BYTES;   // + rt * 32 rows
   const int brow = l31 * G7_ROW_BYTES;
-  f32x16_t acc[2];
+  f32x16_t acc[RB][NB];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+  for (int rt = 0; rt < RB; ++rt)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rt][nb][r] = 0.f;
   int ks = 0;
   int64_t tile = blockIdx.x;
   for (int u = 0; u < units; ++u) {
-    if (u + 1 < units) G7_WAIT_VM(8); else G7_WAIT_VM(0);      // unit u (and the queries) landed; unit u + 1 may be in flight
+    // unit u (and the queries) landed; up to RING - 2 younger units may be in flight
+    const int younger = units - 1 - u;
+    if (RING == 4 && younger >= 2) G7_WAIT_VM(2 * IPU);
+    else if (younger >= 1) G7_WAIT_VM(IPU);
+    else G7_WAIT_VM(0);
     __builtin_amdgcn_s_barrier();                              // ... for every wave; and unit u - 1 has been read by all
-    if (u + 2 < units) issue(u + 2);
-    const char* ua = smem + (u % SS_RING) * G7_UNIT_BYTES + arow;
-    const char* ub = smem + SS_QOFF + ks * 4096 + brow;
+    if (u + RING - 1 < units) issue(u + RING - 1);
+    const char* ua = smem + (u % RING) * UBYTES + arow;
+    const char* ub = smem + SS_QOFF(NB) + ks * 4096 + brow;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int slot = (((kk << 1) | half) ^ key) << 4;
-      const frag_t b = *(const frag_t*)(ub + slot);
-      const frag_t a0 = *(const frag_t*)(ua + slot);
-      const frag_t a1 = *(const frag_t*)(ua + 32 * G7_ROW_BYTES + slot);
-      MmaOps<T>::mma(a0, b, acc[0]);            // acc[rt][r]: row 8(r>>2) + 4 half + (r&3) of the 32-row block, query l31
-      MmaOps<T>::mma(a1, b, acc[1]);
+      frag_t b[NB], a[RB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) b[nb] = *(const frag_t*)(ub + nb * 12 * 4096 + slot);
+#pragma unroll
+      for (int rt = 0; rt < RB; ++rt) a[rt] = *(const frag_t*)(ua + rt * 32 * G7_ROW_BYTES + slot);
+#pragma unroll
+      for (int rt = 0; rt < RB; ++rt)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          MmaOps<T>::mma(a[rt], b[nb], acc[rt][nb]);            // acc[rt][nb][r]: row 8(r>>2) + 4 half + (r&3) of the 32-row block, query 32 nb + l31
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (++ks == nk) {
       ks = 0;
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const f32x16_t a = acc[rt];
-        float mx = fmaxf(fmaxf(a[0], a[1]), a[2]);
+      for (int rt = 0; rt < RB; ++rt)
 #pragma unroll
-        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, a[r]), a[r + 1]);
-        mx = fmaxf(mx, a[15]);
-        if (mx >= th) {                                          // rare by construction of the thresholds
-          // one atomic per lane and block, not per survivor: with one query every append of the round lands on the
-          // same counter, and the first rounds keep a third of their rows (~5 k same-address atomics were ~50 us of a
-          // 57 us round -- profiles/r02_search_q1_timeline.log)
-          const uint32_t id0 = row_base + (uint32_t)(tile * 256) + wave * 64 + rt * 32 + 4 * half;
-          unsigned n = 0;
+        for (int nb = 0; nb < NB; ++nb) {
+          const f32x16_t a = acc[rt][nb];
+          float mx = fmaxf(fmaxf(a[0], a[1]), a[2]);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) n += a[r] >= th ? 1u : 0u;
-          unsigned pos = atomicAdd(cnt + l31, n);
+          for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, a[r]), a[r + 1]);
+          mx = fmaxf(mx, a[15]);
+          if (mx >= th[nb]) {                                      // rare by construction of the thresholds
+            // one atomic per lane and block, not per survivor: with one query every append of the round lands on the
+            // same counter, and the first rounds keep a third of their rows (~5 k same-address atomics were ~50 us of a
+            // 57 us round -- profiles/r02_search_q1_timeline.log)
+            const uint32_t id0 = row_base + (uint32_t)(tile * UROWS) + wave * (UROWS / 4) + rt * 32 + 4 * half;
+            const int qi = nb * 32 + l31;
+            unsigned n = 0;
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (a[r] >= th) {
-              if (pos < SORT_CAP) keys[(int64_t)l31 * SORT_CAP + pos] = pack_key(a[r], id0 + (r & 3) + 8 * (r >> 2));
-              ++pos;
-            }
+            for (int r = 0; r < 16; ++r) n += a[r] >= th[nb] ? 1u : 0u;
+            unsigned pos = atomicAdd(cnt + qi, n);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (a[r] >= th[nb]) {
+                if (pos < SORT_CAP) keys[(int64_t)qi * SORT_CAP + pos] = pack_key(a[r], id0 + (r & 3) + 8 * (r >> 2));
+                ++pos;
+              }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[rt][nb][r] = 0.f;
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
-      }
       tile += gridDim.x;
     }
   }
@@ -853,14 +887,20 @@ struct Scan {
           hipLaunchKernelGGL((sim_filter_kernel6<f16_t>), dim3((unsigned)ntn), dim3(G6_THREADS), G6_LDS_BYTES, s, idx16 + (r0 + whole) * d,
                              n - whole, (uint32_t)(r0 + whole), ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8);
       } else if (wide) SCAN(sim_filter_kernel6, G6_THREADS, G6_LDS_BYTES, f16_t, idx16, ws.qb);
-      else if (nq <= 32 && (d * 2) / G7_ROW_BYTES <= 12 && om_option(OM_OPT_SCAN_GEN7)) {
+      else if (nq <= 64 && (d * 2) / G7_ROW_BYTES <= 12 && om_option(OM_OPT_SCAN_GEN7)) {
         // the HBM-speed pass for small batches over the whole tiles; the generic kernel takes the ragged tail
         const int64_t whole = n & ~(int64_t)255;
         if (whole) {
           int ncu = g7_num_cus();
-          if (whole / 256 < ncu) ncu = (int)(whole / 256);
-          hipLaunchKernelGGL((sim_stream_kernel<f16_t>), dim3((unsigned)ncu), dim3(G6_THREADS), SS_QOFF + 12 * 4096, s, idx16 + r0 * d, whole,
-                             (uint32_t)r0, ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt);
+          if (nq <= 32) {
+            if (whole / 256 < ncu) ncu = (int)(whole / 256);
+            hipLaunchKernelGGL((sim_stream_kernel<f16_t, 1>), dim3((unsigned)ncu), dim3(G6_THREADS), SS_LDS(1), s, idx16 + r0 * d, whole,
+                               (uint32_t)r0, ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt);
+          } else {
+            if (whole / 128 < ncu) ncu = (int)(whole / 128);
+            hipLaunchKernelGGL((sim_stream_kernel<f16_t, 2>), dim3((unsigned)ncu), dim3(G6_THREADS), SS_LDS(2), s, idx16 + r0 * d, whole,
+                               (uint32_t)r0, ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt);
+          }
         }
         if (n > whole)
           hipLaunchKernelGGL((sim_filter_kernel<f16_t>), dim3(1), dim3(G2_THREADS), G2_LDS_BYTES, s, idx16 + (r0 + whole) * d, n - whole,
@@ -1043,7 +1083,8 @@ extern "C" int om_sim_topk(int mode, const float* queries, int64_t n_queries,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES));
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel6<f16_t>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES));
-    OM_HIP(hipFuncSetAttribute((const void*)sim_stream_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, SS_QOFF + 12 * 4096));
+    OM_HIP(hipFuncSetAttribute((const void*)sim_stream_kernel<f16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SS_LDS(1)));
+    OM_HIP(hipFuncSetAttribute((const void*)sim_stream_kernel<f16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SS_LDS(2)));
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel7<f16_t>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
     OM_HIP(hipFuncSetAttribute((const void*)select_radix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -34,6 +34,7 @@ static void fill_f32(float* d, size_t n, float a, float b) {
 }
 
 static bool g_zero = false;
+static bf16_t *g_rlo = nullptr, *g_clo = nullptr;
 template <int ACT, bool RESID, int LNF>
 static void run(const char* what, int64_t M, int64_t N, int64_t K, const bf16_t* A, const bf16_t* B, bf16_t* C, const bf16_t* R,
                 const float* vecs, float* stats_in, float* stats_out) {
@@ -43,7 +44,8 @@ static void run(const char* what, int64_t M, int64_t N, int64_t K, const bf16_t*
   ep.ln_inv_h = 1.0f / 768.0f; ep.ln_eps = 1e-12f;
   if (LNF == 1) { ep.ln_stats = stats_in; ep.ln_colsum = vecs + 4096; }
   if (RESID) { ep.resid = R; ep.ldr = N; }
-  if (LNF == 2) { ep.rln_stats = stats_in; ep.rln_g = vecs + 8192; ep.rln_b = vecs + 12288; ep.stats_out = stats_out; }
+  if (LNF >= 2) { ep.rln_stats = stats_in; ep.rln_g = vecs + 8192; ep.rln_b = vecs + 12288; ep.stats_out = stats_out; }
+  if (LNF == 3) { ep.resid_lo = g_rlo; ep.out_lo = g_clo; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i) launch7<bf16_t, ACT, RESID, LNF>(A, K, B, K, C, N, M, N, K, ep, 0);
   const int reps = 20;
@@ -54,7 +56,7 @@ static void run(const char* what, int64_t M, int64_t N, int64_t K, const bf16_t*
   float ms = 0; hipEventElapsedTime(&ms, e0, e1);
   ms /= reps;
   const double tiles_per_cu = (double)(M / 256) * (N / 256) / 256.0;
-  printf("D%dk%d%s ABL=%-3d %-28s M=%ld N=%ld K=%ld : %8.1f us  %7.1f TFLOP/s  %7.2f us per tile-slot (%.0f tiles/CU)\n", G7_DEFER_STORES, G7_SKEW, g_zero ? "z" : "", G7_ABL, what, (long)M,
+  printf("%s%s ABL=%-3d %-28s M=%ld N=%ld K=%ld : %8.1f us  %7.1f TFLOP/s  %7.2f us per tile-slot (%.0f tiles/CU)\n", VARIANT, g_zero ? "z" : "", G7_ABL, what, (long)M,
          (long)N, (long)K, ms * 1e3, 2.0 * M * N * K / (ms * 1e9), ms * 1e3 / tiles_per_cu, tiles_per_cu);
 }
 
@@ -82,7 +84,7 @@ static void check_plain(int64_t M, int64_t N, int64_t K, const bf16_t* A, const 
     if (!(err <= tol)) ++bad;
     worst = std::max(worst, err);
   }
-  printf("CHECK sched=%d ABL=%d M=%ld N=%ld K=%ld: %s (max |err| %.4f over 512 samples)\n", G7_SCHED, G7_ABL, (long)M, (long)N, (long)K,
+  printf("CHECK r3%d ABL=%d M=%ld N=%ld K=%ld: %s (max |err| %.4f over 512 samples)\n", 0, G7_ABL, (long)M, (long)N, (long)K,
          bad ? "FAILED" : "ok", worst);
 }
 
@@ -90,7 +92,7 @@ int main(int argc, char** argv) {
   const int64_t M = 131072;
   bf16_t *A, *B, *C, *R; float *vecs, *st_in, *st_out;
   hipMalloc(&A, (size_t)M * 3072 * 2); hipMalloc(&B, (size_t)3072 * 3072 * 2); hipMalloc(&C, (size_t)M * 3072 * 2); hipMalloc(&R, (size_t)M * 768 * 2);
-  hipMalloc(&vecs, 16384 * 4); hipMalloc(&st_in, (size_t)M * 8); hipMalloc(&st_out, (size_t)M * 8);
+  hipMalloc(&vecs, 16384 * 4); hipMalloc(&st_in, (size_t)M * 8); hipMalloc(&st_out, (size_t)M * 8 * 8);
   const bool zero = argc > 1; g_zero = zero;          // any argument: zero-filled operands (how much of the rate is the power limit?)
   if (zero) { hipMemset(A, 0, (size_t)M * 3072 * 2); hipMemset(B, 0, (size_t)3072 * 3072 * 2); hipMemset(R, 0, (size_t)M * 768 * 2); printf("operands: zeros\n"); }
   else { fill_bf16(A, (size_t)M * 3072, 1.0f, 1); fill_bf16(B, (size_t)3072 * 3072, 0.05f, 2); fill_bf16(R, (size_t)M * 768, 1.0f, 3); }
@@ -101,6 +103,7 @@ int main(int argc, char** argv) {
     hipMemcpy(st_in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   }
   hipMemset(st_out, 0, (size_t)M * 8);
+  hipMalloc(&g_rlo, (size_t)M * 768 * 2); hipMalloc(&g_clo, (size_t)M * 768 * 2); fill_bf16(g_rlo, (size_t)M * 768, 0.004f, 7);
   if (!(G7_ABL)) {
     check_plain(4096, 768, 768, A, B, C, vecs); check_plain(2048, 2304, 768, A, B, C, vecs); check_plain(2048, 768, 3072, A, B, C, vecs);
     check_plain(512, 512, 128, A, B, C, vecs); check_plain(512, 256, 64, A, B, C, vecs); check_plain(65536, 768, 192, A, B, C, vecs);
@@ -111,6 +114,8 @@ int main(int argc, char** argv) {
     run<OM_ACT_GELU_ERF, false, 1>("ffn1 + gelu (ln-folded A)", M, 3072, 768, A, B, C, R, vecs, st_in, st_out);
     run<OM_ACT_NONE, false, 1>("ffn1 shape, no gelu", M, 3072, 768, A, B, C, R, vecs, st_in, st_out);
     run<OM_ACT_NONE, true, 2>("ffn2 (+LN resid, stats)", M, 768, 3072, A, B, C, R, vecs, st_in, st_out);
+    run<OM_ACT_NONE, true, 3>("out-proj two planes", M, 768, 768, A, B, C, R, vecs, st_in, st_out);
+    run<OM_ACT_NONE, true, 3>("ffn2 two planes", M, 768, 3072, A, B, C, R, vecs, st_in, st_out);
     run<OM_ACT_NONE, false, 0>("plain", 32768, 3072, 3072, A, B, C, R, vecs, st_in, st_out);
   }
   return 0;
