@@ -290,14 +290,30 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
             rplo[nl][j] = *(const uint2*)(buf2 + (((nl * 4 + j) ^ ((l31 >> 1) & 7)) << 4));                    \
       }                                                                                                        \
     }                                                                                                          \
+    if (!LNO) {                                                                                                \
+    f32x8_t gq[4];        /* erf-GELU: the patch's 32 values, eight per polynomial evaluation (four chains in flight) */ \
+    if (ACT == OM_ACT_GELU_ERF) {                                                                              \
+      _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                       \
+        f32x8_t v8;                                                                                            \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) v8[e] = acc[MI][NH * 2 + (g_ >> 1)][8 * (g_ & 1) + e];    \
+        if (LNF == 1) v8 *= rs[MI];                                                                            \
+        gq[g_] = gelu_erf_poly8(v8);                                                                           \
+      }                                                                                                        \
+    }                                                                                                          \
     _Pragma("unroll") for (int nl = 0; nl < 2; ++nl)                                                           \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                          \
         const int ni = NH * 2 + nl;                                                                            \
         const int64_t n = nc + ni * 32 + 8 * j + 4 * half;                                                     \
         f32x2_t a_lo = {acc[MI][ni][4 * j], acc[MI][ni][4 * j + 1]}, a_hi = {acc[MI][ni][4 * j + 2], acc[MI][ni][4 * j + 3]}; \
         if (LNF == 1) { a_lo *= rs[MI]; a_hi *= rs[MI]; }                                                      \
-        f32x2_t lo_ = epi_pair<ACT, false, OutT>(a_lo, m, n, M, N, ep, es, 0, 0);                                    \
-        f32x2_t hi_ = epi_pair<ACT, false, OutT>(a_hi, m, n + 2, M, N, ep, es, 0, 0);                                \
+        f32x2_t lo_, hi_;                                                                                      \
+        if (ACT == OM_ACT_GELU_ERF) {                                                                          \
+          const f32x8_t g8 = gq[nl * 2 + (j >> 1)];                                                            \
+          lo_ = (f32x2_t){g8[4 * (j & 1)], g8[4 * (j & 1) + 1]}; hi_ = (f32x2_t){g8[4 * (j & 1) + 2], g8[4 * (j & 1) + 3]}; \
+        } else {                                                                                               \
+          lo_ = epi_pair<ACT, false, OutT>(a_lo, m, n, M, N, ep, es, 0, 0);                                    \
+          hi_ = epi_pair<ACT, false, OutT>(a_hi, m, n + 2, M, N, ep, es, 0, 0);                                \
+        }                                                                                                      \
         if (RESID) {                                                                                           \
           const uint2 rr = rpatch[nl][j];                                                                      \
           float r0 = Half16<OutT>::lo(rr.x), r1 = Half16<OutT>::hi(rr.x);                                      \
@@ -329,6 +345,54 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
                                          Half16<OutT>::pack2(hi_[0] - Half16<OutT>::lo(pk_.y), hi_[1] - Half16<OutT>::hi(pk_.y))); \
           if (G7_ABL & 2) asm volatile("" ::"v"(pk_)); else *(uint2*)(st_wr + (((nl * 4 + j) ^ skey) << 4)) = pk_; }  \
       }                                                                                                        \
+    } else {                                                                                                   \
+    /* Output-side LayerNorm variants: the same arithmetic on EIGHT values per step (columns 8 j .. of two adjacent j): \
+       every step expands into four independent packed instructions, where the per-(nl, j) form left the compiler one \
+       or two dependent chains at ~9 cycles per instruction (tools/gemm7_probe.hip: 12 us of a 25 us two-plane epilogue) */ \
+    f32x8_t s8 = 0.f, q8 = 0.f;                                                                                \
+    _Pragma("unroll") for (int nl = 0; nl < 2; ++nl)                                                           \
+      _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) {                                                       \
+        const int ni = NH * 2 + nl;                                                                            \
+        f32x8_t v8;                                                                                            \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) v8[e] = acc[MI][ni][8 * jp + e];                         \
+        const uint2 ra_ = rpatch[nl][2 * jp], rb_ = rpatch[nl][2 * jp + 1];                                    \
+        f32x8_t r8 = {Half16<OutT>::lo(ra_.x), Half16<OutT>::hi(ra_.x), Half16<OutT>::lo(ra_.y), Half16<OutT>::hi(ra_.y), \
+                      Half16<OutT>::lo(rb_.x), Half16<OutT>::hi(rb_.x), Half16<OutT>::lo(rb_.y), Half16<OutT>::hi(rb_.y)}; \
+        if (TWO) {                                                                                             \
+          const uint2 la_ = rplo[nl][2 * jp], lb_ = rplo[nl][2 * jp + 1];                                      \
+          const f32x8_t l8 = {Half16<OutT>::lo(la_.x), Half16<OutT>::hi(la_.x), Half16<OutT>::lo(la_.y), Half16<OutT>::hi(la_.y), \
+                              Half16<OutT>::lo(lb_.x), Half16<OutT>::hi(lb_.x), Half16<OutT>::lo(lb_.y), Half16<OutT>::hi(lb_.y)}; \
+          r8 = __builtin_elementwise_fma(l8, (f32x8_t)(rlo_scale), r8);                                        \
+        }                                                                                                      \
+        if (res_ln) {                                                                                          \
+          const int c0 = ni * 32 + 16 * jp + 4 * half;              /* columns c0 .. c0 + 3 and c0 + 8 .. c0 + 11 */ \
+          const f32x4_t ga = *(const f32x4_t*)(etab + c0 * 4), gb = *(const f32x4_t*)(etab + (c0 + 8) * 4);     \
+          const f32x4_t ba = *(const f32x4_t*)(etab + 512 + c0 * 4), bb = *(const f32x4_t*)(etab + 512 + (c0 + 8) * 4); \
+          const f32x8_t g8 = __builtin_shufflevector(ga, gb, 0, 1, 2, 3, 4, 5, 6, 7);                          \
+          const f32x8_t b8 = __builtin_shufflevector(ba, bb, 0, 1, 2, 3, 4, 5, 6, 7);                          \
+          r8 = __builtin_elementwise_fma(__builtin_elementwise_fma(r8, (f32x8_t)(ra[MI]), (f32x8_t)(rc[MI])), g8, b8); \
+        }                                                                                                      \
+        v8 += r8;                                                                                              \
+        s8 += v8;                                                                                              \
+        q8 = __builtin_elementwise_fma(v8, v8, q8);                                                            \
+        const uint2 pa_ = make_uint2(Half16<OutT>::pack2(v8[0], v8[1]), Half16<OutT>::pack2(v8[2], v8[3]));    \
+        const uint2 pb_ = make_uint2(Half16<OutT>::pack2(v8[4], v8[5]), Half16<OutT>::pack2(v8[6], v8[7]));    \
+        if (TWO) {          /* what the 16-bit words dropped, rounded once more: y = hi + lo to ~2^-17 */       \
+          const f32x8_t h8 = {Half16<OutT>::lo(pa_.x), Half16<OutT>::hi(pa_.x), Half16<OutT>::lo(pa_.y), Half16<OutT>::hi(pa_.y), \
+                              Half16<OutT>::lo(pb_.x), Half16<OutT>::hi(pb_.x), Half16<OutT>::lo(pb_.y), Half16<OutT>::hi(pb_.y)}; \
+          const f32x8_t d8 = v8 - h8;                                                                          \
+          plo[nl * 4 + 2 * jp] = make_uint2(Half16<OutT>::pack2(d8[0], d8[1]), Half16<OutT>::pack2(d8[2], d8[3])); \
+          plo[nl * 4 + 2 * jp + 1] = make_uint2(Half16<OutT>::pack2(d8[4], d8[5]), Half16<OutT>::pack2(d8[6], d8[7])); \
+        }                                                                                                      \
+        if (G7_ABL & 2) asm volatile("" ::"v"(pa_), "v"(pb_));                                                 \
+        else {                                                                                                 \
+          *(uint2*)(st_wr + (((nl * 4 + 2 * jp) ^ skey) << 4)) = pa_;                                          \
+          *(uint2*)(st_wr + (((nl * 4 + 2 * jp + 1) ^ skey) << 4)) = pb_;                                      \
+        }                                                                                                      \
+      }                                                                                                        \
+    ssum[0] += (s8[0] + s8[1]) + (s8[2] + s8[3]); ssum[1] += (s8[4] + s8[5]) + (s8[6] + s8[7]);                \
+    ssq[0] += (q8[0] + q8[1]) + (q8[2] + q8[3]); ssq[1] += (q8[4] + q8[5]) + (q8[6] + q8[7]);                  \
+    }                                                                                                          \
     if (LNO && NH == 1) {           /* both column halves of the row block done: this wave's partial sums of the row */ \
       float s1 = ssum[0] + ssum[1], s2 = ssq[0] + ssq[1];                                                      \
       s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);                                              \
