@@ -288,6 +288,13 @@ int om_encoder_train_backward(const OmEncoderConfig* cfg, const OmEncoderWeights
                               const void* tape, const float* d_reps, const OmEncoderGrads* grads,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* Gradient all-reduce overlapped with the backward (multi-GPU training): hand the NEXT om_encoder_train_backward on this
+ * thread an array of n_layers + 1 hipEvent_t.  events[l] (l = n_layers-1 .. 0) is recorded on the backward's stream once
+ * every kernel that writes layer l's gradients has been enqueued, events[n_layers] after the embedding gradients: a
+ * side stream that waits for events[l] can all-reduce layer l's slice of the gradient arena while the rest of the
+ * backward still runs.  NULL entries are skipped; the array is consumed by one backward. */
+int om_encoder_train_set_layer_events(void* const* events, int n);
+
 /* ------------------------------------------------------------------------
  * Exact inner-product search.  Replaces faiss.IndexFlatIP.add / .search
  * (retriever/dense_retriever.py:38-41,105,180) and faiss-GPU sharding (:43-58).

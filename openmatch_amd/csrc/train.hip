@@ -216,6 +216,23 @@ int t5_train_forward(const OmEncoderConfig* c, const OmEncoderWeights* w, const 
   return 0;
 }
 
+// Progress events of the NEXT backward on this thread (gradient all-reduce overlapped with the backward: the host waits
+// for event l on a side stream and reduces layer l's slice of the gradient arena while layers l-1 .. 0 are still being
+// differentiated).  events[l], l = n_layers-1 .. 0: recorded on the backward's stream once every kernel writing layer l's
+// gradients has been enqueued; events[n_layers]: everything (embeddings, T5 position table) enqueued.  Consumed by one call.
+static thread_local void* const* g_bwd_events = nullptr;
+static thread_local int g_bwd_nevents = 0;
+extern "C" int om_encoder_train_set_layer_events(void* const* events, int n) {
+  if (n < 0 || (n > 0 && !events)) OM_FAIL("bad event array");
+  g_bwd_events = n > 0 ? events : nullptr;
+  g_bwd_nevents = n;
+  return 0;
+}
+static int record_layer_event(int l, hipStream_t s) {
+  if (g_bwd_events && l < g_bwd_nevents && g_bwd_events[l]) OM_HIP(hipEventRecord((hipEvent_t)g_bwd_events[l], s));
+  return 0;
+}
+
 // dx: gradient w.r.t. the stack's output (after the final dropout); returns through the grads struct
 int t5_train_backward(const OmEncoderConfig* c, const OmEncoderWeights* w, const int64_t* input_ids,
                       const int64_t* attention_mask, const Dims& d, const Tape& t, Ws& ws, float hd, float ad,
@@ -281,12 +298,15 @@ int t5_train_backward(const OmEncoderConfig* c, const OmEncoderWeights* w, const
     e = GemmEpilogue{};
     RUN(omk_gemm(dt, ws.dqkv, 3 * H, wt.qkv, 3 * H, dt, ws.dy, H, M, H, 3 * H, e, s));  // dn1
     RUN(omk_norm_bwd(dt, ws.dy, x, lw.ln1_g, dx, lg.ln1_g, nullptr, M, H, c->ln_eps, 1, dx_other, s));   // dx of layer input
+    RUN(record_layer_event(l, s));
   }
 #undef WGRAD
   const char* de = dx;
   if (hd > 0.f) { RUN(omk_dropout(dt, dx, ws.dd, M * H, hd, site_seed(seed, 0, 0), s)); de = ws.dd; }
   RUN(omk_t5_embed_bwd(dt, de, input_ids, g->word_emb, M, H, c->vocab, s));
   RUN(omk_t5_bias_bwd(ws.drel, ws.lut, g->rel_bias, (int)d.L, d.nh, s));
+  RUN(record_layer_event(d.nl, s));
+  g_bwd_events = nullptr; g_bwd_nevents = 0;
   return 0;
 }
 #undef RUN
@@ -475,6 +495,7 @@ extern "C" int om_encoder_train_backward(const OmEncoderConfig* c, const OmEncod
       RUN(omk_gemm(dt, ws.dqkv, 3 * H, wt.qkv, 3 * H, dt, dx_prev, H, M, H, 3 * H, e4, s));
     }
     char* tmp = dx; dx = dx_prev; dx_prev = tmp;
+    RUN(record_layer_event(l, s));
   }
   // ---- embeddings: dropout bwd -> LayerNorm bwd -> scatter into the three tables -------------
   const char* de = dx;
@@ -483,5 +504,7 @@ extern "C" int om_encoder_train_backward(const OmEncoderConfig* c, const OmEncod
                     w->emb_ln_g, g->word_emb, g->pos_emb, g->type_emb, g->emb_ln_g, g->emb_ln_b, M,
                     (int)L, H, c->vocab, c->type_vocab, c->ln_eps, s));
 #undef WGRAD
+  RUN(record_layer_event(d.nl, s));
+  g_bwd_events = nullptr; g_bwd_nevents = 0;
   return 0;
 }

@@ -109,6 +109,7 @@ _SIGNATURES = {
     "om_contrastive_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                        c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p]),
+    "om_encoder_train_set_layer_events": (c_int, [c_void_p, c_int]),
     "om_comm_unique_id": (c_int, [c_void_p]),
     "om_comm_init": (c_int, [c_void_p, c_int, c_int, C.POINTER(c_void_p)]),
     "om_comm_destroy": (c_int, [c_void_p]),

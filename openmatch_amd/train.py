@@ -102,17 +102,20 @@ class _EncoderTrain(torch.autograd.Function):
             return t
         layers = (N.OmLayerGrads * nl)()
         per_layer = []
+        layer_bounds = []                       # arena span of every layer (grad_sync buckets)
         if t5:
             gw = buf(g, "word_emb", *model.encoder.embed_tokens.weight.shape)
             gfin = buf(g, "final_ln_g", H)
             grel = buf(g, "rel_bias", cfg.rel_buckets, cfg.n_heads)
             for l in range(nl):
                 lg = layers[l]
+                lo_ = cursor[0]
                 d = dict(qkv_w=buf(lg, "qkv_w", 3 * H, H), o_w=buf(lg, "o_w", H, H), ln1_g=buf(lg, "ln1_g", H),
                          ffn1_w=buf(lg, "ffn1_w", F, H), ffn2_w=buf(lg, "ffn2_w", H, F), ln2_g=buf(lg, "ln2_g", H))
                 if gated:
                     d["ffn1g_w"] = buf(lg, "ffn1g_w", F, H)
                 per_layer.append(d)
+                layer_bounds.append((lo_, cursor[0]))
         else:
             gw = buf(g, "word_emb", *emb.word_embeddings.weight.shape)
             gp = buf(g, "pos_emb", *emb.position_embeddings.weight.shape)
@@ -122,16 +125,29 @@ class _EncoderTrain(torch.autograd.Function):
             gb = buf(g, "emb_ln_b", H)
             for l in range(nl):
                 lg = layers[l]
+                lo_ = cursor[0]
                 per_layer.append(dict(
                     qkv_w=buf(lg, "qkv_w", 3 * H, H), qkv_b=buf(lg, "qkv_b", 3 * H), o_w=buf(lg, "o_w", H, H),
                     o_b=buf(lg, "o_b", H), ln1_g=buf(lg, "ln1_g", H), ln1_b=buf(lg, "ln1_b", H),
                     ffn1_w=buf(lg, "ffn1_w", F, H), ffn1_b=buf(lg, "ffn1_b", F), ffn2_w=buf(lg, "ffn2_w", H, F),
                     ffn2_b=buf(lg, "ffn2_b", H), ln2_g=buf(lg, "ln2_g", H), ln2_b=buf(lg, "ln2_b", H)))
+                layer_bounds.append((lo_, cursor[0]))
         g.layers_host = C.cast(layers, C.POINTER(N.OmLayerGrads))
         ghead = buf(g, "head_w", cfg.head_out, cfg.head_in) if cfg.head_in > 0 else None
         d_reps = d_reps.to(torch.float32).contiguous()
         lib = N.lib()
+        # data-parallel training: the trainer's GradSync (if one is active for this step) all-reduces the arena in
+        # layer-group buckets while the backward runs -- one event per layer tells it when a bucket is complete
+        from . import grad_sync
+        sync = grad_sync.active()
+        events = None
         with torch.cuda.device(device):
+            if sync is not None:
+                events = [torch.cuda.Event() for _ in range(nl + 1)]
+                for e in events:
+                    e.record(torch.cuda.current_stream(device))           # materialises the hipEvent_t handle
+                handles = (C.c_void_p * (nl + 1))(*[e.cuda_event for e in events])
+                N.check(lib.om_encoder_train_set_layer_events(handles, nl + 1))
             nws = lib.om_encoder_train_workspace_bytes(C.byref(cfg), B, L)
             _buf, ws_ptr = N.Workspace.get(device, nws, "train")
             N.check(lib.om_encoder_train_backward(
@@ -155,6 +171,8 @@ class _EncoderTrain(torch.autograd.Function):
                           d["ffn2_w"], d["ffn2_b"], d["ln2_g"], d["ln2_b"]]
         if ghead is not None:
             grads.append(ghead)
+        if sync is not None:
+            sync.reduce_arena(arena, layer_bounds, events)
         ctx.tape = None
         return (None,) * 11 + tuple(grads)
 

@@ -46,7 +46,7 @@ def parameter_groups(model, weight_decay: float):
     return [{"params": decay, "weight_decay": weight_decay}, {"params": no_decay, "weight_decay": 0.0}]
 
 
-def allreduce_mean_(params: List[torch.nn.Parameter], world_size: int, bucket_bytes: int = 256 << 20):
+def allreduce_mean_(params: List[torch.nn.Parameter], world_size: int, bucket_bytes: int = 256 << 20, skip_storages=()):
     """Gradient averaging across ranks = what DistributedDataParallel does for the reference.
 
     The HIP backward writes every parameter gradient of an encoder into ONE zero-initialised f32 arena and hands
@@ -54,7 +54,8 @@ def allreduce_mean_(params: List[torch.nn.Parameter], world_size: int, bucket_by
     storage span is all-reduced IN PLACE with a single collective -- no flatten copy, no copy back.  (xGMI is
     point-to-point: a ring all-reduce is per-link bound, so one large call beats many small ones.)  Gradients that
     live elsewhere (a head trained by plain autograd, CPU tests) go through flat copy buckets of `bucket_bytes`."""
-    grads = [p.grad for p in params if p.grad is not None]
+    # (skip_storages: arenas that openmatch_amd/grad_sync.py already averaged while the backward ran)
+    grads = [p.grad for p in params if p.grad is not None and p.grad.untyped_storage().data_ptr() not in skip_storages]
 
     def reduce_(flat):
         from ..comm import native_comm
@@ -279,6 +280,13 @@ class DRTrainer:
         save_every = int(getattr(a, "save_steps", 0) or 0)
         running, micro, epoch = 0.0, 0, 0
         self.optimizer.zero_grad(set_to_none=True)
+        # multi-GPU: gradient all-reduce in layer-group buckets from inside the backward (grad_sync.py) -- with gradient
+        # accumulation or the gradient cache the per-parameter gradients are sums over several backward passes, which are
+        # reduced once after the last one instead
+        from ..grad_sync import GradSync
+        sync = GradSync(W, getattr(a, "grad_bucket_layers", 3)) if (
+            W > 1 and accum == 1 and type(self).training_step is DRTrainer.training_step
+            and getattr(a, "overlap_grad_allreduce", True)) else None
         if resume_from_checkpoint:
             logger.warning("resume_from_checkpoint=%r is not supported by this trainer (optimizer state is not "
                            "checkpointed): training starts from the model's current weights", resume_from_checkpoint)
@@ -298,12 +306,17 @@ class DRTrainer:
                 loader.sampler.set_epoch(epoch)
             stepped, in_epoch = False, 0
             for batch in loader:
-                running += float(self.training_step(self.model, batch))
+                if sync is not None:
+                    sync.begin()
+                loss_t = self.training_step(self.model, batch)
+                if sync is not None:
+                    sync.finish()
+                running += float(loss_t)
                 micro += 1
                 if micro % accum:
                     continue
                 if W > 1:
-                    allreduce_mean_(params, W)
+                    allreduce_mean_(params, W, skip_storages=sync.reduced if sync is not None else ())
                 max_norm = getattr(a, "max_grad_norm", 0.0)
                 if max_norm and max_norm > 0:
                     torch.nn.utils.clip_grad_norm_(params, max_norm)

@@ -65,10 +65,16 @@ def main():
     model = DRModel(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype="float32"),
                     data_args=NS(train_n_passages=2),
                     train_args=NS(negatives_x_device=True, per_device_train_batch_size=2)).to(dev).train()
+    # the gradient all-reduce runs in layer buckets from inside the backward (openmatch_amd/grad_sync.py), as DRTrainer does
+    from openmatch_amd.grad_sync import GradSync
+    sync = GradSync(world, bucket_layers=1)
     out = model(query=part(q_all, 2), passage=part(p_all, 4))
+    sync.begin()
     out.loss.backward()
+    sync.finish()
+    assert len(sync.reduced) == 1                      # the tied encoder's one arena went through the bucketed path
     params = [p for p in model.parameters() if p.grad is not None]
-    allreduce_mean_(params, world)
+    allreduce_mean_(params, world, skip_storages=sync.reduced)
     full = DRModel(lm_q=ref_lm, lm_p=ref_lm, pooling="first", model_args=NS(encoder_only=False, dtype="float32"),
                    data_args=NS(train_n_passages=2),
                    train_args=NS(negatives_x_device=False, per_device_train_batch_size=2 * world)).to(dev).train()

@@ -131,6 +131,34 @@ def _train_worker(rank, world, port, out_q):
         assert q_.grad.data_ptr() >= ptr and q_.grad.untyped_storage().data_ptr() == arena.untyped_storage().data_ptr()
         assert torch.allclose(q_.grad, torch.full_like(q_.grad, 1.5 * (i + 1)))
     assert float(arena[12:16].abs().sum()) == 0.0
+    # bucketed all-reduce from inside the backward (openmatch_amd/grad_sync.py) == one all-reduce over the whole arena:
+    # an arena laid out as train.py lays it out (embeddings | layers 0..4 | head), buckets of two layers in completion order
+    from openmatch_amd.grad_sync import GradSync
+    gen = torch.Generator().manual_seed(100 + rank)
+    sizes = [192, 128, 128, 128, 128, 128, 64]                # embeddings, five layers, head
+    arena2 = torch.randn(sum(sizes), generator=gen)
+    starts = np.cumsum([0] + sizes)
+    bounds = [(int(starts[i + 1]), int(starts[i + 2])) for i in range(5)]
+    sync = GradSync(world, bucket_layers=2)
+    bk = sync.buckets(bounds, arena2.numel())
+    assert bk == [(576, 896, 3), (320, 576, 1), (192, 320, 0), (0, 192, 5)], bk      # top bucket carries the head; embeddings last
+    covered = torch.zeros(arena2.numel(), dtype=torch.int32)
+    for lo, hi, _ in bk:
+        covered[lo:hi] += 1
+    assert bool((covered == 1).all())
+    single = arena2.clone()
+    dist.all_reduce(single); single /= world
+    sync.begin()
+    from openmatch_amd import grad_sync
+    assert grad_sync.active() is sync
+    sync.reduce_arena(arena2, bounds, None)
+    sync.finish()
+    assert grad_sync.active() is None and torch.equal(arena2, single)
+    # ... and the trainer's post-hoc reduction leaves such an arena alone
+    pz = torch.nn.Parameter(torch.zeros(4)); pz.grad = arena2[:4]
+    before = pz.grad.clone()
+    allreduce_mean_([pz], world, skip_storages=sync.reduced)
+    assert torch.equal(pz.grad, before)
     # loss convention: every rank computes world * mean-CE over the gathered batch; after the mean
     # all-reduce the parameter gradient equals that of the plain global mean-CE
     qs = [torch.randn(2, 8, generator=torch.Generator().manual_seed(10 + r)) for r in range(world)]
