@@ -1080,6 +1080,38 @@ def test_drtrainer_loop_reduces_loss_and_saves(golden, tmp_path):
     assert {"openmatch_config.json", "linear.pt", "head_config.json", "training_args.bin"} <= set(__import__("os").listdir(tmp_path))
 
 
+def test_overlapped_bucketed_allreduce_leaves_single_rank_gradients_unchanged(golden):
+    """openmatch_amd/grad_sync.py on the GPU: per-layer events recorded by om_encoder_train_backward, buckets reduced on a
+    side stream while the backward runs.  On a one-rank RCCL group the mean all-reduce is the identity, so the gradients
+    must equal those of a plain backward -- which exercises the event hand-off, the bucket slicing of the real arena and
+    the stream ordering (the arithmetic across ranks is covered over gloo in tests/test_distributed_cpu.py)."""
+    import torch.distributed as dist
+    from openmatch_amd.grad_sync import GradSync
+    from openmatch_amd.trainer.dense_trainer import allreduce_mean_
+    g = golden("train_bert_tiny")
+    q, p = _train_batch(g)
+    plain = _train_model(g)
+    plain(query=q, passage=p).loss.backward()
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        model = _train_model(g)
+        sync = GradSync(1, bucket_layers=1)
+        out = model(query=q, passage=p)
+        sync.begin()
+        out.loss.backward()
+        sync.finish()
+        assert len(sync.reduced) == 1 and not sync.works
+        params = [t for t in model.parameters() if t.grad is not None]
+        allreduce_mean_(params, 1, skip_storages=sync.reduced)
+        torch.cuda.synchronize()
+        for (n, a), (_, b) in zip(model.named_parameters(), plain.named_parameters()):
+            if b.grad is not None:
+                assert torch.equal(a.grad, b.grad), n
+    finally:
+        dist.destroy_process_group()
+
+
 def test_gradient_cache_step_equals_full_batch_step(golden, tmp_path):
     """GCDenseTrainer (chunked, re-encoded) must give the SAME gradients as one full-batch step."""
     from openmatch.trainer import DRTrainer, GCDenseTrainer
