@@ -1107,7 +1107,8 @@ def test_overlapped_bucketed_allreduce_leaves_single_rank_gradients_unchanged(go
         torch.cuda.synchronize()
         for (n, a), (_, b) in zip(model.named_parameters(), plain.named_parameters()):
             if b.grad is not None:
-                assert torch.equal(a.grad, b.grad), n
+                # (the weight-gradient kernel adds its split-M partials with f32 atomics: two backward passes agree to rounding)
+                assert torch.allclose(a.grad, b.grad, rtol=1e-4, atol=1e-6), n
     finally:
         dist.destroy_process_group()
 
