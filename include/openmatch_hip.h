@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OM_ABI_VERSION 3
+#define OM_ABI_VERSION 4
 
 /* element types */
 #define OM_F32 0
@@ -90,9 +90,7 @@ void om_debug_gemm_gen(int gen);
 #define OM_OPT_GEMM_GROUP_M 6     /* row tiles per group of the persistent GEMM's tile walk (default 8): the group's A panels stay in an
                                    * XCD's L2 while its column tiles are swept */
 #define OM_OPT_SCAN_QGROUP 7      /* query tiles (256 queries each) an XCD keeps resident in its L2 during the index scan (default 8) */
-#define OM_OPT_FOLD_CACHE 8       /* 1: LayerNorm-folded weights are computed once per weight version and cached in library-owned
-                                   * buffers (call om_invalidate_folded_weights() after ANY change of encoder weights); 0 (default for
-                                   * raw C-ABI callers): folded per forward */
+#define OM_OPT_RESERVED_8 8       /* (was the library-owned fold cache: replaced by OmEncoderWeights::folded) */
 #define OM_OPT_ATTENTION_DEBUG 9  /* 0 (default); timing experiments on the bf16 attention kernel at L in (64, 128]: bit 0 no K / V fetch,
                                    * bit 1 no arithmetic, bit 2 no stores (results are garbage) */
 #define OM_OPT_ENCODER_PINGPONG 10 /* 1 (default): the fused bf16 encoder's kernels alternate their walk direction over the token rows so
@@ -104,7 +102,6 @@ void om_debug_gemm_gen(int gen);
 int om_debug_option(int opt, int value);
 /* the attention kernel alone (bf16 qkv [B*L, 3H] -> ctx [B*L, H]; mask [B, L] int64), for timing: csrc/kernels.h omk_attention */
 int om_debug_attention(const void* qkv, void* ctx, const int64_t* mask, int64_t B, int L, int H, int heads, void* stream);
-void om_invalidate_folded_weights(void);   /* see OM_OPT_FOLD_CACHE */
 int om_kernel_timing_enable(int enable);
 int om_kernel_timing_read(int kernel_class, double* total_ms, int64_t* launches, double* flops);
 
@@ -188,7 +185,14 @@ typedef struct OmEncoderWeights {
   const float* final_ln_g; /* T5 final_layer_norm.weight                          */
   const float* rel_bias;   /* T5 block[0] relative_attention_bias [buckets,heads] f32 */
   const float* head_w;     /* LinearHead weight [head_out,head_in] f32, or NULL   */
+  const void* folded;      /* LayerNorm-folded weights made by om_encoder_fold_weights (ABI v4), or NULL: folded per forward */
 } OmEncoderWeights;
+
+/* LayerNorm / RMSNorm folded into the weights that consume the normalised tensor (the 16-bit fused path): size of the
+ * buffer (0 when the configuration has no fused path) and the one-off computation into a caller-owned, 256-byte aligned
+ * device buffer.  Redo it whenever an encoder weight changes; om_encoder_forward reads it through OmEncoderWeights::folded. */
+size_t om_encoder_fold_bytes(const OmEncoderConfig* cfg);
+int om_encoder_fold_weights(const OmEncoderConfig* cfg, const OmEncoderWeights* w, void* folded, size_t bytes, void* stream);
 
 size_t om_encoder_workspace_bytes(const OmEncoderConfig* cfg, int64_t B, int64_t L);
 

@@ -18,59 +18,82 @@
 
 #include "kernels.h"
 
-// Folded LayerNorm weights (W * gamma, its row sums, the folded bias) depend on the weights alone.  With
-// OM_OPT_FOLD_CACHE on they are computed once per weight version and kept in device buffers owned by the library,
-// instead of 23 ln_fold launches per forward; om_invalidate_folded_weights() (called by the host whenever it repacks
-// a model's weights) marks every entry stale.  Off by default for raw C-ABI callers, who may update weights in place.
-#include <map>
-#include <mutex>
-#include <tuple>
+// Folded LayerNorm weights (W * gamma, its row sums, the folded bias) depend on the weights alone.  A caller that
+// keeps weights across forwards folds them ONCE into a buffer it owns (om_encoder_fold_bytes / om_encoder_fold_weights,
+// OmEncoderWeights::folded) -- 23 launches of ln_fold_kernel per forward gone; without one they are folded per forward
+// into workspace scratch.  (Round 2 kept a library-owned cache keyed by weight pointers, which allocated inside a forward
+// and could serve stale folds after an in-place weight update: gone.)
+//
+// Blob layout, per layer l: [qkv: W' (3H x H, 16-bit) | column sums (3H f32) | folded bias (3H f32)]
+//                           [ffn1: W' (F x H)         | column sums (F f32)  | folded bias (F f32)], every part 256-byte aligned.
+// BERT: qkv of layer l is folded with LN2 of layer l-1 (layer 0's slot is unused), ffn1 with LN1 of layer l.
+// T5 (not gated): qkv with the layer's first RMSNorm weight (l >= 1), ffn1 with its second.
 namespace {
-struct FoldEntry { void* wf = nullptr; float* colsum = nullptr; float* bf = nullptr; unsigned long long epoch = 0; hipStream_t stream = nullptr; hipEvent_t ev = nullptr; };
-typedef std::tuple<const void*, const void*, const void*, const void*, int, int, int> FoldKey;
-std::map<FoldKey, FoldEntry> g_folds;
-std::mutex g_fold_mu;
-unsigned long long g_fold_epoch = 1;
-}  // namespace
-extern "C" void om_invalidate_folded_weights(void) {
-  std::lock_guard<std::mutex> lk(g_fold_mu);
-  ++g_fold_epoch;
-  if (g_folds.size() > 160) {          // stale entries keep their buffers for re-use under the same key; bound the pool
-    for (auto& kv : g_folds) {          // (weights that keep moving to new addresses would otherwise grow it without limit)
-      if (kv.second.wf) (void)hipFree(kv.second.wf);
-      if (kv.second.colsum) (void)hipFree(kv.second.colsum);
-      if (kv.second.bf) (void)hipFree(kv.second.bf);
-      if (kv.second.ev) (void)hipEventDestroy(kv.second.ev);
-    }
-    g_folds.clear();
-  }
+struct FoldSlot { size_t w, cs, bf; };
+struct FoldLayout { size_t per_layer, total; FoldSlot qkv, ffn1; };
+FoldLayout fold_layout(const OmEncoderConfig* c) {
+  const size_t H = c->hidden, F = c->ffn;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  FoldLayout L;
+  L.qkv.w = take(3 * H * H * 2); L.qkv.cs = take(3 * H * 4); L.qkv.bf = take(3 * H * 4);
+  L.ffn1.w = take(F * H * 2); L.ffn1.cs = take(F * 4); L.ffn1.bf = take(F * 4);
+  L.per_layer = off;
+  L.total = off * (size_t)c->n_layers;
+  return L;
 }
-// Wf / colsum / bf of (W, gamma, beta, b): from the cache, or computed into the caller's scratch (cache off)
-static int folded_weights(int dt, const void* W, const float* g, const float* beta, const float* b, int N, int K, void* scratch_w,
-                          float* scratch_cs, float* scratch_bf, hipStream_t s, const void** Wf, const float** cs, const float** bf) {
-  if (!om_option(OM_OPT_FOLD_CACHE)) {
-    if (omk_ln_fold(dt, W, g, beta, b, scratch_w, scratch_cs, scratch_bf, N, K, s)) return 1;
-    *Wf = scratch_w; *cs = scratch_cs; *bf = scratch_bf;
+bool fold_applies(const OmEncoderConfig* c) {
+  return (c->dtype == OM_BF16 || c->dtype == OM_F16) && c->n_layers > 0 && c->hidden % 256 == 0 && c->ffn % 256 == 0;
+}
+}  // namespace
+
+extern "C" size_t om_encoder_fold_bytes(const OmEncoderConfig* cfg) {
+  if (!cfg || !fold_applies(cfg)) return 0;
+  return fold_layout(cfg).total;
+}
+
+extern "C" int om_encoder_fold_weights(const OmEncoderConfig* c, const OmEncoderWeights* w, void* blob, size_t bytes, void* stream) {
+  if (!c || !w || !blob) OM_FAIL("null argument");
+  if (!fold_applies(c)) OM_FAIL("nothing to fold for this configuration (om_encoder_fold_bytes is 0)");
+  const FoldLayout L = fold_layout(c);
+  if (bytes < L.total || ((uintptr_t)blob & 255)) OM_FAIL("fold buffer too small or not 256-byte aligned");
+  const OmLayerWeights* Ls = w->layers_host;
+  if (!Ls) OM_FAIL("layers_host is null");
+  hipStream_t s = (hipStream_t)stream;
+  const int H = c->hidden, F = c->ffn;
+  const bool bert = c->arch == OM_ARCH_BERT;
+  for (int l = 0; l < c->n_layers; ++l) {
+    char* base = (char*)blob + (size_t)l * L.per_layer;
+    const OmLayerWeights& lw = Ls[l];
+    if (l > 0) {
+      const float* g = bert ? Ls[l - 1].ln2_g : lw.ln1_g;
+      const float* beta = bert ? Ls[l - 1].ln2_b : nullptr;
+      if (omk_ln_fold(c->dtype, lw.qkv_w, g, beta, bert ? lw.qkv_b : nullptr, base + L.qkv.w, (float*)(base + L.qkv.cs),
+                      (float*)(base + L.qkv.bf), 3 * H, H, s)) return 1;
+    }
+    if (!lw.ffn1g_w) {
+      const float* g = bert ? lw.ln1_g : lw.ln2_g;
+      const float* beta = bert ? lw.ln1_b : nullptr;
+      if (omk_ln_fold(c->dtype, lw.ffn1_w, g, beta, bert ? lw.ffn1_b : nullptr, base + L.ffn1.w, (float*)(base + L.ffn1.cs),
+                      (float*)(base + L.ffn1.bf), F, H, s)) return 1;
+    }
+  }
+  return 0;
+}
+
+// Wf / colsum / bf of one site: from the caller's fold buffer, or computed into workspace scratch
+static int folded_weights(const OmEncoderConfig* c, const OmEncoderWeights* w, int layer, bool ffn1, const void* W, const float* g,
+                          const float* beta, const float* b, int N, int K, void* scratch_w, float* scratch_cs, float* scratch_bf,
+                          hipStream_t s, const void** Wf, const float** cs, const float** bf) {
+  if (w->folded) {
+    const FoldLayout L = fold_layout(c);
+    const char* base = (const char*)w->folded + (size_t)layer * L.per_layer;
+    const FoldSlot& sl = ffn1 ? L.ffn1 : L.qkv;
+    *Wf = base + sl.w; *cs = (const float*)(base + sl.cs); *bf = (const float*)(base + sl.bf);
     return 0;
   }
-  int dev = 0;
-  OM_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lk(g_fold_mu);
-  FoldEntry& e = g_folds[FoldKey(W, g, beta, b, N, K, dev)];
-  if (!e.wf) {
-    OM_HIP(hipMalloc(&e.wf, (size_t)N * K * 2));
-    OM_HIP(hipMalloc((void**)&e.colsum, (size_t)N * 4));
-    OM_HIP(hipMalloc((void**)&e.bf, (size_t)N * 4));
-    OM_HIP(hipEventCreateWithFlags(&e.ev, hipEventDisableTiming));
-  }
-  if (e.epoch != g_fold_epoch) {
-    if (omk_ln_fold(dt, W, g, beta, b, e.wf, e.colsum, e.bf, N, K, s)) return 1;
-    OM_HIP(hipEventRecord(e.ev, s));
-    e.epoch = g_fold_epoch; e.stream = s;
-  } else if (e.stream != s) {
-    OM_HIP(hipStreamWaitEvent(s, e.ev, 0));              // folded on another stream: order after it
-  }
-  *Wf = e.wf; *cs = e.colsum; *bf = e.bf;
+  if (omk_ln_fold(c->dtype, W, g, beta, b, scratch_w, scratch_cs, scratch_bf, N, K, s)) return 1;
+  *Wf = scratch_w; *cs = scratch_cs; *bf = scratch_bf;
   return 0;
 }
 
@@ -234,7 +257,7 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
         } else {
           const OmLayerWeights& pw = Ls[l - 1];
           const void* wf; const float *cs, *bfp;
-          RUN(folded_weights(dt, lw.qkv_w, pw.ln2_g, pw.ln2_b, lw.qkv_b, 3 * H, H, ws.wfold, ws.colsum, ws.bfold, s, &wf, &cs, &bfp));
+          RUN(folded_weights(c, w, l, false, lw.qkv_w, pw.ln2_g, pw.ln2_b, lw.qkv_b, 3 * H, H, ws.wfold, ws.colsum, ws.bfold, s, &wf, &cs, &bfp));
           e.bias = bfp; e.ln_stats = st2p; e.ln_colsum = cs; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps; e.reverse = OM_WALK();
           RUN(omk_gemm(dt, ws.x1, H, wf, H, dt, ws.qkv, 3 * H, Mg, 3 * H, H, e, s));
         }
@@ -255,7 +278,7 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
         RUN(omk_ln_stats_reduce(ws.slots, nslots, Mg, st1, s));
         // ---- FFN1 on LN1(y1), folded
         const void* wf1; const float *cs1, *bf1;
-        RUN(folded_weights(dt, lw.ffn1_w, lw.ln1_g, lw.ln1_b, lw.ffn1_b, F, H, ws.wfold, ws.colsum, ws.bfold, s, &wf1, &cs1, &bf1));
+        RUN(folded_weights(c, w, l, true, lw.ffn1_w, lw.ln1_g, lw.ln1_b, lw.ffn1_b, F, H, ws.wfold, ws.colsum, ws.bfold, s, &wf1, &cs1, &bf1));
         e = GemmEpilogue{};
         e.bias = bf1; e.act = c->act; e.ln_stats = st1; e.ln_colsum = cs1; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
         e.reverse = OM_WALK();
@@ -327,10 +350,11 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
     if (fuse_t5) {
       const float inv_h = 1.0f / (float)H;
       const int nslots = 2 * (H / 256);
-      auto folded = [&](const void* A_, const void* W_, const float* g_, const float* stats_, void* C_, int N_, int act_,
+      auto folded = [&](int layer_, bool ffn1_, const void* A_, const void* W_, const float* g_, const float* stats_, void* C_, int N_, int act_,
                         const void* res_, int64_t ldr_) -> int {
         const void* wf; const float *cs, *bfp;
-        if (folded_weights(dt, W_, g_, nullptr, nullptr, N_, H, ws.wfold, ws.colsum, ws.bfold, s, &wf, &cs, &bfp)) return 1;
+        // (the gated feed-forward's two weights are not in the caller's fold buffer -- and gated layers are not fused at all)
+        if (folded_weights(c, w, layer_, ffn1_, W_, g_, nullptr, nullptr, N_, H, ws.wfold, ws.colsum, ws.bfold, s, &wf, &cs, &bfp)) return 1;
         (void)cs; (void)bfp;            // RMSNorm: no mean, no shift -- only the folded weight is used
         GemmEpilogue e = {};
         e.act = act_; e.resid = res_; e.ldr = ldr_;
@@ -345,19 +369,14 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
           RUN(omk_layernorm(dt, ws.x, H, ws.y, H, lw.ln1_g, nullptr, M, H, c->ln_eps, 1, s));
           GEMM(ws.y, H, lw.qkv_w, H, ws.qkv, 3 * H, 3 * H, H, nullptr, nullptr, 0, OM_ACT_NONE);
         } else {
-          RUN(folded(ws.x, lw.qkv_w, lw.ln1_g, ws.stats2 + (size_t)(l - 1) * Mg * 2, ws.qkv, 3 * H, OM_ACT_NONE, nullptr, 0));
+          RUN(folded(l, false, ws.x, lw.qkv_w, lw.ln1_g, ws.stats2 + (size_t)(l - 1) * Mg * 2, ws.qkv, 3 * H, OM_ACT_NONE, nullptr, 0));
         }
         RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, ws.posbias, B, (int)L, H, nh, 1.0f, 0.f, 0, s));
         GemmEpilogue e = {};
         e.resid = ws.x; e.ldr = H; e.stats_out = ws.slots; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
         RUN(omk_gemm(dt, ws.ctx, H, lw.o_w, H, dt, ws.x, H, Mg, H, H, e, s));           // x += o(ctx), sum(x^2)
         RUN(omk_ln_stats_reduce(ws.slots, nslots, Mg, st1, s));
-        if (lw.ffn1g_w) {
-          RUN(folded(ws.x, lw.ffn1g_w, lw.ln2_g, st1, ws.ff2, F, OM_ACT_NONE, nullptr, 0));
-          RUN(folded(ws.x, lw.ffn1_w, lw.ln2_g, st1, ws.ff, F, c->act | OM_ACT_MUL_RESID, ws.ff2, F));
-        } else {
-          RUN(folded(ws.x, lw.ffn1_w, lw.ln2_g, st1, ws.ff, F, c->act, nullptr, 0));
-        }
+        RUN(folded(l, true, ws.x, lw.ffn1_w, lw.ln2_g, st1, ws.ff, F, c->act, nullptr, 0));      // (fuse_t5 excludes gated layers)
         e = GemmEpilogue{};
         e.resid = ws.x; e.ldr = H; e.stats_out = ws.slots; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
         RUN(omk_gemm(dt, ws.ff, F, lw.ffn2_w, F, dt, ws.x, H, Mg, H, F, e, s));         // x += wo(ff), sum(x^2)

@@ -229,7 +229,6 @@ def packed_weights(model, head, code, device):
     if hit is not None and hit[0] == ver:
         return hit[1]
     pk = _pack_bert(model, code, device) if _arch_of(model) == "bert" else _pack_t5(model, code, device)
-    N.lib().om_invalidate_folded_weights()      # new device copies (possibly at recycled addresses): drop cached folds
     if head is not None:
         lin = head.linear
         pk.weights.head_w = pk.dev(lin.weight, torch.float32, device)
@@ -238,6 +237,25 @@ def packed_weights(model, head, code, device):
         pk.cfg.update(head_in=0, head_out=0)
     cache[key] = (ver, pk)
     return pk
+
+
+def _ensure_folded(pk, device):
+    """LayerNorm-folded weights of the fused 16-bit INFERENCE path, once per weight version, in a buffer the packed
+    object owns (include/openmatch_hip.h: om_encoder_fold_weights; 0 bytes when the configuration has no fused path).
+    Done on first inference use, not at packing time: training repacks every step and never reads them."""
+    if getattr(pk, "fold_done", False):
+        return
+    pk.fold_done = True
+    lib = N.lib()
+    cfg = N.OmEncoderConfig(pooling=N.POOL_NONE, normalize=0, **pk.cfg)
+    nfold = lib.om_encoder_fold_bytes(C.byref(cfg))
+    if nfold:
+        with torch.cuda.device(device):
+            blob = torch.empty(nfold + 256, dtype=torch.uint8, device=device)
+            ptr = blob.data_ptr() + (-blob.data_ptr()) % 256
+            N.check(lib.om_encoder_fold_weights(C.byref(cfg), C.byref(pk.weights), C.c_void_p(ptr), nfold, N.stream_ptr(device)))
+        pk.keep.append(blob)
+        pk.weights.folded = ptr
 
 
 _POOL = {None: N.POOL_NONE, "first": N.POOL_FIRST, "mean": N.POOL_MEAN}
@@ -261,6 +279,7 @@ def hip_encode(model, items, pooling, head, normalize, code, want_hidden=True):
     device = ids.device
     code = inference_code(model, code, ids.shape[1])
     pk = packed_weights(model, head, code, device)
+    _ensure_folded(pk, device)
     cfg = N.OmEncoderConfig(pooling=_POOL[pooling], normalize=int(bool(normalize)), **pk.cfg)
     B, L = ids.shape
     H = cfg.hidden

@@ -38,15 +38,18 @@ class GradSync:
         self.reduced = set()
         _active = self
 
-    def finish(self):
-        """Block the CURRENT stream (not the host) until every bucket's collective has completed."""
-        global _active
-        _active = None
+    def _wait_works(self):
         for w, flat in self.works:
-            w.wait()
+            w.wait()                             # the CURRENT stream (not the host) waits for the collective
             if flat is not None:                 # gloo: sum -> mean
                 flat /= self.world
         self.works = []
+
+    def finish(self):
+        """Block the current stream until every bucket's collective has completed."""
+        global _active
+        _active = None
+        self._wait_works()
         self._keep = []
 
     # ---- backward side --------------------------------------------------------------------------------
@@ -70,6 +73,13 @@ class GradSync:
     def reduce_arena(self, arena: torch.Tensor, layer_bounds, events: Optional[list] = None):
         """Launch the bucketed all-reduce(mean) of `arena` (1-D f32).  events[i]: torch.cuda.Event recorded by the backward
         (None on CPU: the buckets are reduced right away)."""
+        # A step with several backward passes over shared weights (an untied or two-call bi-encoder: queries, then
+        # passages) has autograd ADD the second arena's views into the first's: from the second arena on, everything
+        # launched so far -- and this arena's own collectives, below -- must be complete on the caller's stream before the
+        # backward returns to autograd.  (The one-arena step keeps its collectives in flight until finish().)
+        later = bool(self.reduced)
+        if later:
+            self._wait_works()
         nccl = dist.get_backend() == "nccl"
         if arena.is_cuda and self._side is None:
             self._side = torch.cuda.Stream(device=arena.device)
@@ -90,3 +100,5 @@ class GradSync:
             self.works.append((w, None if (arena.is_cuda and nccl) else flat))
         self._keep.append((arena, events))
         self.reduced.add(arena.untyped_storage().data_ptr())
+        if later:
+            self._wait_works()

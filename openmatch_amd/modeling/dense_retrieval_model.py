@@ -24,6 +24,7 @@ from transformers.modeling_outputs import ModelOutput
 from ..arguments import DataArguments, ModelArguments
 from ..arguments import DRTrainingArguments as TrainingArguments
 from ..encoder import compute_dtype_code, hip_encode
+from ..feed import is_packed, unpack_token_batch
 from ..ops import contrastive_loss, encode_with_grad
 from .linear import LinearHead
 
@@ -104,6 +105,8 @@ class DRModel(nn.Module):
         LayerNorm of just the rows pooling needs, and hidden is None."""
         if items is None:
             return None, None
+        if is_packed(items):            # a batch straight from DRInferenceCollator (16-bit ids + lengths, feed.py): widen it here,
+            items = unpack_token_batch(items, next(model.parameters()).device)     # so `model(passage=batch)` works as with the reference's collator
         items = BatchEncoding(items)
         if "T5" in type(model).__name__ and not self.model_args.encoder_only:
             return self._encode_t5_decoder(items, model, head)

@@ -18,6 +18,7 @@ from transformers import AutoModel, BatchEncoding, PreTrainedModel, T5EncoderMod
 from transformers.modeling_outputs import ModelOutput
 
 from ..encoder import compute_dtype_code, hip_encode
+from ..feed import is_packed, unpack_token_batch
 from ..loss import rr_loss_functions
 from ..ops import encode_with_grad
 from .linear import LinearHead
@@ -60,6 +61,8 @@ class RRModel(nn.Module):
     def encode(self, items):
         if items is None:
             return None, None
+        if is_packed(items):            # a batch straight from RRInferenceCollator (feed.py's compact wire format)
+            items = unpack_token_batch(items, next(self.lm.parameters()).device)
         items = BatchEncoding(items)
         if "T5" in type(self.lm).__name__ and not self.model_args.encoder_only:
             return self._encode_mono_t5(items)

@@ -17,8 +17,7 @@ ACT_MUL_RESID = 0x100
 ARCH_BERT, ARCH_T5 = 0, 1
 POOL_NONE, POOL_FIRST, POOL_MEAN = 0, 1, 2
 SEARCH_F32, SEARCH_F16_RESCORE = 0, 1
-ABI_VERSION = 3
-OPT_FOLD_CACHE = 8          # include/openmatch_hip.h: OM_OPT_FOLD_CACHE
+ABI_VERSION = 4
 
 c_void_p, c_int, c_int64, c_float, c_size_t = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
@@ -41,7 +40,7 @@ class OmEncoderWeights(C.Structure):
     _fields_ = [("word_emb", c_void_p), ("pos_emb", c_void_p), ("type_emb", c_void_p),
                 ("emb_ln_g", c_void_p), ("emb_ln_b", c_void_p),
                 ("layers_host", C.POINTER(OmLayerWeights)), ("final_ln_g", c_void_p),
-                ("rel_bias", c_void_p), ("head_w", c_void_p)]
+                ("rel_bias", c_void_p), ("head_w", c_void_p), ("folded", c_void_p)]
 
 
 class OmT5DecoderLayer(C.Structure):
@@ -75,7 +74,8 @@ _SIGNATURES = {
     "om_debug_gemm_gen": (None, [c_int]),
     "om_debug_option": (c_int, [c_int, c_int]),
     "om_debug_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
-    "om_invalidate_folded_weights": (None, []),
+    "om_encoder_fold_bytes": (c_size_t, [C.POINTER(OmEncoderConfig)]),
+    "om_encoder_fold_weights": (c_int, [C.POINTER(OmEncoderConfig), C.POINTER(OmEncoderWeights), c_void_p, c_size_t, c_void_p]),
     "om_kernel_timing_enable": (c_int, [c_int]),
     "om_kernel_timing_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(c_int64), C.POINTER(C.c_double)]),
     "om_gemm_nt": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64,
@@ -147,10 +147,6 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if handle.om_abi_version() != ABI_VERSION:
             raise NativeError("libopenmatch_hip.so ABI version mismatch; rebuild it")
-        # this host layer repacks weights per parameter version and tells the library (encoder.py: packed_weights),
-        # so LayerNorm-folded weights can be cached across forwards (OM_OPT_FOLD_CACHE; OM_FOLD_CACHE=0 turns it off)
-        if os.environ.get("OM_FOLD_CACHE", "1") != "0":
-            handle.om_debug_option(OPT_FOLD_CACHE, 1)
         _lib = handle
     return _lib
 

@@ -72,7 +72,7 @@ def main():
     sync.begin()
     out.loss.backward()
     sync.finish()
-    assert len(sync.reduced) == 1                      # the tied encoder's one arena went through the bucketed path
+    assert len(sync.reduced) >= 1                      # the encoder's arena(s) went through the bucketed path
     params = [p for p in model.parameters() if p.grad is not None]
     allreduce_mean_(params, world, skip_storages=sync.reduced)
     full = DRModel(lm_q=ref_lm, lm_p=ref_lm, pooling="first", model_args=NS(encoder_only=False, dtype="float32"),

@@ -1101,7 +1101,7 @@ def test_overlapped_bucketed_allreduce_leaves_single_rank_gradients_unchanged(go
         sync.begin()
         out.loss.backward()
         sync.finish()
-        assert len(sync.reduced) == 1 and not sync.works
+        assert len(sync.reduced) >= 1 and not sync.works        # (two arenas when queries and passages take separate passes)
         params = [t for t in model.parameters() if t.grad is not None]
         allreduce_mean_(params, 1, skip_storages=sync.reduced)
         torch.cuda.synchronize()
