@@ -48,6 +48,7 @@ def pmc(counter):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01_bench"
+    rnd = sys.argv[2] if len(sys.argv) > 2 else tag.split("_")[0]        # round prefix of the traffic file (r03 ...)
     rows = kernel_stats(tag)
     fetch, write = pmc("FETCH_SIZE"), pmc("WRITE_SIZE")
     gemm = [k for k in fetch if "gemm_nt_kernel" in k]
@@ -63,7 +64,14 @@ def main():
     # bert-base at 1024 x 128 tokens: the four contractions of a layer, bf16 in and out
     M = 1024 * 128
     shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072)]
-    compulsory = sum(2 * (M * k + n * k + M * n) + (2 * M * n if n == 768 else 0) for n, k in shapes) / len(shapes)
+    # N = 768 launches add the residual; since round 3 the bf16 residual stream has two planes (read hi + lo, write hi + lo)
+    two = any("3, true>" in k or ", 3, " in k for k in names)
+    compulsory = sum(2 * (M * k + n * k + M * n) + ((2 * M * n) * (3 if two else 1) if n == 768 else 0) for n, k in shapes) / len(shapes)
+    per = {}
+    for k in names:
+        if fetch[k]:
+            per[k[:72]] = {"launches": len(fetch[k]), "fetch_kb": sum(fetch[k]) / len(fetch[k]),
+                           "write_kb": (sum(write[k]) / len(write[k])) if write.get(k) else None}
     out = {
         "kernel": name[:60],
         "launches": len(f),
@@ -71,11 +79,13 @@ def main():
         "write_size_kb_avg": wavg,
         "hbm_bytes_per_launch": 2 * favg * 1024 + wavg * 1024,
         "compulsory_bytes_per_launch": compulsory,
+        "two_plane_residual_stream": two,
+        "per_variant": per,
         "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (128-B requests tallied at 64 B); WRITE_SIZE as reported "
                 "(uncalibrated); separate rocprofv3 --pmc passes of `bench.py --steps 3 --warmup 1 --no-search`; "
                 "compulsory = operands + output (+ residual where present) once, averaged over the layer's four GEMMs",
     }
-    dst = os.path.join(REPO, "profiles", "r01_hbm_traffic.json")
+    dst = os.path.join(REPO, "profiles", rnd + "_hbm_traffic.json")
     json.dump(out, open(dst, "w"), indent=1)
     print("wrote", dst, json.dumps(out)[:300])
     if rows:
