@@ -15,8 +15,8 @@ OUT = os.path.join(REPO, "gpurun_out")
 
 
 def find(pattern):
-    hits = glob.glob(os.path.join(OUT, pattern), recursive=True)
-    return hits[0] if hits else None
+    hits = glob.glob(os.path.join(OUT, pattern), recursive=True)      # gpurun merges into gpurun_out/: older rounds' files stay
+    return max(hits, key=os.path.getmtime) if hits else None
 
 
 def kernel_stats(tag):
