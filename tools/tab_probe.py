@@ -8,6 +8,6 @@ for (n,a) in d:
     if n not in names: names.append(n)
     if a not in cols: cols.append(a)
 print("min us     %-20s"%""+"".join("%10s"%c for c in cols))
-for n in names: print("%-30s"%n+"".join("%10.1f"%(min(d[(n,a)])) for a in cols))
+for n in names: print("%-30s"%n+"".join(("%10.1f"%(min(d[(n,a)])) if d.get((n,a)) else "%10s"%"-") for a in cols))
 print("median")
-for n in names: print("%-30s"%n+"".join("%10.1f"%(statistics.median(d[(n,a)])) for a in cols))
+for n in names: print("%-30s"%n+"".join(("%10.1f"%(statistics.median(d[(n,a)])) if d.get((n,a)) else "%10s"%"-") for a in cols))
