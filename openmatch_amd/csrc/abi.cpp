@@ -97,6 +97,9 @@ void opt_init() {
   g_opt[OM_OPT_GEMM_GROUP_M] = e ? atoi(e) : 8;
   e = getenv("OM_ENCODER_TWO_PLANE");
   g_opt[OM_OPT_ENCODER_TWO_PLANE] = e ? atoi(e) : 1;
+  e = getenv("OM_GEMM_VARIANT");
+  g_opt[OM_OPT_GEMM_VARIANT] = e ? atoi(e) : 0;
+  g_opt[OM_OPT_SEARCH_DEBUG] = getenv("OM_SEARCH_DEBUG") ? 1 : 0;
   g_opt_init.store(true);
 }
 }  // namespace

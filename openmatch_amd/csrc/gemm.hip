@@ -95,9 +95,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_nt_kernel2(
 OM_DEFINE_LAUNCHER(launch_gemm, gemm_nt_kernel, GEMM_THREADS, GEMM_LDS_BYTES, GEMM_BM, GEMM_BN)
 OM_DEFINE_LAUNCHER(launch_gemm2, gemm_nt_kernel2, G2_THREADS, G2_LDS_BYTES, G2_BM, G2_BN)
 
-static int gemm_variant() {     // OM_GEMM_VARIANT=1|2|4|6 pins a kernel generation (A/B measurements)
-  static const int v = getenv("OM_GEMM_VARIANT") ? atoi(getenv("OM_GEMM_VARIANT")) : 0;
-  return v;
+static int gemm_variant() {     // OM_OPT_GEMM_VARIANT = 1|2|4|6 pins a kernel generation (A/B measurements; 0: automatic)
+  return om_option(OM_OPT_GEMM_VARIANT);
 }
 
 // The 256-row kernels write whole 16-byte output segments; small or ragged problems use v1.

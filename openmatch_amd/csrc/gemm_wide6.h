@@ -104,9 +104,9 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel6(
 // before the epilogue) was measured and dropped twice (v5, v6p: 3-8 % SLOWER): vmcnt retires in
 // order, so waiting for the prefetched operands also waits for the acknowledgement of every store of
 // the epilogue in front of them, which costs more than the cold start it hides.
-// row tiles that sweep the column tiles together (OM_GEMM_GROUP_M overrides, for A/B measurements)
+// row tiles that sweep the column tiles together (OM_OPT_GEMM_GROUP_M, for A/B measurements)
 static int g6_group_m() {
-  static const int v = getenv("OM_GEMM_GROUP_M") ? atoi(getenv("OM_GEMM_GROUP_M")) : 8;
+  const int v = om_option(OM_OPT_GEMM_GROUP_M);        // (abi.cpp reads the environment once, for every option)
   return v > 0 ? v : 8;
 }
 

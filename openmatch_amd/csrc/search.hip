@@ -923,7 +923,7 @@ struct Scan {
   void trace(const char* what, int64_t done, int64_t chunk, const unsigned (&f)[4]) {
     g_info[1]++;                                  // rounds
     if (f[1] > (unsigned)g_info[3]) g_info[3] = f[1];
-    static const bool dbg = getenv("OM_SEARCH_DEBUG") != nullptr;
+    const bool dbg = om_option(OM_OPT_SEARCH_DEBUG) != 0;
     if (dbg) fprintf(stderr, "[om_sim_topk] %-8s done=%ld chunk=%ld overflow=%u max_list=%u too_wide=%u\n",
                      what, (long)done, (long)chunk, f[0], f[1], f[2]);
   }
