@@ -420,7 +420,16 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
     }
     if (tr && threadIdx.x == 0) tr[16] = clock64();
 #define G7E_RB(I4) ((G7_ABL & 2) ? make_uint4(0u, 0u, 0u, 0u) : *(const uint4*)(st_rd + (I4) * G7E_SPASS + (((lane & 7) ^ (((lane >> 3) + (I4) * 8) & 7)) << 4)))
-#define G7E_ST_(BASE, PP, I4, V) do { if (G7_ABL & 1) asm volatile("" ::"v"((V).x), "v"((V).y), "v"((V).z), "v"((V).w)); else *(uint4*)((BASE) + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128 + coff) = V; } while (0)
+#ifndef G7_NT
+#define G7_NT 1
+#endif
+typedef unsigned int g7_u32x4 __attribute__((ext_vector_type(4)));
+#if G7_NT
+#define G7E_STORE16(P, V) __builtin_nontemporal_store(g7_u32x4{(V).x, (V).y, (V).z, (V).w}, (g7_u32x4*)(P))
+#else
+#define G7E_STORE16(P, V) (*(uint4*)(P) = (V))
+#endif
+#define G7E_ST_(BASE, PP, I4, V) do { if (G7_ABL & 1) asm volatile("" ::"v"((V).x), "v"((V).y), "v"((V).z), "v"((V).w)); else G7E_STORE16((BASE) + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128 + coff, V); } while (0)
 #define G7E_ST(PP, I4, V) G7E_ST_(cbase, PP, I4, V)
     if (!TWO) {
     // Software pipeline over the 8 patches: WRITE(p+1) -> read-back of p+1 ISSUED at once (its data is only needed one

@@ -90,6 +90,25 @@ def position_offset(model):
     return 0
 
 
+def check_position_layout(model, ids, mask):
+    """RoBERTa-family models only: the kernels read position row t (+ position_offset) for token t, HF reads
+    cumsum(input_ids != pad)[t] + padding_idx (modeling_roberta.py create_position_ids_from_input_ids).  The two agree on
+    every attended token exactly when no pad id precedes an attended token (right-padded text without pad ids inside
+    it).  Anything else -- left padding, pad ids inside the text -- would silently read other rows than the reference:
+    rejected here (one small device reduction + host read per call, RoBERTa only)."""
+    if position_offset(model) == 0:
+        return
+    pad = getattr(model.config, "pad_token_id", None)
+    pad = 1 if pad is None else int(pad)
+    L = ids.shape[1]
+    pos = torch.arange(L, device=ids.device)
+    first_pad = torch.where(ids == pad, pos, L).amin(dim=1)
+    last_attended = torch.where(mask != 0, pos, -1).amax(dim=1)
+    if bool((last_attended > first_pad).any()):
+        raise ValueError("RoBERTa position ids: a pad token precedes an attended token (left-padded input, or pad ids "
+                         "inside the text); the HIP encoder numbers positions for right-padded inputs only")
+
+
 def _pack_bert(model, code, device):
     cfg = model.config
     if getattr(cfg, "position_embedding_type", "absolute") != "absolute":
@@ -276,6 +295,7 @@ def hip_encode(model, items, pooling, head, normalize, code, want_hidden=True):
     if tti is not None:
         tti = tti.to(device=ids.device, dtype=torch.int64).contiguous()
     N.require_device(ids, mask, tti)
+    check_position_layout(model, ids, mask)
     device = ids.device
     code = inference_code(model, code, ids.shape[1])
     pk = packed_weights(model, head, code, device)

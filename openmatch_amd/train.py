@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import native as N
-from .encoder import _POOL, _arch_of, packed_weights, position_offset, training_code
+from .encoder import _POOL, _arch_of, check_position_layout, packed_weights, position_offset, training_code
 
 
 def _bert_params(model, head):
@@ -187,6 +187,7 @@ def encode_train(model, head, items, pooling, normalize, code, training):
     if tti is not None:
         tti = tti.to(device=ids.device, dtype=torch.int64).contiguous()
     N.require_device(ids, mask, tti)
+    check_position_layout(model, ids, mask)
     cfg = model.config
     bert = _arch_of(model) == "bert"
     if bert:

@@ -46,6 +46,9 @@ def parameter_groups(model, weight_decay: float):
     return [{"params": decay, "weight_decay": weight_decay}, {"params": no_decay, "weight_decay": 0.0}]
 
 
+_verified_patterns = set()
+
+
 def allreduce_mean_(params: List[torch.nn.Parameter], world_size: int, bucket_bytes: int = 256 << 20, skip_storages=()):
     """Gradient averaging across ranks = what DistributedDataParallel does for the reference.
 
@@ -71,16 +74,29 @@ def allreduce_mean_(params: List[torch.nn.Parameter], world_size: int, bucket_by
     by_store = {}
     for g in grads:
         by_store.setdefault((g.untyped_storage().data_ptr(), g.dtype, g.device), []).append(g)
-    loose = []
+    loose, spans = [], []
     for (_, dtype, _dev), gs in by_store.items():
         lo = min(g.storage_offset() for g in gs)
         hi = max(g.storage_offset() + g.numel() for g in gs)
         dense = all(g.is_contiguous() for g in gs) and sum(g.numel() for g in gs) * 2 >= (hi - lo)
         if len(gs) > 1 and dense:
-            span = torch.empty(0, dtype=dtype, device=gs[0].device).set_(gs[0].untyped_storage(), lo, (hi - lo,))
-            reduce_(span)                                   # the views in `gs` see the averaged values
+            spans.append((dtype, gs[0], lo, hi, len(gs)))
         else:
             loose.extend(gs)
+    # Every rank must issue the same collectives: the span sizes depend on which parameters received a gradient and on
+    # the arena layout.  The first time this rank sees a pattern it is compared across ranks; a mismatch (a parameter
+    # unused on one rank only) raises on every rank instead of hanging in a collective of unequal sizes.
+    sig = (tuple((str(dt), hi - lo, n) for dt, _g, lo, hi, n in spans), tuple(g.numel() for g in loose))
+    if world_size > 1 and dist.is_initialized() and sig not in _verified_patterns:
+        seen = [None] * world_size
+        dist.all_gather_object(seen, sig)
+        if any(s != sig for s in seen):
+            raise RuntimeError("allreduce_mean_: the ranks hold different gradient patterns (a parameter that received "
+                               f"no gradient on some ranks only?): {seen}")
+        _verified_patterns.add(sig)
+    for dtype, g0, lo, hi, _n in spans:
+        span = torch.empty(0, dtype=dtype, device=g0.device).set_(g0.untyped_storage(), lo, (hi - lo,))
+        reduce_(span)                                       # the views of the arena see the averaged values
     bucket, size = [], 0
 
     def flush():

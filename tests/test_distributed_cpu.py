@@ -159,6 +159,17 @@ def _train_worker(rank, world, port, out_q):
     before = pz.grad.clone()
     allreduce_mean_([pz], world, skip_storages=sync.reduced)
     assert torch.equal(pz.grad, before)
+    # ranks that disagree on which parameters hold a gradient fail loudly on EVERY rank (no hang in a collective of
+    # unequal sizes)
+    pa_, pb_ = torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(7))
+    pa_.grad = torch.ones(5)
+    if rank == 0:
+        pb_.grad = torch.ones(7)
+    try:
+        allreduce_mean_([pa_, pb_], world)
+        raise AssertionError("mismatched gradient patterns were not detected")
+    except RuntimeError as e:
+        assert "different gradient patterns" in str(e)
     # loss convention: every rank computes world * mean-CE over the gathered batch; after the mean
     # all-reduce the parameter gradient equals that of the plain global mean-CE
     qs = [torch.randn(2, 8, generator=torch.Generator().manual_seed(10 + r)) for r in range(world)]

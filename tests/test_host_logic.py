@@ -295,6 +295,22 @@ def test_backbone_dispatch_and_position_offset():
     assert _arch_of(t5) == "t5" and position_offset(t5) == 0
     with pytest.raises(NotImplementedError, match="GPT2Model"):
         _arch_of(GPT2Model(GPT2Config(n_embd=32, n_layer=1, n_head=1, vocab_size=50)))
+    # RoBERTa: position t + offset equals HF's cumsum numbering only when no pad id precedes an attended token
+    import torch
+    from openmatch_amd.encoder import check_position_layout
+    pad = rob.config.pad_token_id
+    right = torch.tensor([[5, 6, 7, pad, pad], [5, 6, 7, 8, 9]]); rmask = (right != pad).long()
+    check_position_layout(rob, right, rmask)
+    hf_pos = (torch.cumsum(rmask, 1) * rmask + pad)[rmask.bool()]                        # create_position_ids_from_input_ids
+    ours = (torch.arange(5).expand(2, 5) + position_offset(rob))[rmask.bool()]
+    assert torch.equal(hf_pos, ours)
+    left = torch.tensor([[pad, pad, 5, 6, 7]])
+    with pytest.raises(ValueError, match="pad token precedes"):
+        check_position_layout(rob, left, (left != pad).long())
+    inside = torch.tensor([[5, pad, 6, 7, pad]])
+    with pytest.raises(ValueError, match="pad token precedes"):
+        check_position_layout(rob, inside, torch.tensor([[1, 1, 1, 1, 0]]))
+    check_position_layout(bert, left, (left != pad).long())                               # BERT numbers positions 0..L-1 regardless
 
 
 def test_one_pass_rule_for_tied_training_batches():
