@@ -233,6 +233,45 @@ static int record_layer_event(int l, hipStream_t s) {
   return 0;
 }
 
+// Weight-gradient lane of the BERT backward (OM_OPT_TRAIN_WGRAD_STREAM).  A layer's four weight-gradient GEMMs read
+// the same dY as the data-gradient GEMM that follows each of them and feed nothing inside the backward: at the training
+// batch (9 216 token rows) neither kind of launch fills 256 CUs on its own (108 - 432 tiles), so they run side by side
+// -- weight gradients on a second stream of this thread, ordered against the main stream by events:
+//   ready[l][i]  main -> side : dY (and the zeroed gradient arena) of weight gradient i of layer l is complete
+//   done[l][i]   side -> main : weight gradient i of layer l has finished reading its dY (the buffer may be rewritten)
+//   mark[l]      main -> side : every main-stream kernel of layer l is enqueued (the layer's progress event is then
+//                               recorded on the side stream, after both)
+// One event per (layer, site): no event is re-recorded while a wait on it may be pending.  Created on first use per
+// thread and device and kept (a training process owns one device for its lifetime).
+struct WgradLane {
+  int device = -1;
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> ready, done, mark;
+};
+static thread_local WgradLane g_lane;
+static int lane_get(int n_layers, WgradLane** out) {
+  int dev = 0;
+  OM_HIP(hipGetDevice(&dev));
+  if (g_lane.device != dev) {
+    g_lane = WgradLane{};
+    OM_HIP(hipStreamCreateWithFlags(&g_lane.side, hipStreamNonBlocking));
+    g_lane.device = dev;
+  }
+  auto grow = [](std::vector<hipEvent_t>& v, size_t n) -> int {
+    while (v.size() < n) {
+      hipEvent_t e = nullptr;
+      OM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      v.push_back(e);
+    }
+    return 0;
+  };
+  RUN(grow(g_lane.ready, (size_t)n_layers * 4));
+  RUN(grow(g_lane.done, (size_t)n_layers * 4));
+  RUN(grow(g_lane.mark, (size_t)n_layers + 1));
+  *out = &g_lane;
+  return 0;
+}
+
 // dx: gradient w.r.t. the stack's output (after the final dropout); returns through the grads struct
 int t5_train_backward(const OmEncoderConfig* c, const OmEncoderWeights* w, const int64_t* input_ids,
                       const int64_t* attention_mask, const Dims& d, const Tape& t, Ws& ws, float hd, float ad,
@@ -446,7 +485,24 @@ extern "C" int om_encoder_train_backward(const OmEncoderConfig* c, const OmEncod
     return t5_train_backward(c, w, input_ids, attention_mask, d, t, ws, hidden_dropout, attn_dropout, seed, dx,
                              dx_prev, g, s);
 
-#define WGRAD(dY_, N_, X_, K_, dW_, db_) RUN(wgrad(dt, dY_, N_, X_, K_, dW_, db_, d, ws, s))
+  // weight gradients on the second stream when every one of them takes the direct kernel (16-bit, widths of 128)
+  WgradLane* lane = nullptr;
+  if (om_option(OM_OPT_TRAIN_WGRAD_STREAM) && omk_gemm_tn_ok(dt, M, H, F, H, F) && omk_gemm_tn_ok(dt, M, F, H, F, H) &&
+      omk_gemm_tn_ok(dt, M, H, H, H, H) && omk_gemm_tn_ok(dt, M, 3 * H, H, 3 * H, H))
+    RUN(lane_get(d.nl, &lane));
+#define WGRAD(I_, dY_, N_, X_, K_, dW_, db_)                                                        \
+  do {                                                                                             \
+    if (lane) {                                                                                    \
+      OM_HIP(hipEventRecord(lane->ready[l * 4 + (I_)], s));                                        \
+      OM_HIP(hipStreamWaitEvent(lane->side, lane->ready[l * 4 + (I_)], 0));                        \
+      RUN(wgrad(dt, dY_, N_, X_, K_, dW_, db_, d, ws, lane->side));                                \
+      OM_HIP(hipEventRecord(lane->done[l * 4 + (I_)], lane->side));                                \
+    } else {                                                                                       \
+      RUN(wgrad(dt, dY_, N_, X_, K_, dW_, db_, d, ws, s));                                         \
+    }                                                                                              \
+  } while (0)
+  // before the main stream rewrites a buffer that weight gradient I_ of layer L_ reads
+#define WGRAD_DONE(L_, I_) do { if (lane && (L_) < d.nl) OM_HIP(hipStreamWaitEvent(s, lane->done[(L_) * 4 + (I_)], 0)); } while (0)
   RUN(transpose_weights(dt, Ls, d, ws, s));
 
   for (int l = d.nl - 1; l >= 0; --l) {
@@ -464,39 +520,50 @@ extern "C" int om_encoder_train_backward(const OmEncoderConfig* c, const OmEncod
 
     // LN2 backward: dy2 = d(loss)/d(y2)
     // (+ the FFN output branch's dropout, which sits after the dense and before the residual add, in the same pass)
+    WGRAD_DONE(l + 1, 2);                                           // ws.dy / ws.dd: last read by dWo of the layer above
     RUN(omk_ln_bwd_drop(dt, dx, y2, lw.ln2_g, ws.dy, ws.dd, hidden_dropout, site_seed(seed, l, 4), lg.ln2_g, lg.ln2_b, M, H, c->ln_eps, s));
     const char* dO = hidden_dropout > 0.f ? ws.dd : ws.dy;
-    WGRAD(dO, H, gl, F, lg.ffn2_w, lg.ffn2_b);                      // dW2 [H,F], db2
+    WGRAD(0, dO, H, gl, F, lg.ffn2_w, lg.ffn2_b);                   // dW2 [H,F], db2
     {
       GemmEpilogue e1 = {};
       e1.act = OM_ACT_GELU_ERF_GRAD; e1.resid = f; e1.ldr = F;      // df = (dO W2) * gelu'(f);  W2^T [F,H]
+      WGRAD_DONE(l + 1, 1);                                         // ws.df: last read by dW1 of the layer above
       RUN(omk_gemm(dt, dO, H, wt.f2, H, dt, ws.df, F, M, F, H, e1, s));
     }
-    WGRAD(ws.df, F, x1, H, lg.ffn1_w, lg.ffn1_b);                   // dW1 [F,H], db1
+    WGRAD(1, ws.df, F, x1, H, lg.ffn1_w, lg.ffn1_b);                // dW1 [F,H], db1
     {
       GemmEpilogue e2 = {};
       e2.resid = ws.dy; e2.ldr = H;                                 // dx1 = df W1 + dy2 (residual path);  W1^T [H,F]
       RUN(omk_gemm(dt, ws.df, F, wt.f1, F, dt, ws.dctx, H, M, H, F, e2, s));
     }
     // LN1 backward (ws.dctx holds d/d(x1) for now)
+    WGRAD_DONE(l, 0);                                               // ws.dy / ws.dd: read by dW2 of this layer
     RUN(omk_ln_bwd_drop(dt, ws.dctx, y1, lw.ln1_g, ws.dy, ws.dd, hidden_dropout, site_seed(seed, l, 3), lg.ln1_g, lg.ln1_b, M, H, c->ln_eps, s));
     const char* dA = hidden_dropout > 0.f ? ws.dd : ws.dy;
-    WGRAD(dA, H, ctx, H, lg.o_w, lg.o_b);                           // dWo [H,H], dbo
+    WGRAD(2, dA, H, ctx, H, lg.o_w, lg.o_b);                        // dWo [H,H], dbo
     {
       GemmEpilogue e3 = {};
       RUN(omk_gemm(dt, dA, H, wt.o, H, dt, ws.dctx, H, M, H, H, e3, s));    // dctx = dA Wo
     }
+    WGRAD_DONE(l + 1, 3);                                           // ws.dqkv: last read by dWqkv of the layer above
     RUN(omk_attention_bwd(dt, qkv, ws.dctx, ws.dqkv, attention_mask, B, (int)L, H, d.nh, scale,
                           attn_dropout, site_seed(seed, l, 2), s));
-    WGRAD(ws.dqkv, 3 * H, x, H, lg.qkv_w, lg.qkv_b);                // dWqkv [3H,H], dbqkv
+    WGRAD(3, ws.dqkv, 3 * H, x, H, lg.qkv_w, lg.qkv_b);             // dWqkv [3H,H], dbqkv
     {
       GemmEpilogue e4 = {};
       e4.resid = ws.dy; e4.ldr = H;                                 // dx = dqkv Wqkv + dy1;  Wqkv^T [H,3H]
       RUN(omk_gemm(dt, ws.dqkv, 3 * H, wt.qkv, 3 * H, dt, dx_prev, H, M, H, 3 * H, e4, s));
     }
     char* tmp = dx; dx = dx_prev; dx_prev = tmp;
-    RUN(record_layer_event(l, s));
+    if (lane && g_bwd_events) {                                     // the layer's gradients are complete when BOTH streams got here
+      OM_HIP(hipEventRecord(lane->mark[l], s));
+      OM_HIP(hipStreamWaitEvent(lane->side, lane->mark[l], 0));
+      RUN(record_layer_event(l, lane->side));
+    } else {
+      RUN(record_layer_event(l, s));
+    }
   }
+  if (lane) OM_HIP(hipStreamWaitEvent(s, lane->done[3], 0));        // join: the side stream is in order, layer 0's dWqkv is its last launch
   // ---- embeddings: dropout bwd -> LayerNorm bwd -> scatter into the three tables -------------
   const char* de = dx;
   if (hidden_dropout > 0.f) { RUN(omk_dropout(dt, dx, ws.dd, M * H, hidden_dropout, site_seed(seed, 0, 0), s)); de = ws.dd; }
@@ -504,6 +571,7 @@ extern "C" int om_encoder_train_backward(const OmEncoderConfig* c, const OmEncod
                     w->emb_ln_g, g->word_emb, g->pos_emb, g->type_emb, g->emb_ln_g, g->emb_ln_b, M,
                     (int)L, H, c->vocab, c->type_vocab, c->ln_eps, s));
 #undef WGRAD
+#undef WGRAD_DONE
   RUN(record_layer_event(d.nl, s));
   g_bwd_events = nullptr; g_bwd_nevents = 0;
   return 0;
