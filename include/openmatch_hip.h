@@ -99,7 +99,7 @@ void om_debug_gemm_gen(int gen);
 #define OM_OPT_ENCODER_TWO_PLANE 11 /* 1 (default): the fused bfloat16 BERT encoder keeps its pre-LayerNorm residual stream in TWO 16-bit
                                    * planes (value = hi + lo; the reference's autocast keeps it in f32) -- 1 - cos against the fp32 chain
                                    * 1e-5 instead of 4.8e-5 for +2 bytes per element at the two residual sites of a layer; 0: one plane */
-#define OM_OPT_GEMM_VARIANT 12     /* 0 (default): automatic tile-generation choice; 1 | 2 | 4 | 6 pin a generation (A/B measurements) */
+#define OM_OPT_GEMM_VARIANT 12     /* 0 (default): automatic tile-generation choice; 1 | 2 | 6 pin a generation (A/B measurements) */
 #define OM_OPT_SEARCH_DEBUG 13     /* 1: om_sim_topk logs every round (rows done, chunk, list lengths) to stderr */
 #define OM_OPT_COUNT 14
 int om_debug_option(int opt, int value);

@@ -2,11 +2,13 @@
 // Stands in for the ATen/BLAS GEMM under every nn.Linear on the hot path
 // (HF:models/bert/modeling_bert.py:175-177,289-293,334-351; linear.py:22-23).
 //
-// Kernel generations sharing gemm_epilogue.h:
-//   v1  128x128 tile, 2-stage LDS, direct stores            (small / ragged problems; this file)
-//   v2  256x128 tile, 3-deep LDS ring (gemm_core2.h)         (N < 256; this file)
-//   v4  256x256 tile, 8 waves, 4-deep ring (gemm_wide4.hip)
-//   v6  256x256 tile, 4 waves of 128x128  (gemm_wide6_bf16.hip, gemm_wide6_f32.hip)
+// Four tile shapes, each with a job none of the others does:
+//   v1  128x128 tile, 2-stage LDS, direct stores             any M, N: small / ragged problems, odd alignments (this file)
+//   v2  256x128 tile, 3-deep LDS ring (gemm_core2.h)          M >= 512 with few column tiles: the training batch (this file)
+//   v6  256x256 tile, 4 waves of 128x128, 64-byte K steps     f32 (3 x bf16 split), training epilogues (gemm_wide6_*.hip)
+//   v7  256x256 tile, persistent, 128-byte K steps            16-bit inference: whole tiles, fused LayerNorm (gemm_wide7*.hip)
+// (the eight-wave 256x256 generation 4 that v6 replaced is gone: what it still caught -- a bias that is not 16-byte
+// aligned, an epilogue v6 does not instantiate -- runs on v2)
 #include "gemm_core2.h"
 #include "gemm_epilogue.h"
 
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_nt_kernel2(
 OM_DEFINE_LAUNCHER(launch_gemm, gemm_nt_kernel, GEMM_THREADS, GEMM_LDS_BYTES, GEMM_BM, GEMM_BN)
 OM_DEFINE_LAUNCHER(launch_gemm2, gemm_nt_kernel2, G2_THREADS, G2_LDS_BYTES, G2_BM, G2_BN)
 
-static int gemm_variant() {     // OM_OPT_GEMM_VARIANT = 1|2|4|6 pins a kernel generation (A/B measurements; 0: automatic)
+static int gemm_variant() {     // OM_OPT_GEMM_VARIANT = 1|2|6 pins a kernel generation (A/B measurements; 0: automatic)
   return om_option(OM_OPT_GEMM_VARIANT);
 }
 
@@ -155,9 +157,9 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
     const double c4 = N >= 256 ? rounds(256, 256, 256) * (256.0 * 256.0) / 1.00 : 1e30;
     const double c2 = rounds(256, 128, 256) * (256.0 * 128.0) / 0.92;
     const double c1 = rounds(128, 128, 512) * (2 * 128.0 * 128.0) / 0.70;
-    gen = c4 <= c2 && c4 <= c1 ? 6 : (c2 <= c1 ? 2 : 1);     // 6 falls back to 4 where it has no variant
+    gen = c4 <= c2 && c4 <= c1 ? 6 : (c2 <= c1 ? 2 : 1);     // 6 falls back to 2 where it has no variant
     if (gemm_variant() == 2) gen = 2;
-    if (gemm_variant() == 4 || gemm_variant() == 6) gen = N >= 256 ? gemm_variant() : 2;
+    if (gemm_variant() == 6) gen = N >= 256 ? 6 : 2;
   }
   const bool ln_fused = ep.ln_stats || ep.rln_stats || ep.stats_out;
   if (in_dtype == OM_F16 && out_dtype == OM_F16) {
@@ -186,7 +188,7 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
     // v6 reads the bias as float4 and writes pre-activation pairs
     const bool aligned = (((uintptr_t)ep.bias & 15) == 0) && (ep.ldp % 2 == 0) && (((uintptr_t)ep.pre_act & 3) == 0);
     if (!aligned && ln_fused) OM_FAIL("fused LayerNorm epilogue needs 16-byte aligned bias");
-    if (!aligned) gen = 4;
+    if (!aligned) gen = 2;
     else if (g_debug_gen != 6 && gemm_variant() == 0 && in_dtype == OM_BF16 && out_dtype == OM_BF16 && !train && M % 256 == 0 &&
              N % 256 == 0 && (K * 2) % 128 == 0 && !(ep.ln_stats && (ep.rln_stats || ep.stats_out)) &&
              !((ep.rln_stats || ep.stats_out) && !ep.stats_out) && (!resid || (ep.ldr * 2) % 128 == 0) &&
@@ -198,9 +200,8 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
     else if (omk_gemm_wide6_f32_has(in_dtype, out_dtype, act, train, resid))
       return omk_gemm_wide6_f32(in_dtype, A, lda, B, ldb, out_dtype, C, ldc, M, N, K, ep, s);
     if (ln_fused) OM_FAIL("no kernel for this fused LayerNorm epilogue");
-    gen = 4;
+    gen = 2;
   }
-  if (gen == 4) return omk_gemm_wide4(in_dtype, A, lda, B, ldb, out_dtype, C, ldc, M, N, K, ep, s);
 #define OM_GEMM_GO(TI, TO)                                                                            \
   do {                                                                                                \
     if (gen == 2) return launch_gemm2<TI, TO>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);                 \

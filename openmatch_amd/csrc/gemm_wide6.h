@@ -14,7 +14,7 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel6(
     int64_t ldc, int64_t M, int64_t N, int64_t K, GemmEpilogue ep, int group_m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int64_t m0, n0;
-  g4_tile_coords(M, N, group_m, m0, n0);
+  g6_tile_coords(M, N, group_m, m0, n0);
   f32x16_t acc[4][4];
   unsigned long long* tr = ep.trace ? ep.trace + (size_t)blockIdx.x * 32 : nullptr;
   if (tr && threadIdx.x == 0) { tr[0] = clock64(); tr[30] = wall_clock64(); }
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel6(
   const char* pa[4];
   const char* pb[4];
   g6_point<T>(pa, pb, A, lda, B, ldb, M, N, m0, n0, wave, lane);
-  const int nk = (int)((K * (int64_t)sizeof(T)) / G4_ROW_BYTES);
+  const int nk = (int)((K * (int64_t)sizeof(T)) / G6_ROW_BYTES);
   // Initial value of the accumulators (loads issued BEFORE the first operand DMA: vmcnt retires in
   // order, so they return first and the arithmetic runs while the operands are in flight):
   //   * the bias; or
@@ -113,7 +113,7 @@ static int g6_group_m() {
 template <typename T, typename OutT, int ACT, bool TRAIN, bool RESID, int LNF = 0>
 static int launch6(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                    int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
-  const int64_t nwg = ((M + G4_BM - 1) / G4_BM) * ((N + G4_BN - 1) / G4_BN);
+  const int64_t nwg = ((M + G6_BM - 1) / G6_BM) * ((N + G6_BN - 1) / G6_BN);
   if (nwg > 0x7fffffffLL) OM_FAIL("grid too large");
   // 16-bit kernels with a residual keep three residual patches per wave in LDS next to the staging
   constexpr int lds_bytes = (RESID && sizeof(OutT) == 2 && G6E_RES_LDS_BYTES > G6_LDS_BYTES) ? G6E_RES_LDS_BYTES : G6_LDS_BYTES;

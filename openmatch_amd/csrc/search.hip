@@ -90,10 +90,10 @@ __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel6(
     unsigned* __restrict__ cnt, int group_m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // `group_m` index-row tiles stay resident (L2) while every query tile sweeps over them
-  const int64_t ntr = (nrows + G4_BN - 1) / G4_BN, ntq = (nq + G4_BM - 1) / G4_BM;
+  const int64_t ntr = (nrows + G6_BN - 1) / G6_BN, ntq = (nq + G6_BM - 1) / G6_BM;
   int64_t tr_, tq_;
   gemm_tile_coords(ntr, ntq, group_m, tr_, tq_);
-  const int64_t q0 = tq_ * G4_BM, r0 = tr_ * G4_BN;
+  const int64_t q0 = tq_ * G6_BM, r0 = tr_ * G6_BN;
   f32x16_t acc[4][4];
   {
     f32x16_t zero[4];
@@ -864,7 +864,7 @@ struct Scan {
   }
   int filter_step(int64_t r0, int64_t n, bool bf16, bool check = true /* false: the selection that follows flags overflows */) {
     const bool wide = nq > 128;
-    const int64_t ntm = (n + 255) / 256, ntn = wide ? (nq + G4_BM - 1) / G4_BM : (nq + G2_BN - 1) / G2_BN;
+    const int64_t ntm = (n + 255) / 256, ntn = wide ? (nq + G6_BM - 1) / G6_BM : (nq + G2_BN - 1) / G2_BN;
     if (ntm * ntn > 0x7fffffffLL) OM_FAIL("scan grid too large");
     const bool timing = om_timing_on();
     if (timing) om_timing_begin(OM_TIMING_SCAN, s);
