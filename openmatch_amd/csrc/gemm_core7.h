@@ -228,3 +228,91 @@ __device__ __forceinline__ void gemm_mainloop7_run(const SRC& src, int nk, char*
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                             // everyone is done with the ring
 }
+
+#ifdef G7_M16_PROBE
+// ---- the same K loop on 16 x 16 x 32 MFMAs (round 3) ------------------------------------------------------------------
+// PROBE ONLY (tools/gemm7_probe.hip -DG7_ABL=4 -DG7_M16_PROBE; not compiled into the library).  Why it was tried: under
+// the chip's power budget the matrix core sustains more with the small shape on random operands -- MFMA-only loops on
+// register operands (tools/mfma_power_probe.hip, profiles/r03_mfma_shape_power_probe.log): 32x32x16 1.87 PFLOP/s,
+// 16x16x32 2.15 (zeros: 2.49 / 2.44).  What it gave: the K loop alone 2.5-5 % faster (19.2 vs 20.0 us per K = 768 tile,
+// 80.9 vs 83.1 at K = 3072; profiles/r03_gemm7_kloop_16x16x32_probe.log) -- the loop's limit is not the matrix core's
+// share of the power.  Not worth re-deriving every epilogue for the other accumulator layout; kept for the record.
+//   acc[ti][fj][r] = C[m0 + wm*128 + ti*16 + (lane&15)][n0 + wn*128 + fj*16 + 4*(lane>>4) + r]
+// A fragment = 16 rows x 32 k: lane -> row (lane & 15), 16-byte k block (lane >> 4) of the sub-step's four; a 16-lane
+// group reads 16 consecutive rows at one k block: with chunk position XOR ((row >> 1) & 7) again 16 distinct slots.
+// Per wave and step: two sub-steps of 64 MFMAs; 16 ds_read_b128 and 8 DMA instructions per sub-step:
+//     sub-step 0   computes k 0-31 of step t; reads the fragments of k 32-63; issues A(t+2) -> spare
+//     barrier      vmcnt(8): step t+1 has landed (only A(t+2) is younger); every wave has read its last fragment of step t
+//     sub-step 1   computes k 32-63; reads the fragments of step t+1, k 0-31; issues B(t+2) -> A_cur
+template <typename T> struct Mma16;
+template <> struct Mma16<bf16_t> {
+  __device__ static inline void mma(const bf16x8_t& a, const bf16x8_t& b, f32x4_t& c) { c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mma16<f16_t> {
+  __device__ static inline void mma(const f16x8_t& a, const f16x8_t& b, f32x4_t& c) { c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <typename T, typename SRC = G7Src>
+__device__ __forceinline__ void gemm_mainloop7_run16(const SRC& src, int nk, char* smem,
+                                            f32x4_t (&acc)[8][8], unsigned long long* tr = nullptr,
+                                            bool stores_pending = false) {
+  typedef typename MmaOps<T>::frag_t frag_t;
+  static_assert(sizeof(T) == 2, "128-byte K steps: 16-bit operands only");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..3
+  const int wm = wave >> 1, wn = wave & 1;
+  const int key = (lane >> 1) & 7;           // == ((row >> 1) & 7) for row = 16*x + (lane & 15)
+  const int kb4 = lane >> 4;
+  int slot[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) slot[kk] = (((kk << 2) | kb4) ^ key) << 4;
+  const int rowa = (wm * 128 + (lane & 15)) * G7_ROW_BYTES;
+  const int rowb = (wn * 128 + (lane & 15)) * G7_ROW_BYTES;
+
+  if (stores_pending) { if (nk > 1) __builtin_amdgcn_s_waitcnt(0xC070); else __builtin_amdgcn_s_waitcnt(0x8070); }   // vmcnt(48) / vmcnt(32)
+  else if (nk > 1) __builtin_amdgcn_s_waitcnt(0x4070);      // vmcnt(16) lgkmcnt(0)
+  else __builtin_amdgcn_s_waitcnt(0x0070);                  // vmcnt(0)
+  __builtin_amdgcn_s_barrier();
+
+  const uint32_t lds0 = g7_lds_addr(smem);
+  const char* ka = src.a + 2 * G7_ROW_BYTES;      // K offset of step t + 2 (scalar registers)
+  const char* kb = src.b + 2 * G7_ROW_BYTES;
+  int u_ac = 0, u_bc = G7_UNIT_BYTES, u_an = 2 * G7_UNIT_BYTES, u_bn = 3 * G7_UNIT_BYTES, u_sp = 4 * G7_UNIT_BYTES;
+  frag_t a0[8], b0[8], a1[8], b1[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) b0[i] = *(const frag_t*)(smem + u_bc + rowb + i * 16 * G7_ROW_BYTES + slot[0]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a0[i] = *(const frag_t*)(smem + u_ac + rowa + i * 16 * G7_ROW_BYTES + slot[0]);
+
+#define G7_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define G7_DMA(P, I, UNIT) do { if (!(G7_ABL & 8)) g7_issue_##P(src, k##P, I, lds0 + (UNIT) + ((I) * 4 + wave) * 1024); } while (0)
+  // one k sub-step: 64 MFMAs from (AF, BF); every fourth covers one fragment read into (BN, then AN) from (UA, UB)
+  // chunk SLOT; MFMAs 5, 13, .. each cover one DMA issue of operand P into UNIT when the wave-uniform COND holds
+#define G7_SUB16(AF, BF, AN, BN, UA, UB, SLOT, P, UNIT, COND)                                            \
+  _Pragma("unroll") for (int q = 0; q < 64; ++q) {                                                       \
+    if (!(G7_ABL & 32)) Mma16<T>::mma(BF[q & 7], AF[q >> 3], acc[q >> 3][q & 7]);                        \
+    if ((q & 3) == 0 && !(G7_ABL & 16)) {                                                                \
+      if (q < 32) BN[q >> 2] = *(const frag_t*)(smem + (UB) + rowb + (q >> 2) * 16 * G7_ROW_BYTES + (SLOT)); \
+      else AN[(q >> 2) - 8] = *(const frag_t*)(smem + (UA) + rowa + ((q >> 2) - 8) * 16 * G7_ROW_BYTES + (SLOT)); \
+    }                                                                                                    \
+    if ((q & 7) == 5) { if (COND) G7_DMA(P, q >> 3, UNIT); }                                             \
+    G7_FENCE();                                                                                          \
+  }
+  for (int t = 0; t < nk; ++t) {
+    const bool issue = t + 2 < nk;
+    if (tr && tid == 0 && t < 12) tr[3 + t] = clock64();
+    G7_SUB16(a0, b0, a1, b1, u_ac, u_bc, slot[1], a, u_sp, issue)
+    if (issue) __builtin_amdgcn_s_waitcnt(0x0078); else __builtin_amdgcn_s_waitcnt(0x0070);
+    if (!(G7_ABL & 64)) __builtin_amdgcn_s_barrier();
+    G7_FENCE();
+    G7_SUB16(a1, b1, a0, b0, u_an, u_bn, slot[0], b, u_ac, issue)
+    { const int o_ac = u_ac, o_bc = u_bc; u_ac = u_an; u_bc = u_bn; u_an = u_sp; u_bn = o_ac; u_sp = o_bc; }
+    ka += G7_ROW_BYTES; kb += G7_ROW_BYTES;
+  }
+#undef G7_SUB16
+#undef G7_DMA
+#undef G7_FENCE
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                             // everyone is done with the ring
+}
+#endif  // G7_M16_PROBE

@@ -202,7 +202,22 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
 #pragma unroll
       for (int q = 0; q < 16; ++q) { acc[q >> 2][q & 3] = zero; MmaOps<T>::mma(fb[q & 3], fa[q >> 2], acc[q >> 2][q & 3]); }
     }
+#ifdef G7_M16_PROBE      // tools/gemm7_probe.hip with -DG7_ABL=4: the K loop alone on 16 x 16 x 32 MFMAs
+    f32x4_t acc16[8][8];
+    {
+      typedef typename MmaOps<T>::frag_t frag_t;
+      const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+      const frag_t zf = __builtin_bit_cast(frag_t, z4);
+      const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 64; ++q) { acc16[q >> 3][q & 7] = zero4; Mma16<T>::mma(zf, zf, acc16[q >> 3][q & 7]); }
+    }
+    gemm_mainloop7_run16<T, G7SrcU>(src, nk, smem, acc16, tr, pending);
+#pragma unroll
+    for (int q = 0; q < 64; ++q) asm volatile("" : "+a"(acc16[q >> 3][q & 7]));
+#else
     gemm_mainloop7_run<T, G7SrcU>(src, nk, smem, acc, tr, pending);     // waits again (a no-op now), barrier, K loop, barrier
+#endif
     if (tr && threadIdx.x == 0) tr[15] = clock64();
 
     // ---- next tile (a workgroup that has none re-fetches its own: the instruction stream stays fixed) -----------------
@@ -518,8 +533,10 @@ typedef unsigned int g7_u32x4 __attribute__((ext_vector_type(4)));
 #undef G7E_WRITE
 #undef G7E_WRITE_LO
     } else {
+#ifndef G7_M16_PROBE
 #pragma unroll
       for (int q = 0; q < 16; ++q) asm volatile("" : "+a"(acc[q >> 2][q & 3]));
+#endif
     }
 #undef G7E_RES_DMA
 #undef G7E_RES_SLICE

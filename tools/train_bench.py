@@ -13,11 +13,15 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--wgrad-wgs", type=int, default=0, help="weight-gradient workgroups per launch / 64 (0: the kernel's default, 5)")
     a = ap.parse_args()
     from transformers import BertConfig, BertModel
     from openmatch.modeling import DRModel
     from openmatch.trainer import DRTrainer
     dev = "cuda:0"
+    if a.wgrad_wgs:
+        from openmatch_amd import native as N
+        N.check(N.lib().om_debug_option(5, a.wgrad_wgs << 4))         # OM_OPT_WGRAD_DEBUG: bits 4.. = workgroups / 64
     torch.manual_seed(0)
     cfg = BertConfig(hidden_dropout_prob=a.dropout, attention_probs_dropout_prob=a.dropout)
     lm = BertModel(cfg)
@@ -46,7 +50,7 @@ def main():
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
     flop = 3 * (8 * 5.474e9 + 64 * 22.347e9)
     print(json.dumps({"metric": "contrastive train steps/s (8 q x 32 + 64 p x 128, bert-base, fwd+bwd+AdamW)", "steps_per_s": round(1 / dt, 2),
-                      "ms_per_step": round(dt * 1e3, 2), "precision": a.precision, "dropout": a.dropout,
+                      "ms_per_step": round(dt * 1e3, 2), "precision": a.precision, "dropout": a.dropout, "wgrad_wgs": a.wgrad_wgs,
                       "algorithmic_tflops": round(flop / dt / 1e12, 1), "loss": float(loss)}))
 
 
