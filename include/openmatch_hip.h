@@ -248,6 +248,38 @@ int om_t5_decoder_step(const OmEncoderConfig* cfg, const OmT5DecoderWeights* w, 
                        const int64_t* attention_mask, int64_t B, int64_t L, float* out_hidden,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* Training through the decoder position (reference: autograd under DRModel.encode :137-141 / RRModel.encode :110-114 in
+ * train mode).  `dropout` = HF config.dropout_rate (0 in eval), applied at HF's sites from hashes of (seed, site,
+ * index); the forward keeps a caller-owned tape, the backward ADDS weight gradients into caller-zeroed f32 buffers laid
+ * out like the weights and WRITES d_enc_hidden [B,L,H] (cfg->dtype), the gradient w.r.t. enc_hidden, which
+ * om_encoder_train_backward_hidden takes.  start_emb [H]: gradient of the one embedding row the decoder reads (point it
+ * at row decoder_start of the shared table's gradient; NULL skips it). */
+typedef struct OmT5DecoderLayerGrads {
+  float* sa_v_w;  float* sa_o_w; float* sa_ln_g;
+  float* ca_q_w;  float* ca_kv_w; float* ca_o_w; float* ca_ln_g;
+  float* ffn1_w;  float* ffn1g_w; float* ffn2_w; float* ffn_ln_g;
+} OmT5DecoderLayerGrads;
+typedef struct OmT5DecoderGrads {
+  float* start_emb;
+  float* final_ln_g;
+  const OmT5DecoderLayerGrads* layers_host;   /* HOST array [n_layers] of device pointers */
+} OmT5DecoderGrads;
+size_t om_t5_decoder_tape_bytes(const OmEncoderConfig* cfg, int n_layers, int64_t B, int64_t L);
+size_t om_t5_decoder_train_workspace_bytes(const OmEncoderConfig* cfg, int n_layers, int64_t B, int64_t L);
+int om_t5_decoder_train_forward(const OmEncoderConfig* cfg, const OmT5DecoderWeights* w, const void* enc_hidden,
+                                const int64_t* attention_mask, int64_t B, int64_t L, float dropout, uint64_t seed,
+                                void* tape, size_t tape_bytes, float* out_hidden, void* workspace,
+                                size_t workspace_bytes, void* stream);
+int om_t5_decoder_train_backward(const OmEncoderConfig* cfg, const OmT5DecoderWeights* w, const void* enc_hidden,
+                                 const int64_t* attention_mask, int64_t B, int64_t L, float dropout, uint64_t seed,
+                                 const void* tape, const float* d_out, const OmT5DecoderGrads* grads,
+                                 void* d_enc_hidden, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of y[B,D] = x[B,K] W[D,K]^T in f32 (om_gemm_nt forward): dw [D,K] = dy^T x (written), dx [B,K] = dy W.
+ * Either output may be NULL.  The LinearHead / LM-head rows behind a trained T5 decoder position. */
+int om_linear_f32_backward(const float* dy, const float* x, const float* w, float* dw, float* dx, int B, int D, int K,
+                           void* stream);
+
 /* ------------------------------------------------------------------------
  * Encoder forward + backward for training (BERT; sequence length <= 128).
  * Replaces the autograd graph HF builds under DRModel.forward in train mode
@@ -294,6 +326,22 @@ int om_encoder_train_backward(const OmEncoderConfig* cfg, const OmEncoderWeights
                               float hidden_dropout, float attn_dropout, uint64_t seed,
                               const void* tape, const float* d_reps, const OmEncoderGrads* grads,
                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same pair with the stack's output / its gradient at the boundary instead of pooled representations: out_hidden
+ * and d_hidden are [B,L,H] in cfg->dtype (T5: after the final RMSNorm and its dropout).  cfg->pooling / head / normalize
+ * are ignored.  What the T5 decoder position (om_t5_decoder_train_*) sits on. */
+int om_encoder_train_forward_hidden(const OmEncoderConfig* cfg, const OmEncoderWeights* w,
+                                    const int64_t* input_ids, const int64_t* attention_mask,
+                                    const int64_t* token_type_ids, int64_t B, int64_t L,
+                                    float hidden_dropout, float attn_dropout, uint64_t seed, void* tape,
+                                    size_t tape_bytes, void* out_hidden, void* workspace,
+                                    size_t workspace_bytes, void* stream);
+int om_encoder_train_backward_hidden(const OmEncoderConfig* cfg, const OmEncoderWeights* w,
+                                     const int64_t* input_ids, const int64_t* attention_mask,
+                                     const int64_t* token_type_ids, int64_t B, int64_t L,
+                                     float hidden_dropout, float attn_dropout, uint64_t seed,
+                                     const void* tape, const void* d_hidden, const OmEncoderGrads* grads,
+                                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* Gradient all-reduce overlapped with the backward (multi-GPU training): hand the NEXT om_encoder_train_backward on this
  * thread an array of n_layers + 1 hipEvent_t.  events[l] (l = n_layers-1 .. 0) is recorded on the backward's stream once

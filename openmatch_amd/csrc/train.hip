@@ -362,13 +362,15 @@ extern "C" size_t om_encoder_train_workspace_bytes(const OmEncoderConfig* cfg, i
 
 #define RUN(expr) do { if (expr) return 1; } while (0)
 
-extern "C" int om_encoder_train_forward(const OmEncoderConfig* c, const OmEncoderWeights* w,
-                                        const int64_t* input_ids, const int64_t* attention_mask,
-                                        const int64_t* token_type_ids, int64_t B, int64_t L,
-                                        float hidden_dropout, float attn_dropout, uint64_t seed,
-                                        void* tape_mem, size_t tape_bytes, float* out_reps,
-                                        void* workspace, size_t workspace_bytes, void* stream) {
-  if (!c || !w || !input_ids || !attention_mask || !tape_mem || !workspace || !out_reps) OM_FAIL("null argument");
+// out_hidden != NULL: the stack's output [B,L,H] in the compute dtype (T5: after the final RMSNorm and its dropout) is
+// copied out and the pooling / head / normalise tail is skipped (the T5 decoder position consumes it, decoder.hip)
+static int train_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* w,
+                              const int64_t* input_ids, const int64_t* attention_mask,
+                              const int64_t* token_type_ids, int64_t B, int64_t L,
+                              float hidden_dropout, float attn_dropout, uint64_t seed,
+                              void* tape_mem, size_t tape_bytes, float* out_reps, void* out_hidden,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  if (!c || !w || !input_ids || !attention_mask || !tape_mem || !workspace || (!out_reps && !out_hidden)) OM_FAIL("null argument");
   if (check_train_cfg(c, L)) return 1;
   if (B <= 0) return 0;
   if (((uintptr_t)tape_mem & 255) || ((uintptr_t)workspace & 255)) OM_FAIL("tape/workspace must be 256-byte aligned");
@@ -384,6 +386,10 @@ extern "C" int om_encoder_train_forward(const OmEncoderConfig* c, const OmEncode
   if (d.t5) {
     char* xf_t5 = nullptr;
     if (t5_train_forward(c, w, input_ids, attention_mask, d, t, ws, hidden_dropout, attn_dropout, seed, &xf_t5, s)) return 1;
+    if (out_hidden) {
+      OM_HIP(hipMemcpyAsync(out_hidden, xf_t5, (size_t)M * H * d.es, hipMemcpyDeviceToDevice, s));
+      return 0;
+    }
     const bool head_t5 = c->head_in > 0 && w->head_w;
     RUN(omk_pool(dt, xf_t5, attention_mask, t.pooled, B, (int)L, H, c->pooling, s));
     float* pre_t5 = c->normalize ? t.headout : out_reps;
@@ -430,6 +436,10 @@ extern "C" int om_encoder_train_forward(const OmEncoderConfig* c, const OmEncode
     RUN(omk_layernorm(dt, y2, H, t.x + t.sx * (l + 1), H, lw.ln2_g, lw.ln2_b, M, H, c->ln_eps, 0, s));
   }
   const char* xf = t.x + t.sx * d.nl;
+  if (out_hidden) {
+    OM_HIP(hipMemcpyAsync(out_hidden, xf, (size_t)M * H * d.es, hipMemcpyDeviceToDevice, s));
+    return 0;
+  }
   const bool head = c->head_in > 0 && w->head_w;
   RUN(omk_pool(dt, xf, attention_mask, t.pooled, B, (int)L, H, c->pooling, s));
   float* pre = c->normalize ? t.headout : out_reps;      // value before F.normalize
@@ -443,14 +453,36 @@ extern "C" int om_encoder_train_forward(const OmEncoderConfig* c, const OmEncode
   return 0;
 }
 
-extern "C" int om_encoder_train_backward(const OmEncoderConfig* c, const OmEncoderWeights* w,
-                                         const int64_t* input_ids, const int64_t* attention_mask,
-                                         const int64_t* token_type_ids, int64_t B, int64_t L,
-                                         float hidden_dropout, float attn_dropout, uint64_t seed,
-                                         const void* tape_mem, const float* d_reps,
-                                         const OmEncoderGrads* g, void* workspace,
-                                         size_t workspace_bytes, void* stream) {
-  if (!c || !w || !g || !tape_mem || !d_reps || !workspace) OM_FAIL("null argument");
+extern "C" int om_encoder_train_forward(const OmEncoderConfig* c, const OmEncoderWeights* w,
+                                        const int64_t* input_ids, const int64_t* attention_mask,
+                                        const int64_t* token_type_ids, int64_t B, int64_t L,
+                                        float hidden_dropout, float attn_dropout, uint64_t seed,
+                                        void* tape_mem, size_t tape_bytes, float* out_reps,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+  if (!out_reps) OM_FAIL("null argument");
+  return train_forward_impl(c, w, input_ids, attention_mask, token_type_ids, B, L, hidden_dropout, attn_dropout, seed,
+                            tape_mem, tape_bytes, out_reps, nullptr, workspace, workspace_bytes, stream);
+}
+extern "C" int om_encoder_train_forward_hidden(const OmEncoderConfig* c, const OmEncoderWeights* w,
+                                               const int64_t* input_ids, const int64_t* attention_mask,
+                                               const int64_t* token_type_ids, int64_t B, int64_t L,
+                                               float hidden_dropout, float attn_dropout, uint64_t seed,
+                                               void* tape_mem, size_t tape_bytes, void* out_hidden,
+                                               void* workspace, size_t workspace_bytes, void* stream) {
+  if (!out_hidden) OM_FAIL("null argument");
+  return train_forward_impl(c, w, input_ids, attention_mask, token_type_ids, B, L, hidden_dropout, attn_dropout, seed,
+                            tape_mem, tape_bytes, nullptr, out_hidden, workspace, workspace_bytes, stream);
+}
+
+// d_hidden != NULL: the gradient w.r.t. the stack's output [B,L,H] (compute dtype) replaces the tail's backward
+static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights* w,
+                               const int64_t* input_ids, const int64_t* attention_mask,
+                               const int64_t* token_type_ids, int64_t B, int64_t L,
+                               float hidden_dropout, float attn_dropout, uint64_t seed,
+                               const void* tape_mem, const float* d_reps, const void* d_hidden,
+                               const OmEncoderGrads* g, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  if (!c || !w || !g || !tape_mem || (!d_reps && !d_hidden) || !workspace) OM_FAIL("null argument");
   if (check_train_cfg(c, L)) return 1;
   if (B <= 0) return 0;
   const Dims d = dims_of(c, B, L);
@@ -465,22 +497,26 @@ extern "C" int om_encoder_train_backward(const OmEncoderConfig* c, const OmEncod
   if (!Ls || !Gs) OM_FAIL("layers_host is null");
   const float scale = 1.0f / sqrtf((float)c->head_dim);
 
-  // ---- tail: normalise -> head -> pooling ----------------------------------------------------
-  const bool head = c->head_in > 0 && w->head_w;
-  const float* dhead = d_reps;
-  if (c->normalize) {
-    RUN(omk_l2norm_bwd(t.headout, d_reps, ws.dhead, B, d.D, s));
-    dhead = ws.dhead;
-  }
-  const float* dpooled = dhead;
-  if (head) {
-    if (g->head_w) RUN(omk_small_tn(dhead, t.pooled, g->head_w, (int)B, d.D, c->head_in, s));   // dW = dY^T X
-    RUN(omk_small_nn(dhead, w->head_w, ws.dpooled, (int)B, d.D, c->head_in, s));                 // dX = dY W
-    dpooled = ws.dpooled;
-  }
   char* dx = ws.dxa;       // gradient w.r.t. the current layer's OUTPUT
   char* dx_prev = ws.dxb;  // gradient w.r.t. its input (next iteration's dx)
-  RUN(omk_pool_bwd(dt, dpooled, attention_mask, dx, B, (int)L, H, c->pooling, s));
+  if (d_hidden) {
+    OM_HIP(hipMemcpyAsync(dx, d_hidden, (size_t)M * H * d.es, hipMemcpyDeviceToDevice, s));
+  } else {
+    // ---- tail: normalise -> head -> pooling ----------------------------------------------------
+    const bool head = c->head_in > 0 && w->head_w;
+    const float* dhead = d_reps;
+    if (c->normalize) {
+      RUN(omk_l2norm_bwd(t.headout, d_reps, ws.dhead, B, d.D, s));
+      dhead = ws.dhead;
+    }
+    const float* dpooled = dhead;
+    if (head) {
+      if (g->head_w) RUN(omk_small_tn(dhead, t.pooled, g->head_w, (int)B, d.D, c->head_in, s));   // dW = dY^T X
+      RUN(omk_small_nn(dhead, w->head_w, ws.dpooled, (int)B, d.D, c->head_in, s));                 // dX = dY W
+      dpooled = ws.dpooled;
+    }
+    RUN(omk_pool_bwd(dt, dpooled, attention_mask, dx, B, (int)L, H, c->pooling, s));
+  }
   if (d.t5)
     return t5_train_backward(c, w, input_ids, attention_mask, d, t, ws, hidden_dropout, attn_dropout, seed, dx,
                              dx_prev, g, s);
@@ -575,4 +611,27 @@ extern "C" int om_encoder_train_backward(const OmEncoderConfig* c, const OmEncod
   RUN(record_layer_event(d.nl, s));
   g_bwd_events = nullptr; g_bwd_nevents = 0;
   return 0;
+}
+
+extern "C" int om_encoder_train_backward(const OmEncoderConfig* c, const OmEncoderWeights* w,
+                                         const int64_t* input_ids, const int64_t* attention_mask,
+                                         const int64_t* token_type_ids, int64_t B, int64_t L,
+                                         float hidden_dropout, float attn_dropout, uint64_t seed,
+                                         const void* tape_mem, const float* d_reps,
+                                         const OmEncoderGrads* g, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  if (!d_reps) OM_FAIL("null argument");
+  return train_backward_impl(c, w, input_ids, attention_mask, token_type_ids, B, L, hidden_dropout, attn_dropout, seed,
+                             tape_mem, d_reps, nullptr, g, workspace, workspace_bytes, stream);
+}
+extern "C" int om_encoder_train_backward_hidden(const OmEncoderConfig* c, const OmEncoderWeights* w,
+                                                const int64_t* input_ids, const int64_t* attention_mask,
+                                                const int64_t* token_type_ids, int64_t B, int64_t L,
+                                                float hidden_dropout, float attn_dropout, uint64_t seed,
+                                                const void* tape_mem, const void* d_hidden,
+                                                const OmEncoderGrads* g, void* workspace,
+                                                size_t workspace_bytes, void* stream) {
+  if (!d_hidden) OM_FAIL("null argument");
+  return train_backward_impl(c, w, input_ids, attention_mask, token_type_ids, B, L, hidden_dropout, attn_dropout, seed,
+                             tape_mem, nullptr, d_hidden, g, workspace, workspace_bytes, stream);
 }

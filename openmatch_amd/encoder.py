@@ -234,6 +234,17 @@ def _pack_t5_decoder(model, code, device):
 _PACK_CACHE_ATTR = "_openmatch_amd_packed"
 
 
+class _PackCache(dict):
+    """Per-module cache of packed device weights (ctypes structs + device buffers).  It hangs off the module's __dict__,
+    so `copy.deepcopy(model)` and `torch.save(model)` meet it: a copy / a pickle gets an EMPTY cache (the weights are
+    re-packed on first use) instead of failing on the ctypes pointers."""
+    def __deepcopy__(self, memo):
+        return _PackCache()
+
+    def __reduce__(self):
+        return (_PackCache, ())
+
+
 def _version_key(model, head):
     mods = [model] + ([head] if head is not None else [])
     return tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters())
@@ -241,7 +252,7 @@ def _version_key(model, head):
 
 def packed_weights(model, head, code, device):
     """Packed weights for (model, head, dtype, device), rebuilt only when a parameter changed."""
-    cache = model.__dict__.setdefault(_PACK_CACHE_ATTR, {})
+    cache = model.__dict__.setdefault(_PACK_CACHE_ATTR, _PackCache())
     key = (code, str(device), id(head))
     ver = _version_key(model, head)
     hit = cache.get(key)
@@ -319,6 +330,18 @@ def hip_encode(model, items, pooling, head, normalize, code, want_hidden=True):
     return hidden, reps
 
 
+def packed_decoder_weights(model, code, device):
+    """Packed decoder-side weights for (model, dtype, device), rebuilt only when a parameter changed."""
+    cache = model.__dict__.setdefault(_PACK_CACHE_ATTR + "_dec", _PackCache())
+    key = (code, str(device))
+    ver = _version_key(model, None)
+    hit = cache.get(key)
+    if hit is None or hit[0] != ver:
+        hit = (ver, _pack_t5_decoder(model, code, device))
+        cache[key] = hit
+    return hit[1]
+
+
 def hip_t5_decoder_step(model, items, code):
     """Decoder hidden state [B, H] (f32) of a T5 encoder-decoder after ONE decoder position fed token 0 -- the
     reference's `model(**items, decoder_input_ids=zeros([B, 1])).last_hidden_state[:, 0]`
@@ -329,14 +352,7 @@ def hip_t5_decoder_step(model, items, code):
     enc_hidden, _ = hip_encode(model, items, None, None, False, code, want_hidden=True)
     device = enc_hidden.device
     mask = items["attention_mask"].to(device=device, dtype=torch.int64).contiguous()
-    cache = model.__dict__.setdefault(_PACK_CACHE_ATTR + "_dec", {})
-    key = (code, str(device))
-    ver = _version_key(model, None)
-    hit = cache.get(key)
-    if hit is None or hit[0] != ver:
-        hit = (ver, _pack_t5_decoder(model, code, device))
-        cache[key] = hit
-    dpk = hit[1]
+    dpk = packed_decoder_weights(model, code, device)
     epk = packed_weights(model, None, code, device)
     cfg = N.OmEncoderConfig(pooling=N.POOL_NONE, normalize=0, **epk.cfg)
     B, L = mask.shape
@@ -348,6 +364,32 @@ def hip_t5_decoder_step(model, items, code):
         N.check(lib.om_t5_decoder_step(C.byref(cfg), C.byref(dpk.weights), N.ptr(enc_hidden), N.ptr(mask), B, L,
                                        N.ptr(out), C.c_void_p(ws_ptr), nbytes, N.stream_ptr(device)))
     return out
+
+
+class _LinearF32(torch.autograd.Function):
+    """y = x W^T in f32 with its backward on the device (om_gemm_nt / om_linear_f32_backward): the LinearHead and the two
+    LM-head rows of monoT5 behind the T5 decoder position when it is trained."""
+    @staticmethod
+    def forward(ctx, x, weight):
+        x32 = x.to(torch.float32).contiguous()
+        w32 = weight.to(device=x.device, dtype=torch.float32).contiguous()
+        ctx.save_for_backward(x32, w32)
+        return hip_linear_f32(x32, w32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x32, w32 = ctx.saved_tensors
+        dy = dy.to(torch.float32).contiguous()
+        dx = torch.empty_like(x32)
+        dw = torch.zeros_like(w32)
+        with torch.cuda.device(x32.device):
+            N.check(N.lib().om_linear_f32_backward(N.ptr(dy), N.ptr(x32), N.ptr(w32), N.ptr(dw), N.ptr(dx), x32.shape[0],
+                                                  w32.shape[0], x32.shape[1], N.stream_ptr(x32.device)))
+        return dx, dw
+
+
+def hip_linear_f32_autograd(x, weight):
+    return _LinearF32.apply(x, weight)
 
 
 def hip_linear_f32(x, weight):

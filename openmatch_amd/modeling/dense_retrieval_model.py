@@ -127,16 +127,23 @@ class DRModel(nn.Module):
 
     def _encode_t5_decoder(self, items, model, head):
         """T5 encoder-decoder pooling (reference :137-141): one decoder position fed token 0, reps = its hidden state,
-        then head / normalize.  Inference only: the decoder step has no backward on the HIP path."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()):
-            raise NotImplementedError(
-                "training through the T5 decoder step has no HIP backward; train with --encoder_only "
-                "(T5EncoderModel, what GTR / sentence-T5 checkpoints use) or wrap inference in torch.no_grad()")
-        from ..encoder import hip_linear_f32, hip_t5_decoder_step
-        reps = hip_t5_decoder_step(model, items, compute_dtype_code(self.model_args))
+        then head / normalize.  With autograd on (or dropout active) the training pair om_encoder_train_*_hidden +
+        om_t5_decoder_train_* runs behind one autograd node (openmatch_amd/train.py), the head through a differentiable
+        HIP linear; otherwise the inference kernels."""
+        from ..encoder import hip_linear_f32, hip_linear_f32_autograd, hip_t5_decoder_step
+        code = compute_dtype_code(self.model_args)
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
+        has_dropout = self.training and getattr(model.config, "dropout_rate", 0.0) > 0
+        if needs_grad or has_dropout:
+            from ..train import t5_decoder_state_train
+            reps = t5_decoder_state_train(model, items, code, self.training)
+            linear = hip_linear_f32_autograd
+        else:
+            reps = hip_t5_decoder_step(model, items, code)
+            linear = hip_linear_f32
         hidden = reps.unsqueeze(1)                       # [B, 1, H]: the decoder's last_hidden_state
         if head is not None:
-            reps = hip_linear_f32(reps, head.linear.weight)
+            reps = linear(reps, head.linear.weight)
         if self.normalize:
             reps = torch.nn.functional.normalize(reps, dim=1)
         return hidden, reps

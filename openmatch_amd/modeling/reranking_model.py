@@ -3,7 +3,7 @@
 pair -> CLS / mean pooling -> `LinearHead(H, 1)`.  The whole scoring path is ONE
 `om_encoder_forward` call (head_out = 1); BASELINE config 5 (bert-large, L = 162) runs the same
 kernels as the bi-encoder at H = 1024.  The monoT5 encoder-decoder branch (:110-114) runs the encoder and one T5
-decoder position (`om_t5_decoder_step`) and reads two columns of the LM head: inference only.  Training is supported
+decoder position (`om_t5_decoder_step`; in training `om_t5_decoder_train_*`) and reads two columns of the LM head.  Training is supported
 for encoder-only backbones at sequence lengths the
 HIP backward covers (L <= 256 in bfloat16, <= 192 in float32; the default pair length is 162)."""
 import json
@@ -75,22 +75,29 @@ class RRModel(nn.Module):
 
     def _encode_mono_t5(self, items):
         """monoT5 (reference :110-114): logits[:, 0, [neg_token, pos_token]] of a T5ForConditionalGeneration after one
-        decoder position fed token 0 -> [B, 2]; the Reranker takes log_softmax(...)[:, 1].  Inference only."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.lm.parameters()):
-            raise NotImplementedError("training monoT5 through the decoder step has no HIP backward; "
-                                      "score under torch.no_grad() or train an encoder-only cross-encoder")
+        decoder position fed token 0 -> [B, 2]; the Reranker takes log_softmax(...)[:, 1].  With autograd on the training
+        kernels run behind one autograd node and the two LM-head rows go through a differentiable HIP linear."""
         if self.pos_token_id is None or self.neg_token_id is None:
             raise ValueError("monoT5 scoring needs pos_token and neg_token")
         if not hasattr(self.lm, "lm_head"):
             raise ValueError("monoT5 scoring needs a T5ForConditionalGeneration (lm_head) model")
-        from ..encoder import hip_linear_f32, hip_t5_decoder_step
-        state = hip_t5_decoder_step(self.lm, items, compute_dtype_code(self.model_args))      # [B, H] f32
+        from ..encoder import hip_linear_f32, hip_linear_f32_autograd, hip_t5_decoder_step
+        code = compute_dtype_code(self.model_args)
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.lm.parameters())
+        has_dropout = self.training and getattr(self.lm.config, "dropout_rate", 0.0) > 0
+        if needs_grad or has_dropout:
+            from ..train import t5_decoder_state_train
+            state = t5_decoder_state_train(self.lm, items, code, self.training)              # [B, H] f32, differentiable
+            linear = hip_linear_f32_autograd
+        else:
+            state = hip_t5_decoder_step(self.lm, items, code)                                 # [B, H] f32
+            linear = hip_linear_f32
         cfg = self.lm.config      # HF T5ForConditionalGeneration.forward: original T5 scales the state, v1.1 does not
         scale = cfg.scale_decoder_outputs if hasattr(cfg, "scale_decoder_outputs") else getattr(cfg, "tie_word_embeddings", True)
         if scale:                 # (transformers >= 5 keeps that bit in `scale_decoder_outputs`, 4.x in `tie_word_embeddings`)
             state = state * (cfg.d_model ** -0.5)
         cols = self.lm.lm_head.weight[[self.neg_token_id, self.pos_token_id]]
-        return hip_linear_f32(state, cols)                             # [B, 2]
+        return linear(state, cols)                                     # [B, 2]
 
     @classmethod
     def build(cls, model_args, data_args=None, train_args=None, tokenizer=None, **hf_kwargs):

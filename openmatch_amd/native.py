@@ -53,6 +53,15 @@ class OmT5DecoderWeights(C.Structure):
                 ("layers_host", C.POINTER(OmT5DecoderLayer)), ("n_layers", c_int)]
 
 
+class OmT5DecoderLayerGrads(C.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "sa_v_w", "sa_o_w", "sa_ln_g", "ca_q_w", "ca_kv_w", "ca_o_w", "ca_ln_g", "ffn1_w", "ffn1g_w", "ffn2_w", "ffn_ln_g")]
+
+
+class OmT5DecoderGrads(C.Structure):
+    _fields_ = [("start_emb", c_void_p), ("final_ln_g", c_void_p), ("layers_host", C.POINTER(OmT5DecoderLayerGrads))]
+
+
 class OmLayerGrads(C.Structure):
     _fields_ = [(n, c_void_p) for n in (
         "qkv_w", "qkv_b", "o_w", "o_b", "ln1_g", "ln1_b", "ffn1_w", "ffn1_b", "ffn2_w", "ffn2_b",
@@ -99,6 +108,22 @@ _SIGNATURES = {
                                           c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, C.c_uint64,
                                           c_void_p, c_void_p, C.POINTER(OmEncoderGrads), c_void_p, c_size_t,
                                           c_void_p]),
+    "om_encoder_train_forward_hidden": (c_int, [C.POINTER(OmEncoderConfig), C.POINTER(OmEncoderWeights), c_void_p,
+                                                c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, C.c_uint64,
+                                                c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "om_encoder_train_backward_hidden": (c_int, [C.POINTER(OmEncoderConfig), C.POINTER(OmEncoderWeights), c_void_p,
+                                                 c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, C.c_uint64,
+                                                 c_void_p, c_void_p, C.POINTER(OmEncoderGrads), c_void_p, c_size_t,
+                                                 c_void_p]),
+    "om_t5_decoder_tape_bytes": (c_size_t, [C.POINTER(OmEncoderConfig), c_int, c_int64, c_int64]),
+    "om_t5_decoder_train_workspace_bytes": (c_size_t, [C.POINTER(OmEncoderConfig), c_int, c_int64, c_int64]),
+    "om_t5_decoder_train_forward": (c_int, [C.POINTER(OmEncoderConfig), C.POINTER(OmT5DecoderWeights), c_void_p, c_void_p,
+                                            c_int64, c_int64, c_float, C.c_uint64, c_void_p, c_size_t, c_void_p,
+                                            c_void_p, c_size_t, c_void_p]),
+    "om_t5_decoder_train_backward": (c_int, [C.POINTER(OmEncoderConfig), C.POINTER(OmT5DecoderWeights), c_void_p, c_void_p,
+                                             c_int64, c_int64, c_float, C.c_uint64, c_void_p, c_void_p,
+                                             C.POINTER(OmT5DecoderGrads), c_void_p, c_void_p, c_size_t, c_void_p]),
+    "om_linear_f32_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "om_index_to_f16": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "om_sim_topk_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "om_sim_topk": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int,

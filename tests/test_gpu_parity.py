@@ -968,11 +968,162 @@ def test_t5_encoder_decoder_pooling_and_monot5_match_hf(gated, dtype):
         want_s = torch.log_softmax(want_logits, dim=1)[:, 1]
         got_s = torch.log_softmax(got_logits, dim=1)[:, 1]
         assert (got_s - want_s).abs().max().item() < 3e-2 * max(1.0, want_logits.abs().max().item())      # bf16: relative to the logits' size
-    # training through the decoder step is refused with a message
-    dr_t = type(dr).__mro__[1](lm_q=lm, lm_p=lm, model_args=NS(encoder_only=False, dtype=dtype),
-                               data_args=NS(train_n_passages=1), train_args=NS(negatives_x_device=False)).to(DEV).train()
-    with pytest.raises(NotImplementedError, match="decoder"):
-        dr_t.encode_passage(items)
+
+
+@pytest.mark.parametrize("gated", [False, True])
+def test_t5_encoder_decoder_training_matches_hf_autograd(gated):
+    """Training through the decoder position (reference: autograd under DRModel.encode :137-141 and RRModel.encode
+    :110-114): f32 HIP path (om_encoder_train_*_hidden + om_t5_decoder_train_*) vs HF T5ForConditionalGeneration autograd
+    on the CPU, dropout 0 -- the representations / logits and EVERY parameter gradient: shared embedding (encoder tokens
+    + the decoder's start row [+ the tied LM-head rows]), both stacks' q/k/v/o, RMSNorm weights, feed-forward weights,
+    the encoder's relative-position table; the decoder's self-attention q / k and its position table take part in HF's
+    graph with a zero gradient (softmax over one key) and must come out as zeros, not None."""
+    import copy
+    from transformers import T5Config, T5ForConditionalGeneration
+    from openmatch.modeling import DRModel, LinearHead, RRModel
+    torch.manual_seed(77 + gated)
+    cfg = T5Config(d_model=128, d_ff=256, num_layers=2, num_decoder_layers=3, num_heads=2, d_kv=64, vocab_size=600,
+                   feed_forward_proj="gated-gelu" if gated else "relu", tie_word_embeddings=not gated,
+                   decoder_start_token_id=0, dropout_rate=0.0)
+    lm = T5ForConditionalGeneration(cfg)
+    with torch.no_grad():
+        for name, p in lm.named_parameters():
+            if "layer_norm" in name:
+                p.copy_(1.0 + 0.3 * torch.randn_like(p))
+            elif "relative_attention_bias" in name:
+                p.copy_(0.5 * torch.randn_like(p))
+    rng = np.random.default_rng(19)
+    ids, mask = synth_tokens(rng, 6, 80, vocab=600, lo_len=12, lo_id=300)
+    ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
+    items = {"input_ids": ids_t.to(DEV), "attention_mask": mask_t.to(DEV)}
+    head = LinearHead(128, 64)
+    R = torch.randn(6, 64, generator=torch.Generator().manual_seed(5))
+    R2 = torch.randn(6, 2, generator=torch.Generator().manual_seed(6))
+
+    def hf_state(ref):
+        enc = ref.encoder(input_ids=ids_t, attention_mask=mask_t).last_hidden_state
+        return ref.decoder(input_ids=torch.zeros(6, 1, dtype=torch.long), encoder_hidden_states=enc,
+                           encoder_attention_mask=mask_t).last_hidden_state[:, 0]
+
+    def compare(model_lm, ref, extra=()):
+        names = dict(model_lm.named_parameters())
+        checked = zeros = 0
+        seen = set()
+        for name, rp in ref.named_parameters():
+            if id(rp) in seen:
+                continue
+            seen.add(id(rp))
+            got = names[name].grad
+            if rp.grad is None:
+                assert got is None or float(got.abs().max()) == 0.0, name
+                continue
+            assert got is not None, name
+            got, want = got.float().cpu(), rp.grad
+            if float(want.abs().max()) == 0.0:
+                assert float(got.abs().max()) == 0.0, name
+                zeros += 1
+                continue
+            rel = ((got - want).norm() / (want.norm() + 1e-20)).item()
+            amax = (got - want).abs().max().item()
+            assert rel < 2e-3 or amax < 1e-7, (name, rel, amax)
+            checked += 1
+        for got, want, name in extra:
+            rel = ((got.float().cpu() - want).norm() / (want.norm() + 1e-20)).item()
+            assert rel < 2e-3, (name, rel)
+        return checked, zeros
+
+    # --- bi-encoder pooling through the decoder position, head + normalise
+    ref = copy.deepcopy(lm)
+    ref_head_w = head.linear.weight.detach().clone().requires_grad_()          # (LinearHead itself is HIP-only: plain matmul here)
+    want_reps = torch.nn.functional.normalize(hf_state(ref) @ ref_head_w.t(), dim=1)
+    (want_reps * R).sum().backward()
+    dr = DRModel(lm_q=lm, lm_p=lm, head_q=head, head_p=head, normalize=True, model_args=NS(encoder_only=False, dtype="float32"),
+                 data_args=NS(train_n_passages=1), train_args=NS(negatives_x_device=False)).to(DEV).train()
+    hidden, reps = dr.encode_passage(items)
+    assert hidden.shape == (6, 1, 128) and reps.requires_grad
+    assert (reps.detach().cpu() - want_reps.detach()).abs().max().item() < 1e-4
+    (reps * R.to(DEV)).sum().backward()
+    checked, zeros = compare(dr.lm_p, ref, extra=[(head.linear.weight.grad, ref_head_w.grad, "head")])
+    n_dec, n_enc = 3, 2
+    assert zeros == 2 * n_dec + 1, zeros                      # decoder self-attention q, k per block + its position table
+    assert checked >= 1 + n_enc * (8 if gated else 7) + 2 + n_dec * (11 if gated else 10) + 1, checked
+    # --- monoT5: two LM-head rows of the same state
+    for p_ in list(dr.lm_p.parameters()) + list(head.parameters()):
+        p_.grad = None
+    ref2 = copy.deepcopy(lm).cpu()
+    want_logits = ref2(input_ids=ids_t, attention_mask=mask_t, decoder_input_ids=torch.zeros(6, 1, dtype=torch.long),
+                       return_dict=True).logits[:, 0, [17, 23]]
+    (want_logits * R2).sum().backward()
+
+    class Tok:
+        def encode(self, t, add_special_tokens=False):
+            return [{"true": 23, "false": 17}[t]]
+    rr = RRModel(lm=dr.lm_p, head=LinearHead(128, 1), pos_token="true", neg_token="false", tokenizer=Tok(),
+                 model_args=NS(encoder_only=False, dtype="float32")).to(DEV).train()
+    logits = rr.encode(items)
+    assert logits.shape == (6, 2) and logits.requires_grad
+    assert (logits.detach().cpu() - want_logits.detach()).abs().max().item() < 1e-4 * max(1.0, want_logits.abs().max().item())
+    (logits * R2.to(DEV)).sum().backward()
+    checked2, zeros2 = compare(rr.lm, ref2)
+    assert zeros2 == 2 * n_dec + 1 and checked2 >= checked, (checked2, zeros2)
+
+
+def test_t5_encoder_decoder_training_bf16_and_dropout_are_sane():
+    """bf16 gradients through the decoder position track the f32 ones; with dropout_rate 0.1 the step stays finite, masks
+    change from call to call, eval() is deterministic, and a step along -grad lowers the (eval) loss."""
+    import copy
+    from transformers import T5Config, T5ForConditionalGeneration
+    from openmatch.modeling import DRModel
+    torch.manual_seed(123)
+    cfg = T5Config(d_model=128, d_ff=256, num_layers=2, num_decoder_layers=2, num_heads=2, d_kv=64, vocab_size=600,
+                   feed_forward_proj="gated-gelu", tie_word_embeddings=False, decoder_start_token_id=0, dropout_rate=0.0)
+    lm = T5ForConditionalGeneration(cfg)
+    rng = np.random.default_rng(23)
+    ids, mask = synth_tokens(rng, 8, 64, vocab=600, lo_len=10, lo_id=300)
+    items = {"input_ids": torch.from_numpy(ids).to(DEV), "attention_mask": torch.from_numpy(mask).to(DEV)}
+    R = torch.randn(8, 128, generator=torch.Generator().manual_seed(8)).to(DEV)
+
+    def grads(dtype):
+        m = copy.deepcopy(lm)
+        dr = DRModel(lm_q=m, lm_p=m, model_args=NS(encoder_only=False, dtype=dtype), data_args=NS(train_n_passages=1),
+                     train_args=NS(negatives_x_device=False)).to(DEV).train()
+        _h, reps = dr.encode_passage(items)
+        (reps * R).sum().backward()
+        return {n: p.grad.float().cpu() for n, p in m.named_parameters() if p.grad is not None}
+    g32, g16 = grads("float32"), grads("bfloat16")
+    for key in ("shared.weight", "encoder.block.1.layer.0.SelfAttention.o.weight", "decoder.block.0.layer.1.EncDecAttention.k.weight",
+                "decoder.block.1.layer.2.DenseReluDense.wi_1.weight", "decoder.block.0.layer.0.SelfAttention.v.weight",
+                "decoder.final_layer_norm.weight"):
+        a, b = g32[key].flatten().double(), g16[key].flatten().double()
+        cos = torch.dot(a, b) / (a.norm() * b.norm())
+        assert cos > 0.99, (key, cos.item())
+    m = copy.deepcopy(lm)
+    m.config.dropout_rate = 0.1
+    dr = DRModel(lm_q=m, lm_p=m, model_args=NS(encoder_only=False, dtype="float32"), data_args=NS(train_n_passages=1),
+                 train_args=NS(negatives_x_device=False)).to(DEV).train()
+    loss = lambda: (dr.encode_passage(items)[1] * R).sum()
+    l1, l2 = loss(), loss()
+    assert torch.isfinite(l1) and torch.isfinite(l2) and l1.item() != l2.item()
+    l1.backward()
+    params = [p_ for p_ in m.parameters() if p_.grad is not None]
+    assert all(torch.isfinite(p_.grad).all() for p_ in params)
+    dr.eval()
+    with torch.no_grad():
+        a, b = loss().item(), loss().item()
+        assert a == b
+    # the dropout-free gradient is a descent direction of the dropout-free loss
+    m.config.dropout_rate = 0.0
+    dr.train()
+    for p_ in params:
+        p_.grad = None
+    before = loss()
+    before.backward()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.grad is not None:
+                p_.add_(p_.grad, alpha=-0.02)
+        after = loss().item()
+    assert after < before.item(), (before.item(), after)
 
 
 @pytest.mark.parametrize("arch,L,dtype", [("bert", 384, "float32"), ("bert", 512, "float32"), ("bert", 512, "bfloat16"),

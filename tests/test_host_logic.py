@@ -355,3 +355,22 @@ def test_compute_format_resolution():
     assert inference_code(t5, N.OM_BF16, 128) == N.OM_BF16 and inference_code(bert, N.OM_F32, 512) == N.OM_F32
     assert training_code(N.OM_F16) == N.OM_BF16 and training_code(N.OM_F32) == N.OM_F32
     assert torch_dtype_of(N.OM_F16) == torch.float16 and torch_dtype_of(N.OM_BF16) == torch.bfloat16 and torch_dtype_of(N.OM_F32) == torch.float32
+
+
+def test_packed_weight_cache_survives_deepcopy_and_pickle():
+    """openmatch_amd/encoder.py keeps packed device weights (ctypes structs) in the module's __dict__: a deep copy or a
+    pickle of a model that has already run must not trip over them -- the copy starts with an empty cache."""
+    import copy, ctypes, pickle
+    import torch
+    from openmatch_amd.encoder import _PACK_CACHE_ATTR, _PackCache
+    m = torch.nn.Linear(2, 2)
+
+    class Holder(ctypes.Structure):
+        _fields_ = [("p", ctypes.c_void_p)]
+    cache = m.__dict__.setdefault(_PACK_CACHE_ATTR, _PackCache())
+    cache["k"] = ("v1", Holder())
+    m2 = copy.deepcopy(m)
+    assert isinstance(m2.__dict__[_PACK_CACHE_ATTR], _PackCache) and len(m2.__dict__[_PACK_CACHE_ATTR]) == 0
+    m3 = pickle.loads(pickle.dumps(m))
+    assert len(m3.__dict__[_PACK_CACHE_ATTR]) == 0 and torch.equal(m3.weight, m.weight)
+    assert len(cache) == 1
