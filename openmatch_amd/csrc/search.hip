@@ -136,53 +136,72 @@ __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel6(
 // scores per 32 x 32 block most blocks hold one: appending from inside the block walk (returning atomic on the list
 // counter -> wait -> store, per survivor, as generation 6 does) serialises ~7 L2 round trips per wave and tile
 // (profiles/r02_scan_trace_v0.log: 11.2k cycles of a 44.9k-cycle tile).  Instead the walk only STAGES survivors in
-// wave-private LDS -- position from the wave's ballot, no atomics -- and one flush per tile appends them with all lanes
-// in parallel: a single round trip.  Staging: keys in the wave's OWN DMA slices of units 2 and 3 (only this wave ever
-// writes them, and not before its next tile starts), 2048 of them; their query numbers in unit 4 behind the threshold
-// tables.  A block adds at most 1024 records, so one capacity check per block suffices.
+// wave-private LDS -- position from the wave's ballot, no atomics.  Staging: keys in the wave's OWN DMA slices of units 2
+// and 3 (only this wave ever writes them, and not before its next tile starts), 2048 of them; their query numbers in
+// unit 4 behind the threshold tables.  A block adds at most 1024 records, so one capacity check per block suffices.
+//
+// Round 3 (the tile trace had 12k of a tile's 40k cycles outside the K loop, and the four waves meet at the next tile's
+// first barrier, so the slowest filter sets the pace):
+//  * two-level walk: the block test keeps the maxima of its four register quads; a block with a survivor tests the
+//    quads and walks only the (one, almost always) quad that holds it -- ~8 ballot + branch steps instead of 16;
+//  * the append is split around the NEXT tile's K loop: at the end of a tile's filter its (<= 64, one per lane)
+//    records move from the staging area into registers; after the next K loop the list-counter atomics are issued,
+//    their return is consumed half a filter later and the key stores leave half a filter before the tile start that
+//    would otherwise wait for their acknowledgement (vmcnt retires in order).  Neither round trip is exposed.  More
+//    than 64 records in a tile, or a full staging area, take the synchronous flush (rare);
+//  * the tile walk advances incrementally (no division per tile), and the DMA lane offsets are computed once: the
+//    query panel is padded with zero rows to a whole tile (query_prep_kernel), so no tile needs clamped rows.
 #define SC7_STAGE_CAP 2048
 #define SC7_QIDX_OFF (G7_TAB_OFF + 4096)
 __device__ __forceinline__ char* sc7_key_slot(char* smem, int wave, unsigned pos) {
   return smem + (2 + (pos >> 10)) * G7_UNIT_BYTES + wave * 1024 + ((pos >> 7) & 7) * 4096 + (pos & 127) * 8;
 }
-__device__ __forceinline__ void sc7_flush(char* smem, int wave, unsigned& wcount, int lane, int64_t q0,
+__device__ __forceinline__ uint16_t* sc7_q_slot(char* smem, int wave, unsigned pos) {
+  return (uint16_t*)(smem + SC7_QIDX_OFF + wave * (SC7_STAGE_CAP * 2) + pos * 2);
+}
+// synchronous append of staged records [from, wcount): one atomic round trip, then the stores
+__device__ __forceinline__ void sc7_flush(char* smem, int wave, unsigned from, unsigned wcount, int lane, int64_t q0,
                                           u64* __restrict__ keys, unsigned* __restrict__ cnt) {
-  for (unsigned i = (unsigned)lane; i < wcount; i += 64) {
+  for (unsigned i = from + (unsigned)lane; i < wcount; i += 64) {
     const u64 key = *(const u64*)sc7_key_slot(smem, wave, i);
-    const int64_t q = q0 + *(const uint16_t*)(smem + SC7_QIDX_OFF + wave * (SC7_STAGE_CAP * 2) + i * 2);
+    const int64_t q = q0 + *sc7_q_slot(smem, wave, i);
     const unsigned pos = atomicAdd(cnt + q, 1u);
     if (pos < SORT_CAP) keys[q * SORT_CAP + pos] = key;
   }
-  wcount = 0;
 }
-// whole tiles only: every row of the tile exists
+// query blocks MI0 .. MI1-1 of the wave's 128 x 128 scores; whole tiles only: every row of the tile exists
+template <int MI0, int MI1>
 __device__ __forceinline__ void sc7_filter(f32x16_t (&acc)[4][4], const float (&th)[4], uint32_t id0, uint32_t ql0,
                                            int lane, char* smem, int wave, unsigned& wcount, int64_t q0,
                                            u64* __restrict__ keys, unsigned* __restrict__ cnt) {
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
+  for (int mi = MI0; mi < MI1; ++mi) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       asm volatile("" : "+a"(acc[mi][ni]));            // stays in its AGPRs until this point
       const f32x16_t a = acc[mi][ni];
-      float mx = fmaxf(fmaxf(a[0], a[1]), a[2]);
+      float gm[4];
 #pragma unroll
-      for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, a[r]), a[r + 1]);
-      mx = fmaxf(mx, a[15]);
+      for (int g = 0; g < 4; ++g) gm[g] = fmaxf(fmaxf(fmaxf(a[4 * g], a[4 * g + 1]), a[4 * g + 2]), a[4 * g + 3]);
+      const float mx = fmaxf(fmaxf(fmaxf(gm[0], gm[1]), gm[2]), gm[3]);
       if (__builtin_amdgcn_ballot_w64(mx >= th[mi]) != 0) {          // wave-uniform: some lane holds a survivor
-        if (wcount > SC7_STAGE_CAP - 1024) sc7_flush(smem, wave, wcount, lane, q0, keys, cnt);
+        if (wcount > SC7_STAGE_CAP - 1024) { sc7_flush(smem, wave, 0u, wcount, lane, q0, keys, cnt); wcount = 0; }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const uint32_t off = (uint32_t)(ni * 32 + (r & 3) + 8 * (r >> 2));
-          const bool pass = a[r] >= th[mi];
-          const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-          if (m != 0) {
-            if (pass) {
-              const unsigned pos = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-              *(u64*)sc7_key_slot(smem, wave, pos) = pack_key(a[r], id0 + off);
-              *(uint16_t*)(smem + SC7_QIDX_OFF + wave * (SC7_STAGE_CAP * 2) + pos * 2) = (uint16_t)(ql0 + mi * 32);
+        for (int g = 0; g < 4; ++g) {
+          if (__builtin_amdgcn_ballot_w64(gm[g] >= th[mi]) == 0) continue;
+#pragma unroll
+          for (int r = 4 * g; r < 4 * g + 4; ++r) {
+            const uint32_t off = (uint32_t)(ni * 32 + (r & 3) + 8 * (r >> 2));
+            const bool pass = a[r] >= th[mi];
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+            if (m != 0) {
+              if (pass) {
+                const unsigned pos = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                *(u64*)sc7_key_slot(smem, wave, pos) = pack_key(a[r], id0 + off);
+                *sc7_q_slot(smem, wave, pos) = (uint16_t)(ql0 + mi * 32);
+              }
+              wcount += (unsigned)__builtin_popcountll(m);
             }
-            wcount += (unsigned)__builtin_popcountll(m);
           }
         }
       }
@@ -198,29 +217,49 @@ __device__ __forceinline__ void sc7_filter(f32x16_t (&acc)[4][4], const float (&
 // close to what the memory system delivers at all.  Here every XCD OWNS a group of at most 8 query tiles (<= 3 MiB of
 // query panels, resident in its 4 MiB L2 for the whole launch) and a share of the row tiles, and walks its rows with
 // the query tile running fastest: a row panel is fetched once per query GROUP instead of once per 4 query tiles.
-__device__ __forceinline__ bool sc7_tile(int it, int64_t ntr, int64_t ntq, int group_m, int qgroup, int64_t& r0, int64_t& q0) {
-  if ((gridDim.x & 7) != 0 || ntq > 8 * qgroup) return g7_tile(it, ntr, ntq, group_m, r0, q0);
-  const uint32_t x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-  const uint32_t tq = (uint32_t)ntq, tr = (uint32_t)ntr;
-  uint32_t ng = 1;                                        // query groups: 1, 2, 4 or 8 -- at most 8 query tiles each
-  while (ng < 8 && (tq + ng - 1) / ng > (uint32_t)qgroup) ng <<= 1;
-  const uint32_t g = x % ng, part = x / ng, nparts = 8 / ng;
-  const uint32_t q_lo = g * tq / ng, qn = (g + 1) * tq / ng - q_lo;
-  const uint32_t r_lo = (uint32_t)((uint64_t)part * tr / nparts), rn = (uint32_t)((uint64_t)(part + 1) * tr / nparts) - r_lo;
-  const uint64_t w = (uint64_t)it * nslots + slot;
-  if (qn == 0 || w >= (uint64_t)rn * qn) return false;
-  const uint32_t row = (uint32_t)(w / qn);
-  r0 = (int64_t)(r_lo + row) * 256;
-  q0 = (int64_t)(q_lo + (uint32_t)(w - (uint64_t)row * qn)) * 256;
-  return true;
-}
+// The walk is an iterator: work item w = it * nslots + slot of the XCD's (row, query tile) grid, advanced by nslots per
+// tile with one compare instead of a division.
+struct Sc7Walk {
+  bool owned;                      // XCD-owned query groups (else the GEMM's walk, by index)
+  int it;
+  int64_t ntr, ntq; int group_m;
+  uint32_t q_lo, qn, r_lo, rn, row, qi, d_row, d_qi;
+  __device__ __forceinline__ bool init(int64_t ntr_, int64_t ntq_, int group_m_, int qgroup, int64_t& r0, int64_t& q0) {
+    ntr = ntr_; ntq = ntq_; group_m = group_m_; it = 0;
+    owned = (gridDim.x & 7) == 0 && ntq <= 8 * qgroup;
+    if (!owned) return g7_tile(0, ntr, ntq, group_m, r0, q0);
+    const uint32_t x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const uint32_t tq = (uint32_t)ntq, tr = (uint32_t)ntr;
+    uint32_t ng = 1;                                        // query groups: 1, 2, 4 or 8 -- at most 8 query tiles each
+    while (ng < 8 && (tq + ng - 1) / ng > (uint32_t)qgroup) ng <<= 1;
+    const uint32_t g = x % ng, part = x / ng, nparts = 8 / ng;
+    q_lo = g * tq / ng; qn = (g + 1) * tq / ng - q_lo;
+    r_lo = (uint32_t)((uint64_t)part * tr / nparts); rn = (uint32_t)((uint64_t)(part + 1) * tr / nparts) - r_lo;
+    if (qn == 0) return false;
+    row = slot / qn; qi = slot - row * qn;
+    d_row = nslots / qn; d_qi = nslots - d_row * qn;
+    if (row >= rn) return false;
+    r0 = (int64_t)(r_lo + row) * 256; q0 = (int64_t)(q_lo + qi) * 256;
+    return true;
+  }
+  __device__ __forceinline__ bool next(int64_t& r0, int64_t& q0) {
+    ++it;
+    if (!owned) return g7_tile(it, ntr, ntq, group_m, r0, q0);
+    qi += d_qi; row += d_row;
+    if (qi >= qn) { qi -= qn; ++row; }
+    if (row >= rn) return false;
+    r0 = (int64_t)(r_lo + row) * 256; q0 = (int64_t)(q_lo + qi) * 256;
+    return true;
+  }
+};
 
 // The same scan on generation 7 (gemm_core7.h / gemm_wide7.h): 128-byte K steps (whole-line LDS-DMA requests) in a
 // PERSISTENT kernel -- one workgroup per CU walks (query tile, row tile) pairs, the first K step of the next pair and its
-// 256 thresholds are fetched while the current pair is filtered.  The filter issues no regular stores (appends are rare
-// by construction of theta), so the only wait at a tile start is vmcnt(16): K step 1 may be outstanding, everything
-// older -- the prefetch, and an occasional append -- has landed.  16-bit inputs only (the f32 scan stays on generation 6).
-// `thr` must be readable up to round_up(nq, 256) + 256 entries (+inf beyond nq: carve_search / init_lists_kernel).
+// 256 thresholds are fetched while the current pair is filtered.  The only wait at a tile start is vmcnt(16): K step 1
+// may be outstanding, everything older -- the prefetch, and the appends of the tile before, issued half a filter
+// earlier -- has landed.  16-bit inputs only (the f32 scan stays on generation 6).
+// `thr` must be readable up to round_up(nq, 256) + 256 entries (+inf beyond nq: carve_search / init_lists_kernel);
+// `queries` holds round_up(nq, 256) rows, zeros beyond nq (query_prep_kernel).
 template <typename T>
 __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7(
     const T* __restrict__ rows, int64_t nrows, uint32_t row_base, const T* __restrict__ queries,
@@ -233,14 +272,18 @@ __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7(
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t ntr = (nrows + 255) / 256, ntq = (nq + 255) / 256;
   const int nk = (int)((d * 2) / G7_ROW_BYTES);
-  int it = 0;
   unsigned wcount = 0;                     // records in this wave's staging area (wave-uniform)
+  unsigned pend_n = 0;                     // records of the previous tile held in registers, one per lane (wave-uniform)
+  u64 pend_key = 0; uint32_t pend_q = 0;
   int64_t r0, q0;
   const int qgroup = group_m >> 8;                 // (the host packs both walk parameters into one argument)
   group_m &= 255;
-  if (!sc7_tile(0, ntr, ntq, group_m, qgroup, r0, q0)) return;
+  Sc7Walk walk;
+  if (!walk.init(ntr, ntq, group_m, qgroup, r0, q0)) return;
   G7Src src;
-  g7_point<T>(src, queries, d, rows, d, nq, nrows, q0, r0, wave, lane0);
+  g7_offsets<T>(src, d, d, wave, lane0);           // every row of every tile exists (padded query panel, whole row tiles)
+  src.a = (const char*)(queries + q0 * d);
+  src.b = (const char*)(rows + r0 * d);
   g7_dma((const char*)(thr + q0 + wm * 128), lane0 * 16, g7_lds_addr(smem + G7_TAB_OFF + wave * 1024));
   g7_fill(src.a, src.oa, smem, wave);
   g7_fill(src.b, src.ob, smem + G7_UNIT_BYTES, wave);
@@ -274,27 +317,44 @@ __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7(
     }
     gemm_mainloop7_run<T>(src, nk, smem, acc, tr, false);
     if (tr && threadIdx.x == 0) tr[15] = clock64();
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    // the previous tile's records: list positions requested now, consumed half a filter later
+    unsigned pend_pos = 0;
+    if (pend_n && (unsigned)lane < pend_n) pend_pos = atomicAdd(cnt + pend_q, 1u);
     // next pair: its first K step and its thresholds are fetched under the filter below
-    ++it;
-    int64_t r1 = r0, q1 = q0;
-    const bool has_next = sc7_tile(it, ntr, ntq, group_m, qgroup, r1, q1);
-    G7Src nsrc;
-    g7_point<T>(nsrc, queries, d, rows, d, nq, nrows, q1, r1, wave, lane0);
-    g7_dma((const char*)(thr + q1 + wm * 128), lane0 * 16, g7_lds_addr(smem + G7_TAB_OFF + wave * 1024));
-    g7_fill(nsrc.a, nsrc.oa, smem, wave);
-    g7_fill(nsrc.b, nsrc.ob, smem + G7_UNIT_BYTES, wave);
+    const int64_t rc = r0, qc = q0;
+    const bool has_next = walk.next(r0, q0);       // (r0, q0 unchanged when there is none: a harmless re-fetch)
+    src.a = (const char*)(queries + q0 * d);
+    src.b = (const char*)(rows + r0 * d);
+    g7_dma((const char*)(thr + q0 + wm * 128), lane0 * 16, g7_lds_addr(smem + G7_TAB_OFF + wave * 1024));
+    g7_fill(src.a, src.oa, smem, wave);
+    g7_fill(src.b, src.ob, smem + G7_UNIT_BYTES, wave);
     G7_FENCE_();
     {
-      int lane = lane0;
-      asm volatile("" : "+v"(lane));
-      const uint32_t id0 = row_base + (uint32_t)r0 + (uint32_t)(wn * 128 + 4 * (lane >> 5));    // row id of (ni = 0, r = 0)
+      const uint32_t id0 = row_base + (uint32_t)rc + (uint32_t)(wn * 128 + 4 * (lane >> 5));    // row id of (ni = 0, r = 0)
       const uint32_t ql0 = (uint32_t)(wm * 128 + (lane & 31));
-      sc7_filter(acc, th, id0, ql0, lane, smem, wave, wcount, q0, keys, cnt);
-      if (wcount) sc7_flush(smem, wave, wcount, lane, q0, keys, cnt);
+      sc7_filter<0, 2>(acc, th, id0, ql0, lane, smem, wave, wcount, qc, keys, cnt);
+      if (pend_n) {
+        if ((unsigned)lane < pend_n && pend_pos < SORT_CAP) keys[(int64_t)pend_q * SORT_CAP + pend_pos] = pend_key;
+        pend_n = 0;
+      }
+      G7_FENCE_();
+      sc7_filter<2, 4>(acc, th, id0, ql0, lane, smem, wave, wcount, qc, keys, cnt);
+      if (wcount > 64) sc7_flush(smem, wave, 64u, wcount, lane, qc, keys, cnt);
+      pend_n = wcount < 64u ? wcount : 64u;
+      if ((unsigned)lane < pend_n) {
+        pend_key = *(const u64*)sc7_key_slot(smem, wave, (unsigned)lane);
+        pend_q = (uint32_t)qc + *sc7_q_slot(smem, wave, (unsigned)lane);
+      }
+      wcount = 0;
     }
     if (tr && threadIdx.x == 0) { tr[28] = clock64(); tr[29] = blockIdx.x; tr[31] = wall_clock64(); }
     if (!has_next) break;
-    src = nsrc; r0 = r1; q0 = q1;
+  }
+  if (pend_n && (unsigned)lane0 < pend_n) {
+    const unsigned pos = atomicAdd(cnt + pend_q, 1u);
+    if (pos < SORT_CAP) keys[(int64_t)pend_q * SORT_CAP + pos] = pend_key;
   }
   G7_WAIT_VM(0);
 }
@@ -658,7 +718,11 @@ __global__ __launch_bounds__(256) void query_prep_kernel(const float* __restrict
                                                          int64_t nq, int d) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= nq) return;
+  if (row >= nq) {            // padding of the query panel up to a whole 256-query tile: zero rows (the generation-7 scan reads them)
+    if (row < (nq + 255) / 256 * 256)
+      for (int c = lane; c < d; c += 64) qb[row * d + c] = (f16_t)0.f;
+    return;
+  }
   float n2 = 0.f, e2 = 0.f, b2 = 0.f;
   for (int c = lane; c < d; c += 64) {
     const float v = q[row * d + c];
@@ -797,7 +861,7 @@ static SearchWs carve_search(int64_t nq, int d, char* base) {
   w.thr = (float*)take(((size_t)(nq + 255) / 256 * 256 + 256) * 4);      // +inf beyond nq: the generation-7 scan reads whole tiles of thresholds
   w.margin = (float*)take((size_t)nq * 4);
   w.dense = (float*)take((size_t)nq * DENSE_CHUNK * 4);
-  w.qb = (f16_t*)take((size_t)nq * d * 2);
+  w.qb = (f16_t*)take((size_t)((nq + 255) / 256 * 256) * d * 2);            // whole query tiles, zero rows beyond nq
   w.total = off;
   return w;
 }
@@ -934,7 +998,7 @@ struct Scan {
                        ws.cnt, ws.cnt_prev, ws.thr, nq, ws.flag);
     OM_LAUNCH_CHECK();
     if (bf16) {
-      hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, q32,
+      hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)(((nq + 255) / 256 * 256 + 3) / 4)), dim3(256), 0, s, q32,
                          ws.qb, ws.margin, stats, nq, d);
       OM_LAUNCH_CHECK();
     }
