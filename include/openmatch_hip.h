@@ -101,7 +101,10 @@ void om_debug_gemm_gen(int gen);
                                    * 1e-5 instead of 4.8e-5 for +2 bytes per element at the two residual sites of a layer; 0: one plane */
 #define OM_OPT_GEMM_VARIANT 12     /* 0 (default): automatic tile-generation choice; 1 | 2 | 6 pin a generation (A/B measurements) */
 #define OM_OPT_SEARCH_DEBUG 13     /* 1: om_sim_topk logs every round (rows done, chunk, list lengths) to stderr */
-#define OM_OPT_COUNT 14
+#define OM_OPT_TRAIN_WGRAD_BATCH 14 /* layers per deferred weight-gradient launch of the bf16 BERT backward (default 4; 0: one launch per
+                                     * weight gradient as in round 2): the backward keeps every layer's dY and one om_gemm_tn_acc_batch
+                                     * launch per group of layers computes their weight gradients (env OM_TRAIN_WGRAD_BATCH) */
+#define OM_OPT_COUNT 15
 int om_debug_option(int opt, int value);
 /* the attention kernel alone (bf16 qkv [B*L, 3H] -> ctx [B*L, H]; mask [B, L] int64), for timing: csrc/kernels.h omk_attention */
 int om_debug_attention(const void* qkv, void* ctx, const int64_t* mask, int64_t B, int L, int H, int heads, void* stream);
@@ -130,6 +133,19 @@ int om_gemm_nt(int in_dtype, const void* A, int64_t lda, const void* B, int64_t 
  * ------------------------------------------------------------------------ */
 int om_gemm_tn_acc(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb,
                    float* C, int64_t ldc, float* bias, int64_t M, int64_t N, int64_t K, void* stream);
+
+/* The same contraction for MANY (A, B, C, bias) quadruples over one token count M in ONE launch (round 3): what the
+ * training backward uses for the weight gradients of a whole group of layers -- autograd's dW = dY^T X of every nn.Linear,
+ * deferred to the end of the group (modeling/dense_retrieval_model.py:89-131 + loss.backward()).  256 x 256 output tiles
+ * over the whole token axis, no split and no atomics: every C / bias element is read, added to and written by exactly one
+ * workgroup, so C and bias must not be touched by anything else while the launch runs.  Requires N % 256 == 0,
+ * K % 256 == 0, M >= 32 (tokens past the last multiple of 32 go through the om_gemm_tn_acc kernels on the same stream),
+ * lda / ldb multiples of 8, 16-byte aligned operands; bias may be NULL. */
+typedef struct OmTnProblem {
+  const void* A; const void* B; float* C; float* bias;   /* dY [M,N], X [M,K] (bf16), dW [N,K], db [N] (f32, accumulated) */
+  int64_t lda, ldb, ldc, N, K;
+} OmTnProblem;
+int om_gemm_tn_acc_batch(int in_dtype, const OmTnProblem* problems, int n, int64_t M, void* stream);
 
 /* ------------------------------------------------------------------------
  * Encoder forward:  ids -> hidden [B,L,H] -> pooled/head/normalised reps [B,D]

@@ -17,6 +17,8 @@
 // 64-token steps brought in by LDS-DMA, the default) and `gemm_tn_kernel` (register-staged, zero-fills: ragged tails and
 // short token axes).  The bias column sums are taken from the A fragments themselves (eight tokens of one column per
 // lane) by the vector ALU under the MFMAs, in the waves that own k columns 0..63 of k tile 0.
+#include <string.h>
+
 #include <atomic>
 
 #include "gemm_core7.h"
@@ -286,6 +288,162 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_dma_kernel(
     }
   }
 }
+
+// ---- many contractions in one launch, 256 x 256 tiles over the WHOLE token axis (round 3) ---------------------------------
+// The kernels above split the token axis so that one contraction fills the chip: at the training batch (9 216 tokens) that
+// is ~36 steps of 64 tokens per workgroup and 16 384 memory-side atomics to flush each 128 x 128 tile -- 290-590 TFLOP/s, and
+// the atomics alone ~0.7 ms of a training step (profiles/r02_gemm_tn_variants.log, r02_train_kernel_stats_v8.csv).  The
+// backward does not need a layer's dW before its end, so it now KEEPS the dY of every site (train.hip) and hands the
+// weight gradients of a whole group of layers to one launch: 108 tiles of 256 x 256 per bert-base layer, each over all
+// the tokens -- no split, no atomics (a tile has one owner: C is read, added to and written back with plain accesses), the
+// epilogue amortised over 288 steps, and enough tiles to fill the chip.
+//   workgroup   256 (n) x 256 (k) outputs, four waves of 128 x 128 (256 accumulators per lane), one per CU
+//   step        32 tokens: per operand eight 32-column fragments x two 16-token k steps = sixteen 1 KiB regions in the
+//               transposing-read layout of gemm_tn_dma_kernel; stage = 32 KiB (A | B), FOUR stages (128 KiB)
+//   pipeline    steps t+1, t+2 in flight while step t is computed; ONE barrier per step, in its middle: there every wave
+//               has its part of step t+1 in LDS (vmcnt counted by hand) and has left step t-1, so step t+3 is issued into
+//               that stage and the fragments of step t+1 are read under the second half's MFMAs
+//   LDS port    per step 64 KiB of fragment reads + 32 KiB of DMA writes per 1024 MFMA cycles = 75 % (128 x 128 tiles: 150 %)
+//   XCD         workgroup b runs on XCD b % 8: tile = (b % 8) * chunk + b / 8 -- each XCD walks a CONTIGUOUS run of
+//               tiles, whose A (dY) panel is shared by the tiles of one row and stays in that L2
+constexpr int TW_TOK = 32;
+constexpr int TW_STAGE = 32768;
+constexpr int TW_STAGES = 4;
+constexpr int TW_MAXP = 48;
+struct TwProblem { const bf16_t* A; const bf16_t* B; float* C; float* bias; int lda, ldb, ldc, ntk; };
+struct TwBatch { int n, chunk, total, steps; int tile_start[TW_MAXP + 1]; TwProblem p[TW_MAXP]; };
+
+#define TW_WAIT(K_)                                                                                    \
+  do {                                                                                                 \
+    if ((K_) >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                                   \
+    else if ((K_) == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                               \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                              \
+  } while (0)
+
+__global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_wide_kernel(const TwBatch bt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  int lane = tid & 63;
+  asm volatile("" : "+v"(lane));
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int tile = (int)(blockIdx.x & 7) * bt.chunk + (int)(blockIdx.x >> 3);
+  if (tile >= bt.total) return;
+  int pi = 0;
+  while (pi + 1 < bt.n && tile >= bt.tile_start[pi + 1]) ++pi;              // wave-uniform
+  const bf16_t* const A = bt.p[pi].A;
+  const bf16_t* const B = bt.p[pi].B;
+  float* const C = bt.p[pi].C;
+  float* const bias = bt.p[pi].bias;
+  const int lda = bt.p[pi].lda, ldb = bt.p[pi].ldb, ldc = bt.p[pi].ldc, ntk = bt.p[pi].ntk;
+  const int tl = tile - bt.tile_start[pi];
+  const int n0 = (tl / ntk) * 256, k0 = (tl % ntk) * 256;
+  const int nsteps = bt.steps;
+  const bool do_bias = bias != nullptr && k0 == 0 && wk == 0;
+
+  // DMA: this wave fills the regions (fragment f = (wave >> 1) * 4 + i, k step ks = wave & 1), i = 0..3, of each operand;
+  // lane -> (token, columns) exactly as in gemm_tn_dma_kernel
+  const int dr = lane >> 5, dg = (lane >> 3) & 3, dtl = (lane >> 1) & 3, dh = lane & 1;
+  const int drow = (wave & 1) * 16 + (dg >> 1) * 8 + dr * 4 + dtl;
+  const uint32_t a_off = (uint32_t)((drow * lda + (dg & 1) * 16 + dh * 8) * 2);
+  const uint32_t b_off = (uint32_t)((drow * ldb + (dg & 1) * 16 + dh * 8) * 2);
+  const char* a_at = (const char*)(A + n0 + (wave >> 1) * 128);            // wave-uniform, advanced per step issued
+  const char* b_at = (const char*)(B + k0 + (wave >> 1) * 128);
+  const size_t a_step = (size_t)TW_TOK * lda * 2, b_step = (size_t)TW_TOK * ldb * 2;
+  const uint32_t lds0 = g7_lds_addr(smem);
+  const uint32_t dreg = (uint32_t)((((wave >> 1) * 4) * 2 + (wave & 1)) * 1024);   // region (f, ks) at (f * 2 + ks) KiB
+#define TW_ISSUE(STAGE)                                                                                \
+  do {                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+      g7_dma(a_at + i * 64, a_off, lds0 + (STAGE) * TW_STAGE + dreg + i * 2048);                       \
+      g7_dma(b_at + i * 64, b_off, lds0 + (STAGE) * TW_STAGE + 16384 + dreg + i * 2048);               \
+    }                                                                                                  \
+    a_at += a_step; b_at += b_step;                                                                    \
+  } while (0)
+
+  f32x16_t acc[4][4];
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto frag2 = [](v4s a, v4s b) { return (bf16x8_t){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; };
+  // fragments of k step KS of the stage at ST: A fragments wn * 4 + i, B fragments wk * 4 + i
+#define TW_READ(FA, FB, ST, KS)                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
+    const char* pa_ = (ST) + ((wn * 4 + i) * 2 + (KS)) * 1024 + lane * 8;                              \
+    const char* pb_ = (ST) + 16384 + ((wk * 4 + i) * 2 + (KS)) * 1024 + lane * 8;                      \
+    FA[i] = frag2(tn_read(pa_), tn_read(pa_ + 512));                                                   \
+    FB[i] = frag2(tn_read(pb_), tn_read(pb_ + 512));                                                   \
+  }
+#define TW_MMA(FA, FB)                                                                                 \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) MmaOps<bf16_t>::mma(FA[i], FB[j], acc[i][j]);        \
+    if (do_bias) {      /* the fragment holds 8 tokens of column (lane & 31): add them up under the MFMAs */ \
+      const uint4 w = __builtin_bit_cast(uint4, FA[i]);                                                \
+      bsum[i] += (__uint_as_float(w.x << 16) + __uint_as_float(w.x & 0xffff0000u)) + (__uint_as_float(w.y << 16) + __uint_as_float(w.y & 0xffff0000u)) + \
+                 (__uint_as_float(w.z << 16) + __uint_as_float(w.z & 0xffff0000u)) + (__uint_as_float(w.w << 16) + __uint_as_float(w.w & 0xffff0000u)); \
+    }                                                                                                  \
+  }
+
+  const int pre = nsteps < 3 ? nsteps : 3;
+  for (int sidx = 0; sidx < pre; ++sidx) TW_ISSUE(sidx);
+  TW_WAIT(pre - 1);                                   // step 0 has landed; steps 1, 2 may be in flight
+  __syncthreads();
+  bf16x8_t fa0[4], fb0[4], fa1[4], fb1[4];
+  TW_READ(fa0, fb0, smem, 0)
+  for (int t = 0; t < nsteps; ++t) {
+    const char* st = smem + (t & 3) * TW_STAGE;
+    __builtin_amdgcn_sched_barrier(0);
+    TW_READ(fa1, fb1, st, 1)
+    TW_MMA(fa0, fb0)
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < nsteps) {
+      TW_WAIT(t + 2 < nsteps ? 1 : 0);                // this wave's part of step t + 1 is in LDS (step t + 2 may be in flight)
+      __syncthreads();                                // ... everyone's; and every wave has left step t - 1
+      if (t + 3 < nsteps) TW_ISSUE((t + 3) & 3);
+      const char* sn = smem + ((t + 1) & 3) * TW_STAGE;
+      TW_READ(fa0, fb0, sn, 0)
+    }
+    TW_MMA(fa1, fb1)
+  }
+#undef TW_READ
+#undef TW_MMA
+#undef TW_ISSUE
+
+  // acc[i][j][r]: n = n0 + wn*128 + i*32 + 8*(r>>2) + 4*(lane>>5) + (r&3),  k = k0 + wk*128 + j*32 + (lane & 31): the tile
+  // has one owner -- plain read-add-write, 128-byte rows per half-wave
+  const int kcol = k0 + wk * 128 + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int nbase = n0 + wn * 128 + i * 32 + 4 * (lane >> 5);
+    // eight rows at a time: all 32 loads of the batch are issued before its first store (C may alias itself as far as
+    // the compiler knows: one read-add-write per element would wait for every load's round trip in turn)
+#pragma unroll
+    for (int rb = 0; rb < 16; rb += 8) {
+      float cv[8][4];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float* crow = C + (int64_t)(nbase + 8 * ((rb + r) >> 2) + ((rb + r) & 3)) * ldc + kcol;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cv[r][j] = crow[j * 32];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float* crow = C + (int64_t)(nbase + 8 * ((rb + r) >> 2) + ((rb + r) & 3)) * ldc + kcol;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) crow[j * 32] = cv[r][j] + acc[i][j][rb + r];
+      }
+    }
+    if (do_bias) {                          // lanes l and l + 32 hold the two token halves of column (l & 31)
+      const float tsum = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+      if (lane < 32) bias[n0 + wn * 128 + i * 32 + lane] += tsum;
+    }
+  }
+}
 }  // namespace
 
 bool omk_gemm_tn_ok(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {
@@ -349,4 +507,67 @@ extern "C" int om_gemm_tn_acc(int in_dtype, const void* A, int64_t lda, const vo
   if (!A || !B || !C) OM_FAIL("null argument");
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   return omk_gemm_tn(in_dtype, A, lda, B, ldb, C, ldc, bias, M, N, K, (hipStream_t)stream);
+}
+
+// ---- batched launch ----------------------------------------------------------------------------------------------------------
+bool omk_gemm_tn_batch_ok(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {
+  return dtype == OM_BF16 && M >= TW_TOK && N % 256 == 0 && K % 256 == 0 && lda % 8 == 0 && ldb % 8 == 0 && N <= (1 << 20) &&
+         K <= (1 << 20) && (int64_t)TW_TOK * lda * 2 < (1ll << 31) && (int64_t)TW_TOK * ldb * 2 < (1ll << 31);
+}
+
+int omk_gemm_tn_batch(int dtype, const OmTnProblem* probs, int n, int64_t M, hipStream_t s) {
+  if (n <= 0 || M <= 0) return 0;
+  if (!probs) OM_FAIL("gemm_tn_batch: null problem list");
+  for (int i = 0; i < n; ++i) {
+    const OmTnProblem& q = probs[i];
+    if (!q.A || !q.B || !q.C) OM_FAIL("gemm_tn_batch: null operand");
+    if (!omk_gemm_tn_batch_ok(dtype, M, q.N, q.K, q.lda, q.ldb) || q.ldc > 0x7fffffffLL)
+      OM_FAIL("gemm_tn_batch: bf16 operands with N and K multiples of 256 and at least 32 tokens only");
+    if (((uintptr_t)q.A & 15) || ((uintptr_t)q.B & 15)) OM_FAIL("gemm_tn_batch: operands must be 16-byte aligned");
+  }
+  static std::atomic<bool> attr{false};
+  if (!attr) {
+    OM_HIP(hipFuncSetAttribute((const void*)gemm_tn_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TW_STAGES * TW_STAGE));
+    attr = true;
+  }
+  const bool timing = om_timing_on();
+  const int64_t whole = M / TW_TOK;
+  for (int first = 0; first < n; first += TW_MAXP) {
+    const int cnt = n - first < TW_MAXP ? n - first : TW_MAXP;
+    TwBatch bt;
+    memset(&bt, 0, sizeof(bt));
+    bt.n = cnt; bt.steps = (int)whole;
+    int64_t total = 0;
+    double flops = 0.0;
+    for (int i = 0; i < cnt; ++i) {
+      const OmTnProblem& q = probs[first + i];
+      bt.tile_start[i] = (int)total;
+      bt.p[i].A = (const bf16_t*)q.A; bt.p[i].B = (const bf16_t*)q.B; bt.p[i].C = q.C; bt.p[i].bias = q.bias;
+      bt.p[i].lda = (int)q.lda; bt.p[i].ldb = (int)q.ldb; bt.p[i].ldc = (int)q.ldc; bt.p[i].ntk = (int)(q.K / 256);
+      total += (q.N / 256) * (q.K / 256);
+      flops += 2.0 * (double)M * (double)q.N * (double)q.K;
+      if (total > 0x3fffffffLL) OM_FAIL("gemm_tn_batch: too many tiles");
+    }
+    bt.tile_start[cnt] = (int)total;
+    bt.total = (int)total;
+    bt.chunk = (int)((total + 7) / 8);
+    if (timing) om_timing_begin(OM_TIMING_GEMM_BF16, s);
+    hipLaunchKernelGGL(gemm_tn_wide_kernel, dim3((unsigned)(bt.chunk * 8)), dim3(TN_THREADS), TW_STAGES * TW_STAGE, s, bt);
+    OM_LAUNCH_CHECK();
+    if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, flops * (double)(whole * TW_TOK) / (double)M);
+  }
+  // tokens past the last whole 32-token step: the split kernels above (atomics; ordered behind the launch on the stream)
+  const int64_t done = whole * TW_TOK;
+  if (M > done) {
+    for (int i = 0; i < n; ++i) {
+      const OmTnProblem& q = probs[i];
+      if (launch_tn_regs((const bf16_t*)q.A + done * q.lda, q.lda, (const bf16_t*)q.B + done * q.ldb, q.ldb, q.C, q.ldc, q.bias,
+                         M - done, q.N, q.K, 0, s)) return 1;
+    }
+  }
+  return 0;
+}
+
+extern "C" int om_gemm_tn_acc_batch(int in_dtype, const OmTnProblem* problems, int n, int64_t M, void* stream) {
+  return omk_gemm_tn_batch(in_dtype, problems, n, M, (hipStream_t)stream);
 }

@@ -66,6 +66,9 @@ unsigned long long* omk_debug_trace();
 bool omk_gemm_tn_ok(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb);
 int omk_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* bias,
                 int64_t M, int64_t N, int64_t K, hipStream_t s);      // om_debug_gemm_trace buffer (NULL: off)
+// the same for many problems over one token count in one launch (256 x 256 tiles, whole token axis, no atomics)
+bool omk_gemm_tn_batch_ok(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb);
+int omk_gemm_tn_batch(int dtype, const OmTnProblem* probs, int n, int64_t M, hipStream_t s);
 // wide-tile generations, one translation unit each (gemm_wide6_*.hip, gemm_wide7*.hip); omk_gemm dispatches
 bool omk_gemm_wide6_b16_has(int in_dtype, int out_dtype, int act, bool train, bool resid);
 int omk_gemm_wide6_b16(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int out_dtype,

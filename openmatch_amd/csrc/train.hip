@@ -73,8 +73,14 @@ struct Ws {
   char *nbuf, *df2;
   float *posbias, *drel;
   int* lut;
+  // deferred weight gradients (bf16 BERT, widths of 256): every layer's dY of the four sites is KEPT until the layer
+  // group's batched weight-gradient launch has read it -- per layer [M,H] (FFN2 site) | [M,F] (FFN1) | [M,H] (out-proj)
+  // | [M,3H] (QKV): 127 MB per bert-base layer at 9 216 tokens, 1.5 GB per backward of 288 GB
+  char* keep;
+  size_t skeep;                     // bytes per layer (0: not available for this configuration)
   size_t total;
 };
+inline bool keep_ok(const Dims& d) { return !d.t5 && d.es == 2 && d.H % 256 == 0 && d.F % 256 == 0 && d.M >= 32; }
 Ws carve_ws(const Dims& d, char* base) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return base + o; };
@@ -95,6 +101,8 @@ Ws carve_ws(const Dims& d, char* base) {
   w.posbias = (float*)take(d.t5 ? (size_t)d.nh * d.L * d.L * 4 : 0);
   w.drel = (float*)take(d.t5 ? (size_t)d.nh * (2 * d.L) * 4 : 0);
   w.lut = (int*)take(d.t5 ? (size_t)(2 * d.L) * 4 : 0);
+  w.skeep = keep_ok(d) ? align_up(5 * mh + mf, 256) : 0;
+  w.keep = take(w.skeep * d.nl);
   w.total = off;
   return w;
 }
@@ -526,9 +534,26 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
   if (om_option(OM_OPT_TRAIN_WGRAD_STREAM) && omk_gemm_tn_ok(dt, M, H, F, H, F) && omk_gemm_tn_ok(dt, M, F, H, F, H) &&
       omk_gemm_tn_ok(dt, M, H, H, H, H) && omk_gemm_tn_ok(dt, M, 3 * H, H, 3 * H, H))
     RUN(lane_get(d.nl, &lane));
+  // Deferred, batched weight gradients (OM_OPT_TRAIN_WGRAD_BATCH = layers per launch): the sites only RECORD their
+  // contraction; the dY they name live in the layer's keep slice (never rewritten inside this backward), and after the
+  // lowest layer of a group one om_gemm_tn_acc_batch launch computes the group's 4 x layers weight gradients -- on the
+  // side stream when the lane is on (one event per group each way instead of one per site), else in line.
+  int wbatch = om_option(OM_OPT_TRAIN_WGRAD_BATCH);
+  if (wbatch < 0) wbatch = 0;
+  if (wbatch > 12) wbatch = 12;
+  if (wbatch && !(ws.skeep && omk_gemm_tn_batch_ok(dt, M, H, F, H, F) && omk_gemm_tn_batch_ok(dt, M, F, H, F, H) &&
+                  omk_gemm_tn_batch_ok(dt, M, H, H, H, H) && omk_gemm_tn_batch_ok(dt, M, 3 * H, H, 3 * H, H)))
+    wbatch = 0;
+  std::vector<OmTnProblem> pend;
+  int group_top = d.nl - 1;                                         // highest layer of the group being collected
+  const size_t mh_b = (size_t)M * H * d.es, mf_b = (size_t)M * F * d.es;
 #define WGRAD(I_, dY_, N_, X_, K_, dW_, db_)                                                        \
   do {                                                                                             \
-    if (lane) {                                                                                    \
+    if (wbatch) {                                                                                  \
+      OmTnProblem q_;                                                                              \
+      q_.A = dY_; q_.B = X_; q_.C = dW_; q_.bias = db_; q_.lda = N_; q_.ldb = K_; q_.ldc = K_; q_.N = N_; q_.K = K_; \
+      pend.push_back(q_);                                                                          \
+    } else if (lane) {                                                                             \
       OM_HIP(hipEventRecord(lane->ready[l * 4 + (I_)], s));                                        \
       OM_HIP(hipStreamWaitEvent(lane->side, lane->ready[l * 4 + (I_)], 0));                        \
       RUN(wgrad(dt, dY_, N_, X_, K_, dW_, db_, d, ws, lane->side));                                \
@@ -538,7 +563,7 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
     }                                                                                              \
   } while (0)
   // before the main stream rewrites a buffer that weight gradient I_ of layer L_ reads
-#define WGRAD_DONE(L_, I_) do { if (lane && (L_) < d.nl) OM_HIP(hipStreamWaitEvent(s, lane->done[(L_) * 4 + (I_)], 0)); } while (0)
+#define WGRAD_DONE(L_, I_) do { if (lane && !wbatch && (L_) < d.nl) OM_HIP(hipStreamWaitEvent(s, lane->done[(L_) * 4 + (I_)], 0)); } while (0)
   RUN(transpose_weights(dt, Ls, d, ws, s));
 
   for (int l = d.nl - 1; l >= 0; --l) {
@@ -553,45 +578,70 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
     const char* gl = t.g + t.sf * l;
     const char* y2 = t.y2 + t.sx * l;
     const WtView wt = wt_of(d, ws, l);
+    // where this layer's dY go: shared scratch, or (deferred weight gradients) the layer's keep slice.  The operand of
+    // the FFN2 / out-proj sites is the dropout-masked gradient when there is dropout, else the LayerNorm backward's output.
+    char* const kp = wbatch ? ws.keep + ws.skeep * l : nullptr;
+    char* const dy2 = (wbatch && hidden_dropout <= 0.f) ? kp : ws.dy;
+    char* const dd2 = (wbatch && hidden_dropout > 0.f) ? kp : ws.dd;
+    char* const dfl = wbatch ? kp + mh_b : ws.df;
+    char* const dy1 = (wbatch && hidden_dropout <= 0.f) ? kp + mh_b + mf_b : ws.dy;
+    char* const dd1 = (wbatch && hidden_dropout > 0.f) ? kp + mh_b + mf_b : ws.dd;
+    char* const dqkvl = wbatch ? kp + 2 * mh_b + mf_b : ws.dqkv;
 
     // LN2 backward: dy2 = d(loss)/d(y2)
     // (+ the FFN output branch's dropout, which sits after the dense and before the residual add, in the same pass)
     WGRAD_DONE(l + 1, 2);                                           // ws.dy / ws.dd: last read by dWo of the layer above
-    RUN(omk_ln_bwd_drop(dt, dx, y2, lw.ln2_g, ws.dy, ws.dd, hidden_dropout, site_seed(seed, l, 4), lg.ln2_g, lg.ln2_b, M, H, c->ln_eps, s));
-    const char* dO = hidden_dropout > 0.f ? ws.dd : ws.dy;
+    RUN(omk_ln_bwd_drop(dt, dx, y2, lw.ln2_g, dy2, dd2, hidden_dropout, site_seed(seed, l, 4), lg.ln2_g, lg.ln2_b, M, H, c->ln_eps, s));
+    const char* dO = hidden_dropout > 0.f ? dd2 : dy2;
     WGRAD(0, dO, H, gl, F, lg.ffn2_w, lg.ffn2_b);                   // dW2 [H,F], db2
     {
       GemmEpilogue e1 = {};
       e1.act = OM_ACT_GELU_ERF_GRAD; e1.resid = f; e1.ldr = F;      // df = (dO W2) * gelu'(f);  W2^T [F,H]
       WGRAD_DONE(l + 1, 1);                                         // ws.df: last read by dW1 of the layer above
-      RUN(omk_gemm(dt, dO, H, wt.f2, H, dt, ws.df, F, M, F, H, e1, s));
+      RUN(omk_gemm(dt, dO, H, wt.f2, H, dt, dfl, F, M, F, H, e1, s));
     }
-    WGRAD(1, ws.df, F, x1, H, lg.ffn1_w, lg.ffn1_b);                // dW1 [F,H], db1
+    WGRAD(1, dfl, F, x1, H, lg.ffn1_w, lg.ffn1_b);                  // dW1 [F,H], db1
     {
       GemmEpilogue e2 = {};
-      e2.resid = ws.dy; e2.ldr = H;                                 // dx1 = df W1 + dy2 (residual path);  W1^T [H,F]
-      RUN(omk_gemm(dt, ws.df, F, wt.f1, F, dt, ws.dctx, H, M, H, F, e2, s));
+      e2.resid = dy2; e2.ldr = H;                                   // dx1 = df W1 + dy2 (residual path);  W1^T [H,F]
+      RUN(omk_gemm(dt, dfl, F, wt.f1, F, dt, ws.dctx, H, M, H, F, e2, s));
     }
     // LN1 backward (ws.dctx holds d/d(x1) for now)
     WGRAD_DONE(l, 0);                                               // ws.dy / ws.dd: read by dW2 of this layer
-    RUN(omk_ln_bwd_drop(dt, ws.dctx, y1, lw.ln1_g, ws.dy, ws.dd, hidden_dropout, site_seed(seed, l, 3), lg.ln1_g, lg.ln1_b, M, H, c->ln_eps, s));
-    const char* dA = hidden_dropout > 0.f ? ws.dd : ws.dy;
+    RUN(omk_ln_bwd_drop(dt, ws.dctx, y1, lw.ln1_g, dy1, dd1, hidden_dropout, site_seed(seed, l, 3), lg.ln1_g, lg.ln1_b, M, H, c->ln_eps, s));
+    const char* dA = hidden_dropout > 0.f ? dd1 : dy1;
     WGRAD(2, dA, H, ctx, H, lg.o_w, lg.o_b);                        // dWo [H,H], dbo
     {
       GemmEpilogue e3 = {};
       RUN(omk_gemm(dt, dA, H, wt.o, H, dt, ws.dctx, H, M, H, H, e3, s));    // dctx = dA Wo
     }
     WGRAD_DONE(l + 1, 3);                                           // ws.dqkv: last read by dWqkv of the layer above
-    RUN(omk_attention_bwd(dt, qkv, ws.dctx, ws.dqkv, attention_mask, B, (int)L, H, d.nh, scale,
+    RUN(omk_attention_bwd(dt, qkv, ws.dctx, dqkvl, attention_mask, B, (int)L, H, d.nh, scale,
                           attn_dropout, site_seed(seed, l, 2), s));
-    WGRAD(3, ws.dqkv, 3 * H, x, H, lg.qkv_w, lg.qkv_b);             // dWqkv [3H,H], dbqkv
+    WGRAD(3, dqkvl, 3 * H, x, H, lg.qkv_w, lg.qkv_b);               // dWqkv [3H,H], dbqkv
     {
       GemmEpilogue e4 = {};
-      e4.resid = ws.dy; e4.ldr = H;                                 // dx = dqkv Wqkv + dy1;  Wqkv^T [H,3H]
-      RUN(omk_gemm(dt, ws.dqkv, 3 * H, wt.qkv, 3 * H, dt, dx_prev, H, M, H, 3 * H, e4, s));
+      e4.resid = dy1; e4.ldr = H;                                   // dx = dqkv Wqkv + dy1;  Wqkv^T [H,3H]
+      RUN(omk_gemm(dt, dqkvl, 3 * H, wt.qkv, 3 * H, dt, dx_prev, H, M, H, 3 * H, e4, s));
     }
     char* tmp = dx; dx = dx_prev; dx_prev = tmp;
-    if (lane && g_bwd_events) {                                     // the layer's gradients are complete when BOTH streams got here
+    if (wbatch) {
+      // the group is complete at its lowest layer: one launch for all of its weight gradients, then the progress events
+      // of its layers (their gradients exist once that launch is done)
+      if (l == 0 || group_top - l + 1 >= wbatch) {
+        hipStream_t ws_stream = s;
+        if (lane) {
+          OM_HIP(hipEventRecord(lane->mark[l], s));
+          OM_HIP(hipStreamWaitEvent(lane->side, lane->mark[l], 0));
+          ws_stream = lane->side;
+        }
+        RUN(omk_gemm_tn_batch(dt, pend.data(), (int)pend.size(), M, ws_stream));
+        pend.clear();
+        for (int ll = group_top; ll >= l; --ll) RUN(record_layer_event(ll, ws_stream));
+        if (lane && l == 0) OM_HIP(hipEventRecord(lane->done[3], lane->side));       // the join below waits for it
+        group_top = l - 1;
+      }
+    } else if (lane && g_bwd_events) {                              // the layer's gradients are complete when BOTH streams got here
       OM_HIP(hipEventRecord(lane->mark[l], s));
       OM_HIP(hipStreamWaitEvent(lane->side, lane->mark[l], 0));
       RUN(record_layer_event(l, lane->side));

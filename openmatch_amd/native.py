@@ -43,6 +43,12 @@ class OmEncoderWeights(C.Structure):
                 ("rel_bias", c_void_p), ("head_w", c_void_p), ("folded", c_void_p)]
 
 
+class OmTnProblem(C.Structure):
+    """One weight-gradient contraction of an om_gemm_tn_acc_batch launch (include/openmatch_hip.h)."""
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("bias", c_void_p),
+                ("lda", c_int64), ("ldb", c_int64), ("ldc", c_int64), ("N", c_int64), ("K", c_int64)]
+
+
 class OmT5DecoderLayer(C.Structure):
     _fields_ = [(n, c_void_p) for n in (
         "sa_v_w", "sa_o_w", "sa_ln_g", "ca_q_w", "ca_kv_w", "ca_o_w", "ca_ln_g", "ffn1_w", "ffn1g_w", "ffn2_w", "ffn_ln_g")]
@@ -91,6 +97,7 @@ _SIGNATURES = {
                            c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "om_gemm_tn_acc": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                c_int64, c_int64, c_int64, c_void_p]),
+    "om_gemm_tn_acc_batch": (c_int, [c_int, C.POINTER(OmTnProblem), c_int, c_int64, c_void_p]),
     "om_encoder_workspace_bytes": (c_size_t, [C.POINTER(OmEncoderConfig), c_int64, c_int64]),
     "om_t5_decoder_workspace_bytes": (c_size_t, [C.POINTER(OmEncoderConfig), c_int64, c_int64]),
     "om_t5_decoder_step": (c_int, [C.POINTER(OmEncoderConfig), C.POINTER(OmT5DecoderWeights), c_void_p, c_void_p,

@@ -452,7 +452,57 @@ int main(int argc, char** argv) {
       om_debug_option(OM_OPT_WGRAD_DEBUG, 0);
       CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(db));
     }
-    return 0;
+    // the batched launch (om_gemm_tn_acc_batch): the four contractions of `layers` bert-base layers at once, every layer
+    // with its own operands (as the backward keeps them); checked against the per-shape kernel on layer 0
+    for (int layers : {1, 2, 4, 12}) {
+      std::vector<OmTnProblem> probs;
+      std::vector<void*> owned;
+      double flops = 0.0;
+      std::vector<bf16> hA[4], hB[4];
+      for (int l = 0; l < layers; ++l)
+        for (int si = 0; si < 4; ++si) {
+          const int N = shapes[si][0], K = shapes[si][1];
+          if (l == 0) { hA[si] = to_bf16(randn((size_t)M * N, 1.f)); hB[si] = to_bf16(randn((size_t)M * K, 1.f)); }
+          bf16* dA = upload(hA[si]); bf16* dB = upload(hB[si]);
+          float* dC = dalloc<float>((size_t)N * K); float* db = dalloc<float>(N);
+          CK(hipMemset(dC, 0, (size_t)N * K * 4)); CK(hipMemset(db, 0, N * 4));
+          OmTnProblem q; q.A = dA; q.B = dB; q.C = dC; q.bias = db; q.lda = N; q.ldb = K; q.ldc = K; q.N = N; q.K = K;
+          probs.push_back(q);
+          owned.push_back(dA); owned.push_back(dB); owned.push_back(dC); owned.push_back(db);
+          flops += 2.0 * M * N * K;
+        }
+      OMCK(om_gemm_tn_acc_batch(OM_BF16, probs.data(), (int)probs.size(), M, nullptr));
+      CK(hipDeviceSynchronize());
+      if (layers == 1) {                                   // one accumulation so far: compare with the split kernel
+        for (int si = 0; si < 4; ++si) {
+          const int N = shapes[si][0], K = shapes[si][1];
+          float* dC = dalloc<float>((size_t)N * K); float* db = dalloc<float>(N);
+          CK(hipMemset(dC, 0, (size_t)N * K * 4)); CK(hipMemset(db, 0, N * 4));
+          OMCK(om_gemm_tn_acc(OM_BF16, probs[si].A, N, probs[si].B, K, dC, K, db, M, N, K, nullptr));
+          const std::vector<float> want = download(dC, (size_t)N * K), got = download(probs[si].C, (size_t)N * K);
+          const std::vector<float> wb = download(db, (size_t)N), gb = download(probs[si].bias, (size_t)N);
+          double worst = 0.0, wbias = 0.0;
+          for (size_t e = 0; e < want.size(); ++e) worst = std::max(worst, (double)fabsf(want[e] - got[e]));
+          for (size_t e = 0; e < wb.size(); ++e) wbias = std::max(wbias, (double)fabsf(wb[e] - gb[e]));
+          const bool ok = worst < 2e-5 * sqrt((double)M) * 8 && wbias < 2e-5 * sqrt((double)M) * 8;
+          printf("[%s] gemm_tn batch vs split kernel N=%d K=%d: max |dC| %.3g, max |dbias| %.3g\n", ok ? "OK" : "FAIL", N, K, worst, wbias);
+          if (!ok) ++g_fail;
+          CK(hipFree(dC)); CK(hipFree(db));
+        }
+      }
+      for (int r = 0; r < 2; ++r) OMCK(om_gemm_tn_acc_batch(OM_BF16, probs.data(), (int)probs.size(), M, nullptr));
+      CK(hipDeviceSynchronize());
+      auto t0 = std::chrono::steady_clock::now();
+      const int reps = 10;
+      for (int r = 0; r < reps; ++r) OMCK(om_gemm_tn_acc_batch(OM_BF16, probs.data(), (int)probs.size(), M, nullptr));
+      CK(hipDeviceSynchronize());
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+      printf("[BENCH] gemm_tn batch M=%ld, %d layer(s) x 4 contractions (256x256 tiles, whole token axis): %.1f us  %.1f TFLOP/s\n",
+             (long)M, layers, us, flops / us * 1e-6);
+      for (void* q : owned) CK(hipFree(q));
+    }
+    printf("%s: %d failure(s)\n", g_fail ? "SELFTEST FAILED" : "SELFTEST PASSED", g_fail);
+    return g_fail ? 1 : 0;
   }
   if (what == "attn") {        // bf16 attention kernel alone under the OM_OPT_ATTENTION_DEBUG variants
     const int64_t B = argc > 2 ? atoll(argv[2]) : 1024; const int L = argc > 3 ? atoi(argv[3]) : 128, H = 768, heads = 12;

@@ -773,6 +773,93 @@ def test_weight_gradient_contraction_matches_torch(M, N, K, with_bias):
         assert torch.equal(bd.cpu(), b0)
 
 
+@pytest.mark.parametrize("M", [9216, 4099, 64, 45, 20])
+def test_batched_weight_gradient_contraction_matches_torch(M):
+    """om_gemm_tn_acc_batch (gemm_tn.hip, gemm_tn_wide_kernel): the weight gradients of a group of layers in ONE launch --
+    256 x 256 tiles over the whole token axis, plain read-add-write of C and bias.  Five problems of different shapes
+    (the four of a bert-base layer and a 256 x 256 one) with non-zero C / bias, token counts that are and are not
+    multiples of the 32-token step (the tail goes through the split kernels), against float64 products of the same
+    bf16 values."""
+    from openmatch_amd import native as N_
+    shapes = [(768, 3072, True), (3072, 768, True), (768, 768, True), (2304, 768, True), (256, 256, False)]
+    gen = torch.Generator().manual_seed(M)
+    keep, refs = [], []
+    probs = (N_.OmTnProblem * len(shapes))()
+    for i, (Nn, K, with_bias) in enumerate(shapes):
+        A = torch.randn(M, Nn, generator=gen).to(torch.bfloat16)
+        B = (torch.randn(M, K, generator=gen) * 0.5 + 0.1).to(torch.bfloat16)
+        C0 = torch.randn(Nn, K, generator=gen)
+        b0 = torch.randn(Nn, generator=gen)
+        Ad, Bd, Cd, bd = A.to(DEV), B.to(DEV), C0.to(DEV).contiguous(), b0.to(DEV).contiguous()
+        keep.append((Ad, Bd, Cd, bd, b0))
+        refs.append((C0.double() + A.double().t() @ B.double(), b0.double() + A.double().sum(0), with_bias))
+        probs[i] = N_.OmTnProblem(A=N_.ptr(Ad), B=N_.ptr(Bd), C=N_.ptr(Cd), bias=N_.ptr(bd) if with_bias else None,
+                                  lda=Nn, ldb=K, ldc=K, N=Nn, K=K)
+    with torch.cuda.device(DEV):
+        rc = N_.lib().om_gemm_tn_acc_batch(1, probs, len(shapes), M, N_.stream_ptr(keep[0][2].device))
+    if M < 32:
+        assert rc != 0
+        return
+    N_.check(rc)
+    torch.cuda.synchronize()
+    scale = math.sqrt(M)
+    for (Ad, Bd, Cd, bd, b0), (ref, ref_b, with_bias) in zip(keep, refs):
+        err = (Cd.cpu().double() - ref).abs().max().item()
+        assert err < 2e-5 * scale * 8, (err, scale, tuple(ref.shape))
+        if with_bias:
+            assert (bd.cpu().double() - ref_b).abs().max().item() < 2e-5 * scale * 8
+        else:
+            assert torch.equal(bd.cpu(), b0)
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_deferred_batched_weight_gradients_equal_per_site_launches(p_drop):
+    """OM_OPT_TRAIN_WGRAD_BATCH: the bf16 BERT backward keeps every layer's dY and computes the weight gradients of a
+    group of layers in one om_gemm_tn_acc_batch launch (train.hip).  Same step -- three bert-base-width layers, 6 x 128 +
+    3 x 32 tokens, same dropout seed -- with per-site launches (0), groups of two layers (the last group is a single
+    layer) and one group for the whole stack, each with and without the side stream: every parameter gradient agrees to
+    f32 accumulation-order noise (the data-gradient chain is the same kernels in all of them)."""
+    from transformers import BertConfig, BertModel
+    from openmatch.modeling import DRModel
+    from openmatch_amd import native as N_
+    torch.manual_seed(21)
+    cfg = BertConfig(hidden_size=768, num_hidden_layers=3, num_attention_heads=12, intermediate_size=3072,
+                     vocab_size=600, max_position_embeddings=160, hidden_dropout_prob=p_drop,
+                     attention_probs_dropout_prob=p_drop)
+    lm = BertModel(cfg)
+    rng = np.random.default_rng(9)
+    p_ids, p_mask = synth_tokens(rng, 6, 128, vocab=600, lo_len=16, lo_id=300)
+    q_ids, q_mask = synth_tokens(rng, 3, 32, vocab=600, lo_len=4, lo_id=300)
+    tens = lambda a: torch.from_numpy(a).to(DEV)
+    model = DRModel(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype="bfloat16"),
+                    data_args=NS(train_n_passages=2),
+                    train_args=NS(negatives_x_device=False, per_device_train_batch_size=3)).to(DEV).train()
+    runs = {}
+    try:
+        for batch, lane in ((0, 1), (2, 1), (2, 0), (12, 1), (12, 0)):
+            N_.check(N_.lib().om_debug_option(14, batch))
+            N_.check(N_.lib().om_debug_option(8, lane))
+            model.zero_grad(set_to_none=True)
+            torch.manual_seed(77)                                    # the step's dropout seed
+            out = model(query={"input_ids": tens(q_ids), "attention_mask": tens(q_mask)},
+                        passage={"input_ids": tens(p_ids), "attention_mask": tens(p_mask)})
+            out.loss.backward()
+            torch.cuda.synchronize()
+            runs[(batch, lane)] = (out.loss.item(), {n: p.grad.detach().float().cpu().clone()
+                                                    for n, p in lm.named_parameters() if p.grad is not None})
+    finally:
+        N_.check(N_.lib().om_debug_option(14, 4))
+        N_.check(N_.lib().om_debug_option(8, 1))
+    l0, g0 = runs[(0, 1)]
+    assert any("query.weight" in n for n in g0) and any("output.dense.weight" in n for n in g0)
+    for key, (l1, g1) in runs.items():
+        assert abs(l1 - l0) < 1e-6 * max(1.0, abs(l0)), (key, l0, l1)
+        assert g1.keys() == g0.keys()
+        for n in g0:
+            rel = ((g1[n] - g0[n]).norm() / (g0[n].norm() + 1e-20)).item()
+            assert rel < 1e-4 or (g1[n] - g0[n]).abs().max().item() < 1e-7, (key, n, rel)
+
+
 def test_tied_training_forward_in_one_pass_equals_two_calls(golden):
     """A tied DRModel in training mode pads the queries to the passage length and encodes both batches in one pass
     (modeling/dense_retrieval_model.py: _encode_one_pass); the reference calls the shared module twice (:89-93).  Same
