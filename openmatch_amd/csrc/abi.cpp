@@ -100,7 +100,8 @@ void opt_init() {
   g_opt[OM_OPT_ENCODER_TWO_PLANE] = e ? atoi(e) : 1;
   e = getenv("OM_GEMM_VARIANT");
   g_opt[OM_OPT_GEMM_VARIANT] = e ? atoi(e) : 0;
-  g_opt[OM_OPT_SEARCH_DEBUG] = getenv("OM_SEARCH_DEBUG") ? 1 : 0;
+  e = getenv("OM_SEARCH_DEBUG");
+  g_opt[OM_OPT_SEARCH_DEBUG] = e ? (atoi(e) ? atoi(e) : 1) : 0;
   e = getenv("OM_TRAIN_WGRAD_BATCH");
   g_opt[OM_OPT_TRAIN_WGRAD_BATCH] = e ? atoi(e) : 4;
   g_opt_init.store(true);

@@ -371,22 +371,31 @@ __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_wide_kernel(const TwBat
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto frag2 = [](v4s a, v4s b) { return (bf16x8_t){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; };
-  // fragments of k step KS of the stage at ST: A fragments wn * 4 + i, B fragments wk * 4 + i
+  // fragment I of k step KS of the stage at ST: A fragments wn * 4 + I, B fragments wk * 4 + I (two transposing reads each)
+#define TW_FRAG_A(F, ST, KS, I) { const char* p_ = (ST) + ((wn * 4 + (I)) * 2 + (KS)) * 1024 + lane * 8; F[I] = frag2(tn_read(p_), tn_read(p_ + 512)); }
+#define TW_FRAG_B(F, ST, KS, I) { const char* p_ = (ST) + 16384 + ((wk * 4 + (I)) * 2 + (KS)) * 1024 + lane * 8; F[I] = frag2(tn_read(p_), tn_read(p_ + 512)); }
 #define TW_READ(FA, FB, ST, KS)                                                                        \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
-    const char* pa_ = (ST) + ((wn * 4 + i) * 2 + (KS)) * 1024 + lane * 8;                              \
-    const char* pb_ = (ST) + 16384 + ((wk * 4 + i) * 2 + (KS)) * 1024 + lane * 8;                      \
-    FA[i] = frag2(tn_read(pa_), tn_read(pa_ + 512));                                                   \
-    FB[i] = frag2(tn_read(pb_), tn_read(pb_ + 512));                                                   \
-  }
-#define TW_MMA(FA, FB)                                                                                 \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) MmaOps<bf16_t>::mma(FA[i], FB[j], acc[i][j]);        \
-    if (do_bias) {      /* the fragment holds 8 tokens of column (lane & 31): add them up under the MFMAs */ \
-      const uint4 w = __builtin_bit_cast(uint4, FA[i]);                                                \
-      bsum[i] += (__uint_as_float(w.x << 16) + __uint_as_float(w.x & 0xffff0000u)) + (__uint_as_float(w.y << 16) + __uint_as_float(w.y & 0xffff0000u)) + \
-                 (__uint_as_float(w.z << 16) + __uint_as_float(w.z & 0xffff0000u)) + (__uint_as_float(w.w << 16) + __uint_as_float(w.w & 0xffff0000u)); \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) { TW_FRAG_A(FA, ST, KS, i) TW_FRAG_B(FB, ST, KS, i) }
+  // One k step of 16 tokens: 16 MFMAs from (FA, FB); behind each of the first eight, ONE fragment (two reads) of the next
+  // k step goes into (NA, NB) from stage NST, in the order in which the next half consumes them.  Issue order pinned by
+  // fences: left to itself the compiler put all 16 reads in front, and with more LDS operations in flight than lgkmcnt can
+  // count (15) every MFMA of a half waited for reads issued just before it (2 200 cycles per step for 1 024 of MFMA).
+#define TW_HALF(FA, FB, NA, NB, NST, NKS, DMA_COND, DMA_STAGE)                                         \
+  _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                     \
+    MmaOps<bf16_t>::mma(FA[q >> 2], FB[q & 3], acc[q >> 2][q & 3]);                                    \
+    if (q == 0) TW_FRAG_A(NA, NST, NKS, 0)                                                             \
+    else if (q <= 4) TW_FRAG_B(NB, NST, NKS, q - 1)                                                    \
+    else if (q <= 7) TW_FRAG_A(NA, NST, NKS, q - 4)                                                    \
+    else if (DMA_COND) {                /* MFMAs 8-15 each cover one DMA issue of step t + 3 (wave-uniform branch) */ \
+      if (q & 1) g7_dma(b_at + ((q - 8) >> 1) * 64, b_off, lds0 + (DMA_STAGE) * TW_STAGE + 16384 + dreg + ((q - 8) >> 1) * 2048); \
+      else g7_dma(a_at + ((q - 8) >> 1) * 64, a_off, lds0 + (DMA_STAGE) * TW_STAGE + dreg + ((q - 8) >> 1) * 2048); \
     }                                                                                                  \
+    if (do_bias && (q & 3) == 3) {      /* the fragment holds 8 tokens of column (lane & 31): add them up under the MFMAs */ \
+      const uint4 w = __builtin_bit_cast(uint4, FA[q >> 2]);                                           \
+      bsum[q >> 2] += (__uint_as_float(w.x << 16) + __uint_as_float(w.x & 0xffff0000u)) + (__uint_as_float(w.y << 16) + __uint_as_float(w.y & 0xffff0000u)) + \
+                      (__uint_as_float(w.z << 16) + __uint_as_float(w.z & 0xffff0000u)) + (__uint_as_float(w.w << 16) + __uint_as_float(w.w & 0xffff0000u)); \
+    }                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
   }
 
   const int pre = nsteps < 3 ? nsteps : 3;
@@ -398,20 +407,22 @@ __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_wide_kernel(const TwBat
   for (int t = 0; t < nsteps; ++t) {
     const char* st = smem + (t & 3) * TW_STAGE;
     __builtin_amdgcn_sched_barrier(0);
-    TW_READ(fa1, fb1, st, 1)
-    TW_MMA(fa0, fb0)
-    __builtin_amdgcn_sched_barrier(0);
+    TW_HALF(fa0, fb0, fa1, fb1, st, 1, false, 0)      // tokens 0-15 of step t; reads its tokens 16-31
     if (t + 1 < nsteps) {
       TW_WAIT(t + 2 < nsteps ? 1 : 0);                // this wave's part of step t + 1 is in LDS (step t + 2 may be in flight)
-      __syncthreads();                                // ... everyone's; and every wave has left step t - 1
-      if (t + 3 < nsteps) TW_ISSUE((t + 3) & 3);
-      const char* sn = smem + ((t + 1) & 3) * TW_STAGE;
-      TW_READ(fa0, fb0, sn, 0)
+      __syncthreads();                                // ... everyone's; and every wave has left step t - 1: its stage takes step t + 3
     }
-    TW_MMA(fa1, fb1)
+    const bool issue = t + 3 < nsteps;
+    const int istage = (t + 3) & 3;
+    const char* sn = smem + ((t + 1) & 3) * TW_STAGE; // (past the last step: a stage nobody writes any more; the fragments are not used)
+    __builtin_amdgcn_sched_barrier(0);
+    TW_HALF(fa1, fb1, fa0, fb0, sn, 0, issue, istage) // tokens 16-31 of step t; reads tokens 0-15 of step t + 1; issues step t + 3
+    if (issue) { a_at += a_step; b_at += b_step; }
   }
 #undef TW_READ
-#undef TW_MMA
+#undef TW_HALF
+#undef TW_FRAG_A
+#undef TW_FRAG_B
 #undef TW_ISSUE
 
   // acc[i][j][r]: n = n0 + wn*128 + i*32 + 8*(r>>2) + 4*(lane>>5) + (r&3),  k = k0 + wk*128 + j*32 + (lane & 31): the tile
@@ -422,6 +433,8 @@ __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_wide_kernel(const TwBat
     const int nbase = n0 + wn * 128 + i * 32 + 4 * (lane >> 5);
     // eight rows at a time: all 32 loads of the batch are issued before its first store (C may alias itself as far as
     // the compiler knows: one read-add-write per element would wait for every load's round trip in turn)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[i][j]));      // stays in its AGPRs until here (else all 256 are copied out at once: spills)
 #pragma unroll
     for (int rb = 0; rb < 16; rb += 8) {
       float cv[8][4];

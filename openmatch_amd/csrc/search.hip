@@ -507,6 +507,171 @@ __global__ __launch_bounds__(G6_THREADS) void sim_stream_kernel(
   }
 }
 
+// Round 3: the same pass with the queries in REGISTERS.  The kernel above is bound by the bytes it keeps in flight: LDS is
+// shared between the resident query blocks (48 KiB each) and the ring, which left 64 / 48 KiB of index per CU in flight
+// (NB = 1 / 2: 6.0 / 4.6 TB/s inside the kernel, Little's law at ~2.7 us of loaded latency) and no room at all for a third
+// block.  A wave's B operand never changes: its 32-query block is 12 K steps x 4 MFMA sub-steps x 16 bytes per lane = 192
+// VGPRs of the 512 this one-wave-per-SIMD kernel owns, loaded once from global memory in fragment order.  The whole LDS
+// (160 KiB) is the ring: ten slots of 128 rows x 128 bytes, nine units = 144 KiB per CU in flight.
+//     NB = 1 (Q <= 32)    the four waves share the block and take 32 rows of a unit each
+//     NB = 2 (Q <= 64)    waves 0, 2 / 1, 3 hold block 0 / 1 and take 64 rows each
+//     NB = 4 (Q <= 128)   one block per wave, every wave takes all 128 rows (each reads the whole unit: 64 KiB of fragment
+//                         reads + 16 KiB of DMA per unit is the LDS port's limit at ~15 TB/s, above what HBM delivers)
+// Persistent over 128-row tiles (blockIdx, blockIdx + grid, ...); whole tiles only; d <= 768 (K steps past d / 64 are
+// compiled but skipped: the K loop is unrolled so that the query fragments are indexed statically).
+#define SR_RING 10
+#define SR_UROWS 128
+#define SR_UBYTES (SR_UROWS * G7_ROW_BYTES)
+#define SR_LDS (SR_RING * SR_UBYTES)
+#define SR_IPU (SR_UROWS / 32)                  // DMA instructions per wave and unit
+#define SR_NKMAX 12
+template <typename T, int NB>
+__global__ __launch_bounds__(G6_THREADS) void sim_stream_reg_kernel(
+    const T* __restrict__ rows, int64_t nrows, uint32_t row_base, const T* __restrict__ queries, int64_t nq, int64_t d,
+    const float* __restrict__ thr, u64* __restrict__ keys, unsigned* __restrict__ cnt) {
+  typedef typename MmaOps<T>::frag_t frag_t;
+  constexpr int RBW = NB;                        // 32-row blocks per wave and unit: 4 / NB waves share a query block
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int lane = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nk = (int)((d * 2) / G7_ROW_BYTES);
+  const int64_t ntiles = nrows / SR_UROWS;
+  const int my_tiles = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+  if (my_tiles <= 0) return;
+  const int units = my_tiles * nk;
+  const uint32_t lds0 = g7_lds_addr(smem);
+  const int half = lane >> 5, l31 = lane & 31, key = (l31 >> 1) & 7;
+  const int nb = wave % NB, rgroup = wave / NB;   // this wave's query block and its share of a unit's rows
+
+  // the wave's query block, in MFMA fragment order, straight from global memory (once per launch)
+  frag_t bq[SR_NKMAX][4];
+  {
+    const int qr = nb * 32 + l31;
+    const int rr = qr < nq ? qr : (int)nq - 1;                  // padding rows repeat the last query (their threshold is +inf)
+    const T* qrow = queries + (int64_t)rr * d + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < SR_NKMAX; ++ks)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+        bq[ks][kk] = ks < nk ? *(const frag_t*)(qrow + ks * 64 + kk * 16) : __builtin_bit_cast(frag_t, z4);
+      }
+  }
+  const float th = thr[nb * 32 + l31];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // before the first hand-counted DMA: nothing of the compiler's is in flight
+#pragma unroll
+  for (int ks = 0; ks < SR_NKMAX; ++ks)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) asm volatile("" : "+a"(bq[ks][kk]));    // in the accumulation half of the register file (the matrix core
+                                                                            // reads B from there as well): 192 + 16 NB of its 256; the other half stays free for the row fragments
+
+  // DMA offsets of a unit: instruction i of this wave moves rows (i*4 + wave)*8 .. +7, lane -> row (lane >> 3),
+  // physical chunk (lane & 7) <- source chunk (lane & 7) ^ ((row >> 1) & 7)
+  uint32_t off[SR_IPU];
+#pragma unroll
+  for (int i = 0; i < SR_IPU; ++i) {
+    const int r = (i * 4 + wave) * 8 + (lane >> 3);
+    off[i] = (uint32_t)(r * d * 2) + ((((lane & 7) ^ ((r >> 1) & 7))) << 4);
+  }
+  // issue cursor: (tile, K step, slot) of the next unit to fetch
+  int64_t i_tile = blockIdx.x;
+  int i_ks = 0, i_slot = 0, issued = 0;
+  auto issue = [&]() {
+    const char* base = (const char*)(rows + i_tile * SR_UROWS * d) + i_ks * G7_ROW_BYTES;
+    const uint32_t dst = lds0 + i_slot * SR_UBYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < SR_IPU; ++i) g7_dma(base, off[i], dst + i * 4096);
+    if (++i_ks == nk) { i_ks = 0; i_tile += gridDim.x; }
+    if (++i_slot == SR_RING) i_slot = 0;
+    ++issued;
+  };
+  for (int u = 0; u < SR_RING - 1; ++u)
+    if (u < units) issue();
+
+  const int arow = (rgroup * (32 * RBW) + l31) * G7_ROW_BYTES;   // + rt * 32 rows
+  f32x16_t acc[RBW];
+#pragma unroll
+  for (int rt = 0; rt < RBW; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+  int c_slot = 0, u = 0;
+  int64_t tile = blockIdx.x;
+  for (int ti = 0; ti < my_tiles; ++ti) {
+#pragma unroll
+    for (int ks = 0; ks < SR_NKMAX; ++ks) {
+      if (ks < nk) {                                             // wave-uniform
+        // unit u landed; up to RING - 1 younger units may be in flight
+        const int younger = issued - 1 - u;
+        switch (younger) {
+          case 9: G7_WAIT_VM(9 * SR_IPU); break;
+          case 8: G7_WAIT_VM(8 * SR_IPU); break;
+          case 7: G7_WAIT_VM(7 * SR_IPU); break;
+          case 6: G7_WAIT_VM(6 * SR_IPU); break;
+          case 5: G7_WAIT_VM(5 * SR_IPU); break;
+          case 4: G7_WAIT_VM(4 * SR_IPU); break;
+          case 3: G7_WAIT_VM(3 * SR_IPU); break;
+          case 2: G7_WAIT_VM(2 * SR_IPU); break;
+          case 1: G7_WAIT_VM(1 * SR_IPU); break;
+          default: G7_WAIT_VM(0); break;
+        }
+        __builtin_amdgcn_s_barrier();                            // ... for every wave; and unit u - 1 has been read by all
+        if (issued < units) issue();                             // into the slot of unit u - 1
+        const char* ua = smem + c_slot * SR_UBYTES + arow;
+        // the row fragments of sub-step kk + 1 are read under the MFMAs of sub-step kk (order pinned: left alone the
+        // compiler reads two fragments, waits, multiplies, reads two ... and every LDS round trip is exposed)
+        frag_t a[2][RBW];
+#pragma unroll
+        for (int rt = 0; rt < RBW; ++rt) a[0][rt] = *(const frag_t*)(ua + rt * 32 * G7_ROW_BYTES + ((half ^ key) << 4));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          G7_FENCE_();
+          if (kk < 3) {
+            const int slot = ((((kk + 1) << 1) | half) ^ key) << 4;
+#pragma unroll
+            for (int rt = 0; rt < RBW; ++rt) a[(kk + 1) & 1][rt] = *(const frag_t*)(ua + rt * 32 * G7_ROW_BYTES + slot);
+          }
+          G7_FENCE_();
+#pragma unroll
+          for (int rt = 0; rt < RBW; ++rt)
+            MmaOps<T>::mma(a[kk & 1][rt], bq[ks][kk], acc[rt]); // acc[rt][r]: row 8(r>>2) + 4 half + (r&3) of the 32-row block, query 32 nb + l31
+        }
+        G7_FENCE_();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (++c_slot == SR_RING) c_slot = 0;
+        ++u;
+      }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RBW; ++rt) {
+      const f32x16_t a = acc[rt];
+      float mx = fmaxf(fmaxf(a[0], a[1]), a[2]);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, a[r]), a[r + 1]);
+      mx = fmaxf(mx, a[15]);
+      if (mx >= th) {                                            // rare by construction of the thresholds
+        // one atomic per lane and block, not per survivor (with one query every append of a round lands on one counter)
+        const uint32_t id0 = row_base + (uint32_t)(tile * SR_UROWS) + rgroup * (32 * RBW) + rt * 32 + 4 * half;
+        const int qi = nb * 32 + l31;
+        unsigned n = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) n += a[r] >= th ? 1u : 0u;
+        unsigned pos = atomicAdd(cnt + qi, n);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (a[r] >= th) {
+            if (pos < SORT_CAP) keys[(int64_t)qi * SORT_CAP + pos] = pack_key(a[r], id0 + (r & 3) + 8 * (r >> 2));
+            ++pos;
+          }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+    }
+    tile += gridDim.x;
+  }
+  G7_WAIT_VM(0);
+}
+
 // append a dense score block S[q, 0:n] (rows row_base..) to every list
 __global__ void append_dense_kernel(const float* __restrict__ S, int64_t ldS, int n,
                                     uint32_t row_base, u64* __restrict__ keys,
@@ -951,8 +1116,23 @@ struct Scan {
           hipLaunchKernelGGL((sim_filter_kernel6<f16_t>), dim3((unsigned)ntn), dim3(G6_THREADS), G6_LDS_BYTES, s, idx16 + (r0 + whole) * d,
                              n - whole, (uint32_t)(r0 + whole), ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8);
       } else if (wide) SCAN(sim_filter_kernel6, G6_THREADS, G6_LDS_BYTES, f16_t, idx16, ws.qb);
-      else if (nq <= 64 && (d * 2) / G7_ROW_BYTES <= 12 && om_option(OM_OPT_SCAN_GEN7)) {
-        // the HBM-speed pass for small batches over the whole tiles; the generic kernel takes the ragged tail
+      else if (nq <= 128 && (d * 2) / G7_ROW_BYTES <= SR_NKMAX && om_option(OM_OPT_SCAN_GEN7) && !(om_option(OM_OPT_SEARCH_DEBUG) & 2)) {
+        // the HBM-speed pass for small batches (queries in registers, the whole LDS a ring) over the whole 128-row tiles;
+        // the generic kernel takes the ragged tail
+        const int64_t whole = n & ~(int64_t)127;
+        if (whole) {
+          int ncu = g7_num_cus();
+          if (whole / SR_UROWS < ncu) ncu = (int)(whole / SR_UROWS);
+#define STREAM(NB_) hipLaunchKernelGGL((sim_stream_reg_kernel<f16_t, NB_>), dim3((unsigned)ncu), dim3(G6_THREADS), SR_LDS, s, idx16 + r0 * d, whole, \
+                                       (uint32_t)r0, ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt)
+          if (nq <= 32) STREAM(1); else if (nq <= 64) STREAM(2); else STREAM(4);
+#undef STREAM
+        }
+        if (n > whole)
+          hipLaunchKernelGGL((sim_filter_kernel<f16_t>), dim3((unsigned)((nq + G2_BN - 1) / G2_BN)), dim3(G2_THREADS), G2_LDS_BYTES, s, idx16 + (r0 + whole) * d, n - whole,
+                             (uint32_t)(r0 + whole), ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8);
+      } else if (nq <= 64 && (d * 2) / G7_ROW_BYTES <= 12 && om_option(OM_OPT_SCAN_GEN7)) {
+        // (A/B switch, OM_OPT_SEARCH_DEBUG bit 1: the round-2 kernels with the query blocks in LDS)
         const int64_t whole = n & ~(int64_t)255;
         if (whole) {
           int ncu = g7_num_cus();
@@ -987,7 +1167,7 @@ struct Scan {
   void trace(const char* what, int64_t done, int64_t chunk, const unsigned (&f)[4]) {
     g_info[1]++;                                  // rounds
     if (f[1] > (unsigned)g_info[3]) g_info[3] = f[1];
-    const bool dbg = om_option(OM_OPT_SEARCH_DEBUG) != 0;
+    const bool dbg = (om_option(OM_OPT_SEARCH_DEBUG) & 1) != 0;
     if (dbg) fprintf(stderr, "[om_sim_topk] %-8s done=%ld chunk=%ld overflow=%u max_list=%u too_wide=%u\n",
                      what, (long)done, (long)chunk, f[0], f[1], f[2]);
   }
@@ -1149,6 +1329,9 @@ extern "C" int om_sim_topk(int mode, const float* queries, int64_t n_queries,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES));
     OM_HIP(hipFuncSetAttribute((const void*)sim_stream_kernel<f16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SS_LDS(1)));
     OM_HIP(hipFuncSetAttribute((const void*)sim_stream_kernel<f16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SS_LDS(2)));
+    OM_HIP(hipFuncSetAttribute((const void*)sim_stream_reg_kernel<f16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS));
+    OM_HIP(hipFuncSetAttribute((const void*)sim_stream_reg_kernel<f16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS));
+    OM_HIP(hipFuncSetAttribute((const void*)sim_stream_reg_kernel<f16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS));
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel7<f16_t>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
     OM_HIP(hipFuncSetAttribute((const void*)select_radix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

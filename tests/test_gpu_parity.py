@@ -273,7 +273,8 @@ def _adjudicate(I_gpu, I_ref, P, Q, k):
 
 @pytest.mark.parametrize("precision", ["f32", "f16_rescore"])
 @pytest.mark.parametrize("n,nq,k,clustered", [(1000, 100, 100, True), (50000, 64, 1000, True),
-                                               (50000, 17, 10, False), (300, 5, 1000, False)])
+                                               (50000, 17, 10, False), (300, 5, 1000, False),
+                                               (50000, 128, 1000, True), (40077, 97, 100, False), (20000, 33, 1000, False)])
 def test_flat_ip_search_matches_oracle(precision, n, nq, k, clustered):
     from openmatch_amd.index import FlatIPIndex
     rng = np.random.default_rng(n + k)
@@ -302,7 +303,7 @@ def test_flat_ip_search_matches_oracle(precision, n, nq, k, clustered):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16_rescore"])
-@pytest.mark.parametrize("nq", [4, 64])
+@pytest.mark.parametrize("nq", [4, 64, 128])
 def test_flat_ip_search_with_heavily_duplicated_rows(precision, nq):
     """Collisions: 60 000 rows that are 40 distinct vectors, 1 500 shuffled copies each.  Every score level is a 1 500-way
     exact tie, so the filtered scan's candidate lists fill with ties (longer than the selection kernel's LDS copy, then
