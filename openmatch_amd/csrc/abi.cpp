@@ -107,6 +107,11 @@ void opt_init() {
   g_opt_init.store(true);
 }
 }  // namespace
+// true when the option's environment variable was given (a default that depends on the call's shape must not override it)
+bool om_option_is_set(int opt) {
+  if (opt == OM_OPT_SCAN_GROWTH) return getenv("OM_SCAN_GROWTH") != nullptr;
+  return false;
+}
 int om_option(int opt) {
   if (!g_opt_init.load(std::memory_order_acquire)) opt_init();
   return g_opt[opt].load(std::memory_order_relaxed);

@@ -143,6 +143,7 @@ __device__ inline unsigned xcd_remap(unsigned bid, unsigned nwg) {
 }
 
 // ---- run-time switches and caches (abi.cpp) -------------------------------------
+bool om_option_is_set(int opt);                                           // its environment variable was given (OM_OPT_SCAN_GROWTH only)
 int om_option(int opt);                                                   // OM_OPT_* of include/openmatch_hip.h
 int om_t5_lut_device(int L, int buckets, int max_dist, const int** out);  // device-resident bucket table, built once
 

@@ -80,6 +80,11 @@ __device__ __forceinline__ void g7_point(G7Src& src, const T* __restrict__ A, in
 __device__ __forceinline__ void g7_dma(const char* base, uint32_t lane_off, uint32_t lds) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(lane_off), "s"(base) : "memory");
 }
+// the same with the non-temporal cache policy: for streams that ONE CU reads ONCE (the index pass of a small query batch);
+// MI355X_MICROARCH.md "nt-weights": issued -> landed -18 %, chip 6.5-6.8 instead of 6.4 TB/s
+__device__ __forceinline__ void g7_dma_nt(const char* base, uint32_t lane_off, uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(lds), "v"(lane_off), "s"(base) : "memory");
+}
 // the same with a full 64-bit address per lane (unrelated sources in one instruction)
 __device__ __forceinline__ void g7_dma_v(const void* lane_ptr, uint32_t lds) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(lane_ptr) : "memory");

@@ -359,166 +359,24 @@ __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7(
   G7_WAIT_VM(0);
 }
 
-// Small query batches (<= 64 queries): the scan is a pass over the whole f16 index (13.6 GB at 8.8 M x 768) that has to
+// Small query batches (<= 128 queries): the scan is a pass over the whole f16 index (13.6 GB at 8.8 M x 768) that has to
 // run at HBM speed.  The generic 128-query tile spends 1.7 PFLOP of matrix-core time on padding at Q = 1 (3.99 ms per
-// search in round 1, profiles/r01_search_shapes.jsonl) -- this kernel keeps NB 32-query column blocks resident in LDS for
-// the whole kernel ([block][K step][32 queries][128 B], 48 KiB per block at d = 768) and streams units of the index
-// through an LDS-DMA ring (the generation-7 unit layout and swizzle), one barrier per unit:
-//     NB = 1 (Q <= 32)   256-row units (32 KiB), three slots: two units (64 KiB per CU) in flight, 8 MFMAs per wave and unit
-//     NB = 2 (Q <= 64)   128-row units (16 KiB), four slots: three units (48 KiB per CU) in flight, 8 MFMAs per wave and unit
-//                        (round 3: batches of 33-64 fell onto the generation-2 filter kernel at 4.33 ms per search -- 0.39 of
-//                        the HBM rate -- although their 0.9 TFLOP of MFMA work is nothing; now one index pass as well)
-// Persistent: one workgroup per CU walks row tiles blockIdx, blockIdx + grid, ...  Whole 256-row tiles only (the host gives
-// the tail to the generic kernel).  LDS: ring | query blocks = 96 + 48 KiB or 64 + 96 KiB.
-#define SS_RING(NB) ((NB) == 1 ? 3 : 4)
-#define SS_UROWS(NB) ((NB) == 1 ? 256 : 128)
-#define SS_UBYTES(NB) (SS_UROWS(NB) * G7_ROW_BYTES)
-#define SS_QOFF(NB) (SS_RING(NB) * SS_UBYTES(NB))
-#define SS_LDS(NB) (SS_QOFF(NB) + (NB) * 12 * 4096)
-template <typename T, int NB>
-__global__ __launch_bounds__(G6_THREADS) void sim_stream_kernel(
-    const T* __restrict__ rows, int64_t nrows, uint32_t row_base, const T* __restrict__ queries, int64_t nq, int64_t d,
-    const float* __restrict__ thr, u64* __restrict__ keys, unsigned* __restrict__ cnt) {
-  typedef typename MmaOps<T>::frag_t frag_t;
-  constexpr int RING = SS_RING(NB), UROWS = SS_UROWS(NB), UBYTES = SS_UBYTES(NB);
-  constexpr int IPU = UROWS / 32;                // DMA instructions per wave and unit
-  constexpr int RB = UROWS / 128;                // 32-row blocks per wave and unit
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int lane = threadIdx.x & 63;
-  asm volatile("" : "+v"(lane));
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nk = (int)((d * 2) / G7_ROW_BYTES);
-  const int64_t ntiles = nrows / UROWS;
-  const int my_tiles = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
-  if (my_tiles <= 0) return;
-  const int units = my_tiles * nk;
-  const uint32_t lds0 = g7_lds_addr(smem);
-
-  // DMA offsets of a unit: instruction i of this wave moves rows (i*4 + wave)*8 .. +7, lane -> row (lane >> 3),
-  // physical chunk (lane & 7) <- source chunk (lane & 7) ^ ((row >> 1) & 7)
-  uint32_t off[IPU];
-#pragma unroll
-  for (int i = 0; i < IPU; ++i) {
-    const int r = (i * 4 + wave) * 8 + (lane >> 3);
-    off[i] = (uint32_t)(r * d * 2) + ((((lane & 7) ^ ((r >> 1) & 7))) << 4);
-  }
-  // the queries: block nb, K step ks, rows (queries) 8 j .. 8 j + 7 per instruction; wave w takes K steps w, w + 4, ...
-  {
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      uint32_t qoff[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = j * 8 + (lane >> 3);
-        const int qr = nb * 32 + r;
-        const int rr = qr < nq ? qr : (int)nq - 1;              // padding rows repeat the last query (their threshold is +inf)
-        qoff[j] = (uint32_t)(rr * d * 2) + ((((lane & 7) ^ ((r >> 1) & 7))) << 4);
-      }
-      for (int ks = wave; ks < nk; ks += 4)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          g7_dma((const char*)queries + ks * G7_ROW_BYTES, qoff[j], lds0 + SS_QOFF(NB) + (nb * 12 + ks) * 4096 + j * 1024);
-    }
-  }
-  float th[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) th[nb] = thr[nb * 32 + (lane & 31)];
-  auto issue = [&](int u) {
-    const int64_t tile = blockIdx.x + (int64_t)(u / nk) * gridDim.x;
-    const char* base = (const char*)(rows + tile * UROWS * d) + (u % nk) * G7_ROW_BYTES;
-    const uint32_t dst = lds0 + (u % RING) * UBYTES + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < IPU; ++i) g7_dma(base, off[i], dst + i * 4096);
-  };
-#pragma unroll
-  for (int u = 0; u < RING - 1; ++u)
-    if (u < units) issue(u);
-
-  const int half = lane >> 5, l31 = lane & 31, key = (l31 >> 1) & 7;
-  const int arow = (wave * (UROWS / 4) + l31) * G7_ROW_BYTES;   // + rt * 32 rows
-  const int brow = l31 * G7_ROW_BYTES;
-  f32x16_t acc[RB][NB];
-#pragma unroll
-  for (int rt = 0; rt < RB; ++rt)
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rt][nb][r] = 0.f;
-  int ks = 0;
-  int64_t tile = blockIdx.x;
-  for (int u = 0; u < units; ++u) {
-    // unit u (and the queries) landed; up to RING - 2 younger units may be in flight
-    const int younger = units - 1 - u;
-    if (RING == 4 && younger >= 2) G7_WAIT_VM(2 * IPU);
-    else if (younger >= 1) G7_WAIT_VM(IPU);
-    else G7_WAIT_VM(0);
-    __builtin_amdgcn_s_barrier();                              // ... for every wave; and unit u - 1 has been read by all
-    if (u + RING - 1 < units) issue(u + RING - 1);
-    const char* ua = smem + (u % RING) * UBYTES + arow;
-    const char* ub = smem + SS_QOFF(NB) + ks * 4096 + brow;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int slot = (((kk << 1) | half) ^ key) << 4;
-      frag_t b[NB], a[RB];
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) b[nb] = *(const frag_t*)(ub + nb * 12 * 4096 + slot);
-#pragma unroll
-      for (int rt = 0; rt < RB; ++rt) a[rt] = *(const frag_t*)(ua + rt * 32 * G7_ROW_BYTES + slot);
-#pragma unroll
-      for (int rt = 0; rt < RB; ++rt)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-          MmaOps<T>::mma(a[rt], b[nb], acc[rt][nb]);            // acc[rt][nb][r]: row 8(r>>2) + 4 half + (r&3) of the 32-row block, query 32 nb + l31
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (++ks == nk) {
-      ks = 0;
-#pragma unroll
-      for (int rt = 0; rt < RB; ++rt)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          const f32x16_t a = acc[rt][nb];
-          float mx = fmaxf(fmaxf(a[0], a[1]), a[2]);
-#pragma unroll
-          for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, a[r]), a[r + 1]);
-          mx = fmaxf(mx, a[15]);
-          if (mx >= th[nb]) {                                      // rare by construction of the thresholds
-            // one atomic per lane and block, not per survivor: with one query every append of the round lands on the
-            // same counter, and the first rounds keep a third of their rows (~5 k same-address atomics were ~50 us of a
-            // 57 us round -- profiles/r02_search_q1_timeline.log)
-            const uint32_t id0 = row_base + (uint32_t)(tile * UROWS) + wave * (UROWS / 4) + rt * 32 + 4 * half;
-            const int qi = nb * 32 + l31;
-            unsigned n = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) n += a[r] >= th[nb] ? 1u : 0u;
-            unsigned pos = atomicAdd(cnt + qi, n);
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              if (a[r] >= th[nb]) {
-                if (pos < SORT_CAP) keys[(int64_t)qi * SORT_CAP + pos] = pack_key(a[r], id0 + (r & 3) + 8 * (r >> 2));
-                ++pos;
-              }
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[rt][nb][r] = 0.f;
-        }
-      tile += gridDim.x;
-    }
-  }
-}
-
-// Round 3: the same pass with the queries in REGISTERS.  The kernel above is bound by the bytes it keeps in flight: LDS is
-// shared between the resident query blocks (48 KiB each) and the ring, which left 64 / 48 KiB of index per CU in flight
-// (NB = 1 / 2: 6.0 / 4.6 TB/s inside the kernel, Little's law at ~2.7 us of loaded latency) and no room at all for a third
-// block.  A wave's B operand never changes: its 32-query block is 12 K steps x 4 MFMA sub-steps x 16 bytes per lane = 192
+// search in round 1, profiles/r01_search_shapes.jsonl).  Round 2 kept one or two 32-query blocks resident in LDS beside a
+// three- / four-slot ring (2.56 ms at Q = 1, 3.35 at Q = 64, nothing for 65-128 queries: 4.6 ms on the generation-2 filter
+// kernel) -- LDS shared between the resident blocks (48 KiB each) and the ring had no room for a third block.  Round 3 moves
+// the queries into registers.  A wave's B operand never changes: its 32-query block is 12 K steps x 4 MFMA sub-steps x 16 bytes per lane = 192
 // VGPRs of the 512 this one-wave-per-SIMD kernel owns, loaded once from global memory in fragment order.  The whole LDS
 // (160 KiB) is the ring: ten slots of 128 rows x 128 bytes, nine units = 144 KiB per CU in flight.
 //     NB = 1 (Q <= 32)    the four waves share the block and take 32 rows of a unit each
 //     NB = 2 (Q <= 64)    waves 0, 2 / 1, 3 hold block 0 / 1 and take 64 rows each
 //     NB = 4 (Q <= 128)   one block per wave, every wave takes all 128 rows (each reads the whole unit: 64 KiB of fragment
 //                         reads + 16 KiB of DMA per unit is the LDS port's limit at ~15 TB/s, above what HBM delivers)
-// Persistent over 128-row tiles (blockIdx, blockIdx + grid, ...); whole tiles only; d <= 768 (K steps past d / 64 are
-// compiled but skipped: the K loop is unrolled so that the query fragments are indexed statically).
+// Persistent over 128-row tiles (blockIdx, blockIdx + grid, ...); whole tiles only; 256 <= d <= 768 (K steps past d / 64 are
+// compiled but skipped: the K loop is unrolled so that the query fragments are indexed statically).  The index stream is
+// fetched with the non-temporal policy (read once, by one CU).  Measured (8 841 823 x 768, k = 1000, profiles/r03_search_small_batches.log):
+// Q = 1 2.42-2.62 ms (round 2: 2.56-2.65 on like boxes), Q = 64 3.14-3.22 (3.35), Q = 128 3.59-3.68 (4.63).  What more
+// bytes in flight did NOT buy: the kernel's own time still grows with the resident blocks (2.15 / 2.9 / 3.3 ms for one / two /
+// four, rocprofv3) although neither the matrix core (16 MFMAs per 16 KiB unit at most) nor the LDS port is near a limit.
 #define SR_RING 10
 #define SR_UROWS 128
 #define SR_UBYTES (SR_UROWS * G7_ROW_BYTES)
@@ -528,7 +386,7 @@ __global__ __launch_bounds__(G6_THREADS) void sim_stream_kernel(
 template <typename T, int NB>
 __global__ __launch_bounds__(G6_THREADS) void sim_stream_reg_kernel(
     const T* __restrict__ rows, int64_t nrows, uint32_t row_base, const T* __restrict__ queries, int64_t nq, int64_t d,
-    const float* __restrict__ thr, u64* __restrict__ keys, unsigned* __restrict__ cnt) {
+    const float* __restrict__ thr, u64* __restrict__ keys, unsigned* __restrict__ cnt, int nt) {
   typedef typename MmaOps<T>::frag_t frag_t;
   constexpr int RBW = NB;                        // 32-row blocks per wave and unit: 4 / NB waves share a query block
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -580,8 +438,13 @@ __global__ __launch_bounds__(G6_THREADS) void sim_stream_reg_kernel(
   auto issue = [&]() {
     const char* base = (const char*)(rows + i_tile * SR_UROWS * d) + i_ks * G7_ROW_BYTES;
     const uint32_t dst = lds0 + i_slot * SR_UBYTES + wave * 1024;
+    if (nt) {                                                    // (wave-uniform) the index is read once per pass, by one CU
 #pragma unroll
-    for (int i = 0; i < SR_IPU; ++i) g7_dma(base, off[i], dst + i * 4096);
+      for (int i = 0; i < SR_IPU; ++i) g7_dma_nt(base, off[i], dst + i * 4096);
+    } else {
+#pragma unroll
+      for (int i = 0; i < SR_IPU; ++i) g7_dma(base, off[i], dst + i * 4096);
+    }
     if (++i_ks == nk) { i_ks = 0; i_tile += gridDim.x; }
     if (++i_slot == SR_RING) i_slot = 0;
     ++issued;
@@ -595,6 +458,43 @@ __global__ __launch_bounds__(G6_THREADS) void sim_stream_reg_kernel(
   for (int rt = 0; rt < RBW; ++rt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+  // Appends are split around the next tile.  A 32 x 32 score block holds a survivor about once per tile and query block, and
+  // the list position comes from a returning atomic: ~1.1 us under a streaming load (MI355X_MICROARCH.md "dequeue"), during
+  // which this wave issues nothing -- written in line (returning atomic, then the stores) that was RBW round trips per
+  // 8-12 us tile, and the compiler's wait for the result is vmcnt(0): the whole ring.  Instead the tile's scores move to a
+  // shadow register set, the atomics of all its blocks leave together (inline assembly: invisible to the compiler's
+  // counting), and four units into the NEXT tile -- 16 younger DMA instructions in the in-order queue -- the positions are
+  // there and the keys are stored.
+  f32x16_t sh[RBW];
+  unsigned pn[RBW], ppos[RBW];
+#pragma unroll
+  for (int rt = 0; rt < RBW; ++rt) { pn[rt] = 0; ppos[rt] = 0; }
+  bool pend = false;                                             // (wave-uniform) a tile's appends are in flight
+  int64_t ptile = 0;
+  int since = 0;                                                 // units issued since its atomics
+  const int qi = nb * 32 + l31;
+  auto retire = [&]() {
+    // every atomic has returned once at most the younger operations are outstanding
+    if (since >= 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int rt = 0; rt < RBW; ++rt) asm volatile("" : "+v"(ppos[rt]));      // (the results are read after the wait)
+#pragma unroll
+    for (int rt = 0; rt < RBW; ++rt) {
+      if (pn[rt]) {
+        const uint32_t id0 = row_base + (uint32_t)(ptile * SR_UROWS) + rgroup * (32 * RBW) + rt * 32 + 4 * half;
+        unsigned pos = ppos[rt];
+        u64* const kq = keys + (int64_t)qi * SORT_CAP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (sh[rt][r] >= th) {
+            if (pos < SORT_CAP) kq[pos] = pack_key(sh[rt][r], id0 + (r & 3) + 8 * (r >> 2));
+            ++pos;
+          }
+      }
+    }
+    pend = false;
+  };
   int c_slot = 0, u = 0;
   int64_t tile = blockIdx.x;
   for (int ti = 0; ti < my_tiles; ++ti) {
@@ -616,7 +516,7 @@ __global__ __launch_bounds__(G6_THREADS) void sim_stream_reg_kernel(
           default: G7_WAIT_VM(0); break;
         }
         __builtin_amdgcn_s_barrier();                            // ... for every wave; and unit u - 1 has been read by all
-        if (issued < units) issue();                             // into the slot of unit u - 1
+        if (issued < units) { issue(); ++since; }                // into the slot of unit u - 1
         const char* ua = smem + c_slot * SR_UBYTES + arow;
         // the row fragments of sub-step kk + 1 are read under the MFMAs of sub-step kk (order pinned: left alone the
         // compiler reads two fragments, waits, multiplies, reads two ... and every LDS round trip is exposed)
@@ -640,35 +540,31 @@ __global__ __launch_bounds__(G6_THREADS) void sim_stream_reg_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (++c_slot == SR_RING) c_slot = 0;
         ++u;
+        if (ks == 3 && pend) retire();                           // the previous tile's appends: positions are back by now
       }
     }
+    // (the dispatcher sends d < 256 -- fewer than four K steps, no retire point inside a tile -- to the generic kernels)
+    bool any = false;
 #pragma unroll
     for (int rt = 0; rt < RBW; ++rt) {
-      const f32x16_t a = acc[rt];
-      float mx = fmaxf(fmaxf(a[0], a[1]), a[2]);
+      sh[rt] = acc[rt];
+      unsigned n = 0;
 #pragma unroll
-      for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, a[r]), a[r + 1]);
-      mx = fmaxf(mx, a[15]);
-      if (mx >= th) {                                            // rare by construction of the thresholds
-        // one atomic per lane and block, not per survivor (with one query every append of a round lands on one counter)
-        const uint32_t id0 = row_base + (uint32_t)(tile * SR_UROWS) + rgroup * (32 * RBW) + rt * 32 + 4 * half;
-        const int qi = nb * 32 + l31;
-        unsigned n = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) n += a[r] >= th ? 1u : 0u;
-        unsigned pos = atomicAdd(cnt + qi, n);
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (a[r] >= th) {
-            if (pos < SORT_CAP) keys[(int64_t)qi * SORT_CAP + pos] = pack_key(a[r], id0 + (r & 3) + 8 * (r >> 2));
-            ++pos;
-          }
+      for (int r = 0; r < 16; ++r) n += sh[rt][r] >= th ? 1u : 0u;
+      pn[rt] = n;
+      // one atomic per lane and block, not per survivor (with one query every append of a round lands on one counter)
+      if (n) {
+        unsigned* const cp = cnt + qi;
+        asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=&v"(ppos[rt]) : "v"(cp), "v"(n) : "memory");
       }
+      any = any || __builtin_amdgcn_ballot_w64(n != 0) != 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
     }
+    if (any) { pend = true; ptile = tile; since = 0; }
     tile += gridDim.x;
   }
+  if (pend) { since = 0; retire(); }
   G7_WAIT_VM(0);
 }
 
@@ -1116,7 +1012,7 @@ struct Scan {
           hipLaunchKernelGGL((sim_filter_kernel6<f16_t>), dim3((unsigned)ntn), dim3(G6_THREADS), G6_LDS_BYTES, s, idx16 + (r0 + whole) * d,
                              n - whole, (uint32_t)(r0 + whole), ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8);
       } else if (wide) SCAN(sim_filter_kernel6, G6_THREADS, G6_LDS_BYTES, f16_t, idx16, ws.qb);
-      else if (nq <= 128 && (d * 2) / G7_ROW_BYTES <= SR_NKMAX && om_option(OM_OPT_SCAN_GEN7) && !(om_option(OM_OPT_SEARCH_DEBUG) & 2)) {
+      else if (nq <= 128 && (d * 2) / G7_ROW_BYTES <= SR_NKMAX && (d * 2) / G7_ROW_BYTES >= 4 && om_option(OM_OPT_SCAN_GEN7)) {
         // the HBM-speed pass for small batches (queries in registers, the whole LDS a ring) over the whole 128-row tiles;
         // the generic kernel takes the ragged tail
         const int64_t whole = n & ~(int64_t)127;
@@ -1124,30 +1020,12 @@ struct Scan {
           int ncu = g7_num_cus();
           if (whole / SR_UROWS < ncu) ncu = (int)(whole / SR_UROWS);
 #define STREAM(NB_) hipLaunchKernelGGL((sim_stream_reg_kernel<f16_t, NB_>), dim3((unsigned)ncu), dim3(G6_THREADS), SR_LDS, s, idx16 + r0 * d, whole, \
-                                       (uint32_t)r0, ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt)
+                                       (uint32_t)r0, ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, (om_option(OM_OPT_SEARCH_DEBUG) & 4) ? 0 : 1)
           if (nq <= 32) STREAM(1); else if (nq <= 64) STREAM(2); else STREAM(4);
 #undef STREAM
         }
         if (n > whole)
           hipLaunchKernelGGL((sim_filter_kernel<f16_t>), dim3((unsigned)((nq + G2_BN - 1) / G2_BN)), dim3(G2_THREADS), G2_LDS_BYTES, s, idx16 + (r0 + whole) * d, n - whole,
-                             (uint32_t)(r0 + whole), ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8);
-      } else if (nq <= 64 && (d * 2) / G7_ROW_BYTES <= 12 && om_option(OM_OPT_SCAN_GEN7)) {
-        // (A/B switch, OM_OPT_SEARCH_DEBUG bit 1: the round-2 kernels with the query blocks in LDS)
-        const int64_t whole = n & ~(int64_t)255;
-        if (whole) {
-          int ncu = g7_num_cus();
-          if (nq <= 32) {
-            if (whole / 256 < ncu) ncu = (int)(whole / 256);
-            hipLaunchKernelGGL((sim_stream_kernel<f16_t, 1>), dim3((unsigned)ncu), dim3(G6_THREADS), SS_LDS(1), s, idx16 + r0 * d, whole,
-                               (uint32_t)r0, ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt);
-          } else {
-            if (whole / 128 < ncu) ncu = (int)(whole / 128);
-            hipLaunchKernelGGL((sim_stream_kernel<f16_t, 2>), dim3((unsigned)ncu), dim3(G6_THREADS), SS_LDS(2), s, idx16 + r0 * d, whole,
-                               (uint32_t)r0, ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt);
-          }
-        }
-        if (n > whole)
-          hipLaunchKernelGGL((sim_filter_kernel<f16_t>), dim3(1), dim3(G2_THREADS), G2_LDS_BYTES, s, idx16 + (r0 + whole) * d, n - whole,
                              (uint32_t)(r0 + whole), ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8);
       } else SCAN(sim_filter_kernel, G2_THREADS, G2_LDS_BYTES, f16_t, idx16, ws.qb);
     } else {
@@ -1199,7 +1077,8 @@ struct Scan {
       // few queries: the scan is one HBM pass whatever the thresholds, the per-round launches are what costs -- few, long
       // rounds; many queries: an append costs the scan a slow path, the selection ~0.3 ms -- many short rounds with
       // tight thresholds (profiles/r02_scan_trace_*.log).  Expected survivors of a chunk ~ list * chunk / at.
-      const double growth = nq <= 32 ? 400.0 : (double)std::max(5, om_option(OM_OPT_SCAN_GROWTH));
+      // (33-128 queries, one index pass per round set on the register-resident stream kernel: 100 % measured best of 60 / 100 / 200)
+      const double growth = nq <= 32 ? 400.0 : (nq <= 128 && !om_option_is_set(OM_OPT_SCAN_GROWTH) ? 100.0 : (double)std::max(5, om_option(OM_OPT_SCAN_GROWTH)));
       const double room = 0.75 * (double)(SORT_CAP - list);
       const double want = std::min(room, (double)list * growth / 100.0);
       // selection launches of the rounds: lists are ~list + want keys long; when twice that margin fits 4096 keys the
@@ -1327,8 +1206,6 @@ extern "C" int om_sim_topk(int mode, const float* queries, int64_t n_queries,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES));
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel6<f16_t>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES));
-    OM_HIP(hipFuncSetAttribute((const void*)sim_stream_kernel<f16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SS_LDS(1)));
-    OM_HIP(hipFuncSetAttribute((const void*)sim_stream_kernel<f16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SS_LDS(2)));
     OM_HIP(hipFuncSetAttribute((const void*)sim_stream_reg_kernel<f16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS));
     OM_HIP(hipFuncSetAttribute((const void*)sim_stream_reg_kernel<f16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS));
     OM_HIP(hipFuncSetAttribute((const void*)sim_stream_reg_kernel<f16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS));

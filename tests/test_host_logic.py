@@ -374,3 +374,51 @@ def test_packed_weight_cache_survives_deepcopy_and_pickle():
     m3 = pickle.loads(pickle.dumps(m))
     assert len(m3.__dict__[_PACK_CACHE_ATTR]) == 0 and torch.equal(m3.weight, m.weight)
     assert len(cache) == 1
+
+
+def test_deferred_append_positions_are_not_read_before_their_wait():
+    """sim_stream_reg_kernel (csrc/search.hip) issues the list-counter atomics of a tile as inline assembly and reads
+    their results only behind a hand-written s_waitcnt four units later -- the compiler does not know the destination
+    registers are written asynchronously, so a copy it might insert (loop-carried value) would read them too early.
+    Compile the translation unit to assembly and check, for every instantiation, that no instruction between an atomic
+    and the retire point's wait touches the atomic's destination register."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(REPO, "openmatch_amd", "csrc", "search.hip")
+    out = os.path.join(REPO, "build", "search_check.s")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-x", "hip", "-Wno-unused-result", "-w",
+                    "--cuda-device-only", "-S", src, "-o", out], check=True)
+    text = open(out).read()
+
+    def uses(n, line):
+        if any(int(m.group(1)) == n for m in re.finditer(r"\bv(\d+)\b", line)):
+            return True
+        return any(int(m.group(1)) <= n <= int(m.group(2)) for m in re.finditer(r"\bv\[(\d+):(\d+)\]", line))
+
+    seen = 0
+    for nb in (1, 2, 4):
+        m = re.search(r"^_Z21sim_stream_reg_kernelIDF16_Li%dE.*?\.amdhsa_kernel" % nb, text, re.S | re.M)
+        assert m, nb
+        lines = m.group(0).split("\n")
+        atomics = [i for i, l in enumerate(lines) if "global_atomic_add" in l]
+        assert len(atomics) == nb, (nb, atomics)
+        first = next(i for i, l in enumerate(lines) if "s_waitcnt vmcnt(36)" in l)
+        header = max(i for i, l in enumerate(lines[:first]) if "Loop Header" in l)
+        # the retire point: the hand-written vmcnt(16) that is not part of a unit's wait ladder (no vmcnt(12) right behind it)
+        retire = next(i for i, l in enumerate(lines) if "s_waitcnt vmcnt(16)" in l and i > first
+                      and "vmcnt(12)" not in "".join(lines[i:i + 12]))
+        for a in atomics:
+            reg = int(re.search(r"global_atomic_add v(\d+),", lines[a]).group(1))
+            # rest of the loop body behind the atomic (the staging code ends the body), then from the loop header to the wait
+            tail_end = next((i for i in range(a + 1, len(lines)) if "s_cbranch" in lines[i] and ("LBB" in lines[i])), a + 40)
+            span = list(range(a + 1, tail_end)) + list(range(header, retire))
+            early = [lines[i].strip() for i in span if uses(reg, lines[i]) and not lines[i].strip().startswith(";")
+                     and "global_atomic_add" not in lines[i]]
+            assert not early, (nb, reg, early[:3])
+            seen += 1
+    assert seen == 7
