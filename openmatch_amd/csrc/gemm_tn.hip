@@ -298,8 +298,11 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_dma_kernel(
 // the tokens -- no split, no atomics (a tile has one owner: C is read, added to and written back with plain accesses), the
 // epilogue amortised over 288 steps, and enough tiles to fill the chip.
 //   workgroup   256 (n) x 256 (k) outputs, four waves of 128 x 128 (256 accumulators per lane), one per CU
-//   step        32 tokens: per operand eight 32-column fragments x two 16-token k steps = sixteen 1 KiB regions in the
-//               transposing-read layout of gemm_tn_dma_kernel; stage = 32 KiB (A | B), FOUR stages (128 KiB)
+//   step        32 tokens: per operand eight 32-column fragments x two 16-token k steps x two transposing reads = thirty-two
+//               512-byte half regions in the read layout of gemm_tn_dma_kernel; stage = 32 KiB (A | B), FOUR stages (128 KiB).
+//               A DMA instruction fills the 1 KiB WINDOW of read r of a fragment PAIR (f = 2p, 2p + 1): its lanes cover
+//               8 tokens x 64 columns = eight whole 128-byte lines (a window per fragment, as the 128 x 128 kernel has it,
+//               is sixteen HALF lines per instruction -- the request pattern that bounded the generation-6 GEMM)
 //   pipeline    steps t+1, t+2 in flight while step t is computed; ONE barrier per step, in its middle: there every wave
 //               has its part of step t+1 in LDS (vmcnt counted by hand) and has left step t-1, so step t+3 is issued into
 //               that stage and the fragments of step t+1 are read under the second half's MFMAs
@@ -341,22 +344,27 @@ __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_wide_kernel(const TwBat
   const int nsteps = bt.steps;
   const bool do_bias = bias != nullptr && k0 == 0 && wk == 0;
 
-  // DMA: this wave fills the regions (fragment f = (wave >> 1) * 4 + i, k step ks = wave & 1), i = 0..3, of each operand;
-  // lane -> (token, columns) exactly as in gemm_tn_dma_kernel
-  const int dr = lane >> 5, dg = (lane >> 3) & 3, dtl = (lane >> 1) & 3, dh = lane & 1;
-  const int drow = (wave & 1) * 16 + (dg >> 1) * 8 + dr * 4 + dtl;
-  const uint32_t a_off = (uint32_t)((drow * lda + (dg & 1) * 16 + dh * 8) * 2);
-  const uint32_t b_off = (uint32_t)((drow * ldb + (dg & 1) * 16 + dh * 8) * 2);
-  const char* a_at = (const char*)(A + n0 + (wave >> 1) * 128);            // wave-uniform, advanced per step issued
-  const char* b_at = (const char*)(B + k0 + (wave >> 1) * 128);
+  // DMA: this wave fills the four windows (k step ks, read r) of fragment pair p = wave of each operand.  Window
+  // (p, ks, r) at ((p * 2 + ks) * 2 + r) KiB = [read r of fragment 2p | read r of fragment 2p + 1], 512 bytes each in the
+  // lane order of gemm_tn_dma_kernel's reads:
+  //     lane l = j*32 + g*8 + tl*2 + h  ->  token ks*16 + (g>>1)*8 + r*4 + tl,  columns (2p + j)*32 + (g&1)*16 + h*8 .. + 7
+  // -- the eight lanes of a token (j, g & 1, h) read 128 contiguous bytes.
+  const int dj = lane >> 5, dg = (lane >> 3) & 3, dtl = (lane >> 1) & 3, dh = lane & 1;
+  const int drow = (dg >> 1) * 8 + dtl;                                    // + ks * 16 + r * 4 (per instruction, scalar)
+  const uint32_t a_off = (uint32_t)((drow * lda + dj * 32 + (dg & 1) * 16 + dh * 8) * 2);
+  const uint32_t b_off = (uint32_t)((drow * ldb + dj * 32 + (dg & 1) * 16 + dh * 8) * 2);
+  const char* a_at = (const char*)(A + n0 + wave * 64);                    // wave-uniform, advanced per step issued
+  const char* b_at = (const char*)(B + k0 + wave * 64);
   const size_t a_step = (size_t)TW_TOK * lda * 2, b_step = (size_t)TW_TOK * ldb * 2;
+  const size_t a_row4 = (size_t)4 * lda * 2, b_row4 = (size_t)4 * ldb * 2;  // four tokens
   const uint32_t lds0 = g7_lds_addr(smem);
-  const uint32_t dreg = (uint32_t)((((wave >> 1) * 4) * 2 + (wave & 1)) * 1024);   // region (f, ks) at (f * 2 + ks) KiB
+  const uint32_t dreg = (uint32_t)(wave * 4096);                           // the pair's four windows
+  // instruction i = ks * 2 + r: tokens ks * 16 + r * 4 + ..  ->  window i of the pair
 #define TW_ISSUE(STAGE)                                                                                \
   do {                                                                                                 \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
-      g7_dma(a_at + i * 64, a_off, lds0 + (STAGE) * TW_STAGE + dreg + i * 2048);                       \
-      g7_dma(b_at + i * 64, b_off, lds0 + (STAGE) * TW_STAGE + 16384 + dreg + i * 2048);               \
+      g7_dma(a_at + ((i >> 1) * 4 + (i & 1)) * a_row4, a_off, lds0 + (STAGE) * TW_STAGE + dreg + i * 1024); \
+      g7_dma(b_at + ((i >> 1) * 4 + (i & 1)) * b_row4, b_off, lds0 + (STAGE) * TW_STAGE + 16384 + dreg + i * 1024); \
     }                                                                                                  \
     a_at += a_step; b_at += b_step;                                                                    \
   } while (0)
@@ -372,8 +380,9 @@ __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_wide_kernel(const TwBat
 
   auto frag2 = [](v4s a, v4s b) { return (bf16x8_t){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; };
   // fragment I of k step KS of the stage at ST: A fragments wn * 4 + I, B fragments wk * 4 + I (two transposing reads each)
-#define TW_FRAG_A(F, ST, KS, I) { const char* p_ = (ST) + ((wn * 4 + (I)) * 2 + (KS)) * 1024 + lane * 8; F[I] = frag2(tn_read(p_), tn_read(p_ + 512)); }
-#define TW_FRAG_B(F, ST, KS, I) { const char* p_ = (ST) + 16384 + ((wk * 4 + (I)) * 2 + (KS)) * 1024 + lane * 8; F[I] = frag2(tn_read(p_), tn_read(p_ + 512)); }
+  // (fragment f = 2p + j of k step KS: read r at window (p, KS, r), half j)
+#define TW_FRAG_A(F, ST, KS, I) { const char* p_ = (ST) + ((wn * 2 + ((I) >> 1)) * 4 + (KS) * 2) * 1024 + ((I) & 1) * 512 + lane * 8; F[I] = frag2(tn_read(p_), tn_read(p_ + 1024)); }
+#define TW_FRAG_B(F, ST, KS, I) { const char* p_ = (ST) + 16384 + ((wk * 2 + ((I) >> 1)) * 4 + (KS) * 2) * 1024 + ((I) & 1) * 512 + lane * 8; F[I] = frag2(tn_read(p_), tn_read(p_ + 1024)); }
 #define TW_READ(FA, FB, ST, KS)                                                                        \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) { TW_FRAG_A(FA, ST, KS, i) TW_FRAG_B(FB, ST, KS, i) }
   // One k step of 16 tokens: 16 MFMAs from (FA, FB); behind each of the first eight, ONE fragment (two reads) of the next
@@ -387,8 +396,9 @@ __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_wide_kernel(const TwBat
     else if (q <= 4) TW_FRAG_B(NB, NST, NKS, q - 1)                                                    \
     else if (q <= 7) TW_FRAG_A(NA, NST, NKS, q - 4)                                                    \
     else if (DMA_COND) {                /* MFMAs 8-15 each cover one DMA issue of step t + 3 (wave-uniform branch) */ \
-      if (q & 1) g7_dma(b_at + ((q - 8) >> 1) * 64, b_off, lds0 + (DMA_STAGE) * TW_STAGE + 16384 + dreg + ((q - 8) >> 1) * 2048); \
-      else g7_dma(a_at + ((q - 8) >> 1) * 64, a_off, lds0 + (DMA_STAGE) * TW_STAGE + dreg + ((q - 8) >> 1) * 2048); \
+      const int i_ = (q - 8) >> 1;                                                                     \
+      if (q & 1) g7_dma(b_at + ((i_ >> 1) * 4 + (i_ & 1)) * b_row4, b_off, lds0 + (DMA_STAGE) * TW_STAGE + 16384 + dreg + i_ * 1024); \
+      else g7_dma(a_at + ((i_ >> 1) * 4 + (i_ & 1)) * a_row4, a_off, lds0 + (DMA_STAGE) * TW_STAGE + dreg + i_ * 1024); \
     }                                                                                                  \
     if (do_bias && (q & 3) == 3) {      /* the fragment holds 8 tokens of column (lane & 31): add them up under the MFMAs */ \
       const uint4 w = __builtin_bit_cast(uint4, FA[q >> 2]);                                           \

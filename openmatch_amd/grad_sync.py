@@ -4,7 +4,9 @@ What DistributedDataParallel does for the reference (HF Trainer wraps the model 
 gradients are averaged across ranks in buckets WHILE the backward still runs.  Here the HIP backward writes every
 gradient of an encoder into one f32 arena, layer by layer from the top (openmatch_amd/train.py), and records one event per
 layer on its stream (om_encoder_train_set_layer_events).  `GradSync.reduce_arena` hands each bucket -- a contiguous arena
-slice of `bucket_layers` layers; xGMI rings are per-link bound, so few large collectives -- to the collective as soon as
+slice of `bucket_layers` layers (default 4: the layer group of the backward's deferred weight-gradient launches,
+OM_OPT_TRAIN_WGRAD_BATCH -- a group's progress events are recorded together, behind that launch); xGMI rings are per-link
+bound, so few large collectives -- to the collective as soon as
 its lowest layer's event has fired, on a side stream; `finish()` makes the caller's stream wait for all of them.  A flat
 copy of nothing: the bucket IS the slice.
 
@@ -23,7 +25,7 @@ def active():
 
 
 class GradSync:
-    def __init__(self, world_size: int, bucket_layers: int = 3):
+    def __init__(self, world_size: int, bucket_layers: int = 4):
         self.world = int(world_size)
         self.bucket_layers = max(1, int(bucket_layers))
         self.works = []

@@ -300,7 +300,7 @@ class DRTrainer:
         # accumulation or the gradient cache the per-parameter gradients are sums over several backward passes, which are
         # reduced once after the last one instead
         from ..grad_sync import GradSync
-        sync = GradSync(W, getattr(a, "grad_bucket_layers", 3)) if (
+        sync = GradSync(W, getattr(a, "grad_bucket_layers", 4)) if (
             W > 1 and accum == 1 and type(self).training_step is DRTrainer.training_step
             and getattr(a, "overlap_grad_allreduce", True)) else None
         if resume_from_checkpoint:
