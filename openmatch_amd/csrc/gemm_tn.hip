@@ -303,22 +303,25 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_dma_kernel(
 //               A DMA instruction fills the 1 KiB WINDOW of read r of a fragment PAIR (f = 2p, 2p + 1): its lanes cover
 //               8 tokens x 64 columns = eight whole 128-byte lines (a window per fragment, as the 128 x 128 kernel has it,
 //               is sixteen HALF lines per instruction -- the request pattern that bounded the generation-6 GEMM)
-//   pipeline    steps t+1, t+2 in flight while step t is computed; ONE barrier per step, in its middle: there every wave
-//               has its part of step t+1 in LDS (vmcnt counted by hand) and has left step t-1, so step t+3 is issued into
-//               that stage and the fragments of step t+1 are read under the second half's MFMAs
+//   pipeline    steps t+1 .. t+3 in flight while step t is computed; ONE barrier per step, in its middle: there every wave
+//               has its part of step t+1 in LDS (vmcnt counted by hand) and has left step t-1, so step t+4 is issued into
+//               that stage and the fragments of step t+1 are read under the second half's MFMAs.  (Four stages -- a lead of
+//               two steps, ~3.9 k cycles -- left the waves parked 38 % of their time: SQ_WAIT_ANY, profiles/
+//               r03_pmc_wgrad_batch_and_small_scan.txt; the loaded LDS-DMA latency is ~2.7 us.)
 //   LDS port    per step 64 KiB of fragment reads + 32 KiB of DMA writes per 1024 MFMA cycles = 75 % (128 x 128 tiles: 150 %)
 //   XCD         workgroup b runs on XCD b % 8: tile = (b % 8) * chunk + b / 8 -- each XCD walks a CONTIGUOUS run of
 //               tiles, whose A (dY) panel is shared by the tiles of one row and stays in that L2
 constexpr int TW_TOK = 32;
 constexpr int TW_STAGE = 32768;
-constexpr int TW_STAGES = 4;
+constexpr int TW_STAGES = 5;                   // 160 KiB: the whole LDS (one workgroup per CU anyway)
 constexpr int TW_MAXP = 48;
 struct TwProblem { const bf16_t* A; const bf16_t* B; float* C; float* bias; int lda, ldb, ldc, ntk; };
 struct TwBatch { int n, chunk, total, steps; int tile_start[TW_MAXP + 1]; TwProblem p[TW_MAXP]; };
 
 #define TW_WAIT(K_)                                                                                    \
   do {                                                                                                 \
-    if ((K_) >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                                   \
+    if ((K_) >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                                   \
+    else if ((K_) == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                              \
     else if ((K_) == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                               \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                              \
   } while (0)
@@ -408,26 +411,30 @@ __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_wide_kernel(const TwBat
     __builtin_amdgcn_sched_barrier(0);                                                                 \
   }
 
-  const int pre = nsteps < 3 ? nsteps : 3;
+  const int pre = nsteps < TW_STAGES - 1 ? nsteps : TW_STAGES - 1;
   for (int sidx = 0; sidx < pre; ++sidx) TW_ISSUE(sidx);
-  TW_WAIT(pre - 1);                                   // step 0 has landed; steps 1, 2 may be in flight
+  TW_WAIT(pre - 1);                                   // step 0 has landed; steps 1 .. 3 may be in flight
   __syncthreads();
   bf16x8_t fa0[4], fb0[4], fa1[4], fb1[4];
   TW_READ(fa0, fb0, smem, 0)
+  int cs = 0;                                         // stage of step t; step t + 1 -> cs + 1, step t + 4 -> cs - 1 (mod 5)
   for (int t = 0; t < nsteps; ++t) {
-    const char* st = smem + (t & 3) * TW_STAGE;
+    const char* st = smem + cs * TW_STAGE;
     __builtin_amdgcn_sched_barrier(0);
     TW_HALF(fa0, fb0, fa1, fb1, st, 1, false, 0)      // tokens 0-15 of step t; reads its tokens 16-31
     if (t + 1 < nsteps) {
-      TW_WAIT(t + 2 < nsteps ? 1 : 0);                // this wave's part of step t + 1 is in LDS (step t + 2 may be in flight)
-      __syncthreads();                                // ... everyone's; and every wave has left step t - 1: its stage takes step t + 3
+      const int later = nsteps - 2 - t;               // steps behind t + 1 that exist
+      TW_WAIT(later < 2 ? later : 2);                 // this wave's part of step t + 1 is in LDS (steps t + 2, t + 3 may be in flight)
+      __syncthreads();                                // ... everyone's; and every wave has left step t - 1: its stage takes step t + 4
     }
-    const bool issue = t + 3 < nsteps;
-    const int istage = (t + 3) & 3;
-    const char* sn = smem + ((t + 1) & 3) * TW_STAGE; // (past the last step: a stage nobody writes any more; the fragments are not used)
+    const bool issue = t + TW_STAGES - 1 < nsteps;
+    const int istage = cs == 0 ? TW_STAGES - 1 : cs - 1;
+    const int ns = cs + 1 == TW_STAGES ? 0 : cs + 1;
+    const char* sn = smem + ns * TW_STAGE;            // (past the last step: a stage nobody writes any more; the fragments are not used)
     __builtin_amdgcn_sched_barrier(0);
-    TW_HALF(fa1, fb1, fa0, fb0, sn, 0, issue, istage) // tokens 16-31 of step t; reads tokens 0-15 of step t + 1; issues step t + 3
+    TW_HALF(fa1, fb1, fa0, fb0, sn, 0, issue, istage) // tokens 16-31 of step t; reads tokens 0-15 of step t + 1; issues step t + 4
     if (issue) { a_at += a_step; b_at += b_step; }
+    cs = ns;
   }
 #undef TW_READ
 #undef TW_HALF

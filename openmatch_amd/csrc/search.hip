@@ -537,11 +537,19 @@ __global__ __launch_bounds__(G6_THREADS) void sim_stream_reg_kernel(
             MmaOps<T>::mma(a[kk & 1][rt], bq[ks][kk], acc[rt]); // acc[rt][r]: row 8(r>>2) + 4 half + (r&3) of the 32-row block, query 32 nb + l31
         }
         G7_FENCE_();
+        // the accumulators' home is the AGPR file: without the pin the compiler keeps them in VGPRs across the (wave-uniform)
+        // K-step branches and copies all of them in and out around every unit's MFMAs -- 32 RBW v_accvgpr moves per unit that
+        // also wait for the matrix core to drain (rocprofv3: 88 VALU instructions per unit, the pass 35 / 55 % longer with two /
+        // four resident blocks than with one)
+#pragma unroll
+        for (int rt = 0; rt < RBW; ++rt) asm volatile("" : "+a"(acc[rt]));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (++c_slot == SR_RING) c_slot = 0;
         ++u;
         if (ks == 3 && pend) retire();                           // the previous tile's appends: positions are back by now
       }
+#pragma unroll
+      for (int rt = 0; rt < RBW; ++rt) asm volatile("" : "+a"(acc[rt]));   // (also where the skipped and the taken K step meet)
     }
     // (the dispatcher sends d < 256 -- fewer than four K steps, no retire point inside a tile -- to the generic kernels)
     bool any = false;
