@@ -450,7 +450,7 @@ def main():
         if world == 1 and not a.no_extra:
             # small batches: the scan is one pass over the f16 index -- latency and the implied HBM stream rate
             small = {}
-            for nq_s in (1, 64):
+            for nq_s in (1, 64, 128):
                 qs = q_local[:nq_s]
                 index.search_device(qs, a.topk)
                 torch.cuda.synchronize(); t1 = time.perf_counter()

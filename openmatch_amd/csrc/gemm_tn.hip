@@ -318,6 +318,11 @@ constexpr int TW_MAXP = 48;
 struct TwProblem { const bf16_t* A; const bf16_t* B; float* C; float* bias; int lda, ldb, ldc, ntk; };
 struct TwBatch { int n, chunk, total, steps; int tile_start[TW_MAXP + 1]; TwProblem p[TW_MAXP]; };
 
+// acc + lo + hi of a packed bf16 pair (v_dot2c_f32_bf16 with a pair of ones)
+typedef __bf16 tw_bf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float tw_sum2(uint32_t pair, float acc) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tw_bf2, pair), __builtin_bit_cast(tw_bf2, 0x3f803f80u), acc, false);
+}
 #define TW_WAIT(K_)                                                                                    \
   do {                                                                                                 \
     if ((K_) >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                                   \
@@ -403,10 +408,11 @@ __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_wide_kernel(const TwBat
       if (q & 1) g7_dma(b_at + ((i_ >> 1) * 4 + (i_ & 1)) * b_row4, b_off, lds0 + (DMA_STAGE) * TW_STAGE + 16384 + dreg + i_ * 1024); \
       else g7_dma(a_at + ((i_ >> 1) * 4 + (i_ & 1)) * a_row4, a_off, lds0 + (DMA_STAGE) * TW_STAGE + dreg + i_ * 1024); \
     }                                                                                                  \
-    if (do_bias && (q & 3) == 3) {      /* the fragment holds 8 tokens of column (lane & 31): add them up under the MFMAs */ \
+    if (do_bias && (q & 3) == 3) {      /* the fragment holds 8 tokens of column (lane & 31): add them up under the MFMAs --  \
+                                           four v_dot2c_f32_bf16 against (1, 1) instead of 14 shift / mask / add instructions: the \
+                                           two waves that carry the bias sums reach the step's barrier with the other two */ \
       const uint4 w = __builtin_bit_cast(uint4, FA[q >> 2]);                                           \
-      bsum[q >> 2] += (__uint_as_float(w.x << 16) + __uint_as_float(w.x & 0xffff0000u)) + (__uint_as_float(w.y << 16) + __uint_as_float(w.y & 0xffff0000u)) + \
-                      (__uint_as_float(w.z << 16) + __uint_as_float(w.z & 0xffff0000u)) + (__uint_as_float(w.w << 16) + __uint_as_float(w.w & 0xffff0000u)); \
+      bsum[q >> 2] = tw_sum2(w.x, tw_sum2(w.y, bsum[q >> 2])) + tw_sum2(w.z, tw_sum2(w.w, 0.f));       \
     }                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
   }
