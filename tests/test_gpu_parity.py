@@ -274,7 +274,8 @@ def _adjudicate(I_gpu, I_ref, P, Q, k):
 @pytest.mark.parametrize("precision", ["f32", "f16_rescore"])
 @pytest.mark.parametrize("n,nq,k,clustered", [(1000, 100, 100, True), (50000, 64, 1000, True),
                                                (50000, 17, 10, False), (300, 5, 1000, False),
-                                               (50000, 128, 1000, True), (40077, 97, 100, False), (20000, 33, 1000, False)])
+                                               (50000, 128, 1000, True), (40077, 97, 100, False), (20000, 33, 1000, False),
+                                               (30011, 300, 100, True)])      # (> 128 queries, not a multiple of 256: generation 7 over the padded query panel)
 def test_flat_ip_search_matches_oracle(precision, n, nq, k, clustered):
     from openmatch_amd.index import FlatIPIndex
     rng = np.random.default_rng(n + k)
