@@ -100,8 +100,8 @@ void om_debug_gemm_gen(int gen);
                                    * planes (value = hi + lo; the reference's autocast keeps it in f32) -- 1 - cos against the fp32 chain
                                    * 1e-5 instead of 4.8e-5 for +2 bytes per element at the two residual sites of a layer; 0: one plane */
 #define OM_OPT_GEMM_VARIANT 12     /* 0 (default): automatic tile-generation choice; 1 | 2 | 6 pin a generation (A/B measurements) */
-#define OM_OPT_SEARCH_DEBUG 13     /* bit 0: om_sim_topk logs every round (rows done, chunk, list lengths) to stderr; bit 1 (A/B): batches of up
-                                    * to 64 queries on the round-2 stream kernels (query blocks in LDS) */
+#define OM_OPT_SEARCH_DEBUG 13     /* bit 0: om_sim_topk logs every round (rows done, chunk, list lengths) to stderr; bit 2 (A/B): the small-batch scan
+                                    * fetches the index with the default cache policy instead of non-temporal loads (env OM_SEARCH_DEBUG) */
 #define OM_OPT_TRAIN_WGRAD_BATCH 14 /* layers per deferred weight-gradient launch of the bf16 BERT backward (default 4; 0: one launch per
                                      * weight gradient as in round 2): the backward keeps every layer's dY and one om_gemm_tn_acc_batch
                                      * launch per group of layers computes their weight gradients (env OM_TRAIN_WGRAD_BATCH) */
