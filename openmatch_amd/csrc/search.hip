@@ -432,11 +432,13 @@ __global__ __launch_bounds__(G6_THREADS) void sim_stream_reg_kernel(
     const int r = (i * 4 + wave) * 8 + (lane >> 3);
     off[i] = (uint32_t)(r * d * 2) + ((((lane & 7) ^ ((r >> 1) & 7))) << 4);
   }
-  // issue cursor: (tile, K step, slot) of the next unit to fetch
-  int64_t i_tile = blockIdx.x;
+  // issue cursor: (source address, K step, slot) of the next unit to fetch -- advanced incrementally (the per-unit scalar
+  // work counts: at two and four resident blocks a unit's instruction path is as long as its share of the HBM stream)
+  const char* i_base = (const char*)(rows + (int64_t)blockIdx.x * SR_UROWS * d);
+  const int64_t i_tile_step = (int64_t)gridDim.x * SR_UROWS * d * 2 - (int64_t)nk * G7_ROW_BYTES;   // last K step of a tile -> first of the next
   int i_ks = 0, i_slot = 0, issued = 0;
   auto issue = [&]() {
-    const char* base = (const char*)(rows + i_tile * SR_UROWS * d) + i_ks * G7_ROW_BYTES;
+    const char* base = i_base;
     const uint32_t dst = lds0 + i_slot * SR_UBYTES + wave * 1024;
     if (nt) {                                                    // (wave-uniform) the index is read once per pass, by one CU
 #pragma unroll
@@ -445,7 +447,8 @@ __global__ __launch_bounds__(G6_THREADS) void sim_stream_reg_kernel(
 #pragma unroll
       for (int i = 0; i < SR_IPU; ++i) g7_dma(base, off[i], dst + i * 4096);
     }
-    if (++i_ks == nk) { i_ks = 0; i_tile += gridDim.x; }
+    i_base += G7_ROW_BYTES;
+    if (++i_ks == nk) { i_ks = 0; i_base += i_tile_step; }
     if (++i_slot == SR_RING) i_slot = 0;
     ++issued;
   };
@@ -503,18 +506,11 @@ __global__ __launch_bounds__(G6_THREADS) void sim_stream_reg_kernel(
       if (ks < nk) {                                             // wave-uniform
         // unit u landed; up to RING - 1 younger units may be in flight
         const int younger = issued - 1 - u;
-        switch (younger) {
-          case 9: G7_WAIT_VM(9 * SR_IPU); break;
-          case 8: G7_WAIT_VM(8 * SR_IPU); break;
-          case 7: G7_WAIT_VM(7 * SR_IPU); break;
-          case 6: G7_WAIT_VM(6 * SR_IPU); break;
-          case 5: G7_WAIT_VM(5 * SR_IPU); break;
-          case 4: G7_WAIT_VM(4 * SR_IPU); break;
-          case 3: G7_WAIT_VM(3 * SR_IPU); break;
-          case 2: G7_WAIT_VM(2 * SR_IPU); break;
-          case 1: G7_WAIT_VM(1 * SR_IPU); break;
-          default: G7_WAIT_VM(0); break;
-        }
+        // steady state: the eight units behind unit u are in flight (the ninth is issued behind the barrier below).  While
+        // the ring drains -- the last units of a launch -- everything outstanding is waited for: a ladder of exact counts
+        // compiled to ~40 scalar instructions and a dozen taken branches per unit, a third of what a unit may cost at all
+        if (younger == SR_RING - 2) G7_WAIT_VM((SR_RING - 2) * SR_IPU);
+        else G7_WAIT_VM(0);
         __builtin_amdgcn_s_barrier();                            // ... for every wave; and unit u - 1 has been read by all
         if (issued < units) { issue(); ++since; }                // into the slot of unit u - 1
         const char* ua = smem + c_slot * SR_UBYTES + arow;

@@ -407,11 +407,10 @@ def test_deferred_append_positions_are_not_read_before_their_wait():
         lines = m.group(0).split("\n")
         atomics = [i for i, l in enumerate(lines) if "global_atomic_add" in l]
         assert len(atomics) == nb, (nb, atomics)
-        first = next(i for i, l in enumerate(lines) if "s_waitcnt vmcnt(36)" in l)
+        first = next(i for i, l in enumerate(lines) if "s_waitcnt vmcnt(32)" in l)      # a unit's steady-state wait
         header = max(i for i, l in enumerate(lines[:first]) if "Loop Header" in l)
-        # the retire point: the hand-written vmcnt(16) that is not part of a unit's wait ladder (no vmcnt(12) right behind it)
-        retire = next(i for i, l in enumerate(lines) if "s_waitcnt vmcnt(16)" in l and i > first
-                      and "vmcnt(12)" not in "".join(lines[i:i + 12]))
+        # the retire point: the only hand-written vmcnt(16) of the kernel
+        retire = next(i for i, l in enumerate(lines) if "s_waitcnt vmcnt(16)" in l and i > first)
         for a in atomics:
             reg = int(re.search(r"global_atomic_add v(\d+),", lines[a]).group(1))
             # rest of the loop body behind the atomic (the staging code ends the body), then from the loop header to the wait
