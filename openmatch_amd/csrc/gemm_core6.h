@@ -140,17 +140,24 @@ __device__ inline void gemm_mainloop6_run(const char* (&pa)[4], const char* (&pb
     }                                                                                                    \
     G6_FENCE();                                                                                          \
   }
+#define G6_PIN() _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) asm volatile("" : "+a"(acc[q_ >> 2][q_ & 3]))
 #define G6_STEP(ISSUE, VMW, NEXT)                                                                        \
   do {                                                                                                   \
     const char* cur = smem + o_cur;                                                                      \
     const char* nxt = smem + o_nxt;                                                                      \
     if (tr && tid == 0 && t < 12) tr[3 + t] = clock64();                                                 \
+    G6_PIN();                                                                                            \
     /* slot o_far held tile t-1: every wave finished reading it before the barrier of step t-1 */        \
     G6_HALF(a0, b0, a1, b1, cur, slot1, !(PROBE & 2), (ISSUE) && !(PROBE & 1), pa, 0)                    \
+    G6_PIN();                                                                                            \
     __builtin_amdgcn_s_waitcnt(VMW);     /* vmcnt(n) lgkmcnt(0): tile t+1 landed, my reads done */       \
     if (!(PROBE & 4)) __builtin_amdgcn_s_barrier();                                                      \
     G6_FENCE();                                                                                          \
     G6_HALF(a1, b1, a0, b0, nxt, slot0, (NEXT) && !(PROBE & 2), (ISSUE) && !(PROBE & 1), pb, G6_OPERAND_BYTES) \
+    /* the accumulators' home is the AGPR file: left alone, the register allocator carries one of the 16 tiles in     \
+       VGPRs across the loop's back edge and copies it in and out around its two MFMAs of every step (32-48 v_accvgpr    \
+       moves per K step that also wait for the matrix core -- found by scanning every MFMA loop of the library) */     \
+    G6_PIN();                                                                                            \
     o_cur = o_nxt;                                                                                       \
     o_nxt = o_nxt + G6_STAGE_BYTES == G6_LDS_BYTES ? 0 : o_nxt + G6_STAGE_BYTES;                         \
     o_far = o_far + G6_STAGE_BYTES == G6_LDS_BYTES ? 0 : o_far + G6_STAGE_BYTES;                         \
@@ -168,6 +175,7 @@ __device__ inline void gemm_mainloop6_run(const char* (&pa)[4], const char* (&pb
   if (t + 1 < nk) { G6_STEP(false, 0x0070, true); ++t; }    // vmcnt(0)
   G6_STEP(false, 0x0070, false);                            // last tile
 #undef G6_STEP
+#undef G6_PIN
 #undef G6_HALF
 #undef G6_DMA
 #undef G6_FENCE
