@@ -421,3 +421,53 @@ def test_deferred_append_positions_are_not_read_before_their_wait():
             assert not early, (nb, reg, early[:3])
             seen += 1
     assert seen == 7
+
+
+def test_mfma_loops_keep_their_accumulators_in_agprs():
+    """A register-allocation trap of hipcc on gfx950: unless every accumulator tile is pinned with
+    asm("" : "+a"(acc)) where control flow joins, one of them may get a VGPR home and be copied in and out of the AGPR file
+    around its MFMAs in EVERY loop iteration (32-128 v_accvgpr moves per iteration were found in the generation-6 K loop and
+    in the small-batch scan late in round 3).  Compile the translation units of the hot loops to assembly and require that
+    no loop holding MFMAs also holds v_accvgpr moves -- except the listed ones, whose moves are their work (the scan's
+    filter reads every score) or belong to paths outside the benchmarks (T5 gated-activation training epilogues)."""
+    import re
+    import shutil
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    units = ["search.hip", "gemm_wide6_bf16.hip", "gemm_tn.hip", "gemm_wide7.hip"]
+    allowed = ("sim_filter_kernel7",                      # the persistent tile loop contains the filter: 256 accumulator reads per tile
+               "gemm_nt_kernel6IttLi3",                   # gelu_new (T5 v1.1 gated) training epilogues: one tile still bounces
+               "gemm_nt_kernel6IDF16_DF16_Li3")
+    os.makedirs(os.path.join(REPO, "build"), exist_ok=True)
+
+    def compile_unit(u):
+        out = os.path.join(REPO, "build", "agpr_check_" + u.replace(".hip", ".s"))
+        subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-x", "hip", "-Wno-unused-result", "-w",
+                        "--cuda-device-only", "-S", os.path.join(REPO, "openmatch_amd", "csrc", u), "-o", out], check=True)
+        return open(out).read()
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        texts = list(pool.map(compile_unit, units))
+    checked, offenders = 0, []
+    for text in texts:
+        for m in re.finditer(r"^(\S+):\s*; @\1\n(.*?)^\s*\.amdhsa_kernel \1", text, re.S | re.M):
+            name, lines = m.group(1), m.group(2).split("\n")
+            for i, line in enumerate(lines):
+                head = re.match(r"^(\.LBB\d+_\d+):.*Loop Header", line)
+                if not head:
+                    continue
+                back = [j for j, x in enumerate(lines) if j > i and re.search(r"s_c?branch\S*\s+" + re.escape(head.group(1)) + r"\s*$", x)]
+                if not back:
+                    continue
+                body = lines[i:max(back)]
+                n_mfma = sum("v_mfma" in x for x in body)
+                n_move = sum("v_accvgpr" in x for x in body)
+                if n_mfma:
+                    checked += 1
+                    if n_move and not any(a in name for a in allowed):
+                        offenders.append((name[:70], head.group(1), n_mfma, n_move))
+    assert checked >= 20, checked
+    assert not offenders, offenders
