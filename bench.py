@@ -6,8 +6,11 @@
 
 A *step* = one pass of the encoder hot path over one batch of synthetic MS-MARCO-shaped token
 ids already resident in HBM: ids -> embeddings+LN -> 12 x (QKV GEMM, fused attention, out-proj
-GEMM + residual, LN, FFN GEMMs + GELU, LN) -> CLS pooling -> 768-d embedding.  bf16 MFMA with f32
-accumulation (the reference's documented `--fp16` mode), random-init bert-base weights.
+GEMM + residual, LN, FFN GEMMs + GELU, LN) -> CLS pooling -> 768-d embedding.  float16 MFMA with f32
+accumulation -- the reference's own 16-bit format (`--fp16` = torch.cuda.amp float16, retriever/dense_retriever.py:76,151;
+docs/dr-msmarco-passage.md:74) and the 16-bit mode whose dot products stay within `north_star`'s 1e-4 of the fp32 chain;
+`--precision bf16` runs the two-plane bfloat16 path (reported as the `bf16` sub-object of the default line).
+Random-init bert-base weights.
 `value` = passages/s over all ranks (weak scaling: each rank encodes its own batches).
 The search leg (same process, after the encode leg) serves Q queries against an 8 841 823 x 768
 index sharded over the ranks: all-gather of query vectors -> per-shard filtered MFMA scan +
@@ -34,6 +37,8 @@ GFLOP_PER_PASSAGE = 22.347       # 12*(24*L*H^2 + 4*L^2*H), L=128, H=768 (BASELI
 GEMM_GFLOP_PER_PASSAGE = 12 * 24 * 128 * 768 ** 2 / 1e9
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+# rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md) of this command, committed per round and per format
+TRAFFIC_FILES = {"f16": "r04_hbm_traffic_f16.json", "bf16": "r03_hbm_traffic.json"}
 
 
 def parse():
@@ -49,7 +54,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the strided-subsample parity leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the f32 and training sub-objects")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--precision", default="f16", choices=["bf16", "f16", "f32"],
+                    help="compute format of the headline encode leg (default float16: the reference's --fp16 format)")
     return ap.parse_args()
 
 
@@ -168,7 +174,7 @@ def cpu_baseline(no_search, sample_batches):
     return out
 
 
-def parity_leg(model_bf16, lm, batches, device, index=None, queries=None, topk=1000):
+def parity_leg(model_16, lm, batches, device, index=None, queries=None, topk=1000, headline="f16"):
     """parity of THIS run's configuration on a strided subsample against the CPU oracle.
     Encode: every 16th passage of the first two timed batches through (a) the bf16 path as benchmarked (inside its
     1024-passage batch) and (b) the exact-f32 path, against oracle/encoder_ref.py in fp32.  Search: a strided
@@ -188,12 +194,14 @@ def parity_leg(model_bf16, lm, batches, device, index=None, queries=None, topk=1
     with torch.no_grad():
         _, ref = encoder_ref.encode(sd, lm.config, "bert", {"input_ids": ids, "attention_mask": msk}, "first")
     ref = ref.double()
-    got16 = torch.cat([model_bf16(passage=b).p_reps[sel] for b in batches[:2]]).double().cpu()
+    other = "bfloat16" if headline == "f16" else "float16"
+    got_head = torch.cat([model_16(passage=b).p_reps[sel] for b in batches[:2]]).double().cpu()
     m32 = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype="float32")).to(device).eval()
     got32 = m32(passage={"input_ids": ids.to(device), "attention_mask": msk.to(device)}).p_reps.double().cpu()
-    mf16 = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype="float16")).to(device).eval()
-    gotf16 = torch.cat([mf16(passage=b).p_reps[sel] for b in batches[:2]]).double().cpu()
-    del mf16
+    m_other = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype=other)).to(device).eval()
+    got_other = torch.cat([m_other(passage=b).p_reps[sel] for b in batches[:2]]).double().cpu()
+    del m_other
+    got16, gotf16 = (got_other, got_head) if headline == "f16" else (got_head, got_other)
     cos = torch.nn.functional.cosine_similarity(got16, ref, dim=1)
     cosf = torch.nn.functional.cosine_similarity(gotf16, ref, dim=1)
     dots_ref = ref[:16] @ ref.t()
@@ -201,6 +209,7 @@ def parity_leg(model_bf16, lm, batches, device, index=None, queries=None, topk=1
         "sample": f"{ids.shape[0]} passages (every {stride}th of two timed batches) vs oracle/encoder_ref.py fp32, {time.perf_counter() - t0:.1f} s of CPU",
         "bf16_min_cosine": round(float(cos.min()), 6), "bf16_mean_cosine": round(float(cos.mean()), 6),
         "bf16_max_abs_ddot": round(float(((got16[:16] @ got16.t()) - dots_ref).abs().max()), 4),
+        "bf16_max_rel_ddot": float((((got16[:16] @ got16.t()) - dots_ref).abs() / dots_ref.abs().clamp_min(1.0)).max()),
         "f16_min_cosine": round(float(cosf.min()), 8), "f16_mean_cosine": round(float(cosf.mean()), 8),
         "f16_max_abs_ddot": round(float(((gotf16[:16] @ gotf16.t()) - dots_ref).abs().max()), 4),
         "f16_max_rel_ddot": float((((gotf16[:16] @ gotf16.t()) - dots_ref).abs() / dots_ref.abs().clamp_min(1.0)).max()),
@@ -367,12 +376,11 @@ def main():
     gemm_tflops = flops.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
     peak = PEAK_BF16_TFLOPS if half else 157.3
     traffic, tsrc = None, None   # HBM bytes per launch of the dominant kernel: the round's committed rocprofv3 --pmc passes of this command
-    import glob
-    cand = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_traffic.json")))
-    if half and a.batch == 1024 and cand:
+    tfile = os.path.join(REPO, "profiles", TRAFFIC_FILES.get(a.precision, ""))
+    if half and a.batch == 1024 and os.path.isfile(tfile):      # named per precision and round: a stale file is never picked up by sort order
         try:
-            tj = json.load(open(cand[-1]))
-            traffic, tsrc = tj["hbm_bytes_per_launch"], "profiles/" + os.path.basename(cand[-1]) + ": " + tj.get("note", "")
+            tj = json.load(open(tfile))
+            traffic, tsrc = tj["hbm_bytes_per_launch"], "profiles/" + os.path.basename(tfile) + ": " + tj.get("note", "")
         except Exception:
             traffic = None
     roofline = {
@@ -460,27 +468,30 @@ def main():
                 small["q%d" % nq_s] = {"ms": round(dt_s * 1e3, 2), "index_stream_TBps": round(scan_bytes / dt_s / 1e12, 2),
                                        "frac_of_hbm_peak": round(scan_bytes / dt_s / 1e9 / PEAK_HBM_GBS, 3)}
             search["small_batch_latency"] = small
-        if rank == 0 and world == 1 and not a.no_parity and a.precision == "bf16":
-            parity = parity_leg(model, lm, batches, device, index, q_local, a.topk)
+        if rank == 0 and world == 1 and not a.no_parity and half:
+            parity = parity_leg(model, lm, batches, device, index, q_local, a.topk, headline=a.precision)
         del index
         torch.cuda.empty_cache()
-    if parity is None and rank == 0 and world == 1 and not a.no_parity and a.precision == "bf16":
-        parity = parity_leg(model, lm, batches, device)
+    if parity is None and rank == 0 and world == 1 and not a.no_parity and half:
+        parity = parity_leg(model, lm, batches, device, headline=a.precision)
 
     # ---------------- exact-f32 mode and the training step (sub-objects; N = 1 only) ----------
     f32_mode, train, f16_mode = None, None, None
-    if rank == 0 and world == 1 and not a.no_extra and a.precision == "bf16":
-        # the float16 mode on the SAME timed batches: same kernels and MFMA rate, 11-bit mantissa activations
+    other16 = "bf16" if a.precision == "f16" else "f16"
+    if rank == 0 and world == 1 and not a.no_extra and half:
+        # the OTHER 16-bit format on the SAME timed batches (same kernels and MFMA rate): bfloat16 carries its pre-LayerNorm
+        # residual stream in two planes to stay inside the reference's 16-bit envelope, float16 needs one
         m16 = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first",
-                                  model_args=NS(encoder_only=False, dtype="float16")).to(device).eval()
+                                  model_args=NS(encoder_only=False, dtype={"bf16": "bfloat16", "f16": "float16"}[other16])).to(device).eval()
         for i in range(a.warmup):
             m16(passage=batches[i % len(batches)])
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(a.steps):
             m16(passage=batches[i % len(batches)])
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
-        f16_mode = {"metric": "passages/s encode in the float16 MFMA mode (the reference's --fp16 format; same kernels as bf16, "
-                              "three more mantissa bits per stored activation; parity in `parity.encode.f16_*`)",
+        f16_mode = {"metric": ("passages/s encode in the bfloat16 MFMA mode (two-plane residual stream; parity in `parity.encode.bf16_*`)"
+                               if other16 == "bf16" else
+                               "passages/s encode in the float16 MFMA mode (the reference's --fp16 format; parity in `parity.encode.f16_*`)"),
                     "value": round(a.batch / dt, 1), "unit": "passages/s", "ms_per_step": round(dt * 1e3, 3),
                     "algorithmic_tflops": round(a.batch * GFLOP_PER_PASSAGE / 1e3 / dt, 1),
                     "frac_of_mfma_peak": round(a.batch * GFLOP_PER_PASSAGE / 1e3 / dt / PEAK_BF16_TFLOPS, 4)}
@@ -522,7 +533,7 @@ def main():
                        "passages_per_step_per_gpu": a.batch, "seq_len": L, "global_batch": a.batch * world,
                        "index_rows": a.index_rows, "queries": a.queries, "topk": a.topk,
                        "weights": "random-init BertConfig() seed 0", "parallelism": f"shard{world}"},
-            "roofline": roofline, "search": search, "parity": parity, "f16": f16_mode, "f32": f32_mode, "train": train, "cpu_baseline": cpu,
+            "roofline": roofline, "search": search, "parity": parity, other16: f16_mode, "f32": f32_mode, "train": train, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -105,7 +105,10 @@ void om_debug_gemm_gen(int gen);
 #define OM_OPT_TRAIN_WGRAD_BATCH 14 /* layers per deferred weight-gradient launch of the bf16 BERT backward (default 4; 0: one launch per
                                      * weight gradient as in round 2): the backward keeps every layer's dY and one om_gemm_tn_acc_batch
                                      * launch per group of layers computes their weight gradients (env OM_TRAIN_WGRAD_BATCH) */
-#define OM_OPT_COUNT 15
+#define OM_OPT_GEMM_MAX_GRID 15    /* 0 (default): the persistent 16-bit GEMM takes every CU; > 0: at most this many workgroups (one per CU) --
+                                    * two half-batch encoder forwards on two streams share the chip with 128 each */
+#define OM_OPT_GEMM_STAGGER 16     /* 0 (default); > 0: the persistent GEMM's workgroups start in four phases, this many x 256 shader cycles apart */
+#define OM_OPT_COUNT 17
 int om_debug_option(int opt, int value);
 /* the attention kernel alone (bf16 qkv [B*L, 3H] -> ctx [B*L, H]; mask [B, L] int64), for timing: csrc/kernels.h omk_attention */
 int om_debug_attention(const void* qkv, void* ctx, const int64_t* mask, int64_t B, int L, int H, int heads, void* stream);

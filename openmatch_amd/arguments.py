@@ -26,7 +26,7 @@ class ModelArguments:
     add_linear_head: bool = _f(False)
     projection_in_dim: int = _f(768)
     projection_out_dim: int = _f(768)
-    dtype: Optional[str] = _f("float32", "float32 | float16 | bfloat16; 16-bit selects the bf16 MFMA path")
+    dtype: Optional[str] = _f("float32", "float32 | float16 | bfloat16; float16 is the reference's --fp16 format (BERT-family inference runs it natively; T5 and every training path are served in bfloat16)")
     encoder_only: bool = _f(False, "load only the encoder stack of a T5 checkpoint")
     pos_token: Optional[str] = _f(None, "re-ranker: token meaning 'relevant'")
     neg_token: Optional[str] = _f(None, "re-ranker: token meaning 'irrelevant'")

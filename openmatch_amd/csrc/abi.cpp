@@ -104,6 +104,10 @@ void opt_init() {
   g_opt[OM_OPT_SEARCH_DEBUG] = e ? (atoi(e) ? atoi(e) : 1) : 0;
   e = getenv("OM_TRAIN_WGRAD_BATCH");
   g_opt[OM_OPT_TRAIN_WGRAD_BATCH] = e ? atoi(e) : 4;
+  e = getenv("OM_GEMM_MAX_GRID");
+  g_opt[OM_OPT_GEMM_MAX_GRID] = e ? atoi(e) : 0;
+  e = getenv("OM_GEMM_STAGGER");
+  g_opt[OM_OPT_GEMM_STAGGER] = e ? atoi(e) : 0;
   g_opt_init.store(true);
 }
 }  // namespace

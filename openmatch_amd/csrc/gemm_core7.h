@@ -234,6 +234,85 @@ __device__ __forceinline__ void gemm_mainloop7_run(const SRC& src, int nk, char*
   __builtin_amdgcn_s_barrier();                             // everyone is done with the ring
 }
 
+// ---- the continuous ring (round 4) --------------------------------------------------------------------------------------
+// The K loop above restarts the ring for every tile: the epilogue issues K step 0 of the next tile (16 DMA instructions
+// among its stores), the tile start issues K step 1 (16 more, ~1.3-1.9 k cycles of issue time at ~100 cycles each while
+// the stores drain) and the first steps run on a cold pipeline.  The tile traces of round 4 (profiles/r04_probe1_*) show
+// that every phase of a tile costs the SAME number of shader cycles whatever else the chip does (8 ... 256 active CUs:
+// K loop 32.9 k, plain epilogue 7.8 k, tile start 3.8-4.3 k) -- the whole tile is a per-CU instruction stream, and the
+// 12 k cycles outside the K loop are 28 % of an encoder layer.  Here the ring NEVER stops: step t of a tile always issues
+// steps t + 1 (second half of B) and t + 2, and once t + 2 reaches the tile's step count the sources are the NEXT tile's
+// first steps.  When a tile's last step ends, steps 0 and 1 of the next tile are already landed / in flight in four of
+// the five units; the epilogue lives in the fifth (the spare: this wave's own 1 KiB slices of it, so no barrier), and
+// the next tile's first MFMA follows the epilogue's last store without a wait, a barrier or a DMA issue in between.
+//
+// On entry (steady state and first tile alike): step 0 of the tile is landed and published (ring.ac / ring.bc), A(1) is
+// issued into ring.an, the FIRST half of B(1) (instructions 0-3) into ring.bn; acc holds the tile's initial values.
+// Needs nk >= 3 (the sources of step t + 2 are at most one tile ahead).
+struct G7Ring { int ac, bc, an, bn, sp; };      // byte offsets of the five units: A / B of the current step, of the next, spare
+__device__ __forceinline__ void g7_ring_reset(G7Ring& r) {
+  r.ac = 0; r.bc = G7_UNIT_BYTES; r.an = 2 * G7_UNIT_BYTES; r.bn = 3 * G7_UNIT_BYTES; r.sp = 4 * G7_UNIT_BYTES;
+}
+template <typename T>
+__device__ __forceinline__ void gemm_mainloop7_cont(const G7SrcU& src, const char* cur_a, const char* cur_b,
+                                                    const char* next_a, const char* next_b, int nk, char* smem, G7Ring& ring,
+                                                    f32x16_t (&acc)[4][4], unsigned long long* tr = nullptr) {
+  typedef typename MmaOps<T>::frag_t frag_t;
+  static_assert(sizeof(T) == 2, "128-byte K steps: 16-bit operands only");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..3
+  const int wm = wave >> 1, wn = wave & 1;
+  const int key = (lane >> 1) & 7;
+  const int half = lane >> 5;
+  int slot[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) slot[kk] = (((kk << 1) | half) ^ key) << 4;
+  const int rowa = (wm * 128 + (lane & 31)) * G7_ROW_BYTES;
+  const int rowb = (wn * 128 + (lane & 31)) * G7_ROW_BYTES;
+  const uint32_t lds0 = g7_lds_addr(smem);
+  const char* ka = cur_a + 2 * G7_ROW_BYTES;      // source of A(t + 2)
+  const char* kb = cur_b + 2 * G7_ROW_BYTES;      // source of B(t + 2)
+  const char* kbp = cur_b + G7_ROW_BYTES;         // source of B(t + 1): its second half is still to be issued
+  int u_ac = ring.ac, u_bc = ring.bc, u_an = ring.an, u_bn = ring.bn, u_sp = ring.sp;
+  frag_t a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a0[i] = *(const frag_t*)(smem + u_ac + rowa + i * 32 * G7_ROW_BYTES + slot[0]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b0[i] = *(const frag_t*)(smem + u_bc + rowb + i * 32 * G7_ROW_BYTES + slot[0]);
+
+#define G7_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // one k sub-step: 16 MFMAs from (AF, BF); the first eight each cover one fragment read into (AN, BN) from (UA, UB) chunk
+  // SLOT; MFMAs 8, 10, 12, 14 each cover one DMA issue of operand P (source base PTR, instructions DBASE .. DBASE + 3) into UNIT
+#define G7C_SUB(AF, BF, AN, BN, UA, UB, SLOT, P, PTR, UNIT, DBASE)                                       \
+  _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                       \
+    MmaOps<T>::mma(BF[q & 3], AF[q >> 2], acc[q >> 2][q & 3]);                                           \
+    if (q < 8) {                                                                                         \
+      if (q < 4) AN[q] = *(const frag_t*)(smem + (UA) + rowa + q * 32 * G7_ROW_BYTES + (SLOT));          \
+      else BN[q - 4] = *(const frag_t*)(smem + (UB) + rowb + (q - 4) * 32 * G7_ROW_BYTES + (SLOT));      \
+    } else if (!(q & 1)) {                                                                               \
+      g7_issue_##P(src, PTR, (DBASE) + ((q - 8) >> 1), lds0 + (UNIT) + (((DBASE) + ((q - 8) >> 1)) * 4 + wave) * 1024); \
+    }                                                                                                    \
+    G7_FENCE();                                                                                          \
+  }
+  for (int t = 0; t < nk; ++t) {
+    if (tr && tid == 0 && t < 12) tr[3 + t] = clock64();
+    G7C_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[1], b, kbp, u_bn, 4)          // second half of B(t+1)
+    G7C_SUB(a1, b1, a0, b0, u_ac, u_bc, slot[2], a, ka, u_sp, 0)           // A(t+2)
+    G7C_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[3], a, ka, u_sp, 4)
+    __builtin_amdgcn_s_waitcnt(0x0078);                                     // vmcnt(8) lgkmcnt(0): everything but A(t+2) has landed
+    __builtin_amdgcn_s_barrier();
+    G7_FENCE();
+    G7C_SUB(a1, b1, a0, b0, u_an, u_bn, slot[0], b, kb, u_ac, 0)           // first half of B(t+2) into the unit A(t) leaves
+    { const int o_ac = u_ac, o_bc = u_bc; u_ac = u_an; u_bc = u_bn; u_an = u_sp; u_bn = o_ac; u_sp = o_bc; }
+    kbp = kb;
+    if (t + 3 == nk) { ka = next_a; kb = next_b; } else { ka += G7_ROW_BYTES; kb += G7_ROW_BYTES; }
+  }
+#undef G7C_SUB
+#undef G7_FENCE
+  ring.ac = u_ac; ring.bc = u_bc; ring.an = u_an; ring.bn = u_bn; ring.sp = u_sp;
+}
+
 #ifdef G7_M16_PROBE
 // ---- the same K loop on 16 x 16 x 32 MFMAs (round 3) ------------------------------------------------------------------
 // PROBE ONLY (tools/gemm7_probe.hip -DG7_ABL=4 -DG7_M16_PROBE; not compiled into the library).  Why it was tried: under

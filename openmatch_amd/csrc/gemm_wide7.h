@@ -64,7 +64,7 @@ __device__ __forceinline__ bool g7_tile(int it, int64_t ntm, int64_t ntn, int gr
     w = (uint32_t)it * gridDim.x + blockIdx.x;
   }
   if (w >= ntiles) return false;
-  if (group_m >> 16) w = ntiles - 1 - w;
+  if ((group_m >> 16) & 1) w = ntiles - 1 - w;
   const uint32_t per_group = gm * tn;
   const uint32_t g = w / per_group;
   const uint32_t first_m = g * gm;
@@ -122,6 +122,12 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
   int it = 0;
   int64_t m0, n0;
   if (!g7_tile(0, ntm, ntn, group_m, m0, n0)) return;
+  // Staggered start (bits 17.. of group_m, units of 256 shader cycles; OM_OPT_GEMM_STAGGER): the workgroups of an XCD start in
+  // four phases, so that the CUs sharing an L2 and a fabric link do not all reach their epilogue's store burst at once.
+  if ((uint32_t)group_m >> 17) {
+    const unsigned long long t_end = clock64() + (unsigned long long)((blockIdx.x >> 3) & 3) * ((uint32_t)group_m >> 17) * 256ull;
+    while (clock64() < t_end) __builtin_amdgcn_s_sleep(16);
+  }
   G7SrcU src;                                  // per-lane offsets once; only the two tile bases change
   g7_offsets_u<T>(src, lda, ldb, wave, lane0);
   src.a = (const char*)(A + m0 * lda);
@@ -435,16 +441,26 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
     }
     if (tr && threadIdx.x == 0) tr[16] = clock64();
 #define G7E_RB(I4) ((G7_ABL & 2) ? make_uint4(0u, 0u, 0u, 0u) : *(const uint4*)(st_rd + (I4) * G7E_SPASS + (((lane & 7) ^ (((lane >> 3) + (I4) * 8) & 7)) << 4)))
-#ifndef G7_NT
-#define G7_NT 1
+// cache policy of the output stores: 0 plain, 1 non-temporal (lines stay in the XCD's L2 either way), 2 sc1, 3 sc0 sc1
+// (write-through: the line is NOT kept in L2 -- MI355X_MICROARCH.md, stores of each flavour)
+#ifndef G7_ST_POLICY
+#define G7_ST_POLICY 1
 #endif
 typedef unsigned int g7_u32x4 __attribute__((ext_vector_type(4)));
-#if G7_NT
+#if G7_ST_POLICY == 1
 #define G7E_STORE16(P, V) __builtin_nontemporal_store(g7_u32x4{(V).x, (V).y, (V).z, (V).w}, (g7_u32x4*)(P))
+#elif G7_ST_POLICY == 2
+#define G7E_STORE16U(UB, VO, V) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(VO), "v"(g7_u32x4{(V).x, (V).y, (V).z, (V).w}), "s"(UB) : "memory")
+#elif G7_ST_POLICY == 3
+#define G7E_STORE16U(UB, VO, V) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(VO), "v"(g7_u32x4{(V).x, (V).y, (V).z, (V).w}), "s"(UB) : "memory")
 #else
 #define G7E_STORE16(P, V) (*(uint4*)(P) = (V))
 #endif
+#ifdef G7E_STORE16U      // wave-uniform base in scalar registers + 32-bit lane offset (what the compiler selects for the builtin forms)
+#define G7E_ST_(BASE, PP, I4, V) do { if (G7_ABL & 1) asm volatile("" ::"v"((V).x), "v"((V).y), "v"((V).z), "v"((V).w)); else G7E_STORE16U((BASE) + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128, coff, V); } while (0)
+#else
 #define G7E_ST_(BASE, PP, I4, V) do { if (G7_ABL & 1) asm volatile("" ::"v"((V).x), "v"((V).y), "v"((V).z), "v"((V).w)); else G7E_STORE16((BASE) + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128 + coff, V); } while (0)
+#endif
 #define G7E_ST(PP, I4, V) G7E_ST_(cbase, PP, I4, V)
     if (!TWO) {
     // Software pipeline over the 8 patches: WRITE(p+1) -> read-back of p+1 ISSUED at once (its data is only needed one
@@ -566,7 +582,10 @@ static int launch7(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   const int64_t ntiles = (M / 256) * (N / 256);
   if (ntiles >= 0x7fff0000LL) OM_FAIL("gemm: more than 2^31 output tiles");      // g7_tile works in 32 bits
   int grid = g7_num_cus();
+  const int cap = om_option(OM_OPT_GEMM_MAX_GRID);       // > 0: at most this many workgroups (multiples of 8 keep the XCD-aware walk)
+  if (cap > 0 && cap < grid) grid = cap;
   if (ntiles < grid) grid = (int)ntiles;
+  const int stagger = om_option(OM_OPT_GEMM_STAGGER) & 0x3fff;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel7<T, ACT, RESID, LNF, true>,
@@ -576,7 +595,7 @@ static int launch7(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   const bool timing = om_timing_on();
   if (timing) om_timing_begin(OM_TIMING_GEMM_BF16, s);
   hipLaunchKernelGGL((gemm_nt_kernel7<T, ACT, RESID, LNF, true>), dim3((unsigned)grid), dim3(G6_THREADS), G7_LDS_BYTES, s,
-                     (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, std::max(1, om_option(OM_OPT_GEMM_GROUP_M)) | (ep.reverse ? 1 << 16 : 0));
+                     (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, (std::max(1, om_option(OM_OPT_GEMM_GROUP_M)) & 0xffff) | (ep.reverse ? 1 << 16 : 0) | (stagger << 17));
   if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, 2.0 * (double)M * (double)N * (double)K);
   OM_LAUNCH_CHECK();
   return 0;

@@ -236,6 +236,9 @@ extern "C" int om_encoder_train_set_layer_events(void* const* events, int n) {
   g_bwd_nevents = n;
   return 0;
 }
+// "Consumed by one call" on EVERY exit path: the array is owned by the caller (a ctypes buffer that may be freed right after the
+// call), so an early return or a failing launch must not leave the pointer behind for the next backward on this thread.
+struct BwdEventsScope { ~BwdEventsScope() { g_bwd_events = nullptr; g_bwd_nevents = 0; } };
 static int record_layer_event(int l, hipStream_t s) {
   if (g_bwd_events && l < g_bwd_nevents && g_bwd_events[l]) OM_HIP(hipEventRecord((hipEvent_t)g_bwd_events[l], s));
   return 0;
@@ -490,6 +493,7 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
                                const void* tape_mem, const float* d_reps, const void* d_hidden,
                                const OmEncoderGrads* g, void* workspace,
                                size_t workspace_bytes, void* stream) {
+  BwdEventsScope events_scope;
   if (!c || !w || !g || !tape_mem || (!d_reps && !d_hidden) || !workspace) OM_FAIL("null argument");
   if (check_train_cfg(c, L)) return 1;
   if (B <= 0) return 0;

@@ -152,8 +152,19 @@ def sharded_topk(index, queries: torch.Tensor, k: int, id_offset: int, merge=Non
     if comm is not None:                         # OPENMATCH_AMD_COMM=native: om_exchange_topk behind the C ABI
         recv_D, recv_I = comm.exchange_topk(D, I)
     else:
-        recv_D, recv_I = torch.empty_like(D), torch.empty_like(I)
-        dist.all_to_all_single(recv_D, D.contiguous())          # block w of recv = shard w's candidates for MY queries
-        dist.all_to_all_single(recv_I, I.contiguous())
+        # ONE all-to-all: per destination rank a block of [blk*k f32 score bits | blk*k int32 SHARD-LOCAL row ids | the
+        # sender's 64-bit id offset as two int32] -- 8 bytes per candidate instead of 12 (int64 global ids in a second
+        # call): 56 MB instead of 84 MB per GPU at Q = 6980, k = 1000, and one ring set-up instead of two
+        n = blk * k
+        payload = torch.empty(W, 2 * n + 2, dtype=torch.int32, device=dev)
+        payload[:, :n] = D.contiguous().view(W, n).view(torch.int32)
+        payload[:, n:2 * n] = torch.where(I >= 0, I - id_offset, I).to(torch.int32).view(W, n)
+        payload[:, 2 * n:] = torch.tensor([id_offset], dtype=torch.int64).view(torch.int32).to(dev)
+        recv = torch.empty_like(payload)
+        dist.all_to_all_single(recv, payload)                   # block w of recv = shard w's candidates for MY queries
+        recv_D = recv[:, :n].view(torch.float32).contiguous()
+        loc = recv[:, n:2 * n].to(torch.int64)
+        offs = recv[:, 2 * n:].contiguous().view(torch.int64)   # [W, 1]: shard w's first global row id
+        recv_I = torch.where(loc >= 0, loc + offs, loc)
     Dm, Im = (merge or merge_topk)(recv_D.view(W, blk, k), recv_I.view(W, blk, k), k)
     return Dm.to(dev), Im.to(dev), blk

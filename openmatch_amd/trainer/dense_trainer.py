@@ -46,7 +46,16 @@ def parameter_groups(model, weight_decay: float):
     return [{"params": decay, "weight_decay": weight_decay}, {"params": no_decay, "weight_decay": 0.0}]
 
 
-_verified_patterns = set()
+_ctl = {"group": None, "made": False}
+
+
+def _control_group():
+    """A host-side (gloo) process group for tiny control collectives that must not touch the GPU stream.  Created on the
+    first gradient averaging, which every rank reaches together; the default group itself when that is already gloo."""
+    if not _ctl["made"]:
+        _ctl["made"] = True
+        _ctl["group"] = None if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+    return _ctl["group"]
 
 
 def allreduce_mean_(params: List[torch.nn.Parameter], world_size: int, bucket_bytes: int = 256 << 20, skip_storages=()):
@@ -84,16 +93,19 @@ def allreduce_mean_(params: List[torch.nn.Parameter], world_size: int, bucket_by
         else:
             loose.extend(gs)
     # Every rank must issue the same collectives: the span sizes depend on which parameters received a gradient and on
-    # the arena layout.  The first time this rank sees a pattern it is compared across ranks; a mismatch (a parameter
-    # unused on one rank only) raises on every rank instead of hanging in a collective of unequal sizes.
+    # the arena layout.  EVERY step a 56-bit hash of this rank's pattern goes through one 16-byte host-side all-reduce
+    # (max of h and of -h: all ranks see the same two numbers, so they all raise or none does); a mismatch (a parameter
+    # unused on one rank only) raises everywhere instead of hanging in collectives of unequal sizes.  (Round 3 compared
+    # a pattern only the first time a rank saw it: a rank with a NEW pattern then gathered while the others all-reduced.)
     sig = (tuple((str(dt), hi - lo, n) for dt, _g, lo, hi, n in spans), tuple(g.numel() for g in loose))
-    if world_size > 1 and dist.is_initialized() and sig not in _verified_patterns:
-        seen = [None] * world_size
-        dist.all_gather_object(seen, sig)
-        if any(s != sig for s in seen):
+    if world_size > 1 and dist.is_initialized():
+        import hashlib
+        h = int.from_bytes(hashlib.blake2b(repr(sig).encode(), digest_size=7).digest(), "little")
+        t = torch.tensor([h, -h], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_control_group())
+        if int(t[0]) != -int(t[1]):
             raise RuntimeError("allreduce_mean_: the ranks hold different gradient patterns (a parameter that received "
-                               f"no gradient on some ranks only?): {seen}")
-        _verified_patterns.add(sig)
+                               f"no gradient on some ranks only?); this rank: {sig}")
     for dtype, g0, lo, hi, _n in spans:
         span = torch.empty(0, dtype=dtype, device=g0.device).set_(g0.untyped_storage(), lo, (hi - lo,))
         reduce_(span)                                       # the views of the arena see the averaged values
@@ -324,9 +336,11 @@ class DRTrainer:
             for batch in loader:
                 if sync is not None:
                     sync.begin()
-                loss_t = self.training_step(self.model, batch)
-                if sync is not None:
-                    sync.finish()
+                try:
+                    loss_t = self.training_step(self.model, batch)
+                finally:                          # a raising step must not leave the bucket hand-off armed for later backwards
+                    if sync is not None:
+                        sync.finish()
                 running += float(loss_t)
                 micro += 1
                 if micro % accum:

@@ -8,6 +8,14 @@ REFERENCE in the build container:  python oracle/make_golden_base.py   (needs /r
                           16-bit mode (its `--fp16` switch wraps the model call in autocast,
                           retriever/dense_retriever.py:76) -- so that the HIP bf16 path is judged against what
                           the REFERENCE loses in 16-bit arithmetic, not against an arbitrary threshold.
+  config1_spread.npz      The same chain with BertConfig(initializer_range=0.1) (round 4): with the default 0.02 every CLS
+                          vector of a random-init bert-base is nearly the same (all dots 762 +- 0.3), so ONE swapped
+                          near-tie moves MRR@10 by 0.005 and the "MRR@10 within 1e-4" gate cannot be evaluated at any
+                          16-bit precision, the reference's own included (0.0035).  Five-fold weights spread the scores
+                          (std of a query's 1 000 dots ~ 1e-2 of the dot scale instead of 4e-4); the relevant document of
+                          a query is drawn uniformly from the reference ranks 1..10 whose document is separated from both
+                          neighbours by more than 5e-4 of the dot scale (five times the 1e-4 dot-product bar): the gate
+                          then tests rank stability, not tie-breaking.  fp32 only.
   gtr_base.npz            GTR-base-sized T5 encoder (12 x 768, relu, mean pooling, 768->768 head, normalised):
                           64 passages + 16 queries, fp32 and autocast.
   bert_large_rr.npz       bert-large cross-encoder (24 x 1024) RRModel scores of 32 pairs x 162 tok, fp32 and autocast.
@@ -142,6 +150,51 @@ def config1(rng):
     print("wrote config1_bert_base.npz")
 
 
+def config1_spread(rng):
+    torch.manual_seed(0)
+    cfg = BertConfig(initializer_range=0.1)
+    lm = BertModel(cfg).eval()
+    ref = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False))
+    n, nq = 1000, 100
+    p_ids, p_mask = mg.synth_batch(rng, n, 128, cfg.vocab_size, 16)
+    q_ids, q_mask = mg.synth_batch(rng, nq, 32, cfg.vocab_size, 4)
+    doc_ids = [f"D{7 * i + 3}" for i in range(n)]
+    qry_ids = [f"Q{i}" for i in range(nq)]
+    out = {"p_input_ids": p_ids.astype(np.uint16), "p_len": lengths(p_mask), "q_input_ids": q_ids.astype(np.uint16),
+           "q_len": lengths(q_mask), "doc_ids": np.array(doc_ids), "qry_ids": np.array(qry_ids), "weight_checksum": checksum(lm)}
+    eval_mrr = mg.reference_eval_mrr()
+    P = encode_all(ref, "passage", p_ids, p_mask, 50, False)
+    Q = encode_all(ref, "query", q_ids, q_mask, 50, False)
+    run, trec = reference_search(P, Q, doc_ids, qry_ids, 100)
+    I, D = run_to_arrays(run, qry_ids, doc_ids)
+    out.update(P_f32=P, Q_f32=Q, I100_f32=I, D100_f32=D)
+    S = Q.astype(np.float64) @ P.astype(np.float64).T
+    scale = float(np.abs(S).max())
+    qrel, gaps, redraws = {}, [], 0
+    for qi, qid in enumerate(qry_ids):
+        ranked = sorted(run[qid].items(), key=lambda kv: kv[1], reverse=True)
+        sc = np.sort(S[qi])[::-1]
+        gap_at = lambda r: min(sc[r - 1] - sc[r] if r else np.inf, sc[r] - sc[r + 1])
+        ok = [r for r in range(10) if gap_at(r) > 5e-4 * scale]
+        if ok:
+            r = int(ok[int(rng.integers(0, len(ok)))])
+        else:                       # no separated document in the top 10: the best-separated one of the top 10
+            r = int(np.argmax([gap_at(r) for r in range(10)]))
+            redraws += 1
+        gap = gap_at(r)
+        qrel[qid] = {ranked[r][0]: 1}
+        gaps.append(gap / scale)
+    out["qrel_docs"] = np.array([list(qrel[q])[0] for q in qry_ids])
+    out["mrr10_f32"] = np.array(eval_mrr(qrel, run, cutoff=10)["all"])
+    out["dot_scale"] = np.array(scale)
+    out["qrel_min_gap_rel"] = np.array(min(gaps))
+    out["score_std_rel"] = np.array(float(S.std(axis=1).mean() / scale))
+    print("  spread fixture: dot scale %.1f, mean per-query std of dots %.2e of it, relevant-document gap >= %.2e of it (%d queries without a separated top-10 document), MRR@10 %.4f"
+          % (scale, float(out["score_std_rel"]), min(gaps), redraws, float(out["mrr10_f32"])))
+    np.savez_compressed(os.path.join(OUT, "config1_spread.npz"), **out)
+    print("wrote config1_spread.npz")
+
+
 def gtr_base(rng):
     torch.manual_seed(1)
     cfg = T5Config(d_model=768, d_ff=3072, num_layers=12, num_heads=12, d_kv=64, feed_forward_proj="relu")
@@ -203,6 +256,8 @@ def main():
     what = sys.argv[1:] or ["config1", "gtr", "large"]
     if "config1" in what:
         config1(np.random.default_rng(SEED + 11))
+    if "spread" in what:
+        config1_spread(np.random.default_rng(SEED + 14))
     if "gtr" in what:
         gtr_base(np.random.default_rng(SEED + 12))
     if "large" in what:

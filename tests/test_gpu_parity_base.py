@@ -57,13 +57,13 @@ def _bert_base():
     return BertModel(BertConfig()).eval()
 
 
-def _chain(g, tmp_path, dtype, fp16):
+def _chain(g, tmp_path, dtype, fp16, lm=None):
     """encode 1 000 passages + 100 queries -> index -> search -> TREC -> MRR@10, all through the HIP path
     behind the reference API (Retriever.build_all / retrieve), passages in batches of 512 x 128 tokens."""
     from openmatch.modeling import DRModelForInference
     from openmatch.retriever import Retriever
     from openmatch.utils import eval_mrr, load_from_trec, save_as_trec
-    lm = _bert_base()
+    lm = lm if lm is not None else _bert_base()
     assert np.allclose(_checksum(lm), g["weight_checksum"], rtol=1e-9), "seeded weights differ from the fixture's"
     model = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype=dtype)).to(DEV).eval()
     p_ids, p_mask = _tokens(g, "p_", 128)
@@ -196,6 +196,37 @@ def test_config1_f16_chain_beats_reference_16bit_envelope(golden, tmp_path):
     assert d_mrr <= r_d_mrr + 1e-9, (mrr, float(g["mrr10_f32"]), r_d_mrr)     # deterministic since round 3: no floor
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float16", "bfloat16"])
+def test_config1_spread_scores_mrr_and_topk_gate(golden, tmp_path, dtype):
+    """north_star's gate where it can be evaluated: bert-base with BertConfig(initializer_range=0.1) (oracle/make_golden_base.py
+    `spread`: a query's 1 000 dots spread over ~1e-2 of the dot scale, every relevant document separated from its neighbours
+    by > 5e-4 of it).  float32 and float16 (the benchmarked format): dot products within 1e-4 of the dot scale, MRR@10 within
+    1e-4 of the reference's, top-100 id sets identical up to fp64-adjudicated near-ties (|score - 100th score| inside the
+    1e-4 dot-product bar).  bfloat16 (8 mantissa bits) is printed and held to 4e-4 / the same MRR gate."""
+    from transformers import BertConfig, BertModel
+    g = golden("config1_spread")
+    torch.manual_seed(0)
+    lm = BertModel(BertConfig(initializer_range=0.1)).eval()
+    P, Q, I, run, mrr, _ = _chain(g, tmp_path, dtype, fp16=False, lm=lm)
+    scale = float(g["dot_scale"])
+    cmin, cmean, ddot = _stats(P, Q, g["P_f32"], g["Q_f32"])
+    P64, Q64 = torch.from_numpy(g["P_f32"]).double(), torch.from_numpy(g["Q_f32"]).double()
+
+    def full(q, disputed):
+        sc = P64 @ Q64[q]
+        return sc[torch.tensor(disputed)].numpy(), torch.topk(sc, 100).values[-1].item()
+    tol = {"float32": 2e-6, "float16": 1e-4, "bfloat16": 4e-4}[dtype]
+    n_exact, n_tie, n_bad, detail = flatip.topk_sets_equal(I, g["I100_f32"].astype(np.int64), full, rel_tol=tol)
+    d_mrr = abs(mrr - float(g["mrr10_f32"]))
+    print(f"\n[config 1 spread, {dtype}] min cos {cmin:.8f}; max|ddot| {ddot:.4f} = {ddot / scale:.2e} of the dot scale {scale:.0f} "
+          f"(per-query score std {float(g['score_std_rel']):.1e}, relevant-document gap >= {float(g['qrel_min_gap_rel']):.1e}); top-100 sets identical "
+          f"{n_exact}/100, fp64 near-tie (tol {tol:.0e}) {n_tie}, wrong {n_bad}; MRR@10 {mrr:.6f} vs reference {float(g['mrr10_f32']):.6f}")
+    assert float(g["qrel_min_gap_rel"]) > 3e-4                # the fixture keeps the gate evaluable
+    assert ddot <= tol * scale * (50 if dtype == "float32" else 1), (ddot, scale)      # f32: 1e-4 of the scale
+    assert n_bad == 0, detail
+    assert d_mrr < 1e-4, (mrr, float(g["mrr10_f32"]))
+
+
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
 def test_gtr_base_sized_t5_matches_reference(golden, dtype):
     """BASELINE config 4's model: T5 encoder 12 x 768 (relu), mean pooling, 768 -> 768 head, L2-normalised."""
@@ -220,7 +251,8 @@ def test_gtr_base_sized_t5_matches_reference(golden, dtype):
     if dtype == "float32":
         assert np.abs(P - g["P_f32"]).max() < 1e-4 and np.abs(Q - g["Q_f32"]).max() < 1e-4 and ddot < 1e-4
     else:
-        assert 1.0 - cmin <= 4.0 * (1.0 - r_cmin) and ddot <= 4.0 * r_ddot
+        # inside the reference's own autocast deviation, factor 1.0 (measured 1.27e-5 vs 1.7e-5 and 9.8e-4 vs 4.0e-3)
+        assert 1.0 - cmin <= 1.0 * (1.0 - r_cmin) and ddot <= 1.0 * r_ddot
 
 
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
@@ -250,4 +282,4 @@ def test_bert_large_cross_encoder_matches_reference(golden, dtype):
     elif dtype == "float16":
         assert err <= 0.5 * r_err                  # inside the reference's own 16-bit deviation
     else:
-        assert err <= 4.0 * r_err
+        assert err <= 1.0 * r_err                  # two-plane residual stream: 4.5e-3 against the reference's own 6.9e-3

@@ -13,7 +13,8 @@ void om_set_error(const std::string& s) { fprintf(stderr, "error: %s\n", s.c_str
 bool om_timing_on() { return false; }
 void om_timing_begin(int, hipStream_t) {}
 void om_timing_end(int, hipStream_t, double) {}
-int om_option(int) { return 8; }      // OM_OPT_GEMM_GROUP_M default
+static int g_grid_cap = 0, g_stagger = 0;
+int om_option(int o) { return o == OM_OPT_GEMM_MAX_GRID ? g_grid_cap : (o == OM_OPT_GEMM_STAGGER ? g_stagger : 8); }      // OM_OPT_GEMM_GROUP_M default 8
 
 static void fill_bf16(bf16_t* d, size_t n, float scale, unsigned long long seed) {
   const size_t chunk = std::min<size_t>(n, (size_t)1 << 22);      // 4 M random values, repeated (rows differ: 4 M is not a multiple of any row)
@@ -34,6 +35,7 @@ static void fill_f32(float* d, size_t n, float a, float b) {
 }
 
 static bool g_zero = false;
+static unsigned long long* g_trace = nullptr;
 static bf16_t *g_rlo = nullptr, *g_clo = nullptr;
 template <int ACT, bool RESID, int LNF>
 static void run(const char* what, int64_t M, int64_t N, int64_t K, const bf16_t* A, const bf16_t* B, bf16_t* C, const bf16_t* R,
@@ -56,8 +58,29 @@ static void run(const char* what, int64_t M, int64_t N, int64_t K, const bf16_t*
   float ms = 0; hipEventElapsedTime(&ms, e0, e1);
   ms /= reps;
   const double tiles_per_cu = (double)(M / 256) * (N / 256) / 256.0;
-  printf("%s%s ABL=%-3d %-28s M=%ld N=%ld K=%ld : %8.1f us  %7.1f TFLOP/s  %7.2f us per tile-slot (%.0f tiles/CU)\n", VARIANT, g_zero ? "z" : "", G7_ABL, what, (long)M,
+  printf("%s%s ABL=%-3d pol=%d cap=%-3d stag=%-4d %-28s M=%ld N=%ld K=%ld : %8.1f us  %7.1f TFLOP/s  %7.2f us per tile-slot (%.1f tiles/CU)\n", VARIANT, g_zero ? "z" : "", G7_ABL, G7_ST_POLICY, g_grid_cap, g_stagger, what, (long)M,
          (long)N, (long)K, ms * 1e3, 2.0 * M * N * K / (ms * 1e9), ms * 1e3 / tiles_per_cu, tiles_per_cu);
+  if (g_trace) {            // one traced launch: average phase lengths of a tile in shader ticks, and ticks per wall microsecond
+    const size_t nblk = 8192;
+    hipMemset(g_trace, 0, nblk * 32 * 8);
+    ep.trace = g_trace; ep.reverse = 0;
+    launch7<bf16_t, ACT, RESID, LNF>(A, K, B, K, C, N, M, N, K, ep, 0);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(nblk * 32);
+    hipMemcpy(h.data(), g_trace, nblk * 32 * 8, hipMemcpyDeviceToHost);
+    double init = 0, pro = 0, loop = 0, epi = 0, tot = 0, clk = 0, st0 = 0, strest = 0; size_t n = 0;
+    const int nk = (int)(K / 64);
+    for (size_t b = 0; b < nblk; ++b) {
+      const unsigned long long* t = &h[b * 32];
+      if (!(t[0] && t[28] && t[15] && t[3] && t[1] && t[31] > t[30])) continue;
+      init += (double)(t[1] - t[0]); pro += (double)(t[3] - t[1]); loop += (double)(t[15] - t[3]); epi += (double)(t[28] - t[15]); tot += (double)(t[28] - t[0]);
+      clk += (double)(t[28] - t[0]) / ((double)(t[31] - t[30]) * 10.0);      // ticks per ns (100 MHz wall counter)
+      if (nk >= 3) { st0 += (double)(t[4] - t[3]); strest += (double)(t[3 + std::min(nk, 12) - 1] - t[4]) / (std::min(nk, 12) - 2); }
+      ++n;
+    }
+    if (n) printf("    trace over %zu tiles: wait-for-tables %.0f  acc-init %.0f  K loop %.0f (MFMA %ld, x%.3f; step0 %.0f, later steps %.0f)  epilogue %.0f  tile %.0f ticks; %.2f GHz shader clock (per-tile mean)\n",
+                  n, init / n, pro / n, loop / n, (long)(K * 32), loop / n / (K * 32.0), st0 / n, strest / n, epi / n, tot / n, clk / n);
+  }
 }
 
 // spot check of the plain variant (bias only): 512 sampled outputs against a host dot product in double
@@ -107,6 +130,28 @@ int main(int argc, char** argv) {
   if (!(G7_ABL)) {
     check_plain(4096, 768, 768, A, B, C, vecs); check_plain(2048, 2304, 768, A, B, C, vecs); check_plain(2048, 768, 3072, A, B, C, vecs);
     check_plain(512, 512, 128, A, B, C, vecs); check_plain(512, 256, 64, A, B, C, vecs); check_plain(65536, 768, 192, A, B, C, vecs);
+  }
+  hipMalloc(&g_trace, 8192 * 32 * 8);
+  if (getenv("G7_MODE") && atoi(getenv("G7_MODE")) == 1) {
+    // (a) how a tile's phases change with the number of CUs that run at once (same tiles per CU): burst contention or a per-CU limit?
+    for (int cap : {256, 128, 64, 32, 8}) {
+      g_grid_cap = cap; g_stagger = 0;
+      const int64_t Mc = M * cap / 256;
+      run<OM_ACT_NONE, false, 1>("qkv (ln-folded A)", Mc, 2304, 768, A, B, C, R, vecs, st_in, st_out);
+      run<OM_ACT_NONE, true, 2>("out-proj (+LN resid, stats)", Mc, 768, 768, A, B, C, R, vecs, st_in, st_out);
+      run<OM_ACT_NONE, true, 2>("ffn2 (+LN resid, stats)", Mc, 768, 3072, A, B, C, R, vecs, st_in, st_out);
+    }
+    // (b) staggered start of the CUs of an XCD (four phases, `stag` x 256 cycles apart), full grid
+    g_grid_cap = 0;
+    for (int rep = 0; rep < 2; ++rep)
+      for (int stag : {0, 8, 16, 24, 40, 64}) {
+        g_stagger = stag;
+        run<OM_ACT_NONE, false, 1>("qkv (ln-folded A)", M, 2304, 768, A, B, C, R, vecs, st_in, st_out);
+        run<OM_ACT_NONE, true, 2>("out-proj (+LN resid, stats)", M, 768, 768, A, B, C, R, vecs, st_in, st_out);
+        run<OM_ACT_GELU_ERF, false, 1>("ffn1 + gelu (ln-folded A)", M, 3072, 768, A, B, C, R, vecs, st_in, st_out);
+        run<OM_ACT_NONE, true, 2>("ffn2 (+LN resid, stats)", M, 768, 3072, A, B, C, R, vecs, st_in, st_out);
+      }
+    return 0;
   }
   for (int round = 0; round < 2; ++round) {
     run<OM_ACT_NONE, false, 1>("qkv (ln-folded A)", M, 2304, 768, A, B, C, R, vecs, st_in, st_out);
