@@ -46,6 +46,21 @@
 #define G7_TAB_OFF (4 * G7_UNIT_BYTES)
 #define G7_ETAB_OFF (G7_TAB_OFF + 8192)
 
+// cache policy of the output stores: 0 plain, 1 non-temporal (lines stay in the XCD's L2 either way), 2 sc1, 3 sc0 sc1
+// (write-through: the line is NOT kept in L2 -- MI355X_MICROARCH.md, stores of each flavour)
+#ifndef G7_ST_POLICY
+#define G7_ST_POLICY 1
+#endif
+typedef unsigned int g7_u32x4 __attribute__((ext_vector_type(4)));
+#if G7_ST_POLICY == 1
+#define G7E_STORE16(P, V) __builtin_nontemporal_store(g7_u32x4{(V).x, (V).y, (V).z, (V).w}, (g7_u32x4*)(P))
+#elif G7_ST_POLICY == 2
+#define G7E_STORE16U(UB, VO, V) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(VO), "v"(g7_u32x4{(V).x, (V).y, (V).z, (V).w}), "s"(UB) : "memory")
+#elif G7_ST_POLICY == 3
+#define G7E_STORE16U(UB, VO, V) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(VO), "v"(g7_u32x4{(V).x, (V).y, (V).z, (V).w}), "s"(UB) : "memory")
+#else
+#define G7E_STORE16(P, V) (*(uint4*)(P) = (V))
+#endif
 #define G7_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 #define G7_FENCE_() __builtin_amdgcn_sched_barrier(0)
 
@@ -122,12 +137,6 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
   int it = 0;
   int64_t m0, n0;
   if (!g7_tile(0, ntm, ntn, group_m, m0, n0)) return;
-  // Staggered start (bits 17.. of group_m, units of 256 shader cycles; OM_OPT_GEMM_STAGGER): the workgroups of an XCD start in
-  // four phases, so that the CUs sharing an L2 and a fabric link do not all reach their epilogue's store burst at once.
-  if ((uint32_t)group_m >> 17) {
-    const unsigned long long t_end = clock64() + (unsigned long long)((blockIdx.x >> 3) & 3) * ((uint32_t)group_m >> 17) * 256ull;
-    while (clock64() < t_end) __builtin_amdgcn_s_sleep(16);
-  }
   G7SrcU src;                                  // per-lane offsets once; only the two tile bases change
   g7_offsets_u<T>(src, lda, ldb, wave, lane0);
   src.a = (const char*)(A + m0 * lda);
@@ -441,21 +450,6 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
     }
     if (tr && threadIdx.x == 0) tr[16] = clock64();
 #define G7E_RB(I4) ((G7_ABL & 2) ? make_uint4(0u, 0u, 0u, 0u) : *(const uint4*)(st_rd + (I4) * G7E_SPASS + (((lane & 7) ^ (((lane >> 3) + (I4) * 8) & 7)) << 4)))
-// cache policy of the output stores: 0 plain, 1 non-temporal (lines stay in the XCD's L2 either way), 2 sc1, 3 sc0 sc1
-// (write-through: the line is NOT kept in L2 -- MI355X_MICROARCH.md, stores of each flavour)
-#ifndef G7_ST_POLICY
-#define G7_ST_POLICY 1
-#endif
-typedef unsigned int g7_u32x4 __attribute__((ext_vector_type(4)));
-#if G7_ST_POLICY == 1
-#define G7E_STORE16(P, V) __builtin_nontemporal_store(g7_u32x4{(V).x, (V).y, (V).z, (V).w}, (g7_u32x4*)(P))
-#elif G7_ST_POLICY == 2
-#define G7E_STORE16U(UB, VO, V) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(VO), "v"(g7_u32x4{(V).x, (V).y, (V).z, (V).w}), "s"(UB) : "memory")
-#elif G7_ST_POLICY == 3
-#define G7E_STORE16U(UB, VO, V) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(VO), "v"(g7_u32x4{(V).x, (V).y, (V).z, (V).w}), "s"(UB) : "memory")
-#else
-#define G7E_STORE16(P, V) (*(uint4*)(P) = (V))
-#endif
 #ifdef G7E_STORE16U      // wave-uniform base in scalar registers + 32-bit lane offset (what the compiler selects for the builtin forms)
 #define G7E_ST_(BASE, PP, I4, V) do { if (G7_ABL & 1) asm volatile("" ::"v"((V).x), "v"((V).y), "v"((V).z), "v"((V).w)); else G7E_STORE16U((BASE) + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128, coff, V); } while (0)
 #else
@@ -473,6 +467,7 @@ typedef unsigned int g7_u32x4 __attribute__((ext_vector_type(4)));
     // CUR / NXT: the register sets holding patch P_ (read last iteration) and patch P_ + 1 (read now)
 #define G7E_ITER(P_, YWAIT, C0, C1, C2, C3, N0, N1, N2, N3)                                                    \
   do {                                                                                                         \
+    if (tr && threadIdx.x == 0) tr[17 + (P_)] = clock64();                                                     \
     if ((P_) + 1 < 8) {                                                                                        \
       if (RESID) {                                                                                             \
         if ((P_) + 3 < 8) G7E_RES_DMA((P_) + 3);                                                               \
@@ -566,6 +561,233 @@ typedef unsigned int g7_u32x4 __attribute__((ext_vector_type(4)));
   G7_WAIT_VM(0);      // the last (dummy) prefetch must not outlive the workgroup's LDS allocation
 }
 
+// =========================================================================================================================
+// Generation 7 on the CONTINUOUS ring (round 4; gemm_core7.h: gemm_mainloop7_cont) -- the variants without a residual:
+// the encoder's QKV and FFN1 contractions, 42 of the 54 tiles a CU computes per layer.
+//
+// What the restart-per-tile kernel above pays between two K loops (tile traces, profiles/r04_probe1_*): the epilogue
+// (7.8 k cycles plain, 14.9 k with GELU), then 1.3-1.9 k cycles issuing the 16 DMA instructions of K step 1 while the
+// stores drain, then 2.5 k cycles building the accumulator-initialising fragments -- 12-19 k cycles per 30 k-cycle K loop,
+// all of it at the same cycle cost whether 8 or 256 CUs run.  Here:
+//   * the ring never stops: when the K loop of a tile ends, steps 0 and 1 of the next tile are landed / in flight, so the
+//     tile boundary issues no operand DMA at all;
+//   * the epilogue lives in the spare unit (this wave's own 1 KiB slices: staging patch 0-3, tables 4-5) -- no barrier on
+//     either side of it;
+//   * the next tile's tables are fetched at the start of the epilogue, its initialising fragments are built between the
+//     sixth and the seventh patch (VALU work under the store-bound part) and the 16 initialising MFMAs are issued behind the
+//     last conversion, under the last patch's stores: the next K loop starts at the epilogue's last store;
+//   * the output stores of patch p are spread over the four quarters of patch p + 1's conversion (one store behind each
+//     quarter) instead of four back to back: with GELU the polynomial and the store path now overlap.
+// One loop body  [epilogue of the previous tile + initialisation of this one][K loop]  with two wave-uniform flags: `live`
+// (false on the first pass only: nothing to store) and `have` (false on the last: nothing to initialise).
+template <int LNF>
+__device__ __forceinline__ void g7c_tables(const GemmEpilogue& ep, const void* dummy, char* tab0, char* tab1, int64_t mc, int64_t nc,
+                                           int lane) {
+  const float* d = (const float*)dummy;
+  const float* cs = (LNF == 1 && ep.ln_colsum) ? ep.ln_colsum + nc : d;
+  const float* bs = ep.bias ? ep.bias + nc : d;
+  g7_table2(cs, bs, tab0, lane);                                   // s_n | b_n of my 128 columns
+  if (LNF == 1) g7_table1(ep.ln_stats + mc * 2, tab1, lane);       // (sum, sum of squares) of my 128 rows
+}
+
+template <typename T, int ACT, int LNF>
+__global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c(
+    const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, T* C, int64_t ldc,
+    int64_t M, int64_t N, int64_t K, GemmEpilogue ep, int group_m) {
+  typedef T OutT;
+  typedef typename MmaOps<T>::frag_t frag_t;
+  static_assert(sizeof(T) == 2, "16-bit in, 16-bit out");
+  static_assert(LNF == 0 || LNF == 1, "no residual: plain or LayerNorm-folded A operand");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane0 = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t ntm = M / 256, ntn = N / 256;
+  const int nk = (int)((K * 2) / G7_ROW_BYTES);
+  const EpiScalars es(ep);
+  constexpr int TI = LNF == 1 ? 2 : 1;         // DMA instructions of a tile's tables
+
+  int it = 0;
+  int64_t m0, n0;
+  if (!g7_tile(0, ntm, ntn, group_m, m0, n0)) return;
+  G7SrcU src;
+  g7_offsets_u<T>(src, lda, ldb, wave, lane0);
+  G7Ring ring;
+  g7_ring_reset(ring);
+  const char* cur_a = (const char*)(A + m0 * lda);
+  const char* cur_b = (const char*)(B + n0 * ldb);
+  // what every later tile finds when its predecessor's K loop ends: step 0, A(1), the first half of B(1)
+  g7_fill_a(src, cur_a, smem + ring.ac, wave);
+  g7_fill_b(src, cur_b, smem + ring.bc, wave);
+  g7_fill_a(src, cur_a + G7_ROW_BYTES, smem + ring.an, wave);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) g7_issue_b(src, cur_b + G7_ROW_BYTES, i, g7_lds_addr(smem + ring.bn) + (i * 4 + wave) * 1024);
+
+  bool live = false, have = true;              // wave-uniform: acc holds a finished tile (pm, pn) / there is a tile (m0, n0) to start
+  int64_t pm = m0, pn = n0;
+  f32x16_t acc[4][4];
+  float rs[4] = {1.f, 1.f, 1.f, 1.f};
+  unsigned long long* tr_prev = nullptr;
+
+  for (;;) {
+    // this wave's slices of the spare unit: slice i at sp + i * 4096
+    char* const sp = smem + ring.sp + wave * 1024;
+    char* const tab0 = sp + 4 * 4096;
+    char* const tab1 = sp + 5 * 4096;
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));             // opaque: per-lane addresses are rebuilt per tile, not hoisted and spilled
+    if (have) g7c_tables<LNF>(ep, A, tab0, tab1, m0 + wm * 128, n0 + wn * 128, lane);
+    const int l31 = lane & 31, half = lane >> 5;
+    float rsn[4] = {1.f, 1.f, 1.f, 1.f};
+    frag_t fa[4], fb[4];
+    size_t ldc2 = (size_t)ldc * sizeof(OutT);
+    asm volatile("" : "+s"(ldc2));
+    const int64_t pmc = pm + wm * 128, pnc = pn + wn * 128;
+    const int skey = l31 & 7;
+    char* const st_wr = sp + G7E_ROW(l31) + 8 * half;
+    const char* const st_rd = sp + (lane >> 3) * 128;
+    char* const cbase = (char*)(C + pmc * ldc + pnc);                   // wave-uniform; the per-lane part is 32 bits
+    const uint32_t coff = (uint32_t)((lane >> 3) * ldc2) + (lane & 7) * 16;
+    uint4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+
+    // quarter G_ of patch P_ = (mi, nh): columns nl = G_ >> 1, j = 2 (G_ & 1) + {0, 1} -- eight accumulator registers per lane
+#define G7C_WRITE_Q(P_, G_)                                                                                    \
+  do {                                                                                                         \
+    constexpr int MI = (P_) >> 1, NH = (P_) & 1, NL = (G_) >> 1, NI = NH * 2 + NL, GO = 8 * ((G_) & 1);        \
+    if ((G_) == 0) asm volatile("" : "+a"(acc[MI][NH * 2]), "+a"(acc[MI][NH * 2 + 1]));                        \
+    const int64_t m = pmc + MI * 32 + l31;                                                                     \
+    f32x8_t v8;                                                                                                \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) v8[e] = acc[MI][NI][GO + e];                                 \
+    if (LNF == 1) v8 *= rs[MI];                                                                                \
+    if (ACT == OM_ACT_GELU_ERF) v8 = gelu_erf_poly8(v8);                                                       \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                         \
+      const int j = 2 * ((G_) & 1) + jj;                                                                       \
+      f32x2_t lo_ = {v8[4 * jj], v8[4 * jj + 1]}, hi_ = {v8[4 * jj + 2], v8[4 * jj + 3]};                      \
+      if (ACT != OM_ACT_GELU_ERF) {                                                                            \
+        const int64_t n = pnc + NI * 32 + 8 * j + 4 * half;                                                    \
+        lo_ = epi_pair<ACT, false, OutT>(lo_, m, n, M, N, ep, es, 0, 0);                                       \
+        hi_ = epi_pair<ACT, false, OutT>(hi_, m, n + 2, M, N, ep, es, 0, 0);                                   \
+      }                                                                                                        \
+      const uint2 pk_ = make_uint2(Half16<OutT>::pack2(lo_[0], lo_[1]), Half16<OutT>::pack2(hi_[0], hi_[1]));  \
+      *(uint2*)(st_wr + (((NL * 4 + j) ^ skey) << 4)) = pk_;                                                   \
+    }                                                                                                          \
+  } while (0)
+#define G7C_RB(I4) (*(const uint4*)(st_rd + (I4) * 4096 + (((lane & 7) ^ (((lane >> 3) + (I4) * 8) & 7)) << 4)))
+#ifdef G7E_STORE16U
+#define G7C_ST(PP, I4, V) G7E_STORE16U(cbase + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128, coff, V)
+#else
+#define G7C_ST(PP, I4, V) G7E_STORE16(cbase + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128 + coff, V)
+#endif
+    // stores of patch P_ (read back one iteration ago into C0..C3), one behind each quarter of patch P_ + 1's conversion;
+    // then the read-back of P_ + 1 into N0..N3.  A wave's LDS operations execute in order: one staging patch, no waits.
+#define G7C_ITER(P_, C0, C1, C2, C3, N0, N1, N2, N3)                                                           \
+  do {                                                                                                         \
+    if ((P_) + 1 < 8) {                                                                                        \
+      G7C_WRITE_Q((P_) + 1, 0); G7_FENCE_(); G7C_ST(P_, 0, C0); G7_FENCE_();                                   \
+      G7C_WRITE_Q((P_) + 1, 1); G7_FENCE_(); G7C_ST(P_, 1, C1); G7_FENCE_();                                   \
+      G7C_WRITE_Q((P_) + 1, 2); G7_FENCE_(); G7C_ST(P_, 2, C2); G7_FENCE_();                                   \
+      G7C_WRITE_Q((P_) + 1, 3); G7_FENCE_();                                                                   \
+      N0 = G7C_RB(0); N1 = G7C_RB(1); N2 = G7C_RB(2); N3 = G7C_RB(3);                                          \
+      G7_FENCE_(); G7C_ST(P_, 3, C3); G7_FENCE_();                                                             \
+    } else {                                                                                                   \
+      G7C_ST(P_, 0, C0); G7C_ST(P_, 1, C1); G7C_ST(P_, 2, C2); G7C_ST(P_, 3, C3); G7_FENCE_();                 \
+    }                                                                                                          \
+  } while (0)
+
+    if (live) {
+      G7C_WRITE_Q(0, 0); G7C_WRITE_Q(0, 1); G7C_WRITE_Q(0, 2); G7C_WRITE_Q(0, 3);
+      G7_FENCE_();
+      sa0 = G7C_RB(0); sa1 = G7C_RB(1); sa2 = G7C_RB(2); sa3 = G7C_RB(3);
+      G7_FENCE_();
+      G7C_ITER(0, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
+      G7C_ITER(1, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+      G7C_ITER(2, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
+      G7C_ITER(3, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+      G7C_ITER(4, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
+      G7C_ITER(5, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+    }
+    // ---- the next tile's initialising fragments (tables -> fa, fb): accumulators start at the bias, or at
+    // b'_n / rstd_m - mu_m s_n for a raw pre-LayerNorm A operand -- the rank-2 product u_m b_n + v_m s_n with every factor split
+    // into 16-bit hi + lo (kernel above).  vmcnt retires in order: with 24 stores issued since the tables, "at most 8
+    // outstanding" covers them; the first pass has issued no store and waits for everything (it needs K step 0 anyway).
+    if (have) {
+      if (live) G7_WAIT_VM(8); else G7_WAIT_VM(0);
+      const bool ln_in = LNF == 1 && ep.ln_stats != nullptr;
+      const bool has_cs = LNF == 1 && ep.ln_colsum != nullptr, has_b = ep.bias != nullptr;
+      auto split = [](float x, uint32_t& hi, uint32_t& lo) {
+        hi = Half16<T>::bits(x); lo = Half16<T>::bits(x - Half16<T>::value(hi));
+      };
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        float u = 1.f, v = 0.f;
+        if (ln_in) {
+          const float2 st = *(const float2*)(tab1 + (mi * 32 + l31) * 8);
+          const float mu = ep.ln_rms ? 0.f : st.x * ep.ln_inv_h;
+          const float var = fmaxf(st.y * ep.ln_inv_h - mu * mu, 0.f) + ep.ln_eps;
+          rsn[mi] = rsqrtf(var);
+          u = sqrtf(var); v = -mu;
+        }
+        uint32_t uh, ul, vh, vl;
+        split(u, uh, ul); split(v, vh, vl);
+        uint4 w = make_uint4(uh | (ul << 16), uh | (vh << 16), vl | (vh << 16), 0u);     // k: u_hi u_lo u_hi v_hi v_lo v_hi 0 0
+        if (half) w = make_uint4(0u, 0u, 0u, 0u);
+        asm volatile("" : "+v"(w.x), "+v"(w.y), "+v"(w.z));       // opaque per row block: 16 MFMAs, not 4 + 192 accumulator moves
+        fa[mi] = __builtin_bit_cast(frag_t, w);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        float b = *(const float*)(tab0 + 512 + (ni * 32 + l31) * 4), sc = *(const float*)(tab0 + (ni * 32 + l31) * 4);
+        if (!has_b) b = 0.f;
+        if (!(ln_in && has_cs)) sc = 0.f;
+        uint32_t bh, bl, sh, sl;
+        split(b, bh, bl); split(sc, sh, sl);
+        uint4 w = make_uint4(bh | (bh << 16), bl | (sh << 16), sh | (sl << 16), 0u);     // k: b_hi b_hi b_lo s_hi s_hi s_lo 0 0
+        if (half) w = make_uint4(0u, 0u, 0u, 0u);
+        fb[ni] = __builtin_bit_cast(frag_t, w);
+      }
+    }
+    if (live) G7C_ITER(6, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);     // converts patch 7: the last reader of the accumulators
+    if (have) {
+      const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { acc[q >> 2][q & 3] = zero; MmaOps<T>::mma(fb[q & 3], fa[q >> 2], acc[q >> 2][q & 3]); }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) asm volatile("" : "+a"(acc[q >> 2][q & 3]));      // one home for every tile where the paths join
+    if (live) {
+      G7C_ITER(7, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+      if (tr_prev && threadIdx.x == 0) { tr_prev[28] = clock64(); tr_prev[29] = blockIdx.x; tr_prev[31] = wall_clock64(); }
+    }
+#undef G7C_ITER
+#undef G7C_ST
+#undef G7C_RB
+#undef G7C_WRITE_Q
+    if (!have) break;
+    if (!live) __builtin_amdgcn_s_barrier();     // first pass: K step 0 (waited for above) is published to the other waves
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) rs[mi] = rsn[mi];
+
+    // ---- the tile after this one (a workgroup that has none prefetches its own again: the instruction stream stays fixed)
+    ++it;
+    int64_t m1 = m0, n1 = n0;
+    const bool has_next = g7_tile(it, ntm, ntn, group_m, m1, n1);
+    const char* const next_a = (const char*)(A + m1 * lda);
+    const char* const next_b = (const char*)(B + n1 * ldb);
+    unsigned long long* tr = nullptr;
+    if (ep.trace) {
+      const int64_t tile_id = (m0 / 256) * ntn + n0 / 256;
+      if (tile_id < 8192) tr = ep.trace + tile_id * 32;
+    }
+    if (tr && threadIdx.x == 0) { tr[0] = tr[1] = clock64(); tr[30] = wall_clock64(); }
+    gemm_mainloop7_cont<T>(src, cur_a, cur_b, next_a, next_b, nk, smem, ring, acc, tr);
+    if (tr && threadIdx.x == 0) tr[15] = clock64();
+    tr_prev = tr;
+    pm = m0; pn = n0; live = true;
+    cur_a = next_a; cur_b = next_b; m0 = m1; n0 = n1; have = has_next;
+  }
+  G7_WAIT_VM(0);      // the last (dummy) prefetch must not outlive the workgroup's LDS allocation
+}
+
 static int g7_num_cus() {
   static int n = 0;
   if (!n) {
@@ -576,16 +798,41 @@ static int g7_num_cus() {
   return n;
 }
 
+template <typename T, int ACT, int LNF>
+static int launch7c(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                    int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
+  const int64_t ntiles = (M / 256) * (N / 256);
+  if (ntiles >= 0x7fff0000LL) OM_FAIL("gemm: more than 2^31 output tiles");
+  int grid = g7_num_cus();
+  const int cap = om_option(OM_OPT_GEMM_MAX_GRID);
+  if (cap > 0 && cap < grid) grid = cap;
+  if (ntiles < grid) grid = (int)ntiles;
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set) {
+    OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel7c<T, ACT, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
+    attr_set = true;
+  }
+  const bool timing = om_timing_on();
+  if (timing) om_timing_begin(OM_TIMING_GEMM_BF16, s);
+  hipLaunchKernelGGL((gemm_nt_kernel7c<T, ACT, LNF>), dim3((unsigned)grid), dim3(G6_THREADS), G7_LDS_BYTES, s,
+                     (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, (std::max(1, om_option(OM_OPT_GEMM_GROUP_M)) & 0xffff) | (ep.reverse ? 1 << 16 : 0));
+  if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, 2.0 * (double)M * (double)N * (double)K);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T, int ACT, bool RESID, int LNF>
 static int launch7(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                    int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
+  if constexpr (!RESID && LNF <= 1) {      // the continuous ring: needs three K steps (its prefetch reaches at most one tile ahead)
+    if (K * 2 >= 3 * G7_ROW_BYTES && om_option(OM_OPT_GEMM_CONT) != 0) return launch7c<T, ACT, LNF>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+  }
   const int64_t ntiles = (M / 256) * (N / 256);
   if (ntiles >= 0x7fff0000LL) OM_FAIL("gemm: more than 2^31 output tiles");      // g7_tile works in 32 bits
   int grid = g7_num_cus();
   const int cap = om_option(OM_OPT_GEMM_MAX_GRID);       // > 0: at most this many workgroups (multiples of 8 keep the XCD-aware walk)
   if (cap > 0 && cap < grid) grid = cap;
   if (ntiles < grid) grid = (int)ntiles;
-  const int stagger = om_option(OM_OPT_GEMM_STAGGER) & 0x3fff;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel7<T, ACT, RESID, LNF, true>,
@@ -595,7 +842,7 @@ static int launch7(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   const bool timing = om_timing_on();
   if (timing) om_timing_begin(OM_TIMING_GEMM_BF16, s);
   hipLaunchKernelGGL((gemm_nt_kernel7<T, ACT, RESID, LNF, true>), dim3((unsigned)grid), dim3(G6_THREADS), G7_LDS_BYTES, s,
-                     (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, (std::max(1, om_option(OM_OPT_GEMM_GROUP_M)) & 0xffff) | (ep.reverse ? 1 << 16 : 0) | (stagger << 17));
+                     (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, (std::max(1, om_option(OM_OPT_GEMM_GROUP_M)) & 0xffff) | (ep.reverse ? 1 << 16 : 0));
   if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, 2.0 * (double)M * (double)N * (double)K);
   OM_LAUNCH_CHECK();
   return 0;

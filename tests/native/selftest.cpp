@@ -404,6 +404,13 @@ int main(int argc, char** argv) {
       test_gemm(OM_BF16, 2048, 768, 3072, true, true, OM_ACT_NONE, OM_BF16);       // 24 steps through the unit rotation
       test_gemm(OM_BF16, 70 * 256, 1024, 256, true, true, OM_ACT_NONE, OM_BF16);   // 280 tiles: more than one per workgroup
       test_gemm(OM_BF16, 70 * 256, 768, 128, true, false, OM_ACT_RELU, OM_BF16);
+      if (gen != 0) continue;
+      // the continuous ring (round 4: no residual, >= 3 K steps): several tiles per workgroup, the ring carried across them
+      test_gemm(OM_BF16, 70 * 256, 1024, 192, true, false, OM_ACT_GELU_ERF, OM_BF16);  // three steps: the prefetch reaches exactly one tile ahead
+      test_gemm(OM_BF16, 70 * 256, 768, 768, true, false, OM_ACT_NONE, OM_BF16);       // 840 tiles on 256 workgroups, 12 steps
+      test_gemm(OM_BF16, 70 * 256, 768, 256, false, false, OM_ACT_NONE, OM_BF16);      // four steps (ring period 5 against 4), no bias
+      test_gemm(OM_BF16, 2048, 768, 3072, true, false, OM_ACT_RELU, OM_BF16);          // 48 steps, one tile per workgroup
+      test_gemm(OM_BF16, 256, 256, 448, true, false, OM_ACT_NONE, OM_BF16);            // one tile, one workgroup, seven steps
     }
     const int64_t M = argc > 2 ? atoll(argv[2]) : 131072;
     for (int rep = 0; rep < 2; ++rep)

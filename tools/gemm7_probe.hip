@@ -13,8 +13,8 @@ void om_set_error(const std::string& s) { fprintf(stderr, "error: %s\n", s.c_str
 bool om_timing_on() { return false; }
 void om_timing_begin(int, hipStream_t) {}
 void om_timing_end(int, hipStream_t, double) {}
-static int g_grid_cap = 0, g_stagger = 0;
-int om_option(int o) { return o == OM_OPT_GEMM_MAX_GRID ? g_grid_cap : (o == OM_OPT_GEMM_STAGGER ? g_stagger : 8); }      // OM_OPT_GEMM_GROUP_M default 8
+static int g_grid_cap = 0, g_stagger = 0, g_cont = 1;
+int om_option(int o) { return o == OM_OPT_GEMM_MAX_GRID ? g_grid_cap : (o == OM_OPT_GEMM_CONT ? g_cont : 8); }      // OM_OPT_GEMM_GROUP_M default 8
 
 static void fill_bf16(bf16_t* d, size_t n, float scale, unsigned long long seed) {
   const size_t chunk = std::min<size_t>(n, (size_t)1 << 22);      // 4 M random values, repeated (rows differ: 4 M is not a multiple of any row)
@@ -58,7 +58,7 @@ static void run(const char* what, int64_t M, int64_t N, int64_t K, const bf16_t*
   float ms = 0; hipEventElapsedTime(&ms, e0, e1);
   ms /= reps;
   const double tiles_per_cu = (double)(M / 256) * (N / 256) / 256.0;
-  printf("%s%s ABL=%-3d pol=%d cap=%-3d stag=%-4d %-28s M=%ld N=%ld K=%ld : %8.1f us  %7.1f TFLOP/s  %7.2f us per tile-slot (%.1f tiles/CU)\n", VARIANT, g_zero ? "z" : "", G7_ABL, G7_ST_POLICY, g_grid_cap, g_stagger, what, (long)M,
+  printf("%s%s ABL=%-3d pol=%d cap=%-3d cont=%d %-28s M=%ld N=%ld K=%ld : %8.1f us  %7.1f TFLOP/s  %7.2f us per tile-slot (%.1f tiles/CU)\n", VARIANT, g_zero ? "z" : "", G7_ABL, G7_ST_POLICY, g_grid_cap, g_cont, what, (long)M,
          (long)N, (long)K, ms * 1e3, 2.0 * M * N * K / (ms * 1e9), ms * 1e3 / tiles_per_cu, tiles_per_cu);
   if (g_trace) {            // one traced launch: average phase lengths of a tile in shader ticks, and ticks per wall microsecond
     const size_t nblk = 8192;
@@ -77,6 +77,17 @@ static void run(const char* what, int64_t M, int64_t N, int64_t K, const bf16_t*
       clk += (double)(t[28] - t[0]) / ((double)(t[31] - t[30]) * 10.0);      // ticks per ns (100 MHz wall counter)
       if (nk >= 3) { st0 += (double)(t[4] - t[3]); strest += (double)(t[3 + std::min(nk, 12) - 1] - t[4]) / (std::min(nk, 12) - 2); }
       ++n;
+    }
+    if (n && RESID) {      // per patch iteration of the residual epilogue: stamps 17..24, then the end (28)
+      double it[9] = {0}; size_t m = 0;
+      for (size_t b = 0; b < nblk; ++b) {
+        const unsigned long long* t = &h[b * 32];
+        if (!(t[15] && t[16] && t[17] && t[24] && t[28])) continue;
+        it[0] += (double)(t[17] - t[15]);
+        for (int p = 0; p < 7; ++p) it[1 + p] += (double)(t[18 + p] - t[17 + p]);
+        it[8] += (double)(t[28] - t[24]); ++m;
+      }
+      if (m) { printf("    residual epilogue: to first patch %.0f | iterations", it[0] / m); for (int p = 1; p < 9; ++p) printf(" %.0f", it[p] / m); printf(" ticks\n"); }
     }
     if (n) printf("    trace over %zu tiles: wait-for-tables %.0f  acc-init %.0f  K loop %.0f (MFMA %ld, x%.3f; step0 %.0f, later steps %.0f)  epilogue %.0f  tile %.0f ticks; %.2f GHz shader clock (per-tile mean)\n",
                   n, init / n, pro / n, loop / n, (long)(K * 32), loop / n / (K * 32.0), st0 / n, strest / n, epi / n, tot / n, clk / n);
@@ -107,7 +118,7 @@ static void check_plain(int64_t M, int64_t N, int64_t K, const bf16_t* A, const 
     if (!(err <= tol)) ++bad;
     worst = std::max(worst, err);
   }
-  printf("CHECK r3%d ABL=%d M=%ld N=%ld K=%ld: %s (max |err| %.4f over 512 samples)\n", 0, G7_ABL, (long)M, (long)N, (long)K,
+  printf("CHECK cont=%d ABL=%d M=%ld N=%ld K=%ld: %s (max |err| %.4f over 512 samples)\n", g_cont, G7_ABL, (long)M, (long)N, (long)K,
          bad ? "FAILED" : "ok", worst);
 }
 
@@ -127,7 +138,7 @@ int main(int argc, char** argv) {
   }
   hipMemset(st_out, 0, (size_t)M * 8);
   hipMalloc(&g_rlo, (size_t)M * 768 * 2); hipMalloc(&g_clo, (size_t)M * 768 * 2); fill_bf16(g_rlo, (size_t)M * 768, 0.004f, 7);
-  if (!(G7_ABL)) {
+  if (!(G7_ABL)) for (g_cont = 0; g_cont < 2; ++g_cont) {
     check_plain(4096, 768, 768, A, B, C, vecs); check_plain(2048, 2304, 768, A, B, C, vecs); check_plain(2048, 768, 3072, A, B, C, vecs);
     check_plain(512, 512, 128, A, B, C, vecs); check_plain(512, 256, 64, A, B, C, vecs); check_plain(65536, 768, 192, A, B, C, vecs);
   }
@@ -154,14 +165,18 @@ int main(int argc, char** argv) {
     return 0;
   }
   for (int round = 0; round < 2; ++round) {
-    run<OM_ACT_NONE, false, 1>("qkv (ln-folded A)", M, 2304, 768, A, B, C, R, vecs, st_in, st_out);
+    for (int cont = 0; cont < 2; ++cont) {      // the ring restarted per tile (round 3) / continuous (round 4): the variants without a residual
+      g_cont = cont;
+      printf("-- continuous ring %s\n", cont ? "ON" : "off");
+      run<OM_ACT_NONE, false, 1>("qkv (ln-folded A)", M, 2304, 768, A, B, C, R, vecs, st_in, st_out);
+      run<OM_ACT_GELU_ERF, false, 1>("ffn1 + gelu (ln-folded A)", M, 3072, 768, A, B, C, R, vecs, st_in, st_out);
+      run<OM_ACT_NONE, false, 1>("ffn1 shape, no gelu", M, 3072, 768, A, B, C, R, vecs, st_in, st_out);
+      run<OM_ACT_NONE, false, 0>("plain", 32768, 3072, 3072, A, B, C, R, vecs, st_in, st_out);
+    }
     run<OM_ACT_NONE, true, 2>("out-proj (+LN resid, stats)", M, 768, 768, A, B, C, R, vecs, st_in, st_out);
-    run<OM_ACT_GELU_ERF, false, 1>("ffn1 + gelu (ln-folded A)", M, 3072, 768, A, B, C, R, vecs, st_in, st_out);
-    run<OM_ACT_NONE, false, 1>("ffn1 shape, no gelu", M, 3072, 768, A, B, C, R, vecs, st_in, st_out);
     run<OM_ACT_NONE, true, 2>("ffn2 (+LN resid, stats)", M, 768, 3072, A, B, C, R, vecs, st_in, st_out);
     run<OM_ACT_NONE, true, 3>("out-proj two planes", M, 768, 768, A, B, C, R, vecs, st_in, st_out);
     run<OM_ACT_NONE, true, 3>("ffn2 two planes", M, 768, 3072, A, B, C, R, vecs, st_in, st_out);
-    run<OM_ACT_NONE, false, 0>("plain", 32768, 3072, 3072, A, B, C, R, vecs, st_in, st_out);
   }
   return 0;
 }

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 4, probe 2: the continuous ring -- kernel self-test, tile traces and launch times against the restart-per-tile kernel,
+# the encode leg with OM_GEMM_CONT = 0 / 1, then the GPU suite
+R=$PWD; O=$R/gpurun_out/r4_probe2; mkdir -p $O; rm -f $O/*.log $O/*.json
+export TMPDIR=/tmp LD_LIBRARY_PATH=$R/openmatch_amd/csrc:$LD_LIBRARY_PATH
+timeout 600 build/selftest gen7 4096 > $O/selftest_gen7.log 2>&1; echo "selftest gen7 rc=$?"; grep -c "\[ OK \]" $O/selftest_gen7.log; grep "FAIL" $O/selftest_gen7.log | head
+timeout 300 build/g7probe_v10 > $O/g7probe.log 2>&1; echo "probe rc=$?"; grep CHECK $O/g7probe.log | grep -v " ok " | head
+grep -A1 "cont=[01] " $O/g7probe.log | grep -v "^--" | cut -c1-330 | tail -48
+for round in 1 2; do for v in 0 1; do
+  OM_GEMM_CONT=$v timeout 300 python bench.py --steps 10 --warmup 3 --no-search --no-cpu-baseline --no-extra --no-parity > $O/bench_cont${v}_$round.json 2>$O/bench.err
+  echo "OM_GEMM_CONT=$v $(grep -o '"value": [0-9.]*' $O/bench_cont${v}_$round.json | head -1) $(grep -o '"achieved": [0-9.]*' $O/bench_cont${v}_$round.json | head -1)"
+done; done
+timeout 1500 python -m pytest tests -m gpu -q -x -s > $O/pytest.log 2>&1; echo "pytest rc=$?"; grep -E " passed| failed| error" $O/pytest.log | tail -3
