@@ -253,10 +253,17 @@ struct G7Ring { int ac, bc, an, bn, sp; };      // byte offsets of the five unit
 __device__ __forceinline__ void g7_ring_reset(G7Ring& r) {
   r.ac = 0; r.bc = G7_UNIT_BYTES; r.an = 2 * G7_UNIT_BYTES; r.bn = 3 * G7_UNIT_BYTES; r.sp = 4 * G7_UNIT_BYTES;
 }
-template <typename T>
+// TAIL (residual variants, gemm_wide7.h kernel 7r): the LAST step of a tile gives its twelve issue slots behind sub-steps
+// 1, 2, 3 -- A(nk + 1) and the first half of B(nk + 1) in the plain ring -- to tail(slot 0..11, spare unit, the unit A(nk - 1) leaves): the epilogue's tables and
+// its first residual patches go into the units that step frees (the spare during sub-steps 1-2, the unit A(nk - 1) leaves
+// behind the barrier), so that the epilogue starts on landed data.  The tile after then starts with step 0 resident only and
+// issues A(1) / the first half of B(1) itself.  The eight issues of sub-steps 1-2 are the step's youngest at its barrier
+// either way (vmcnt(8)).
+struct G7NoTail { __device__ __forceinline__ void operator()(int, int, int) const {} };
+template <typename T, bool TAIL = false, typename TailFn = G7NoTail>
 __device__ __forceinline__ void gemm_mainloop7_cont(const G7SrcU& src, const char* cur_a, const char* cur_b,
                                                     const char* next_a, const char* next_b, int nk, char* smem, G7Ring& ring,
-                                                    f32x16_t (&acc)[4][4], unsigned long long* tr = nullptr) {
+                                                    f32x16_t (&acc)[4][4], unsigned long long* tr = nullptr, TailFn tail = TailFn()) {
   typedef typename MmaOps<T>::frag_t frag_t;
   static_assert(sizeof(T) == 2, "128-byte K steps: 16-bit operands only");
   const int tid = threadIdx.x;
@@ -283,31 +290,41 @@ __device__ __forceinline__ void gemm_mainloop7_cont(const G7SrcU& src, const cha
 
 #define G7_FENCE() __builtin_amdgcn_sched_barrier(0)
   // one k sub-step: 16 MFMAs from (AF, BF); the first eight each cover one fragment read into (AN, BN) from (UA, UB) chunk
-  // SLOT; MFMAs 8, 10, 12, 14 each cover one DMA issue of operand P (source base PTR, instructions DBASE .. DBASE + 3) into UNIT
-#define G7C_SUB(AF, BF, AN, BN, UA, UB, SLOT, P, PTR, UNIT, DBASE)                                       \
+  // SLOT; MFMAs 8, 10, 12, 14 each cover one DMA issue: operand P (source base PTR, instructions DBASE .. DBASE + 3) into
+  // UNIT, or -- LASTSTEP with a tail slot -- tail(TSLOT .. TSLOT + 3).  No branch anywhere in a step: the restart-per-tile loop
+  // above guards every issue with a wave-uniform flag, and those 16 scalar branches per step cost it ~800 of its ~3200 cycles
+  // (the first version of the TAIL loop had 12 and ran 3209 cycles per step against 2404: profiles/r04_probe4_*).
+#define G7C_SUB(AF, BF, AN, BN, UA, UB, SLOT, P, PTR, UNIT, DBASE, TSLOT, LASTSTEP)                      \
   _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                       \
     MmaOps<T>::mma(BF[q & 3], AF[q >> 2], acc[q >> 2][q & 3]);                                           \
     if (q < 8) {                                                                                         \
       if (q < 4) AN[q] = *(const frag_t*)(smem + (UA) + rowa + q * 32 * G7_ROW_BYTES + (SLOT));          \
       else BN[q - 4] = *(const frag_t*)(smem + (UB) + rowb + (q - 4) * 32 * G7_ROW_BYTES + (SLOT));      \
     } else if (!(q & 1)) {                                                                               \
-      g7_issue_##P(src, PTR, (DBASE) + ((q - 8) >> 1), lds0 + (UNIT) + (((DBASE) + ((q - 8) >> 1)) * 4 + wave) * 1024); \
+      if ((LASTSTEP) && (TSLOT) >= 0) tail((TSLOT) + ((q - 8) >> 1), u_sp, u_ac);                        \
+      else g7_issue_##P(src, PTR, (DBASE) + ((q - 8) >> 1), lds0 + (UNIT) + (((DBASE) + ((q - 8) >> 1)) * 4 + wave) * 1024); \
     }                                                                                                    \
     G7_FENCE();                                                                                          \
   }
-  for (int t = 0; t < nk; ++t) {
-    if (tr && tid == 0 && t < 12) tr[3 + t] = clock64();
-    G7C_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[1], b, kbp, u_bn, 4)          // second half of B(t+1)
-    G7C_SUB(a1, b1, a0, b0, u_ac, u_bc, slot[2], a, ka, u_sp, 0)           // A(t+2)
-    G7C_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[3], a, ka, u_sp, 4)
-    __builtin_amdgcn_s_waitcnt(0x0078);                                     // vmcnt(8) lgkmcnt(0): everything but A(t+2) has landed
-    __builtin_amdgcn_s_barrier();
-    G7_FENCE();
-    G7C_SUB(a1, b1, a0, b0, u_an, u_bn, slot[0], b, kb, u_ac, 0)           // first half of B(t+2) into the unit A(t) leaves
-    { const int o_ac = u_ac, o_bc = u_bc; u_ac = u_an; u_bc = u_bn; u_an = u_sp; u_bn = o_ac; u_sp = o_bc; }
-    kbp = kb;
-    if (t + 3 == nk) { ka = next_a; kb = next_b; } else { ka += G7_ROW_BYTES; kb += G7_ROW_BYTES; }
-  }
+#define G7C_STEP(LASTSTEP)                                                                               \
+  do {                                                                                                   \
+    if (tr && tid == 0 && t < 12) tr[3 + t] = clock64();                                                 \
+    G7C_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[1], b, kbp, u_bn, 4, -1, LASTSTEP)   /* second half of B(t+1) */ \
+    G7C_SUB(a1, b1, a0, b0, u_ac, u_bc, slot[2], a, ka, u_sp, 0, 0, LASTSTEP)     /* A(t+2) */            \
+    G7C_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[3], a, ka, u_sp, 4, 4, LASTSTEP)                            \
+    __builtin_amdgcn_s_waitcnt(0x0078);                /* vmcnt(8) lgkmcnt(0): everything but the last eight issues has landed */ \
+    __builtin_amdgcn_s_barrier();                                                                        \
+    G7_FENCE();                                                                                          \
+    G7C_SUB(a1, b1, a0, b0, u_an, u_bn, slot[0], b, kb, u_ac, 0, 8, LASTSTEP)     /* first half of B(t+2) into the unit A(t) leaves */ \
+    { const int o_ac = u_ac, o_bc = u_bc; u_ac = u_an; u_bc = u_bn; u_an = u_sp; u_bn = o_ac; u_sp = o_bc; } \
+    kbp = kb;                                                                                            \
+    if (t + 3 == nk) { ka = next_a; kb = next_b; } else { ka += G7_ROW_BYTES; kb += G7_ROW_BYTES; }      \
+  } while (0)
+  int t = 0;
+  const int nplain = TAIL ? nk - 1 : nk;
+  for (; t < nplain; ++t) G7C_STEP(false);
+  if (TAIL) G7C_STEP(true);                          // (one more copy of the step body: ~7 KiB of code, no branch inside either)
+#undef G7C_STEP
 #undef G7C_SUB
 #undef G7_FENCE
   ring.ac = u_ac; ring.bc = u_bc; ring.an = u_an; ring.bn = u_bn; ring.sp = u_sp;

@@ -788,6 +788,300 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c(
   G7_WAIT_VM(0);      // the last (dummy) prefetch must not outlive the workgroup's LDS allocation
 }
 
+// =========================================================================================================================
+// Generation 7 on the continuous ring, the variants WITH a residual (round 4): out-proj and FFN2 of the encoder -- one-plane
+// residual stream (LNF 0: plain residual; LNF 2: normalised residual + row statistics of the output).
+//
+// Per-patch stamps of the restart kernel's residual epilogue (profiles/r04_probe3_residual_epilogue_per_patch.log): 7.6 k of
+// its 21 k cycles pass before the first patch is converted -- 29 DMA issues (residual ring, next tile's K step 0, tables)
+// and the HBM latency of the first residual patch behind them.  Here the LAST K step of a tile issues the epilogue's
+// tables and its first two residual patches in the twelve slots that would fetch A(nk + 1) / B(nk + 1) (gemm_core7.h TAIL):
+// they land under that step's MFMAs, in the units the step frees.  Across the boundary the ring keeps step 0 of the next
+// tile only; A(1) and the first half of B(1) are issued behind the last conversion of the epilogue, and the accumulator
+// initialisation of the next tile runs under the last patch's stores as in kernel 7c.
+//   after the K loop (ring rotated):   ring.an (the spare of the last step)   slices 0-3 residual slot 0, 4 gamma | beta,
+//                                                                              5 statistics of the residual rows, 6 next tile's s_n | b_n
+//                                      ring.bn (the unit A(nk - 1) left)      slices 0-3 residual slot 1, 4-7 slot 2
+//                                      ring.sp (the unit B(nk - 1) left)      slices 0-3 staging patch
+// (slice i of a unit = this wave's i-th own KiB, at unit + (4 i + wave) KiB: no wave touches another wave's slices.)
+template <typename T, int ACT, int LNF>
+__global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r(
+    const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, T* C, int64_t ldc,
+    int64_t M, int64_t N, int64_t K, GemmEpilogue ep, int group_m) {
+  typedef T OutT;
+  typedef typename MmaOps<T>::frag_t frag_t;
+  static_assert(sizeof(T) == 2, "16-bit in, 16-bit out");
+  static_assert(LNF == 0 || LNF == 2, "residual variants: plain, or output-side LayerNorm on a one-plane residual stream");
+  constexpr bool LNO = LNF == 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane0 = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t ntm = M / 256, ntn = N / 256;
+  const int nk = (int)((K * 2) / G7_ROW_BYTES);
+  const EpiScalars es(ep);
+  const uint32_t lds_base = g7_lds_addr(smem);
+
+  int it = 0;
+  int64_t m0, n0;
+  if (!g7_tile(0, ntm, ntn, group_m, m0, n0)) return;
+  G7SrcU src;
+  g7_offsets_u<T>(src, lda, ldb, wave, lane0);
+  G7Ring ring;
+  g7_ring_reset(ring);
+  const char* cur_a = (const char*)(A + m0 * lda);
+  const char* cur_b = (const char*)(B + n0 * ldb);
+  g7_fill_a(src, cur_a, smem + ring.ac, wave);
+  g7_fill_b(src, cur_b, smem + ring.bc, wave);
+  g7_fill_a(src, cur_a + G7_ROW_BYTES, smem + ring.an, wave);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) g7_issue_b(src, cur_b + G7_ROW_BYTES, i, lds_base + ring.bn + (i * 4 + wave) * 1024);
+  // first tile: its s_n | b_n table goes to the spare unit (later tiles find theirs in ring.an, fetched by the previous K loop)
+  g7_table2((const float*)A, ep.bias ? ep.bias + n0 + wn * 128 : (const float*)A, smem + ring.sp + (6 * 4 + wave) * 1024, lane0);
+
+  bool live = false, have = true;
+  int64_t pm = m0, pn = n0;
+  f32x16_t acc[4][4];
+  unsigned long long* tr_prev = nullptr;
+  size_t ldc2 = (size_t)ldc * sizeof(OutT), ldr2 = (size_t)ep.ldr * sizeof(OutT);
+  asm volatile("" : "+s"(ldc2), "+s"(ldr2));
+
+  for (;;) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int l31 = lane & 31, half = lane >> 5;
+    const int64_t pmc = pm + wm * 128, pnc = pn + wn * 128;
+    char* const an0 = smem + ring.an + wave * 1024;          // slice i at + i * 4096
+    char* const bn0 = smem + ring.bn + wave * 1024;
+    char* const sp0 = smem + ring.sp + wave * 1024;
+    const char* const etab0 = an0 + 4 * 4096;                 // gamma | beta
+    const char* const etab1 = an0 + 5 * 4096;                 // (sum, sum of squares) of my 128 residual rows
+    const char* const tab0 = (live ? an0 : sp0) + 6 * 4096;   // s_n | b_n of the tile about to start
+    const bool res_ln = LNO && ep.rln_stats != nullptr;
+    const char* const rbase = (const char*)((const OutT*)ep.resid + pmc * ep.ldr + pnc);     // wave-uniform
+    uint32_t roff[4];                                         // row (lane >> 3) of an 8-row group, swizzled source chunk
+#pragma unroll
+    for (int k = 0; k < 4; ++k) roff[k] = (uint32_t)((lane >> 3) * ldr2) + (((lane & 7) ^ ((4 * k + (lane >> 4)) & 7)) << 4);
+    float ra[4] = {1.f, 1.f, 1.f, 1.f}, rc[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x2_t ssum = {0.f, 0.f}, ssq = {0.f, 0.f};
+    frag_t fa[4], fb[4];
+    const int skey = l31 & 7;
+    char* const st_wr = sp0 + G7E_ROW(l31) + 8 * half;
+    const char* const st_rd = sp0 + (lane >> 3) * 128;
+    char* const cbase = (char*)(C + pmc * ldc + pnc);
+    const uint32_t coff = (uint32_t)((lane >> 3) * ldc2) + (lane & 7) * 16;
+    float2* const stat_slot = LNO ? (float2*)ep.stats_out + ((pn >> 8) * 2 + wn) * M : nullptr;
+    uint4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+
+    // residual patch P_ = (mi, nh): 32 rows x 128 B; ring slot P_ % 3
+#define G7R_SLOT(P_) (((P_) % 3) == 0 ? an0 : (((P_) % 3) == 1 ? bn0 : bn0 + 4 * 4096))
+#define G7R_RES_DMA(P_)                                                                                        \
+  do {                                                                                                         \
+    const size_t poff = (size_t)(((P_) >> 1) * 32) * ldr2 + ((P_) & 1) * 128;                                  \
+    const uint32_t buf = g7_lds_addr(G7R_SLOT(P_));                                                            \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) g7_dma(rbase + poff + (size_t)(8 * k) * ldr2, roff[k], buf + k * 4096); \
+  } while (0)
+    // quarter G_ of patch P_: eight accumulator registers per lane (columns nl = G_ >> 1, j = 2 (G_ & 1) + {0, 1})
+#define G7R_WRITE_Q(P_, G_)                                                                                    \
+  do {                                                                                                         \
+    constexpr int MI = (P_) >> 1, NH = (P_) & 1, NL = (G_) >> 1, NI = NH * 2 + NL, JP = (G_) & 1;              \
+    if ((G_) == 0) asm volatile("" : "+a"(acc[MI][NH * 2]), "+a"(acc[MI][NH * 2 + 1]));                        \
+    const int64_t m = pmc + MI * 32 + l31;                                                                     \
+    const char* buf = G7R_SLOT(P_) + G7E_ROW(l31) + 8 * half;                                                  \
+    const uint2 ra_ = *(const uint2*)(buf + (((NL * 4 + 2 * JP) ^ ((l31 >> 1) & 7)) << 4));                    \
+    const uint2 rb_ = *(const uint2*)(buf + (((NL * 4 + 2 * JP + 1) ^ ((l31 >> 1) & 7)) << 4));                \
+    f32x8_t v8;                                                                                                \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) v8[e] = acc[MI][NI][8 * JP + e];                             \
+    f32x8_t r8 = {Half16<OutT>::lo(ra_.x), Half16<OutT>::hi(ra_.x), Half16<OutT>::lo(ra_.y), Half16<OutT>::hi(ra_.y), \
+                  Half16<OutT>::lo(rb_.x), Half16<OutT>::hi(rb_.x), Half16<OutT>::lo(rb_.y), Half16<OutT>::hi(rb_.y)}; \
+    if (LNO) {                                                                                                 \
+      if (res_ln) {                                                                                            \
+        const int c0 = NI * 32 + 16 * JP + 4 * half;                /* columns c0 .. c0 + 3 and c0 + 8 .. c0 + 11 */ \
+        const f32x4_t ga = *(const f32x4_t*)(etab0 + c0 * 4), gb = *(const f32x4_t*)(etab0 + (c0 + 8) * 4);     \
+        const f32x4_t ba = *(const f32x4_t*)(etab0 + 512 + c0 * 4), bb = *(const f32x4_t*)(etab0 + 512 + (c0 + 8) * 4); \
+        const f32x8_t g8 = __builtin_shufflevector(ga, gb, 0, 1, 2, 3, 4, 5, 6, 7);                            \
+        const f32x8_t b8 = __builtin_shufflevector(ba, bb, 0, 1, 2, 3, 4, 5, 6, 7);                            \
+        r8 = __builtin_elementwise_fma(__builtin_elementwise_fma(r8, (f32x8_t)(ra[MI]), (f32x8_t)(rc[MI])), g8, b8); \
+      }                                                                                                        \
+      v8 += r8;                                                                                                \
+      ssum[0] += (v8[0] + v8[1]) + (v8[2] + v8[3]); ssum[1] += (v8[4] + v8[5]) + (v8[6] + v8[7]);              \
+      const f32x8_t q8 = v8 * v8;                                                                              \
+      ssq[0] += (q8[0] + q8[1]) + (q8[2] + q8[3]); ssq[1] += (q8[4] + q8[5]) + (q8[6] + q8[7]);                \
+    } else {                                                                                                   \
+      _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                       \
+        const int64_t n = pnc + NI * 32 + 8 * (2 * JP + jj) + 4 * half;                                        \
+        f32x2_t lo_ = {v8[4 * jj], v8[4 * jj + 1]}, hi_ = {v8[4 * jj + 2], v8[4 * jj + 3]};                    \
+        lo_ = epi_pair<ACT, false, OutT>(lo_, m, n, M, N, ep, es, 0, 0);                                       \
+        hi_ = epi_pair<ACT, false, OutT>(hi_, m, n + 2, M, N, ep, es, 0, 0);                                   \
+        if (es.mul) { lo_[0] *= r8[4 * jj]; lo_[1] *= r8[4 * jj + 1]; hi_[0] *= r8[4 * jj + 2]; hi_[1] *= r8[4 * jj + 3]; } \
+        else {                                                                                                 \
+          lo_[0] = epi_resid<ACT, true>(lo_[0], r8[4 * jj], false); lo_[1] = epi_resid<ACT, true>(lo_[1], r8[4 * jj + 1], false);       \
+          hi_[0] = epi_resid<ACT, true>(hi_[0], r8[4 * jj + 2], false); hi_[1] = epi_resid<ACT, true>(hi_[1], r8[4 * jj + 3], false);   \
+        }                                                                                                      \
+        v8[4 * jj] = lo_[0]; v8[4 * jj + 1] = lo_[1]; v8[4 * jj + 2] = hi_[0]; v8[4 * jj + 3] = hi_[1];        \
+      }                                                                                                        \
+    }                                                                                                          \
+    const uint2 pa_ = make_uint2(Half16<OutT>::pack2(v8[0], v8[1]), Half16<OutT>::pack2(v8[2], v8[3]));        \
+    const uint2 pb_ = make_uint2(Half16<OutT>::pack2(v8[4], v8[5]), Half16<OutT>::pack2(v8[6], v8[7]));        \
+    *(uint2*)(st_wr + (((NL * 4 + 2 * JP) ^ skey) << 4)) = pa_;                                                \
+    *(uint2*)(st_wr + (((NL * 4 + 2 * JP + 1) ^ skey) << 4)) = pb_;                                            \
+    if (LNO && NH == 1 && (G_) == 3) {     /* both column halves of the row block done: this wave's partial sums of the row */ \
+      float s1 = ssum[0] + ssum[1], s2 = ssq[0] + ssq[1];                                                      \
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);                                              \
+      if (half == 0) stat_slot[m] = make_float2(s1, s2);                                                       \
+      ssum = (f32x2_t){0.f, 0.f}; ssq = (f32x2_t){0.f, 0.f};                                                   \
+    }                                                                                                          \
+  } while (0)
+#define G7R_RB(I4) (*(const uint4*)(st_rd + (I4) * 4096 + (((lane & 7) ^ (((lane >> 3) + (I4) * 8) & 7)) << 4)))
+#ifdef G7E_STORE16U
+#define G7R_ST(PP, I4, V) G7E_STORE16U(cbase + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128, coff, V)
+#else
+#define G7R_ST(PP, I4, V) G7E_STORE16(cbase + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128 + coff, V)
+#endif
+    // iteration P_: fetch residual patch P_ + 3 into the slot patch P_ left, wait for patch P_ + 1 (vmcnt retires in order:
+    // YWAIT = operations issued after its fetch, the row-statistics stores NOT counted -- a wait can only be stricter for it),
+    // convert it in quarters with one store of patch P_ behind each, read it back
+#define G7R_ITER(P_, YWAIT, C0, C1, C2, C3, N0, N1, N2, N3)                                                    \
+  do {                                                                                                         \
+    if (tr_prev && threadIdx.x == 0) tr_prev[17 + (P_)] = clock64();                                           \
+    if ((P_) + 1 < 8) {                                                                                        \
+      if ((P_) + 3 < 8) G7R_RES_DMA((P_) + 3);                                                                 \
+      G7_WAIT_VM(YWAIT);                                                                                       \
+      G7R_WRITE_Q((P_) + 1, 0); G7_FENCE_(); G7R_ST(P_, 0, C0); G7_FENCE_();                                   \
+      G7R_WRITE_Q((P_) + 1, 1); G7_FENCE_(); G7R_ST(P_, 1, C1); G7_FENCE_();                                   \
+      G7R_WRITE_Q((P_) + 1, 2); G7_FENCE_(); G7R_ST(P_, 2, C2); G7_FENCE_();                                   \
+      G7R_WRITE_Q((P_) + 1, 3); G7_FENCE_();                                                                   \
+      N0 = G7R_RB(0); N1 = G7R_RB(1); N2 = G7R_RB(2); N3 = G7R_RB(3);                                          \
+      G7_FENCE_(); G7R_ST(P_, 3, C3); G7_FENCE_();                                                             \
+    } else {                                                                                                   \
+      G7R_ST(P_, 0, C0); G7R_ST(P_, 1, C1); G7R_ST(P_, 2, C2); G7R_ST(P_, 3, C3); G7_FENCE_();                 \
+    }                                                                                                          \
+  } while (0)
+
+    if (live) {
+      G7R_RES_DMA(2);                          // patches 0 and 1 and the tables were fetched by the K loop's last step
+      G7_WAIT_VM(8);                           // ... and have landed: only patches 1 and 2 are younger
+      if (res_ln) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const float2 st = *(const float2*)(etab1 + (mi * 32 + l31) * 8);
+          const float mu = st.x * ep.ln_inv_h;
+          const float rstd = rsqrtf(fmaxf(st.y * ep.ln_inv_h - mu * mu, 0.f) + ep.ln_eps);
+          ra[mi] = rstd; rc[mi] = -mu * rstd;
+        }
+      }
+      if (tr_prev && threadIdx.x == 0) tr_prev[16] = clock64();
+      G7R_WRITE_Q(0, 0); G7R_WRITE_Q(0, 1); G7R_WRITE_Q(0, 2); G7R_WRITE_Q(0, 3);
+      G7_FENCE_();
+      sa0 = G7R_RB(0); sa1 = G7R_RB(1); sa2 = G7R_RB(2); sa3 = G7R_RB(3);
+      G7_FENCE_();
+      G7R_ITER(0, 8, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);        // younger than patch 1: patch 2, patch 3
+      G7R_ITER(1, 12, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);       // patch 3, stores of 0, patch 4
+      G7R_ITER(2, 16, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);       // stores of 0, patch 4, stores of 1, patch 5
+      G7R_ITER(3, 16, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+      G7R_ITER(4, 16, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
+      G7R_ITER(5, 12, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);       // stores of 3, patch 7, stores of 4
+    }
+    // ---- the next tile's initialising fragments (bias only: these variants have no folded A operand)
+    if (have) {
+      if (!live) G7_WAIT_VM(0);                // first pass: its table and K step 0 (a later tile's table is older than its residual patch 0)
+      const bool has_b = ep.bias != nullptr;
+      auto split = [](float x, uint32_t& hi, uint32_t& lo) {
+        hi = Half16<T>::bits(x); lo = Half16<T>::bits(x - Half16<T>::value(hi));
+      };
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        uint32_t uh, ul;
+        split(1.f, uh, ul);
+        uint4 w = make_uint4(uh | (ul << 16), uh, 0u, 0u);              // k: u_hi u_lo u_hi 0 ...
+        if (half) w = make_uint4(0u, 0u, 0u, 0u);
+        asm volatile("" : "+v"(w.x), "+v"(w.y));                        // opaque per row block: 16 MFMAs, not 4 + 192 accumulator moves
+        fa[mi] = __builtin_bit_cast(frag_t, w);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        float b = *(const float*)(tab0 + 512 + (ni * 32 + l31) * 4);
+        if (!has_b) b = 0.f;
+        uint32_t bh, bl;
+        split(b, bh, bl);
+        uint4 w = make_uint4(bh | (bh << 16), bl, 0u, 0u);              // k: b_hi b_hi b_lo 0 ...
+        if (half) w = make_uint4(0u, 0u, 0u, 0u);
+        fb[ni] = __builtin_bit_cast(frag_t, w);
+      }
+    }
+    if (live) {
+      G7R_ITER(6, 8, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);          // stores of 4, stores of 5; converts patch 7, the last reader of acc
+      // every ring slot and table of this epilogue has been read: A(1) and the first half of B(1) of the next tile
+      if (have) {
+        g7_fill_a(src, cur_a + G7_ROW_BYTES, smem + ring.an, wave);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g7_issue_b(src, cur_b + G7_ROW_BYTES, i, lds_base + ring.bn + (i * 4 + wave) * 1024);
+      }
+    }
+    if (have) {
+      const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { acc[q >> 2][q & 3] = zero; MmaOps<T>::mma(fb[q & 3], fa[q >> 2], acc[q >> 2][q & 3]); }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) asm volatile("" : "+a"(acc[q >> 2][q & 3]));
+    if (live) {
+      G7R_ITER(7, 0, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+      if (tr_prev && threadIdx.x == 0) { tr_prev[28] = clock64(); tr_prev[29] = blockIdx.x; tr_prev[31] = wall_clock64(); }
+    }
+#undef G7R_ITER
+#undef G7R_ST
+#undef G7R_RB
+#undef G7R_WRITE_Q
+#undef G7R_RES_DMA
+#undef G7R_SLOT
+    if (!have) break;
+    if (!live) __builtin_amdgcn_s_barrier();     // first pass: K step 0 (waited for above) is published to the other waves
+
+    // ---- the tile after this one
+    ++it;
+    int64_t m1 = m0, n1 = n0;
+    const bool has_next = g7_tile(it, ntm, ntn, group_m, m1, n1);
+    const char* const next_a = (const char*)(A + m1 * lda);
+    const char* const next_b = (const char*)(B + n1 * ldb);
+    unsigned long long* tr = nullptr;
+    if (ep.trace) {
+      const int64_t tile_id = (m0 / 256) * ntn + n0 / 256;
+      if (tile_id < 8192) tr = ep.trace + tile_id * 32;
+    }
+    if (tr && threadIdx.x == 0) { tr[0] = tr[1] = clock64(); tr[30] = wall_clock64(); }
+    {
+      // the last K step's twelve spare issue slots: this tile's epilogue tables and residual patches 0 and 1, the next tile's table
+      const int64_t mc = m0 + wm * 128, nc = n0 + wn * 128;
+      const char* const rb_ = (const char*)((const OutT*)ep.resid + mc * ep.ldr + nc);
+      const bool rln = LNO && ep.rln_stats != nullptr;
+      const float* const dummy = (const float*)A;
+      const float* const t_g = rln ? ep.rln_g + nc : dummy;
+      const float* const t_b = rln ? ep.rln_b + nc : dummy;
+      const float* const t_s = rln ? ep.rln_stats + mc * 2 : dummy;
+      const float* const t_bias = ep.bias ? ep.bias + n1 + wn * 128 : dummy;
+      uint32_t ro[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ro[k] = (uint32_t)((lane0 >> 3) * ldr2) + (((lane0 & 7) ^ ((4 * k + (lane0 >> 4)) & 7)) << 4);
+      const int w1k = wave * 1024;
+      auto tail = [&](int slot, int u_spare, int u_olda) __attribute__((always_inline)) {
+        char* const s0 = smem + u_spare + w1k;               // own slices of the spare: 0-3 patch 0, 4 gamma | beta, 5 statistics, 6 next table
+        if (slot == 0) g7_table2(t_g, t_b, s0 + 4 * 4096, lane0);
+        else if (slot == 1) g7_table1(t_s, s0 + 5 * 4096, lane0);
+        else if (slot == 2 || slot == 3) g7_table2(dummy, t_bias, s0 + 6 * 4096, lane0);
+        else if (slot < 8) g7_dma(rb_ + (size_t)(8 * (slot - 4)) * ldr2, ro[slot - 4], g7_lds_addr(s0) + (slot - 4) * 4096);     // patch 0 = (mi 0, nh 0)
+        else g7_dma(rb_ + 128 + (size_t)(8 * (slot - 8)) * ldr2, ro[slot - 8], lds_base + u_olda + w1k + (slot - 8) * 4096);      // patch 1 = (mi 0, nh 1)
+      };
+      gemm_mainloop7_cont<T, true>(src, cur_a, cur_b, next_a, next_b, nk, smem, ring, acc, tr, tail);
+    }
+    if (tr && threadIdx.x == 0) tr[15] = clock64();
+    tr_prev = tr;
+    pm = m0; pn = n0; live = true;
+    cur_a = next_a; cur_b = next_b; m0 = m1; n0 = n1; have = has_next;
+  }
+  G7_WAIT_VM(0);
+}
+
 static int g7_num_cus() {
   static int n = 0;
   if (!n) {
@@ -821,11 +1115,37 @@ static int launch7c(const void* A, int64_t lda, const void* B, int64_t ldb, void
   return 0;
 }
 
+template <typename T, int ACT, int LNF>
+static int launch7r(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                    int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
+  const int64_t ntiles = (M / 256) * (N / 256);
+  if (ntiles >= 0x7fff0000LL) OM_FAIL("gemm: more than 2^31 output tiles");
+  int grid = g7_num_cus();
+  const int cap = om_option(OM_OPT_GEMM_MAX_GRID);
+  if (cap > 0 && cap < grid) grid = cap;
+  if (ntiles < grid) grid = (int)ntiles;
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set) {
+    OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel7r<T, ACT, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
+    attr_set = true;
+  }
+  const bool timing = om_timing_on();
+  if (timing) om_timing_begin(OM_TIMING_GEMM_BF16, s);
+  hipLaunchKernelGGL((gemm_nt_kernel7r<T, ACT, LNF>), dim3((unsigned)grid), dim3(G6_THREADS), G7_LDS_BYTES, s,
+                     (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, (std::max(1, om_option(OM_OPT_GEMM_GROUP_M)) & 0xffff) | (ep.reverse ? 1 << 16 : 0));
+  if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, 2.0 * (double)M * (double)N * (double)K);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T, int ACT, bool RESID, int LNF>
 static int launch7(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                    int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
   if constexpr (!RESID && LNF <= 1) {      // the continuous ring: needs three K steps (its prefetch reaches at most one tile ahead)
     if (K * 2 >= 3 * G7_ROW_BYTES && om_option(OM_OPT_GEMM_CONT) != 0) return launch7c<T, ACT, LNF>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+  }
+  if constexpr (RESID && (LNF == 0 || LNF == 2)) {      // one-plane residual variants on the continuous ring (bit 1 of the option)
+    if (K * 2 >= 3 * G7_ROW_BYTES && (om_option(OM_OPT_GEMM_CONT) & 2) != 0) return launch7r<T, ACT, LNF>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
   }
   const int64_t ntiles = (M / 256) * (N / 256);
   if (ntiles >= 0x7fff0000LL) OM_FAIL("gemm: more than 2^31 output tiles");      // g7_tile works in 32 bits

@@ -138,7 +138,7 @@ int main(int argc, char** argv) {
   }
   hipMemset(st_out, 0, (size_t)M * 8);
   hipMalloc(&g_rlo, (size_t)M * 768 * 2); hipMalloc(&g_clo, (size_t)M * 768 * 2); fill_bf16(g_rlo, (size_t)M * 768, 0.004f, 7);
-  if (!(G7_ABL)) for (g_cont = 0; g_cont < 2; ++g_cont) {
+  if (!(G7_ABL)) for (g_cont = 0; g_cont < 4; g_cont += 3) {
     check_plain(4096, 768, 768, A, B, C, vecs); check_plain(2048, 2304, 768, A, B, C, vecs); check_plain(2048, 768, 3072, A, B, C, vecs);
     check_plain(512, 512, 128, A, B, C, vecs); check_plain(512, 256, 64, A, B, C, vecs); check_plain(65536, 768, 192, A, B, C, vecs);
   }
@@ -165,16 +165,16 @@ int main(int argc, char** argv) {
     return 0;
   }
   for (int round = 0; round < 2; ++round) {
-    for (int cont = 0; cont < 2; ++cont) {      // the ring restarted per tile (round 3) / continuous (round 4): the variants without a residual
+    for (int cont : {0, 3}) {      // the ring restarted per tile (round 3) / continuous (round 4: 7c without, 7r with a residual)
       g_cont = cont;
       printf("-- continuous ring %s\n", cont ? "ON" : "off");
       run<OM_ACT_NONE, false, 1>("qkv (ln-folded A)", M, 2304, 768, A, B, C, R, vecs, st_in, st_out);
+      run<OM_ACT_NONE, true, 2>("out-proj (+LN resid, stats)", M, 768, 768, A, B, C, R, vecs, st_in, st_out);
       run<OM_ACT_GELU_ERF, false, 1>("ffn1 + gelu (ln-folded A)", M, 3072, 768, A, B, C, R, vecs, st_in, st_out);
-      run<OM_ACT_NONE, false, 1>("ffn1 shape, no gelu", M, 3072, 768, A, B, C, R, vecs, st_in, st_out);
+      run<OM_ACT_NONE, true, 2>("ffn2 (+LN resid, stats)", M, 768, 3072, A, B, C, R, vecs, st_in, st_out);
+      run<OM_ACT_NONE, true, 0>("ffn2 shape, plain residual", M, 768, 3072, A, B, C, R, vecs, st_in, st_out);
       run<OM_ACT_NONE, false, 0>("plain", 32768, 3072, 3072, A, B, C, R, vecs, st_in, st_out);
     }
-    run<OM_ACT_NONE, true, 2>("out-proj (+LN resid, stats)", M, 768, 768, A, B, C, R, vecs, st_in, st_out);
-    run<OM_ACT_NONE, true, 2>("ffn2 (+LN resid, stats)", M, 768, 3072, A, B, C, R, vecs, st_in, st_out);
     run<OM_ACT_NONE, true, 3>("out-proj two planes", M, 768, 768, A, B, C, R, vecs, st_in, st_out);
     run<OM_ACT_NONE, true, 3>("ffn2 two planes", M, 768, 3072, A, B, C, R, vecs, st_in, st_out);
   }
