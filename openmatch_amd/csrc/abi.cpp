@@ -107,7 +107,7 @@ void opt_init() {
   e = getenv("OM_GEMM_MAX_GRID");
   g_opt[OM_OPT_GEMM_MAX_GRID] = e ? atoi(e) : 0;
   e = getenv("OM_GEMM_CONT");
-  g_opt[OM_OPT_GEMM_CONT] = e ? atoi(e) : 3;
+  g_opt[OM_OPT_GEMM_CONT] = e ? atoi(e) : 7;
   g_opt_init.store(true);
 }
 }  // namespace

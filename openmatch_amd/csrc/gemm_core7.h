@@ -258,9 +258,9 @@ __device__ __forceinline__ void g7_ring_reset(G7Ring& r) {
 // its first residual patches go into the units that step frees (the spare during sub-steps 1-2, the unit A(nk - 1) leaves
 // behind the barrier), so that the epilogue starts on landed data.  The tile after then starts with step 0 resident only and
 // issues A(1) / the first half of B(1) itself.  The eight issues of sub-steps 1-2 are the step's youngest at its barrier
-// either way (vmcnt(8)).
+// either way (vmcnt(8)).  TAIL_EMPTY: a tail that issues nothing (the index scan: its filter needs the three units for staging).
 struct G7NoTail { __device__ __forceinline__ void operator()(int, int, int) const {} };
-template <typename T, bool TAIL = false, typename TailFn = G7NoTail>
+template <typename T, bool TAIL = false, typename TailFn = G7NoTail, bool TAIL_EMPTY = false>
 __device__ __forceinline__ void gemm_mainloop7_cont(const G7SrcU& src, const char* cur_a, const char* cur_b,
                                                     const char* next_a, const char* next_b, int nk, char* smem, G7Ring& ring,
                                                     f32x16_t (&acc)[4][4], unsigned long long* tr = nullptr, TailFn tail = TailFn()) {
@@ -312,7 +312,8 @@ __device__ __forceinline__ void gemm_mainloop7_cont(const G7SrcU& src, const cha
     G7C_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[1], b, kbp, u_bn, 4, -1, LASTSTEP)   /* second half of B(t+1) */ \
     G7C_SUB(a1, b1, a0, b0, u_ac, u_bc, slot[2], a, ka, u_sp, 0, 0, LASTSTEP)     /* A(t+2) */            \
     G7C_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[3], a, ka, u_sp, 4, 4, LASTSTEP)                            \
-    __builtin_amdgcn_s_waitcnt(0x0078);                /* vmcnt(8) lgkmcnt(0): everything but the last eight issues has landed */ \
+    /* vmcnt(8) lgkmcnt(0): everything but the last eight issues has landed (an EMPTY tail issues nothing behind sub-steps 1-2: vmcnt(0)) */ \
+    if ((LASTSTEP) && TAIL_EMPTY) __builtin_amdgcn_s_waitcnt(0x0070); else __builtin_amdgcn_s_waitcnt(0x0078); \
     __builtin_amdgcn_s_barrier();                                                                        \
     G7_FENCE();                                                                                          \
     G7C_SUB(a1, b1, a0, b0, u_an, u_bn, slot[0], b, kb, u_ac, 0, 8, LASTSTEP)     /* first half of B(t+2) into the unit A(t) leaves */ \

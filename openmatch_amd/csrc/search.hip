@@ -359,6 +359,180 @@ __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7(
   G7_WAIT_VM(0);
 }
 
+// ---- the same scan on the CONTINUOUS ring (round 4; gemm_core7.h gemm_mainloop7_cont, gemm_wide7.h kernels 7c / 7r) ------
+// What the kernel above pays per tile beside its 12 k-cycle filter: 16 wave-uniform branches in every K step (one around each
+// DMA issue: ~800 of a step's ~3200 cycles -- the branch-free loop runs 2400), 16 DMA issues of K step 1 at every tile start
+// and a cold first step.  Here the K loop of a pair prefetches step 0 of the next pair (its last step issues nothing else:
+// TAIL_EMPTY), A(1) of the next pair is issued right behind the K loop and lands under the filter, the first half of B(1)
+// behind the filter.  The filter's staging lives in the units the last step frees -- this wave's own slices of them, so no
+// barrier brackets the filter:
+//     ring.bn (the unit A(nk - 1) left)   slices 0-7   keys 0 .. 1023
+//     ring.sp (the unit B(nk - 1) left)   slices 0-3   keys 1024 .. 1535;  4-6 query numbers;  7 the next pair's thresholds
+//     ring.an (the spare of the last step)              A(1) of the next pair
+#define SC7C_CAP 1536
+struct Sc7cStage { char* bn; char* sp; };
+__device__ __forceinline__ char* sc7c_key_slot(const Sc7cStage& st, unsigned pos) {
+  const unsigned sl = pos >> 7;
+  return (sl < 8 ? st.bn + sl * 4096 : st.sp + (sl - 8) * 4096) + (pos & 127) * 8;
+}
+__device__ __forceinline__ uint16_t* sc7c_q_slot(const Sc7cStage& st, unsigned pos) { return (uint16_t*)(st.sp + (4 + (pos >> 9)) * 4096 + (pos & 511) * 2); }
+__device__ __forceinline__ void sc7c_flush(const Sc7cStage& st, unsigned from, unsigned wcount, int lane, int64_t q0, u64* __restrict__ keys,
+                                           unsigned* __restrict__ cnt) {
+  for (unsigned i = from + (unsigned)lane; i < wcount; i += 64) {
+    const u64 key = *(const u64*)sc7c_key_slot(st, i);
+    const int64_t q = q0 + *sc7c_q_slot(st, i);
+    const unsigned pos = atomicAdd(cnt + q, 1u);
+    if (pos < SORT_CAP) keys[q * SORT_CAP + pos] = key;
+  }
+}
+template <int MI0, int MI1>
+__device__ __forceinline__ void sc7c_filter(f32x16_t (&acc)[4][4], const float (&th)[4], uint32_t id0, uint32_t ql0, int lane, const Sc7cStage& st,
+                                            unsigned& wcount, int64_t q0, u64* __restrict__ keys, unsigned* __restrict__ cnt) {
+#pragma unroll
+  for (int mi = MI0; mi < MI1; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      asm volatile("" : "+a"(acc[mi][ni]));            // stays in its AGPRs until this point
+      const f32x16_t a = acc[mi][ni];
+      float gm[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gm[g] = fmaxf(fmaxf(fmaxf(a[4 * g], a[4 * g + 1]), a[4 * g + 2]), a[4 * g + 3]);
+      const float mx = fmaxf(fmaxf(fmaxf(gm[0], gm[1]), gm[2]), gm[3]);
+      if (__builtin_amdgcn_ballot_w64(mx >= th[mi]) != 0) {          // wave-uniform: some lane holds a survivor
+        if (wcount > SC7C_CAP - 1024) { sc7c_flush(st, 0u, wcount, lane, q0, keys, cnt); wcount = 0; }      // a block adds at most 1024
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (__builtin_amdgcn_ballot_w64(gm[g] >= th[mi]) == 0) continue;
+#pragma unroll
+          for (int r = 4 * g; r < 4 * g + 4; ++r) {
+            const uint32_t off = (uint32_t)(ni * 32 + (r & 3) + 8 * (r >> 2));
+            const bool pass = a[r] >= th[mi];
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+            if (m != 0) {
+              if (pass) {
+                const unsigned pos = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                *(u64*)sc7c_key_slot(st, pos) = pack_key(a[r], id0 + off);
+                *sc7c_q_slot(st, pos) = (uint16_t)(ql0 + mi * 32);
+              }
+              wcount += (unsigned)__builtin_popcountll(m);
+            }
+          }
+        }
+      }
+      G7_FENCE_();
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7c(
+    const T* __restrict__ rows, int64_t nrows, uint32_t row_base, const T* __restrict__ queries,
+    int64_t nq, int64_t d, const float* __restrict__ thr, u64* __restrict__ keys,
+    unsigned* __restrict__ cnt, int group_m, unsigned long long* __restrict__ trace) {
+  typedef typename MmaOps<T>::frag_t frag_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane0 = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t ntr = (nrows + 255) / 256, ntq = (nq + 255) / 256;
+  const int nk = (int)((d * 2) / G7_ROW_BYTES);
+  unsigned wcount = 0;                     // records in this wave's staging area (wave-uniform)
+  unsigned pend_n = 0;                     // records of the previous tile held in registers, one per lane (wave-uniform)
+  u64 pend_key = 0; uint32_t pend_q = 0;
+  int64_t r0, q0;
+  const int qgroup = group_m >> 8;
+  group_m &= 255;
+  Sc7Walk walk;
+  if (!walk.init(ntr, ntq, group_m, qgroup, r0, q0)) return;
+  G7SrcU src;
+  g7_offsets_u<T>(src, d, d, wave, lane0);         // every row of every tile exists (padded query panel, whole row tiles)
+  G7Ring ring;
+  g7_ring_reset(ring);
+  const uint32_t lds_base = g7_lds_addr(smem);
+  const char* cur_a = (const char*)(queries + q0 * d);
+  const char* cur_b = (const char*)(rows + r0 * d);
+  g7_dma((const char*)(thr + q0 + wm * 128), lane0 * 16, lds_base + ring.sp + (7 * 4 + wave) * 1024);
+  g7_fill_a(src, cur_a, smem + ring.ac, wave);
+  g7_fill_b(src, cur_b, smem + ring.bc, wave);
+  g7_fill_a(src, cur_a + G7_ROW_BYTES, smem + ring.an, wave);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) g7_issue_b(src, cur_b + G7_ROW_BYTES, i, lds_base + ring.bn + (i * 4 + wave) * 1024);
+  G7_WAIT_VM(12);                                  // the thresholds and K step 0 (A(1) and half of B(1) may be outstanding)
+  __builtin_amdgcn_s_barrier();                    // first pair only: K step 0 published
+  int64_t r1 = r0, q1 = q0;
+  bool has_next = walk.next(r1, q1);
+  for (;;) {
+    unsigned long long* tr = nullptr;
+    if (trace) {
+      const int64_t tile_id = (r0 / 256) * ntq + q0 / 256;
+      if (tile_id < 8192) tr = trace + tile_id * 32;
+    }
+    if (tr && threadIdx.x == 0) { tr[0] = tr[1] = clock64(); tr[30] = wall_clock64(); }
+    float th[4];
+    f32x16_t acc[4][4];
+    {
+      int lane_i = lane0;
+      asm volatile("" : "+v"(lane_i));
+      const char* const tab = smem + ring.sp + (7 * 4 + wave) * 1024;      // this pair's thresholds (fetched under the previous filter)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) th[mi] = *(const float*)(tab + (mi * 32 + (lane_i & 31)) * 4);
+      const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+      const frag_t zf = __builtin_bit_cast(frag_t, z4);
+      const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { acc[q >> 2][q & 3] = zero; MmaOps<T>::mma(zf, zf, acc[q >> 2][q & 3]); }   // zero by the matrix core
+    }
+    const char* const next_a = (const char*)(queries + q1 * d);      // (no next pair: this one again -- a harmless prefetch)
+    const char* const next_b = (const char*)(rows + r1 * d);
+    gemm_mainloop7_cont<T, true, G7NoTail, true>(src, cur_a, cur_b, next_a, next_b, nk, smem, ring, acc, tr);
+    if (tr && threadIdx.x == 0) tr[15] = clock64();
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const Sc7cStage st = {smem + ring.bn + wave * 1024, smem + ring.sp + wave * 1024};
+    // the previous tile's records: list positions requested now, consumed half a filter later
+    unsigned pend_pos = 0;
+    if (pend_n && (unsigned)lane < pend_n) pend_pos = atomicAdd(cnt + pend_q, 1u);
+    // under the filter: A(1) of the next pair (into the unit the filter does not use) and its thresholds
+    g7_fill_a(src, next_a + G7_ROW_BYTES, smem + ring.an, wave);
+    g7_dma((const char*)(thr + q1 + wm * 128), lane0 * 16, g7_lds_addr(st.sp) + 7 * 4096);
+    G7_FENCE_();
+    {
+      const uint32_t id0 = row_base + (uint32_t)r0 + (uint32_t)(wn * 128 + 4 * (lane >> 5));    // row id of (ni = 0, r = 0)
+      const uint32_t ql0 = (uint32_t)(wm * 128 + (lane & 31));
+      sc7c_filter<0, 2>(acc, th, id0, ql0, lane, st, wcount, q0, keys, cnt);
+      if (pend_n) {
+        if ((unsigned)lane < pend_n && pend_pos < SORT_CAP) keys[(int64_t)pend_q * SORT_CAP + pend_pos] = pend_key;
+        pend_n = 0;
+      }
+      G7_FENCE_();
+      sc7c_filter<2, 4>(acc, th, id0, ql0, lane, st, wcount, q0, keys, cnt);
+      if (wcount > 64) sc7c_flush(st, 64u, wcount, lane, q0, keys, cnt);
+      pend_n = wcount < 64u ? wcount : 64u;
+      if ((unsigned)lane < pend_n) {
+        pend_key = *(const u64*)sc7c_key_slot(st, (unsigned)lane);
+        pend_q = (uint32_t)q0 + *sc7c_q_slot(st, (unsigned)lane);
+      }
+      wcount = 0;
+    }
+    // A(1) and the thresholds were fetched a whole filter ago; everything issued since (the key stores of the pending records,
+    // half a filter old; a synchronous flush, rare) is older than any DMA of the next K loop.  The staging area has been read
+    // (lgkmcnt): the first half of B(1) may overwrite it.
+    G7_WAIT_VM(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g7_issue_b(src, next_b + G7_ROW_BYTES, i, lds_base + ring.bn + (i * 4 + wave) * 1024);
+    if (tr && threadIdx.x == 0) { tr[28] = clock64(); tr[29] = blockIdx.x; tr[31] = wall_clock64(); }
+    if (!has_next) break;
+    cur_a = next_a; cur_b = next_b; r0 = r1; q0 = q1;
+    has_next = walk.next(r1, q1);
+  }
+  if (pend_n && (unsigned)lane0 < pend_n) {
+    const unsigned pos = atomicAdd(cnt + pend_q, 1u);
+    if (pos < SORT_CAP) keys[(int64_t)pend_q * SORT_CAP + pos] = pend_key;
+  }
+  G7_WAIT_VM(0);
+}
+
 // Small query batches (<= 128 queries): the scan is a pass over the whole f16 index (13.6 GB at 8.8 M x 768) that has to
 // run at HBM speed.  The generic 128-query tile spends 1.7 PFLOP of matrix-core time on padding at Q = 1 (3.99 ms per
 // search in round 1, profiles/r01_search_shapes.jsonl).  Round 2 kept one or two 32-query blocks resident in LDS beside a
@@ -1009,6 +1183,10 @@ struct Scan {
           int ncu = g7_num_cus();
           const int64_t tiles = (whole / 256) * ntn;
           if (tiles < ncu) ncu = (int)tiles;
+          if ((d * 2) / G7_ROW_BYTES >= 3 && (om_option(OM_OPT_GEMM_CONT) & 4))      // bit 2: the scan on the continuous ring
+            hipLaunchKernelGGL((sim_filter_kernel7c<f16_t>), dim3((unsigned)ncu), dim3(G6_THREADS), G7_LDS_BYTES, s, idx16 + r0 * d, whole,
+                               (uint32_t)r0, ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8 | (std::max(1, om_option(OM_OPT_SCAN_QGROUP)) << 8), omk_debug_trace());
+          else
           hipLaunchKernelGGL((sim_filter_kernel7<f16_t>), dim3((unsigned)ncu), dim3(G6_THREADS), G7_LDS_BYTES, s, idx16 + r0 * d, whole,
                              (uint32_t)r0, ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8 | (std::max(1, om_option(OM_OPT_SCAN_QGROUP)) << 8), omk_debug_trace());
         }
@@ -1214,6 +1392,8 @@ extern "C" int om_sim_topk(int mode, const float* queries, int64_t n_queries,
     OM_HIP(hipFuncSetAttribute((const void*)sim_stream_reg_kernel<f16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS));
     OM_HIP(hipFuncSetAttribute((const void*)sim_stream_reg_kernel<f16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS));
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel7<f16_t>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
+    OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel7c<f16_t>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
     OM_HIP(hipFuncSetAttribute((const void*)select_radix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                SORT_CAP * 8 + 1024 + 64));
