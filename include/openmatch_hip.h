@@ -42,6 +42,8 @@ extern "C" {
 #define OM_ACT_RELU 2      /* HF "relu"      (T5 DenseReluDense)                  */
 #define OM_ACT_GELU_TANH 3 /* HF "gelu_new"  (T5 v1.1 gated act)                  */
 #define OM_ACT_MUL_RESID 0x100 /* flag: multiply by `resid` instead of adding it (gated FFN) */
+#define OM_ACT_PRE_GRAD 0x200  /* flag (erf-GELU training epilogue, 16-bit output): `pre_act` receives gelu'(v) instead of the pre-activation
+                                * v -- the backward's dgrad then multiplies by it (OM_ACT_MUL_RESID) instead of evaluating gelu' */
 
 /* encoder architecture */
 #define OM_ARCH_BERT 0 /* HF:models/bert/modeling_bert.py  BertModel       */
@@ -111,7 +113,8 @@ void om_debug_gemm_gen(int gen);
                                     * variants, bit 2: the f16 index scan of wide query batches, run on the continuous ring (the K loop of
                                     * a tile prefetches the next tile's first two steps; epilogue and accumulator initialisation of the next
                                     * tile interleaved); 0: the ring restarts per tile as in round 3 (A/B measurements) */
-#define OM_OPT_COUNT 17
+#define OM_OPT_TRAIN_TAPE_GRAD 17  /* 1 (default): the bf16 BERT training forward keeps gelu'(f) on its tape instead of f (env OM_TRAIN_TAPE_GRAD) */
+#define OM_OPT_COUNT 18
 int om_debug_option(int opt, int value);
 /* the attention kernel alone (bf16 qkv [B*L, 3H] -> ctx [B*L, H]; mask [B, L] int64), for timing: csrc/kernels.h omk_attention */
 int om_debug_attention(const void* qkv, void* ctx, const int64_t* mask, int64_t B, int L, int H, int heads, void* stream);

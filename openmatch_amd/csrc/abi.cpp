@@ -106,6 +106,8 @@ void opt_init() {
   g_opt[OM_OPT_TRAIN_WGRAD_BATCH] = e ? atoi(e) : 4;
   e = getenv("OM_GEMM_MAX_GRID");
   g_opt[OM_OPT_GEMM_MAX_GRID] = e ? atoi(e) : 0;
+  e = getenv("OM_TRAIN_TAPE_GRAD");
+  g_opt[OM_OPT_TRAIN_TAPE_GRAD] = e ? atoi(e) : 1;
   e = getenv("OM_GEMM_CONT");
   g_opt[OM_OPT_GEMM_CONT] = e ? atoi(e) : 7;
   g_opt_init.store(true);

@@ -62,7 +62,11 @@ __device__ __forceinline__ float epi_value(float v, int64_t m, int64_t n, int64_
                                   const GemmEpilogue& ep, uint32_t drop_thresh, float drop_scale) {
   if (ACT == OM_ACT_GELU_ERF_GRAD) return v;          // multiplied by gelu'(resid) at store time
   if (TRAIN) {
-    if (ep.pre_act && m < M && n < N) ElemOps<OutT>::store((OutT*)ep.pre_act + m * ep.ldp + n, v);
+    if (ep.pre_act && m < M && n < N) {
+      float pv = v;          // OM_ACT_PRE_GRAD: the tape keeps gelu'(v) instead of v (every generation's epilogue honours the flag)
+      if (ACT == OM_ACT_GELU_ERF && (ep.act & OM_ACT_PRE_GRAD)) pv = sizeof(OutT) == 2 ? gelu_erf_grad_fast(v) : gelu_erf_grad(v);
+      ElemOps<OutT>::store((OutT*)ep.pre_act + m * ep.ldp + n, pv);
+    }
   }
   v = act_apply<ACT, sizeof(OutT) == 2>(v);
   if (TRAIN) {

@@ -38,6 +38,25 @@ __device__ __forceinline__ f32x2_t gelu_erf_poly2(f32x2_t x) {
   return x * __builtin_elementwise_fma(xc, q, (f32x2_t){0.5f, 0.5f});
 }
 
+// gelu(x) and gelu'(x) = Phi(x) + x phi(x) from ONE evaluation of the polynomial (training forward, OM_ACT_PRE_GRAD): the
+// backward's GELU' epilogue (the same polynomial + exp2 on a [tokens, 3072] tensor: 160 us per layer against ~60 for a plain
+// multiply, profiles/r03_bench_v4_kernel_stats.csv) becomes a multiplication by a stored tensor.
+__device__ __forceinline__ f32x2_t gelu_erf_poly2_both(f32x2_t x, f32x2_t& grad) {
+  const f32x2_t xc = {__builtin_amdgcn_fmed3f(x[0], -4.2f, 4.2f), __builtin_amdgcn_fmed3f(x[1], -4.2f, 4.2f)};
+  const f32x2_t t = xc * xc;
+  f32x2_t q = {5.998145036e-11f, 5.998145036e-11f};
+#define OM_G2(K) q = __builtin_elementwise_fma(q, t, (f32x2_t){K, K})
+  OM_G2(-5.633389311e-09f); OM_G2(2.343703613e-07f); OM_G2(-5.760840850e-06f); OM_G2(9.457556007e-05f);
+  OM_G2(-1.114161685e-03f); OM_G2(9.830250405e-03f); OM_G2(-6.636118144e-02f); OM_G2(3.989123106e-01f);
+#undef OM_G2
+  const f32x2_t Phi = __builtin_elementwise_fma(xc, q, (f32x2_t){0.5f, 0.5f});
+  const f32x2_t x2 = x * x;
+  const f32x2_t pdf = {0.3989422804014327f * __builtin_amdgcn_exp2f(-0.7213475204444817f * x2[0]),
+                       0.3989422804014327f * __builtin_amdgcn_exp2f(-0.7213475204444817f * x2[1])};
+  grad = __builtin_elementwise_fma(x, pdf, Phi);
+  return x * Phi;
+}
+
 // The same on EIGHT elements at once.  One Horner chain is nine dependent packed FMAs, and the compiler issues the
 // chains of a patch one after the other (each instruction waits for the previous one's result: the GELU epilogue of the
 // persistent GEMM ran at ~9 cycles per VALU instruction).  Vector-of-8 arithmetic expands every step into four
@@ -63,10 +82,19 @@ __device__ __forceinline__ f32x2_t epi_pair(f32x2_t v, int64_t m, int64_t n, int
                                            const GemmEpilogue& ep, const EpiScalars& es, uint64_t dbits, int e0) {
   if (ACT == OM_ACT_GELU_ERF && sizeof(OutT) == 2) {
     if (TRAIN) {
-      if (ep.pre_act && m < M && n < N)
-        *(uint32_t*)((OutT*)ep.pre_act + m * ep.ldp + n) = Half16<OutT>::pack2(v[0], v[1]);
+      if (ep.act & OM_ACT_PRE_GRAD) {      // the tape keeps gelu'(v): Phi(v) is the polynomial the forward evaluates anyway, + v phi(v) by exp2
+        f32x2_t gr;
+        v = gelu_erf_poly2_both(v, gr);
+        if (ep.pre_act && m < M && n < N)
+          *(uint32_t*)((OutT*)ep.pre_act + m * ep.ldp + n) = Half16<OutT>::pack2(gr[0], gr[1]);
+      } else {
+        if (ep.pre_act && m < M && n < N)
+          *(uint32_t*)((OutT*)ep.pre_act + m * ep.ldp + n) = Half16<OutT>::pack2(v[0], v[1]);
+        v = gelu_erf_poly2(v);
+      }
+    } else {
+      v = gelu_erf_poly2(v);
     }
-    v = gelu_erf_poly2(v);
     if (TRAIN) {
       if (es.drop_thresh) {
         v[0] = dropout_field(dbits, e0, es.drop_thresh) ? v[0] * es.drop_scale : 0.f;

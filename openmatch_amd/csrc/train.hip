@@ -239,6 +239,9 @@ extern "C" int om_encoder_train_set_layer_events(void* const* events, int n) {
 // "Consumed by one call" on EVERY exit path: the array is owned by the caller (a ctypes buffer that may be freed right after the
 // call), so an early return or a failing launch must not leave the pointer behind for the next backward on this thread.
 struct BwdEventsScope { ~BwdEventsScope() { g_bwd_events = nullptr; g_bwd_nevents = 0; } };
+// 16-bit BERT training keeps gelu'(f) on the tape instead of f (OM_ACT_PRE_GRAD: honoured by every generation's training
+// epilogue); forward and backward must agree on what the tape's `f` holds, so both ask here
+static bool tape_grad(int dt, int64_t, int, int) { return dt == OM_BF16 && om_option(OM_OPT_TRAIN_TAPE_GRAD) != 0; }
 static int record_layer_event(int l, hipStream_t s) {
   if (g_bwd_events && l < g_bwd_nevents && g_bwd_events[l]) OM_HIP(hipEventRecord((hipEvent_t)g_bwd_events[l], s));
   return 0;
@@ -439,7 +442,8 @@ static int train_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* 
     RUN(omk_layernorm(dt, y1, H, x1, H, lw.ln1_g, lw.ln1_b, M, H, c->ln_eps, 0, s));
     ep = GemmEpilogue{};
     char* gl = t.g + t.sf * l;
-    ep.bias = lw.ffn1_b; ep.act = OM_ACT_GELU_ERF; ep.pre_act = f; ep.ldp = F;
+    // 16-bit runs keep gelu'(f) on the tape instead of f (the forward has Phi(f) in hand; the backward multiplies): OM_ACT_PRE_GRAD
+    ep.bias = lw.ffn1_b; ep.act = OM_ACT_GELU_ERF | (tape_grad(dt, M, F, H) ? OM_ACT_PRE_GRAD : 0); ep.pre_act = f; ep.ldp = F;
     RUN(omk_gemm(dt, x1, H, lw.ffn1_w, H, dt, gl, F, M, F, H, ep, s));
     ep = GemmEpilogue{};
     ep.bias = lw.ffn2_b; ep.resid = x1; ep.ldr = H; ep.drop_p = hidden_dropout; ep.seed = site_seed(seed, l, 4);
@@ -600,7 +604,8 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
     WGRAD(0, dO, H, gl, F, lg.ffn2_w, lg.ffn2_b);                   // dW2 [H,F], db2
     {
       GemmEpilogue e1 = {};
-      e1.act = OM_ACT_GELU_ERF_GRAD; e1.resid = f; e1.ldr = F;      // df = (dO W2) * gelu'(f);  W2^T [F,H]
+      // df = (dO W2) * gelu'(f);  W2^T [F,H].  The tape holds gelu'(f) itself in 16-bit runs (see the forward)
+      e1.act = tape_grad(dt, M, F, H) ? OM_ACT_MUL_RESID : OM_ACT_GELU_ERF_GRAD; e1.resid = f; e1.ldr = F;
       WGRAD_DONE(l + 1, 1);                                         // ws.df: last read by dW1 of the layer above
       RUN(omk_gemm(dt, dO, H, wt.f2, H, dt, dfl, F, M, F, H, e1, s));
     }
