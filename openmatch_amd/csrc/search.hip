@@ -557,7 +557,9 @@ __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7c(
 #define SR_LDS (SR_RING * SR_UBYTES)
 #define SR_IPU (SR_UROWS / 32)                  // DMA instructions per wave and unit
 #define SR_NKMAX 12
-template <typename T, int NB>
+// DBG (timing probes only, OM_OPT_SEARCH_DEBUG bits 3 / 4; the results are wrong): 1 = every second MFMA sub-step skipped (does
+// the pass's time follow its matrix-core work?), 2 = no MFMA at all
+template <typename T, int NB, int DBG = 0>
 __global__ __launch_bounds__(G6_THREADS) void sim_stream_reg_kernel(
     const T* __restrict__ rows, int64_t nrows, uint32_t row_base, const T* __restrict__ queries, int64_t nq, int64_t d,
     const float* __restrict__ thr, u64* __restrict__ keys, unsigned* __restrict__ cnt, int nt) {
@@ -674,6 +676,14 @@ __global__ __launch_bounds__(G6_THREADS) void sim_stream_reg_kernel(
   };
   int c_slot = 0, u = 0;
   int64_t tile = blockIdx.x;
+  // Round 4, what the pass's time is made of (timing probes with half / none of the MFMAs compiled out, DBG above;
+  // profiles/r04_probe9_small_batch_mfma_share.log): with HALF the matrix-core work the pass runs at the no-MFMA time (2.16-2.40 ms
+  // whatever the batch: the HBM stream), with all of it +0.2 ms (Q = 1) to +1.0 ms (Q = 64, 128) -- a threshold, not a slope,
+  // and not the clock round 3 suspected.  Reading the first fragments of unit u + 1 under the last MFMAs of unit u (the
+  // barrier of u certifying u + 1 as well, eight units in flight instead of nine) changed nothing (Q = 64 3.20, Q = 128 3.32 ms:
+  // profiles/r04_probe10_small_batch_cross_unit_prefetch.log) and was removed: the chain that is too long for a unit's share of
+  // the stream is the four dependent read -> MFMA stages themselves.
+  frag_t a[2][RBW];
   for (int ti = 0; ti < my_tiles; ++ti) {
 #pragma unroll
     for (int ks = 0; ks < SR_NKMAX; ++ks) {
@@ -690,7 +700,6 @@ __global__ __launch_bounds__(G6_THREADS) void sim_stream_reg_kernel(
         const char* ua = smem + c_slot * SR_UBYTES + arow;
         // the row fragments of sub-step kk + 1 are read under the MFMAs of sub-step kk (order pinned: left alone the
         // compiler reads two fragments, waits, multiplies, reads two ... and every LDS round trip is exposed)
-        frag_t a[2][RBW];
 #pragma unroll
         for (int rt = 0; rt < RBW; ++rt) a[0][rt] = *(const frag_t*)(ua + rt * 32 * G7_ROW_BYTES + ((half ^ key) << 4));
 #pragma unroll
@@ -704,7 +713,7 @@ __global__ __launch_bounds__(G6_THREADS) void sim_stream_reg_kernel(
           G7_FENCE_();
 #pragma unroll
           for (int rt = 0; rt < RBW; ++rt)
-            MmaOps<T>::mma(a[kk & 1][rt], bq[ks][kk], acc[rt]); // acc[rt][r]: row 8(r>>2) + 4 half + (r&3) of the 32-row block, query 32 nb + l31
+            if (DBG == 0 || (DBG == 1 && !(kk & 1))) MmaOps<T>::mma(a[kk & 1][rt], bq[ks][kk], acc[rt]); // acc[rt][r]: row 8(r>>2) + 4 half + (r&3) of the 32-row block, query 32 nb + l31
         }
         G7_FENCE_();
         // the accumulators' home is the AGPR file: without the pin the compiler keeps them in VGPRs across the (wave-uniform)
@@ -1201,10 +1210,12 @@ struct Scan {
         if (whole) {
           int ncu = g7_num_cus();
           if (whole / SR_UROWS < ncu) ncu = (int)(whole / SR_UROWS);
-#define STREAM(NB_) hipLaunchKernelGGL((sim_stream_reg_kernel<f16_t, NB_>), dim3((unsigned)ncu), dim3(G6_THREADS), SR_LDS, s, idx16 + r0 * d, whole, \
+#define STREAM_(NB_, DBG_) hipLaunchKernelGGL((sim_stream_reg_kernel<f16_t, NB_, DBG_>), dim3((unsigned)ncu), dim3(G6_THREADS), SR_LDS, s, idx16 + r0 * d, whole, \
                                        (uint32_t)r0, ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, (om_option(OM_OPT_SEARCH_DEBUG) & 4) ? 0 : 1)
+#define STREAM(NB_) do { const int dbg_ = (om_option(OM_OPT_SEARCH_DEBUG) >> 3) & 3; if (dbg_ == 1) STREAM_(NB_, 1); else if (dbg_ == 2) STREAM_(NB_, 2); else STREAM_(NB_, 0); } while (0)
           if (nq <= 32) STREAM(1); else if (nq <= 64) STREAM(2); else STREAM(4);
 #undef STREAM
+#undef STREAM_
         }
         if (n > whole)
           hipLaunchKernelGGL((sim_filter_kernel<f16_t>), dim3((unsigned)((nq + G2_BN - 1) / G2_BN)), dim3(G2_THREADS), G2_LDS_BYTES, s, idx16 + (r0 + whole) * d, n - whole,
@@ -1388,9 +1399,9 @@ extern "C" int om_sim_topk(int mode, const float* queries, int64_t n_queries,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES));
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel6<f16_t>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS_BYTES));
-    OM_HIP(hipFuncSetAttribute((const void*)sim_stream_reg_kernel<f16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS));
-    OM_HIP(hipFuncSetAttribute((const void*)sim_stream_reg_kernel<f16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS));
-    OM_HIP(hipFuncSetAttribute((const void*)sim_stream_reg_kernel<f16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS));
+#define SR_ATTR(NB_, DBG_) OM_HIP(hipFuncSetAttribute((const void*)sim_stream_reg_kernel<f16_t, NB_, DBG_>, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS))
+    SR_ATTR(1, 0); SR_ATTR(2, 0); SR_ATTR(4, 0); SR_ATTR(1, 1); SR_ATTR(2, 1); SR_ATTR(4, 1); SR_ATTR(1, 2); SR_ATTR(2, 2); SR_ATTR(4, 2);
+#undef SR_ATTR
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel7<f16_t>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel7c<f16_t>,
