@@ -177,8 +177,13 @@ __device__ __forceinline__ F vfrag_of(v4s_a_t a, v4s_a_t b) { return __builtin_b
 
 // DBG (timing experiments, OM_OPT_ATTENTION_DEBUG): bit 0 no K / V fetch, bit 1 no arithmetic, bit 2 no stores
 // T: bf16_t or f16_t (the float16 inference mode) -- same instruction stream, the other MFMA / conversion opcodes
-template <typename T, int KT, bool BIAS, bool DROP, int DBG = 0>
-__global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) void attention_fwd16_kernel(
+// KTV: the key tiles this (batch, head) walks -- KT, or fewer when its trailing tiles hold no unmasked key (round 4).  Every key
+// at or past kmax[b] is masked and its probability is exactly 0 (exp2(-1e30 - max) with the max over an unmasked key): its K / V
+// rows need not be fetched, scored or multiplied.  One straight-line body per tile count (the kernel below switches once per
+// workgroup): run-time guards around each tile's code cost the full-length case more than the short ones gained (161 vs 148 us,
+// profiles/r04_probe12_*).
+template <typename T, int KT, bool BIAS, bool DROP, int DBG, int KTV>
+__device__ __forceinline__ void attention_fwd16_body(
     const T* __restrict__ qkv, T* __restrict__ ctx, const int64_t* __restrict__ mask,
     const float* __restrict__ pos_bias, int L, int H, int heads, float scale, float drop_p, uint64_t seed, int rev) {
   typedef typename MmaOps<T>::frag_t frag_t;
@@ -194,7 +199,6 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t ld2 = 6 * (int64_t)H;                       // row pitch of qkv in bytes
   const char* const base = (const char*)(qkv + b * L * 3 * (int64_t)H + h * 64);
-
   // K and V rows of this (batch, head): instruction i of wave w moves rows (i * KT + w) * 8 .. + 7, lane -> row
   // (lane >> 3), physical 16-byte chunk (lane & 7) <- source chunk (lane & 7) ^ ((row >> 1) & 7) for K (row-per-lane
   // 16-byte reads), ^ 4 ((row >> 1) & 1) for V: the four rows of a transposing read then sit in the four 64-byte
@@ -202,6 +206,7 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
   if (!(DBG & 1))
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    if (KTV < KT && i * KT + wave >= KTV * 4) continue;         // (wave-uniform) rows of a fully masked key tile
     const int r = (i * KT + wave) * 8 + (lane >> 3);
     const int rr = r < L ? r : L - 1;
     const uint32_t off = (uint32_t)(rr * ld2) + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
@@ -223,10 +228,10 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
   __syncthreads();
   if (q0 >= L) return;
 
-  constexpr int KTC = (DBG & 2) ? 0 : KT;          // key tiles the arithmetic walks
+  constexpr int KTC = (DBG & 2) ? 0 : KTV;         // key tiles the arithmetic walks
   // S^T = K Q^T : lane owns query l31, keys (r&3) + 8(r>>2) + 4 half of each 32-key tile
   const int key = (l31 >> 1) & 7;
-  f32x16_t s[KT];
+  f32x16_t s[KTV];
 #pragma unroll
   for (int t = 0; t < KTC; ++t) {
 #pragma unroll
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
     const AttnDrop dr(drop_p);
 #pragma unroll
     for (int t = 0; t < KTC; ++t)
-#pragma unroll
+  #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const uint64_t bits = attn_drop_bits(seed, b, h, heads, L, q0 + l31, (t * 32 + 8 * g + 4 * half) >> 2);
 #pragma unroll
@@ -351,9 +356,26 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
   }
 }
 
+template <typename T, int KT, bool BIAS, bool DROP, int DBG = 0>
+__global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) void attention_fwd16_kernel(
+    const T* __restrict__ qkv, T* __restrict__ ctx, const int64_t* __restrict__ mask,
+    const float* __restrict__ pos_bias, int L, int H, int heads, float scale, float drop_p, uint64_t seed, int rev,
+    const int* __restrict__ kmax) {
+#define OM_ATTN_BODY(V) attention_fwd16_body<T, KT, BIAS, DROP, DBG, V>(qkv, ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed, rev)
+  if (KT == 4 && !BIAS && !DROP && kmax) {          // (the encoder's inference shape; kmax[b] = L for a row without any unmasked key)
+    const int64_t b = rev ? (int64_t)(gridDim.x / heads) - 1 - blockIdx.x / heads : blockIdx.x / heads;
+    const int kt = (__builtin_amdgcn_readfirstlane(kmax[b]) + 31) >> 5;
+    if (kt <= 1) { OM_ATTN_BODY(1); return; }
+    if (kt == 2) { OM_ATTN_BODY(2); return; }
+    if (kt == 3) { OM_ATTN_BODY(3); return; }
+  }
+  OM_ATTN_BODY(KT);
+#undef OM_ATTN_BODY
+}
+
 template <typename T, int KT, bool BIAS, bool DROP>
 static int launch_attn16_(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias, int64_t B, int L, int H,
-                         int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, int rev) {
+                         int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, int rev, const int* kmax) {
   const int lds = 2 * KT * 32 * 128 + KT * 32 * 4;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
@@ -365,7 +387,7 @@ static int launch_attn16_(const void* qkv, void* ctx, const int64_t* mask, const
 #define OM_ATTN_DBG(D)                                                                                                        \
   case D:                                                                                                                     \
     hipLaunchKernelGGL((attention_fwd16_kernel<bf16_t, 4, false, false, D>), dim3((unsigned)(heads * B)), dim3(256), lds, s,          \
-                       (const bf16_t*)qkv, (bf16_t*)ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed, rev);               \
+                       (const bf16_t*)qkv, (bf16_t*)ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed, rev, kmax);         \
     break;
     switch (dbg) { OM_ATTN_DBG(1) OM_ATTN_DBG(2) OM_ATTN_DBG(3) OM_ATTN_DBG(4) OM_ATTN_DBG(5) OM_ATTN_DBG(6) OM_ATTN_DBG(7) default: break; }
 #undef OM_ATTN_DBG
@@ -373,23 +395,23 @@ static int launch_attn16_(const void* qkv, void* ctx, const int64_t* mask, const
     return 0;
   }
   hipLaunchKernelGGL((attention_fwd16_kernel<T, KT, BIAS, DROP>), dim3((unsigned)(heads * B)), dim3(64 * KT), lds, s, (const T*)qkv,
-                     (T*)ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed, rev);
+                     (T*)ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed, rev, kmax);
   OM_LAUNCH_CHECK();
   return 0;
 }
 template <typename T, int KT>
 static int launch_attn16(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias, int64_t B, int L, int H,
-                         int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, int rev) {
+                         int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, int rev, const int* kmax) {
   if (std::is_same<T, f16_t>::value) {            // float16: BERT-family inference only (no bias table, no dropout)
     if (drop_p > 0.f || pos_bias) OM_FAIL("float16 attention: inference without a position-bias table only");
-    return launch_attn16_<T, KT, false, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev);
+    return launch_attn16_<T, KT, false, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev, kmax);
   }
   if (drop_p > 0.f) {
-    if (pos_bias) return launch_attn16_<bf16_t, KT, true, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, rev);
-    return launch_attn16_<bf16_t, KT, false, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, rev);
+    if (pos_bias) return launch_attn16_<bf16_t, KT, true, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, rev, kmax);
+    return launch_attn16_<bf16_t, KT, false, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, rev, kmax);
   }
-  if (pos_bias) return launch_attn16_<bf16_t, KT, true, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev);
-  return launch_attn16_<bf16_t, KT, false, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev);
+  if (pos_bias) return launch_attn16_<bf16_t, KT, true, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev, kmax);
+  return launch_attn16_<bf16_t, KT, false, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev, kmax);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -584,9 +606,28 @@ static int dispatch_attn(const void* qkv, void* ctx, const int64_t* mask, const 
   return launch_attn<T, 8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
 }
 
+// kmax[b] = 1 + the last unmasked key of batch row b (L when the row has none): once per forward, read by every layer's
+// attention launch (attention_fwd16_kernel: key tiles past it are skipped)
+__global__ void mask_extent_kernel(const int64_t* __restrict__ mask, int64_t B, int L, int* __restrict__ kmax) {
+  const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int lane = threadIdx.x & 63;
+  int last = 0;
+  for (int k = lane; k < L; k += 64) if (mask[b * L + k] != 0) last = k + 1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+  if (lane == 0) kmax[b] = last ? last : L;
+}
+int omk_mask_extent(const int64_t* mask, int64_t B, int L, int* kmax, hipStream_t s) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(mask_extent_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, mask, B, L, kmax);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
 int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
                   const float* pos_bias, int64_t B, int L, int H, int heads, float scale,
-                  float drop_p, uint64_t seed, hipStream_t s, int reverse) {
+                  float drop_p, uint64_t seed, hipStream_t s, int reverse, const int* kmax) {
   if (B <= 0) return 0;
   if (L < 1 || L > 1024) OM_FAIL("sequence length must be in [1,1024]");
   if (L > 256 && drop_p > 0.f) OM_FAIL("training supports sequence lengths up to 256");
@@ -597,22 +638,22 @@ int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
       if (drop_p > 0.f || pos_bias) OM_FAIL("float16 attention: inference without a position-bias table only");
       return launch_attn_long<f16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
     }
-    if (L <= 32) return launch_attn16<f16_t, 1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
-    if (L <= 64) return launch_attn16<f16_t, 2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
-    if (L <= 128) return launch_attn16<f16_t, 4>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
-    if (L <= 192) return launch_attn16<f16_t, 6>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
-    return launch_attn16<f16_t, 8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
+    if (L <= 32) return launch_attn16<f16_t, 1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
+    if (L <= 64) return launch_attn16<f16_t, 2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
+    if (L <= 128) return launch_attn16<f16_t, 4>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
+    if (L <= 192) return launch_attn16<f16_t, 6>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
+    return launch_attn16<f16_t, 8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
   }
   if (L > 256) {                                              // online-softmax kernel, any dtype
     if (dtype == OM_BF16) return launch_attn_long<bf16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
     return launch_attn_long<float>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
   }
   if (dtype == OM_BF16 && om_option(OM_OPT_ATTENTION_FAST)) {        // the low-instruction-count kernel (inference, and training with dropout)
-    if (L <= 32) return launch_attn16<bf16_t, 1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
-    if (L <= 64) return launch_attn16<bf16_t, 2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
-    if (L <= 128) return launch_attn16<bf16_t, 4>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
-    if (L <= 192) return launch_attn16<bf16_t, 6>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
-    return launch_attn16<bf16_t, 8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse);
+    if (L <= 32) return launch_attn16<bf16_t, 1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
+    if (L <= 64) return launch_attn16<bf16_t, 2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
+    if (L <= 128) return launch_attn16<bf16_t, 4>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
+    if (L <= 192) return launch_attn16<bf16_t, 6>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
+    return launch_attn16<bf16_t, 8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
   }
   if (dtype == OM_BF16) return dispatch_attn<bf16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
   return dispatch_attn<float>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);

@@ -102,6 +102,7 @@ struct EncWs {
   float *pooled, *headout, *posbias;
   float* final32;   // 16-bit runs: the last normalisation's output in f32 for the pooling tail (CLS rows, or all rows for mean pooling)
   int* lut;
+  int* kmax;        // per batch row: 1 + its last unmasked key (omk_mask_extent), read by every layer's attention launch
   // fused-LayerNorm path (16-bit): folded weight, its column sums and bias, two statistics buffers per layer, the slot
   // partials one GEMM leaves (kernels.h: GemmEpilogue::stats_out), and the second plane of the two residual tensors
   char* wfold;
@@ -133,6 +134,7 @@ static EncWs carve(const OmEncoderConfig* c, int64_t B, int64_t L, char* base) {
   w.headout = (float*)take((size_t)B * (c->head_out > 0 ? c->head_out : 1) * 4);
   w.posbias = (float*)take(c->arch == OM_ARCH_T5 ? (size_t)c->n_heads * L * L * 4 : 0);
   w.lut = (int*)take(c->arch == OM_ARCH_T5 ? (size_t)(2 * L) * 4 : 0);
+  w.kmax = (int*)take((size_t)B * 4);
   w.final32 = (float*)take(half && c->pooling != OM_POOL_NONE ? (c->pooling == OM_POOL_FIRST ? (size_t)B : Mreal) * H * 4 : 0);
   const bool fuse = half;                             // fused-norm path (BERT LayerNorm / T5 RMSNorm)
   const size_t wide = std::max((size_t)3 * H, F);
@@ -211,6 +213,7 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
   } while (0)
 #define RUN(expr) do { if (expr) return 1; } while (0)
 
+  RUN(omk_mask_extent(attention_mask, B, (int)L, ws.kmax, s));
   char* final_hidden = nullptr;
   // 16-bit runs that only return representations: the LAST normalisation writes f32 (the reference's autocast runs
   // layer_norm in fp32), into ws.final32 -- B CLS rows (pooling "first": already the pooled vectors) or all M rows
@@ -261,7 +264,7 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
           e.bias = bfp; e.ln_stats = st2p; e.ln_colsum = cs; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps; e.reverse = OM_WALK();
           RUN(omk_gemm(dt, ws.x1, H, wf, H, dt, ws.qkv, 3 * H, Mg, 3 * H, H, e, s));
         }
-        RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, nullptr, B, (int)L, H, nh, scale, 0.f, 0, s, OM_WALK()));
+        RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, nullptr, B, (int)L, H, nh, scale, 0.f, 0, s, OM_WALK(), ws.kmax));
         // ---- attention output + residual -> y1, statistics of LN1
         e = GemmEpilogue{};
         e.bias = lw.o_b; e.ldr = H; e.stats_out = ws.slots; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
@@ -310,7 +313,7 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
     for (int l = 0; l < c->n_layers; ++l) {
       const OmLayerWeights& lw = Ls[l];
       GEMM(ws.x, H, lw.qkv_w, H, ws.qkv, 3 * H, 3 * H, H, lw.qkv_b, nullptr, 0, OM_ACT_NONE);
-      RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, nullptr, B, (int)L, H, nh, scale, 0.f, 0, s));
+      RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, nullptr, B, (int)L, H, nh, scale, 0.f, 0, s, 0, ws.kmax));
       GEMM(ws.ctx, H, lw.o_w, H, ws.y, H, H, H, lw.o_b, ws.x, H, OM_ACT_NONE);
       RUN(omk_layernorm(dt, ws.y, H, ws.x1, H, lw.ln1_g, lw.ln1_b, M, H, c->ln_eps, 0, s));
       GEMM(ws.x1, H, lw.ffn1_w, H, ws.ff, F, F, H, lw.ffn1_b, nullptr, 0, c->act);
@@ -371,7 +374,7 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
         } else {
           RUN(folded(l, false, ws.x, lw.qkv_w, lw.ln1_g, ws.stats2 + (size_t)(l - 1) * Mg * 2, ws.qkv, 3 * H, OM_ACT_NONE, nullptr, 0));
         }
-        RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, ws.posbias, B, (int)L, H, nh, 1.0f, 0.f, 0, s));
+        RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, ws.posbias, B, (int)L, H, nh, 1.0f, 0.f, 0, s, 0, ws.kmax));
         GemmEpilogue e = {};
         e.resid = ws.x; e.ldr = H; e.stats_out = ws.slots; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
         RUN(omk_gemm(dt, ws.ctx, H, lw.o_w, H, dt, ws.x, H, Mg, H, H, e, s));           // x += o(ctx), sum(x^2)
@@ -387,7 +390,7 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
       const OmLayerWeights& lw = Ls[l];
       RUN(omk_layernorm(dt, ws.x, H, ws.y, H, lw.ln1_g, nullptr, M, H, c->ln_eps, 1, s));
       GEMM(ws.y, H, lw.qkv_w, H, ws.qkv, 3 * H, 3 * H, H, nullptr, nullptr, 0, OM_ACT_NONE);
-      RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, ws.posbias, B, (int)L, H, nh, 1.0f, 0.f, 0, s));
+      RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, ws.posbias, B, (int)L, H, nh, 1.0f, 0.f, 0, s, 0, ws.kmax));
       GEMM(ws.ctx, H, lw.o_w, H, ws.x, H, H, H, nullptr, ws.x, H, OM_ACT_NONE);  // x += o(ctx)
       RUN(omk_layernorm(dt, ws.x, H, ws.y, H, lw.ln2_g, nullptr, M, H, c->ln_eps, 1, s));
       if (lw.ffn1g_w) {

@@ -23,7 +23,9 @@ int omk_t5_bias(const float* table, const int* lut, float* out, int L, int heads
 // projection output [B*L, 3H] (q | k | v), ctx is [B*L, H].  L <= 256, head_dim == 64.
 int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
                   const float* pos_bias, int64_t B, int L, int H, int heads, float scale,
-                  float drop_p, uint64_t seed, hipStream_t s, int reverse = 0 /* batch rows last to first */);
+                  float drop_p, uint64_t seed, hipStream_t s, int reverse = 0 /* batch rows last to first */,
+                  const int* kmax = nullptr /* omk_mask_extent: per batch row, 1 + its last unmasked key (16-bit kernels skip the key tiles past it) */);
+int omk_mask_extent(const int64_t* mask, int64_t B, int L, int* kmax, hipStream_t s);
 
 // ---- extended GEMM epilogue (training) ---------------------------------------------------
 // order: v = acc + bias ; [pre_act <- v] ; v = act(v) ; v = dropout(v) ; v = v (+|*) resid

@@ -177,6 +177,43 @@ def test_encoder_matches_oracle_on_ragged_batches():
         assert np.abs(got.cpu().numpy() - ref.numpy()).max() < 1e-4, (B, L)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_attention_skips_masked_key_tiles_exactly(dtype):
+    """Round 4: the 16-bit attention kernel fetches and scores only the 32-key tiles that hold an unmasked key (kmax per batch
+    row, omk_mask_extent).  Masks with holes, an unmasked key in the last tile behind a long gap, a single leading key and a
+    row without any unmasked key (stays uniform over all L keys, as HF's finfo.min makes it) against the f32 path of the same
+    library, which reads every key."""
+    from transformers import BertModel
+    from openmatch.modeling import DRModelForInference
+    from tests.helpers import tiny_bert_config
+    torch.manual_seed(11)
+    cfg = tiny_bert_config()
+    lm = BertModel(cfg).eval()
+    m32 = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype="float32")).to(DEV).eval()
+    m16 = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype=dtype)).to(DEV).eval()
+    g = torch.Generator().manual_seed(3)
+    B, L = 12, 128
+    ids = torch.randint(300, 600, (B, L), generator=g)
+    mask = torch.zeros(B, L, dtype=torch.long)
+    for b, n in enumerate((128, 97, 64, 33, 32, 31, 16, 1)):
+        mask[b, :n] = 1
+    mask[8, :20] = 1; mask[8, 120] = 1                     # a lone key in the last tile behind three masked tiles' worth of gap
+    mask[9, ::3] = 1                                         # holes everywhere
+    mask[10, 40:50] = 1                                      # leading masked keys
+    # row 11: no unmasked key at all
+    items = {"input_ids": ids.to(DEV), "attention_mask": mask.to(DEV)}
+    h32, _ = m32.encode_passage(items)
+    h16, _ = m16.encode_passage(items)
+    h32, h16 = h32.float().cpu(), h16.float().cpu()
+    assert torch.isfinite(h16).all()
+    tol = 2e-2 if dtype == "float16" else 8e-2
+    for b in range(B):
+        keep = mask[b].bool() if mask[b].any() else torch.ones(L, dtype=torch.bool)      # padded positions carry no contract
+        err = (h16[b][keep] - h32[b][keep]).abs().max().item()
+        assert err < tol, (dtype, b, err)
+
+
 def _encode_with_fused_ln(model, items, on):
     """A/B switch of the encoder (include/openmatch_hip.h: om_debug_option(OM_OPT_ENCODER_FUSED_LN, .))."""
     from openmatch_amd import native as N
