@@ -331,17 +331,19 @@ __device__ __forceinline__ void gemm_mainloop7_cont(const G7SrcU& src, const cha
   ring.ac = u_ac; ring.bc = u_bc; ring.an = u_an; ring.bn = u_bn; ring.sp = u_sp;
 }
 
-#ifdef G7_CONT16_PROBE
-// ---- the continuous ring on 16 x 16 x 32 MFMAs: PROBE ONLY (tools/gemm7c16_probe.hip; round 4) ----------------------------
+// ---- the continuous ring on 16 x 16 x 32 MFMAs (round 4) -----------------------------------------------------------------
 // The chip is power-bound under these kernels (tile traces: the same cycle counts at 8 and at 256 active CUs, 2.4 vs 1.7 GHz),
-// and MFMA-only loops sustain 2.15 PFLOP/s with this shape against 1.87 with 32 x 32 x 16 on random data (round 3).  Is the
-// branch-free K loop faster with it?
+// and MFMA-only loops sustain 2.15 PFLOP/s with this shape against 1.87 with 32 x 32 x 16 on random data (round 3:
+// profiles/r03_mfma_shape_power_probe.log).  The branch-free K loop alone runs 0.5-9 % faster with it
+// (profiles/r04_probe13_kloop_32x32x16_vs_16x16x32_continuous_ring.log).
 //   acc[ti][fj][r] = C[m0 + wm*128 + ti*16 + (lane&15)][n0 + wn*128 + fj*16 + 4*(lane>>4) + r]
 // Per step two sub-steps of 64 MFMAs; 16 fragment reads and 8 DMA issues each (one behind every eighth MFMA):
 //     sub-step 0   k 0-31 of step t;  reads k 32-63;  A(t+2) -> spare
 //     barrier      vmcnt(8): everything but A(t+2) has landed (B(t+1) is a step and a half old)
 //     sub-step 1   k 32-63;  reads step t+1, k 0-31;  B(t+2) -> the unit A(t) leaves
-// On entry: step 0 landed and published, A(1) and ALL of B(1) issued.
+// On entry: step 0 landed and published, A(1) and ALL of B(1) issued (the 32 x 32 x 16 loop above enters with half of B(1)).
+// TAIL: the last step's sixteen issue slots go to tail(slot 0..15, spare unit, the unit A(nk - 1) leaves) -- slots 0-7 behind
+// sub-step 0 (the step's youngest at its barrier), 8-15 behind sub-step 1.
 template <typename T> struct Mma16c;
 template <> struct Mma16c<bf16_t> {
   __device__ static inline void mma(const bf16x8_t& a, const bf16x8_t& b, f32x4_t& c) { c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
@@ -349,11 +351,12 @@ template <> struct Mma16c<bf16_t> {
 template <> struct Mma16c<f16_t> {
   __device__ static inline void mma(const f16x8_t& a, const f16x8_t& b, f32x4_t& c) { c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
-template <typename T>
+template <typename T, bool TAIL = false, typename TailFn = G7NoTail>
 __device__ __forceinline__ void gemm_mainloop7_cont16(const G7SrcU& src, const char* cur_a, const char* cur_b,
                                                       const char* next_a, const char* next_b, int nk, char* smem, G7Ring& ring,
-                                                      f32x4_t (&acc)[8][8]) {
+                                                      f32x4_t (&acc)[8][8], unsigned long long* tr = nullptr, TailFn tail = TailFn()) {
   typedef typename MmaOps<T>::frag_t frag_t;
+  static_assert(sizeof(T) == 2, "128-byte K steps: 16-bit operands only");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -376,31 +379,41 @@ __device__ __forceinline__ void gemm_mainloop7_cont16(const G7SrcU& src, const c
   for (int i = 0; i < 8; ++i) a0[i] = *(const frag_t*)(smem + u_ac + rowa + i * 16 * G7_ROW_BYTES + slot[0]);
 #define G7_FENCE() __builtin_amdgcn_sched_barrier(0)
   // 64 MFMAs from (AF, BF); every fourth covers one fragment read into (BN, then AN) from (UA, UB) chunk SLOT; MFMAs 5, 13, ..
-  // each cover one DMA issue of operand P (PTR, instruction q >> 3) into UNIT
-#define G7C_SUB16(AF, BF, AN, BN, UA, UB, SLOT, P, PTR, UNIT)                                            \
+  // each cover one DMA issue of operand P (PTR, instruction q >> 3) into UNIT -- or, in the last step of a TAIL loop, tail(TBASE + (q >> 3))
+#define G7C_SUB16(AF, BF, AN, BN, UA, UB, SLOT, P, PTR, UNIT, TBASE, LASTSTEP)                           \
   _Pragma("unroll") for (int q = 0; q < 64; ++q) {                                                       \
     Mma16c<T>::mma(BF[q & 7], AF[q >> 3], acc[q >> 3][q & 7]);                                           \
     if ((q & 3) == 0) {                                                                                  \
       if (q < 32) BN[q >> 2] = *(const frag_t*)(smem + (UB) + rowb + (q >> 2) * 16 * G7_ROW_BYTES + (SLOT)); \
       else AN[(q >> 2) - 8] = *(const frag_t*)(smem + (UA) + rowa + ((q >> 2) - 8) * 16 * G7_ROW_BYTES + (SLOT)); \
     }                                                                                                    \
-    if ((q & 7) == 5) g7_issue_##P(src, PTR, q >> 3, lds0 + (UNIT) + ((q >> 3) * 4 + wave) * 1024);      \
+    if ((q & 7) == 5) {                                                                                  \
+      if (LASTSTEP) tail((TBASE) + (q >> 3), u_sp, u_ac);                                                \
+      else g7_issue_##P(src, PTR, q >> 3, lds0 + (UNIT) + ((q >> 3) * 4 + wave) * 1024);                 \
+    }                                                                                                    \
     G7_FENCE();                                                                                          \
   }
-  for (int t = 0; t < nk; ++t) {
-    G7C_SUB16(a0, b0, a1, b1, u_ac, u_bc, slot[1], a, ka, u_sp)
-    __builtin_amdgcn_s_waitcnt(0x0078);                                                  // vmcnt(8) lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();
-    G7_FENCE();
-    G7C_SUB16(a1, b1, a0, b0, u_an, u_bn, slot[0], b, kb, u_ac)
-    { const int o_ac = u_ac, o_bc = u_bc; u_ac = u_an; u_bc = u_bn; u_an = u_sp; u_bn = o_ac; u_sp = o_bc; }
-    if (t + 3 == nk) { ka = next_a; kb = next_b; } else { ka += G7_ROW_BYTES; kb += G7_ROW_BYTES; }
-  }
+#define G7C_STEP16(LASTSTEP)                                                                             \
+  do {                                                                                                   \
+    if (tr && tid == 0 && t < 12) tr[3 + t] = clock64();                                                 \
+    G7C_SUB16(a0, b0, a1, b1, u_ac, u_bc, slot[1], a, ka, u_sp, 0, LASTSTEP)                             \
+    __builtin_amdgcn_s_waitcnt(0x0078);                                     /* vmcnt(8) lgkmcnt(0) */     \
+    __builtin_amdgcn_s_barrier();                                                                        \
+    G7_FENCE();                                                                                          \
+    G7C_SUB16(a1, b1, a0, b0, u_an, u_bn, slot[0], b, kb, u_ac, 8, LASTSTEP)                             \
+    { const int o_ac = u_ac, o_bc = u_bc; u_ac = u_an; u_bc = u_bn; u_an = u_sp; u_bn = o_ac; u_sp = o_bc; } \
+    if (t + 3 == nk) { ka = next_a; kb = next_b; } else { ka += G7_ROW_BYTES; kb += G7_ROW_BYTES; }      \
+  } while (0)
+  int t = 0;
+  const int nplain = TAIL ? nk - 1 : nk;
+  for (; t < nplain; ++t) G7C_STEP16(false);
+  if (TAIL) G7C_STEP16(true);
+#undef G7C_STEP16
 #undef G7C_SUB16
 #undef G7_FENCE
   ring.ac = u_ac; ring.bc = u_bc; ring.an = u_an; ring.bn = u_bn; ring.sp = u_sp;
 }
-#endif  // G7_CONT16_PROBE
+
 
 #ifdef G7_M16_PROBE
 // ---- the same K loop on 16 x 16 x 32 MFMAs (round 3) ------------------------------------------------------------------

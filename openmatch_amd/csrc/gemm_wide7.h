@@ -789,6 +789,201 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c(
 }
 
 // =========================================================================================================================
+// Kernel 7c on 16 x 16 x 32 MFMAs (round 4, late): the same tile boundary, the K loop of gemm_mainloop7_cont16.
+//   acc[ti][fj][r] = C[m0 + wm*128 + ti*16 + (lane&15)][n0 + wn*128 + fj*16 + 4*(lane>>4) + r]
+// A lane owns output row (lane & 15) of each 16-row block and four consecutive columns of each 16-column block.  Patch
+// P = (mi, nh) is still 32 rows x 64 columns (two row blocks x four column blocks: 32 values per lane); quarter G of it is
+// row block ti2 = G >> 1 and the column-block pair 2 (G & 1) + {0, 1}.  Staging and read-back as above: row = 128 B, 16-byte
+// chunk XOR (row & 7); the lane's four columns are 8 bytes at chunk 2 fjl + (lane >> 5), half (lane >> 4) & 1.
+// The accumulator-initialising rank-2 product needs one MFMA per 16 x 16 tile (64, under the last patch's stores).
+template <typename T, int ACT, int LNF>
+__global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c16(
+    const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, T* C, int64_t ldc,
+    int64_t M, int64_t N, int64_t K, GemmEpilogue ep, int group_m) {
+  typedef T OutT;
+  typedef typename MmaOps<T>::frag_t frag_t;
+  static_assert(sizeof(T) == 2, "16-bit in, 16-bit out");
+  static_assert(LNF == 0 || LNF == 1, "no residual: plain or LayerNorm-folded A operand");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane0 = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t ntm = M / 256, ntn = N / 256;
+  const int nk = (int)((K * 2) / G7_ROW_BYTES);
+  const EpiScalars es(ep);
+
+  int it = 0;
+  int64_t m0, n0;
+  if (!g7_tile(0, ntm, ntn, group_m, m0, n0)) return;
+  G7SrcU src;
+  g7_offsets_u<T>(src, lda, ldb, wave, lane0);
+  G7Ring ring;
+  g7_ring_reset(ring);
+  const char* cur_a = (const char*)(A + m0 * lda);
+  const char* cur_b = (const char*)(B + n0 * ldb);
+  g7_fill_a(src, cur_a, smem + ring.ac, wave);
+  g7_fill_b(src, cur_b, smem + ring.bc, wave);
+  g7_fill_a(src, cur_a + G7_ROW_BYTES, smem + ring.an, wave);
+  g7_fill_b(src, cur_b + G7_ROW_BYTES, smem + ring.bn, wave);
+
+  bool live = false, have = true;
+  int64_t pm = m0, pn = n0;
+  f32x4_t acc[8][8];
+  float rs[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+  unsigned long long* tr_prev = nullptr;
+
+  for (;;) {
+    char* const sp = smem + ring.sp + wave * 1024;         // this wave's slices of the spare unit: slice i at sp + i * 4096
+    char* const tab0 = sp + 4 * 4096;
+    char* const tab1 = sp + 5 * 4096;
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    if (have) g7c_tables<LNF>(ep, A, tab0, tab1, m0 + wm * 128, n0 + wn * 128, lane);
+    const int l15 = lane & 15, q4 = lane >> 4;
+    float rsn[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    frag_t fa[8], fb[8];
+    size_t ldc2 = (size_t)ldc * sizeof(OutT);
+    asm volatile("" : "+s"(ldc2));
+    const int64_t pmc = pm + wm * 128, pnc = pn + wn * 128;
+    const char* const st_rd = sp + (lane >> 3) * 128;
+    char* const cbase = (char*)(C + pmc * ldc + pnc);
+    const uint32_t coff = (uint32_t)((lane >> 3) * ldc2) + (lane & 7) * 16;
+    uint4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+
+#define G7C_WRITE_Q(P_, G_)                                                                                    \
+  do {                                                                                                         \
+    constexpr int MI = (P_) >> 1, NH = (P_) & 1, TI = 2 * MI + ((G_) >> 1), FJ0 = 4 * NH + 2 * ((G_) & 1);     \
+    if ((G_) == 0) { _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) asm volatile("" : "+a"(acc[2 * MI + (u_ >> 2)][4 * NH + (u_ & 3)])); } \
+    const int rr = ((G_) >> 1) * 16 + l15;                           /* row of the 32-row patch */             \
+    const int64_t m = pmc + MI * 32 + rr;                                                                      \
+    f32x8_t v8;                                                                                                \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) v8[e] = acc[TI][FJ0 + (e >> 2)][e & 3];                      \
+    if (LNF == 1) v8 *= rs[TI];                                                                                \
+    if (ACT == OM_ACT_GELU_ERF) v8 = gelu_erf_poly8(v8);                                                       \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                         \
+      f32x2_t lo_ = {v8[4 * jj], v8[4 * jj + 1]}, hi_ = {v8[4 * jj + 2], v8[4 * jj + 3]};                      \
+      if (ACT != OM_ACT_GELU_ERF) {                                                                            \
+        const int64_t n = pnc + (FJ0 + jj) * 16 + 4 * q4;                                                      \
+        lo_ = epi_pair<ACT, false, OutT>(lo_, m, n, M, N, ep, es, 0, 0);                                       \
+        hi_ = epi_pair<ACT, false, OutT>(hi_, m, n + 2, M, N, ep, es, 0, 0);                                   \
+      }                                                                                                        \
+      const uint2 pk_ = make_uint2(Half16<OutT>::pack2(lo_[0], lo_[1]), Half16<OutT>::pack2(hi_[0], hi_[1]));  \
+      const int c_ = (2 * ((G_) & 1) + jj) * 2 + (q4 >> 1);          /* 16-byte chunk of the patch row */       \
+      *(uint2*)(sp + G7E_ROW(rr) + ((c_ ^ (rr & 7)) << 4) + 8 * (q4 & 1)) = pk_;                               \
+    }                                                                                                          \
+  } while (0)
+#define G7C_RB(I4) (*(const uint4*)(st_rd + (I4) * 4096 + (((lane & 7) ^ (((lane >> 3) + (I4) * 8) & 7)) << 4)))
+#ifdef G7E_STORE16U
+#define G7C_ST(PP, I4, V) G7E_STORE16U(cbase + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128, coff, V)
+#else
+#define G7C_ST(PP, I4, V) G7E_STORE16(cbase + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128 + coff, V)
+#endif
+#define G7C_ITER(P_, C0, C1, C2, C3, N0, N1, N2, N3)                                                           \
+  do {                                                                                                         \
+    if ((P_) + 1 < 8) {                                                                                        \
+      G7C_WRITE_Q((P_) + 1, 0); G7_FENCE_(); G7C_ST(P_, 0, C0); G7_FENCE_();                                   \
+      G7C_WRITE_Q((P_) + 1, 1); G7_FENCE_(); G7C_ST(P_, 1, C1); G7_FENCE_();                                   \
+      G7C_WRITE_Q((P_) + 1, 2); G7_FENCE_(); G7C_ST(P_, 2, C2); G7_FENCE_();                                   \
+      G7C_WRITE_Q((P_) + 1, 3); G7_FENCE_();                                                                   \
+      N0 = G7C_RB(0); N1 = G7C_RB(1); N2 = G7C_RB(2); N3 = G7C_RB(3);                                          \
+      G7_FENCE_(); G7C_ST(P_, 3, C3); G7_FENCE_();                                                             \
+    } else {                                                                                                   \
+      G7C_ST(P_, 0, C0); G7C_ST(P_, 1, C1); G7C_ST(P_, 2, C2); G7C_ST(P_, 3, C3); G7_FENCE_();                 \
+    }                                                                                                          \
+  } while (0)
+
+    if (live) {
+      G7C_WRITE_Q(0, 0); G7C_WRITE_Q(0, 1); G7C_WRITE_Q(0, 2); G7C_WRITE_Q(0, 3);
+      G7_FENCE_();
+      sa0 = G7C_RB(0); sa1 = G7C_RB(1); sa2 = G7C_RB(2); sa3 = G7C_RB(3);
+      G7_FENCE_();
+      G7C_ITER(0, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
+      G7C_ITER(1, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+      G7C_ITER(2, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
+      G7C_ITER(3, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+      G7C_ITER(4, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
+      G7C_ITER(5, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+    }
+    // ---- the next tile's initialising fragments: u_m b_n + v_m s_n as ONE 16 x 16 x 32 MFMA per tile, factors split into
+    // 16-bit hi + lo in k slots 0-5 of k block 0 (lanes 0-15); the other k blocks are zero
+    if (have) {
+      if (live) G7_WAIT_VM(8); else G7_WAIT_VM(0);
+      const bool ln_in = LNF == 1 && ep.ln_stats != nullptr;
+      const bool has_cs = LNF == 1 && ep.ln_colsum != nullptr, has_b = ep.bias != nullptr;
+      auto split = [](float x, uint32_t& hi, uint32_t& lo) {
+        hi = Half16<T>::bits(x); lo = Half16<T>::bits(x - Half16<T>::value(hi));
+      };
+#pragma unroll
+      for (int ti = 0; ti < 8; ++ti) {
+        float u = 1.f, v = 0.f;
+        if (ln_in) {
+          const float2 st = *(const float2*)(tab1 + (ti * 16 + l15) * 8);
+          const float mu = ep.ln_rms ? 0.f : st.x * ep.ln_inv_h;
+          const float var = fmaxf(st.y * ep.ln_inv_h - mu * mu, 0.f) + ep.ln_eps;
+          rsn[ti] = rsqrtf(var);
+          u = sqrtf(var); v = -mu;
+        }
+        uint32_t uh, ul, vh, vl;
+        split(u, uh, ul); split(v, vh, vl);
+        uint4 w = make_uint4(uh | (ul << 16), uh | (vh << 16), vl | (vh << 16), 0u);     // k: u_hi u_lo u_hi v_hi v_lo v_hi 0 0
+        if (q4) w = make_uint4(0u, 0u, 0u, 0u);
+        asm volatile("" : "+v"(w.x), "+v"(w.y), "+v"(w.z));       // opaque per row block: one MFMA per tile, no accumulator copies
+        fa[ti] = __builtin_bit_cast(frag_t, w);
+      }
+#pragma unroll
+      for (int fj = 0; fj < 8; ++fj) {
+        float b = *(const float*)(tab0 + 512 + (fj * 16 + l15) * 4), sc = *(const float*)(tab0 + (fj * 16 + l15) * 4);
+        if (!has_b) b = 0.f;
+        if (!(ln_in && has_cs)) sc = 0.f;
+        uint32_t bh, bl, sh, sl;
+        split(b, bh, bl); split(sc, sh, sl);
+        uint4 w = make_uint4(bh | (bh << 16), bl | (sh << 16), sh | (sl << 16), 0u);     // k: b_hi b_hi b_lo s_hi s_hi s_lo 0 0
+        if (q4) w = make_uint4(0u, 0u, 0u, 0u);
+        fb[fj] = __builtin_bit_cast(frag_t, w);
+      }
+    }
+    if (live) G7C_ITER(6, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);     // converts patch 7: the last reader of the accumulators
+    if (have) {
+      const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 64; ++q) { acc[q >> 3][q & 7] = zero; Mma16c<T>::mma(fb[q & 7], fa[q >> 3], acc[q >> 3][q & 7]); }
+    }
+#pragma unroll
+    for (int q = 0; q < 64; ++q) asm volatile("" : "+a"(acc[q >> 3][q & 7]));
+    if (live) {
+      G7C_ITER(7, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+      if (tr_prev && threadIdx.x == 0) { tr_prev[28] = clock64(); tr_prev[29] = blockIdx.x; tr_prev[31] = wall_clock64(); }
+    }
+#undef G7C_ITER
+#undef G7C_ST
+#undef G7C_RB
+#undef G7C_WRITE_Q
+    if (!have) break;
+    if (!live) __builtin_amdgcn_s_barrier();     // first pass: K step 0 (waited for above) is published to the other waves
+#pragma unroll
+    for (int ti = 0; ti < 8; ++ti) rs[ti] = rsn[ti];
+
+    ++it;
+    int64_t m1 = m0, n1 = n0;
+    const bool has_next = g7_tile(it, ntm, ntn, group_m, m1, n1);
+    const char* const next_a = (const char*)(A + m1 * lda);
+    const char* const next_b = (const char*)(B + n1 * ldb);
+    unsigned long long* tr = nullptr;
+    if (ep.trace) {
+      const int64_t tile_id = (m0 / 256) * ntn + n0 / 256;
+      if (tile_id < 8192) tr = ep.trace + tile_id * 32;
+    }
+    if (tr && threadIdx.x == 0) { tr[0] = tr[1] = clock64(); tr[30] = wall_clock64(); }
+    gemm_mainloop7_cont16<T>(src, cur_a, cur_b, next_a, next_b, nk, smem, ring, acc, tr);
+    if (tr && threadIdx.x == 0) tr[15] = clock64();
+    tr_prev = tr;
+    pm = m0; pn = n0; live = true;
+    cur_a = next_a; cur_b = next_b; m0 = m1; n0 = n1; have = has_next;
+  }
+  G7_WAIT_VM(0);
+}
+
+// =========================================================================================================================
 // Generation 7 on the continuous ring, the variants WITH a residual (round 4): out-proj and FFN2 of the encoder -- one-plane
 // residual stream (LNF 0: plain residual; LNF 2: normalised residual + row statistics of the output).
 //
@@ -1082,6 +1277,281 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r(
   G7_WAIT_VM(0);
 }
 
+// =========================================================================================================================
+// Kernel 7r on 16 x 16 x 32 MFMAs (round 4, late): layout as kernel 7c16.  The last K step has sixteen tail slots: tables and
+// residual patch 0 behind sub-step 0 (into the spare unit), patches 1 and 2 behind sub-step 1 (into the unit A(nk - 1) leaves) --
+// the epilogue starts with all three ring slots in flight.  Behind the last conversion the next tile's A(1) and ALL of B(1) are
+// issued (gemm_mainloop7_cont16 enters with both).
+template <typename T, int ACT, int LNF>
+__global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
+    const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, T* C, int64_t ldc,
+    int64_t M, int64_t N, int64_t K, GemmEpilogue ep, int group_m) {
+  typedef T OutT;
+  typedef typename MmaOps<T>::frag_t frag_t;
+  static_assert(sizeof(T) == 2, "16-bit in, 16-bit out");
+  static_assert(LNF == 0 || LNF == 2, "residual variants: plain, or output-side LayerNorm on a one-plane residual stream");
+  constexpr bool LNO = LNF == 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane0 = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t ntm = M / 256, ntn = N / 256;
+  const int nk = (int)((K * 2) / G7_ROW_BYTES);
+  const EpiScalars es(ep);
+  const uint32_t lds_base = g7_lds_addr(smem);
+
+  int it = 0;
+  int64_t m0, n0;
+  if (!g7_tile(0, ntm, ntn, group_m, m0, n0)) return;
+  G7SrcU src;
+  g7_offsets_u<T>(src, lda, ldb, wave, lane0);
+  G7Ring ring;
+  g7_ring_reset(ring);
+  const char* cur_a = (const char*)(A + m0 * lda);
+  const char* cur_b = (const char*)(B + n0 * ldb);
+  g7_fill_a(src, cur_a, smem + ring.ac, wave);
+  g7_fill_b(src, cur_b, smem + ring.bc, wave);
+  g7_fill_a(src, cur_a + G7_ROW_BYTES, smem + ring.an, wave);
+  g7_fill_b(src, cur_b + G7_ROW_BYTES, smem + ring.bn, wave);
+  g7_table2((const float*)A, ep.bias ? ep.bias + n0 + wn * 128 : (const float*)A, smem + ring.sp + (6 * 4 + wave) * 1024, lane0);
+
+  bool live = false, have = true;
+  int64_t pm = m0, pn = n0;
+  f32x4_t acc[8][8];
+  unsigned long long* tr_prev = nullptr;
+  size_t ldc2 = (size_t)ldc * sizeof(OutT), ldr2 = (size_t)ep.ldr * sizeof(OutT);
+  asm volatile("" : "+s"(ldc2), "+s"(ldr2));
+
+  for (;;) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int64_t pmc = pm + wm * 128, pnc = pn + wn * 128;
+    char* const an0 = smem + ring.an + wave * 1024;          // slice i at + i * 4096
+    char* const bn0 = smem + ring.bn + wave * 1024;
+    char* const sp0 = smem + ring.sp + wave * 1024;
+    const char* const etab0 = an0 + 4 * 4096;                 // gamma | beta
+    const char* const etab1 = an0 + 5 * 4096;                 // (sum, sum of squares) of my 128 residual rows
+    const char* const tab0 = (live ? an0 : sp0) + 6 * 4096;   // s_n | b_n of the tile about to start
+    const bool res_ln = LNO && ep.rln_stats != nullptr;
+    const char* const rbase = (const char*)((const OutT*)ep.resid + pmc * ep.ldr + pnc);
+    uint32_t roff[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) roff[k] = (uint32_t)((lane >> 3) * ldr2) + (((lane & 7) ^ ((4 * k + (lane >> 4)) & 7)) << 4);
+    float ra[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, rc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};          // per row block of the current 32-row pair
+    frag_t fa[8], fb[8];
+    const char* const st_rd = sp0 + (lane >> 3) * 128;
+    char* const cbase = (char*)(C + pmc * ldc + pnc);
+    const uint32_t coff = (uint32_t)((lane >> 3) * ldc2) + (lane & 7) * 16;
+    float2* const stat_slot = LNO ? (float2*)ep.stats_out + ((pn >> 8) * 2 + wn) * M : nullptr;
+    uint4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+
+#define G7R_SLOT(P_) (((P_) % 3) == 0 ? an0 : (((P_) % 3) == 1 ? bn0 : bn0 + 4 * 4096))
+#define G7R_RES_DMA(P_)                                                                                        \
+  do {                                                                                                         \
+    const size_t poff = (size_t)(((P_) >> 1) * 32) * ldr2 + ((P_) & 1) * 128;                                  \
+    const uint32_t buf = g7_lds_addr(G7R_SLOT(P_));                                                            \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) g7_dma(rbase + poff + (size_t)(8 * k) * ldr2, roff[k], buf + k * 4096); \
+  } while (0)
+    // quarter G_ of patch P_ = (mi, nh): row block ti2 = G_ >> 1, column blocks 2 (G_ & 1) + {0, 1} -- eight values per lane
+#define G7R_WRITE_Q(P_, G_)                                                                                    \
+  do {                                                                                                         \
+    constexpr int MI = (P_) >> 1, NH = (P_) & 1, T2 = (G_) >> 1, TI = 2 * MI + T2, FJ0 = 4 * NH + 2 * ((G_) & 1); \
+    if ((G_) == 0) { _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) asm volatile("" : "+a"(acc[2 * MI + (u_ >> 2)][4 * NH + (u_ & 3)])); } \
+    const int rr = T2 * 16 + l15;                                                                              \
+    const int64_t m = pmc + MI * 32 + rr;                                                                      \
+    const int c0_ = (2 * ((G_) & 1)) * 2 + (q4 >> 1), c1_ = c0_ + 2;          /* 16-byte chunks of the patch row */ \
+    const char* buf = G7R_SLOT(P_) + G7E_ROW(rr) + 8 * (q4 & 1);                                               \
+    const uint2 ra_ = *(const uint2*)(buf + ((c0_ ^ ((rr >> 1) & 7)) << 4));                                   \
+    const uint2 rb_ = *(const uint2*)(buf + ((c1_ ^ ((rr >> 1) & 7)) << 4));                                   \
+    f32x8_t v8;                                                                                                \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) v8[e] = acc[TI][FJ0 + (e >> 2)][e & 3];                      \
+    f32x8_t r8 = {Half16<OutT>::lo(ra_.x), Half16<OutT>::hi(ra_.x), Half16<OutT>::lo(ra_.y), Half16<OutT>::hi(ra_.y), \
+                  Half16<OutT>::lo(rb_.x), Half16<OutT>::hi(rb_.x), Half16<OutT>::lo(rb_.y), Half16<OutT>::hi(rb_.y)}; \
+    if (LNO) {                                                                                                 \
+      if (res_ln) {                                                                                            \
+        const int n0_ = FJ0 * 16 + 4 * q4;                          /* columns n0_ .. + 3 and n0_ + 16 .. + 19 of my 128 */ \
+        const f32x4_t ga = *(const f32x4_t*)(etab0 + n0_ * 4), gb = *(const f32x4_t*)(etab0 + (n0_ + 16) * 4);  \
+        const f32x4_t ba = *(const f32x4_t*)(etab0 + 512 + n0_ * 4), bb = *(const f32x4_t*)(etab0 + 512 + (n0_ + 16) * 4); \
+        const f32x8_t g8 = __builtin_shufflevector(ga, gb, 0, 1, 2, 3, 4, 5, 6, 7);                            \
+        const f32x8_t b8 = __builtin_shufflevector(ba, bb, 0, 1, 2, 3, 4, 5, 6, 7);                            \
+        r8 = __builtin_elementwise_fma(__builtin_elementwise_fma(r8, (f32x8_t)(ra[TI]), (f32x8_t)(rc[TI])), g8, b8); \
+      }                                                                                                        \
+      v8 += r8;                                                                                                \
+      ssum[T2] += ((v8[0] + v8[1]) + (v8[2] + v8[3])) + ((v8[4] + v8[5]) + (v8[6] + v8[7]));                   \
+      const f32x8_t q8 = v8 * v8;                                                                              \
+      ssq[T2] += ((q8[0] + q8[1]) + (q8[2] + q8[3])) + ((q8[4] + q8[5]) + (q8[6] + q8[7]));                    \
+    } else {                                                                                                   \
+      _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                       \
+        const int64_t n = pnc + (FJ0 + jj) * 16 + 4 * q4;                                                      \
+        f32x2_t lo_ = {v8[4 * jj], v8[4 * jj + 1]}, hi_ = {v8[4 * jj + 2], v8[4 * jj + 3]};                    \
+        lo_ = epi_pair<ACT, false, OutT>(lo_, m, n, M, N, ep, es, 0, 0);                                       \
+        hi_ = epi_pair<ACT, false, OutT>(hi_, m, n + 2, M, N, ep, es, 0, 0);                                   \
+        if (es.mul) { lo_[0] *= r8[4 * jj]; lo_[1] *= r8[4 * jj + 1]; hi_[0] *= r8[4 * jj + 2]; hi_[1] *= r8[4 * jj + 3]; } \
+        else {                                                                                                 \
+          lo_[0] = epi_resid<ACT, true>(lo_[0], r8[4 * jj], false); lo_[1] = epi_resid<ACT, true>(lo_[1], r8[4 * jj + 1], false);       \
+          hi_[0] = epi_resid<ACT, true>(hi_[0], r8[4 * jj + 2], false); hi_[1] = epi_resid<ACT, true>(hi_[1], r8[4 * jj + 3], false);   \
+        }                                                                                                      \
+        v8[4 * jj] = lo_[0]; v8[4 * jj + 1] = lo_[1]; v8[4 * jj + 2] = hi_[0]; v8[4 * jj + 3] = hi_[1];        \
+      }                                                                                                        \
+    }                                                                                                          \
+    const uint2 pa_ = make_uint2(Half16<OutT>::pack2(v8[0], v8[1]), Half16<OutT>::pack2(v8[2], v8[3]));        \
+    const uint2 pb_ = make_uint2(Half16<OutT>::pack2(v8[4], v8[5]), Half16<OutT>::pack2(v8[6], v8[7]));        \
+    *(uint2*)(sp0 + G7E_ROW(rr) + ((c0_ ^ (rr & 7)) << 4) + 8 * (q4 & 1)) = pa_;                               \
+    *(uint2*)(sp0 + G7E_ROW(rr) + ((c1_ ^ (rr & 7)) << 4) + 8 * (q4 & 1)) = pb_;                               \
+    if (LNO && NH == 1 && ((G_) & 1) == 1) {   /* row block T2 of this 32-row pair has all its 128 columns: partial sums of the row */ \
+      float s1 = ssum[T2], s2 = ssq[T2];                                                                       \
+      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);                                              \
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);                                              \
+      if (q4 == 0) stat_slot[m] = make_float2(s1, s2);                                                         \
+      ssum[T2] = 0.f; ssq[T2] = 0.f;                                                                           \
+    }                                                                                                          \
+  } while (0)
+#define G7R_RB(I4) (*(const uint4*)(st_rd + (I4) * 4096 + (((lane & 7) ^ (((lane >> 3) + (I4) * 8) & 7)) << 4)))
+#ifdef G7E_STORE16U
+#define G7R_ST(PP, I4, V) G7E_STORE16U(cbase + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128, coff, V)
+#else
+#define G7R_ST(PP, I4, V) G7E_STORE16(cbase + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128 + coff, V)
+#endif
+    // (YWAIT: operations issued after the awaited patch's fetch, the row-statistics stores -- two per odd patch here -- NOT counted)
+#define G7R_ITER(P_, YWAIT, C0, C1, C2, C3, N0, N1, N2, N3)                                                    \
+  do {                                                                                                         \
+    if (tr_prev && threadIdx.x == 0) tr_prev[17 + (P_)] = clock64();                                           \
+    if ((P_) + 1 < 8) {                                                                                        \
+      if ((P_) + 3 < 8) G7R_RES_DMA((P_) + 3);                                                                 \
+      G7_WAIT_VM(YWAIT);                                                                                       \
+      G7R_WRITE_Q((P_) + 1, 0); G7_FENCE_(); G7R_ST(P_, 0, C0); G7_FENCE_();                                   \
+      G7R_WRITE_Q((P_) + 1, 1); G7_FENCE_(); G7R_ST(P_, 1, C1); G7_FENCE_();                                   \
+      G7R_WRITE_Q((P_) + 1, 2); G7_FENCE_(); G7R_ST(P_, 2, C2); G7_FENCE_();                                   \
+      G7R_WRITE_Q((P_) + 1, 3); G7_FENCE_();                                                                   \
+      N0 = G7R_RB(0); N1 = G7R_RB(1); N2 = G7R_RB(2); N3 = G7R_RB(3);                                          \
+      G7_FENCE_(); G7R_ST(P_, 3, C3); G7_FENCE_();                                                             \
+    } else {                                                                                                   \
+      G7R_ST(P_, 0, C0); G7R_ST(P_, 1, C1); G7R_ST(P_, 2, C2); G7R_ST(P_, 3, C3); G7_FENCE_();                 \
+    }                                                                                                          \
+  } while (0)
+
+    if (live) {
+      G7_WAIT_VM(8);                           // tables and patch 0 (last step, sub-step 0) have landed: only patches 1 and 2 are younger
+      if (res_ln) {
+#pragma unroll
+        for (int ti = 0; ti < 8; ++ti) {
+          const float2 st = *(const float2*)(etab1 + (ti * 16 + l15) * 8);
+          const float mu = st.x * ep.ln_inv_h;
+          const float rstd = rsqrtf(fmaxf(st.y * ep.ln_inv_h - mu * mu, 0.f) + ep.ln_eps);
+          ra[ti] = rstd; rc[ti] = -mu * rstd;
+        }
+      }
+      if (tr_prev && threadIdx.x == 0) tr_prev[16] = clock64();
+      G7R_WRITE_Q(0, 0); G7R_WRITE_Q(0, 1); G7R_WRITE_Q(0, 2); G7R_WRITE_Q(0, 3);
+      G7_FENCE_();
+      sa0 = G7R_RB(0); sa1 = G7R_RB(1); sa2 = G7R_RB(2); sa3 = G7R_RB(3);
+      G7_FENCE_();
+      G7R_ITER(0, 8, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);        // younger than patch 1: patch 2, patch 3
+      G7R_ITER(1, 12, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);       // patch 3, stores of 0, patch 4
+      G7R_ITER(2, 16, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);       // stores of 0, patch 4, stores of 1, patch 5
+      G7R_ITER(3, 16, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+      G7R_ITER(4, 16, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
+      G7R_ITER(5, 12, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);       // stores of 3, patch 7, stores of 4
+    }
+    if (have) {
+      if (!live) G7_WAIT_VM(0);
+      const bool has_b = ep.bias != nullptr;
+      auto split = [](float x, uint32_t& hi, uint32_t& lo) {
+        hi = Half16<T>::bits(x); lo = Half16<T>::bits(x - Half16<T>::value(hi));
+      };
+#pragma unroll
+      for (int ti = 0; ti < 8; ++ti) {
+        uint32_t uh, ul;
+        split(1.f, uh, ul);
+        uint4 w = make_uint4(uh | (ul << 16), uh, 0u, 0u);              // k: u_hi u_lo u_hi 0 ...
+        if (q4) w = make_uint4(0u, 0u, 0u, 0u);
+        asm volatile("" : "+v"(w.x), "+v"(w.y));
+        fa[ti] = __builtin_bit_cast(frag_t, w);
+      }
+#pragma unroll
+      for (int fj = 0; fj < 8; ++fj) {
+        float b = *(const float*)(tab0 + 512 + (fj * 16 + l15) * 4);
+        if (!has_b) b = 0.f;
+        uint32_t bh, bl;
+        split(b, bh, bl);
+        uint4 w = make_uint4(bh | (bh << 16), bl, 0u, 0u);              // k: b_hi b_hi b_lo 0 ...
+        if (q4) w = make_uint4(0u, 0u, 0u, 0u);
+        fb[fj] = __builtin_bit_cast(frag_t, w);
+      }
+    }
+    if (live) {
+      G7R_ITER(6, 8, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
+      if (have) {                              // every ring slot and table of this epilogue has been read: A(1) and B(1) of the next tile
+        g7_fill_a(src, cur_a + G7_ROW_BYTES, smem + ring.an, wave);
+        g7_fill_b(src, cur_b + G7_ROW_BYTES, smem + ring.bn, wave);
+      }
+    }
+    if (have) {
+      const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 64; ++q) { acc[q >> 3][q & 7] = zero; Mma16c<T>::mma(fb[q & 7], fa[q >> 3], acc[q >> 3][q & 7]); }
+    }
+#pragma unroll
+    for (int q = 0; q < 64; ++q) asm volatile("" : "+a"(acc[q >> 3][q & 7]));
+    if (live) {
+      G7R_ITER(7, 0, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+      if (tr_prev && threadIdx.x == 0) { tr_prev[28] = clock64(); tr_prev[29] = blockIdx.x; tr_prev[31] = wall_clock64(); }
+    }
+#undef G7R_ITER
+#undef G7R_ST
+#undef G7R_RB
+#undef G7R_WRITE_Q
+#undef G7R_RES_DMA
+#undef G7R_SLOT
+    if (!have) break;
+    if (!live) __builtin_amdgcn_s_barrier();
+
+    ++it;
+    int64_t m1 = m0, n1 = n0;
+    const bool has_next = g7_tile(it, ntm, ntn, group_m, m1, n1);
+    const char* const next_a = (const char*)(A + m1 * lda);
+    const char* const next_b = (const char*)(B + n1 * ldb);
+    unsigned long long* tr = nullptr;
+    if (ep.trace) {
+      const int64_t tile_id = (m0 / 256) * ntn + n0 / 256;
+      if (tile_id < 8192) tr = ep.trace + tile_id * 32;
+    }
+    if (tr && threadIdx.x == 0) { tr[0] = tr[1] = clock64(); tr[30] = wall_clock64(); }
+    {
+      const int64_t mc = m0 + wm * 128, nc = n0 + wn * 128;
+      const char* const rb_ = (const char*)((const OutT*)ep.resid + mc * ep.ldr + nc);
+      const bool rln = LNO && ep.rln_stats != nullptr;
+      const float* const dummy = (const float*)A;
+      const float* const t_g = rln ? ep.rln_g + nc : dummy;
+      const float* const t_b = rln ? ep.rln_b + nc : dummy;
+      const float* const t_s = rln ? ep.rln_stats + mc * 2 : dummy;
+      const float* const t_bias = ep.bias ? ep.bias + n1 + wn * 128 : dummy;
+      uint32_t ro[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ro[k] = (uint32_t)((lane0 >> 3) * ldr2) + (((lane0 & 7) ^ ((4 * k + (lane0 >> 4)) & 7)) << 4);
+      const int w1k = wave * 1024;
+      auto tail = [&](int slot, int u_spare, int u_olda) __attribute__((always_inline)) {
+        char* const s0 = smem + u_spare + w1k;               // spare: slices 0-3 patch 0, 4 gamma | beta, 5 statistics, 6 next table
+        const uint32_t o0 = lds_base + u_olda + w1k;         // the unit A(nk - 1) leaves: slices 0-3 patch 1, 4-7 patch 2
+        if (slot == 0) g7_table2(t_g, t_b, s0 + 4 * 4096, lane0);
+        else if (slot == 1) g7_table1(t_s, s0 + 5 * 4096, lane0);
+        else if (slot == 2 || slot == 3) g7_table2(dummy, t_bias, s0 + 6 * 4096, lane0);
+        else if (slot < 8) g7_dma(rb_ + (size_t)(8 * (slot - 4)) * ldr2, ro[slot - 4], g7_lds_addr(s0) + (slot - 4) * 4096);     // patch 0 = (mi 0, nh 0)
+        else if (slot < 12) g7_dma(rb_ + 128 + (size_t)(8 * (slot - 8)) * ldr2, ro[slot - 8], o0 + (slot - 8) * 4096);          // patch 1 = (mi 0, nh 1)
+        else g7_dma(rb_ + (size_t)32 * ldr2 + (size_t)(8 * (slot - 12)) * ldr2, ro[slot - 12], o0 + (slot - 8) * 4096);         // patch 2 = (mi 1, nh 0)
+      };
+      gemm_mainloop7_cont16<T, true>(src, cur_a, cur_b, next_a, next_b, nk, smem, ring, acc, tr, tail);
+    }
+    if (tr && threadIdx.x == 0) tr[15] = clock64();
+    tr_prev = tr;
+    pm = m0; pn = n0; live = true;
+    cur_a = next_a; cur_b = next_b; m0 = m1; n0 = n1; have = has_next;
+  }
+  G7_WAIT_VM(0);
+}
+
 static int g7_num_cus() {
   static int n = 0;
   if (!n) {
@@ -1108,8 +1578,18 @@ static int launch7c(const void* A, int64_t lda, const void* B, int64_t ldb, void
   }
   const bool timing = om_timing_on();
   if (timing) om_timing_begin(OM_TIMING_GEMM_BF16, s);
+  const int gm_arg = (std::max(1, om_option(OM_OPT_GEMM_GROUP_M)) & 0xffff) | (ep.reverse ? 1 << 16 : 0);
+  if (om_option(OM_OPT_GEMM_CONT) & 8) {           // bit 3: the 16 x 16 x 32 form
+    static std::atomic<bool> attr16{false};
+    if (!attr16) {
+      OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel7c16<T, ACT, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
+      attr16 = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_kernel7c16<T, ACT, LNF>), dim3((unsigned)grid), dim3(G6_THREADS), G7_LDS_BYTES, s,
+                       (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, gm_arg);
+  } else
   hipLaunchKernelGGL((gemm_nt_kernel7c<T, ACT, LNF>), dim3((unsigned)grid), dim3(G6_THREADS), G7_LDS_BYTES, s,
-                     (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, (std::max(1, om_option(OM_OPT_GEMM_GROUP_M)) & 0xffff) | (ep.reverse ? 1 << 16 : 0));
+                     (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, gm_arg);
   if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, 2.0 * (double)M * (double)N * (double)K);
   OM_LAUNCH_CHECK();
   return 0;
@@ -1131,8 +1611,18 @@ static int launch7r(const void* A, int64_t lda, const void* B, int64_t ldb, void
   }
   const bool timing = om_timing_on();
   if (timing) om_timing_begin(OM_TIMING_GEMM_BF16, s);
+  const int gm_arg = (std::max(1, om_option(OM_OPT_GEMM_GROUP_M)) & 0xffff) | (ep.reverse ? 1 << 16 : 0);
+  if (om_option(OM_OPT_GEMM_CONT) & 8) {           // bit 3: the 16 x 16 x 32 form
+    static std::atomic<bool> attr16{false};
+    if (!attr16) {
+      OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel7r16<T, ACT, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
+      attr16 = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_kernel7r16<T, ACT, LNF>), dim3((unsigned)grid), dim3(G6_THREADS), G7_LDS_BYTES, s,
+                       (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, gm_arg);
+  } else
   hipLaunchKernelGGL((gemm_nt_kernel7r<T, ACT, LNF>), dim3((unsigned)grid), dim3(G6_THREADS), G7_LDS_BYTES, s,
-                     (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, (std::max(1, om_option(OM_OPT_GEMM_GROUP_M)) & 0xffff) | (ep.reverse ? 1 << 16 : 0));
+                     (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, gm_arg);
   if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, 2.0 * (double)M * (double)N * (double)K);
   OM_LAUNCH_CHECK();
   return 0;

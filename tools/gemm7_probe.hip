@@ -138,7 +138,7 @@ int main(int argc, char** argv) {
   }
   hipMemset(st_out, 0, (size_t)M * 8);
   hipMalloc(&g_rlo, (size_t)M * 768 * 2); hipMalloc(&g_clo, (size_t)M * 768 * 2); fill_bf16(g_rlo, (size_t)M * 768, 0.004f, 7);
-  if (!(G7_ABL)) for (g_cont = 0; g_cont < 4; g_cont += 3) {
+  if (!(G7_ABL)) for (int gc_ : {0, 3, 11}) { g_cont = gc_;
     check_plain(4096, 768, 768, A, B, C, vecs); check_plain(2048, 2304, 768, A, B, C, vecs); check_plain(2048, 768, 3072, A, B, C, vecs);
     check_plain(512, 512, 128, A, B, C, vecs); check_plain(512, 256, 64, A, B, C, vecs); check_plain(65536, 768, 192, A, B, C, vecs);
   }
@@ -165,9 +165,9 @@ int main(int argc, char** argv) {
     return 0;
   }
   for (int round = 0; round < 2; ++round) {
-    for (int cont : {0, 3}) {      // the ring restarted per tile (round 3) / continuous (round 4: 7c without, 7r with a residual)
+    for (int cont : {0, 3, 11}) {      // the ring restarted per tile (round 3) / continuous (round 4: 7c without, 7r with a residual) / the same on 16 x 16 x 32 MFMAs
       g_cont = cont;
-      printf("-- continuous ring %s\n", cont ? "ON" : "off");
+      printf("-- continuous ring %s\n", cont == 0 ? "off" : (cont & 8 ? "ON, 16x16x32" : "ON, 32x32x16"));
       run<OM_ACT_NONE, false, 1>("qkv (ln-folded A)", M, 2304, 768, A, B, C, R, vecs, st_in, st_out);
       run<OM_ACT_NONE, true, 2>("out-proj (+LN resid, stats)", M, 768, 768, A, B, C, R, vecs, st_in, st_out);
       run<OM_ACT_GELU_ERF, false, 1>("ffn1 + gelu (ln-folded A)", M, 3072, 768, A, B, C, R, vecs, st_in, st_out);

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(G6_THREADS) void kloop_kernel(const T* __restrict__
       const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < 64; ++q) acc[q >> 3][q & 7] = z4;
-      gemm_mainloop7_cont16<T>(src, cur_a, cur_b, next_a, next_b, nk, smem, ring, acc);
+      gemm_mainloop7_cont16<T>(src, cur_a, cur_b, next_a, next_b, nk, smem, ring, acc, nullptr);
 #pragma unroll
       for (int q = 0; q < 64; ++q) { asm volatile("" : "+a"(acc[q >> 3][q & 7])); keep += acc[q >> 3][q & 7][0]; }
     } else {
