@@ -299,6 +299,46 @@ def train_leg(device, steps=8):
     return out
 
 
+def packed_leg(model, batches, a, L):
+    """The SAME timed batches through om_encoder_forward_packed: only the rows up to each sequence's last token (lengths
+    ~ U{16..128}) enter the embedding, the contractions and the normalisations; attention runs per sequence.  The
+    reference pads to 128 and computes over the padding (dataset/data_collator.py:27-38), so the headline `value` stays
+    the padded computation; this is what the product's own collator path (feed.py: host-side lengths) runs.  The row bound
+    is computed from the lengths on the host BEFORE the timed region (in production it comes with the collator's batch)."""
+    from openmatch_amd import encoder as E
+    from openmatch_amd.encoder import compute_dtype_code, hip_encode, packed_rows_bound
+    code = compute_dtype_code(model.model_args)
+    bounds = [packed_rows_bound(b["attention_mask"]) for b in batches]
+    tokens = [int(b["attention_mask"].sum()) for b in batches]
+
+    def run(i, packed):
+        b = batches[i % len(batches)]
+        return hip_encode(model.lm_p, b, "first", None, False, code, want_hidden=False,
+                          packed_rows=bounds[i % len(batches)] if packed else None)[1]
+    same, took = True, None
+    for i in range(len(batches)):
+        got = run(i, True)
+        took = dict(E.LAST_CALL)
+        same = same and bool(torch.equal(got, run(i, False)))
+    res = {}
+    for packed in (False, True, False, True):          # interleaved: padded, packed, padded, packed
+        for i in range(a.warmup):
+            run(i, packed)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(a.steps):
+            run(i, packed)
+        torch.cuda.synchronize()
+        res.setdefault(packed, []).append((time.perf_counter() - t0) / a.steps)
+    dt_p, dt_d = min(res[True]), min(res[False])
+    return {"metric": "passages/s encode over packed rows (om_encoder_forward_packed; same batches, same representations)",
+            "value": round(a.batch / dt_p, 1), "unit": "passages/s", "ms_per_step": round(dt_p * 1e3, 3),
+            "padded_same_loop_ms_per_step": round(dt_d * 1e3, 3), "speedup_vs_padded": round(dt_d / dt_p, 3),
+            "rows_per_step": bounds, "tokens_per_step": tokens, "padded_rows_per_step": a.batch * L,
+            "row_fraction": round(sum(bounds) / (len(bounds) * a.batch * L), 4),
+            "identical_to_padded": same, "last_call": took,
+            "algorithmic_tflops_on_packed_rows": round(sum(bounds) / len(bounds) / L * GFLOP_PER_PASSAGE / 1e3 / dt_p, 1)}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -476,7 +516,7 @@ def main():
         parity = parity_leg(model, lm, batches, device, headline=a.precision)
 
     # ---------------- exact-f32 mode and the training step (sub-objects; N = 1 only) ----------
-    f32_mode, train, f16_mode = None, None, None
+    f32_mode, train, f16_mode, packed_mode = None, None, None, None
     other16 = "bf16" if a.precision == "f16" else "f16"
     if rank == 0 and world == 1 and not a.no_extra and half:
         # the OTHER 16-bit format on the SAME timed batches (same kernels and MFMA rate): bfloat16 carries its pre-LayerNorm
@@ -497,6 +537,7 @@ def main():
                     "frac_of_mfma_peak": round(a.batch * GFLOP_PER_PASSAGE / 1e3 / dt / PEAK_BF16_TFLOPS, 4)}
         del m16
         torch.cuda.empty_cache()
+        packed_mode = packed_leg(model, batches, a, L)
         m32 = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first",
                                   model_args=NS(encoder_only=False, dtype="float32")).to(device).eval()
         sub = {k: v[:256] for k, v in batches[0].items()}
@@ -533,7 +574,7 @@ def main():
                        "passages_per_step_per_gpu": a.batch, "seq_len": L, "global_batch": a.batch * world,
                        "index_rows": a.index_rows, "queries": a.queries, "topk": a.topk,
                        "weights": "random-init BertConfig() seed 0", "parallelism": f"shard{world}"},
-            "roofline": roofline, "search": search, "parity": parity, other16: f16_mode, "f32": f32_mode, "train": train, "cpu_baseline": cpu,
+            "roofline": roofline, "search": search, "parity": parity, other16: f16_mode, "packed": packed_mode, "f32": f32_mode, "train": train, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

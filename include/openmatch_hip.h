@@ -240,6 +240,24 @@ int om_encoder_forward(const OmEncoderConfig* cfg, const OmEncoderWeights* w,
                        void* out_hidden, float* out_reps, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* The same representations from PACKED rows: the reference pads every sequence of a batch to one length
+ * (dataset/data_collator.py:27-38 `padding='max_length'`, or the longest of the batch) and HF runs every layer over the
+ * padding; a padded key is masked out of every softmax, so the rows of a sequence up to its last unmasked token do not
+ * depend on what follows them.  This entry keeps only those rows, back to back ([CLS] of sequence b at row cu[b]), runs
+ * the embedding, all contractions and the normalisations over `packed_rows` rows instead of B * L, attention per
+ * sequence over its own rows, and pools from them: the representations om_encoder_forward returns, for
+ * sum(lengths) / (B * L) of the work.  16-bit BERT-family configurations with the fused path (hidden, ffn multiples of
+ * 256, erf-GELU), L <= 256, pooling set (no out_hidden).
+ * packed_rows: the caller's bound on the token count -- sum over sequences of (1 + index of the last unmasked token) --
+ * rounded up to a multiple of 256, >= 512.  The bound is checked on the device: a batch that holds more tokens returns
+ * NaN in every representation (no host synchronisation, never a truncated batch).
+ * Workspace: om_encoder_workspace_bytes_packed(cfg, B, L, packed_rows). */
+size_t om_encoder_workspace_bytes_packed(const OmEncoderConfig* cfg, int64_t B, int64_t L, int64_t packed_rows);
+int om_encoder_forward_packed(const OmEncoderConfig* cfg, const OmEncoderWeights* w,
+                              const int64_t* input_ids, const int64_t* attention_mask,
+                              const int64_t* token_type_ids, int64_t B, int64_t L, int64_t packed_rows,
+                              float* out_reps, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * One decoder position of a T5 encoder-decoder over the encoder's output (inference):
  * what the reference computes for T5 backbones that are not --encoder_only --

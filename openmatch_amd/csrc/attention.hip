@@ -185,7 +185,8 @@ __device__ __forceinline__ F vfrag_of(v4s_a_t a, v4s_a_t b) { return __builtin_b
 template <typename T, int KT, bool BIAS, bool DROP, int DBG, int KTV>
 __device__ __forceinline__ void attention_fwd16_body(
     const T* __restrict__ qkv, T* __restrict__ ctx, const int64_t* __restrict__ mask,
-    const float* __restrict__ pos_bias, int L, int H, int heads, float scale, float drop_p, uint64_t seed, int rev) {
+    const float* __restrict__ pos_bias, int L, int H, int heads, float scale, float drop_p, uint64_t seed, int rev,
+    int64_t row0, int Lm) {      // row0: first row of this sequence in qkv / ctx (b * L, or its packed offset); L: ITS length; Lm: row pitch of `mask`
   typedef typename MmaOps<T>::frag_t frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sK = smem;
@@ -198,7 +199,7 @@ __device__ __forceinline__ void attention_fwd16_body(
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t ld2 = 6 * (int64_t)H;                       // row pitch of qkv in bytes
-  const char* const base = (const char*)(qkv + b * L * 3 * (int64_t)H + h * 64);
+  const char* const base = (const char*)(qkv + row0 * 3 * (int64_t)H + h * 64);
   // K and V rows of this (batch, head): instruction i of wave w moves rows (i * KT + w) * 8 .. + 7, lane -> row
   // (lane >> 3), physical 16-byte chunk (lane & 7) <- source chunk (lane & 7) ^ ((row >> 1) & 7) for K (row-per-lane
   // 16-byte reads), ^ 4 ((row >> 1) & 1) for V: the four rows of a transposing read then sit in the four 64-byte
@@ -217,7 +218,7 @@ __device__ __forceinline__ void attention_fwd16_body(
   }
   const float LOG2E = 1.4426950408889634f;
   for (int k = tid; k < KT * 32; k += 64 * KT)
-    sM[k] = k < L ? (mask[b * L + k] != 0 ? 0.f : -1e30f) : -INFINITY;
+    sM[k] = k < L ? (mask[b * Lm + k] != 0 ? 0.f : -1e30f) : -INFINITY;
 
   const int q0 = wave * 32;
   const int qrow = (q0 + l31) < L ? (q0 + l31) : (L - 1);
@@ -347,7 +348,7 @@ __device__ __forceinline__ void attention_fwd16_body(
       // lanes 0-31: d = 32 dt + 16 gp + 0..7 ; lanes 32-63: d = 32 dt + 16 gp + 8..15   (chunk 4 dt + 2 gp + half)
       *(uint4*)(so + l31 * 128 + (((4 * dt + 2 * gp + half) ^ (l31 & 7)) << 4)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
     }
-  char* const out = (char*)(ctx + (b * L + q0) * (int64_t)H + h * 64);
+  char* const out = (char*)(ctx + (row0 + q0) * (int64_t)H + h * 64);
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int row = it * 8 + (lane >> 3), c = lane & 7;
@@ -360,11 +361,18 @@ template <typename T, int KT, bool BIAS, bool DROP, int DBG = 0>
 __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) void attention_fwd16_kernel(
     const T* __restrict__ qkv, T* __restrict__ ctx, const int64_t* __restrict__ mask,
     const float* __restrict__ pos_bias, int L, int H, int heads, float scale, float drop_p, uint64_t seed, int rev,
-    const int* __restrict__ kmax) {
-#define OM_ATTN_BODY(V) attention_fwd16_body<T, KT, BIAS, DROP, DBG, V>(qkv, ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed, rev)
-  if (KT == 4 && !BIAS && !DROP && kmax) {          // (the encoder's inference shape; kmax[b] = L for a row without any unmasked key)
-    const int64_t b = rev ? (int64_t)(gridDim.x / heads) - 1 - blockIdx.x / heads : blockIdx.x / heads;
-    const int kt = (__builtin_amdgcn_readfirstlane(kmax[b]) + 31) >> 5;
+    const int* __restrict__ kmax, const int* __restrict__ cu) {
+#define OM_ATTN_BODY(V) attention_fwd16_body<T, KT, BIAS, DROP, DBG, V>(qkv, ctx, mask, pos_bias, Lb, H, heads, scale, drop_p, seed, rev, row0, L)
+  const int64_t b = rev ? (int64_t)(gridDim.x / heads) - 1 - blockIdx.x / heads : blockIdx.x / heads;
+  int64_t row0 = b * L;
+  int Lb = L;
+  if (cu) {                                          // packed rows (om_encoder_forward_packed): sequence b is rows cu[b] .. cu[b + 1] - 1
+    const int c0 = __builtin_amdgcn_readfirstlane(cu[b]), c1 = __builtin_amdgcn_readfirstlane(cu[b + 1]);
+    row0 = c0; Lb = c1 - c0;
+    if (Lb <= 0) return;
+  }
+  if (KT == 4 && !BIAS && !DROP && (kmax || cu)) {   // (the encoder's inference shape; kmax[b] = L for a row without any unmasked key)
+    const int kt = ((cu ? Lb : __builtin_amdgcn_readfirstlane(kmax[b])) + 31) >> 5;
     if (kt <= 1) { OM_ATTN_BODY(1); return; }
     if (kt == 2) { OM_ATTN_BODY(2); return; }
     if (kt == 3) { OM_ATTN_BODY(3); return; }
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(64 * KT, KT <= 4 ? ((BIAS || DROP) ? 3 : 4) : 2) vo
 
 template <typename T, int KT, bool BIAS, bool DROP>
 static int launch_attn16_(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias, int64_t B, int L, int H,
-                         int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, int rev, const int* kmax) {
+                         int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, int rev, const int* kmax, const int* cu = nullptr) {
   const int lds = 2 * KT * 32 * 128 + KT * 32 * 4;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
@@ -387,7 +395,7 @@ static int launch_attn16_(const void* qkv, void* ctx, const int64_t* mask, const
 #define OM_ATTN_DBG(D)                                                                                                        \
   case D:                                                                                                                     \
     hipLaunchKernelGGL((attention_fwd16_kernel<bf16_t, 4, false, false, D>), dim3((unsigned)(heads * B)), dim3(256), lds, s,          \
-                       (const bf16_t*)qkv, (bf16_t*)ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed, rev, kmax);         \
+                       (const bf16_t*)qkv, (bf16_t*)ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed, rev, kmax, cu);    \
     break;
     switch (dbg) { OM_ATTN_DBG(1) OM_ATTN_DBG(2) OM_ATTN_DBG(3) OM_ATTN_DBG(4) OM_ATTN_DBG(5) OM_ATTN_DBG(6) OM_ATTN_DBG(7) default: break; }
 #undef OM_ATTN_DBG
@@ -395,23 +403,23 @@ static int launch_attn16_(const void* qkv, void* ctx, const int64_t* mask, const
     return 0;
   }
   hipLaunchKernelGGL((attention_fwd16_kernel<T, KT, BIAS, DROP>), dim3((unsigned)(heads * B)), dim3(64 * KT), lds, s, (const T*)qkv,
-                     (T*)ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed, rev, kmax);
+                     (T*)ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed, rev, kmax, cu);
   OM_LAUNCH_CHECK();
   return 0;
 }
 template <typename T, int KT>
 static int launch_attn16(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias, int64_t B, int L, int H,
-                         int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, int rev, const int* kmax) {
+                         int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, int rev, const int* kmax, const int* cu = nullptr) {
   if (std::is_same<T, f16_t>::value) {            // float16: BERT-family inference only (no bias table, no dropout)
     if (drop_p > 0.f || pos_bias) OM_FAIL("float16 attention: inference without a position-bias table only");
-    return launch_attn16_<T, KT, false, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev, kmax);
+    return launch_attn16_<T, KT, false, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev, kmax, cu);
   }
   if (drop_p > 0.f) {
-    if (pos_bias) return launch_attn16_<bf16_t, KT, true, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, rev, kmax);
-    return launch_attn16_<bf16_t, KT, false, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, rev, kmax);
+    if (pos_bias) return launch_attn16_<bf16_t, KT, true, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, rev, kmax, cu);
+    return launch_attn16_<bf16_t, KT, false, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, rev, kmax, cu);
   }
-  if (pos_bias) return launch_attn16_<bf16_t, KT, true, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev, kmax);
-  return launch_attn16_<bf16_t, KT, false, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev, kmax);
+  if (pos_bias) return launch_attn16_<bf16_t, KT, true, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev, kmax, cu);
+  return launch_attn16_<bf16_t, KT, false, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev, kmax, cu);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -618,6 +626,46 @@ __global__ void mask_extent_kernel(const int64_t* __restrict__ mask, int64_t B, 
   for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
   if (lane == 0) kmax[b] = last ? last : L;
 }
+// packed rows: cu[0..B] = exclusive scan of kmax clamped to `rows`; row_map[t] = b * L + pos of packed row t (-1 for the pad rows
+// up to `rows`).  One workgroup (B is a few thousand at most).  More tokens than `rows`: the sequences past the bound get the
+// rows that are left (possibly none) so that no kernel leaves the buffers, cu[B + 1] keeps the true count, and the pooling
+// tail turns every representation into NaN (omk_pack_overflow_poison) instead of returning a silently truncated batch.
+__global__ __launch_bounds__(1024) void pack_rows_kernel(const int* __restrict__ kmax, int64_t B, int L, int64_t rows, int* __restrict__ cu,
+                                                          int* __restrict__ cls_rows, int* __restrict__ row_map) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int64_t per = (B + 1023) / 1024, lo = tid * per, hi = lo + per < B ? lo + per : B;
+  int sum = 0;
+  for (int64_t i = lo; i < hi; ++i) sum += kmax[i];
+  part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - sum;                       // exclusive prefix of this thread's rows
+  const int cap = (int)rows;
+  for (int64_t i = lo; i < hi; ++i) {
+    cu[i] = run < cap ? run : cap;
+    cls_rows[i] = run < cap ? run : cap - 1;
+    const int n = kmax[i];
+    for (int k = 0; k < n; ++k) if (run + k < cap) row_map[run + k] = (int)(i * L + k);
+    run += n;
+  }
+  const int total = part[1023];
+  if (tid == 1023) { cu[B] = total < cap ? total : cap; cu[B + 1] = total; }
+  for (int64_t t = total + tid; t < rows; t += 1024) row_map[t] = -1;
+}
+int omk_pack_rows(const int* kmax, int64_t B, int L, int64_t rows, int* cu, int* cls_rows, int* row_map, hipStream_t s) {
+  if (B <= 0) return 0;
+  if (rows > 0x7fffffff || B * (int64_t)L > 0x7fffffff) OM_FAIL("packed rows: token counts below 2^31");
+  hipLaunchKernelGGL(pack_rows_kernel, dim3(1), dim3(1024), 0, s, kmax, B, L, rows, cu, cls_rows, row_map);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
 int omk_mask_extent(const int64_t* mask, int64_t B, int L, int* kmax, hipStream_t s) {
   if (B <= 0) return 0;
   hipLaunchKernelGGL(mask_extent_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, mask, B, L, kmax);
@@ -627,8 +675,9 @@ int omk_mask_extent(const int64_t* mask, int64_t B, int L, int* kmax, hipStream_
 
 int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
                   const float* pos_bias, int64_t B, int L, int H, int heads, float scale,
-                  float drop_p, uint64_t seed, hipStream_t s, int reverse, const int* kmax) {
+                  float drop_p, uint64_t seed, hipStream_t s, int reverse, const int* kmax, const int* cu) {
   if (B <= 0) return 0;
+  if (cu && !((dtype == OM_BF16 || dtype == OM_F16) && L <= 256 && !pos_bias && drop_p == 0.f)) OM_FAIL("packed rows: 16-bit inference attention, L <= 256");
   if (L < 1 || L > 1024) OM_FAIL("sequence length must be in [1,1024]");
   if (L > 256 && drop_p > 0.f) OM_FAIL("training supports sequence lengths up to 256");
   if (H != heads * 64) OM_FAIL("head_dim must be 64");
@@ -638,22 +687,22 @@ int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
       if (drop_p > 0.f || pos_bias) OM_FAIL("float16 attention: inference without a position-bias table only");
       return launch_attn_long<f16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
     }
-    if (L <= 32) return launch_attn16<f16_t, 1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
-    if (L <= 64) return launch_attn16<f16_t, 2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
-    if (L <= 128) return launch_attn16<f16_t, 4>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
-    if (L <= 192) return launch_attn16<f16_t, 6>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
-    return launch_attn16<f16_t, 8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
+    if (L <= 32) return launch_attn16<f16_t, 1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
+    if (L <= 64) return launch_attn16<f16_t, 2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
+    if (L <= 128) return launch_attn16<f16_t, 4>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
+    if (L <= 192) return launch_attn16<f16_t, 6>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
+    return launch_attn16<f16_t, 8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
   }
   if (L > 256) {                                              // online-softmax kernel, any dtype
     if (dtype == OM_BF16) return launch_attn_long<bf16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
     return launch_attn_long<float>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
   }
   if (dtype == OM_BF16 && om_option(OM_OPT_ATTENTION_FAST)) {        // the low-instruction-count kernel (inference, and training with dropout)
-    if (L <= 32) return launch_attn16<bf16_t, 1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
-    if (L <= 64) return launch_attn16<bf16_t, 2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
-    if (L <= 128) return launch_attn16<bf16_t, 4>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
-    if (L <= 192) return launch_attn16<bf16_t, 6>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
-    return launch_attn16<bf16_t, 8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax);
+    if (L <= 32) return launch_attn16<bf16_t, 1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
+    if (L <= 64) return launch_attn16<bf16_t, 2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
+    if (L <= 128) return launch_attn16<bf16_t, 4>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
+    if (L <= 192) return launch_attn16<bf16_t, 6>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
+    return launch_attn16<bf16_t, 8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
   }
   if (dtype == OM_BF16) return dispatch_attn<bf16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);
   return dispatch_attn<float>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s);

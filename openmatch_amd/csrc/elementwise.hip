@@ -88,16 +88,18 @@ __device__ inline void norm_and_store(float (&x)[MAX_VEC][4], int nvec, int lane
 template <typename TIn, typename TOut, int MAX_VEC>
 __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_kernel(
     const TIn* __restrict__ x, int64_t ldx, TOut* __restrict__ y, int64_t ldy,
-    const float* __restrict__ g, const float* __restrict__ b, int64_t M, int H, float eps, int rms) {
+    const float* __restrict__ g, const float* __restrict__ b, int64_t M, int H, float eps, int rms,
+    const int* __restrict__ rows = nullptr) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= M) return;
+  const int64_t src = rows ? (int64_t)rows[row] : row;      // gather (packed rows: the [CLS] row of every sequence)
   const int nvec = (H / 4 + 63) / 64;
   float v[MAX_VEC][4];
 #pragma unroll
   for (int j = 0; j < MAX_VEC; ++j) {
     const int c = (lane + 64 * j) * 4;
-    if (j < nvec && c < H) Vec4<TIn>::load(x + row * ldx + c, v[j]);
+    if (j < nvec && c < H) Vec4<TIn>::load(x + src * ldx + c, v[j]);
   }
   norm_and_store<TOut, MAX_VEC>(v, nvec, lane, H, g, b, eps, rms, y + row * ldy);
 }
@@ -109,10 +111,12 @@ template <int NV, typename TOut = bf16_t>      // TOut = float: the LAST normali
 __global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(     // runs layer_norm in fp32 and returns fp32)
     const bf16_t* __restrict__ x, int64_t ldx, TOut* __restrict__ y, int64_t ldy,
     const float* __restrict__ g, const float* __restrict__ b, int64_t M, int H, float eps, int rms,
-    const bf16_t* __restrict__ x_lo) {        // x_lo: second plane of a two-plane residual stream (value = x + x_lo), or NULL
+    const bf16_t* __restrict__ x_lo,          // x_lo: second plane of a two-plane residual stream (value = x + x_lo), or NULL
+    const int* __restrict__ rows = nullptr) { // gather: output row r normalises input row rows[r]
   const int lane = threadIdx.x & 31;
-  const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
-  if (row >= M) return;
+  const int64_t orow = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (orow >= M) return;
+  const int64_t row = rows ? (int64_t)rows[orow] : orow;
   const int nv8 = H / 8;
   float v[NV][8];
 #pragma unroll
@@ -174,10 +178,10 @@ __global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(     // runs laye
         w[e] = (uint32_t)f32_to_bf16(y0) | ((uint32_t)f32_to_bf16(y1) << 16);
       }
       if (sizeof(TOut) == 4) {
-        Vec4<float>::store((float*)y + row * ldy + c * 8, *(float(*)[4])&o[0]);
-        Vec4<float>::store((float*)y + row * ldy + c * 8 + 4, *(float(*)[4])&o[4]);
+        Vec4<float>::store((float*)y + orow * ldy + c * 8, *(float(*)[4])&o[0]);
+        Vec4<float>::store((float*)y + orow * ldy + c * 8 + 4, *(float(*)[4])&o[4]);
       } else {
-        *(uint4*)(y + row * ldy + c * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+        *(uint4*)(y + orow * ldy + c * 8) = make_uint4(w[0], w[1], w[2], w[3]);
       }
     }
   }
@@ -232,10 +236,18 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void embed_kernel(
     const int64_t* __restrict__ ids, const int64_t* __restrict__ type_ids,
     const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
     const float* __restrict__ g, const float* __restrict__ b, TOut* __restrict__ out, int64_t M,
-    int L, int H, int vocab, int type_vocab, float eps, int bert) {
+    int L, int H, int vocab, int type_vocab, float eps, int bert, const int* __restrict__ row_map) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int64_t orow = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (orow >= M) return;
+  int64_t row = orow;
+  if (row_map) {                                   // packed rows: output row t embeds token row_map[t]; pad rows are zero
+    row = row_map[orow];
+    if (row < 0) {
+      for (int c = lane * 4; c < H; c += 256) { float z[4] = {0.f, 0.f, 0.f, 0.f}; Vec4<TOut>::store(out + orow * H + c, z); }
+      return;
+    }
+  }
   int64_t id = ids[row];
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
   const int nvec = (H / 4 + 63) / 64;
@@ -256,14 +268,14 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void embed_kernel(
         for (int e = 0; e < 4; ++e) v[j][e] = (w[e] + ty[e]) + p[e];
       }
     }
-    norm_and_store<TOut, MAX_VEC>(v, nvec, lane, H, g, b, eps, 0, out + row * H);
+    norm_and_store<TOut, MAX_VEC>(v, nvec, lane, H, g, b, eps, 0, out + orow * H);
   } else {
 #pragma unroll
     for (int j = 0; j < MAX_VEC; ++j) {
       const int c = (lane + 64 * j) * 4;
       if (j < nvec && c < H) {
         Vec4<float>::load(word + id * H + c, v[j]);
-        Vec4<TOut>::store(out + row * H + c, v[j]);
+        Vec4<TOut>::store(out + orow * H + c, v[j]);
       }
     }
   }
@@ -272,16 +284,17 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void embed_kernel(
 // pooling == FIRST: hidden[:,0,:] ; MEAN: sum(h*m)/clamp(sum(m),1e-9)  (utils.py:233-235)
 template <typename T>
 __global__ void pool_kernel(const T* __restrict__ x, const int64_t* __restrict__ mask,
-                            float* __restrict__ out, int L, int H, int mode) {
+                            float* __restrict__ out, int L, int H, int mode, const int* __restrict__ cu) {
   const int64_t b = blockIdx.x;
-  const T* xb = x + b * (int64_t)L * H;
+  const T* xb = x + (cu ? (int64_t)cu[b] : b * (int64_t)L) * H;
+  const int Lb = cu ? cu[b + 1] - cu[b] : L;        // packed rows: this sequence's own length (the mask keeps pitch L)
   for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (mode == OM_POOL_FIRST) {
       Vec4<T>::load(xb + c, acc);
     } else {
       float cnt = 0.f;
-      for (int t = 0; t < L; ++t) {
+      for (int t = 0; t < Lb; ++t) {
         const float m = (float)mask[b * L + t];
         float v[4];
         Vec4<T>::load(xb + (int64_t)t * H + c, v);
@@ -350,14 +363,14 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void index_to_f16_kernel(
 // ---- host launchers ---------------------------------------------------------
 template <typename TIn, typename TOut>
 static int launch_ln(const void* x, int64_t ldx, void* y, int64_t ldy, const float* g,
-                     const float* b, int64_t M, int H, float eps, int rms, hipStream_t s) {
+                     const float* b, int64_t M, int H, float eps, int rms, hipStream_t s, const int* rows = nullptr) {
   const unsigned grid = (unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
   if (H <= 1024)
     hipLaunchKernelGGL((layernorm_kernel<TIn, TOut, 4>), dim3(grid), dim3(64 * ROWS_PER_BLOCK), 0, s,
-                       (const TIn*)x, ldx, (TOut*)y, ldy, g, b, M, H, eps, rms);
+                       (const TIn*)x, ldx, (TOut*)y, ldy, g, b, M, H, eps, rms, rows);
   else
     hipLaunchKernelGGL((layernorm_kernel<TIn, TOut, 8>), dim3(grid), dim3(64 * ROWS_PER_BLOCK), 0, s,
-                       (const TIn*)x, ldx, (TOut*)y, ldy, g, b, M, H, eps, rms);
+                       (const TIn*)x, ldx, (TOut*)y, ldy, g, b, M, H, eps, rms, rows);
   OM_LAUNCH_CHECK();
   return 0;
 }
@@ -380,7 +393,7 @@ int omk_ln_stats_reduce(const float* slots, int nslots, int64_t M, float* out, h
 
 // x in the compute format (optionally two planes, bf16) -> y in f32
 int omk_layernorm_f32out(int dtype, const void* x, int64_t ldx, float* y, int64_t ldy, const float* g, const float* b,
-                         int64_t M, int H, float eps, int rms, hipStream_t s, const void* x_lo) {
+                         int64_t M, int H, float eps, int rms, hipStream_t s, const void* x_lo, const int* rows) {
   if (H % 4 != 0 || H > 64 * 4 * MAX_VEC_LIMIT) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
   if (M <= 0) return 0;
   if (dtype == OM_BF16 && H % 8 == 0 && H <= 1024 && ldx % 8 == 0 && ldy % 4 == 0 &&
@@ -388,16 +401,28 @@ int omk_layernorm_f32out(int dtype, const void* x, int64_t ldx, float* y, int64_
     const unsigned grid = (unsigned)((M + 7) / 8);
     const int nv = (H / 8 + 31) / 32;
 #define LN8F(NV) hipLaunchKernelGGL((layernorm_bf16x8_kernel<NV, float>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ldx, \
-                                    y, ldy, g, b, M, H, eps, rms, (const bf16_t*)x_lo)
+                                    y, ldy, g, b, M, H, eps, rms, (const bf16_t*)x_lo, rows)
     if (nv <= 1) LN8F(1); else if (nv == 2) LN8F(2); else if (nv == 3) LN8F(3); else LN8F(4);
 #undef LN8F
     OM_LAUNCH_CHECK();
     return 0;
   }
   if (x_lo) OM_FAIL("two-plane LayerNorm input: bf16 rows of whole 16-byte vectors only");
-  if (dtype == OM_BF16) return launch_ln<bf16_t, float>(x, ldx, y, ldy, g, b, M, H, eps, rms, s);
-  if (dtype == OM_F16) return launch_ln<f16_t, float>(x, ldx, y, ldy, g, b, M, H, eps, rms, s);
-  return launch_ln<float, float>(x, ldx, y, ldy, g, b, M, H, eps, rms, s);
+  if (dtype == OM_BF16) return launch_ln<bf16_t, float>(x, ldx, y, ldy, g, b, M, H, eps, rms, s, rows);
+  if (dtype == OM_F16) return launch_ln<f16_t, float>(x, ldx, y, ldy, g, b, M, H, eps, rms, s, rows);
+  return launch_ln<float, float>(x, ldx, y, ldy, g, b, M, H, eps, rms, s, rows);
+}
+
+// packed rows: more tokens than the caller's row bound -> every representation becomes NaN (never a silently truncated batch)
+__global__ void pack_overflow_poison_kernel(const int* __restrict__ cu, int64_t B, int64_t rows, float* __restrict__ out, int64_t n) {
+  if ((int64_t)cu[B + 1] <= rows) return;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = __int_as_float(0x7fc00000);
+}
+int omk_pack_overflow_poison(const int* cu, int64_t B, int64_t rows, float* out, int64_t n, hipStream_t s) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(pack_overflow_poison_kernel, dim3(64), dim3(256), 0, s, cu, B, rows, out, n);
+  OM_LAUNCH_CHECK();
+  return 0;
 }
 
 int omk_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* g,
@@ -426,13 +451,13 @@ int omk_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, c
 int omk_embed(int dtype, const int64_t* ids, const int64_t* type_ids, const float* word,
               const float* pos, const float* type, const float* g, const float* b, void* out,
               int64_t M, int L, int H, int vocab, int type_vocab, float eps, int bert,
-              hipStream_t s) {
+              hipStream_t s, const int* row_map) {
   if (H % 4 != 0 || H > 64 * 4 * MAX_VEC_LIMIT) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
   if (M <= 0) return 0;
   const unsigned grid = (unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
 #define EMBED_LAUNCH(TT, NV)                                                                   \
   hipLaunchKernelGGL((embed_kernel<TT, NV>), dim3(grid), dim3(64 * ROWS_PER_BLOCK), 0, s, ids, \
-                     type_ids, word, pos, type, g, b, (TT*)out, M, L, H, vocab, type_vocab, eps, bert)
+                     type_ids, word, pos, type, g, b, (TT*)out, M, L, H, vocab, type_vocab, eps, bert, row_map)
   if (dtype == OM_BF16) {
     if (H <= 1024) EMBED_LAUNCH(bf16_t, 4); else EMBED_LAUNCH(bf16_t, 8);
   } else if (dtype == OM_F16) {
@@ -446,18 +471,18 @@ int omk_embed(int dtype, const int64_t* ids, const int64_t* type_ids, const floa
 }
 
 int omk_pool(int dtype, const void* x, const int64_t* mask, float* out, int64_t B, int L, int H,
-             int mode, hipStream_t s) {
+             int mode, hipStream_t s, const int* cu) {
   if (B <= 0) return 0;
   if (H % 4 != 0) OM_FAIL("hidden size must be a multiple of 4");
   if (dtype == OM_BF16)
     hipLaunchKernelGGL((pool_kernel<bf16_t>), dim3((unsigned)B), dim3(256), 0, s, (const bf16_t*)x,
-                       mask, out, L, H, mode);
+                       mask, out, L, H, mode, cu);
   else if (dtype == OM_F16)
     hipLaunchKernelGGL((pool_kernel<f16_t>), dim3((unsigned)B), dim3(256), 0, s, (const f16_t*)x,
-                       mask, out, L, H, mode);
+                       mask, out, L, H, mode, cu);
   else
     hipLaunchKernelGGL((pool_kernel<float>), dim3((unsigned)B), dim3(256), 0, s, (const float*)x,
-                       mask, out, L, H, mode);
+                       mask, out, L, H, mode, cu);
   OM_LAUNCH_CHECK();
   return 0;
 }

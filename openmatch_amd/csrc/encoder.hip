@@ -103,6 +103,7 @@ struct EncWs {
   float* final32;   // 16-bit runs: the last normalisation's output in f32 for the pooling tail (CLS rows, or all rows for mean pooling)
   int* lut;
   int* kmax;        // per batch row: 1 + its last unmasked key (omk_mask_extent), read by every layer's attention launch
+  int *cu, *cls_rows, *row_map;   // packed rows (om_encoder_forward_packed): sequence offsets [B + 2], [CLS] row of each sequence [B], token of each row
   // fused-LayerNorm path (16-bit): folded weight, its column sums and bias, two statistics buffers per layer, the slot
   // partials one GEMM leaves (kernels.h: GemmEpilogue::stats_out), and the second plane of the two residual tensors
   char* wfold;
@@ -112,13 +113,13 @@ struct EncWs {
   size_t total;
 };
 
-static EncWs carve(const OmEncoderConfig* c, int64_t B, int64_t L, char* base) {
+static EncWs carve(const OmEncoderConfig* c, int64_t B, int64_t L, char* base, int64_t packed_rows = 0) {
   const bool half = c->dtype == OM_BF16 || c->dtype == OM_F16;
   const size_t es = half ? 2 : 4;
   // 16-bit batches of >= 512 tokens are padded to whole 256-row tiles: the persistent GEMM generation
   // (gemm_wide7.h) takes whole tiles only.  Rows are independent in every contraction, so whatever the pad rows
   // hold stays in the pad rows; every other kernel (embedding, attention, normalisation, pooling) sees B*L rows.
-  const size_t Mreal = (size_t)B * L, H = c->hidden, F = c->ffn;
+  const size_t Mreal = packed_rows > 0 ? (size_t)packed_rows : (size_t)B * L, H = c->hidden, F = c->ffn;
   const size_t M = (half && Mreal >= 512) ? (Mreal + 255) / 256 * 256 : Mreal;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return base + o; };
@@ -135,6 +136,9 @@ static EncWs carve(const OmEncoderConfig* c, int64_t B, int64_t L, char* base) {
   w.posbias = (float*)take(c->arch == OM_ARCH_T5 ? (size_t)c->n_heads * L * L * 4 : 0);
   w.lut = (int*)take(c->arch == OM_ARCH_T5 ? (size_t)(2 * L) * 4 : 0);
   w.kmax = (int*)take((size_t)B * 4);
+  w.cu = (int*)take(packed_rows > 0 ? (size_t)(B + 2) * 4 : 0);
+  w.cls_rows = (int*)take(packed_rows > 0 ? (size_t)B * 4 : 0);
+  w.row_map = (int*)take(packed_rows > 0 ? (size_t)packed_rows * 4 : 0);
   w.final32 = (float*)take(half && c->pooling != OM_POOL_NONE ? (c->pooling == OM_POOL_FIRST ? (size_t)B : Mreal) * H * 4 : 0);
   const bool fuse = half;                             // fused-norm path (BERT LayerNorm / T5 RMSNorm)
   const size_t wide = std::max((size_t)3 * H, F);
@@ -156,6 +160,11 @@ static EncWs carve(const OmEncoderConfig* c, int64_t B, int64_t L, char* base) {
 extern "C" size_t om_encoder_workspace_bytes(const OmEncoderConfig* cfg, int64_t B, int64_t L) {
   if (!cfg || B <= 0 || L <= 0) return 0;
   return carve(cfg, B, L, nullptr).total;
+}
+
+extern "C" size_t om_encoder_workspace_bytes_packed(const OmEncoderConfig* cfg, int64_t B, int64_t L, int64_t packed_rows) {
+  if (!cfg || B <= 0 || L <= 0 || packed_rows <= 0) return 0;
+  return carve(cfg, B, L, nullptr, packed_rows).total;
 }
 
 extern "C" int om_t5_relative_bucket(int relative_position, int num_buckets, int max_distance) {
@@ -185,22 +194,31 @@ static int check_cfg(const OmEncoderConfig* c) {
   return 0;
 }
 
-extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeights* w,
-                                  const int64_t* input_ids, const int64_t* attention_mask,
-                                  const int64_t* token_type_ids, int64_t B, int64_t L,
-                                  void* out_hidden, float* out_reps, void* workspace,
-                                  size_t workspace_bytes, void* stream) {
+// packed_rows > 0: the token axis holds only the rows up to each sequence's last unmasked token, back to back
+// (om_encoder_forward_packed); every per-token kernel and contraction then runs over packed_rows rows instead of B * L.
+static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* w,
+                                const int64_t* input_ids, const int64_t* attention_mask,
+                                const int64_t* token_type_ids, int64_t B, int64_t L,
+                                void* out_hidden, float* out_reps, void* workspace,
+                                size_t workspace_bytes, void* stream, int64_t packed_rows) {
   if (!c || !w || !input_ids || !attention_mask) OM_FAIL("null argument");
   if (check_cfg(c)) return 1;
   if (B <= 0) return 0;
   if (L < 1 || L > 1024) OM_FAIL("sequence length must be in [1,1024]");
   if (!workspace || ((uintptr_t)workspace & 255)) OM_FAIL("workspace must be 256-byte aligned");
-  EncWs ws = carve(c, B, L, (char*)workspace);
+  const bool packed = packed_rows > 0;
+  if (packed) {
+    if (c->arch != OM_ARCH_BERT || c->dtype == OM_F32 || out_hidden || c->pooling == OM_POOL_NONE || L > 256 || c->n_layers < 1)
+      OM_FAIL("packed rows: 16-bit BERT-family inference that returns representations only, L <= 256");
+    if (packed_rows % 256 || packed_rows < 512 || packed_rows > B * L + 255) OM_FAIL("packed_rows: a multiple of 256 in [512, B * L + 255]");
+  }
+  EncWs ws = carve(c, B, L, (char*)workspace, packed_rows);
   if (ws.total > workspace_bytes) OM_FAIL("workspace too small");
   if (c->pooling != OM_POOL_NONE && !out_reps) OM_FAIL("out_reps required when pooling is set");
   hipStream_t s = (hipStream_t)stream;
   const int dt = c->dtype, H = c->hidden, F = c->ffn, nh = c->n_heads;
-  const int64_t M = B * L;
+  const int64_t M = packed ? packed_rows : B * L;
+  const int* const cu = packed ? ws.cu : nullptr;
   const int64_t Mg = ws.Mp;          // rows of the contractions (M padded to whole tiles for large 16-bit batches)
   const bool bert = c->arch == OM_ARCH_BERT;
   const OmLayerWeights* Ls = w->layers_host;
@@ -214,6 +232,7 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
 #define RUN(expr) do { if (expr) return 1; } while (0)
 
   RUN(omk_mask_extent(attention_mask, B, (int)L, ws.kmax, s));
+  if (packed) RUN(omk_pack_rows(ws.kmax, B, (int)L, packed_rows, ws.cu, ws.cls_rows, ws.row_map, s));
   char* final_hidden = nullptr;
   // 16-bit runs that only return representations: the LAST normalisation writes f32 (the reference's autocast runs
   // layer_norm in fp32), into ws.final32 -- B CLS rows (pooling "first": already the pooled vectors) or all M rows
@@ -221,7 +240,7 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
   if (bert) {
     if (L > c->max_pos) OM_FAIL("sequence longer than the position table");
     RUN(omk_embed(dt, input_ids, token_type_ids, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g,
-                  w->emb_ln_b, ws.x, M, (int)L, H, c->vocab, c->type_vocab, c->ln_eps, 1, s));
+                  w->emb_ln_b, ws.x, M, (int)L, H, c->vocab, c->type_vocab, c->ln_eps, 1, s, packed ? ws.row_map : nullptr));
     const float scale = 1.0f / sqrtf((float)c->head_dim);
     // LayerNorm fused across the GEMMs (bf16, large batches): the LayerNorm outputs are never
     // written.  The GEMM that produces a pre-LayerNorm sum y also accumulates its row statistics; the
@@ -233,7 +252,8 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
     const bool fuse = !no_fuse && c->act == OM_ACT_GELU_ERF && c->n_layers > 0 && H % 8 == 0 &&
                       omk_gemm_ln_fusable(dt, Mg, H, H) && omk_gemm_ln_fusable(dt, Mg, F, H) &&
                       omk_gemm_ln_fusable(dt, Mg, 3 * H, H) && omk_gemm_ln_fusable(dt, Mg, H, F);
-    if (om_option(OM_OPT_ENCODER_DEBUG)) fprintf(stderr, "om_encoder_forward: M=%ld fused_ln=%d\n", (long)M, (int)fuse);
+    if (om_option(OM_OPT_ENCODER_DEBUG)) fprintf(stderr, "om_encoder_forward: M=%ld fused_ln=%d packed=%d\n", (long)M, (int)fuse, (int)packed);
+    if (packed && !fuse) OM_FAIL("packed rows need the fused 16-bit path (hidden, ffn multiples of 256; erf-GELU)");
     if (fuse) {
       const float inv_h = 1.0f / (float)H;
       // Two-plane residual stream (bfloat16): y1 = ws.y + ws.y_lo, y2 = ws.x1 + ws.x1_lo; the GEMMs that consume LN(y)
@@ -264,7 +284,7 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
           e.bias = bfp; e.ln_stats = st2p; e.ln_colsum = cs; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps; e.reverse = OM_WALK();
           RUN(omk_gemm(dt, ws.x1, H, wf, H, dt, ws.qkv, 3 * H, Mg, 3 * H, H, e, s));
         }
-        RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, nullptr, B, (int)L, H, nh, scale, 0.f, 0, s, OM_WALK(), ws.kmax));
+        RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, nullptr, B, (int)L, H, nh, scale, 0.f, 0, s, OM_WALK(), ws.kmax, cu));
         // ---- attention output + residual -> y1, statistics of LN1
         e = GemmEpilogue{};
         e.bias = lw.o_b; e.ldr = H; e.stats_out = ws.slots; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
@@ -298,7 +318,10 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
 #undef OM_WALK
       const OmLayerWeights& last = Ls[c->n_layers - 1];
       const void* lo = two ? ws.x1_lo : nullptr;
-      if (!out_hidden && c->pooling == OM_POOL_FIRST) {    // only the [CLS] rows are ever read: normalised straight into f32
+      if (packed && c->pooling == OM_POOL_FIRST) {         // the [CLS] row of sequence b is packed row cu[b]
+        RUN(omk_layernorm_f32out(dt, ws.x1, H, ws.final32, H, last.ln2_g, last.ln2_b, B, H, c->ln_eps, 0, s, lo, ws.cls_rows));
+        final32_rows = B;
+      } else if (!out_hidden && c->pooling == OM_POOL_FIRST) {    // only the [CLS] rows are ever read: normalised straight into f32
         RUN(omk_layernorm_f32out(dt, ws.x1, L * H, ws.final32, H, last.ln2_g, last.ln2_b, B, H, c->ln_eps, 0, s, lo));
         final32_rows = B;
       } else if (!out_hidden && c->pooling != OM_POOL_NONE) {
@@ -420,7 +443,7 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
     if (final32_rows == B && c->pooling == OM_POOL_FIRST)
       OM_HIP(hipMemcpyAsync(pooled, ws.final32, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));
     else if (final32_rows == M)
-      RUN(omk_pool(OM_F32, ws.final32, attention_mask, pooled, B, (int)L, H, c->pooling, s));
+      RUN(omk_pool(OM_F32, ws.final32, attention_mask, pooled, B, (int)L, H, c->pooling, s, cu));
     else
       RUN(omk_pool(dt, final_hidden, attention_mask, pooled, B, (int)L, H, c->pooling, s));
     int D = H;
@@ -431,8 +454,25 @@ extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeigh
         return 1;
     }
     if (c->normalize) RUN(omk_l2norm(out_reps, out_reps, B, D, s));
+    if (packed) RUN(omk_pack_overflow_poison(ws.cu, B, packed_rows, out_reps, B * (int64_t)D, s));
   }
 #undef GEMM
 #undef RUN
   return 0;
+}
+
+extern "C" int om_encoder_forward(const OmEncoderConfig* c, const OmEncoderWeights* w,
+                                  const int64_t* input_ids, const int64_t* attention_mask,
+                                  const int64_t* token_type_ids, int64_t B, int64_t L,
+                                  void* out_hidden, float* out_reps, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  return encoder_forward_impl(c, w, input_ids, attention_mask, token_type_ids, B, L, out_hidden, out_reps, workspace, workspace_bytes, stream, 0);
+}
+
+extern "C" int om_encoder_forward_packed(const OmEncoderConfig* c, const OmEncoderWeights* w,
+                                         const int64_t* input_ids, const int64_t* attention_mask,
+                                         const int64_t* token_type_ids, int64_t B, int64_t L, int64_t packed_rows,
+                                         float* out_reps, void* workspace, size_t workspace_bytes, void* stream) {
+  if (packed_rows <= 0) OM_FAIL("packed_rows must be positive");
+  return encoder_forward_impl(c, w, input_ids, attention_mask, token_type_ids, B, L, nullptr, out_reps, workspace, workspace_bytes, stream, packed_rows);
 }

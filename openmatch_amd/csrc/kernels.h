@@ -9,13 +9,14 @@ int omk_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, c
                   const float* b, int64_t M, int H, float eps, int rms, hipStream_t s,
                   const void* x_lo = nullptr /* second plane of a two-plane input: normalises x + x_lo */);
 int omk_layernorm_f32out(int dtype, const void* x, int64_t ldx, float* y, int64_t ldy, const float* g, const float* b,
-                         int64_t M, int H, float eps, int rms, hipStream_t s, const void* x_lo = nullptr);
+                         int64_t M, int H, float eps, int rms, hipStream_t s, const void* x_lo = nullptr,
+                         const int* rows = nullptr /* gather: output row r normalises input row rows[r] */);
 int omk_embed(int dtype, const int64_t* ids, const int64_t* type_ids, const float* word,
               const float* pos, const float* type, const float* g, const float* b, void* out,
               int64_t M, int L, int H, int vocab, int type_vocab, float eps, int bert,
-              hipStream_t s);
+              hipStream_t s, const int* row_map = nullptr /* packed rows: output row t embeds token row_map[t] of ids (-1: a zero row) */);
 int omk_pool(int dtype, const void* x, const int64_t* mask, float* out, int64_t B, int L, int H,
-             int mode, hipStream_t s);
+             int mode, hipStream_t s, const int* cu = nullptr /* packed rows: sequence b is rows cu[b] .. of x */);
 int omk_l2norm(const float* x, float* y, int64_t M, int D, hipStream_t s);
 int omk_t5_bias(const float* table, const int* lut, float* out, int L, int heads, hipStream_t s);
 
@@ -24,7 +25,12 @@ int omk_t5_bias(const float* table, const int* lut, float* out, int L, int heads
 int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
                   const float* pos_bias, int64_t B, int L, int H, int heads, float scale,
                   float drop_p, uint64_t seed, hipStream_t s, int reverse = 0 /* batch rows last to first */,
-                  const int* kmax = nullptr /* omk_mask_extent: per batch row, 1 + its last unmasked key (16-bit kernels skip the key tiles past it) */);
+                  const int* kmax = nullptr /* omk_mask_extent: per batch row, 1 + its last unmasked key (16-bit kernels skip the key tiles past it) */,
+                  const int* cu = nullptr /* packed rows: sequence b occupies rows cu[b] .. cu[b + 1] - 1 of qkv / ctx (L stays the mask's row pitch) */);
+// packed rows (om_encoder_forward_packed): cu[0..B] = offsets of the sequences (kmax[b] rows each) clamped to `rows`, cu[B + 1] = the
+// unclamped token count; cls_rows[b] = min(cu[b], rows - 1); row_map[t] = b * L + position of packed row t, -1 for the pad rows
+int omk_pack_rows(const int* kmax, int64_t B, int L, int64_t rows, int* cu, int* cls_rows, int* row_map, hipStream_t s);
+int omk_pack_overflow_poison(const int* cu, int64_t B, int64_t rows, float* out, int64_t n, hipStream_t s);
 int omk_mask_extent(const int64_t* mask, int64_t B, int L, int* kmax, hipStream_t s);
 
 // ---- extended GEMM epilogue (training) ---------------------------------------------------

@@ -7,6 +7,7 @@ parameters so `state_dict()` / `save_pretrained()` keep the reference's checkpoi
 (modeling/dense_retrieval_model.py:230-245).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -291,9 +292,38 @@ def _ensure_folded(pk, device):
 _POOL = {None: N.POOL_NONE, "first": N.POOL_FIRST, "mean": N.POOL_MEAN}
 
 
-def hip_encode(model, items, pooling, head, normalize, code, want_hidden=True):
+def packed_rows_bound(mask):
+    """om_encoder_forward_packed's row bound for an attention mask held on the HOST (the collator's output, before it is
+    moved to the device): sum over sequences of (1 + index of the last unmasked token; L for an all-masked row),
+    rounded up to whole 256-row tiles.  None when packing cannot apply (fewer than 512 rows)."""
+    m = mask.cpu() != 0
+    L = m.shape[1]
+    last = torch.where(m.any(1), L - m.flip(1).to(torch.int8).argmax(1), torch.full((m.shape[0],), L))
+    rows = (int(last.sum()) + 255) // 256 * 256
+    return rows if rows >= 512 else None
+
+
+LAST_CALL = {}       # what the most recent hip_encode ran on: {"rows": token rows of the contractions, "packed": bool} (tests, bench)
+
+
+def packed_rows_apply(cfg, B, L, rows, want_hidden, pooling):
+    """Whether om_encoder_forward_packed takes this call (include/openmatch_hip.h states the same conditions) and pays:
+    a 16-bit BERT-family encoder on its fused path, representations only, and at least one 256-row tile saved.
+    OM_ENCODER_PACKED=0 keeps every batch on the padded entry."""
+    if os.environ.get("OM_ENCODER_PACKED", "1") == "0" or want_hidden or pooling is None:
+        return False
+    if cfg.arch != N.ARCH_BERT or cfg.dtype not in (N.OM_BF16, N.OM_F16) or cfg.act != N.ACT_GELU_ERF:
+        return False
+    if cfg.hidden % 256 or cfg.ffn % 256 or cfg.n_layers < 1 or L > 256:
+        return False
+    return rows % 256 == 0 and 512 <= rows <= (B * L) // 256 * 256 - 256
+
+
+def hip_encode(model, items, pooling, head, normalize, code, want_hidden=True, packed_rows=None):
     """(hidden [B,L,H], reps [B,D] f32) through om_encoder_forward.  `items` holds
-    input_ids / attention_mask / optional token_type_ids as int64 device tensors."""
+    input_ids / attention_mask / optional token_type_ids as int64 device tensors.
+    packed_rows (with want_hidden=False): run om_encoder_forward_packed over that many rows (packed_rows_bound of the
+    mask, computed where the mask still lives on the host) instead of B * L padded ones."""
     if pooling not in _POOL:
         raise ValueError("Unknown pooling type: {}".format(pooling))
     ids = items["input_ids"]
@@ -316,14 +346,25 @@ def hip_encode(model, items, pooling, head, normalize, code, want_hidden=True):
     H = cfg.hidden
     D = cfg.head_out if cfg.head_in > 0 else H
     lib = N.lib()
+    if packed_rows and not packed_rows_apply(cfg, B, L, int(packed_rows), want_hidden, pooling):
+        packed_rows = None
+    LAST_CALL.update(rows=int(packed_rows) if packed_rows else B * L, packed=bool(packed_rows))
     with torch.cuda.device(device):
-        nbytes = lib.om_encoder_workspace_bytes(C.byref(cfg), B, L)
+        if packed_rows:
+            nbytes = lib.om_encoder_workspace_bytes_packed(C.byref(cfg), B, L, int(packed_rows))
+        else:
+            nbytes = lib.om_encoder_workspace_bytes(C.byref(cfg), B, L)
         ws_buf, ws_ptr = N.Workspace.get(device, nbytes, "encoder")
         hidden = None
         if want_hidden:
             hidden = torch.empty(B, L, H, device=device,
                                  dtype=torch_dtype_of(code))
         reps = torch.empty(B, D, device=device, dtype=torch.float32) if pooling is not None else None
+        if packed_rows:
+            N.check(lib.om_encoder_forward_packed(C.byref(cfg), C.byref(pk.weights), N.ptr(ids), N.ptr(mask),
+                                                  N.ptr(tti), B, L, int(packed_rows), N.ptr(reps),
+                                                  C.c_void_p(ws_ptr), nbytes, N.stream_ptr(device)))
+            return None, reps
         N.check(lib.om_encoder_forward(C.byref(cfg), C.byref(pk.weights), N.ptr(ids), N.ptr(mask),
                                        N.ptr(tti), B, L, N.ptr(hidden), N.ptr(reps),
                                        C.c_void_p(ws_ptr), nbytes, N.stream_ptr(device)))

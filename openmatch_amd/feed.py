@@ -65,5 +65,17 @@ def unpack_token_batch(batch, device, non_blocking=True):
     return out
 
 
+def token_rows_bound(batch):
+    """Row bound of om_encoder_forward_packed (include/openmatch_hip.h) for a compact batch whose `lengths` still live on
+    the host: the sequences' token counts (a row without any token counts as L, as the encoder treats it), summed and
+    rounded up to whole 256-row tiles.  None when the batch carries no host-side lengths -- the padded entry runs then."""
+    if not is_packed(batch) or "lengths" not in batch or batch["lengths"].is_cuda:
+        return None
+    n, L = (int(x) for x in batch[PACKED_KEY])
+    lens = batch["lengths"].to(torch.int64)
+    total = int(torch.where(lens > 0, lens, torch.full_like(lens, L)).sum())
+    return (total + 255) // 256 * 256
+
+
 def packed_nbytes(batch):
     return sum(v.numel() * v.element_size() for v in batch.values() if torch.is_tensor(v))

@@ -24,7 +24,7 @@ from transformers.modeling_outputs import ModelOutput
 from ..arguments import DataArguments, ModelArguments
 from ..arguments import DRTrainingArguments as TrainingArguments
 from ..encoder import compute_dtype_code, hip_encode
-from ..feed import is_packed, unpack_token_batch
+from ..feed import is_packed, token_rows_bound, unpack_token_batch
 from ..ops import contrastive_loss, encode_with_grad
 from .linear import LinearHead
 
@@ -105,7 +105,9 @@ class DRModel(nn.Module):
         LayerNorm of just the rows pooling needs, and hidden is None."""
         if items is None:
             return None, None
+        rows = None
         if is_packed(items):            # a batch straight from DRInferenceCollator (16-bit ids + lengths, feed.py): widen it here,
+            rows = None if want_hidden else token_rows_bound(items)     # (its lengths are on the host: the bound of the packed-rows encoder)
             items = unpack_token_batch(items, next(model.parameters()).device)     # so `model(passage=batch)` works as with the reference's collator
         items = BatchEncoding(items)
         if "T5" in type(model).__name__ and not self.model_args.encoder_only:
@@ -123,7 +125,7 @@ class DRModel(nn.Module):
         if needs_grad or has_dropout:      # train-mode forward (dropout), also under no_grad (GradCache)
             return encode_with_grad(model, head, items, self.pooling, self.normalize, code,
                                     self.training)
-        return hip_encode(model, items, self.pooling, head, self.normalize, code, want_hidden=want_hidden)
+        return hip_encode(model, items, self.pooling, head, self.normalize, code, want_hidden=want_hidden, packed_rows=rows)
 
     def _encode_t5_decoder(self, items, model, head):
         """T5 encoder-decoder pooling (reference :137-141): one decoder position fed token 0, reps = its hidden state,

@@ -214,6 +214,70 @@ def test_attention_skips_masked_key_tiles_exactly(dtype):
         assert err < tol, (dtype, b, err)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("pooling", ["first", "mean"])
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_packed_rows_encoder_is_bit_identical_to_padded(dtype, pooling):
+    """Round 4: om_encoder_forward_packed keeps only the rows up to each sequence's last unmasked token (the reference pads to
+    one length and computes over the padding, dataset/data_collator.py:27-38).  Every row of a contraction and every
+    sequence of the attention is computed independently of where it sits, so the representations must be the SAME BITS as
+    om_encoder_forward's -- ragged lengths, a full-length row, masks with holes, leading masked tokens, a row without any
+    token; through the compact collator batch (host-side lengths) and through an explicit row bound.  A bound that is too
+    small must poison the batch (NaN), never truncate it."""
+    from transformers import BertConfig, BertModel
+    from openmatch.modeling import DRModelForInference
+    from openmatch_amd import encoder as enc_mod
+    from openmatch_amd.encoder import compute_dtype_code, hip_encode, packed_rows_bound
+    from openmatch_amd.feed import pack_token_batch, token_rows_bound
+    torch.manual_seed(5)
+    cfg = BertConfig(hidden_size=256, num_hidden_layers=3, num_attention_heads=4, intermediate_size=1024, vocab_size=600,
+                     max_position_embeddings=128)
+    lm = BertModel(cfg).eval()
+    with torch.no_grad():
+        for name, p in lm.named_parameters():
+            if "LayerNorm.weight" in name:
+                p.copy_(1.0 + 0.3 * torch.randn_like(p))
+            elif "bias" in name:
+                p.copy_(0.1 * torch.randn_like(p))
+    model = DRModelForInference(lm_q=lm, lm_p=lm, pooling=pooling, model_args=NS(encoder_only=False, dtype=dtype)).to(DEV).eval()
+    code = compute_dtype_code(model.model_args)
+    rng = np.random.default_rng(9)
+    B, L = 40, 128
+    ids, mask = synth_tokens(rng, B, L, vocab=600, lo_len=3, lo_id=300)
+    ids[0, :], mask[0, :] = rng.integers(300, 600, L), 1                     # a full-length row
+    prefix = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
+    # (1) the collator's compact batch: lengths on the host -> the packed entry, chosen by DRModel.encode
+    compact = pack_token_batch(dict(prefix))
+    rows = token_rows_bound(compact)
+    assert rows is not None and rows % 256 == 0 and rows < B * L - 256, rows
+    dev_items = {k: v.to(DEV) for k, v in prefix.items()}
+    padded = hip_encode(model.lm_p, dev_items, pooling, None, False, code, want_hidden=False)[1]
+    assert enc_mod.LAST_CALL == {"rows": B * L, "packed": False}
+    via_model = model(passage=compact).p_reps
+    assert enc_mod.LAST_CALL == {"rows": rows, "packed": True}
+    assert torch.isfinite(padded).all()
+    assert torch.equal(via_model, padded)
+    explicit = hip_encode(model.lm_p, dev_items, pooling, None, False, code, want_hidden=False, packed_rows=rows)[1]
+    assert torch.equal(explicit, padded)
+    # (2) masks that are not prefixes: holes, leading masked tokens, a lone late token, an empty row
+    mask2 = mask.copy()
+    mask2[1, :] = 0; mask2[1, ::3] = 1
+    mask2[2, :] = 0; mask2[2, 40:50] = 1
+    mask2[3, :] = 0; mask2[3, :20] = 1; mask2[3, 120] = 1
+    mask2[4, :] = 0
+    m2 = torch.from_numpy(mask2)
+    rows2 = packed_rows_bound(m2)
+    last = [(np.nonzero(r)[0][-1] + 1) if r.any() else L for r in mask2]
+    assert rows2 == (sum(last) + 255) // 256 * 256
+    items2 = {"input_ids": dev_items["input_ids"], "attention_mask": m2.to(DEV)}
+    padded2 = hip_encode(model.lm_p, items2, pooling, None, False, code, want_hidden=False)[1]
+    packed2 = hip_encode(model.lm_p, items2, pooling, None, False, code, want_hidden=False, packed_rows=rows2)[1]
+    assert torch.equal(packed2, padded2)
+    # (3) a bound below the token count: NaN everywhere
+    small = hip_encode(model.lm_p, items2, pooling, None, False, code, want_hidden=False, packed_rows=rows2 - 256)[1]
+    assert torch.isnan(small).all()
+
+
 def _encode_with_fused_ln(model, items, on):
     """A/B switch of the encoder (include/openmatch_hip.h: om_debug_option(OM_OPT_ENCODER_FUSED_LN, .))."""
     from openmatch_amd import native as N

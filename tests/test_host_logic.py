@@ -495,3 +495,22 @@ def test_mfma_loops_keep_their_accumulators_in_agprs():
                     offenders.append((name[:70], header, n_mfma, n_move, limit))
     assert checked >= 25, checked
     assert not offenders, offenders
+
+
+def test_token_rows_bound_counts_rows_up_to_last_token():
+    """feed.token_rows_bound / encoder.packed_rows_bound: the host-side row bound of om_encoder_forward_packed."""
+    import torch
+    from openmatch_amd.encoder import packed_rows_bound
+    from openmatch_amd.feed import pack_token_batch, token_rows_bound
+    L = 128
+    lens = [128, 1, 77, 0, 33] * 4
+    mask = (torch.arange(L)[None, :] < torch.tensor(lens)[:, None]).long()
+    ids = torch.randint(1, 30000, (len(lens), L)) * mask
+    want = (sum(n if n else L for n in lens) + 255) // 256 * 256
+    assert token_rows_bound(pack_token_batch({"input_ids": ids, "attention_mask": mask})) == want
+    assert packed_rows_bound(mask) == want
+    holes = mask.clone(); holes[0, 5:100] = 0                  # not a prefix mask: travels as mask8, no lengths -> no bound
+    assert token_rows_bound(pack_token_batch({"input_ids": ids, "attention_mask": holes})) is None
+    assert packed_rows_bound(holes) == want                    # last unmasked token of row 0 is still 127
+    assert token_rows_bound({"input_ids": ids, "attention_mask": mask}) is None
+    assert packed_rows_bound(mask[:1, :64]) is None            # fewer than 512 rows
