@@ -424,8 +424,10 @@ def main():
         except Exception:
             traffic = None
     roofline = {
-        "kernel": ("gemm_nt_kernel7<%s> (persistent 256x256 tiles, 128-byte K steps; encoder QKV / out-proj / FFN contractions, "
-                   "three epilogue variants)" % a.precision if half else "gemm_nt_kernel6<f32> (exact-f32 MFMA)"),
+        "kernel": (("gemm_nt_kernel7c16 / 7r16<%s> (persistent 256x256 tiles on a continuous five-unit LDS ring, 128-byte K steps, "
+                    "16x16x32 MFMAs; encoder QKV / out-proj / FFN contractions, plain / GELU / LayerNorm-residual epilogues"
+                    "%s)" % (a.precision, "; bf16: the two-plane residual epilogue runs on gemm_nt_kernel7" if a.precision == "bf16" else ""))
+                   if half else "gemm_nt_kernel6<f32> (exact-f32 MFMA)"),
         "bound": "mfma", "achieved": round(gemm_tflops, 1), "peak": peak, "unit": "TFLOP/s",
         "frac": round(gemm_tflops / peak, 4), "traffic": traffic,
         "traffic_source": tsrc,
