@@ -184,7 +184,7 @@ __device__ __forceinline__ void sc7_filter(f32x16_t (&acc)[4][4], const float (&
 #pragma unroll
       for (int g = 0; g < 4; ++g) gm[g] = fmaxf(fmaxf(fmaxf(a[4 * g], a[4 * g + 1]), a[4 * g + 2]), a[4 * g + 3]);
       const float mx = fmaxf(fmaxf(fmaxf(gm[0], gm[1]), gm[2]), gm[3]);
-      if (__builtin_amdgcn_ballot_w64(mx >= th[mi]) != 0) {          // wave-uniform: some lane holds a survivor
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx >= th[mi]) != 0, 0)) {          // wave-uniform: some lane holds a survivor (cold: laid out behind the 16 block tests)
         if (wcount > SC7_STAGE_CAP - 1024) { sc7_flush(smem, wave, 0u, wcount, lane, q0, keys, cnt); wcount = 0; }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -385,33 +385,55 @@ __device__ __forceinline__ void sc7c_flush(const Sc7cStage& st, unsigned from, u
     if (pos < SORT_CAP) keys[q * SORT_CAP + pos] = key;
   }
 }
+__device__ __forceinline__ float sc7c_max3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float sc7c_max16(const f32x16_t& a) {      // eight v_max3 (the compiler's fmaxf tree: 13 v_max + 5 v_max3)
+  const float t0 = sc7c_max3(a[0], a[1], a[2]), t1 = sc7c_max3(a[3], a[4], a[5]), t2 = sc7c_max3(a[6], a[7], a[8]);
+  const float t3 = sc7c_max3(a[9], a[10], a[11]), t4 = sc7c_max3(a[12], a[13], a[14]);
+  return sc7c_max3(sc7c_max3(t0, t1, t2), sc7c_max3(t3, t4, a[15]), t0);
+}
+// One row block of queries (mi) against the wave's 128 index rows: the common case -- no score of the block's 64 per lane reaches
+// its query's threshold -- is 64 accumulator reads, 33 v_max3, ONE compare and ONE branch; the survivor path is laid out as cold
+// code behind the straight line.  Tile trace at the benchmark's size (profiles/r04_probe16_scan_filter_phases.log): filter 5.4 k
+// cycles per tile with one test per column block and the survivor code inline (each test 5 KB from the next), 4.7 k like this;
+// 3.4 survivors per wave and tile cost ~850 cycles each, the 16 block tests ~1.8 k.  A COMPACT survivor path (scores parked in LDS,
+// run-time loop over the score indices: 70 KB of code down to 12) measured 8.9 k -- the unrolled per-score code is the faster one,
+// the instruction cache is not what it waits for.
 template <int MI0, int MI1>
 __device__ __forceinline__ void sc7c_filter(f32x16_t (&acc)[4][4], const float (&th)[4], uint32_t id0, uint32_t ql0, int lane, const Sc7cStage& st,
                                             unsigned& wcount, int64_t q0, u64* __restrict__ keys, unsigned* __restrict__ cnt) {
 #pragma unroll
   for (int mi = MI0; mi < MI1; ++mi) {
+    f32x16_t a[4];
+    float bm[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       asm volatile("" : "+a"(acc[mi][ni]));            // stays in its AGPRs until this point
-      const f32x16_t a = acc[mi][ni];
-      float gm[4];
+      a[ni] = acc[mi][ni];
+      bm[ni] = sc7c_max16(a[ni]);
+    }
+    const float mx = sc7c_max3(sc7c_max3(bm[0], bm[1], bm[2]), bm[3], bm[3]);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx >= th[mi]) != 0, 0)) {          // wave-uniform: some lane holds a survivor
 #pragma unroll
-      for (int g = 0; g < 4; ++g) gm[g] = fmaxf(fmaxf(fmaxf(a[4 * g], a[4 * g + 1]), a[4 * g + 2]), a[4 * g + 3]);
-      const float mx = fmaxf(fmaxf(fmaxf(gm[0], gm[1]), gm[2]), gm[3]);
-      if (__builtin_amdgcn_ballot_w64(mx >= th[mi]) != 0) {          // wave-uniform: some lane holds a survivor
+      for (int ni = 0; ni < 4; ++ni) {
+        if (__builtin_amdgcn_ballot_w64(bm[ni] >= th[mi]) == 0) continue;
         if (wcount > SC7C_CAP - 1024) { sc7c_flush(st, 0u, wcount, lane, q0, keys, cnt); wcount = 0; }      // a block adds at most 1024
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          if (__builtin_amdgcn_ballot_w64(gm[g] >= th[mi]) == 0) continue;
+          const float gm = fmaxf(fmaxf(a[ni][4 * g], a[ni][4 * g + 1]), fmaxf(a[ni][4 * g + 2], a[ni][4 * g + 3]));
+          if (__builtin_amdgcn_ballot_w64(gm >= th[mi]) == 0) continue;
 #pragma unroll
           for (int r = 4 * g; r < 4 * g + 4; ++r) {
             const uint32_t off = (uint32_t)(ni * 32 + (r & 3) + 8 * (r >> 2));
-            const bool pass = a[r] >= th[mi];
+            const bool pass = a[ni][r] >= th[mi];
             const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
             if (m != 0) {
               if (pass) {
                 const unsigned pos = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                *(u64*)sc7c_key_slot(st, pos) = pack_key(a[r], id0 + off);
+                *(u64*)sc7c_key_slot(st, pos) = pack_key(a[ni][r], id0 + off);
                 *sc7c_q_slot(st, pos) = (uint16_t)(ql0 + mi * 32);
               }
               wcount += (unsigned)__builtin_popcountll(m);
@@ -419,8 +441,8 @@ __device__ __forceinline__ void sc7c_filter(f32x16_t (&acc)[4][4], const float (
           }
         }
       }
-      G7_FENCE_();
     }
+    G7_FENCE_();
   }
 }
 
@@ -496,6 +518,7 @@ __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7c(
     g7_fill_a(src, next_a + G7_ROW_BYTES, smem + ring.an, wave);
     g7_dma((const char*)(thr + q1 + wm * 128), lane0 * 16, g7_lds_addr(st.sp) + 7 * 4096);
     G7_FENCE_();
+    if (tr && threadIdx.x == 0) tr[16] = clock64();
     {
       const uint32_t id0 = row_base + (uint32_t)r0 + (uint32_t)(wn * 128 + 4 * (lane >> 5));    // row id of (ni = 0, r = 0)
       const uint32_t ql0 = (uint32_t)(wm * 128 + (lane & 31));
@@ -505,7 +528,9 @@ __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7c(
         pend_n = 0;
       }
       G7_FENCE_();
+      if (tr && threadIdx.x == 0) tr[17] = clock64();
       sc7c_filter<2, 4>(acc, th, id0, ql0, lane, st, wcount, q0, keys, cnt);
+      if (tr && threadIdx.x == 0) { tr[18] = clock64(); tr[20] = wcount; }
       if (wcount > 64) sc7c_flush(st, 64u, wcount, lane, q0, keys, cnt);
       pend_n = wcount < 64u ? wcount : 64u;
       if ((unsigned)lane < pend_n) {
@@ -517,8 +542,10 @@ __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7c(
     // A(1) and the thresholds were fetched a whole filter ago; everything issued since (the key stores of the pending records,
     // half a filter old; a synchronous flush, rare) is older than any DMA of the next K loop.  The staging area has been read
     // (lgkmcnt): the first half of B(1) may overwrite it.
+    if (tr && threadIdx.x == 0) tr[19] = clock64();
     G7_WAIT_VM(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (tr && threadIdx.x == 0) tr[21] = clock64();
 #pragma unroll
     for (int i = 0; i < 4; ++i) g7_issue_b(src, next_b + G7_ROW_BYTES, i, lds_base + ring.bn + (i * 4 + wave) * 1024);
     if (tr && threadIdx.x == 0) { tr[28] = clock64(); tr[29] = blockIdx.x; tr[31] = wall_clock64(); }

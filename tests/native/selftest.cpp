@@ -579,6 +579,17 @@ int main(int argc, char** argv) {
         loop += (double)(h[b * 32 + 15] - h[b * 32 + 3]); filt += (double)(h[b * 32 + 28] - h[b * 32 + 15]); tot += (double)(h[b * 32 + 28] - h[b * 32]);
         ++n;
       }
+      {
+        double ph[6] = {0}; double surv = 0; size_t m = 0;
+        for (size_t b = 0; b < nblk; ++b) if (h[b * 32 + 16] && h[b * 32 + 21] && h[b * 32 + 28]) {
+          const unsigned long long* t = &h[b * 32];
+          ph[0] += (double)(t[16] - t[15]); ph[1] += (double)(t[17] - t[16]); ph[2] += (double)(t[18] - t[17]);
+          ph[3] += (double)(t[19] - t[18]); ph[4] += (double)(t[21] - t[19]); ph[5] += (double)(t[28] - t[21]); surv += (double)t[20]; ++m;
+        }
+        if (m) printf("   filter phase (continuous-ring scan), avg over %zu tiles: pending atomics + A(1) issue %.0f | filter rows 0-1 %.0f | rows 2-3 %.0f | "
+                      "flush + pending reload %.0f | wait vmcnt(0) %.0f | B(1) issue %.0f ; survivors of wave 0 per tile %.1f\n",
+                      m, ph[0] / m, ph[1] / m, ph[2] / m, ph[3] / m, ph[4] / m, ph[5] / m, surv / m);
+      }
       if (n) printf("   last round, avg over %zu tiles: start+wait %.0f  init %.0f  K loop %.0f (MFMA time %d, x%.3f)  prefetch+filter %.0f  whole tile %.0f (memtime ticks)\n",
                     n, wait / n, init / n, loop / n, d * 32, loop / n / (d * 32.0), filt / n, tot / n);
     }
