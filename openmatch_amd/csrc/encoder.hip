@@ -331,6 +331,15 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
         void* dst = out_hidden ? out_hidden : (void*)ws.x;
         RUN(omk_layernorm(dt, ws.x1, H, dst, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, 0, s, lo));
         final_hidden = (char*)dst;
+        // hidden states AND representations: the pooled rows still come from an f32 normalisation (the reference's autocast
+        // returns fp32 from layer_norm), so encode() and forward() give the same representations
+        if (c->pooling == OM_POOL_FIRST) {
+          RUN(omk_layernorm_f32out(dt, ws.x1, L * H, ws.final32, H, last.ln2_g, last.ln2_b, B, H, c->ln_eps, 0, s, lo));
+          final32_rows = B;
+        } else if (c->pooling != OM_POOL_NONE) {
+          RUN(omk_layernorm_f32out(dt, ws.x1, H, ws.final32, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, 0, s, lo));
+          final32_rows = M;
+        }
       }
     } else
     for (int l = 0; l < c->n_layers; ++l) {
@@ -352,6 +361,13 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
         void* dst = (l == c->n_layers - 1 && out_hidden) ? out_hidden : (void*)ws.x;
         RUN(omk_layernorm(dt, ws.y, H, dst, H, lw.ln2_g, lw.ln2_b, M, H, c->ln_eps, 0, s));
         final_hidden = (char*)dst;
+        if (l == c->n_layers - 1 && half16 && c->pooling == OM_POOL_FIRST) {          // (with out_hidden: pooled rows from f32 all the same)
+          RUN(omk_layernorm_f32out(dt, ws.y, L * H, ws.final32, H, lw.ln2_g, lw.ln2_b, B, H, c->ln_eps, 0, s));
+          final32_rows = B;
+        } else if (l == c->n_layers - 1 && half16 && c->pooling != OM_POOL_NONE) {
+          RUN(omk_layernorm_f32out(dt, ws.y, H, ws.final32, H, lw.ln2_g, lw.ln2_b, M, H, c->ln_eps, 0, s));
+          final32_rows = M;
+        }
       }
     }
     if (c->n_layers == 0) final_hidden = ws.x;
@@ -434,6 +450,13 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
       void* dst = out_hidden ? out_hidden : (void*)ws.y;
       RUN(omk_layernorm(dt, ws.x, H, dst, H, w->final_ln_g, nullptr, M, H, c->ln_eps, 1, s));
       final_hidden = (char*)dst;
+      if (dt != OM_F32 && c->pooling == OM_POOL_FIRST) {
+        RUN(omk_layernorm_f32out(dt, ws.x, L * H, ws.final32, H, w->final_ln_g, nullptr, B, H, c->ln_eps, 1, s));
+        final32_rows = B;
+      } else if (dt != OM_F32 && c->pooling != OM_POOL_NONE) {
+        RUN(omk_layernorm_f32out(dt, ws.x, H, ws.final32, H, w->final_ln_g, nullptr, M, H, c->ln_eps, 1, s));
+        final32_rows = M;
+      }
     }
   }
 

@@ -24,9 +24,24 @@ def active():
     return _active
 
 
+class _SideStreamWork:
+    """What dist.all_reduce(async_op=True) returns, for a stand-in collective: wait() orders the current stream behind it."""
+
+    def __init__(self, stream):
+        self.event = torch.cuda.Event()
+        self.event.record(stream)
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
 class GradSync:
-    def __init__(self, world_size: int, bucket_layers: int = 4):
+    def __init__(self, world_size: int, bucket_layers: int = 4, collective=None):
+        """collective (tests): a callable run on the side stream IN PLACE of the all-reduce, on each bucket -- a visible
+        operation (e.g. `flat.mul_(2)`) shows on ONE device whether a bucket was handed over before its last gradient
+        had been written, which an identity all-reduce on a one-rank group cannot."""
         self.world = int(world_size)
+        self._collective = collective
         self.bucket_layers = max(1, int(bucket_layers))
         self.works = []
         self.reduced = set()          # storage pointers whose gradients are already averaged
@@ -82,7 +97,7 @@ class GradSync:
         later = bool(self.reduced)
         if later:
             self._wait_works()
-        nccl = dist.get_backend() == "nccl"
+        nccl = self._collective is None and dist.get_backend() == "nccl"
         if arena.is_cuda and self._side is None:
             self._side = torch.cuda.Stream(device=arena.device)
         for lo, hi, ev in self.buckets(layer_bounds, arena.numel()):
@@ -95,11 +110,15 @@ class GradSync:
                 else:
                     self._side.wait_stream(torch.cuda.current_stream(arena.device))
                 with torch.cuda.stream(self._side):
-                    w = dist.all_reduce(flat, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, async_op=True)
+                    if self._collective is not None:
+                        self._collective(flat)
+                        w = _SideStreamWork(self._side)
+                    else:
+                        w = dist.all_reduce(flat, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, async_op=True)
                 flat.record_stream(self._side)
             else:
                 w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
-            self.works.append((w, None if (arena.is_cuda and nccl) else flat))
+            self.works.append((w, None if ((arena.is_cuda and nccl) or self._collective is not None) else flat))
         self._keep.append((arena, events))
         self.reduced.add(arena.untyped_storage().data_ptr())
         if later:

@@ -10,6 +10,7 @@ one all-gather over RCCL.  There is no CPU or eager fallback.
 """
 import copy
 import json
+import inspect
 import logging
 import os
 from dataclasses import dataclass
@@ -81,8 +82,7 @@ class DRModel(nn.Module):
         if self._one_pass_ok(query, passage):
             q_reps, p_reps = self._encode_one_pass(query, passage)
         else:
-            _, q_reps = self.encode(query, self.lm_q, self.head_q, want_hidden=False)
-            _, p_reps = self.encode(passage, self.lm_p, self.head_p, want_hidden=False)
+            q_reps, p_reps = self._reps_only(self.encode_query, query), self._reps_only(self.encode_passage, passage)
         if q_reps is None or p_reps is None:
             return DROutput(q_reps=q_reps, p_reps=p_reps)
 
@@ -150,11 +150,20 @@ class DRModel(nn.Module):
             reps = torch.nn.functional.normalize(reps, dim=1)
         return hidden, reps
 
-    def encode_passage(self, psg):
-        return self.encode(psg, self.lm_p, self.head_p)
+    def encode_passage(self, psg, want_hidden=True):
+        return self.encode(psg, self.lm_p, self.head_p, want_hidden=want_hidden)
 
-    def encode_query(self, qry):
-        return self.encode(qry, self.lm_q, self.head_q)
+    def encode_query(self, qry, want_hidden=True):
+        return self.encode(qry, self.lm_q, self.head_q, want_hidden=want_hidden)
+
+    @staticmethod
+    def _reps_only(encode_fn, items):
+        """forward() goes through encode_query / encode_passage as the reference's does (:89-93), so a subclass that
+        overrides them is honoured; the hidden states are skipped where the method takes `want_hidden` (an override
+        written against the reference's signature is called as it is)."""
+        if "want_hidden" in inspect.signature(encode_fn).parameters:
+            return encode_fn(items, want_hidden=False)[1]
+        return encode_fn(items)[1]
 
     # A tied bi-encoder runs the SAME weights over the queries and the passages (reference :89-93: two calls of one
     # module).  In a training step the query batch is a few short rows -- 8 x 32 tokens beside 64 x 128 -- and a second
@@ -276,15 +285,14 @@ class DRModelForInference(DRModel):
     """No-grad variant (reference :261-282): `forward` returns only the representations."""
 
     @torch.no_grad()
-    def encode_passage(self, psg):
-        return super().encode_passage(psg)
+    def encode_passage(self, psg, want_hidden=True):
+        return super().encode_passage(psg, want_hidden=want_hidden)
 
     @torch.no_grad()
-    def encode_query(self, qry):
-        return super().encode_query(qry)
+    def encode_query(self, qry, want_hidden=True):
+        return super().encode_query(qry, want_hidden=want_hidden)
 
     @torch.no_grad()
     def forward(self, query: Dict[str, Tensor] = None, passage: Dict[str, Tensor] = None):
-        _, q_reps = self.encode(query, self.lm_q, self.head_q, want_hidden=False)
-        _, p_reps = self.encode(passage, self.lm_p, self.head_p, want_hidden=False)
+        q_reps, p_reps = self._reps_only(self.encode_query, query), self._reps_only(self.encode_passage, passage)
         return DROutput(q_reps=q_reps, p_reps=p_reps)

@@ -17,7 +17,7 @@ ACT_MUL_RESID = 0x100
 ARCH_BERT, ARCH_T5 = 0, 1
 POOL_NONE, POOL_FIRST, POOL_MEAN = 0, 1, 2
 # om_debug_option switches used from Python (include/openmatch_hip.h: OM_OPT_*)
-OPT_GEMM_MAX_GRID, OPT_GEMM_CONT = 15, 16
+OPT_TRAIN_WGRAD_BATCH, OPT_GEMM_MAX_GRID, OPT_GEMM_CONT = 14, 15, 16
 SEARCH_F32, SEARCH_F16_RESCORE = 0, 1
 ABI_VERSION = 4
 

@@ -278,6 +278,40 @@ def test_packed_rows_encoder_is_bit_identical_to_padded(dtype, pooling):
     assert torch.isnan(small).all()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("pooling", ["first", "mean"])
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_encode_and_forward_return_the_same_representations(dtype, pooling):
+    """16-bit `forward()` pooled from an f32 final LayerNorm while `encode_passage()` (hidden states requested)
+    pooled from the 16-bit hidden states -- two answers for one input.  Both pool from the f32 normalisation now (the
+    reference's autocast returns fp32 from layer_norm either way), and forward() goes through encode_query / encode_passage,
+    so a subclass that overrides them (reference signature, no `want_hidden`) is honoured."""
+    from transformers import BertConfig, BertModel
+    from openmatch.modeling import DRModelForInference
+    torch.manual_seed(13)
+    cfg = BertConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024, vocab_size=600,
+                     max_position_embeddings=64)
+    lm = BertModel(cfg).eval()
+    rng = np.random.default_rng(2)
+    outs = []
+    for n, L in ((24, 48), (3, 20)):                     # the fused path (>= 512 tokens) and the per-site path
+        ids, mask = synth_tokens(rng, n, L, vocab=600, lo_len=4, lo_id=300)
+        items = {"input_ids": torch.from_numpy(ids).to(DEV), "attention_mask": torch.from_numpy(mask).to(DEV)}
+        model = DRModelForInference(lm_q=lm, lm_p=lm, pooling=pooling, model_args=NS(encoder_only=False, dtype=dtype)).to(DEV).eval()
+        hidden, reps = model.encode_passage(items)
+        fwd = model(passage=items).p_reps
+        assert hidden is not None and reps.dtype == torch.float32
+        assert torch.equal(reps, fwd), (n, L, (reps - fwd).abs().max().item())
+        outs.append(reps)
+
+    class Doubling(DRModelForInference):
+        def encode_passage(self, psg):                   # the reference's signature
+            hidden, reps = super().encode_passage(psg)
+            return hidden, 2.0 * reps
+    sub = Doubling(lm_q=lm, lm_p=lm, pooling=pooling, model_args=NS(encoder_only=False, dtype=dtype)).to(DEV).eval()
+    assert torch.equal(sub(passage=items).p_reps, 2.0 * outs[-1])
+
+
 def _encode_with_fused_ln(model, items, on):
     """A/B switch of the encoder (include/openmatch_hip.h: om_debug_option(OM_OPT_ENCODER_FUSED_LN, .))."""
     from openmatch_amd import native as N
@@ -1452,6 +1486,55 @@ def test_overlapped_bucketed_allreduce_leaves_single_rank_gradients_unchanged(go
                 assert torch.allclose(a.grad, b.grad, rtol=1e-4, atol=1e-6), n
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_layers,wbatch", [(2, 4), (4, 4), (1, 2), (4, 0)])
+def test_bucket_handover_in_bf16_waits_for_the_deferred_weight_gradients(bucket_layers, wbatch):
+    """The path the trainer actually runs: bfloat16, widths of 256, M >= 32 -- the backward keeps the layers' activation
+    gradients, launches the weight gradients of a GROUP of layers in one batched kernel on its side lane and records the layers'
+    events behind it.  A bucket handed to the collective before that launch has written its slice would be reduced too early; on
+    one device an all-reduce cannot show it, so the collective is replaced by a visible in-place operation (x 2 on the side
+    stream): every gradient must come out as twice the plain backward's, for bucket sizes below, equal to and above the
+    weight-gradient group (and with the group launch off)."""
+    from transformers import BertConfig, BertModel
+    from openmatch.modeling import DRModel
+    from openmatch_amd import native as N
+    from openmatch_amd.grad_sync import GradSync
+    torch.manual_seed(3)
+    cfg = BertConfig(hidden_size=256, num_hidden_layers=6, num_attention_heads=4, intermediate_size=1024, vocab_size=600,
+                     max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    lm = BertModel(cfg)
+    mk_model = lambda: DRModel(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype="bfloat16"),
+                               data_args=NS(train_n_passages=4),
+                               train_args=NS(negatives_x_device=False, per_device_train_batch_size=4)).to(DEV).train()
+    g = torch.Generator().manual_seed(4)
+    mk = lambda n, L: {"input_ids": torch.randint(300, 600, (n, L), generator=g).to(DEV), "attention_mask": torch.ones(n, L, dtype=torch.long).to(DEV)}
+    q, p = mk(4, 16), mk(16, 48)
+    N.check(N.lib().om_debug_option(N.OPT_TRAIN_WGRAD_BATCH, wbatch))
+    try:
+        model = mk_model()
+        model(query=q, passage=p).loss.backward()
+        plain = {n: t.grad.clone() for n, t in model.named_parameters() if t.grad is not None}
+        model.zero_grad(set_to_none=True)
+        sync = GradSync(1, bucket_layers=bucket_layers, collective=lambda flat: flat.mul_(2.0))
+        out = model(query=q, passage=p)
+        sync.begin()
+        try:
+            out.loss.backward()
+        finally:
+            sync.finish()
+        torch.cuda.synchronize()
+        assert len(sync.reduced) == 1                       # the tied training step takes ONE pass: one arena
+        n_checked = 0
+        for n, t in model.named_parameters():
+            if n in plain:
+                # (a bucket handed over early leaves part of it at 1x; sums formed with atomics -- the embedding scatter -- differ
+                #  between two backward passes in the last bits only)
+                assert torch.allclose(t.grad, 2.0 * plain[n], rtol=1e-3, atol=1e-6), (n, (t.grad - 2.0 * plain[n]).abs().max().item())
+                n_checked += 1
+        assert n_checked > 6 * 12
+    finally:
+        N.check(N.lib().om_debug_option(N.OPT_TRAIN_WGRAD_BATCH, 4))
 
 
 def test_gradient_cache_step_equals_full_batch_step(golden, tmp_path):
