@@ -246,8 +246,8 @@ int om_encoder_forward(const OmEncoderConfig* cfg, const OmEncoderWeights* w,
  * depend on what follows them.  This entry keeps only those rows, back to back ([CLS] of sequence b at row cu[b]), runs
  * the embedding, all contractions and the normalisations over `packed_rows` rows instead of B * L, attention per
  * sequence over its own rows, and pools from them: the representations om_encoder_forward returns, for
- * sum(lengths) / (B * L) of the work.  16-bit BERT-family configurations with the fused path (hidden, ffn multiples of
- * 256, erf-GELU), L <= 256, pooling set (no out_hidden).
+ * sum(lengths) / (B * L) of the work.  16-bit configurations with the fused path (hidden, ffn multiples of 256;
+ * BERT-family: erf-GELU, float16 or bfloat16; T5 encoders: bfloat16, no gated feed-forward), L <= 256, pooling set (no out_hidden).
  * packed_rows: the caller's bound on the token count -- sum over sequences of (1 + index of the last unmasked token) --
  * rounded up to a multiple of 256, >= 512.  The bound is checked on the device: a batch that holds more tokens returns
  * NaN in every representation (no host synchronisation, never a truncated batch).

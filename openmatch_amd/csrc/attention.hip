@@ -255,9 +255,9 @@ __device__ __forceinline__ void attention_fwd16_body(
       const f32x4_t mb = *(const f32x4_t*)(sM + k0);
       f32x4_t pb = {0.f, 0.f, 0.f, 0.f};
       if (BIAS) {              // T5: bias[h][q][k], four consecutive keys per load (L % 4 == 0 is not required: clamp)
-        const float* pr = pos_bias + ((int64_t)h * L + qrow) * L;
+        const float* pr = pos_bias + ((int64_t)h * Lm + qrow) * Lm;      // (the table's pitch: the padded length, also for packed rows)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pb[e] = pr[(k0 + e) < L ? (k0 + e) : (L - 1)] * LOG2E;
+        for (int e = 0; e < 4; ++e) pb[e] = pr[(k0 + e) < Lm ? (k0 + e) : (Lm - 1)] * LOG2E;
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -677,7 +677,8 @@ int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
                   const float* pos_bias, int64_t B, int L, int H, int heads, float scale,
                   float drop_p, uint64_t seed, hipStream_t s, int reverse, const int* kmax, const int* cu) {
   if (B <= 0) return 0;
-  if (cu && !((dtype == OM_BF16 || dtype == OM_F16) && L <= 256 && !pos_bias && drop_p == 0.f)) OM_FAIL("packed rows: 16-bit inference attention, L <= 256");
+  if (cu && !((dtype == OM_F16 || (dtype == OM_BF16 && om_option(OM_OPT_ATTENTION_FAST))) && L <= 256 && drop_p == 0.f))
+    OM_FAIL("packed rows: 16-bit inference attention, L <= 256");
   if (L < 1 || L > 1024) OM_FAIL("sequence length must be in [1,1024]");
   if (L > 256 && drop_p > 0.f) OM_FAIL("training supports sequence lengths up to 256");
   if (H != heads * 64) OM_FAIL("head_dim must be 64");

@@ -208,8 +208,8 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
   if (!workspace || ((uintptr_t)workspace & 255)) OM_FAIL("workspace must be 256-byte aligned");
   const bool packed = packed_rows > 0;
   if (packed) {
-    if (c->arch != OM_ARCH_BERT || c->dtype == OM_F32 || out_hidden || c->pooling == OM_POOL_NONE || L > 256 || c->n_layers < 1)
-      OM_FAIL("packed rows: 16-bit BERT-family inference that returns representations only, L <= 256");
+    if (c->dtype == OM_F32 || out_hidden || c->pooling == OM_POOL_NONE || L > 256 || c->n_layers < 1)
+      OM_FAIL("packed rows: 16-bit inference that returns representations only, L <= 256");
     if (packed_rows % 256 || packed_rows < 512 || packed_rows > B * L + 255) OM_FAIL("packed_rows: a multiple of 256 in [512, B * L + 255]");
   }
   EncWs ws = carve(c, B, L, (char*)workspace, packed_rows);
@@ -378,7 +378,7 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
     RUN(om_t5_lut_device((int)L, c->rel_buckets, c->rel_max_dist, &lut));
     RUN(omk_t5_bias(w->rel_bias, lut, ws.posbias, (int)L, nh, s));
     RUN(omk_embed(dt, input_ids, nullptr, w->word_emb, nullptr, nullptr, nullptr, nullptr, ws.x, M,
-                  (int)L, H, c->vocab, 1, c->ln_eps, 0, s));
+                  (int)L, H, c->vocab, 1, c->ln_eps, 0, s, packed ? ws.row_map : nullptr));
     // RMSNorm fused across the GEMMs (bf16, >= 512 tokens), the pre-norm counterpart of the BERT path
     // above: the GEMM that updates the residual stream x accumulates sum(x^2) per row; the GEMMs that
     // consume rms(x) * g read x itself against the folded weight W * g and scale their rows by
@@ -388,7 +388,8 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
     const bool fuse_t5 = !no_fuse_t5 && c->n_layers > 0 && !Ls[0].ffn1g_w && H % 8 == 0 && omk_gemm_ln_fusable(dt, Mg, H, H) &&
                          omk_gemm_ln_fusable(dt, Mg, F, H) && omk_gemm_ln_fusable(dt, Mg, 3 * H, H) &&
                          omk_gemm_ln_fusable(dt, Mg, H, F);
-    if (om_option(OM_OPT_ENCODER_DEBUG)) fprintf(stderr, "om_encoder_forward (t5): M=%ld fused_norm=%d\n", (long)M, (int)fuse_t5);
+    if (om_option(OM_OPT_ENCODER_DEBUG)) fprintf(stderr, "om_encoder_forward (t5): M=%ld fused_norm=%d packed=%d\n", (long)M, (int)fuse_t5, (int)packed);
+    if (packed && !fuse_t5) OM_FAIL("packed rows need the fused 16-bit path (T5: widths of 256, no gated feed-forward)");
     if (fuse_t5) {
       const float inv_h = 1.0f / (float)H;
       const int nslots = 2 * (H / 256);
@@ -413,7 +414,7 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
         } else {
           RUN(folded(l, false, ws.x, lw.qkv_w, lw.ln1_g, ws.stats2 + (size_t)(l - 1) * Mg * 2, ws.qkv, 3 * H, OM_ACT_NONE, nullptr, 0));
         }
-        RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, ws.posbias, B, (int)L, H, nh, 1.0f, 0.f, 0, s, 0, ws.kmax));
+        RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, ws.posbias, B, (int)L, H, nh, 1.0f, 0.f, 0, s, 0, ws.kmax, cu));
         GemmEpilogue e = {};
         e.resid = ws.x; e.ldr = H; e.stats_out = ws.slots; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
         RUN(omk_gemm(dt, ws.ctx, H, lw.o_w, H, dt, ws.x, H, Mg, H, H, e, s));           // x += o(ctx), sum(x^2)
@@ -440,7 +441,10 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
       }
       GEMM(ws.ff, F, lw.ffn2_w, F, ws.x, H, H, F, nullptr, ws.x, H, OM_ACT_NONE);  // x += wo(ff)
     }
-    if (dt != OM_F32 && !out_hidden && c->pooling == OM_POOL_FIRST) {
+    if (packed && c->pooling == OM_POOL_FIRST) {
+      RUN(omk_layernorm_f32out(dt, ws.x, H, ws.final32, H, w->final_ln_g, nullptr, B, H, c->ln_eps, 1, s, nullptr, ws.cls_rows));
+      final32_rows = B;
+    } else if (dt != OM_F32 && !out_hidden && c->pooling == OM_POOL_FIRST) {
       RUN(omk_layernorm_f32out(dt, ws.x, L * H, ws.final32, H, w->final_ln_g, nullptr, B, H, c->ln_eps, 1, s));
       final32_rows = B;
     } else if (dt != OM_F32 && !out_hidden && c->pooling != OM_POOL_NONE) {

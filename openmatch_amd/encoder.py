@@ -306,15 +306,18 @@ def packed_rows_bound(mask):
 LAST_CALL = {}       # what the most recent hip_encode ran on: {"rows": token rows of the contractions, "packed": bool} (tests, bench)
 
 
-def packed_rows_apply(cfg, B, L, rows, want_hidden, pooling):
+def packed_rows_apply(cfg, B, L, rows, want_hidden, pooling, gated=False):
     """Whether om_encoder_forward_packed takes this call (include/openmatch_hip.h states the same conditions) and pays:
-    a 16-bit BERT-family encoder on its fused path, representations only, and at least one 256-row tile saved.
+    a 16-bit encoder on its fused path (BERT-family erf-GELU; T5 without a gated feed-forward), representations only, and
+    at least one 256-row tile saved.
     OM_ENCODER_PACKED=0 keeps every batch on the padded entry."""
     if os.environ.get("OM_ENCODER_PACKED", "1") == "0" or want_hidden or pooling is None:
         return False
-    if cfg.arch != N.ARCH_BERT or cfg.dtype not in (N.OM_BF16, N.OM_F16) or cfg.act != N.ACT_GELU_ERF:
+    if cfg.dtype not in (N.OM_BF16, N.OM_F16) or cfg.hidden % 256 or cfg.ffn % 256 or cfg.n_layers < 1 or L > 256:
         return False
-    if cfg.hidden % 256 or cfg.ffn % 256 or cfg.n_layers < 1 or L > 256:
+    if cfg.arch == N.ARCH_BERT and cfg.act != N.ACT_GELU_ERF:
+        return False
+    if cfg.arch == N.ARCH_T5 and gated:
         return False
     return rows % 256 == 0 and 512 <= rows <= (B * L) // 256 * 256 - 256
 
@@ -346,7 +349,8 @@ def hip_encode(model, items, pooling, head, normalize, code, want_hidden=True, p
     H = cfg.hidden
     D = cfg.head_out if cfg.head_in > 0 else H
     lib = N.lib()
-    if packed_rows and not packed_rows_apply(cfg, B, L, int(packed_rows), want_hidden, pooling):
+    gated = bool(getattr(getattr(model, "config", None), "is_gated_act", False))
+    if packed_rows and not packed_rows_apply(cfg, B, L, int(packed_rows), want_hidden, pooling, gated):
         packed_rows = None
     LAST_CALL.update(rows=int(packed_rows) if packed_rows else B * L, packed=bool(packed_rows))
     with torch.cuda.device(device):

@@ -18,7 +18,7 @@ from transformers import AutoModel, BatchEncoding, PreTrainedModel, T5EncoderMod
 from transformers.modeling_outputs import ModelOutput
 
 from ..encoder import compute_dtype_code, hip_encode
-from ..feed import is_packed, unpack_token_batch
+from ..feed import is_packed, token_rows_bound, unpack_token_batch
 from ..loss import rr_loss_functions
 from ..ops import encode_with_grad
 from .linear import LinearHead
@@ -61,7 +61,9 @@ class RRModel(nn.Module):
     def encode(self, items):
         if items is None:
             return None, None
+        rows = None
         if is_packed(items):            # a batch straight from RRInferenceCollator (feed.py's compact wire format)
+            rows = token_rows_bound(items)      # host-side lengths: the packed-rows encoder computes the real tokens only
             items = unpack_token_batch(items, next(self.lm.parameters()).device)
         items = BatchEncoding(items)
         if "T5" in type(self.lm).__name__ and not self.model_args.encoder_only:
@@ -71,7 +73,7 @@ class RRModel(nn.Module):
         code = compute_dtype_code(self.model_args)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.lm.parameters()):
             return encode_with_grad(self.lm, self.head, items, self.pooling, False, code, self.training)[1]
-        return hip_encode(self.lm, items, self.pooling, self.head, False, code, want_hidden=False)[1]   # [B,1]
+        return hip_encode(self.lm, items, self.pooling, self.head, False, code, want_hidden=False, packed_rows=rows)[1]   # [B,1]
 
     def _encode_mono_t5(self, items):
         """monoT5 (reference :110-114): logits[:, 0, [neg_token, pos_token]] of a T5ForConditionalGeneration after one

@@ -312,6 +312,36 @@ def test_encode_and_forward_return_the_same_representations(dtype, pooling):
     assert torch.equal(sub(passage=items).p_reps, 2.0 * outs[-1])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("pooling", ["first", "mean"])
+def test_packed_rows_t5_encoder_is_bit_identical_to_padded(pooling):
+    """The packed-rows entry on the fused T5 path (GTR shape in miniature: bfloat16, RMSNorm folded into the GEMMs, the
+    relative-position bias table read at the sequence's own positions): same bits as the padded entry."""
+    from transformers import T5Config, T5EncoderModel
+    from openmatch.modeling import DRModelForInference
+    from openmatch_amd import encoder as enc_mod
+    from openmatch_amd.encoder import compute_dtype_code, hip_encode, packed_rows_bound
+    torch.manual_seed(8)
+    cfg = T5Config(d_model=256, d_ff=1024, num_layers=3, num_heads=4, d_kv=64, vocab_size=600, feed_forward_proj="relu")
+    lm = T5EncoderModel(cfg).eval()
+    model = DRModelForInference(lm_q=lm, lm_p=lm, pooling=pooling, model_args=NS(encoder_only=True, dtype="bfloat16")).to(DEV).eval()
+    code = compute_dtype_code(model.model_args)
+    rng = np.random.default_rng(4)
+    B, L = 40, 128
+    ids, mask = synth_tokens(rng, B, L, vocab=600, lo_len=3, lo_id=300)
+    ids[0, :], mask[0, :] = rng.integers(300, 600, L), 1
+    mask[1, :] = 0; mask[1, ::3] = 1                       # holes
+    mask[2, :] = 0                                        # an empty row
+    m = torch.from_numpy(mask)
+    rows = packed_rows_bound(m)
+    items = {"input_ids": torch.from_numpy(ids).to(DEV), "attention_mask": m.to(DEV)}
+    padded = hip_encode(model.lm_p, items, pooling, None, False, code, want_hidden=False)[1]
+    assert enc_mod.LAST_CALL == {"rows": B * L, "packed": False}
+    packed = hip_encode(model.lm_p, items, pooling, None, False, code, want_hidden=False, packed_rows=rows)[1]
+    assert enc_mod.LAST_CALL == {"rows": rows, "packed": True}
+    assert torch.isfinite(padded).all() and torch.equal(packed, padded)
+
+
 def _encode_with_fused_ln(model, items, on):
     """A/B switch of the encoder (include/openmatch_hip.h: om_debug_option(OM_OPT_ENCODER_FUSED_LN, .))."""
     from openmatch_amd import native as N

@@ -36,6 +36,25 @@ def main():
             model(passage=items)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
         out["fused_norm" if fused == "1" else "norm_kernels"] = {"passages_per_s": round(a.batch / dt, 1), "ms_per_step": round(dt * 1e3, 2)}
+    N.check(N.lib().om_debug_option(0, 1))
+    if not a.gated:      # ragged batches (lengths ~ U{16..128}, as bench.py's) padded vs packed rows (om_encoder_forward_packed)
+        import bench
+        from openmatch_amd import encoder as E
+        rid, rmask = bench.synth_ids(a.batch, 128, torch.device(dev), 7)
+        ragged = {"input_ids": rid, "attention_mask": rmask}
+        rows = E.packed_rows_bound(rmask)
+        code = E.compute_dtype_code(model.model_args)
+        run = lambda pr: E.hip_encode(model.lm_p, ragged, "mean", model.head_p, True, code, want_hidden=False, packed_rows=pr)[1]
+        same = bool(torch.equal(run(rows), run(None)))
+        for name, pr in (("ragged_padded", None), ("ragged_packed", rows)):
+            for _ in range(2):
+                run(pr)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(a.steps):
+                run(pr)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
+            out[name] = {"passages_per_s": round(a.batch / dt, 1), "ms_per_step": round(dt * 1e3, 2)}
+        out["ragged_packed"].update(rows=rows, padded_rows=a.batch * 128, identical_to_padded=same)
     print(json.dumps({"metric": "GTR-base-shaped encode passages/s (T5 encoder, 128 tokens, bf16)", "batch": a.batch,
                       "gated": a.gated, **out}))
 

@@ -32,8 +32,34 @@ def main():
             model.encode(items)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
     gflop = 24 * (24 * L * 1024 * 1024 + 4 * L * L * 1024) / 1e9
+    # ragged pairs (query + passage of ~U{40..162} tokens, padded to 162 by the collator): the padded entry vs the packed-rows
+    # entry the model takes by itself when the batch arrives in the collator's compact form (feed.py: host-side lengths)
+    from openmatch_amd import encoder as E
+    from openmatch_amd.feed import pack_token_batch, token_rows_bound
+    g = torch.Generator().manual_seed(3)
+    lens = torch.randint(40, L + 1, (a.pairs,), generator=g)
+    hmask = (torch.arange(L)[None, :] < lens[:, None]).long()
+    hids = torch.randint(1000, 30000, (a.pairs, L), generator=g) * hmask
+    htt = ((torch.arange(L)[None, :] >= 34) & (hmask > 0)).long()
+    compact = pack_token_batch({"input_ids": hids, "attention_mask": hmask, "token_type_ids": htt})
+    compact = {k: (v.to(dev) if k != "lengths" and k != "_packed_tokens" else v) for k, v in compact.items()}
+    padded_items = {"input_ids": hids.to(dev), "attention_mask": hmask.to(dev), "token_type_ids": htt.to(dev)}
+    ragged = {}
+    with torch.no_grad():
+        same = bool(torch.equal(model.encode(compact), model.encode(padded_items)))
+        took = dict(E.LAST_CALL)
+        for name, items_r in (("ragged_padded", padded_items), ("ragged_packed", compact)):
+            for _ in range(2):
+                model.encode(items_r)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(a.steps):
+                model.encode(items_r)
+            torch.cuda.synchronize(); dtr = (time.perf_counter() - t0) / a.steps
+            ragged[name] = {"pairs_per_s": round(a.pairs / dtr, 1), "ms_per_batch": round(dtr * 1e3, 2)}
+    ragged["ragged_packed"].update(rows=token_rows_bound(compact), padded_rows=a.pairs * L, identical_to_padded=same, padded_call=took)
     print(json.dumps({"metric": "cross-encoder pairs/s (bert-large, 162 tokens, bf16)", "pairs_per_s": round(a.pairs / dt, 1),
-                      "ms_per_batch": round(dt * 1e3, 2), "pairs": a.pairs, "algorithmic_tflops": round(gflop * a.pairs / dt / 1e3, 1)}))
+                      "ms_per_batch": round(dt * 1e3, 2), "pairs": a.pairs, "algorithmic_tflops": round(gflop * a.pairs / dt / 1e3, 1),
+                      **ragged}))
 
 
 if __name__ == "__main__":
