@@ -65,6 +65,15 @@ def unpack_token_batch(batch, device, non_blocking=True):
     return out
 
 
+def model_batch(batch, device, model):
+    """What the encode loops hand to `model`: the compact batch itself when the model widens it on its own (this package's
+    DRModel / RRModel: `accepts_compact_batches` -- they read the host-side lengths first, which is what lets the encoder
+    skip the padding rows, then call unpack_token_batch), the int64 tensors on `device` for any other model."""
+    if is_packed(batch) and getattr(model, "accepts_compact_batches", False):
+        return batch
+    return unpack_token_batch(batch, device)
+
+
 def token_rows_bound(batch):
     """Row bound of om_encoder_forward_packed (include/openmatch_hip.h) for a compact batch whose `lengths` still live on
     the host: the sequences' token counts (a row without any token counts as L, as the encoder treats it), summed and

@@ -77,6 +77,8 @@ class DRModel(nn.Module):
             "normalize": self.normalize,
         }
 
+    accepts_compact_batches = True     # encode() widens feed.py's compact batches itself (and reads their host-side lengths first)
+
     # ------------------------------------------------------------------ forward
     def forward(self, query: Dict[str, Tensor] = None, passage: Dict[str, Tensor] = None):
         if self._one_pass_ok(query, passage):

@@ -34,6 +34,8 @@ class RROutput(ModelOutput):
 
 
 class RRModel(nn.Module):
+    accepts_compact_batches = True     # encode() widens feed.py's compact batches itself (and reads their host-side lengths first)
+
     def __init__(self, lm: PreTrainedModel, head: nn.Module, feature: str = "last_hidden_state",
                  pooling: str = "first", pos_token: str = None, neg_token: str = None, tokenizer=None,
                  model_args=None, data_args=None, train_args=None):

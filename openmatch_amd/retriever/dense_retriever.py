@@ -28,7 +28,7 @@ from tqdm import tqdm
 
 from ..arguments import InferenceArguments as EncodingArguments
 from ..dataset import DRInferenceCollator
-from ..feed import unpack_token_batch
+from ..feed import model_batch
 from ..index import FlatIPIndex, merge_topk, sharded_topk
 from ..modeling import DRModelForInference, DROutput
 from ..utils import merge_retrieval_results_by_score
@@ -80,7 +80,7 @@ class Retriever:
         for batch_ids, batch in tqdm(loader, disable=self.args.local_process_index > 0):
             ids.extend(batch_ids)
             with self._autocast(), torch.no_grad():
-                batch = unpack_token_batch(batch, self.args.device)      # 16-bit ids + lengths on the wire (feed.py)
+                batch = model_batch(batch, self.args.device, self.model)      # 16-bit ids + lengths on the wire (feed.py)
                 out: DROutput = self.model(query=batch) if is_query else self.model(passage=batch)
                 chunks.append(out.q_reps if is_query else out.p_reps)      # stays in HBM
         if chunks:

@@ -15,7 +15,7 @@ from transformers.trainer_pt_utils import IterableDatasetShard
 
 from ..dataset.data_collator import RRInferenceCollator
 from ..utils import load_from_trec, merge_retrieval_results_by_score, save_as_trec
-from ..feed import unpack_token_batch
+from ..feed import model_batch
 
 logger = logging.getLogger(__name__)
 
@@ -87,7 +87,7 @@ class Reranker:
         with torch.no_grad():
             for qids, dids, batch in tqdm(loader, desc="Reranking", disable=a.local_process_index > 0):
                 with cast:
-                    batch = unpack_token_batch(batch, a.device)
+                    batch = model_batch(batch, a.device, self.model)
                     out = self.model.encode(batch)
                 if out.dim() == 2 and out.shape[1] == 2:
                     out = F.log_softmax(out, dim=1)[:, 1]

@@ -22,7 +22,7 @@ import torch
 from torch.utils.data import IterableDataset
 
 from oracle import flatip
-from tests.helpers import NS
+from tests.helpers import NS, synth_tokens
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -90,6 +90,40 @@ def _chain(g, tmp_path, dtype, fp16, lm=None):
     pos = {d: i for i, d in enumerate(doc_ids)}
     I = np.array([[pos[d] for d in run[q]] for q in qry_ids], np.int64)
     return P, Q, I, run, mrr, open(out / "run.trec").read()
+
+
+@pytest.mark.gpu
+def test_retriever_encode_loop_takes_packed_rows_and_matches_padded(monkeypatch, tmp_path):
+    """The product's own path end to end: Retriever.doc_embedding_inference -> DRInferenceCollator (16-bit ids + one host-side
+    length per row) -> model(passage=compact batch) -> om_encoder_forward_packed.  Same pickled embeddings, bit for bit, as
+    with OM_ENCODER_PACKED=0 (the padded entry), and the packed entry really was the one that ran."""
+    from transformers import BertConfig, BertModel
+    from openmatch.modeling import DRModelForInference
+    from openmatch.retriever import Retriever
+    from openmatch_amd import encoder as enc_mod
+    torch.manual_seed(17)
+    cfg = BertConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024, vocab_size=600,
+                     max_position_embeddings=128)
+    lm = BertModel(cfg).eval()
+    rng = np.random.default_rng(5)
+    n, L = 96, 128
+    ids, mask = synth_tokens(rng, n, L, vocab=600, lo_len=4, lo_id=300)
+    names = [str(i) for i in range(n)]
+    outs = {}
+    for packed in ("1", "0"):
+        monkeypatch.setenv("OM_ENCODER_PACKED", packed)
+        model = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype="float16")).to(DEV).eval()
+        out = tmp_path / packed
+        out.mkdir()
+        args = NS(device=DEV, output_dir=str(out), world_size=1, process_index=0, local_process_index=0, fp16=False,
+                  per_device_eval_batch_size=48, dataloader_num_workers=0, dataloader_pin_memory=False)
+        r = Retriever(model, _Rows(torch.from_numpy(ids), torch.from_numpy(mask), names), args)
+        r.doc_embedding_inference()
+        assert enc_mod.LAST_CALL["packed"] == (packed == "1"), enc_mod.LAST_CALL
+        with open(out / "embeddings.corpus.rank.0", "rb") as f:
+            outs[packed] = pickle.load(f)
+    assert outs["1"][1] == outs["0"][1] == names
+    assert np.array_equal(outs["1"][0], outs["0"][0])
 
 
 def _stats(P, Q, Pr, Qr):
