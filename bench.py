@@ -361,10 +361,13 @@ def main():
 
     lib = N.lib()
     if world > 1:      # ranks as RCCL itself counts them (ncclCommCount on a communicator built from this rendezvous)
-        from openmatch_amd.comm import RcclComm
-        comm = RcclComm.from_torch_distributed(device)
-        rccl_ranks = comm.count()
-        comm.close()
+        try:           # (a diagnostic: it must not cost the run its measurements)
+            from openmatch_amd.comm import RcclComm
+            comm = RcclComm.from_torch_distributed(device)
+            rccl_ranks = comm.count()
+            comm.close()
+        except Exception as e:      # noqa: BLE001
+            rccl_ranks = "unavailable: %s" % (str(e)[:120],)
     torch.manual_seed(0)
     lm = BertModel(BertConfig()).eval()
     half = a.precision in ("bf16", "f16")
