@@ -260,7 +260,9 @@ __device__ __forceinline__ void g7_ring_reset(G7Ring& r) {
 // issues A(1) / the first half of B(1) itself.  The eight issues of sub-steps 1-2 are the step's youngest at its barrier
 // either way (vmcnt(8)).  TAIL_EMPTY: a tail that issues nothing (the index scan: its filter needs the three units for staging).
 struct G7NoTail { __device__ __forceinline__ void operator()(int, int, int) const {} };
-template <typename T, bool TAIL = false, typename TailFn = G7NoTail, bool TAIL_EMPTY = false>
+// ZERO_FIRST (the index scan): the tile starts from zero -- the first sixteen MFMAs of its first step take the constant 0 as
+// their C operand and `acc` need not be initialised (one more copy of the step body instead of sixteen initialising MFMAs).
+template <typename T, bool TAIL = false, typename TailFn = G7NoTail, bool TAIL_EMPTY = false, bool ZERO_FIRST = false>
 __device__ __forceinline__ void gemm_mainloop7_cont(const G7SrcU& src, const char* cur_a, const char* cur_b,
                                                     const char* next_a, const char* next_b, int nk, char* smem, G7Ring& ring,
                                                     f32x16_t (&acc)[4][4], unsigned long long* tr = nullptr, TailFn tail = TailFn()) {
@@ -294,9 +296,11 @@ __device__ __forceinline__ void gemm_mainloop7_cont(const G7SrcU& src, const cha
   // UNIT, or -- LASTSTEP with a tail slot -- tail(TSLOT .. TSLOT + 3).  No branch anywhere in a step: the restart-per-tile loop
   // above guards every issue with a wave-uniform flag, and those 16 scalar branches per step cost it ~800 of its ~3200 cycles
   // (the first version of the TAIL loop had 12 and ran 3209 cycles per step against 2404: profiles/r04_probe4_*).
-#define G7C_SUB(AF, BF, AN, BN, UA, UB, SLOT, P, PTR, UNIT, DBASE, TSLOT, LASTSTEP)                      \
+#define G7C_SUB(AF, BF, AN, BN, UA, UB, SLOT, P, PTR, UNIT, DBASE, TSLOT, LASTSTEP, ZERO)                \
   _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                       \
-    MmaOps<T>::mma(BF[q & 3], AF[q >> 2], acc[q >> 2][q & 3]);                                           \
+    if (ZERO) { f32x16_t z_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  \
+                MmaOps<T>::mma(BF[q & 3], AF[q >> 2], z_); acc[q >> 2][q & 3] = z_; }                     \
+    else MmaOps<T>::mma(BF[q & 3], AF[q >> 2], acc[q >> 2][q & 3]);                                      \
     if (q < 8) {                                                                                         \
       if (q < 4) AN[q] = *(const frag_t*)(smem + (UA) + rowa + q * 32 * G7_ROW_BYTES + (SLOT));          \
       else BN[q - 4] = *(const frag_t*)(smem + (UB) + rowb + (q - 4) * 32 * G7_ROW_BYTES + (SLOT));      \
@@ -306,25 +310,26 @@ __device__ __forceinline__ void gemm_mainloop7_cont(const G7SrcU& src, const cha
     }                                                                                                    \
     G7_FENCE();                                                                                          \
   }
-#define G7C_STEP(LASTSTEP)                                                                               \
+#define G7C_STEP(LASTSTEP, ZERO)                                                                         \
   do {                                                                                                   \
     if (tr && tid == 0 && t < 12) tr[3 + t] = clock64();                                                 \
-    G7C_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[1], b, kbp, u_bn, 4, -1, LASTSTEP)   /* second half of B(t+1) */ \
-    G7C_SUB(a1, b1, a0, b0, u_ac, u_bc, slot[2], a, ka, u_sp, 0, 0, LASTSTEP)     /* A(t+2) */            \
-    G7C_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[3], a, ka, u_sp, 4, 4, LASTSTEP)                            \
+    G7C_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[1], b, kbp, u_bn, 4, -1, LASTSTEP, ZERO)   /* second half of B(t+1) */ \
+    G7C_SUB(a1, b1, a0, b0, u_ac, u_bc, slot[2], a, ka, u_sp, 0, 0, LASTSTEP, false)     /* A(t+2) */            \
+    G7C_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[3], a, ka, u_sp, 4, 4, LASTSTEP, false)                            \
     /* vmcnt(8) lgkmcnt(0): everything but the last eight issues has landed (an EMPTY tail issues nothing behind sub-steps 1-2: vmcnt(0)) */ \
     if ((LASTSTEP) && TAIL_EMPTY) __builtin_amdgcn_s_waitcnt(0x0070); else __builtin_amdgcn_s_waitcnt(0x0078); \
     __builtin_amdgcn_s_barrier();                                                                        \
     G7_FENCE();                                                                                          \
-    G7C_SUB(a1, b1, a0, b0, u_an, u_bn, slot[0], b, kb, u_ac, 0, 8, LASTSTEP)     /* first half of B(t+2) into the unit A(t) leaves */ \
+    G7C_SUB(a1, b1, a0, b0, u_an, u_bn, slot[0], b, kb, u_ac, 0, 8, LASTSTEP, false)     /* first half of B(t+2) into the unit A(t) leaves */ \
     { const int o_ac = u_ac, o_bc = u_bc; u_ac = u_an; u_bc = u_bn; u_an = u_sp; u_bn = o_ac; u_sp = o_bc; } \
     kbp = kb;                                                                                            \
     if (t + 3 == nk) { ka = next_a; kb = next_b; } else { ka += G7_ROW_BYTES; kb += G7_ROW_BYTES; }      \
   } while (0)
   int t = 0;
   const int nplain = TAIL ? nk - 1 : nk;
-  for (; t < nplain; ++t) G7C_STEP(false);
-  if (TAIL) G7C_STEP(true);                          // (one more copy of the step body: ~7 KiB of code, no branch inside either)
+  if (ZERO_FIRST) { G7C_STEP(false, true); ++t; }
+  for (; t < nplain; ++t) G7C_STEP(false, false);
+  if (TAIL) G7C_STEP(true, false);                   // (one more copy of the step body: ~7 KiB of code, no branch inside either)
 #undef G7C_STEP
 #undef G7C_SUB
 #undef G7_FENCE

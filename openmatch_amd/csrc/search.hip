@@ -313,7 +313,12 @@ __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7(
       const frag_t zf = __builtin_bit_cast(frag_t, z4);
       const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < 16; ++q) { acc[q >> 2][q & 3] = zero; MmaOps<T>::mma(zf, zf, acc[q >> 2][q & 3]); }   // zero by the matrix core
+      for (int q = 0; q < 16; ++q) {       // zero by the matrix core, one MFMA per accumulator tile: with ONE shared zero fragment the
+        frag_t zq = zf;                    // compiler issues one product and copies it into the other fifteen tiles with 240
+        asm volatile("" : "+v"(zq));       // v_accvgpr_mov (~1 k of the 1.5 k cycles this block took per pair)
+        acc[q >> 2][q & 3] = zero;
+        MmaOps<T>::mma(zq, zq, acc[q >> 2][q & 3]);
+      }
     }
     gemm_mainloop7_run<T>(src, nk, smem, acc, tr, false);
     if (tr && threadIdx.x == 0) tr[15] = clock64();
@@ -491,22 +496,17 @@ __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7c(
     }
     if (tr && threadIdx.x == 0) { tr[0] = tr[1] = clock64(); tr[30] = wall_clock64(); }
     float th[4];
-    f32x16_t acc[4][4];
+    f32x16_t acc[4][4];          // (starts from zero inside the K loop: ZERO_FIRST -- no initialising pass)
     {
       int lane_i = lane0;
       asm volatile("" : "+v"(lane_i));
       const char* const tab = smem + ring.sp + (7 * 4 + wave) * 1024;      // this pair's thresholds (fetched under the previous filter)
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) th[mi] = *(const float*)(tab + (mi * 32 + (lane_i & 31)) * 4);
-      const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
-      const frag_t zf = __builtin_bit_cast(frag_t, z4);
-      const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int q = 0; q < 16; ++q) { acc[q >> 2][q & 3] = zero; MmaOps<T>::mma(zf, zf, acc[q >> 2][q & 3]); }   // zero by the matrix core
     }
     const char* const next_a = (const char*)(queries + q1 * d);      // (no next pair: this one again -- a harmless prefetch)
     const char* const next_b = (const char*)(rows + r1 * d);
-    gemm_mainloop7_cont<T, true, G7NoTail, true>(src, cur_a, cur_b, next_a, next_b, nk, smem, ring, acc, tr);
+    gemm_mainloop7_cont<T, true, G7NoTail, true, true>(src, cur_a, cur_b, next_a, next_b, nk, smem, ring, acc, tr);
     if (tr && threadIdx.x == 0) tr[15] = clock64();
     int lane = lane0;
     asm volatile("" : "+v"(lane));
