@@ -200,6 +200,7 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7(
         split(u, uh, ul); split(v, vh, vl);
         uint4 w = make_uint4(uh | (ul << 16), uh | (vh << 16), vl | (vh << 16), 0u);     // k: u_hi u_lo u_hi v_hi v_lo v_hi 0 0
         if (half) w = make_uint4(0u, 0u, 0u, 0u);
+        asm volatile("" : "+v"(w.x), "+v"(w.y), "+v"(w.z));       // opaque per row block: 16 MFMAs, not 4 + 192 accumulator moves (as kernels 7c / 7r)
         fa[mi] = __builtin_bit_cast(frag_t, w);
       }
 #pragma unroll
