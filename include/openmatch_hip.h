@@ -109,7 +109,7 @@ void om_debug_gemm_gen(int gen);
                                      * launch per group of layers computes their weight gradients (env OM_TRAIN_WGRAD_BATCH) */
 #define OM_OPT_GEMM_MAX_GRID 15    /* 0 (default): the persistent 16-bit GEMM takes every CU; > 0: at most this many workgroups (one per CU) --
                                     * two half-batch encoder forwards on two streams share the chip with 128 each */
-#define OM_OPT_GEMM_CONT 16        /* bit 0 (default 15 = all): the persistent 16-bit GEMM variants without a residual, bit 1: the one-plane residual
+#define OM_OPT_GEMM_CONT 16        /* (bit 4, A/B, off: plain whole-tile bf16 shapes prefer the continuous kernels even when they leave CUs idle) bit 0 (default 15 = all): the persistent 16-bit GEMM variants without a residual, bit 1: the one-plane residual
                                     * variants, bit 2: the f16 index scan of wide query batches, run on the continuous ring; bit 3: the GEMM variants of bits 0-1 on 16 x 16 x 32 MFMAs (kernels 7c16 / 7r16) (the K loop of
                                     * a tile prefetches the next tile's first two steps; epilogue and accumulator initialisation of the next
                                     * tile interleaved); 0: the ring restarts per tile as in round 3 (A/B measurements) */

@@ -160,6 +160,12 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
     gen = c4 <= c2 && c4 <= c1 ? 6 : (c2 <= c1 ? 2 : 1);     // 6 falls back to 2 where it has no variant
     if (gemm_variant() == 2) gen = 2;
     if (gemm_variant() == 6) gen = N >= 256 ? 6 : 2;
+    // A/B (OM_OPT_GEMM_CONT bit 4): plain 16-bit shapes of whole 256 x 256 tiles go to the continuous-ring kernels even when
+    // those leave CUs idle (training: N = 768 at 9 216 token rows is 108 tiles -- the cost model above prefers 216 tiles of
+    // 256 x 128 on generation 2; the idle CUs are not idle in a training step, the weight-gradient lane runs beside)
+    if ((om_option(OM_OPT_GEMM_CONT) & 16) && in_dtype == OM_BF16 && out_dtype == OM_BF16 && !ep.pre_act && ep.drop_p == 0.f &&
+        M % 256 == 0 && N % 256 == 0 && K * 2 >= 3 * 128)
+      gen = 6;
   }
   const bool ln_fused = ep.ln_stats || ep.rln_stats || ep.stats_out;
   if (in_dtype == OM_F16 && out_dtype == OM_F16) {
