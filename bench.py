@@ -330,7 +330,24 @@ def packed_leg(model, batches, a, L):
         torch.cuda.synchronize()
         res.setdefault(packed, []).append((time.perf_counter() - t0) / a.steps)
     dt_p, dt_d = min(res[True]), min(res[False])
+    # the packed leg's own roofline: EXECUTED flops of its GEMM launches (2 M N K with M = the packed rows) over their hipEvent time
+    from openmatch_amd import native as N
+    lib = N.lib()
+    lib.om_kernel_timing_read(0, None, None, None)
+    lib.om_kernel_timing_enable(1)
+    for i in range(a.steps):
+        run(i, True)
+    torch.cuda.synchronize()
+    ms, n_launch, flops = C.c_double(), C.c_int64(), C.c_double()
+    N.check(lib.om_kernel_timing_read(0, C.byref(ms), C.byref(n_launch), C.byref(flops)))
+    lib.om_kernel_timing_enable(0)
+    tf = flops.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+    roof = {"kernel": "the same GEMM kernels over the packed rows", "bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "launches": int(n_launch.value),
+            "flops_per_launch": flops.value / max(n_launch.value, 1), "avg_launch_us": round(ms.value * 1e3 / max(n_launch.value, 1), 2),
+            "measured": "hipEvents around every GEMM launch of a.steps packed steps; executed flops (M = packed rows), not the padded shape's"}
     return {"metric": "passages/s encode over packed rows (om_encoder_forward_packed; same batches, same representations)",
+            "roofline": roof,
             "value": round(a.batch / dt_p, 1), "unit": "passages/s", "ms_per_step": round(dt_p * 1e3, 3),
             "padded_same_loop_ms_per_step": round(dt_d * 1e3, 3), "speedup_vs_padded": round(dt_d / dt_p, 3),
             "rows_per_step": bounds, "tokens_per_step": tokens, "padded_rows_per_step": a.batch * L,
