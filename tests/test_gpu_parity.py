@@ -526,6 +526,32 @@ def test_search_properties_at_scale():
         assert (out[precision][0] - Dr.cpu()).abs().max() <= 1e-4
 
 
+def test_sharded_topk_over_a_one_rank_rccl_group_equals_the_local_search():
+    """The candidate exchange of the sharded search (index.sharded_topk: ONE all_to_all_single of score bits | shard-local
+    ids | the sender's offset, round 4) on GPU tensors through RCCL -- a one-rank group is all a one-GPU box offers; the
+    arithmetic across ranks is covered over gloo at world size 2 and 8 (tests/test_distributed_cpu.py).  An id offset
+    beyond 2^31 checks the 64-bit offset's trip through the int32 payload."""
+    import torch.distributed as dist
+    from openmatch_amd.index import FlatIPIndex, sharded_topk
+    g = torch.Generator(device=DEV).manual_seed(3)
+    n, d, nq, k = 30000, 768, 77, 100
+    P = torch.randn(n, d, device=DEV, generator=g)
+    Q = torch.randn(nq, d, device=DEV, generator=g)
+    idx = FlatIPIndex(d, device=DEV, precision="f16_rescore")
+    idx.add(P)
+    offset = (1 << 33) + 12345
+    D0, I0 = idx.search_device(Q, k, id_offset=offset)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29547", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        D1, I1, blk = sharded_topk(idx, Q, k, offset)
+    finally:
+        dist.destroy_process_group()
+    assert blk == nq
+    assert torch.equal(D1[:nq], D0) and torch.equal(I1[:nq], I0)
+    assert int(I1.min()) >= offset
+
+
 def test_topk_merge_equals_single_index():
     """Per-shard search + om_topk_merge == one index over all rows (K14 / faiss shard merge)."""
     from openmatch_amd.index import FlatIPIndex, merge_topk
