@@ -80,13 +80,18 @@ def shard_range(total, world, rank):
 
 
 def barrier_sync(world):
-    if world > 1:
+    if world > 1 or FORCE_DIST:
         dist.barrier()
     torch.cuda.synchronize()
 
 
+# OM_BENCH_FORCE_DIST=1 with one process: the N > 1 code path (process group, query all-gather, candidate all-to-all, max over
+# ranks, RCCL rank count) on a one-rank RCCL group -- all a one-GPU box can execute of it; the extras of the N = 1 line are skipped
+FORCE_DIST = os.environ.get("OM_BENCH_FORCE_DIST", "0") == "1"
+
+
 def max_over_ranks(x, world, device):
-    if world == 1:
+    if world == 1 and not FORCE_DIST:
         return x
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -361,8 +366,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    dist_on = world > 1 or FORCE_DIST
+    json_out = sys.stdout
+    if dist_on:
+        # RCCL prints a version banner to the C-level stdout (buffered: it lands BEHIND the JSON line at exit).  The one line on
+        # stdout must be the JSON: file descriptor 1 is pointed at stderr for everything else, the line goes to the saved one.
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        json_out = os.fdopen(saved_fd, "w")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29553"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -377,7 +392,7 @@ def main():
     from types import SimpleNamespace as NS
 
     lib = N.lib()
-    if world > 1:      # ranks as RCCL itself counts them (ncclCommCount on a communicator built from this rendezvous)
+    if dist_on:      # ranks as RCCL itself counts them (ncclCommCount on a communicator built from this rendezvous)
         try:           # (a diagnostic: it must not cost the run its measurements)
             from openmatch_amd.comm import RcclComm
             comm = RcclComm.from_torch_distributed(device)
@@ -472,7 +487,7 @@ def main():
         q_local = torch.randn(nq_local, 768, device=device, generator=g) * 0.05 + shared * 0.05
 
         def search_once():
-            if world > 1:
+            if dist_on:
                 nmax = (a.queries + world - 1) // world
                 pad = torch.zeros(nmax, 768, device=device)
                 pad[:nq_local] = q_local
@@ -482,7 +497,7 @@ def main():
                 queries = torch.cat([allq[r * nmax:r * nmax + sizes[r]] for r in range(world)])
             else:
                 queries = q_local
-            if world > 1:      # candidates exchanged by query range (all-to-all), merged per slice: openmatch_amd/index.py
+            if dist_on:      # candidates exchanged by query range (all-to-all), merged per slice: openmatch_amd/index.py
                 D, I, _ = sharded_topk(index, queries, a.topk, offset)
             else:
                 D, I = index.search_device(queries, a.topk, id_offset=offset)
@@ -517,7 +532,7 @@ def main():
                             "ms_per_search": round(sms.value / reps, 2), "launches_per_search": int(sl.value // reps),
                             "index_stream_GBps_if_read_once": round(scan_bytes / max(sms.value / reps, 1e-9) / 1e6, 1)},
         }
-        if world == 1 and not a.no_extra:
+        if not dist_on and not a.no_extra:
             # small batches: the scan is one pass over the f16 index -- latency and the implied HBM stream rate
             small = {}
             for nq_s in (1, 64, 128):
@@ -530,17 +545,17 @@ def main():
                 small["q%d" % nq_s] = {"ms": round(dt_s * 1e3, 2), "index_stream_TBps": round(scan_bytes / dt_s / 1e12, 2),
                                        "frac_of_hbm_peak": round(scan_bytes / dt_s / 1e9 / PEAK_HBM_GBS, 3)}
             search["small_batch_latency"] = small
-        if rank == 0 and world == 1 and not a.no_parity and half:
+        if rank == 0 and not dist_on and not a.no_parity and half:
             parity = parity_leg(model, lm, batches, device, index, q_local, a.topk, headline=a.precision)
         del index
         torch.cuda.empty_cache()
-    if parity is None and rank == 0 and world == 1 and not a.no_parity and half:
+    if parity is None and rank == 0 and not dist_on and not a.no_parity and half:
         parity = parity_leg(model, lm, batches, device, headline=a.precision)
 
     # ---------------- exact-f32 mode and the training step (sub-objects; N = 1 only) ----------
     f32_mode, train, f16_mode, packed_mode = None, None, None, None
     other16 = "bf16" if a.precision == "f16" else "f16"
-    if rank == 0 and world == 1 and not a.no_extra and half:
+    if rank == 0 and not dist_on and not a.no_extra and half:
         # the OTHER 16-bit format on the SAME timed batches (same kernels and MFMA rate): bfloat16 carries its pre-LayerNorm
         # residual stream in two planes to stay inside the reference's 16-bit envelope, float16 needs one
         m16 = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first",
@@ -578,7 +593,7 @@ def main():
         train = train_leg(device)
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and not dist_on and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.no_search, batches)
 
     if rank == 0:
@@ -598,8 +613,8 @@ def main():
                        "weights": "random-init BertConfig() seed 0", "parallelism": f"shard{world}"},
             "roofline": roofline, "search": search, "parity": parity, other16: f16_mode, "packed": packed_mode, "f32": f32_mode, "train": train, "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        print(json.dumps(line), file=json_out, flush=True)
+    if dist_on:
         dist.destroy_process_group()
 
 
