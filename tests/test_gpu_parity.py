@@ -1593,6 +1593,38 @@ def test_bucket_handover_in_bf16_waits_for_the_deferred_weight_gradients(bucket_
         N.check(N.lib().om_debug_option(N.OPT_TRAIN_WGRAD_BATCH, 4))
 
 
+def test_cross_device_negatives_over_a_one_rank_rccl_group_equal_the_local_step(golden):
+    """DRModel with negatives_x_device on GPU tensors through RCCL (dist_gather_tensor: one all_gather_into_tensor, the local
+    slot keeping autograd; reference modeling/dense_retrieval_model.py:247-258, loss.py:33-38).  With one rank the gathered
+    batch IS the local one: loss, scores and every gradient must equal the plain step's.  (Two ranks: gloo, tests/test_distributed_cpu.py.)"""
+    import torch.distributed as dist
+    from openmatch.modeling import DRModel, LinearHead
+    g = golden("train_bert_tiny")
+    q, p = _train_batch(g)
+    plain = _train_model(g)
+    out0 = plain(query=q, passage=p)
+    out0.loss.backward()
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29549", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        cfg, lm = model_from_golden(g, "bert", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+        head = LinearHead(128, 128)
+        head.linear.weight.data.copy_(torch.from_numpy(g["head_w"]))
+        model = DRModel(lm_q=lm, lm_p=lm, pooling="mean", head_q=head, head_p=head, normalize=True,
+                        model_args=NS(encoder_only=False, dtype="float32"), data_args=NS(train_n_passages=int(g["n_psg"])),
+                        train_args=NS(negatives_x_device=True, per_device_train_batch_size=4)).to(DEV).train()
+        out1 = model(query=q, passage=p)
+        out1.loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert abs(out1.loss.item() - out0.loss.item()) < 1e-6
+    assert torch.allclose(out1.scores, out0.scores, atol=1e-6)
+    for (n, a), (_, b) in zip(model.named_parameters(), plain.named_parameters()):
+        if b.grad is not None:
+            assert a.grad is not None and torch.allclose(a.grad, b.grad, rtol=1e-4, atol=1e-6), n
+
+
 def test_gradient_cache_step_equals_full_batch_step(golden, tmp_path):
     """GCDenseTrainer (chunked, re-encoded) must give the SAME gradients as one full-batch step."""
     from openmatch.trainer import DRTrainer, GCDenseTrainer
