@@ -514,3 +514,39 @@ def test_token_rows_bound_counts_rows_up_to_last_token():
     assert packed_rows_bound(holes) == want                    # last unmasked token of row 0 is still 127
     assert token_rows_bound({"input_ids": ids, "attention_mask": mask}) is None
     assert packed_rows_bound(mask[:1, :64]) is None            # fewer than 512 rows
+
+
+def test_model_batch_and_packed_rows_apply_conditions():
+    """feed.model_batch hands the compact batch only to models that widen it themselves; encoder.packed_rows_apply states
+    the conditions of om_encoder_forward_packed (include/openmatch_hip.h) on the host."""
+    import torch
+    from types import SimpleNamespace as NS
+    from openmatch_amd import native as N
+    from openmatch_amd.encoder import packed_rows_apply
+    from openmatch_amd.feed import is_packed, model_batch, pack_token_batch
+    from openmatch_amd.modeling import DRModel, RRModel
+    L = 16
+    mask = (torch.arange(L)[None, :] < torch.tensor([16, 3, 9])[:, None]).long()
+    compact = pack_token_batch({"input_ids": torch.randint(1, 100, (3, L)) * mask, "attention_mask": mask})
+    assert is_packed(compact)
+    assert DRModel.accepts_compact_batches and RRModel.accepts_compact_batches
+    assert model_batch(compact, "cpu", NS(accepts_compact_batches=True)) is compact
+    wide = model_batch(compact, "cpu", object())            # any other model: the reference's three int64 tensors
+    assert set(wide) == {"input_ids", "attention_mask"} and wide["input_ids"].dtype == torch.int64
+    assert torch.equal(wide["attention_mask"], mask)
+
+    cfg = NS(arch=N.ARCH_BERT, dtype=N.OM_F16, act=N.ACT_GELU_ERF, hidden=768, ffn=3072, n_layers=12)
+    B, Lp = 64, 128
+    ok = lambda **kw: packed_rows_apply(NS(**{**vars(cfg), **kw.pop("cfg", {})}), kw.pop("B", B), kw.pop("L", Lp), kw.pop("rows", 4096),
+                                        kw.pop("want_hidden", False), kw.pop("pooling", "first"), kw.pop("gated", False))
+    assert ok()
+    assert not ok(want_hidden=True) and not ok(pooling=None)
+    assert not ok(cfg={"dtype": N.OM_F32}) and not ok(cfg={"hidden": 128}) and not ok(cfg={"act": N.ACT_RELU})
+    assert ok(cfg={"arch": N.ARCH_T5, "act": N.ACT_RELU, "dtype": N.OM_BF16}) and not ok(cfg={"arch": N.ARCH_T5, "act": N.ACT_RELU}, gated=True)
+    assert not ok(rows=256) and not ok(rows=4100) and not ok(rows=B * Lp) and ok(rows=B * Lp - 256)
+    assert not ok(L=512, rows=4096)
+    os.environ["OM_ENCODER_PACKED"] = "0"
+    try:
+        assert not ok()
+    finally:
+        del os.environ["OM_ENCODER_PACKED"]
