@@ -342,6 +342,35 @@ def test_packed_rows_t5_encoder_is_bit_identical_to_padded(pooling):
     assert torch.isfinite(padded).all() and torch.equal(packed, padded)
 
 
+@pytest.mark.gpu
+def test_cross_encoder_takes_packed_rows_for_compact_pair_batches():
+    """RRModel.encode on the collator's compact batch (16-bit ids, one host-side length per pair, token types 0 / 1): the
+    packed-rows entry with the bf16 two-plane residual stream and a 1-wide head -- the same scores, bit for bit, as the padded
+    tensors give."""
+    from transformers import BertConfig, BertModel
+    from openmatch.modeling import LinearHead, RRModel
+    from openmatch_amd import encoder as enc_mod
+    from openmatch_amd.feed import pack_token_batch
+    torch.manual_seed(23)
+    cfg = BertConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024, vocab_size=600,
+                     max_position_embeddings=192)
+    model = RRModel(lm=BertModel(cfg).eval(), head=LinearHead(256, 1), pooling="first",
+                    model_args=NS(encoder_only=False, dtype="bfloat16")).to(DEV).eval()
+    rng = np.random.default_rng(6)
+    n, L = 24, 162
+    ids, mask = synth_tokens(rng, n, L, vocab=600, lo_len=20, lo_id=300)
+    tt = np.zeros_like(ids)
+    for i in range(n):
+        ln = int(mask[i].sum()); tt[i, ln // 3:ln] = 1
+    host = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask), "token_type_ids": torch.from_numpy(tt)}
+    with torch.no_grad():
+        padded = model.encode({k: v.to(DEV) for k, v in host.items()})
+        assert enc_mod.LAST_CALL["packed"] is False
+        packed = model.encode(pack_token_batch(dict(host)))
+        assert enc_mod.LAST_CALL["packed"] is True and enc_mod.LAST_CALL["rows"] < n * L
+    assert padded.shape == (n, 1) and torch.isfinite(padded).all() and torch.equal(packed, padded)
+
+
 def _encode_with_fused_ln(model, items, on):
     """A/B switch of the encoder (include/openmatch_hip.h: om_debug_option(OM_OPT_ENCODER_FUSED_LN, .))."""
     from openmatch_amd import native as N
