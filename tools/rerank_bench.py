@@ -11,6 +11,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=512)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16"], help="f16 = the reference's --fp16 (torch.cuda.amp float16)")
     a = ap.parse_args()
     from transformers import BertConfig, BertModel
     from openmatch.modeling import RRModel, LinearHead
@@ -19,7 +20,7 @@ def main():
     cfg = BertConfig(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
     lm = BertModel(cfg).eval()
     model = RRModel(lm=lm, head=LinearHead(1024, 1), pooling="first",
-                    model_args=NS(encoder_only=False, dtype="bfloat16")).to(dev).eval()
+                    model_args=NS(encoder_only=False, dtype={"bf16": "bfloat16", "f16": "float16"}[a.precision])).to(dev).eval()
     L = 162
     ids = torch.randint(1000, 30000, (a.pairs, L), device=dev)
     items = {"input_ids": ids, "attention_mask": torch.ones_like(ids),
@@ -57,7 +58,7 @@ def main():
             torch.cuda.synchronize(); dtr = (time.perf_counter() - t0) / a.steps
             ragged[name] = {"pairs_per_s": round(a.pairs / dtr, 1), "ms_per_batch": round(dtr * 1e3, 2)}
     ragged["ragged_packed"].update(rows=token_rows_bound(compact), padded_rows=a.pairs * L, identical_to_padded=same, padded_call=took)
-    print(json.dumps({"metric": "cross-encoder pairs/s (bert-large, 162 tokens, bf16)", "pairs_per_s": round(a.pairs / dt, 1),
+    print(json.dumps({"metric": "cross-encoder pairs/s (bert-large, 162 tokens, %s)" % a.precision, "pairs_per_s": round(a.pairs / dt, 1),
                       "ms_per_batch": round(dt * 1e3, 2), "pairs": a.pairs, "algorithmic_tflops": round(gflop * a.pairs / dt / 1e3, 1),
                       **ragged}))
 
