@@ -77,13 +77,33 @@ __device__ __forceinline__ void g7_point(G7Src& src, const T* __restrict__ A, in
 // s_waitcnt bookkeeping: every wait for them in this generation is written by hand.  M0 carries the LDS address
 // (nothing else in these kernels uses M0); `s_nop 4` covers both the M0 write -> DMA wait state and a base that the
 // compiler produced with v_readfirstlane (VALU-written SGPR -> VMEM address: 5 wait states).
+// G7_DMA_FORM: 2 (default since late round 4) = the base is copied to a scratch SGPR pair by s_mov_b64 -- a SALU-written address
+// needs no wait states before the VMEM instruction whatever produced `base`, and the copy IS the one wait state M0 needs: no
+// s_nop.  0 = `s_nop 4` as rounds 2-4 had it: five wait states of four cycles each on the only wave of the SIMD, sixteen times per K
+// step -- 260 of a step's 2 620 cycles (tools/gemm7h_probe.hip, profiles/r04_probe17_*: K loop 2 622 -> 2 425 cycles per step, 566 ->
+// 551 us at K = 3072).  1 = `s_nop 0` (probe only: unsafe if the compiler hands over a v_readfirstlane result; 2 362 cycles).
+#ifndef G7_DMA_FORM
+#define G7_DMA_FORM 2
+#endif
 __device__ __forceinline__ void g7_dma(const char* base, uint32_t lane_off, uint32_t lds) {
+#if G7_DMA_FORM == 2
+  const char* t_;
+  asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 %0, %3\n\tglobal_load_lds_dwordx4 %2, %0" : "=&s"(t_) : "s"(lds), "v"(lane_off), "s"(base) : "memory");
+#elif G7_DMA_FORM == 1
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(lane_off), "s"(base) : "memory");
+#else
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(lane_off), "s"(base) : "memory");
+#endif
 }
 // the same with the non-temporal cache policy: for streams that ONE CU reads ONCE (the index pass of a small query batch);
 // MI355X_MICROARCH.md "nt-weights": issued -> landed -18 %, chip 6.5-6.8 instead of 6.4 TB/s
 __device__ __forceinline__ void g7_dma_nt(const char* base, uint32_t lane_off, uint32_t lds) {
+#if G7_DMA_FORM == 2
+  const char* t_;
+  asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 %0, %3\n\tglobal_load_lds_dwordx4 %2, %0 nt" : "=&s"(t_) : "s"(lds), "v"(lane_off), "s"(base) : "memory");
+#else
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(lds), "v"(lane_off), "s"(base) : "memory");
+#endif
 }
 // the same with a full 64-bit address per lane (unrelated sources in one instruction)
 __device__ __forceinline__ void g7_dma_v(const void* lane_ptr, uint32_t lds) {

@@ -54,20 +54,25 @@ __device__ __forceinline__ void gemm_mainloop7_cont16h(const G7SrcU& src, const 
   for (int i = 0; i < 8; ++i) b0[i] = *(const frag_t*)(smem + u_bc + rowb + i * 16 * G7_ROW_BYTES + slot[0]);
 #pragma unroll
   for (int i = 0; i < TIN; ++i) a0[i] = *(const frag_t*)(smem + u_ac + rowa + i * 16 * G7_ROW_BYTES + slot[0]);
-#define G7_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // G7H_ABL (timing probes; results are garbage): bit 0 no DMA issues, bit 1 no fragment reads (the first step's are reused),
+  // bit 2 no barrier, bit 3 no vmcnt wait, bit 4 no scheduling fences, bit 5 every second MFMA dropped
+#ifndef G7H_ABL
+#define G7H_ABL 0
+#endif
+#define G7_FENCE() do { if (!(G7H_ABL & 16)) __builtin_amdgcn_sched_barrier(0); } while (0)
   // TIN * 8 MFMAs from (AF, BF); sixteen of them each cover one fragment read into (BN, then AN) from (UA, UB) chunk SLOT (every
   // fourth MFMA of 64, every second of 32); NISS of them each cover one DMA issue of operand P (PTR, instruction index) into UNIT
   // -- or, in the last step of a TAIL loop, tail(TBASE + index)
 #define G7C_SUB16(AF, BF, AN, BN, UA, UB, SLOT, P, PTR, UNIT, TBASE, LASTSTEP, NISS)                     \
   _Pragma("unroll") for (int q = 0; q < TIN * 8; ++q) {                                                  \
     constexpr int RSTR = TIN / 2, ISTR = TIN * 8 / (NISS);      /* MFMAs per fragment read / per DMA issue */ \
-    Mma16c<T>::mma(BF[q & 7], AF[q >> 3], acc[q >> 3][q & 7]);                                           \
-    if (q % RSTR == 0) {                                                                                 \
+    if (!(G7H_ABL & 32) || !(q & 1)) Mma16c<T>::mma(BF[q & 7], AF[q >> 3], acc[q >> 3][q & 7]);          \
+    if (!(G7H_ABL & 2) && q % RSTR == 0) {                                                               \
       const int r_ = q / RSTR;                                                                           \
       if (r_ < 8) BN[r_] = *(const frag_t*)(smem + (UB) + rowb + r_ * 16 * G7_ROW_BYTES + (SLOT));       \
       else if (r_ < 8 + TIN) AN[r_ - 8] = *(const frag_t*)(smem + (UA) + rowa + (r_ - 8) * 16 * G7_ROW_BYTES + (SLOT)); \
     }                                                                                                    \
-    if (G7_DMA_EARLY_ ? (q < (NISS) * G7_DMA_EARLY_ && q % G7_DMA_EARLY_ == G7_DMA_EARLY_ - 1) : (q % ISTR == (ISTR == 8 ? 5 : 1))) { \
+    if (!(G7H_ABL & 1) && (G7_DMA_EARLY_ ? (q < (NISS) * G7_DMA_EARLY_ && q % G7_DMA_EARLY_ == G7_DMA_EARLY_ - 1) : (q % ISTR == (ISTR == 8 ? 5 : 1)))) { \
       const int di_ = G7_DMA_EARLY_ ? q / (G7_DMA_EARLY_ ? G7_DMA_EARLY_ : 1) : q / ISTR;                \
       if (LASTSTEP) tail((TBASE) + di_, u_sp, u_ac);                                                     \
       else g7_issue_##P(src, PTR, di_, lds0 + (UNIT) + (di_ * 4 + wave) * 1024);                         \
@@ -78,8 +83,8 @@ __device__ __forceinline__ void gemm_mainloop7_cont16h(const G7SrcU& src, const 
   do {                                                                                                   \
     if (tr && tid == 0 && t < 12) tr[3 + t] = clock64();                                                 \
     G7C_SUB16(a0, b0, a1, b1, u_ac, u_bc, slot[1], a, ka, u_sp, 0, LASTSTEP, TIN)                        \
-    __builtin_amdgcn_s_waitcnt(0x0070 | TIN);                   /* vmcnt(TIN) lgkmcnt(0): all but A(t+2) */ \
-    __builtin_amdgcn_s_barrier();                                                                        \
+    if (G7H_ABL & 8) __builtin_amdgcn_s_waitcnt(0xC07F); else __builtin_amdgcn_s_waitcnt(0x0070 | TIN);   /* vmcnt(TIN) lgkmcnt(0): all but A(t+2) */ \
+    if (!(G7H_ABL & 4)) __builtin_amdgcn_s_barrier();                                                    \
     G7_FENCE();                                                                                          \
     G7C_SUB16(a1, b1, a0, b0, u_an, u_bn, slot[0], b, kb, u_ac, 8, LASTSTEP, 8)                          \
     { const int o_ac = u_ac, o_bc = u_bc; u_ac = u_an; u_bc = u_bn; u_an = u_sp; u_bn = o_ac; u_sp = o_bc; } \
@@ -190,7 +195,7 @@ static void run(const char* what, int64_t M, int64_t N, int64_t K, const bf16_t*
 
 int main(int argc, char** argv) {
   const int64_t M = argc > 1 ? atoll(argv[1]) : 9216;      // 9216: the training step's token rows; 131072: the encoder benchmark's
-  printf("G7_DMA_EARLY=%d  M=%ld\n", (int)G7_DMA_EARLY, (long)M);
+  printf("G7_DMA_EARLY=%d  G7H_ABL=%d  M=%ld\n", (int)G7_DMA_EARLY, (int)G7H_ABL, (long)M);
   bf16_t *A, *B; float* out; unsigned long long* cyc;
   hipMalloc(&A, (size_t)M * 3072 * 2); hipMalloc(&B, (size_t)3072 * 3072 * 2); hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 512 * 8);
   fill_bf16(A, (size_t)M * 3072, 1.0f, 1); fill_bf16(B, (size_t)3072 * 3072, 0.05f, 2);
