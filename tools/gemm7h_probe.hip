@@ -4,6 +4,10 @@
 // random operands, hipEvents around 20 launches.  The question: is a half-height tile's K loop fast enough (its prefetch distance
 // is two steps of ~1.4 k cycles) to replace the 256 x 128 generation (kernel 2: ~2.7 k cycles per step, 70 / 52 / 18 / 50 us on the
 // four shapes below)?     hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/gemm7h_probe.hip -o build/g7h_probe
+// Also the round's K-step ablation: -DG7H_ABL=<bits> compiles parts of the loop out (bit 0 DMA issues, 1 fragment reads, 2 barrier,
+// 3 vmcnt wait, 4 scheduling fences, 5 every second MFMA), -DG7_DMA_EARLY=n front-loads a sub-step's DMA issues, -DG7_DMA_FORM=0|1|2
+// selects the LDS-DMA helper's form (gemm_core7.h).  `build/g7h_probe [M]`, recipe and results: tools/r4/probe17.sh,
+// profiles/r04_probe17_* / r04_probe18_*.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string>
