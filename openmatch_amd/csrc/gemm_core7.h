@@ -164,6 +164,16 @@ __device__ __forceinline__ void g7_begin(const G7Src& src, int nk, char* smem, i
 
 // The K loop of one tile whose steps 0 and 1 are in flight (g7_begin, nk >= 2).  acc as in gemm_core6.h:
 //   acc[mi][ni][r] = C[m0 + wm*128 + mi*32 + (lane&31)][n0 + wn*128 + ni*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)]
+// Per-step trace stamps (tr[3 + t]) are compiled in only for the probes (-DG7_TRACE_STEPS; tools/gemm7_probe.hip): with a run-time
+// trace pointer the test is a wave-uniform branch in EVERY K step of every production launch -- on the only wave of a SIMD.  The
+// library stamps tr[3] once, in front of the loop.
+#ifdef G7_TRACE_STEPS
+#define G7_STEP_STAMP() do { if (tr && tid == 0 && t < 12) tr[3 + t] = clock64(); } while (0)
+#define G7_LOOP_STAMP() do {} while (0)
+#else
+#define G7_STEP_STAMP() do {} while (0)
+#define G7_LOOP_STAMP() do { if (tr && tid == 0) tr[3] = clock64(); } while (0)
+#endif
 template <typename T, typename SRC = G7Src>
 __device__ __forceinline__ void gemm_mainloop7_run(const SRC& src, int nk, char* smem,
                                           f32x16_t (&acc)[4][4], unsigned long long* tr = nullptr,
@@ -227,7 +237,7 @@ __device__ __forceinline__ void gemm_mainloop7_run(const SRC& src, int nk, char*
   // four times slower (instruction cache; profiles/r03_gemm7_ablation_v0.log vs the peeled build).
 #define G7_STEP(ISSUE, B2H)                                                                              \
   do {                                                                                                   \
-    if (tr && tid == 0 && t < 12) tr[3 + t] = clock64();                                                 \
+    G7_STEP_STAMP();                                                                                     \
     { const char* const kb_cur = kb; kb -= G7_ROW_BYTES;                                                 \
       G7_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[1], true, 1, b, u_bn, 4, B2H)                              \
       kb = kb_cur; }                                                                                     \
@@ -241,6 +251,7 @@ __device__ __forceinline__ void gemm_mainloop7_run(const SRC& src, int nk, char*
     ka += G7_ROW_BYTES; kb += G7_ROW_BYTES;                                                              \
   } while (0)
 
+  G7_LOOP_STAMP();
   for (int t = 0; t < nk; ++t) {
     const bool issue = t + 2 < nk;
     const bool b2h = t > 0 && t + 1 < nk;
@@ -332,7 +343,7 @@ __device__ __forceinline__ void gemm_mainloop7_cont(const G7SrcU& src, const cha
   }
 #define G7C_STEP(LASTSTEP, ZERO)                                                                         \
   do {                                                                                                   \
-    if (tr && tid == 0 && t < 12) tr[3 + t] = clock64();                                                 \
+    G7_STEP_STAMP();                                                                                     \
     G7C_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[1], b, kbp, u_bn, 4, -1, LASTSTEP, ZERO)   /* second half of B(t+1) */ \
     G7C_SUB(a1, b1, a0, b0, u_ac, u_bc, slot[2], a, ka, u_sp, 0, 0, LASTSTEP, false)     /* A(t+2) */            \
     G7C_SUB(a0, b0, a1, b1, u_ac, u_bc, slot[3], a, ka, u_sp, 4, 4, LASTSTEP, false)                            \
@@ -346,6 +357,7 @@ __device__ __forceinline__ void gemm_mainloop7_cont(const G7SrcU& src, const cha
     if (t + 3 == nk) { ka = next_a; kb = next_b; } else { ka += G7_ROW_BYTES; kb += G7_ROW_BYTES; }      \
   } while (0)
   int t = 0;
+  G7_LOOP_STAMP();
   const int nplain = TAIL ? nk - 1 : nk;
   if (ZERO_FIRST) { G7C_STEP(false, true); ++t; }
   for (; t < nplain; ++t) G7C_STEP(false, false);
@@ -420,7 +432,7 @@ __device__ __forceinline__ void gemm_mainloop7_cont16(const G7SrcU& src, const c
   }
 #define G7C_STEP16(LASTSTEP)                                                                             \
   do {                                                                                                   \
-    if (tr && tid == 0 && t < 12) tr[3 + t] = clock64();                                                 \
+    G7_STEP_STAMP();                                                                                     \
     G7C_SUB16(a0, b0, a1, b1, u_ac, u_bc, slot[1], a, ka, u_sp, 0, LASTSTEP)                             \
     __builtin_amdgcn_s_waitcnt(0x0078);                                     /* vmcnt(8) lgkmcnt(0) */     \
     __builtin_amdgcn_s_barrier();                                                                        \
@@ -430,6 +442,7 @@ __device__ __forceinline__ void gemm_mainloop7_cont16(const G7SrcU& src, const c
     if (t + 3 == nk) { ka = next_a; kb = next_b; } else { ka += G7_ROW_BYTES; kb += G7_ROW_BYTES; }      \
   } while (0)
   int t = 0;
+  G7_LOOP_STAMP();
   const int nplain = TAIL ? nk - 1 : nk;
   for (; t < nplain; ++t) G7C_STEP16(false);
   if (TAIL) G7C_STEP16(true);

@@ -1,6 +1,7 @@
 // Developer tool: times the generation-7 persistent GEMM (gemm_wide7.h) on the encoder's four shapes with parts of
 // the tile compiled out (-DG7_ABL=<bits>, gemm_core7.h), on random operands, hipEvents around 20 launches.
 //   for a in 0 1 2 4 8 16 32 64 ...; do hipcc -O3 -std=c++17 --offload-arch=gfx950 -DG7_ABL=$a tools/gemm7_probe.hip -o build/g7probe_$a; done
+#define G7_TRACE_STEPS 1      // per-step stamps (step0 / later steps below): compiled out of the library
 #include <stdio.h>
 #include <stdlib.h>
 #include <string>
