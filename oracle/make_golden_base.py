@@ -22,6 +22,16 @@ REFERENCE in the build container:  python oracle/make_golden_base.py   (needs /r
                           64 passages + 16 queries, fp32 and autocast.
   bert_large_rr.npz       bert-large cross-encoder (24 x 1024) RRModel scores of 32 pairs x 162 tok, fp32 and autocast.
 
+  train_base.npz          The BENCHMARKED training step (round 5): bert-base width (768 / 3072 / 12 heads), two layers, 8 queries
+                          x 32 tok + 64 passages x 128 tok (train_n_passages = 8, the per-GPU batch of docs/dr-msmarco-passage.md:
+                          75-76), dropout 0  ->  reference DRModel.forward + loss.backward() three times: fp32, under
+                          torch.autocast(bfloat16) and under torch.autocast(float16) with a static loss scale (what the reference's
+                          `--fp16` training does through HF Trainer's GradScaler, trainer/dense_trainer.py:141-149).  Stored: the fp32
+                          gradients on a strided row subset of every parameter (stride 11: every residue of a 16 / 32 / 256-row tile
+                          is visited; the embedding table on the rows of tokens that occur), and PER TENSOR the relative L2 distance
+                          of the two autocast runs from the fp32 run on that subset and on the whole tensor -- the yardstick the
+                          HIP 16-bit training step is held to (factor 1.0).
+
 Weights are re-created from the seed by the tests (HF is in the image); a checksum pins them.
 """
 import os
@@ -270,9 +280,110 @@ def bert_large_rr(rng):
     print("wrote bert_large_rr.npz")
 
 
+TRAIN_STRIDE = 11
+
+
+def train_subset_rows(name, shape, used_tokens):
+    """Row indices of parameter `name` whose gradient the fixture keeps (None: the whole tensor)."""
+    if name == "embeddings.word_embeddings.weight":
+        return used_tokens[::3]
+    if len(shape) == 2 and shape[0] * shape[1] > 200_000:
+        return np.arange(0, shape[0], TRAIN_STRIDE)
+    return None
+
+
+def train_base(rng):
+    from openmatch.modeling import DRModel  # the reference
+    torch.manual_seed(3)
+    cfg = BertConfig(num_hidden_layers=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    lm = BertModel(cfg)
+    n_psg, nq = 8, 8
+    model = DRModel(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False), data_args=NS(train_n_passages=n_psg),
+                    train_args=NS(negatives_x_device=False, per_device_train_batch_size=nq))
+    model.train()
+    q_ids, q_mask = mg.synth_batch(rng, nq, 32, cfg.vocab_size, 4)
+    p_ids, p_mask = mg.synth_batch(rng, nq * n_psg, 128, cfg.vocab_size, 16)
+    mk = lambda ids, mask: {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask),
+                            "token_type_ids": torch.zeros_like(torch.from_numpy(ids))}
+    q, p = mk(q_ids, q_mask), mk(p_ids, p_mask)
+    used = np.unique(np.concatenate([q_ids[q_mask > 0], p_ids[p_mask > 0]]))
+    params = [(k, v) for k, v in lm.named_parameters()]
+
+    def run(ac_dtype, loss_scale, enc_only=False):
+        """enc_only: autocast covers the two encoder calls only; scores and cross entropy (modeling/dense_retrieval_model.py:
+        113-122, the reference's own `loss_fn` member) are evaluated in fp32 on the float()-ed representations."""
+        for _, v in params:
+            v.grad = None
+        t0 = time.time()
+        if ac_dtype is None:
+            o = model(query=q, passage=p)
+            loss, scores = o.loss, o.scores
+        elif not enc_only:
+            with torch.autocast("cpu", dtype=ac_dtype):
+                o = model(query=q, passage=p)
+            loss, scores = o.loss, o.scores
+        else:
+            with torch.autocast("cpu", dtype=ac_dtype):
+                _, q_reps = model.encode_query(q)
+                _, p_reps = model.encode_passage(p)
+            scores = torch.matmul(q_reps.float(), p_reps.float().transpose(0, 1))
+            target = torch.arange(scores.size(0), dtype=torch.long) * n_psg
+            loss = model.loss_fn(scores, target)
+        (loss.float() * loss_scale).backward()
+        grads = {k: (v.grad.detach().double() / loss_scale) for k, v in params if v.grad is not None}
+        assert all(torch.isfinite(g_).all() for g_ in grads.values()), "non-finite gradient: lower the loss scale"
+        print(f"    train step autocast={ac_dtype} enc_only={enc_only}: loss {float(loss):.6f}  {time.time() - t0:.1f} s", flush=True)
+        return float(loss), scores.detach().float().numpy(), grads
+
+    loss32, scores32, g32 = run(None, 1.0)
+    loss_bf, _, gbf = run(torch.bfloat16, 1.0)
+    # float16: a static scale of 2^12 stands in for GradScaler's dynamic one (same arithmetic: the loss is multiplied before
+    # backward, the f32 parameter gradients divided afterwards; a power of two changes no mantissa)
+    loss_h, _, gh = run(torch.float16, 4096.0)
+    # The whole-forward autocast runs are LOOSE yardsticks on a random-init model: every CLS dot is ~762 +- 0.3 and autocast
+    # rounds the score matrix itself to 16 bits (a bf16 ulp at 762 is 4).  The tight ones keep the loss in fp32:
+    loss_bf_e, _, gbf_e = run(torch.bfloat16, 1.0, enc_only=True)
+    loss_h_e, _, gh_e = run(torch.float16, 4096.0, enc_only=True)
+    out = {"q_input_ids": q_ids.astype(np.uint16), "q_len": lengths(q_mask), "p_input_ids": p_ids.astype(np.uint16),
+           "p_len": lengths(p_mask), "weight_checksum": checksum(lm), "n_psg": np.array(n_psg),
+           "loss_f32": np.array(loss32), "loss_acbf16": np.array(loss_bf), "loss_ac16": np.array(loss_h), "scores_f32": scores32,
+           "loss_acbf16_enc": np.array(loss_bf_e), "loss_ac16_enc": np.array(loss_h_e),
+           "stride": np.array(TRAIN_STRIDE)}
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-300))
+    names, yard = [], []
+    for k, v in params:
+        if k not in g32:
+            continue
+        rows = train_subset_rows(k, tuple(v.shape), used)
+        full = g32[k]
+        sub = (lambda t: t) if rows is None else (lambda t, r=torch.from_numpy(rows): t[r])
+        out["g::" + k] = sub(full).float().numpy()
+        if rows is not None:
+            out["rows::" + k] = rows.astype(np.int32)
+        names.append(k)
+        # columns: bf16-autocast on the subset, on the whole tensor; float16-autocast on the subset, on the whole tensor; |g|_2 (whole);
+        # then the same four for the encoder-only autocast runs (fp32 loss); |g|_2 of the subset
+        yard.append([rel(sub(gbf[k]), sub(full)), rel(gbf[k], full), rel(sub(gh[k]), sub(full)), rel(gh[k], full), float(full.norm()),
+                     rel(sub(gbf_e[k]), sub(full)), rel(gbf_e[k], full), rel(sub(gh_e[k]), sub(full)), rel(gh_e[k], full), float(sub(full).norm())])
+    out["grad_names"] = np.array(names)
+    out["yardstick"] = np.array(yard)
+    y = out["yardstick"]
+    print("  train_base: %d gradient tensors; reference bf16-autocast rel-L2 from fp32: median %.2e max %.2e; float16-autocast: median %.2e max %.2e"
+          % (len(names), np.median(y[:, 1]), y[:, 1].max(), np.median(y[:, 3]), y[:, 3].max()))
+    print("              encoder-only autocast (fp32 loss): bf16 median %.2e max %.2e; float16 median %.2e max %.2e"
+          % (np.median(y[:, 6]), y[:, 6].max(), np.median(y[:, 8]), y[:, 8].max()))
+    for n_, r_ in zip(names, y):
+        print("    %-52s whole fwd: bf16 %.2e f16 %.2e | encoder only: bf16 %.2e (sub %.2e) f16 %.2e (sub %.2e)  |g| %.2e"
+              % (n_, r_[1], r_[3], r_[6], r_[5], r_[8], r_[7], r_[4]))
+    np.savez_compressed(os.path.join(OUT, "train_base.npz"), **out)
+    print("wrote train_base.npz  (%.1f MB)" % (os.path.getsize(os.path.join(OUT, "train_base.npz")) / 1e6))
+
+
 def main():
     torch.set_num_threads(os.cpu_count() or 1)
     what = sys.argv[1:] or ["config1", "gtr", "large"]
+    if "train" in what:
+        train_base(np.random.default_rng(SEED + 15))
     if "config1" in what:
         config1(np.random.default_rng(SEED + 11))
     if "spread" in what:
