@@ -279,14 +279,16 @@ def train_leg(device, steps=8):
     mk = lambda n, L: {"input_ids": torch.randint(1000, 30000, (n, L), generator=g), "attention_mask": torch.ones(n, L, dtype=torch.long)}
     batch = (mk(8, 32), mk(64, 128))
     args = NS(device=device, world_size=1, process_index=0, per_device_train_batch_size=8, negatives_x_device=False,
-              learning_rate=5e-6, gradient_accumulation_steps=1, fp16=False, bf16=False)
+              learning_rate=5e-6, weight_decay=0.0, max_grad_norm=1.0, gradient_accumulation_steps=1, fp16=False, bf16=False)
     trainer = DRTrainer(model=model, args=args)
-    opt = torch.optim.AdamW(model.parameters(), lr=5e-6, fused=True)
+    # the product's own step: DRTrainer.training_step (forward + loss + backward) and DRTrainer.optimizer_step (what
+    # DRTrainer.train runs between two batches: clip_grad_norm_(1.0) + AdamW + the refresh of the packed bf16 weights, on
+    # openmatch_amd.optim.FusedAdamW -- HF Trainer's defaults of the reference's command line, docs/dr-msmarco-passage.md:62-80)
+    trainer.create_optimizer_and_scheduler(num_training_steps=10 ** 6)
 
     def step():
         loss = trainer.training_step(model, batch)
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
-        opt.step(); opt.zero_grad(set_to_none=True)
+        trainer.optimizer_step()
         return loss
     for _ in range(3):
         step()
@@ -299,7 +301,8 @@ def train_leg(device, steps=8):
            "value": round(1 / dt, 2), "unit": "steps/s", "ms_per_step": round(dt * 1e3, 2), "dtype": "bf16",
            "algorithmic_tflops": round(flop / dt / 1e12, 1), "frac_of_mfma_peak": round(flop / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
            "loss": float(loss)}
-    del model, trainer, opt
+    out["optimizer"] = type(trainer.optimizer).__name__
+    del model, trainer
     torch.cuda.empty_cache()
     return out
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OM_ABI_VERSION 4
+#define OM_ABI_VERSION 5   /* 5 (round 5): om_grad_sqnorm, om_adamw_step */
 
 /* element types */
 #define OM_F32 0
@@ -109,10 +109,13 @@ void om_debug_gemm_gen(int gen);
                                      * launch per group of layers computes their weight gradients (env OM_TRAIN_WGRAD_BATCH) */
 #define OM_OPT_GEMM_MAX_GRID 15    /* 0 (default): the persistent 16-bit GEMM takes every CU; > 0: at most this many workgroups (one per CU) --
                                     * two half-batch encoder forwards on two streams share the chip with 128 each */
-#define OM_OPT_GEMM_CONT 16        /* (bit 4, A/B, off: plain whole-tile bf16 shapes prefer the continuous kernels even when they leave CUs idle) bit 0 (default 15 = all): the persistent 16-bit GEMM variants without a residual, bit 1: the one-plane residual
-                                    * variants, bit 2: the f16 index scan of wide query batches, run on the continuous ring; bit 3: the GEMM variants of bits 0-1 on 16 x 16 x 32 MFMAs (kernels 7c16 / 7r16) (the K loop of
-                                    * a tile prefetches the next tile's first two steps; epilogue and accumulator initialisation of the next
-                                    * tile interleaved); 0: the ring restarts per tile as in round 3 (A/B measurements) */
+#define OM_OPT_GEMM_CONT 16        /* bit mask (env OM_GEMM_CONT, default 47 = bits 0-3 and 5) of the persistent 16-bit GEMM's continuous ring (the K loop of a tile
+                                    * prefetches the next tile's first two steps; epilogue and accumulator initialisation of the next tile interleaved).
+                                    * bit 0: the variants without a residual; bit 1: the one-plane residual variants; bit 2: the f16 index scan of wide
+                                    * query batches; bit 3: (no effect since round 5: the continuous GEMM kernels exist on 16 x 16 x 32 MFMAs only);
+                                    * bit 4 (A/B, off): plain whole-tile bf16 shapes prefer the continuous kernels even when they leave CUs idle;
+                                    * bit 5: the training forward's FFN1 (gelu + gelu' to the tape) on the continuous kernel with a two-output
+                                    * epilogue; a cleared bit 0 / 1: the ring restarts per tile as in round 3 (A/B measurements) */
 #define OM_OPT_TRAIN_TAPE_GRAD 17  /* 1 (default): the bf16 BERT training forward keeps gelu'(f) on its tape instead of f (env OM_TRAIN_TAPE_GRAD) */
 #define OM_OPT_COUNT 18
 int om_debug_option(int opt, int value);
@@ -393,6 +396,35 @@ int om_encoder_train_backward_hidden(const OmEncoderConfig* cfg, const OmEncoder
  * side stream that waits for events[l] can all-reduce layer l's slice of the gradient arena while the rest of the
  * backward still runs.  NULL entries are skipped; the array is consumed by one backward. */
 int om_encoder_train_set_layer_events(void* const* events, int n);
+
+/* ------------------------------------------------------------------------
+ * Optimizer step of the training loop: global-norm gradient clipping + AdamW + refresh of the packed compute-dtype
+ * copies of the updated weights, for a whole model in three launches.  Replaces what the reference inherits from HF
+ * Trainer.train per optimizer step (trainer/dense_trainer.py:27-108: torch.nn.utils.clip_grad_norm_(max_grad_norm),
+ * torch.optim.AdamW.step) and the re-packing of the encoder's 16-bit weight matrices that would follow it here.
+ *
+ * tensors / chunks are DEVICE arrays the caller builds once per set of buffers: `tensors[t]` describes one parameter
+ * (p, g, m, v: f32 [n]; g == NULL: the parameter received no gradient and is left alone; shadow0 / shadow1: up to two
+ * copies of p in shadow*_dtype (OM_F32 | OM_BF16 | OM_F16) that are rewritten with the updated values -- the packed
+ * weights OmLayerWeights points at -- or NULL); `chunks[2 c], chunks[2 c + 1]` = (tensor index, chunk index within it)
+ * for every OM_ADAM_CHUNK elements of every tensor, one workgroup each.
+ *   om_grad_sqnorm   out_sq[0] = sum over all tensors of |g|^2 (f32; fixed summation order); partial: n_chunks floats of scratch
+ *   om_adamw_step    torch.optim.AdamW's update with bias corrections for `step` (counted from 1) on
+ *                    g' = g * grad_scale * min(1, max_norm / (|g * grad_scale|_2 + 1e-6))   (max_norm <= 0: no clipping);
+ *                    gnorm_sq = om_grad_sqnorm's out_sq (required when clipping).  skip_nonfinite != 0: an inf / nan norm
+ *                    leaves every buffer untouched (the skipped step of a float16 GradScaler); the caller reads out_sq to learn of it.
+ * ------------------------------------------------------------------------ */
+#define OM_ADAM_CHUNK 16384
+typedef struct OmAdamTensor {
+  float* p; const float* g; float* m; float* v;
+  void* shadow0; void* shadow1;
+  int64_t n;
+  float weight_decay;
+  int shadow0_dtype, shadow1_dtype, reserved;
+} OmAdamTensor;
+int om_grad_sqnorm(const OmAdamTensor* tensors, const int32_t* chunks, int n_chunks, float* partial, float* out_sq, void* stream);
+int om_adamw_step(const OmAdamTensor* tensors, const int32_t* chunks, int n_chunks, float lr, float beta1, float beta2, float eps,
+                  int64_t step, const float* gnorm_sq, float max_norm, float grad_scale, int skip_nonfinite, void* stream);
 
 /* ------------------------------------------------------------------------
  * Exact inner-product search.  Replaces faiss.IndexFlatIP.add / .search

@@ -132,6 +132,10 @@ int omk_gemm_wide7_f16(const void* A, int64_t lda, const void* B, int64_t ldb, v
 int omk_gemm_wide7(bool persist, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                    int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s);
 
+bool omk_gemm_wide7_train_ok(int64_t M, int64_t N, int64_t K, int64_t ldc, const GemmEpilogue& ep);
+int omk_gemm_wide7_train(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                         int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s);
+
 int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int out_dtype,
              void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep_in,
              hipStream_t s) {
@@ -168,6 +172,10 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
       gen = 6;
   }
   const bool ln_fused = ep.ln_stats || ep.rln_stats || ep.stats_out;
+  // the training forward's FFN1 (gelu + gelu' to the tape): the continuous 256 x 256 kernel with its two-output epilogue
+  if (wide && in_dtype == OM_BF16 && out_dtype == OM_BF16 && gemm_variant() == 0 && g_debug_gen != 6 &&
+      omk_gemm_wide7_train_ok(M, N, K, ldc, ep))
+    return omk_gemm_wide7_train(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
   if (in_dtype == OM_F16 && out_dtype == OM_F16) {
     // float16 -> float16 (the inference encoder's float16 mode): the persistent 256 x 256 kernel where the problem is
     // made of whole tiles, else the generic 128 / 256-row tiles; no training epilogues

@@ -75,6 +75,27 @@ __device__ __forceinline__ f32x8_t gelu_erf_poly8(f32x8_t x) {
   return x * __builtin_elementwise_fma(xc, q, (f32x8_t)(0.5f));
 }
 
+// gelu and gelu' of eight values from one evaluation of the polynomial (gelu_erf_poly2_both's arithmetic, four chains in flight):
+// the two-output training epilogue of the continuous 256 x 256 kernel (gemm_wide7.h, TRAIN)
+__device__ __forceinline__ f32x8_t gelu_erf_poly8_both(f32x8_t x, f32x8_t& grad) {
+  f32x8_t xc;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) xc[i] = __builtin_amdgcn_fmed3f(x[i], -4.2f, 4.2f);
+  const f32x8_t t = xc * xc;
+  f32x8_t q = 5.998145036e-11f;
+#define OM_G8(K) q = __builtin_elementwise_fma(q, t, (f32x8_t)(K))
+  OM_G8(-5.633389311e-09f); OM_G8(2.343703613e-07f); OM_G8(-5.760840850e-06f); OM_G8(9.457556007e-05f);
+  OM_G8(-1.114161685e-03f); OM_G8(9.830250405e-03f); OM_G8(-6.636118144e-02f); OM_G8(3.989123106e-01f);
+#undef OM_G8
+  const f32x8_t Phi = __builtin_elementwise_fma(xc, q, (f32x8_t)(0.5f));
+  const f32x8_t e = x * x * (f32x8_t)(-0.7213475204444817f);
+  f32x8_t pdf;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) pdf[i] = 0.3989422804014327f * __builtin_amdgcn_exp2f(e[i]);
+  grad = __builtin_elementwise_fma(x, pdf, Phi);
+  return x * Phi;
+}
+
 // two adjacent output elements (columns n, n+1 of row m) before the residual
 // dbits: the dropout hash of the four-column group holding (m, n) (dropout_bits; N % 4 == 0), e0 = n & 3 (0 or 2)
 template <int ACT, bool TRAIN, typename OutT>

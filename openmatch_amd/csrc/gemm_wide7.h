@@ -591,204 +591,6 @@ __device__ __forceinline__ void g7c_tables(const GemmEpilogue& ep, const void* d
   if (LNF == 1) g7_table1(ep.ln_stats + mc * 2, tab1, lane);       // (sum, sum of squares) of my 128 rows
 }
 
-template <typename T, int ACT, int LNF>
-__global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c(
-    const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, T* C, int64_t ldc,
-    int64_t M, int64_t N, int64_t K, GemmEpilogue ep, int group_m) {
-  typedef T OutT;
-  typedef typename MmaOps<T>::frag_t frag_t;
-  static_assert(sizeof(T) == 2, "16-bit in, 16-bit out");
-  static_assert(LNF == 0 || LNF == 1, "no residual: plain or LayerNorm-folded A operand");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane0 = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int64_t ntm = M / 256, ntn = N / 256;
-  const int nk = (int)((K * 2) / G7_ROW_BYTES);
-  const EpiScalars es(ep);
-  constexpr int TI = LNF == 1 ? 2 : 1;         // DMA instructions of a tile's tables
-
-  int it = 0;
-  int64_t m0, n0;
-  if (!g7_tile(0, ntm, ntn, group_m, m0, n0)) return;
-  G7SrcU src;
-  g7_offsets_u<T>(src, lda, ldb, wave, lane0);
-  G7Ring ring;
-  g7_ring_reset(ring);
-  const char* cur_a = (const char*)(A + m0 * lda);
-  const char* cur_b = (const char*)(B + n0 * ldb);
-  // what every later tile finds when its predecessor's K loop ends: step 0, A(1), the first half of B(1)
-  g7_fill_a(src, cur_a, smem + ring.ac, wave);
-  g7_fill_b(src, cur_b, smem + ring.bc, wave);
-  g7_fill_a(src, cur_a + G7_ROW_BYTES, smem + ring.an, wave);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) g7_issue_b(src, cur_b + G7_ROW_BYTES, i, g7_lds_addr(smem + ring.bn) + (i * 4 + wave) * 1024);
-
-  bool live = false, have = true;              // wave-uniform: acc holds a finished tile (pm, pn) / there is a tile (m0, n0) to start
-  int64_t pm = m0, pn = n0;
-  f32x16_t acc[4][4];
-  float rs[4] = {1.f, 1.f, 1.f, 1.f};
-  unsigned long long* tr_prev = nullptr;
-
-  for (;;) {
-    // this wave's slices of the spare unit: slice i at sp + i * 4096
-    char* const sp = smem + ring.sp + wave * 1024;
-    char* const tab0 = sp + 4 * 4096;
-    char* const tab1 = sp + 5 * 4096;
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));             // opaque: per-lane addresses are rebuilt per tile, not hoisted and spilled
-    if (have) g7c_tables<LNF>(ep, A, tab0, tab1, m0 + wm * 128, n0 + wn * 128, lane);
-    const int l31 = lane & 31, half = lane >> 5;
-    float rsn[4] = {1.f, 1.f, 1.f, 1.f};
-    frag_t fa[4], fb[4];
-    size_t ldc2 = (size_t)ldc * sizeof(OutT);
-    asm volatile("" : "+s"(ldc2));
-    const int64_t pmc = pm + wm * 128, pnc = pn + wn * 128;
-    const int skey = l31 & 7;
-    char* const st_wr = sp + G7E_ROW(l31) + 8 * half;
-    const char* const st_rd = sp + (lane >> 3) * 128;
-    char* const cbase = (char*)(C + pmc * ldc + pnc);                   // wave-uniform; the per-lane part is 32 bits
-    const uint32_t coff = (uint32_t)((lane >> 3) * ldc2) + (lane & 7) * 16;
-    uint4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
-
-    // quarter G_ of patch P_ = (mi, nh): columns nl = G_ >> 1, j = 2 (G_ & 1) + {0, 1} -- eight accumulator registers per lane
-#define G7C_WRITE_Q(P_, G_)                                                                                    \
-  do {                                                                                                         \
-    constexpr int MI = (P_) >> 1, NH = (P_) & 1, NL = (G_) >> 1, NI = NH * 2 + NL, GO = 8 * ((G_) & 1);        \
-    if ((G_) == 0) asm volatile("" : "+a"(acc[MI][NH * 2]), "+a"(acc[MI][NH * 2 + 1]));                        \
-    const int64_t m = pmc + MI * 32 + l31;                                                                     \
-    f32x8_t v8;                                                                                                \
-    _Pragma("unroll") for (int e = 0; e < 8; ++e) v8[e] = acc[MI][NI][GO + e];                                 \
-    if (LNF == 1) v8 *= rs[MI];                                                                                \
-    if (ACT == OM_ACT_GELU_ERF) v8 = gelu_erf_poly8(v8);                                                       \
-    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                         \
-      const int j = 2 * ((G_) & 1) + jj;                                                                       \
-      f32x2_t lo_ = {v8[4 * jj], v8[4 * jj + 1]}, hi_ = {v8[4 * jj + 2], v8[4 * jj + 3]};                      \
-      if (ACT != OM_ACT_GELU_ERF) {                                                                            \
-        const int64_t n = pnc + NI * 32 + 8 * j + 4 * half;                                                    \
-        lo_ = epi_pair<ACT, false, OutT>(lo_, m, n, M, N, ep, es, 0, 0);                                       \
-        hi_ = epi_pair<ACT, false, OutT>(hi_, m, n + 2, M, N, ep, es, 0, 0);                                   \
-      }                                                                                                        \
-      const uint2 pk_ = make_uint2(Half16<OutT>::pack2(lo_[0], lo_[1]), Half16<OutT>::pack2(hi_[0], hi_[1]));  \
-      *(uint2*)(st_wr + (((NL * 4 + j) ^ skey) << 4)) = pk_;                                                   \
-    }                                                                                                          \
-  } while (0)
-#define G7C_RB(I4) (*(const uint4*)(st_rd + (I4) * 4096 + (((lane & 7) ^ (((lane >> 3) + (I4) * 8) & 7)) << 4)))
-#ifdef G7E_STORE16U
-#define G7C_ST(PP, I4, V) G7E_STORE16U(cbase + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128, coff, V)
-#else
-#define G7C_ST(PP, I4, V) G7E_STORE16(cbase + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128 + coff, V)
-#endif
-    // stores of patch P_ (read back one iteration ago into C0..C3), one behind each quarter of patch P_ + 1's conversion;
-    // then the read-back of P_ + 1 into N0..N3.  A wave's LDS operations execute in order: one staging patch, no waits.
-#define G7C_ITER(P_, C0, C1, C2, C3, N0, N1, N2, N3)                                                           \
-  do {                                                                                                         \
-    if ((P_) + 1 < 8) {                                                                                        \
-      G7C_WRITE_Q((P_) + 1, 0); G7_FENCE_(); G7C_ST(P_, 0, C0); G7_FENCE_();                                   \
-      G7C_WRITE_Q((P_) + 1, 1); G7_FENCE_(); G7C_ST(P_, 1, C1); G7_FENCE_();                                   \
-      G7C_WRITE_Q((P_) + 1, 2); G7_FENCE_(); G7C_ST(P_, 2, C2); G7_FENCE_();                                   \
-      G7C_WRITE_Q((P_) + 1, 3); G7_FENCE_();                                                                   \
-      N0 = G7C_RB(0); N1 = G7C_RB(1); N2 = G7C_RB(2); N3 = G7C_RB(3);                                          \
-      G7_FENCE_(); G7C_ST(P_, 3, C3); G7_FENCE_();                                                             \
-    } else {                                                                                                   \
-      G7C_ST(P_, 0, C0); G7C_ST(P_, 1, C1); G7C_ST(P_, 2, C2); G7C_ST(P_, 3, C3); G7_FENCE_();                 \
-    }                                                                                                          \
-  } while (0)
-
-    if (live) {
-      G7C_WRITE_Q(0, 0); G7C_WRITE_Q(0, 1); G7C_WRITE_Q(0, 2); G7C_WRITE_Q(0, 3);
-      G7_FENCE_();
-      sa0 = G7C_RB(0); sa1 = G7C_RB(1); sa2 = G7C_RB(2); sa3 = G7C_RB(3);
-      G7_FENCE_();
-      G7C_ITER(0, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
-      G7C_ITER(1, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
-      G7C_ITER(2, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
-      G7C_ITER(3, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
-      G7C_ITER(4, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
-      G7C_ITER(5, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
-    }
-    // ---- the next tile's initialising fragments (tables -> fa, fb): accumulators start at the bias, or at
-    // b'_n / rstd_m - mu_m s_n for a raw pre-LayerNorm A operand -- the rank-2 product u_m b_n + v_m s_n with every factor split
-    // into 16-bit hi + lo (kernel above).  vmcnt retires in order: with 24 stores issued since the tables, "at most 8
-    // outstanding" covers them; the first pass has issued no store and waits for everything (it needs K step 0 anyway).
-    if (have) {
-      if (live) G7_WAIT_VM(8); else G7_WAIT_VM(0);
-      const bool ln_in = LNF == 1 && ep.ln_stats != nullptr;
-      const bool has_cs = LNF == 1 && ep.ln_colsum != nullptr, has_b = ep.bias != nullptr;
-      auto split = [](float x, uint32_t& hi, uint32_t& lo) {
-        hi = Half16<T>::bits(x); lo = Half16<T>::bits(x - Half16<T>::value(hi));
-      };
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        float u = 1.f, v = 0.f;
-        if (ln_in) {
-          const float2 st = *(const float2*)(tab1 + (mi * 32 + l31) * 8);
-          const float mu = ep.ln_rms ? 0.f : st.x * ep.ln_inv_h;
-          const float var = fmaxf(st.y * ep.ln_inv_h - mu * mu, 0.f) + ep.ln_eps;
-          rsn[mi] = rsqrtf(var);
-          u = sqrtf(var); v = -mu;
-        }
-        uint32_t uh, ul, vh, vl;
-        split(u, uh, ul); split(v, vh, vl);
-        uint4 w = make_uint4(uh | (ul << 16), uh | (vh << 16), vl | (vh << 16), 0u);     // k: u_hi u_lo u_hi v_hi v_lo v_hi 0 0
-        if (half) w = make_uint4(0u, 0u, 0u, 0u);
-        asm volatile("" : "+v"(w.x), "+v"(w.y), "+v"(w.z));       // opaque per row block: 16 MFMAs, not 4 + 192 accumulator moves
-        fa[mi] = __builtin_bit_cast(frag_t, w);
-      }
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        float b = *(const float*)(tab0 + 512 + (ni * 32 + l31) * 4), sc = *(const float*)(tab0 + (ni * 32 + l31) * 4);
-        if (!has_b) b = 0.f;
-        if (!(ln_in && has_cs)) sc = 0.f;
-        uint32_t bh, bl, sh, sl;
-        split(b, bh, bl); split(sc, sh, sl);
-        uint4 w = make_uint4(bh | (bh << 16), bl | (sh << 16), sh | (sl << 16), 0u);     // k: b_hi b_hi b_lo s_hi s_hi s_lo 0 0
-        if (half) w = make_uint4(0u, 0u, 0u, 0u);
-        fb[ni] = __builtin_bit_cast(frag_t, w);
-      }
-    }
-    if (live) G7C_ITER(6, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);     // converts patch 7: the last reader of the accumulators
-    if (have) {
-      const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int q = 0; q < 16; ++q) { acc[q >> 2][q & 3] = zero; MmaOps<T>::mma(fb[q & 3], fa[q >> 2], acc[q >> 2][q & 3]); }
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) asm volatile("" : "+a"(acc[q >> 2][q & 3]));      // one home for every tile where the paths join
-    if (live) {
-      G7C_ITER(7, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
-      if (tr_prev && threadIdx.x == 0) { tr_prev[28] = clock64(); tr_prev[29] = blockIdx.x; tr_prev[31] = wall_clock64(); }
-    }
-#undef G7C_ITER
-#undef G7C_ST
-#undef G7C_RB
-#undef G7C_WRITE_Q
-    if (!have) break;
-    if (!live) __builtin_amdgcn_s_barrier();     // first pass: K step 0 (waited for above) is published to the other waves
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) rs[mi] = rsn[mi];
-
-    // ---- the tile after this one (a workgroup that has none prefetches its own again: the instruction stream stays fixed)
-    ++it;
-    int64_t m1 = m0, n1 = n0;
-    const bool has_next = g7_tile(it, ntm, ntn, group_m, m1, n1);
-    const char* const next_a = (const char*)(A + m1 * lda);
-    const char* const next_b = (const char*)(B + n1 * ldb);
-    unsigned long long* tr = nullptr;
-    if (ep.trace) {
-      const int64_t tile_id = (m0 / 256) * ntn + n0 / 256;
-      if (tile_id < 8192) tr = ep.trace + tile_id * 32;
-    }
-    if (tr && threadIdx.x == 0) { tr[0] = tr[1] = clock64(); tr[30] = wall_clock64(); }
-    gemm_mainloop7_cont<T>(src, cur_a, cur_b, next_a, next_b, nk, smem, ring, acc, tr);
-    if (tr && threadIdx.x == 0) tr[15] = clock64();
-    tr_prev = tr;
-    pm = m0; pn = n0; live = true;
-    cur_a = next_a; cur_b = next_b; m0 = m1; n0 = n1; have = has_next;
-  }
-  G7_WAIT_VM(0);      // the last (dummy) prefetch must not outlive the workgroup's LDS allocation
-}
-
 // =========================================================================================================================
 // Kernel 7c on 16 x 16 x 32 MFMAs (round 4, late): the same tile boundary, the K loop of gemm_mainloop7_cont16.
 //   acc[ti][fj][r] = C[m0 + wm*128 + ti*16 + (lane&15)][n0 + wn*128 + fj*16 + 4*(lane>>4) + r]
@@ -797,7 +599,14 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c(
 // row block ti2 = G >> 1 and the column-block pair 2 (G & 1) + {0, 1}.  Staging and read-back as above: row = 128 B, 16-byte
 // chunk XOR (row & 7); the lane's four columns are 8 bytes at chunk 2 fjl + (lane >> 5), half (lane >> 4) & 1.
 // The accumulator-initialising rank-2 product needs one MFMA per 16 x 16 tile (64, under the last patch's stores).
-template <typename T, int ACT, int LNF>
+//
+// TRAIN (round 5): the training forward's FFN1 (train.hip) -- erf-GELU whose backward factor gelu'(v) goes to the tape
+// (OM_ACT_PRE_GRAD) -- writes TWO tensors per tile: C = gelu(v) and ep.pre_act = gelu'(v) (ldp == ldc).  Generation 6 wrote the
+// second one as 4-byte scattered stores from the accumulator layout (32 rows per instruction: 120 us per launch at 9 216 x 3072 x 768
+// against ~60 for the contraction itself, profiles/r04_train_kernel_stats_v0.csv).  Here one evaluation of the polynomial yields both
+// values; the staging patch is used twice per patch -- "virtual patch" 2 P is gelu of patch P, 2 P + 1 its gelu' (kept packed in 16
+// registers from the conversion until its turn; a wave's LDS operations execute in order) -- and both leave as whole 128-byte lines.
+template <typename T, int ACT, int LNF, bool TRAIN = false>
 __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c16(
     const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, T* C, int64_t ldc,
     int64_t M, int64_t N, int64_t K, GemmEpilogue ep, int group_m) {
@@ -805,6 +614,8 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c16(
   typedef typename MmaOps<T>::frag_t frag_t;
   static_assert(sizeof(T) == 2, "16-bit in, 16-bit out");
   static_assert(LNF == 0 || LNF == 1, "no residual: plain or LayerNorm-folded A operand");
+  static_assert(!TRAIN || (ACT == OM_ACT_GELU_ERF && LNF == 0), "two-output form: erf-GELU + gelu' only");
+  constexpr int NVP = TRAIN ? 16 : 8;          // virtual patches per wave tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -848,19 +659,22 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c16(
     const int64_t pmc = pm + wm * 128, pnc = pn + wn * 128;
     const char* const st_rd = sp + (lane >> 3) * 128;
     char* const cbase = (char*)(C + pmc * ldc + pnc);
+    char* const pbase = TRAIN ? (char*)((OutT*)ep.pre_act + pmc * ldc + pnc) : cbase;      // second output (ldp == ldc: the launcher checks)
     const uint32_t coff = (uint32_t)((lane >> 3) * ldc2) + (lane & 7) * 16;
     uint4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+    uint32_t gk[16];                                       // TRAIN: the patch's packed gelu' values, quarter G at gk[4 G .. 4 G + 3]
 
+    // quarter G_ of patch P_: convert (and, TRAIN, keep gelu') and stage the first output
 #define G7C_WRITE_Q(P_, G_)                                                                                    \
   do {                                                                                                         \
     constexpr int MI = (P_) >> 1, NH = (P_) & 1, TI = 2 * MI + ((G_) >> 1), FJ0 = 4 * NH + 2 * ((G_) & 1);     \
     if ((G_) == 0) { _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) asm volatile("" : "+a"(acc[2 * MI + (u_ >> 2)][4 * NH + (u_ & 3)])); } \
     const int rr = ((G_) >> 1) * 16 + l15;                           /* row of the 32-row patch */             \
     const int64_t m = pmc + MI * 32 + rr;                                                                      \
-    f32x8_t v8;                                                                                                \
+    f32x8_t v8, g8;                                                                                            \
     _Pragma("unroll") for (int e = 0; e < 8; ++e) v8[e] = acc[TI][FJ0 + (e >> 2)][e & 3];                      \
     if (LNF == 1) v8 *= rs[TI];                                                                                \
-    if (ACT == OM_ACT_GELU_ERF) v8 = gelu_erf_poly8(v8);                                                       \
+    if (ACT == OM_ACT_GELU_ERF) { if (TRAIN) v8 = gelu_erf_poly8_both(v8, g8); else v8 = gelu_erf_poly8(v8); } \
     _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                         \
       f32x2_t lo_ = {v8[4 * jj], v8[4 * jj + 1]}, hi_ = {v8[4 * jj + 2], v8[4 * jj + 3]};                      \
       if (ACT != OM_ACT_GELU_ERF) {                                                                            \
@@ -869,41 +683,79 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c16(
         hi_ = epi_pair<ACT, false, OutT>(hi_, m, n + 2, M, N, ep, es, 0, 0);                                   \
       }                                                                                                        \
       const uint2 pk_ = make_uint2(Half16<OutT>::pack2(lo_[0], lo_[1]), Half16<OutT>::pack2(hi_[0], hi_[1]));  \
+      if (TRAIN) {                                                                                             \
+        gk[4 * (G_) + 2 * jj] = Half16<OutT>::pack2(g8[4 * jj], g8[4 * jj + 1]);                               \
+        gk[4 * (G_) + 2 * jj + 1] = Half16<OutT>::pack2(g8[4 * jj + 2], g8[4 * jj + 3]);                       \
+      }                                                                                                        \
       const int c_ = (2 * ((G_) & 1) + jj) * 2 + (q4 >> 1);          /* 16-byte chunk of the patch row */       \
       *(uint2*)(sp + G7E_ROW(rr) + ((c_ ^ (rr & 7)) << 4) + 8 * (q4 & 1)) = pk_;                               \
     }                                                                                                          \
   } while (0)
+    // TRAIN: quarter G_ of the kept gelu' values into the staging patch (second use of it for this patch)
+#define G7C_STAGE_GK(G_)                                                                                       \
+  do {                                                                                                         \
+    const int rr = ((G_) >> 1) * 16 + l15;                                                                     \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                         \
+      const int c_ = (2 * ((G_) & 1) + jj) * 2 + (q4 >> 1);                                                    \
+      *(uint2*)(sp + G7E_ROW(rr) + ((c_ ^ (rr & 7)) << 4) + 8 * (q4 & 1)) = make_uint2(gk[4 * (G_) + 2 * jj], gk[4 * (G_) + 2 * jj + 1]); \
+    }                                                                                                          \
+  } while (0)
+    // virtual patch VP_: patch VP_ itself, or (TRAIN) output VP_ & 1 of patch VP_ >> 1
+#define G7C_WRITE_V(VP_, G_)                                                                                   \
+  do {                                                                                                         \
+    if constexpr (!TRAIN) G7C_WRITE_Q(((VP_) & 7), G_);                                                        \
+    else if constexpr (((VP_) & 1) == 0) G7C_WRITE_Q((((VP_) >> 1) & 7), G_);                                  \
+    else G7C_STAGE_GK(G_);                                                                                     \
+  } while (0)
 #define G7C_RB(I4) (*(const uint4*)(st_rd + (I4) * 4096 + (((lane & 7) ^ (((lane >> 3) + (I4) * 8) & 7)) << 4)))
 #ifdef G7E_STORE16U
-#define G7C_ST(PP, I4, V) G7E_STORE16U(cbase + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128, coff, V)
+#define G7C_STB(BASE, PP, I4, V) G7E_STORE16U((BASE) + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128, coff, V)
 #else
-#define G7C_ST(PP, I4, V) G7E_STORE16(cbase + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128 + coff, V)
+#define G7C_STB(BASE, PP, I4, V) G7E_STORE16((BASE) + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128 + coff, V)
 #endif
+#define G7C_ST(VP_, I4, V)                                                                                     \
+  do {                                                                                                         \
+    if constexpr (!TRAIN) G7C_STB(cbase, VP_, I4, V);                                                          \
+    else if constexpr (((VP_) & 1) == 0) G7C_STB(cbase, (VP_) >> 1, I4, V);                                    \
+    else G7C_STB(pbase, (VP_) >> 1, I4, V);                                                                    \
+  } while (0)
 #define G7C_ITER(P_, C0, C1, C2, C3, N0, N1, N2, N3)                                                           \
   do {                                                                                                         \
-    if ((P_) + 1 < 8) {                                                                                        \
-      G7C_WRITE_Q((P_) + 1, 0); G7_FENCE_(); G7C_ST(P_, 0, C0); G7_FENCE_();                                   \
-      G7C_WRITE_Q((P_) + 1, 1); G7_FENCE_(); G7C_ST(P_, 1, C1); G7_FENCE_();                                   \
-      G7C_WRITE_Q((P_) + 1, 2); G7_FENCE_(); G7C_ST(P_, 2, C2); G7_FENCE_();                                   \
-      G7C_WRITE_Q((P_) + 1, 3); G7_FENCE_();                                                                   \
+    if constexpr ((P_) + 1 < NVP) {                                                                            \
+      G7C_WRITE_V((P_) + 1, 0); G7_FENCE_(); G7C_ST(P_, 0, C0); G7_FENCE_();                                   \
+      G7C_WRITE_V((P_) + 1, 1); G7_FENCE_(); G7C_ST(P_, 1, C1); G7_FENCE_();                                   \
+      G7C_WRITE_V((P_) + 1, 2); G7_FENCE_(); G7C_ST(P_, 2, C2); G7_FENCE_();                                   \
+      G7C_WRITE_V((P_) + 1, 3); G7_FENCE_();                                                                   \
       N0 = G7C_RB(0); N1 = G7C_RB(1); N2 = G7C_RB(2); N3 = G7C_RB(3);                                          \
       G7_FENCE_(); G7C_ST(P_, 3, C3); G7_FENCE_();                                                             \
     } else {                                                                                                   \
       G7C_ST(P_, 0, C0); G7C_ST(P_, 1, C1); G7C_ST(P_, 2, C2); G7C_ST(P_, 3, C3); G7_FENCE_();                 \
     }                                                                                                          \
   } while (0)
+#define G7C_SA sa0, sa1, sa2, sa3
+#define G7C_SB sb0, sb1, sb2, sb3
+#define G7C_ITER_(...) G7C_ITER(__VA_ARGS__)
 
     if (live) {
-      G7C_WRITE_Q(0, 0); G7C_WRITE_Q(0, 1); G7C_WRITE_Q(0, 2); G7C_WRITE_Q(0, 3);
+      G7C_WRITE_V(0, 0); G7C_WRITE_V(0, 1); G7C_WRITE_V(0, 2); G7C_WRITE_V(0, 3);
       G7_FENCE_();
       sa0 = G7C_RB(0); sa1 = G7C_RB(1); sa2 = G7C_RB(2); sa3 = G7C_RB(3);
       G7_FENCE_();
-      G7C_ITER(0, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
-      G7C_ITER(1, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
-      G7C_ITER(2, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
-      G7C_ITER(3, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
-      G7C_ITER(4, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
-      G7C_ITER(5, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+      G7C_ITER_(0, G7C_SA, G7C_SB);
+      G7C_ITER_(1, G7C_SB, G7C_SA);
+      G7C_ITER_(2, G7C_SA, G7C_SB);
+      G7C_ITER_(3, G7C_SB, G7C_SA);
+      G7C_ITER_(4, G7C_SA, G7C_SB);
+      G7C_ITER_(5, G7C_SB, G7C_SA);
+      if constexpr (TRAIN) {
+        G7C_ITER_(6, G7C_SA, G7C_SB);
+        G7C_ITER_(7, G7C_SB, G7C_SA);
+        G7C_ITER_(8, G7C_SA, G7C_SB);
+        G7C_ITER_(9, G7C_SB, G7C_SA);
+        G7C_ITER_(10, G7C_SA, G7C_SB);
+        G7C_ITER_(11, G7C_SB, G7C_SA);
+        G7C_ITER_(12, G7C_SA, G7C_SB);
+      }
     }
     // ---- the next tile's initialising fragments: u_m b_n + v_m s_n as ONE 16 x 16 x 32 MFMA per tile, factors split into
     // 16-bit hi + lo in k slots 0-5 of k block 0 (lanes 0-15); the other k blocks are zero
@@ -943,7 +795,9 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c16(
         fb[fj] = __builtin_bit_cast(frag_t, w);
       }
     }
-    if (live) G7C_ITER(6, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);     // converts patch 7: the last reader of the accumulators
+    if (live) {                                  // converts the last patch: the last reader of the accumulators
+      if constexpr (TRAIN) G7C_ITER_(13, G7C_SB, G7C_SA); else G7C_ITER_(6, G7C_SA, G7C_SB);
+    }
     if (have) {
       const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -952,12 +806,19 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c16(
 #pragma unroll
     for (int q = 0; q < 64; ++q) asm volatile("" : "+a"(acc[q >> 3][q & 7]));
     if (live) {
-      G7C_ITER(7, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+      if constexpr (TRAIN) { G7C_ITER_(14, G7C_SA, G7C_SB); G7C_ITER_(15, G7C_SB, G7C_SA); }
+      else G7C_ITER_(7, G7C_SB, G7C_SA);
       if (tr_prev && threadIdx.x == 0) { tr_prev[28] = clock64(); tr_prev[29] = blockIdx.x; tr_prev[31] = wall_clock64(); }
     }
+#undef G7C_ITER_
+#undef G7C_SB
+#undef G7C_SA
 #undef G7C_ITER
 #undef G7C_ST
+#undef G7C_STB
 #undef G7C_RB
+#undef G7C_WRITE_V
+#undef G7C_STAGE_GK
 #undef G7C_WRITE_Q
     if (!have) break;
     if (!live) __builtin_amdgcn_s_barrier();     // first pass: K step 0 (waited for above) is published to the other waves
@@ -1000,284 +861,6 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c16(
 //                                      ring.bn (the unit A(nk - 1) left)      slices 0-3 residual slot 1, 4-7 slot 2
 //                                      ring.sp (the unit B(nk - 1) left)      slices 0-3 staging patch
 // (slice i of a unit = this wave's i-th own KiB, at unit + (4 i + wave) KiB: no wave touches another wave's slices.)
-template <typename T, int ACT, int LNF>
-__global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r(
-    const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, T* C, int64_t ldc,
-    int64_t M, int64_t N, int64_t K, GemmEpilogue ep, int group_m) {
-  typedef T OutT;
-  typedef typename MmaOps<T>::frag_t frag_t;
-  static_assert(sizeof(T) == 2, "16-bit in, 16-bit out");
-  static_assert(LNF == 0 || LNF == 2, "residual variants: plain, or output-side LayerNorm on a one-plane residual stream");
-  constexpr bool LNO = LNF == 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane0 = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int64_t ntm = M / 256, ntn = N / 256;
-  const int nk = (int)((K * 2) / G7_ROW_BYTES);
-  const EpiScalars es(ep);
-  const uint32_t lds_base = g7_lds_addr(smem);
-
-  int it = 0;
-  int64_t m0, n0;
-  if (!g7_tile(0, ntm, ntn, group_m, m0, n0)) return;
-  G7SrcU src;
-  g7_offsets_u<T>(src, lda, ldb, wave, lane0);
-  G7Ring ring;
-  g7_ring_reset(ring);
-  const char* cur_a = (const char*)(A + m0 * lda);
-  const char* cur_b = (const char*)(B + n0 * ldb);
-  g7_fill_a(src, cur_a, smem + ring.ac, wave);
-  g7_fill_b(src, cur_b, smem + ring.bc, wave);
-  g7_fill_a(src, cur_a + G7_ROW_BYTES, smem + ring.an, wave);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) g7_issue_b(src, cur_b + G7_ROW_BYTES, i, lds_base + ring.bn + (i * 4 + wave) * 1024);
-  // first tile: its s_n | b_n table goes to the spare unit (later tiles find theirs in ring.an, fetched by the previous K loop)
-  g7_table2((const float*)A, ep.bias ? ep.bias + n0 + wn * 128 : (const float*)A, smem + ring.sp + (6 * 4 + wave) * 1024, lane0);
-
-  bool live = false, have = true;
-  int64_t pm = m0, pn = n0;
-  f32x16_t acc[4][4];
-  unsigned long long* tr_prev = nullptr;
-  size_t ldc2 = (size_t)ldc * sizeof(OutT), ldr2 = (size_t)ep.ldr * sizeof(OutT);
-  asm volatile("" : "+s"(ldc2), "+s"(ldr2));
-
-  for (;;) {
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const int l31 = lane & 31, half = lane >> 5;
-    const int64_t pmc = pm + wm * 128, pnc = pn + wn * 128;
-    char* const an0 = smem + ring.an + wave * 1024;          // slice i at + i * 4096
-    char* const bn0 = smem + ring.bn + wave * 1024;
-    char* const sp0 = smem + ring.sp + wave * 1024;
-    const char* const etab0 = an0 + 4 * 4096;                 // gamma | beta
-    const char* const etab1 = an0 + 5 * 4096;                 // (sum, sum of squares) of my 128 residual rows
-    const char* const tab0 = (live ? an0 : sp0) + 6 * 4096;   // s_n | b_n of the tile about to start
-    const bool res_ln = LNO && ep.rln_stats != nullptr;
-    const char* const rbase = (const char*)((const OutT*)ep.resid + pmc * ep.ldr + pnc);     // wave-uniform
-    uint32_t roff[4];                                         // row (lane >> 3) of an 8-row group, swizzled source chunk
-#pragma unroll
-    for (int k = 0; k < 4; ++k) roff[k] = (uint32_t)((lane >> 3) * ldr2) + (((lane & 7) ^ ((4 * k + (lane >> 4)) & 7)) << 4);
-    float ra[4] = {1.f, 1.f, 1.f, 1.f}, rc[4] = {0.f, 0.f, 0.f, 0.f};
-    f32x2_t ssum = {0.f, 0.f}, ssq = {0.f, 0.f};
-    frag_t fa[4], fb[4];
-    const int skey = l31 & 7;
-    char* const st_wr = sp0 + G7E_ROW(l31) + 8 * half;
-    const char* const st_rd = sp0 + (lane >> 3) * 128;
-    char* const cbase = (char*)(C + pmc * ldc + pnc);
-    const uint32_t coff = (uint32_t)((lane >> 3) * ldc2) + (lane & 7) * 16;
-    float2* const stat_slot = LNO ? (float2*)ep.stats_out + ((pn >> 8) * 2 + wn) * M : nullptr;
-    uint4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
-
-    // residual patch P_ = (mi, nh): 32 rows x 128 B; ring slot P_ % 3
-#define G7R_SLOT(P_) (((P_) % 3) == 0 ? an0 : (((P_) % 3) == 1 ? bn0 : bn0 + 4 * 4096))
-#define G7R_RES_DMA(P_)                                                                                        \
-  do {                                                                                                         \
-    const size_t poff = (size_t)(((P_) >> 1) * 32) * ldr2 + ((P_) & 1) * 128;                                  \
-    const uint32_t buf = g7_lds_addr(G7R_SLOT(P_));                                                            \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k) g7_dma(rbase + poff + (size_t)(8 * k) * ldr2, roff[k], buf + k * 4096); \
-  } while (0)
-    // quarter G_ of patch P_: eight accumulator registers per lane (columns nl = G_ >> 1, j = 2 (G_ & 1) + {0, 1})
-#define G7R_WRITE_Q(P_, G_)                                                                                    \
-  do {                                                                                                         \
-    constexpr int MI = (P_) >> 1, NH = (P_) & 1, NL = (G_) >> 1, NI = NH * 2 + NL, JP = (G_) & 1;              \
-    if ((G_) == 0) asm volatile("" : "+a"(acc[MI][NH * 2]), "+a"(acc[MI][NH * 2 + 1]));                        \
-    const int64_t m = pmc + MI * 32 + l31;                                                                     \
-    const char* buf = G7R_SLOT(P_) + G7E_ROW(l31) + 8 * half;                                                  \
-    const uint2 ra_ = *(const uint2*)(buf + (((NL * 4 + 2 * JP) ^ ((l31 >> 1) & 7)) << 4));                    \
-    const uint2 rb_ = *(const uint2*)(buf + (((NL * 4 + 2 * JP + 1) ^ ((l31 >> 1) & 7)) << 4));                \
-    f32x8_t v8;                                                                                                \
-    _Pragma("unroll") for (int e = 0; e < 8; ++e) v8[e] = acc[MI][NI][8 * JP + e];                             \
-    f32x8_t r8 = {Half16<OutT>::lo(ra_.x), Half16<OutT>::hi(ra_.x), Half16<OutT>::lo(ra_.y), Half16<OutT>::hi(ra_.y), \
-                  Half16<OutT>::lo(rb_.x), Half16<OutT>::hi(rb_.x), Half16<OutT>::lo(rb_.y), Half16<OutT>::hi(rb_.y)}; \
-    if (LNO) {                                                                                                 \
-      if (res_ln) {                                                                                            \
-        const int c0 = NI * 32 + 16 * JP + 4 * half;                /* columns c0 .. c0 + 3 and c0 + 8 .. c0 + 11 */ \
-        const f32x4_t ga = *(const f32x4_t*)(etab0 + c0 * 4), gb = *(const f32x4_t*)(etab0 + (c0 + 8) * 4);     \
-        const f32x4_t ba = *(const f32x4_t*)(etab0 + 512 + c0 * 4), bb = *(const f32x4_t*)(etab0 + 512 + (c0 + 8) * 4); \
-        const f32x8_t g8 = __builtin_shufflevector(ga, gb, 0, 1, 2, 3, 4, 5, 6, 7);                            \
-        const f32x8_t b8 = __builtin_shufflevector(ba, bb, 0, 1, 2, 3, 4, 5, 6, 7);                            \
-        r8 = __builtin_elementwise_fma(__builtin_elementwise_fma(r8, (f32x8_t)(ra[MI]), (f32x8_t)(rc[MI])), g8, b8); \
-      }                                                                                                        \
-      v8 += r8;                                                                                                \
-      ssum[0] += (v8[0] + v8[1]) + (v8[2] + v8[3]); ssum[1] += (v8[4] + v8[5]) + (v8[6] + v8[7]);              \
-      const f32x8_t q8 = v8 * v8;                                                                              \
-      ssq[0] += (q8[0] + q8[1]) + (q8[2] + q8[3]); ssq[1] += (q8[4] + q8[5]) + (q8[6] + q8[7]);                \
-    } else {                                                                                                   \
-      _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                       \
-        const int64_t n = pnc + NI * 32 + 8 * (2 * JP + jj) + 4 * half;                                        \
-        f32x2_t lo_ = {v8[4 * jj], v8[4 * jj + 1]}, hi_ = {v8[4 * jj + 2], v8[4 * jj + 3]};                    \
-        lo_ = epi_pair<ACT, false, OutT>(lo_, m, n, M, N, ep, es, 0, 0);                                       \
-        hi_ = epi_pair<ACT, false, OutT>(hi_, m, n + 2, M, N, ep, es, 0, 0);                                   \
-        if (es.mul) { lo_[0] *= r8[4 * jj]; lo_[1] *= r8[4 * jj + 1]; hi_[0] *= r8[4 * jj + 2]; hi_[1] *= r8[4 * jj + 3]; } \
-        else {                                                                                                 \
-          lo_[0] = epi_resid<ACT, true>(lo_[0], r8[4 * jj], false); lo_[1] = epi_resid<ACT, true>(lo_[1], r8[4 * jj + 1], false);       \
-          hi_[0] = epi_resid<ACT, true>(hi_[0], r8[4 * jj + 2], false); hi_[1] = epi_resid<ACT, true>(hi_[1], r8[4 * jj + 3], false);   \
-        }                                                                                                      \
-        v8[4 * jj] = lo_[0]; v8[4 * jj + 1] = lo_[1]; v8[4 * jj + 2] = hi_[0]; v8[4 * jj + 3] = hi_[1];        \
-      }                                                                                                        \
-    }                                                                                                          \
-    const uint2 pa_ = make_uint2(Half16<OutT>::pack2(v8[0], v8[1]), Half16<OutT>::pack2(v8[2], v8[3]));        \
-    const uint2 pb_ = make_uint2(Half16<OutT>::pack2(v8[4], v8[5]), Half16<OutT>::pack2(v8[6], v8[7]));        \
-    *(uint2*)(st_wr + (((NL * 4 + 2 * JP) ^ skey) << 4)) = pa_;                                                \
-    *(uint2*)(st_wr + (((NL * 4 + 2 * JP + 1) ^ skey) << 4)) = pb_;                                            \
-    if (LNO && NH == 1 && (G_) == 3) {     /* both column halves of the row block done: this wave's partial sums of the row */ \
-      float s1 = ssum[0] + ssum[1], s2 = ssq[0] + ssq[1];                                                      \
-      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);                                              \
-      if (half == 0) stat_slot[m] = make_float2(s1, s2);                                                       \
-      ssum = (f32x2_t){0.f, 0.f}; ssq = (f32x2_t){0.f, 0.f};                                                   \
-    }                                                                                                          \
-  } while (0)
-#define G7R_RB(I4) (*(const uint4*)(st_rd + (I4) * 4096 + (((lane & 7) ^ (((lane >> 3) + (I4) * 8) & 7)) << 4)))
-#ifdef G7E_STORE16U
-#define G7R_ST(PP, I4, V) G7E_STORE16U(cbase + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128, coff, V)
-#else
-#define G7R_ST(PP, I4, V) G7E_STORE16(cbase + (size_t)(((PP) >> 1) * 32 + (I4) * 8) * ldc2 + ((PP) & 1) * 128 + coff, V)
-#endif
-    // iteration P_: fetch residual patch P_ + 3 into the slot patch P_ left, wait for patch P_ + 1 (vmcnt retires in order:
-    // YWAIT = operations issued after its fetch, the row-statistics stores NOT counted -- a wait can only be stricter for it),
-    // convert it in quarters with one store of patch P_ behind each, read it back
-#define G7R_ITER(P_, YWAIT, C0, C1, C2, C3, N0, N1, N2, N3)                                                    \
-  do {                                                                                                         \
-    if (tr_prev && threadIdx.x == 0) tr_prev[17 + (P_)] = clock64();                                           \
-    if ((P_) + 1 < 8) {                                                                                        \
-      if ((P_) + 3 < 8) G7R_RES_DMA((P_) + 3);                                                                 \
-      G7_WAIT_VM(YWAIT);                                                                                       \
-      G7R_WRITE_Q((P_) + 1, 0); G7_FENCE_(); G7R_ST(P_, 0, C0); G7_FENCE_();                                   \
-      G7R_WRITE_Q((P_) + 1, 1); G7_FENCE_(); G7R_ST(P_, 1, C1); G7_FENCE_();                                   \
-      G7R_WRITE_Q((P_) + 1, 2); G7_FENCE_(); G7R_ST(P_, 2, C2); G7_FENCE_();                                   \
-      G7R_WRITE_Q((P_) + 1, 3); G7_FENCE_();                                                                   \
-      N0 = G7R_RB(0); N1 = G7R_RB(1); N2 = G7R_RB(2); N3 = G7R_RB(3);                                          \
-      G7_FENCE_(); G7R_ST(P_, 3, C3); G7_FENCE_();                                                             \
-    } else {                                                                                                   \
-      G7R_ST(P_, 0, C0); G7R_ST(P_, 1, C1); G7R_ST(P_, 2, C2); G7R_ST(P_, 3, C3); G7_FENCE_();                 \
-    }                                                                                                          \
-  } while (0)
-
-    if (live) {
-      G7R_RES_DMA(2);                          // patches 0 and 1 and the tables were fetched by the K loop's last step
-      G7_WAIT_VM(8);                           // ... and have landed: only patches 1 and 2 are younger
-      if (res_ln) {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-          const float2 st = *(const float2*)(etab1 + (mi * 32 + l31) * 8);
-          const float mu = st.x * ep.ln_inv_h;
-          const float rstd = rsqrtf(fmaxf(st.y * ep.ln_inv_h - mu * mu, 0.f) + ep.ln_eps);
-          ra[mi] = rstd; rc[mi] = -mu * rstd;
-        }
-      }
-      if (tr_prev && threadIdx.x == 0) tr_prev[16] = clock64();
-      G7R_WRITE_Q(0, 0); G7R_WRITE_Q(0, 1); G7R_WRITE_Q(0, 2); G7R_WRITE_Q(0, 3);
-      G7_FENCE_();
-      sa0 = G7R_RB(0); sa1 = G7R_RB(1); sa2 = G7R_RB(2); sa3 = G7R_RB(3);
-      G7_FENCE_();
-      G7R_ITER(0, 8, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);        // younger than patch 1: patch 2, patch 3
-      G7R_ITER(1, 12, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);       // patch 3, stores of 0, patch 4
-      G7R_ITER(2, 16, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);       // stores of 0, patch 4, stores of 1, patch 5
-      G7R_ITER(3, 16, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
-      G7R_ITER(4, 16, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
-      G7R_ITER(5, 12, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);       // stores of 3, patch 7, stores of 4
-    }
-    // ---- the next tile's initialising fragments (bias only: these variants have no folded A operand)
-    if (have) {
-      if (!live) G7_WAIT_VM(0);                // first pass: its table and K step 0 (a later tile's table is older than its residual patch 0)
-      const bool has_b = ep.bias != nullptr;
-      auto split = [](float x, uint32_t& hi, uint32_t& lo) {
-        hi = Half16<T>::bits(x); lo = Half16<T>::bits(x - Half16<T>::value(hi));
-      };
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        uint32_t uh, ul;
-        split(1.f, uh, ul);
-        uint4 w = make_uint4(uh | (ul << 16), uh, 0u, 0u);              // k: u_hi u_lo u_hi 0 ...
-        if (half) w = make_uint4(0u, 0u, 0u, 0u);
-        asm volatile("" : "+v"(w.x), "+v"(w.y));                        // opaque per row block: 16 MFMAs, not 4 + 192 accumulator moves
-        fa[mi] = __builtin_bit_cast(frag_t, w);
-      }
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        float b = *(const float*)(tab0 + 512 + (ni * 32 + l31) * 4);
-        if (!has_b) b = 0.f;
-        uint32_t bh, bl;
-        split(b, bh, bl);
-        uint4 w = make_uint4(bh | (bh << 16), bl, 0u, 0u);              // k: b_hi b_hi b_lo 0 ...
-        if (half) w = make_uint4(0u, 0u, 0u, 0u);
-        fb[ni] = __builtin_bit_cast(frag_t, w);
-      }
-    }
-    if (live) {
-      G7R_ITER(6, 8, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);          // stores of 4, stores of 5; converts patch 7, the last reader of acc
-      // every ring slot and table of this epilogue has been read: A(1) and the first half of B(1) of the next tile
-      if (have) {
-        g7_fill_a(src, cur_a + G7_ROW_BYTES, smem + ring.an, wave);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) g7_issue_b(src, cur_b + G7_ROW_BYTES, i, lds_base + ring.bn + (i * 4 + wave) * 1024);
-      }
-    }
-    if (have) {
-      const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int q = 0; q < 16; ++q) { acc[q >> 2][q & 3] = zero; MmaOps<T>::mma(fb[q & 3], fa[q >> 2], acc[q >> 2][q & 3]); }
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) asm volatile("" : "+a"(acc[q >> 2][q & 3]));
-    if (live) {
-      G7R_ITER(7, 0, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
-      if (tr_prev && threadIdx.x == 0) { tr_prev[28] = clock64(); tr_prev[29] = blockIdx.x; tr_prev[31] = wall_clock64(); }
-    }
-#undef G7R_ITER
-#undef G7R_ST
-#undef G7R_RB
-#undef G7R_WRITE_Q
-#undef G7R_RES_DMA
-#undef G7R_SLOT
-    if (!have) break;
-    if (!live) __builtin_amdgcn_s_barrier();     // first pass: K step 0 (waited for above) is published to the other waves
-
-    // ---- the tile after this one
-    ++it;
-    int64_t m1 = m0, n1 = n0;
-    const bool has_next = g7_tile(it, ntm, ntn, group_m, m1, n1);
-    const char* const next_a = (const char*)(A + m1 * lda);
-    const char* const next_b = (const char*)(B + n1 * ldb);
-    unsigned long long* tr = nullptr;
-    if (ep.trace) {
-      const int64_t tile_id = (m0 / 256) * ntn + n0 / 256;
-      if (tile_id < 8192) tr = ep.trace + tile_id * 32;
-    }
-    if (tr && threadIdx.x == 0) { tr[0] = tr[1] = clock64(); tr[30] = wall_clock64(); }
-    {
-      // the last K step's twelve spare issue slots: this tile's epilogue tables and residual patches 0 and 1, the next tile's table
-      const int64_t mc = m0 + wm * 128, nc = n0 + wn * 128;
-      const char* const rb_ = (const char*)((const OutT*)ep.resid + mc * ep.ldr + nc);
-      const bool rln = LNO && ep.rln_stats != nullptr;
-      const float* const dummy = (const float*)A;
-      const float* const t_g = rln ? ep.rln_g + nc : dummy;
-      const float* const t_b = rln ? ep.rln_b + nc : dummy;
-      const float* const t_s = rln ? ep.rln_stats + mc * 2 : dummy;
-      const float* const t_bias = ep.bias ? ep.bias + n1 + wn * 128 : dummy;
-      uint32_t ro[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) ro[k] = (uint32_t)((lane0 >> 3) * ldr2) + (((lane0 & 7) ^ ((4 * k + (lane0 >> 4)) & 7)) << 4);
-      const int w1k = wave * 1024;
-      auto tail = [&](int slot, int u_spare, int u_olda) __attribute__((always_inline)) {
-        char* const s0 = smem + u_spare + w1k;               // own slices of the spare: 0-3 patch 0, 4 gamma | beta, 5 statistics, 6 next table
-        if (slot == 0) g7_table2(t_g, t_b, s0 + 4 * 4096, lane0);
-        else if (slot == 1) g7_table1(t_s, s0 + 5 * 4096, lane0);
-        else if (slot == 2 || slot == 3) g7_table2(dummy, t_bias, s0 + 6 * 4096, lane0);
-        else if (slot < 8) g7_dma(rb_ + (size_t)(8 * (slot - 4)) * ldr2, ro[slot - 4], g7_lds_addr(s0) + (slot - 4) * 4096);     // patch 0 = (mi 0, nh 0)
-        else g7_dma(rb_ + 128 + (size_t)(8 * (slot - 8)) * ldr2, ro[slot - 8], lds_base + u_olda + w1k + (slot - 8) * 4096);      // patch 1 = (mi 0, nh 1)
-      };
-      gemm_mainloop7_cont<T, true>(src, cur_a, cur_b, next_a, next_b, nk, smem, ring, acc, tr, tail);
-    }
-    if (tr && threadIdx.x == 0) tr[15] = clock64();
-    tr_prev = tr;
-    pm = m0; pn = n0; live = true;
-    cur_a = next_a; cur_b = next_b; m0 = m1; n0 = n1; have = has_next;
-  }
-  G7_WAIT_VM(0);
-}
-
 // =========================================================================================================================
 // Kernel 7r on 16 x 16 x 32 MFMAs (round 4, late): layout as kernel 7c16.  The last K step has sixteen tail slots: tables and
 // residual patch 0 behind sub-step 0 (into the spare unit), patches 1 and 2 behind sub-step 1 (into the unit A(nk - 1) leaves) --
@@ -1563,33 +1146,26 @@ static int g7_num_cus() {
   return n;
 }
 
-template <typename T, int ACT, int LNF>
+template <typename T, int ACT, int LNF, bool TRAIN = false>
 static int launch7c(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                     int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
   const int64_t ntiles = (M / 256) * (N / 256);
   if (ntiles >= 0x7fff0000LL) OM_FAIL("gemm: more than 2^31 output tiles");
+  if (TRAIN && (!ep.pre_act || ep.ldp != ldc || ep.drop_p > 0.f || !(ep.act & OM_ACT_PRE_GRAD) || ((uintptr_t)ep.pre_act & 15)))
+    OM_FAIL("two-output GELU epilogue: pre_act with ldp == ldc, OM_ACT_PRE_GRAD, no dropout");
   int grid = g7_num_cus();
   const int cap = om_option(OM_OPT_GEMM_MAX_GRID);
   if (cap > 0 && cap < grid) grid = cap;
   if (ntiles < grid) grid = (int)ntiles;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
-    OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel7c<T, ACT, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
+    OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel7c16<T, ACT, LNF, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
     attr_set = true;
   }
   const bool timing = om_timing_on();
   if (timing) om_timing_begin(OM_TIMING_GEMM_BF16, s);
   const int gm_arg = (std::max(1, om_option(OM_OPT_GEMM_GROUP_M)) & 0xffff) | (ep.reverse ? 1 << 16 : 0);
-  if (om_option(OM_OPT_GEMM_CONT) & 8) {           // bit 3: the 16 x 16 x 32 form
-    static std::atomic<bool> attr16{false};
-    if (!attr16) {
-      OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel7c16<T, ACT, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
-      attr16 = true;
-    }
-    hipLaunchKernelGGL((gemm_nt_kernel7c16<T, ACT, LNF>), dim3((unsigned)grid), dim3(G6_THREADS), G7_LDS_BYTES, s,
-                       (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, gm_arg);
-  } else
-  hipLaunchKernelGGL((gemm_nt_kernel7c<T, ACT, LNF>), dim3((unsigned)grid), dim3(G6_THREADS), G7_LDS_BYTES, s,
+  hipLaunchKernelGGL((gemm_nt_kernel7c16<T, ACT, LNF, TRAIN>), dim3((unsigned)grid), dim3(G6_THREADS), G7_LDS_BYTES, s,
                      (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, gm_arg);
   if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, 2.0 * (double)M * (double)N * (double)K);
   OM_LAUNCH_CHECK();
@@ -1607,22 +1183,13 @@ static int launch7r(const void* A, int64_t lda, const void* B, int64_t ldb, void
   if (ntiles < grid) grid = (int)ntiles;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
-    OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel7r<T, ACT, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
+    OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel7r16<T, ACT, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
     attr_set = true;
   }
   const bool timing = om_timing_on();
   if (timing) om_timing_begin(OM_TIMING_GEMM_BF16, s);
   const int gm_arg = (std::max(1, om_option(OM_OPT_GEMM_GROUP_M)) & 0xffff) | (ep.reverse ? 1 << 16 : 0);
-  if (om_option(OM_OPT_GEMM_CONT) & 8) {           // bit 3: the 16 x 16 x 32 form
-    static std::atomic<bool> attr16{false};
-    if (!attr16) {
-      OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel7r16<T, ACT, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
-      attr16 = true;
-    }
-    hipLaunchKernelGGL((gemm_nt_kernel7r16<T, ACT, LNF>), dim3((unsigned)grid), dim3(G6_THREADS), G7_LDS_BYTES, s,
-                       (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, gm_arg);
-  } else
-  hipLaunchKernelGGL((gemm_nt_kernel7r<T, ACT, LNF>), dim3((unsigned)grid), dim3(G6_THREADS), G7_LDS_BYTES, s,
+  hipLaunchKernelGGL((gemm_nt_kernel7r16<T, ACT, LNF>), dim3((unsigned)grid), dim3(G6_THREADS), G7_LDS_BYTES, s,
                      (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, gm_arg);
   if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, 2.0 * (double)M * (double)N * (double)K);
   OM_LAUNCH_CHECK();
@@ -1633,7 +1200,7 @@ template <typename T, int ACT, bool RESID, int LNF>
 static int launch7(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                    int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
   if constexpr (!RESID && LNF <= 1) {      // the continuous ring: needs three K steps (its prefetch reaches at most one tile ahead)
-    if (K * 2 >= 3 * G7_ROW_BYTES && om_option(OM_OPT_GEMM_CONT) != 0) return launch7c<T, ACT, LNF>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    if (K * 2 >= 3 * G7_ROW_BYTES && (om_option(OM_OPT_GEMM_CONT) & 1) != 0) return launch7c<T, ACT, LNF>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
   }
   if constexpr (RESID && (LNF == 0 || LNF == 2)) {      // one-plane residual variants on the continuous ring (bit 1 of the option)
     if (K * 2 >= 3 * G7_ROW_BYTES && (om_option(OM_OPT_GEMM_CONT) & 2) != 0) return launch7r<T, ACT, LNF>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);

@@ -54,3 +54,14 @@ int omk_gemm_wide7(bool persist, const void* A, int64_t lda, const void* B, int6
 #undef OM_L7
   OM_FAIL("no generation-7 kernel for this epilogue");
 }
+
+// The training forward's FFN1: C = gelu(A B^T + bias) and ep.pre_act = gelu'(A B^T + bias), both as whole lines (kernel 7c16, TRAIN)
+bool omk_gemm_wide7_train_ok(int64_t M, int64_t N, int64_t K, int64_t ldc, const GemmEpilogue& ep) {
+  return (om_option(OM_OPT_GEMM_CONT) & 32) && M % 256 == 0 && N % 256 == 0 && (K * 2) % G7_ROW_BYTES == 0 && K * 2 >= 3 * G7_ROW_BYTES &&
+         (ep.act & 0xff) == OM_ACT_GELU_ERF && (ep.act & OM_ACT_PRE_GRAD) && !(ep.act & OM_ACT_MUL_RESID) && ep.pre_act && ep.ldp == ldc &&
+         !ep.resid && ep.drop_p == 0.f && (((uintptr_t)ep.pre_act | (uintptr_t)ep.bias) & 15) == 0 && !ep.ln_stats && !ep.rln_stats && !ep.stats_out;
+}
+int omk_gemm_wide7_train(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                         int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
+  return launch7c<bf16_t, OM_ACT_GELU_ERF, 0, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+}

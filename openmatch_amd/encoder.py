@@ -61,10 +61,45 @@ class _Packed:
         self.weights = N.OmEncoderWeights()
         self.layers = None
 
-    def dev(self, t, dtype, device):
+    def dev(self, t, dtype, device, sources=None):
+        """Device copy of `t` in `dtype` (an alias of `t` itself when it already is that).  `sources`: the parameters the
+        buffer is made of, in row order (default: `t` itself when it is a parameter) -- recorded so that an optimizer which
+        updates the parameters in place can refresh the copy in the same pass (openmatch_amd/optim.py)."""
+        src = t
         t = t.detach().to(device=device, dtype=dtype).contiguous()
         self.keep.append(t)
+        if sources is None and isinstance(src, torch.nn.Parameter):
+            sources = [src]
+        if sources:
+            off = 0
+            for s_ in sources:
+                if t.data_ptr() + off * t.element_size() != s_.data_ptr():       # not an alias of the parameter's own storage
+                    _register_shadow(s_, self, t, off)
+                off += s_.numel()
         return t.data_ptr()
+
+
+# parameter -> the packed copies of it that live in some _Packed: [(weakref to the _Packed, buffer, element offset)]
+_SHADOWS = {}
+
+
+def _register_shadow(param, pk, buf, offset):
+    import weakref
+    key = id(param)
+    lst = _SHADOWS.setdefault(key, [])
+    lst[:] = [e for e in lst if e[0]() is not None and e[3]() is param]
+    lst.append((weakref.ref(pk), buf, int(offset), weakref.ref(param)))
+
+
+def shadows_of(param):
+    """Live packed copies of `param`: [(packed object, buffer tensor, element offset)]; a _Packed that was replaced in its
+    cache (or whose model is gone) no longer counts."""
+    out = []
+    for ref, buf, off, pref in _SHADOWS.get(id(param), ()):
+        pk = ref()
+        if pk is not None and pref() is param and not getattr(pk, "retired", False):
+            out.append((pk, buf, off))
+    return out
 
 
 def _arch_of(model):
@@ -130,8 +165,8 @@ def _pack_bert(model, code, device):
         at, lw = layer.attention, layers[i]
         qkv_w = torch.cat([at.self.query.weight, at.self.key.weight, at.self.value.weight], 0)
         qkv_b = torch.cat([at.self.query.bias, at.self.key.bias, at.self.value.bias], 0)
-        lw.qkv_w = pk.dev(qkv_w, wd, device)
-        lw.qkv_b = pk.dev(qkv_b, f32, device)
+        lw.qkv_w = pk.dev(qkv_w, wd, device, [at.self.query.weight, at.self.key.weight, at.self.value.weight])
+        lw.qkv_b = pk.dev(qkv_b, f32, device, [at.self.query.bias, at.self.key.bias, at.self.value.bias])
         lw.o_w = pk.dev(at.output.dense.weight, wd, device)
         lw.o_b = pk.dev(at.output.dense.bias, f32, device)
         lw.ln1_g = pk.dev(at.output.LayerNorm.weight, f32, device)
@@ -171,7 +206,7 @@ def _pack_t5(model, code, device):
     gated = bool(getattr(cfg, "is_gated_act", False))
     for i, block in enumerate(enc.block):
         sa, ff, lw = block.layer[0].SelfAttention, block.layer[1].DenseReluDense, layers[i]
-        lw.qkv_w = pk.dev(torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], 0), wd, device)
+        lw.qkv_w = pk.dev(torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], 0), wd, device, [sa.q.weight, sa.k.weight, sa.v.weight])
         lw.o_w = pk.dev(sa.o.weight, wd, device)
         lw.ln1_g = pk.dev(block.layer[0].layer_norm.weight, f32, device)
         lw.ln2_g = pk.dev(block.layer[1].layer_norm.weight, f32, device)
@@ -215,7 +250,7 @@ def _pack_t5_decoder(model, code, device):
         lw.sa_o_w = pk.dev(sa.o.weight, wd, device)
         lw.sa_ln_g = pk.dev(block.layer[0].layer_norm.weight, f32, device)
         lw.ca_q_w = pk.dev(ca.q.weight, wd, device)
-        lw.ca_kv_w = pk.dev(torch.cat([ca.k.weight, ca.v.weight], 0), wd, device)
+        lw.ca_kv_w = pk.dev(torch.cat([ca.k.weight, ca.v.weight], 0), wd, device, [ca.k.weight, ca.v.weight])
         lw.ca_o_w = pk.dev(ca.o.weight, wd, device)
         lw.ca_ln_g = pk.dev(block.layer[1].layer_norm.weight, f32, device)
         if gated:
@@ -259,7 +294,10 @@ def packed_weights(model, head, code, device):
     hit = cache.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
+    if hit is not None:
+        hit[1].retired = True                   # its buffers are no longer anyone's weights: optimizers stop refreshing them
     pk = _pack_bert(model, code, device) if _arch_of(model) == "bert" else _pack_t5(model, code, device)
+    pk.owner_cache, pk.owner_key = cache, key
     if head is not None:
         lin = head.linear
         pk.weights.head_w = pk.dev(lin.weight, torch.float32, device)
@@ -287,6 +325,34 @@ def _ensure_folded(pk, device):
             N.check(lib.om_encoder_fold_weights(C.byref(cfg), C.byref(pk.weights), C.c_void_p(ptr), nfold, N.stream_ptr(device)))
         pk.keep.append(blob)
         pk.weights.folded = ptr
+
+
+def after_inplace_update(refreshed, stale):
+    """An optimizer rewrote parameters through raw pointers (no version bump).  `refreshed`: packed objects whose copies it
+    rewrote in the same pass -- they stay valid, only what was DERIVED from them (LayerNorm-folded inference weights) is
+    dropped; `stale`: packed objects it could not refresh -- evicted from their cache, re-packed on next use."""
+    for pk in refreshed:
+        if getattr(pk, "fold_done", False):
+            pk.fold_done = False
+            pk.weights.folded = None
+    for pk in stale:
+        pk.retired = True
+        cache, key = getattr(pk, "owner_cache", None), getattr(pk, "owner_key", None)
+        if cache is not None and cache.get(key, (None, None))[1] is pk:
+            del cache[key]
+
+
+def invalidate_packed(root):
+    """Drop every packed-weight cache under `root` (an nn.Module tree): the next HIP forward re-packs from the parameters.
+    For optimizers that update parameters without bumping their version counters (torch's fused AdamW does not) -- the
+    cache's freshness test cannot see those updates."""
+    for mod in root.modules():
+        for attr in (_PACK_CACHE_ATTR, _PACK_CACHE_ATTR + "_dec"):
+            cache = mod.__dict__.get(attr)
+            if cache:
+                for _ver, pk in cache.values():
+                    pk.retired = True
+                cache.clear()
 
 
 _POOL = {None: N.POOL_NONE, "first": N.POOL_FIRST, "mean": N.POOL_MEAN}
@@ -382,7 +448,10 @@ def packed_decoder_weights(model, code, device):
     ver = _version_key(model, None)
     hit = cache.get(key)
     if hit is None or hit[0] != ver:
+        if hit is not None:
+            hit[1].retired = True
         hit = (ver, _pack_t5_decoder(model, code, device))
+        hit[1].owner_cache, hit[1].owner_key = cache, key
         cache[key] = hit
     return hit[1]
 

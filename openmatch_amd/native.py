@@ -19,7 +19,7 @@ POOL_NONE, POOL_FIRST, POOL_MEAN = 0, 1, 2
 # om_debug_option switches used from Python (include/openmatch_hip.h: OM_OPT_*)
 OPT_TRAIN_WGRAD_BATCH, OPT_GEMM_MAX_GRID, OPT_GEMM_CONT = 14, 15, 16
 SEARCH_F32, SEARCH_F16_RESCORE = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_void_p, c_int, c_int64, c_float, c_size_t = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
@@ -68,6 +68,15 @@ class OmT5DecoderLayerGrads(C.Structure):
 
 class OmT5DecoderGrads(C.Structure):
     _fields_ = [("start_emb", c_void_p), ("final_ln_g", c_void_p), ("layers_host", C.POINTER(OmT5DecoderLayerGrads))]
+
+
+class OmAdamTensor(C.Structure):
+    """One parameter of an om_adamw_step launch (include/openmatch_hip.h)."""
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("shadow0", c_void_p), ("shadow1", c_void_p),
+                ("n", c_int64), ("weight_decay", c_float), ("shadow0_dtype", c_int), ("shadow1_dtype", c_int), ("reserved", c_int)]
+
+
+ADAM_CHUNK = 16384
 
 
 class OmLayerGrads(C.Structure):
@@ -155,6 +164,9 @@ _SIGNATURES = {
     "om_allgather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "om_allreduce_grads": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "om_exchange_topk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "om_grad_sqnorm": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "om_adamw_step": (c_int, [c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_int64, c_void_p, c_float, c_float,
+                              c_int, c_void_p]),
     "om_contrastive_fwd_bwd_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
                                           c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p]),

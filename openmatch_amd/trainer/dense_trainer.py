@@ -272,14 +272,47 @@ class DRTrainer:
     def create_optimizer_and_scheduler(self, num_training_steps: int):
         a = self.args
         if self.optimizer is None:
-            self.optimizer = torch.optim.AdamW(
-                parameter_groups(self.model, getattr(a, "weight_decay", 0.0)), lr=a.learning_rate,
-                betas=(getattr(a, "adam_beta1", 0.9), getattr(a, "adam_beta2", 0.999)),
-                eps=getattr(a, "adam_epsilon", 1e-8))
+            groups = parameter_groups(self.model, getattr(a, "weight_decay", 0.0))
+            kw = dict(lr=a.learning_rate, betas=(getattr(a, "adam_beta1", 0.9), getattr(a, "adam_beta2", 0.999)),
+                      eps=getattr(a, "adam_epsilon", 1e-8))
+            on_gpu = all(p.is_cuda and p.dtype == torch.float32 for g in groups for p in g["params"])
+            if on_gpu and any(g["params"] for g in groups):
+                # HF Trainer's AdamW + clip_grad_norm_(max_grad_norm) as ONE pass that also refreshes the packed 16-bit weights
+                from ..optim import FusedAdamW
+                self.optimizer = FusedAdamW(groups, max_grad_norm=float(getattr(a, "max_grad_norm", 0.0) or 0.0), **kw)
+            else:
+                self.optimizer = torch.optim.AdamW(groups, **kw)
         if self.lr_scheduler is None:
             warm = getattr(a, "warmup_steps", 0) or math.ceil(num_training_steps * getattr(a, "warmup_ratio", 0.0))
             self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(
                 self.optimizer, lambda s: linear_schedule_factor(s, warm, num_training_steps))
+
+    def optimizer_step(self, params=None, skip_storages=()):
+        """Everything between the last backward of a step and the next forward (HF Trainer.train's inner tail): gradient
+        averaging across ranks, clip_grad_norm_(max_grad_norm), optimizer.step, lr_scheduler.step, zero_grad.  With the default
+        optimizer (openmatch_amd.optim.FusedAdamW) clipping and the refresh of the packed 16-bit weights are part of its one
+        pass; any other optimizer is followed by a re-pack (torch's fused optimizers do not bump parameter versions, so the
+        packed-weight cache cannot see their updates)."""
+        a = self.args
+        W, _ = self._world()
+        if params is None:
+            params = [p for p in self.model.parameters() if p.requires_grad]
+        if W > 1:
+            allreduce_mean_(params, W, skip_storages=skip_storages)
+        from ..optim import FusedAdamW
+        max_norm = getattr(a, "max_grad_norm", 0.0)
+        if isinstance(self.optimizer, FusedAdamW):
+            self.optimizer.max_grad_norm = float(max_norm or 0.0)
+            self.optimizer.step()
+        else:
+            if max_norm and max_norm > 0:
+                torch.nn.utils.clip_grad_norm_(params, max_norm)
+            self.optimizer.step()
+            from ..encoder import invalidate_packed
+            invalidate_packed(self.model)
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
+        self.optimizer.zero_grad(set_to_none=True)
 
     def _num_steps(self, loader):
         a = self.args
@@ -345,14 +378,7 @@ class DRTrainer:
                 micro += 1
                 if micro % accum:
                     continue
-                if W > 1:
-                    allreduce_mean_(params, W, skip_storages=sync.reduced if sync is not None else ())
-                max_norm = getattr(a, "max_grad_norm", 0.0)
-                if max_norm and max_norm > 0:
-                    torch.nn.utils.clip_grad_norm_(params, max_norm)
-                self.optimizer.step()
-                self.lr_scheduler.step()
-                self.optimizer.zero_grad(set_to_none=True)
+                self.optimizer_step(params, skip_storages=sync.reduced if sync is not None else ())
                 self.state.global_step += 1
                 stepped = True
                 in_epoch += 1

@@ -220,8 +220,47 @@ def config1_spread(rng):
           "top-100 overlap %.1f (min %d); %d of %d queries have a top-10 relevant document separated by > %.2e of the scale; MRR@10 fp32 %.4f, float16 autocast %.4f"
           % (scale, float(out["score_std_rel"]), float(cos16.min()), noise, noise / scale, np.mean(ov16), np.min(ov16), in_top10, nq, thr / scale,
              float(out["mrr10_f32"]), float(out["mrr10_ac16"])))
+    _spread_uniform_qrels(out, run, run16, qry_ids)
     np.savez_compressed(os.path.join(OUT, "config1_spread.npz"), **out)
     print("wrote config1_spread.npz")
+
+
+def _spread_uniform_qrels(out, run, run16, qry_ids):
+    """A SECOND set of judgments on the spread fixture, drawn WITHOUT looking at score gaps (round 5): one relevant
+    document per query at a uniform reference rank in 1..10.  On these the reference's own float16 run does move MRR@10 (stored:
+    mrr10_ac16_uniform) -- the unconditioned yardstick next to the gap-conditioned gate above, which passes by construction for
+    anything at the reference's 16-bit noise level."""
+    rng = np.random.default_rng(SEED + 16)
+    eval_mrr = mg.reference_eval_mrr()
+    qrel = {}
+    for qid in qry_ids:
+        ranked = sorted(run[qid].items(), key=lambda kv: kv[1], reverse=True)
+        qrel[qid] = {ranked[int(rng.integers(0, 10))][0]: 1}
+    out["qrel_docs_uniform"] = np.array([list(qrel[q])[0] for q in qry_ids])
+    out["mrr10_f32_uniform"] = np.array(eval_mrr(qrel, run, cutoff=10)["all"])
+    out["mrr10_ac16_uniform"] = np.array(eval_mrr(qrel, run16, cutoff=10)["all"])
+    print("  spread fixture, unconditioned judgments (uniform rank 1..10): MRR@10 fp32 %.6f, reference float16 autocast %.6f (|d| %.6f)"
+          % (float(out["mrr10_f32_uniform"]), float(out["mrr10_ac16_uniform"]), abs(float(out["mrr10_f32_uniform"]) - float(out["mrr10_ac16_uniform"]))))
+
+
+def spread_qrels():
+    """Adds the unconditioned judgments to an existing config1_spread.npz from the reference embeddings stored in it (the
+    reference's Retriever.search is re-run on them: the same runs config1_spread() builds, without the two encoding passes)."""
+    path = os.path.join(OUT, "config1_spread.npz")
+    g = np.load(path, allow_pickle=False)
+    out = {k: g[k] for k in g.files}
+    doc_ids, qry_ids = [str(x) for x in out["doc_ids"]], [str(x) for x in out["qry_ids"]]
+    run, _ = reference_search(out["P_f32"], out["Q_f32"], doc_ids, qry_ids, 100)
+    I, _ = run_to_arrays(run, qry_ids, doc_ids)
+    assert np.array_equal(I, out["I100_f32"]), "the stored fp32 embeddings do not reproduce the stored run"
+    # the float16-autocast embeddings were stored rounded to 16 bits, so its run is rebuilt from the stored ranking itself
+    # (eval_mrr only orders a query's documents by score)
+    run16 = {q: {doc_ids[d]: -float(r) for r, d in enumerate(row)} for q, row in zip(qry_ids, out["I100_ac16"])}
+    assert abs(mg.reference_eval_mrr()({q: {str(d): 1} for q, d in zip(qry_ids, out["qrel_docs"])}, run16, cutoff=10)["all"]
+               - float(out["mrr10_ac16"])) < 1e-12
+    _spread_uniform_qrels(out, run, run16, qry_ids)
+    np.savez_compressed(path, **out)
+    print("updated config1_spread.npz")
 
 
 def gtr_base(rng):
@@ -239,10 +278,24 @@ def gtr_base(rng):
     for tag, ac in (("f32", False), ("ac", True)):
         out[f"P_{tag}"] = encode_all(ref, "passage", p_ids, p_mask, 32, ac)
         out[f"Q_{tag}"] = encode_all(ref, "query", q_ids, q_mask, 16, ac)
-    cos = torch.nn.functional.cosine_similarity(torch.from_numpy(out["P_f32"]).double(), torch.from_numpy(out["P_ac"]).double(), dim=1)
-    dd = np.abs(out["Q_ac"].astype(np.float64) @ out["P_ac"].astype(np.float64).T - out["Q_f32"].astype(np.float64) @ out["P_f32"].astype(np.float64).T)
-    out["ac_vs_f32"] = np.array([float(cos.min()), float(cos.mean()), float(dd.max())])
-    print("  GTR-base reference autocast vs fp32: min cos %.6f mean cos %.6f max|ddot| %.5f" % tuple(out["ac_vs_f32"]))
+    # the reference's REAL 16-bit mode is float16 autocast (retriever/dense_retriever.py:76,151: torch.cuda.amp.autocast());
+    # round 5 records it next to the bf16-autocast run.  T5 in float16 can overflow (HF clamps, modeling_t5.py:
+    # 467-474): non-finite rows are counted and the yardstick is taken over the finite ones.
+    out["P_ac16"] = encode_all(ref, "passage", p_ids, p_mask, 32, True, ac_dtype=torch.float16)
+    out["Q_ac16"] = encode_all(ref, "query", q_ids, q_mask, 16, True, ac_dtype=torch.float16)
+
+    def yard(Pa, Qa):
+        ok_p, ok_q = np.isfinite(Pa).all(1), np.isfinite(Qa).all(1)
+        cos = torch.nn.functional.cosine_similarity(torch.from_numpy(out["P_f32"][ok_p]).double(), torch.from_numpy(Pa[ok_p]).double(), dim=1)
+        dd = np.abs(Qa[ok_q].astype(np.float64) @ Pa[ok_p].astype(np.float64).T
+                    - out["Q_f32"][ok_q].astype(np.float64) @ out["P_f32"][ok_p].astype(np.float64).T)
+        return [float(cos.min()), float(cos.mean()), float(dd.max())], int((~ok_p).sum() + (~ok_q).sum())
+    out["ac_vs_f32"] = np.array(yard(out["P_ac"], out["Q_ac"])[0])
+    y16, bad16 = yard(out["P_ac16"], out["Q_ac16"])
+    out["ac16_vs_f32"] = np.array(y16)
+    out["ac16_nonfinite_rows"] = np.array(bad16)
+    print("  GTR-base reference bf16 autocast vs fp32: min cos %.6f mean cos %.6f max|ddot| %.5f" % tuple(out["ac_vs_f32"]))
+    print("  GTR-base reference float16 autocast vs fp32: min cos %.8f mean cos %.8f max|ddot| %.6f  (%d non-finite rows)" % (*y16, bad16))
     np.savez_compressed(os.path.join(OUT, "gtr_base.npz"), **out)
     print("wrote gtr_base.npz")
 
@@ -260,22 +313,25 @@ def bert_large_rr(rng):
     tt = np.zeros_like(ids)
     out = {"input_ids": ids.astype(np.uint16), "len": lengths(mask), "weight_checksum": checksum(lm),
            "head_w": head.linear.weight.detach().numpy()}
-    for tag, ac in (("f32", False), ("ac", True)):
+    # "ac16": float16 autocast, the reference's real `--fp16` mode (retriever/reranker.py:90-133 under torch.cuda.amp); "ac": bf16 autocast
+    for tag, ac in (("f32", None), ("ac", torch.bfloat16), ("ac16", torch.float16)):
         sc = []
         t0 = time.time()
         for s in range(0, n, 8):
             batch = {"input_ids": torch.from_numpy(ids[s:s + 8]), "attention_mask": torch.from_numpy(mask[s:s + 8]),
                      "token_type_ids": torch.from_numpy(tt[s:s + 8])}
             with torch.no_grad():
-                if ac:
-                    with torch.autocast("cpu", dtype=torch.bfloat16):
+                if ac is not None:
+                    with torch.autocast("cpu", dtype=ac):
                         sc.append(ref.encode(batch).float().numpy())
                 else:
                     sc.append(ref.encode(batch).float().numpy())
         out[f"scores_{tag}"] = np.concatenate(sc)[:, 0]
         print(f"    bert-large pairs autocast={ac}: {time.time() - t0:.1f} s", flush=True)
     out["ac_vs_f32"] = np.array([float(np.abs(out["scores_ac"] - out["scores_f32"]).max()), float(np.abs(out["scores_f32"]).max())])
-    print("  bert-large RR reference autocast vs fp32: max|dscore| %.5f (|score| <= %.3f)" % tuple(out["ac_vs_f32"]))
+    out["ac16_vs_f32"] = np.array([float(np.abs(out["scores_ac16"] - out["scores_f32"]).max()), float(np.abs(out["scores_f32"]).max())])
+    print("  bert-large RR reference bf16 autocast vs fp32: max|dscore| %.5f (|score| <= %.3f)" % tuple(out["ac_vs_f32"]))
+    print("  bert-large RR reference float16 autocast vs fp32: max|dscore| %.6f" % out["ac16_vs_f32"][0])
     np.savez_compressed(os.path.join(OUT, "bert_large_rr.npz"), **out)
     print("wrote bert_large_rr.npz")
 
@@ -388,6 +444,8 @@ def main():
         config1(np.random.default_rng(SEED + 11))
     if "spread" in what:
         config1_spread(np.random.default_rng(SEED + 14))
+    if "spread_qrels" in what:
+        spread_qrels()
     if "gtr" in what:
         gtr_base(np.random.default_rng(SEED + 12))
     if "large" in what:

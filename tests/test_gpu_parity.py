@@ -1708,3 +1708,92 @@ def test_cross_encoder_bert_large_width_matches_oracle():
         want = sorted(range(q * 8, q * 8 + 8), key=lambda i: -float(ref[i, 0]))
         have = [int(d[1:]) for d, _ in sorted(run[f"q{q}"].items(), key=lambda kv: -kv[1])]
         assert have == want
+
+
+@pytest.mark.parametrize("max_norm", [0.0, 0.5])
+def test_fused_adamw_matches_torch_adamw(max_norm):
+    """openmatch_amd.optim.FusedAdamW (om_grad_sqnorm + om_adamw_step) against clip_grad_norm_ + torch.optim.AdamW (the
+    single-tensor reference form) over five steps: odd sizes (chunk tails, unaligned tails), two weight-decay groups, a
+    parameter that stops receiving gradients, a changing learning rate."""
+    from openmatch_amd.optim import FusedAdamW
+    gen = torch.Generator().manual_seed(3)
+    sizes = [(1,), (7,), (16384,), (16385,), (257, 389), (3, 5, 7), (40000,)]
+    mine = [torch.nn.Parameter(torch.randn(*s, generator=gen).to(DEV)) for s in sizes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    mk = lambda ps: [{"params": ps[:4], "weight_decay": 0.01}, {"params": ps[4:], "weight_decay": 0.0}]
+    fo = FusedAdamW(mk(mine), lr=1e-2, betas=(0.9, 0.98), eps=1e-8, max_grad_norm=max_norm)
+    to = torch.optim.AdamW(mk(ref), lr=1e-2, betas=(0.9, 0.98), eps=1e-8, foreach=False, fused=False)
+    for step in range(5):
+        for i, (a, b) in enumerate(zip(mine, ref)):
+            if i == 2 and step >= 3:                     # no gradient any more: both leave it alone
+                a.grad = b.grad = None
+                continue
+            gr = (torch.randn(*a.shape, generator=gen) * (3.0 if step == 1 else 0.3)).to(DEV)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        for o in (fo, to):
+            for grp in o.param_groups:
+                grp["lr"] = 1e-2 / (1 + step)
+        if max_norm > 0:
+            tn = torch.nn.utils.clip_grad_norm_([p for p in ref if p.grad is not None], max_norm)
+        fo.step(); to.step()
+        if max_norm > 0:
+            assert abs(fo.grad_norm().item() - tn.item()) <= 1e-5 * tn.item()
+        for a, b in zip(mine, ref):
+            assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item()), (step, tuple(a.shape))
+            sa, sb = fo.state[a], to.state[b]
+            if "exp_avg" in sb:
+                assert (sa["exp_avg"] - sb["exp_avg"]).abs().max().item() <= 1e-6
+                assert (sa["exp_avg_sq"] - sb["exp_avg_sq"]).abs().max().item() <= 1e-6
+                assert sa["step"] == int(sb["step"])
+    # a non-finite gradient with skip_nonfinite: nothing moves (the skipped step of a float16 loss scaler)
+    fo.skip_nonfinite = True
+    before = [p.detach().clone() for p in mine]
+    for p in mine:
+        p.grad = torch.zeros_like(p)
+    mine[4].grad[3, 5] = float("inf")
+    fo.step()
+    assert not math.isfinite(fo.grad_norm().item())
+    assert all(torch.equal(a, b) for a, b in zip(mine, before))
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float32"])
+def test_optimizer_step_refreshes_the_packed_weights(golden, dtype):
+    """The forward reads PACKED copies of the weights (Q|K|V fused, matrices in the compute dtype).  After DRTrainer.optimizer_step
+    -- on FusedAdamW, which rewrites those copies in its own pass, and on torch's fused AdamW, which updates the parameters
+    without bumping their versions (the trainer re-packs behind it) -- the next forward must see the NEW weights: its loss
+    equals that of a freshly built model holding the same parameters."""
+    import copy
+    from openmatch.trainer import DRTrainer
+    from openmatch_amd import encoder as enc
+    g = golden("train_bert_tiny")
+    q, p = _train_batch(g)
+    for which in ("fused", "torch"):
+        model = _train_model(g, dtype=dtype)
+        args = NS(device=DEV, world_size=1, process_index=0, per_device_train_batch_size=4, negatives_x_device=False,
+                  learning_rate=5e-2, weight_decay=0.01, max_grad_norm=1.0, gradient_accumulation_steps=1, fp16=False, bf16=False)
+        trainer = DRTrainer(model=model, args=args)
+        if which == "torch":
+            trainer.optimizer = torch.optim.AdamW(model.parameters(), lr=5e-2, fused=True)
+        else:
+            trainer.create_optimizer_and_scheduler(num_training_steps=100)
+            assert type(trainer.optimizer).__name__ == "FusedAdamW"
+        l0 = trainer.training_step(model, (q, p)).item()
+        trainer.optimizer_step()
+        l1 = trainer.training_step(model, (q, p)).item()
+        assert l1 < l0 - 1e-3, (which, l0, l1)                    # lr 5e-2 on one batch: the step is visible in the loss
+        fresh = copy.deepcopy(model)                              # deep copies start with an empty pack cache
+        with torch.no_grad():
+            l_fresh = fresh(query=q, passage=p).loss.item()
+        model.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            l_again = model(query=q, passage=p).loss.item()
+        assert l_again == l_fresh, (which, dtype, l_again, l_fresh)
+        if which == "fused":                                      # the packed Q|K|V block is cat(q, k, v) of the UPDATED parameters
+            at = model.lm_q.encoder.layer[0].attention.self
+            sh = enc.shadows_of(at.key.weight)
+            assert sh, "the fused Q|K|V buffer is registered as a copy of key.weight"
+            pk, buf, off = sh[0]
+            H = at.key.weight.shape[0]
+            assert off == H * at.key.weight.shape[1]
+            want = torch.cat([at.query.weight, at.key.weight, at.value.weight], 0).detach().to(buf.dtype)
+            assert torch.equal(buf.view(3 * H, -1), want)

@@ -7,9 +7,13 @@
 #   tools/gpu.sh ab [tag] VAR v1 v2 ...      interleaved A/B of one environment switch on the encode leg (two rounds)
 #   tools/gpu.sh probes [tag] GLOB [env...]  every probe binary matching build/GLOB twice, interleaved (tools/*_probe.hip builds)
 #   tools/gpu.sh py [tag] script.py [args]   one python tool (tools/*.py) with its output kept
+#   tools/gpu.sh train [tag] [CFG...]        the training step: interleaved A/B of "OM_GEMM_CONT optimizer" pairs (default: "47 fused"
+#                                            "15 fused" "47 torch"), then rocprofv3 kernel stats of the default configuration
+#   tools/gpu.sh suite [tag] [pytest args]   the GPU suite alone (-m gpu), log kept
 #
 # Output goes to gpurun_out/<tag>/ (merged back by gpurun); copy what should be judged into profiles/.
-# Rounds 1-3 used one script per experiment (tools/gpu_r3*.sh ...); they are in the git history up to 9937a22.
+# Rounds 1-3 used one script per experiment (tools/gpu_r3*.sh ...); they are in the git history up to 9937a22; round 4's
+# tools/r4/probe*.sh up to 6ae6e48.  New experiments become sub-commands here.
 set -u
 R=$PWD; sub=${1:-validate}; tag=${2:-$sub}; shift; shift
 O=$R/gpurun_out/$tag; mkdir -p $O
@@ -60,6 +64,21 @@ probes)
 py)
   s=$1; shift
   timeout 900 python $s "$@" > $O/$(basename $s .py).log 2>&1; echo "rc=$?"; grep -v Warning $O/$(basename $s .py).log | tail -40
+  ;;
+train)
+  [ $# -eq 0 ] && set -- "47 fused" "15 fused" "47 torch"
+  for round in 1 2; do for cfg in "$@"; do
+    c=${cfg% *}; o=${cfg#* }
+    OM_GEMM_CONT=$c timeout 300 python tools/train_bench.py --steps 30 --optimizer $o > $O/train_${c}_${o}_$round.json 2>$O/train.err
+    echo "OM_GEMM_CONT=$c optimizer=$o $(grep -o '"steps_per_s": [0-9.]*' $O/train_${c}_${o}_$round.json) $(grep -o '"loss": [0-9.]*' $O/train_${c}_${o}_$round.json)"
+  done; done
+  cd /tmp
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/tools/train_bench.py --steps 20 > $O/prof.log 2>&1
+  cd $R; f=$(find $O/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { cp "$f" $O/train_kernel_stats.csv; head -16 "$f" | cut -c1-150; }
+  ;;
+suite)
+  timeout 1500 python -m pytest tests -m gpu -q -x -s "$@" > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log
+  grep -E " passed| failed| error|^FAILED|^E  " $O/pytest.log | tail -15
   ;;
 *) echo "unknown subcommand $sub"; exit 2 ;;
 esac

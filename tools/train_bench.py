@@ -13,6 +13,8 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--optimizer", default="fused", help="fused: the product's FusedAdamW (clip + AdamW + weight refresh in one pass); "
+                    "torch: clip_grad_norm_ + torch.optim.AdamW(fused=True) + a re-pack of the 16-bit weights")
     ap.add_argument("--wgrad-wgs", type=int, default=0, help="weight-gradient workgroups per launch / 64 (0: the kernel's default, 5)")
     a = ap.parse_args()
     from transformers import BertConfig, BertModel
@@ -36,11 +38,13 @@ def main():
               learning_rate=5e-6, weight_decay=0.0, adam_beta1=0.9, adam_beta2=0.999, adam_epsilon=1e-8,
               gradient_accumulation_steps=1, max_grad_norm=1.0, fp16=False, bf16=False)
     trainer = DRTrainer(model=model, args=args)
-    opt = torch.optim.AdamW(model.parameters(), lr=5e-6, fused=True)
+    if a.optimizer == "torch":
+        trainer.optimizer = torch.optim.AdamW(model.parameters(), lr=5e-6, weight_decay=0.0, fused=True)
+    else:
+        trainer.create_optimizer_and_scheduler(num_training_steps=10 ** 6)
     def step():
         loss = trainer.training_step(model, batch)
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
-        opt.step(); opt.zero_grad(set_to_none=True)
+        trainer.optimizer_step()
         return loss
     for _ in range(3):
         step()
@@ -50,7 +54,7 @@ def main():
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
     flop = 3 * (8 * 5.474e9 + 64 * 22.347e9)
     print(json.dumps({"metric": "contrastive train steps/s (8 q x 32 + 64 p x 128, bert-base, fwd+bwd+AdamW)", "steps_per_s": round(1 / dt, 2),
-                      "ms_per_step": round(dt * 1e3, 2), "precision": a.precision, "dropout": a.dropout, "wgrad_wgs": a.wgrad_wgs,
+                      "ms_per_step": round(dt * 1e3, 2), "precision": a.precision, "dropout": a.dropout, "wgrad_wgs": a.wgrad_wgs, "optimizer": a.optimizer,
                       "algorithmic_tflops": round(flop / dt / 1e12, 1), "loss": float(loss)}))
 
 
