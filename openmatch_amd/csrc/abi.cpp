@@ -109,7 +109,7 @@ void opt_init() {
   e = getenv("OM_TRAIN_TAPE_GRAD");
   g_opt[OM_OPT_TRAIN_TAPE_GRAD] = e ? atoi(e) : 1;
   e = getenv("OM_GEMM_CONT");
-  g_opt[OM_OPT_GEMM_CONT] = e ? atoi(e) : 47;
+  g_opt[OM_OPT_GEMM_CONT] = e ? atoi(e) : 111;
   g_opt_init.store(true);
 }
 }  // namespace

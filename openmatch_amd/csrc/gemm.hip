@@ -167,9 +167,17 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
     // A/B (OM_OPT_GEMM_CONT bit 4): plain 16-bit shapes of whole 256 x 256 tiles go to the continuous-ring kernels even when
     // those leave CUs idle (training: N = 768 at 9 216 token rows is 108 tiles -- the cost model above prefers 216 tiles of
     // 256 x 128 on generation 2; the idle CUs are not idle in a training step, the weight-gradient lane runs beside)
-    if ((om_option(OM_OPT_GEMM_CONT) & 16) && in_dtype == OM_BF16 && out_dtype == OM_BF16 && !ep.pre_act && ep.drop_p == 0.f &&
-        M % 256 == 0 && N % 256 == 0 && K * 2 >= 3 * 128)
-      gen = 6;
+    const bool plain16 = in_dtype == OM_BF16 && out_dtype == OM_BF16 && !ep.pre_act && ep.drop_p == 0.f && M % 256 == 0 && N % 256 == 0 &&
+                         K * 2 >= 3 * 128;
+    if ((om_option(OM_OPT_GEMM_CONT) & 16) && plain16) gen = 6;
+    // Round 5 (bit 6, default on): the model above prices generation 2 at 0.92 of a 256 x 256 tile's rate; measured in the training
+    // step (profiles/r05_train_timeline_v0.txt) its K step takes ~2 650 cycles for 1 024 cycles of MFMA against 2 425 for 2 048 on
+    // the continuous ring -- 0.55.  With that figure the QKV projection of the training forward (9 216 x 2 304: 324 whole tiles, two
+    // rounds) moves to the continuous kernel (51 -> ~40 us); the N = 768 shapes (108 tiles on 256 CUs) stay where they are.
+    if ((om_option(OM_OPT_GEMM_CONT) & 64) && plain16 && gen == 2 && gemm_variant() == 0) {
+      const double c7 = rounds(256, 256, 256) * (256.0 * 256.0), c2r = rounds(256, 128, 256) * (256.0 * 128.0) / 0.55;
+      if (c7 < c2r) gen = 6;
+    }
   }
   const bool ln_fused = ep.ln_stats || ep.rln_stats || ep.stats_out;
   // the training forward's FFN1 (gelu + gelu' to the tape): the continuous 256 x 256 kernel with its two-output epilogue

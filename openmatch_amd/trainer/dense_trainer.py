@@ -339,7 +339,9 @@ class DRTrainer:
         accum = max(1, getattr(a, "gradient_accumulation_steps", 1))
         log_every = max(1, int(getattr(a, "logging_steps", 500) or 500))
         save_every = int(getattr(a, "save_steps", 0) or 0)
-        running, micro, epoch = 0.0, 0, 0
+        # the running loss stays on the device between log lines: float(loss) every step is a stream synchronisation per step,
+        # and the host then cannot enqueue step n + 1 while step n still runs
+        running, micro, epoch = torch.zeros((), dtype=torch.float32, device=a.device), 0, 0
         self.optimizer.zero_grad(set_to_none=True)
         # multi-GPU: gradient all-reduce in layer-group buckets from inside the backward (grad_sync.py) -- with gradient
         # accumulation or the gradient cache the per-parameter gradients are sums over several backward passes, which are
@@ -374,7 +376,7 @@ class DRTrainer:
                 finally:                          # a raising step must not leave the bucket hand-off armed for later backwards
                     if sync is not None:
                         sync.finish()
-                running += float(loss_t)
+                running += loss_t.detach().to(running.dtype)
                 micro += 1
                 if micro % accum:
                     continue
@@ -385,12 +387,12 @@ class DRTrainer:
                 if per_epoch:                 # HF: epoch + (steps done in this epoch) / (steps per epoch)
                     self.state.epoch = epoch + min(1.0, in_epoch / per_epoch)
                 if self.state.global_step % log_every == 0:
-                    entry = {"loss": running / (log_every * accum), "learning_rate": self.lr_scheduler.get_last_lr()[0],
+                    entry = {"loss": float(running) / (log_every * accum), "learning_rate": self.lr_scheduler.get_last_lr()[0],
                              "epoch": self.state.epoch, "step": self.state.global_step}
                     self.state.log_history.append(entry)
                     if self.is_world_process_zero():
                         logger.info("%s", entry)
-                    running = 0.0
+                    running.zero_()
                 if do_eval and strategy == "steps" and self.state.global_step % eval_every == 0:
                     self.evaluate()
                 if save_every and self.state.global_step % save_every == 0 and self.is_world_process_zero():
@@ -402,7 +404,7 @@ class DRTrainer:
             epoch += 1
             if not stepped:
                 raise ValueError("the training dataloader produced no batches")
-        return SimpleNamespace(global_step=self.state.global_step, training_loss=running)
+        return SimpleNamespace(global_step=self.state.global_step, training_loss=float(running))
 
 
 def split_dense_inputs(model_input: dict, chunk_size: int):

@@ -67,10 +67,12 @@ py)
   ;;
 train)
   [ $# -eq 0 ] && set -- "47 fused" "15 fused" "47 torch"
-  for round in 1 2; do for cfg in "$@"; do
-    c=${cfg% *}; o=${cfg#* }
-    OM_GEMM_CONT=$c timeout 300 python tools/train_bench.py --steps 30 --optimizer $o > $O/train_${c}_${o}_$round.json 2>$O/train.err
-    echo "OM_GEMM_CONT=$c optimizer=$o $(grep -o '"steps_per_s": [0-9.]*' $O/train_${c}_${o}_$round.json) $(grep -o '"loss": [0-9.]*' $O/train_${c}_${o}_$round.json)"
+  cfgs=("$@")
+  for round in 1 2; do for cfg in "${cfgs[@]}"; do
+    set -- $cfg; c=$1; o=$2; h=${3:-dev}          # "OM_GEMM_CONT optimizer [host]": host = the batch stays in pageable host memory (a copy + sync per step)
+    hb=0; [ "$h" = host ] && hb=1
+    TRAIN_BENCH_HOST_BATCH=$hb OM_GEMM_CONT=$c timeout 300 python tools/train_bench.py --steps 30 --optimizer $o > $O/train_${c}_${o}_${h}_$round.json 2>$O/train.err
+    echo "OM_GEMM_CONT=$c optimizer=$o batch=$h $(grep -o '"steps_per_s": [0-9.]*' $O/train_${c}_${o}_${h}_$round.json) $(grep -o '"loss": [0-9.]*' $O/train_${c}_${o}_${h}_$round.json)"
   done; done
   cd /tmp
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/tools/train_bench.py --steps 20 > $O/prof.log 2>&1

@@ -33,7 +33,10 @@ def main():
                     train_args=NS(negatives_x_device=False, per_device_train_batch_size=8)).to(dev)
     g = torch.Generator().manual_seed(1)
     mk = lambda n, L: {"input_ids": torch.randint(1000, 30000, (n, L), generator=g), "attention_mask": torch.ones(n, L, dtype=torch.long)}
+    ap_host = os.environ.get("TRAIN_BENCH_HOST_BATCH") == "1"       # 1: pageable host tensors, copied (synchronously) every step as before round 5
     batch = (mk(8, 32), mk(64, 128))
+    if not ap_host:
+        batch = tuple({k: v.to(dev) for k, v in b.items()} for b in batch)
     args = NS(device=dev, world_size=1, process_index=0, per_device_train_batch_size=8, negatives_x_device=False,
               learning_rate=5e-6, weight_decay=0.0, adam_beta1=0.9, adam_beta2=0.999, adam_epsilon=1e-8,
               gradient_accumulation_steps=1, max_grad_norm=1.0, fp16=False, bf16=False)
