@@ -456,7 +456,25 @@ static int train_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* 
     return 0;
   }
   const bool head = c->head_in > 0 && w->head_w;
-  RUN(omk_pool(dt, xf, attention_mask, t.pooled, B, (int)L, H, c->pooling, s));
+  if (d.es == 2 && d.nl > 0) {
+    // 16-bit runs: the pooled rows come from an f32 evaluation of the LAST LayerNorm (its input y2 is on the tape) -- the reference's
+    // autocast runs layer_norm in fp32, so its representations are not rounded to 16 bits on the way to the loss, and the loss of a
+    // contrastive batch lives in the DIFFERENCES between near-equal dot products (tests/golden/train_base.npz: the bf16 rounding
+    // of the final hidden state alone moved the gradients by tens of percent on a random-init model).  The backward is unchanged:
+    // the same function of y2; t.x[n_layers] stays on the tape in the compute format for callers that want the hidden state.
+    const OmLayerWeights& last = Ls[d.nl - 1];
+    const char* y2_last = t.y2 + t.sx * (d.nl - 1);
+    if (c->pooling == OM_POOL_FIRST) {
+      RUN(omk_layernorm_f32out(dt, y2_last, L * H, t.pooled, H, last.ln2_g, last.ln2_b, B, H, c->ln_eps, 0, s));
+    } else {
+      float* x32 = (float*)ws.df;                        // [M, H] f32 fits the [M, F] 16-bit scratch of the backward (F >= 2 H: checked)
+      if ((size_t)F * d.es < (size_t)H * 4) OM_FAIL("training: mean pooling in a 16-bit format needs ffn >= 2 * hidden");
+      RUN(omk_layernorm_f32out(dt, y2_last, H, x32, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, 0, s));
+      RUN(omk_pool(OM_F32, x32, attention_mask, t.pooled, B, (int)L, H, c->pooling, s));
+    }
+  } else {
+    RUN(omk_pool(dt, xf, attention_mask, t.pooled, B, (int)L, H, c->pooling, s));
+  }
   float* pre = c->normalize ? t.headout : out_reps;      // value before F.normalize
   if (head) {
     if (om_gemm_nt(OM_F32, t.pooled, H, w->head_w, c->head_in, OM_F32, pre, d.D, B, d.D, c->head_in,

@@ -10,6 +10,7 @@
 #   tools/gpu.sh train [tag] [CFG...]        the training step: interleaved A/B of "OM_GEMM_CONT optimizer" pairs (default: "47 fused"
 #                                            "15 fused" "47 torch"), then rocprofv3 kernel stats of the default configuration
 #   tools/gpu.sh suite [tag] [pytest args]   the GPU suite alone (-m gpu), log kept
+#   tools/gpu.sh sweep [tag] VAR v1 v2 .. -- CMD   CMD once per value of the environment variable VAR, twice, interleaved; last JSON line of each kept
 #
 # Output goes to gpurun_out/<tag>/ (merged back by gpurun); copy what should be judged into profiles/.
 # Rounds 1-3 used one script per experiment (tools/gpu_r3*.sh ...); they are in the git history up to 9937a22; round 4's
@@ -78,8 +79,17 @@ train)
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/tools/train_bench.py --steps 20 > $O/prof.log 2>&1
   cd $R; f=$(find $O/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { cp "$f" $O/train_kernel_stats.csv; head -16 "$f" | cut -c1-150; }
   ;;
+sweep)
+  V=$1; shift; vals=()
+  while [ $# -gt 0 ] && [ "$1" != "--" ]; do vals+=("$1"); shift; done
+  shift
+  for round in 1 2; do for val in "${vals[@]}"; do
+    env $V=$val timeout 600 "$@" > $O/sweep_${V}_${val}_$round.log 2>$O/sweep.err
+    echo "$V=$val $(grep '^{' $O/sweep_${V}_${val}_$round.log | tail -1 | cut -c1-260)"
+  done; done
+  ;;
 suite)
-  timeout 1500 python -m pytest tests -m gpu -q -x -s "$@" > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log
+  timeout 1500 python -m pytest tests -m gpu -q -s "$@" > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log
   grep -E " passed| failed| error|^FAILED|^E  " $O/pytest.log | tail -15
   ;;
 *) echo "unknown subcommand $sub"; exit 2 ;;
