@@ -118,7 +118,11 @@ void om_debug_gemm_gen(int gen);
                                     * epilogue; bit 6: generation 2 priced at its measured 0.55 of a 256 x 256 tile's rate when choosing between it and the
                                     * continuous kernel for plain whole-tile bf16 shapes; a cleared bit 0 / 1: the ring restarts per tile as in round 3 */
 #define OM_OPT_TRAIN_TAPE_GRAD 17  /* 1 (default): the bf16 BERT training forward keeps gelu'(f) on its tape instead of f (env OM_TRAIN_TAPE_GRAD) */
-#define OM_OPT_COUNT 18
+#define OM_OPT_TRAIN_RES32 18      /* 1 (default): the bf16 BERT training FORWARD keeps its residual stream in f32, as the reference's autocast does (layer_norm
+                                    * runs and returns fp32): pre-LayerNorm sums in f32 on the tape, every LayerNorm output also unrounded for the next
+                                    * residual add; 0: 16-bit residual stream as in rounds 1-4 (env OM_TRAIN_RES32; ~3 % faster, 2.4 x further from the
+                                    * reference's fp32 gradients on tests/golden/train_base.npz) */
+#define OM_OPT_COUNT 19
 int om_debug_option(int opt, int value);
 /* the attention kernel alone (bf16 qkv [B*L, 3H] -> ctx [B*L, H]; mask [B, L] int64), for timing: csrc/kernels.h omk_attention */
 int om_debug_attention(const void* qkv, void* ctx, const int64_t* mask, int64_t B, int L, int H, int heads, void* stream);

@@ -108,6 +108,8 @@ void opt_init() {
   g_opt[OM_OPT_GEMM_MAX_GRID] = e ? atoi(e) : 0;
   e = getenv("OM_TRAIN_TAPE_GRAD");
   g_opt[OM_OPT_TRAIN_TAPE_GRAD] = e ? atoi(e) : 1;
+  e = getenv("OM_TRAIN_RES32");
+  g_opt[OM_OPT_TRAIN_RES32] = e ? atoi(e) : 1;
   e = getenv("OM_GEMM_CONT");
   g_opt[OM_OPT_GEMM_CONT] = e ? atoi(e) : 111;
   g_opt_init.store(true);

@@ -48,7 +48,7 @@ template <> struct Vec4<f16_t> {
 template <typename TOut, int MAX_VEC>
 __device__ inline void norm_and_store(float (&x)[MAX_VEC][4], int nvec, int lane, int H,
                                       const float* __restrict__ g, const float* __restrict__ b,
-                                      float eps, int rms, TOut* __restrict__ out) {
+                                      float eps, int rms, TOut* __restrict__ out, float* __restrict__ out32 = nullptr) {
   float mean = 0.f;
   if (!rms) {
     float s = 0.f;
@@ -81,6 +81,7 @@ __device__ inline void norm_and_store(float (&x)[MAX_VEC][4], int nvec, int lane
         for (int e = 0; e < 4; ++e) y[e] = (x[j][e] - mean) * rstd * gv[e];
       }
       Vec4<TOut>::store(out + c, y);
+      if (out32) Vec4<float>::store(out32 + c, y);      // the unrounded copy (16-bit training: what the next residual add reads)
     }
   }
 }
@@ -89,7 +90,7 @@ template <typename TIn, typename TOut, int MAX_VEC>
 __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_kernel(
     const TIn* __restrict__ x, int64_t ldx, TOut* __restrict__ y, int64_t ldy,
     const float* __restrict__ g, const float* __restrict__ b, int64_t M, int H, float eps, int rms,
-    const int* __restrict__ rows = nullptr) {
+    const int* __restrict__ rows = nullptr, float* __restrict__ y32 = nullptr) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_kernel(
     const int c = (lane + 64 * j) * 4;
     if (j < nvec && c < H) Vec4<TIn>::load(x + src * ldx + c, v[j]);
   }
-  norm_and_store<TOut, MAX_VEC>(v, nvec, lane, H, g, b, eps, rms, y + row * ldy);
+  norm_and_store<TOut, MAX_VEC>(v, nvec, lane, H, g, b, eps, rms, y + row * ldy, y32 ? y32 + row * ldy : nullptr);
 }
 
 // bf16 rows with 16-byte accesses: 32 lanes own one row (two rows per wave), every lane holds NV
@@ -421,6 +422,23 @@ __global__ void pack_overflow_poison_kernel(const int* __restrict__ cu, int64_t 
 int omk_pack_overflow_poison(const int* cu, int64_t B, int64_t rows, float* out, int64_t n, hipStream_t s) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(pack_overflow_poison_kernel, dim3(64), dim3(256), 0, s, cu, B, rows, out, n);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+// f32 rows in -> the normalised rows in `dtype` (the next contraction's operand) AND in f32 (y32: what the next residual add reads):
+// the LayerNorm of the 16-bit training forward, whose residual stream stays in f32 as the reference's autocast keeps it
+int omk_layernorm_dual(int dtype, const float* x, int64_t ldx, void* y, float* y32, int64_t ldy, const float* g, const float* b,
+                       int64_t M, int H, float eps, hipStream_t s) {
+  if (H % 4 != 0 || H > 64 * 4 * MAX_VEC_LIMIT) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
+  if (M <= 0) return 0;
+  const unsigned grid = (unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+#define LND(TO, MV) hipLaunchKernelGGL((layernorm_kernel<float, TO, MV>), dim3(grid), dim3(64 * ROWS_PER_BLOCK), 0, s, x, ldx, (TO*)y, ldy, g, b, M, \
+                                       H, eps, 0, (const int*)nullptr, y32)
+  if (dtype == OM_BF16) { if (H <= 1024) LND(bf16_t, 4); else LND(bf16_t, 8); }
+  else if (dtype == OM_F16) { if (H <= 1024) LND(f16_t, 4); else LND(f16_t, 8); }
+  else OM_FAIL("a 16-bit output format");
+#undef LND
   OM_LAUNCH_CHECK();
   return 0;
 }

@@ -8,6 +8,8 @@ int omk_ln_fold(int dtype /* OM_BF16 | OM_F16 */, const void* W, const float* ga
 int omk_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* g,
                   const float* b, int64_t M, int H, float eps, int rms, hipStream_t s,
                   const void* x_lo = nullptr /* second plane of a two-plane input: normalises x + x_lo */);
+int omk_layernorm_dual(int dtype, const float* x, int64_t ldx, void* y, float* y32, int64_t ldy, const float* g, const float* b,
+                       int64_t M, int H, float eps, hipStream_t s);
 int omk_layernorm_f32out(int dtype, const void* x, int64_t ldx, float* y, int64_t ldy, const float* g, const float* b,
                          int64_t M, int H, float eps, int rms, hipStream_t s, const void* x_lo = nullptr,
                          const int* rows = nullptr /* gather: output row r normalises input row rows[r] */);

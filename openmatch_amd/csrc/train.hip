@@ -11,12 +11,21 @@
 // Every dense contraction runs on the NT MFMA GEMM (gemm.hip); wgrad outputs are f32.
 #include <math.h>
 
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "train_kernels.h"
 
 namespace {
-struct Dims { int64_t M, Mp, B, L; int H, F, nl, nh, D; size_t es; bool t5, gated; };
+struct Dims {
+  int64_t M, Mp, B, L; int H, F, nl, nh, D; size_t es; bool t5, gated;
+  // what a 16-bit BERT tape holds (fixed by the FORWARD, remembered per tape: tape_flags below):
+  bool bert16;       // 16-bit BERT: the configurations the two flags below apply to
+  bool res32;        // the pre-LayerNorm sums y1 / y2 in f32 (the forward's residual stream stays in f32: OM_OPT_TRAIN_RES32)
+  bool pre_grad;     // gelu'(f) in place of f (OM_OPT_TRAIN_TAPE_GRAD)
+};
+constexpr int TAPE_RES32 = 1, TAPE_PRE_GRAD = 2;
 
 Dims dims_of(const OmEncoderConfig* c, int64_t B, int64_t L) {
   Dims d;
@@ -26,8 +35,13 @@ Dims dims_of(const OmEncoderConfig* c, int64_t B, int64_t L) {
   d.es = c->dtype == OM_BF16 ? 2 : 4;
   d.t5 = c->arch == OM_ARCH_T5;
   d.gated = d.t5 && (c->act & 0xff) == OM_ACT_GELU_TANH;      // T5 v1.1: gated gelu_new (wi_0, wi_1)
+  d.bert16 = !d.t5 && c->dtype == OM_BF16 && (size_t)d.F * d.es >= (size_t)d.H * 4;
+  d.res32 = d.bert16 && om_option(OM_OPT_TRAIN_RES32) != 0;
+  d.pre_grad = c->dtype == OM_BF16 && om_option(OM_OPT_TRAIN_TAPE_GRAD) != 0;
   return d;
 }
+Dims dims_with_flags(Dims d, int flags) { d.res32 = (flags & TAPE_RES32) != 0; d.pre_grad = (flags & TAPE_PRE_GRAD) != 0; return d; }
+int flags_of(const Dims& d) { return (d.res32 ? TAPE_RES32 : 0) | (d.pre_grad ? TAPE_PRE_GRAD : 0); }
 
 // ---- tape: activations saved by the forward ------------------------------------------------
 struct Tape {
@@ -39,6 +53,7 @@ struct Tape {
   float *pooled, *headout;             // [B,H], [B,D] (pre-normalise)
   size_t total;
   size_t sx, sqkv, sf;     // per-layer strides in bytes
+  size_t sy;               // stride of y1 / y2 (f32 when Dims::res32)
 };
 Tape carve_tape(const Dims& d, char* base) {
   size_t off = 0;
@@ -47,13 +62,14 @@ Tape carve_tape(const Dims& d, char* base) {
   t.sx = align_up((size_t)d.M * d.H * d.es, 256);
   t.sqkv = align_up((size_t)d.M * 3 * d.H * d.es, 256);
   t.sf = align_up((size_t)d.M * d.F * d.es, 256);
+  t.sy = d.res32 ? align_up((size_t)d.M * d.H * 4, 256) : t.sx;
   t.x = take(t.sx * (d.nl + 1));
   t.qkv = take(t.sqkv * d.nl);
   t.ctx = take(t.sx * d.nl);
-  t.y1 = take(d.t5 ? 0 : t.sx * d.nl);           // BERT: pre-LayerNorm sums; T5 (pre-norm) keeps none
+  t.y1 = take(d.t5 ? 0 : t.sy * d.nl);           // BERT: pre-LayerNorm sums; T5 (pre-norm) keeps none
   t.x1 = take(t.sx * d.nl);
   t.f = take(t.sf * d.nl);
-  t.y2 = take(d.t5 ? 0 : t.sx * d.nl);
+  t.y2 = take(d.t5 ? 0 : t.sy * d.nl);
   t.f2 = take(d.gated ? t.sf * d.nl : 0);
   t.g = take(d.t5 ? 0 : t.sf * d.nl);
   t.pooled = (float*)take((size_t)d.B * d.H * 4);
@@ -71,6 +87,7 @@ struct Ws {
   float *dhead, *dpooled;
   // T5 extras: normed-input scratch, gate gradient, bias [nh,L,L], its LUT and per-offset gradient
   char *nbuf, *df2;
+  float *x32a, *x32b;               // res32: the unrounded LayerNorm outputs the residual adds read (layer input / after attention)
   float *posbias, *drel;
   int* lut;
   // deferred weight gradients (bf16 BERT, widths of 256): every layer's dY of the four sites is KEPT until the layer
@@ -96,6 +113,8 @@ Ws carve_ws(const Dims& d, char* base) {
   w.wt = take(w.swt * d.nl);
   w.dhead = (float*)take((size_t)d.B * d.D * 4);
   w.dpooled = (float*)take((size_t)d.B * d.H * 4);
+  w.x32a = (float*)take(d.bert16 ? (size_t)d.M * d.H * 4 : 0);      // (reserved whatever the option says now: a tape written
+  w.x32b = (float*)take(d.bert16 ? (size_t)d.M * d.H * 4 : 0);      //  under the other setting must find the same workspace)
   w.nbuf = take(d.t5 ? mh : 0);
   w.df2 = take(d.gated ? mf : 0);
   w.posbias = (float*)take(d.t5 ? (size_t)d.nh * d.L * d.L * 4 : 0);
@@ -239,9 +258,21 @@ extern "C" int om_encoder_train_set_layer_events(void* const* events, int n) {
 // "Consumed by one call" on EVERY exit path: the array is owned by the caller (a ctypes buffer that may be freed right after the
 // call), so an early return or a failing launch must not leave the pointer behind for the next backward on this thread.
 struct BwdEventsScope { ~BwdEventsScope() { g_bwd_events = nullptr; g_bwd_nevents = 0; } };
-// 16-bit BERT training keeps gelu'(f) on the tape instead of f (OM_ACT_PRE_GRAD: honoured by every generation's training
-// epilogue); forward and backward must agree on what the tape's `f` holds, so both ask here
-static bool tape_grad(int dt, int64_t, int, int) { return dt == OM_BF16 && om_option(OM_OPT_TRAIN_TAPE_GRAD) != 0; }
+// What a tape holds is decided by the run-time options AT THE FORWARD (gelu'(f) in place of f: OM_OPT_TRAIN_TAPE_GRAD; f32
+// pre-LayerNorm sums: OM_OPT_TRAIN_RES32) and remembered per tape address: a backward that runs after an option was toggled
+// (A/B scripts, GradCache replays over several tapes) reads the tape as it was written, not as the options say now.
+static std::mutex g_tape_mu;
+static std::unordered_map<const void*, int> g_tape_flags;
+static void tape_flags_set(const void* tape, int flags) {
+  std::lock_guard<std::mutex> lk(g_tape_mu);
+  if (g_tape_flags.size() > 4096) g_tape_flags.clear();
+  g_tape_flags[tape] = flags;
+}
+static int tape_flags_get(const void* tape, int fallback) {
+  std::lock_guard<std::mutex> lk(g_tape_mu);
+  auto it = g_tape_flags.find(tape);
+  return it == g_tape_flags.end() ? fallback : it->second;
+}
 static int record_layer_event(int l, hipStream_t s) {
   if (g_bwd_events && l < g_bwd_nevents && g_bwd_events[l]) OM_HIP(hipEventRecord((hipEvent_t)g_bwd_events[l], s));
   return 0;
@@ -418,37 +449,54 @@ static int train_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* 
   }
   if (L > c->max_pos) OM_FAIL("sequence longer than the position table");
 
+  tape_flags_set(tape_mem, flags_of(d));
   RUN(omk_embed(dt, input_ids, token_type_ids, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g,
                 w->emb_ln_b, t.x, M, (int)L, H, c->vocab, c->type_vocab, c->ln_eps, 1, s));
   if (hidden_dropout > 0.f) RUN(omk_dropout(dt, t.x, t.x, M * H, hidden_dropout, site_seed(seed, 0, 0), s));
+  // res32 (16-bit BERT, default): the residual stream of the FORWARD stays in f32, as the reference's autocast keeps it (layer_norm
+  // runs and returns fp32; the residual add of a 16-bit dense output and an fp32 LayerNorm output is fp32).  The pre-LayerNorm sums
+  // y1 / y2 are f32 on the tape; every LayerNorm writes its output twice -- in the compute format (the next contraction's operand,
+  // and the weight gradient's) and unrounded into x32a / x32b (what the next residual add reads).  On tests/golden/train_base.npz the
+  // 16-bit residual stream was the reason the step sat 2.4 x further from the reference's fp32 gradients than the reference's own
+  // encoder-only bf16 autocast; with it in f32: 1.0 x (tools/emulate_train_dataflow.py).  The gradient stream stays 16-bit.
+  float* xres = nullptr;        // f32 copy of the current layer input
+  if (d.res32) {
+    RUN(omk_embed(OM_F32, input_ids, token_type_ids, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g,
+                  w->emb_ln_b, ws.x32a, M, (int)L, H, c->vocab, c->type_vocab, c->ln_eps, 1, s));
+    if (hidden_dropout > 0.f) RUN(omk_dropout(OM_F32, ws.x32a, ws.x32a, M * H, hidden_dropout, site_seed(seed, 0, 0), s));
+    xres = ws.x32a;
+  }
+  const int ydt = d.res32 ? OM_F32 : dt;      // format of y1 / y2 and of the residual operands
   const float scale = 1.0f / sqrtf((float)c->head_dim);
   for (int l = 0; l < d.nl; ++l) {
     const OmLayerWeights& lw = Ls[l];
     char* x = t.x + t.sx * l;
     char* qkv = t.qkv + t.sqkv * l;
     char* ctx = t.ctx + t.sx * l;
-    char* y1 = t.y1 + t.sx * l;
+    char* y1 = t.y1 + t.sy * l;
     char* x1 = t.x1 + t.sx * l;
     char* f = t.f + t.sf * l;
-    char* y2 = t.y2 + t.sx * l;
+    char* y2 = t.y2 + t.sy * l;
     GemmEpilogue ep = {};
     ep.bias = lw.qkv_b;
     RUN(omk_gemm(dt, x, H, lw.qkv_w, H, dt, qkv, 3 * H, M, 3 * H, H, ep, s));
     RUN(omk_attention(dt, qkv, ctx, attention_mask, nullptr, B, (int)L, H, d.nh, scale, attn_dropout,
                       site_seed(seed, l, 2), s));
     ep = GemmEpilogue{};
-    ep.bias = lw.o_b; ep.resid = x; ep.ldr = H; ep.drop_p = hidden_dropout; ep.seed = site_seed(seed, l, 3);
-    RUN(omk_gemm(dt, ctx, H, lw.o_w, H, dt, y1, H, M, H, H, ep, s));
-    RUN(omk_layernorm(dt, y1, H, x1, H, lw.ln1_g, lw.ln1_b, M, H, c->ln_eps, 0, s));
+    ep.bias = lw.o_b; ep.resid = d.res32 ? (const void*)xres : (const void*)x; ep.ldr = H; ep.drop_p = hidden_dropout; ep.seed = site_seed(seed, l, 3);
+    RUN(omk_gemm(dt, ctx, H, lw.o_w, H, ydt, y1, H, M, H, H, ep, s));
+    if (d.res32) RUN(omk_layernorm_dual(dt, (const float*)y1, H, x1, ws.x32b, H, lw.ln1_g, lw.ln1_b, M, H, c->ln_eps, s));
+    else RUN(omk_layernorm(dt, y1, H, x1, H, lw.ln1_g, lw.ln1_b, M, H, c->ln_eps, 0, s));
     ep = GemmEpilogue{};
     char* gl = t.g + t.sf * l;
     // 16-bit runs keep gelu'(f) on the tape instead of f (the forward has Phi(f) in hand; the backward multiplies): OM_ACT_PRE_GRAD
-    ep.bias = lw.ffn1_b; ep.act = OM_ACT_GELU_ERF | (tape_grad(dt, M, F, H) ? OM_ACT_PRE_GRAD : 0); ep.pre_act = f; ep.ldp = F;
+    ep.bias = lw.ffn1_b; ep.act = OM_ACT_GELU_ERF | (d.pre_grad ? OM_ACT_PRE_GRAD : 0); ep.pre_act = f; ep.ldp = F;
     RUN(omk_gemm(dt, x1, H, lw.ffn1_w, H, dt, gl, F, M, F, H, ep, s));
     ep = GemmEpilogue{};
-    ep.bias = lw.ffn2_b; ep.resid = x1; ep.ldr = H; ep.drop_p = hidden_dropout; ep.seed = site_seed(seed, l, 4);
-    RUN(omk_gemm(dt, gl, F, lw.ffn2_w, F, dt, y2, H, M, H, F, ep, s));
-    RUN(omk_layernorm(dt, y2, H, t.x + t.sx * (l + 1), H, lw.ln2_g, lw.ln2_b, M, H, c->ln_eps, 0, s));
+    ep.bias = lw.ffn2_b; ep.resid = d.res32 ? (const void*)ws.x32b : (const void*)x1; ep.ldr = H; ep.drop_p = hidden_dropout; ep.seed = site_seed(seed, l, 4);
+    RUN(omk_gemm(dt, gl, F, lw.ffn2_w, F, ydt, y2, H, M, H, F, ep, s));
+    if (d.res32) RUN(omk_layernorm_dual(dt, (const float*)y2, H, t.x + t.sx * (l + 1), ws.x32a, H, lw.ln2_g, lw.ln2_b, M, H, c->ln_eps, s));
+    else RUN(omk_layernorm(dt, y2, H, t.x + t.sx * (l + 1), H, lw.ln2_g, lw.ln2_b, M, H, c->ln_eps, 0, s));
   }
   const char* xf = t.x + t.sx * d.nl;
   if (out_hidden) {
@@ -456,20 +504,20 @@ static int train_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* 
     return 0;
   }
   const bool head = c->head_in > 0 && w->head_w;
-  if (d.es == 2 && d.nl > 0) {
+  if (d.es == 2 && d.nl > 0 && (c->pooling == OM_POOL_FIRST || d.bert16)) {
     // 16-bit runs: the pooled rows come from an f32 evaluation of the LAST LayerNorm (its input y2 is on the tape) -- the reference's
     // autocast runs layer_norm in fp32, so its representations are not rounded to 16 bits on the way to the loss, and the loss of a
     // contrastive batch lives in the DIFFERENCES between near-equal dot products (tests/golden/train_base.npz: the bf16 rounding
     // of the final hidden state alone moved the gradients by tens of percent on a random-init model).  The backward is unchanged:
     // the same function of y2; t.x[n_layers] stays on the tape in the compute format for callers that want the hidden state.
     const OmLayerWeights& last = Ls[d.nl - 1];
-    const char* y2_last = t.y2 + t.sx * (d.nl - 1);
+    const char* y2_last = t.y2 + t.sy * (d.nl - 1);
+    const int ydt_last = d.res32 ? OM_F32 : dt;
     if (c->pooling == OM_POOL_FIRST) {
-      RUN(omk_layernorm_f32out(dt, y2_last, L * H, t.pooled, H, last.ln2_g, last.ln2_b, B, H, c->ln_eps, 0, s));
+      RUN(omk_layernorm_f32out(ydt_last, y2_last, L * H, t.pooled, H, last.ln2_g, last.ln2_b, B, H, c->ln_eps, 0, s));
     } else {
-      float* x32 = (float*)ws.df;                        // [M, H] f32 fits the [M, F] 16-bit scratch of the backward (F >= 2 H: checked)
-      if ((size_t)F * d.es < (size_t)H * 4) OM_FAIL("training: mean pooling in a 16-bit format needs ffn >= 2 * hidden");
-      RUN(omk_layernorm_f32out(dt, y2_last, H, x32, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, 0, s));
+      float* x32 = (float*)ws.df;                        // [M, H] f32 fits the [M, F] 16-bit scratch of the backward (bert16: F >= 2 H)
+      RUN(omk_layernorm_f32out(ydt_last, y2_last, H, x32, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, 0, s));
       RUN(omk_pool(OM_F32, x32, attention_mask, t.pooled, B, (int)L, H, c->pooling, s));
     }
   } else {
@@ -519,7 +567,8 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
   if (!c || !w || !g || !tape_mem || (!d_reps && !d_hidden) || !workspace) OM_FAIL("null argument");
   if (check_train_cfg(c, L)) return 1;
   if (B <= 0) return 0;
-  const Dims d = dims_of(c, B, L);
+  const Dims d0 = dims_of(c, B, L);
+  const Dims d = dims_with_flags(d0, tape_flags_get(tape_mem, flags_of(d0)));      // the tape as its forward wrote it
   Tape t = carve_tape(d, (char*)tape_mem);
   Ws ws = carve_ws(d, (char*)workspace);
   if (ws.total > workspace_bytes) OM_FAIL("workspace too small");
@@ -533,6 +582,7 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
 
   char* dx = ws.dxa;       // gradient w.r.t. the current layer's OUTPUT
   char* dx_prev = ws.dxb;  // gradient w.r.t. its input (next iteration's dx)
+  const float* dpool32 = nullptr;      // the same for the top layer as f32 (16-bit BERT, pooled tail)
   if (d_hidden) {
     OM_HIP(hipMemcpyAsync(dx, d_hidden, (size_t)M * H * d.es, hipMemcpyDeviceToDevice, s));
   } else {
@@ -549,7 +599,16 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
       RUN(omk_small_nn(dhead, w->head_w, ws.dpooled, (int)B, d.D, c->head_in, s));                 // dX = dY W
       dpooled = ws.dpooled;
     }
-    RUN(omk_pool_bwd(dt, dpooled, attention_mask, dx, B, (int)L, H, c->pooling, s));
+    // 16-bit BERT: the gradient of the pooled rows enters the last LayerNorm's backward in f32 (ws.df is free until the first
+    // GELU' contraction writes it).  That backward projects out most of a contrastive gradient -- the pooled vectors of a batch are
+    // nearly parallel -- and what survives is of the size of a bf16 rounding of what went in: rounding here alone moved the
+    // step from 2.4 x to 3.9 x (worst tensor 8.9 x) the reference's encoder-only bf16 autocast (tools/emulate_train_dataflow.py).
+    if (d.bert16) {
+      dpool32 = (const float*)ws.df;
+      RUN(omk_pool_bwd(OM_F32, dpooled, attention_mask, ws.df, B, (int)L, H, c->pooling, s));
+    } else {
+      RUN(omk_pool_bwd(dt, dpooled, attention_mask, dx, B, (int)L, H, c->pooling, s));
+    }
   }
   if (d.t5)
     return t5_train_backward(c, w, input_ids, attention_mask, d, t, ws, hidden_dropout, attn_dropout, seed, dx,
@@ -598,11 +657,11 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
     const char* x = t.x + t.sx * l;
     const char* qkv = t.qkv + t.sqkv * l;
     const char* ctx = t.ctx + t.sx * l;
-    const char* y1 = t.y1 + t.sx * l;
+    const char* y1 = t.y1 + t.sy * l;
     const char* x1 = t.x1 + t.sx * l;
     const char* f = t.f + t.sf * l;
     const char* gl = t.g + t.sf * l;
-    const char* y2 = t.y2 + t.sx * l;
+    const char* y2 = t.y2 + t.sy * l;
     const WtView wt = wt_of(d, ws, l);
     // where this layer's dY go: shared scratch, or (deferred weight gradients) the layer's keep slice.  The operand of
     // the FFN2 / out-proj sites is the dropout-masked gradient when there is dropout, else the LayerNorm backward's output.
@@ -617,13 +676,14 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
     // LN2 backward: dy2 = d(loss)/d(y2)
     // (+ the FFN output branch's dropout, which sits after the dense and before the residual add, in the same pass)
     WGRAD_DONE(l + 1, 2);                                           // ws.dy / ws.dd: last read by dWo of the layer above
-    RUN(omk_ln_bwd_drop(dt, dx, y2, lw.ln2_g, dy2, dd2, hidden_dropout, site_seed(seed, l, 4), lg.ln2_g, lg.ln2_b, M, H, c->ln_eps, s));
+    RUN(omk_ln_bwd_drop(dt, dx, y2, lw.ln2_g, dy2, dd2, hidden_dropout, site_seed(seed, l, 4), lg.ln2_g, lg.ln2_b, M, H, c->ln_eps, s,
+                        l == d.nl - 1 ? dpool32 : nullptr, d.res32 ? (const float*)y2 : nullptr));
     const char* dO = hidden_dropout > 0.f ? dd2 : dy2;
     WGRAD(0, dO, H, gl, F, lg.ffn2_w, lg.ffn2_b);                   // dW2 [H,F], db2
     {
       GemmEpilogue e1 = {};
       // df = (dO W2) * gelu'(f);  W2^T [F,H].  The tape holds gelu'(f) itself in 16-bit runs (see the forward)
-      e1.act = tape_grad(dt, M, F, H) ? OM_ACT_MUL_RESID : OM_ACT_GELU_ERF_GRAD; e1.resid = f; e1.ldr = F;
+      e1.act = d.pre_grad ? OM_ACT_MUL_RESID : OM_ACT_GELU_ERF_GRAD; e1.resid = f; e1.ldr = F;
       WGRAD_DONE(l + 1, 1);                                         // ws.df: last read by dW1 of the layer above
       RUN(omk_gemm(dt, dO, H, wt.f2, H, dt, dfl, F, M, F, H, e1, s));
     }
@@ -635,7 +695,8 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
     }
     // LN1 backward (ws.dctx holds d/d(x1) for now)
     WGRAD_DONE(l, 0);                                               // ws.dy / ws.dd: read by dW2 of this layer
-    RUN(omk_ln_bwd_drop(dt, ws.dctx, y1, lw.ln1_g, dy1, dd1, hidden_dropout, site_seed(seed, l, 3), lg.ln1_g, lg.ln1_b, M, H, c->ln_eps, s));
+    RUN(omk_ln_bwd_drop(dt, ws.dctx, y1, lw.ln1_g, dy1, dd1, hidden_dropout, site_seed(seed, l, 3), lg.ln1_g, lg.ln1_b, M, H, c->ln_eps, s,
+                        nullptr, d.res32 ? (const float*)y1 : nullptr));
     const char* dA = hidden_dropout > 0.f ? dd1 : dy1;
     WGRAD(2, dA, H, ctx, H, lg.o_w, lg.o_b);                        // dWo [H,H], dbo
     {

@@ -12,7 +12,9 @@ int omk_ln_bwd(int dtype, const void* dy, const void* x, const float* g, void* d
                float* db, int64_t M, int H, float eps, hipStream_t s);
 // LayerNorm backward that also writes dx_drop = dropout(dx) (mask of the forward: seed, element index) when drop_p > 0
 int omk_ln_bwd_drop(int dtype, const void* dy, const void* x, const float* g, void* dx, void* dx_drop, float drop_p,
-                    uint64_t drop_seed, float* dg, float* db, int64_t M, int H, float eps, hipStream_t s);
+                    uint64_t drop_seed, float* dg, float* db, int64_t M, int H, float eps, hipStream_t s,
+                    const float* dy32 = nullptr /* the incoming gradient as f32 [M,H] instead of dy */,
+                    const float* x32 = nullptr /* the normalisation's input as f32 [M,H] instead of x */);
 // LayerNorm (rms = 0) or T5 RMSNorm (rms = 1) backward; `add` (optional, same shape) is added to dx
 int omk_norm_bwd(int dtype, const void* dy, const void* x, const float* g, void* dx, float* dg,
                  float* db, int64_t M, int H, float eps, int rms, const void* add, hipStream_t s);

@@ -181,7 +181,11 @@ __global__ __launch_bounds__((NV == 8 || MODE == 1) ? 256 : 512) void ln_bwd_ker
     const int64_t* __restrict__ ids, const int64_t* __restrict__ type_ids,
     const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
     float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype_, int L, int vocab,
-    int type_vocab, int rms, const T* __restrict__ add, T* __restrict__ dx_drop, float drop_p, uint64_t drop_seed) {
+    int type_vocab, int rms, const T* __restrict__ add, T* __restrict__ dx_drop, float drop_p, uint64_t drop_seed,
+    const float* __restrict__ dy32, const float* __restrict__ x32) {
+  // dy32 / x32 != NULL (MODE 0): the incoming gradient / the normalisation's input are read from these f32 tensors instead of dy / x
+  // (round 5: the gradient of the pooled rows enters the last LayerNorm unrounded; the pre-LayerNorm sums of the 16-bit training
+  // forward are kept in f32 -- tools/emulate_train_dataflow.py)
   constexpr int LNB_WAVES = (NV == 8 || MODE == 1) ? 4 : 8;
   // dx_drop != NULL: also writes dropout(dx) with the forward's mask (seed, element index) -- the gradient entering the
   // dense layer in front of the residual add -- so that no separate dropout pass re-reads dx.
@@ -235,12 +239,12 @@ __global__ __launch_bounds__((NV == 8 || MODE == 1) ? 256 : 512) void ln_bwd_ker
       const int c = (lane + 64 * j) * 4;
       if (c < H) {
         if (MODE == 0) {
-          load4<T>(x + row * H + c, xv[j]);
+          if (x32) load4<float>(x32 + row * H + c, xv[j]); else load4<T>(x + row * H + c, xv[j]);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) xv[j][e] = (word[id * H + c + e] + type[tt * H + c + e]) + pos[(int64_t)t * H + c + e];
         }
-        load4<T>(dy + row * H + c, dv[j]);
+        if (MODE == 0 && dy32) load4<float>(dy32 + row * H + c, dv[j]); else load4<T>(dy + row * H + c, dv[j]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) s1 += xv[j][e];
       } else {
@@ -381,7 +385,8 @@ static int launch_ln_bwd(const void* dy, const void* x, const float* g, void* dx
                          int64_t M, int H, float eps, const int64_t* ids, const int64_t* tt,
                          const float* word, const float* pos, const float* type, float* dword,
                          float* dpos, float* dtype_, int L, int vocab, int type_vocab, hipStream_t s,
-                         int rms = 0, const void* add = nullptr, void* dx_drop = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0) {
+                         int rms = 0, const void* add = nullptr, void* dx_drop = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0,
+                         const float* dy32 = nullptr, const float* x32 = nullptr) {
   const int waves = (H <= 1024 && MODE == 0) ? 8 : 4;
   const int64_t want = (M + waves - 1) / waves;
   // two blocks per CU: ~12 MB of loads in flight (one row per wave at a time), what ~5 TB/s x ~2 us of latency needs;
@@ -393,7 +398,7 @@ static int launch_ln_bwd(const void* dy, const void* x, const float* g, void* dx
     grid = (unsigned)(L * parts);
   }
   const size_t lds = (size_t)2 * waves * H * sizeof(float);       // <= 64 KiB for both shapes
-#define LNB(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, MODE>), dim3(grid), dim3(64 * waves), lds, s, (const T*)dy, (const T*)x, g, (T*)dx, dg, db, M, H, eps, ids, tt, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, rms, (const T*)add, (T*)dx_drop, drop_p, drop_seed)
+#define LNB(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, MODE>), dim3(grid), dim3(64 * waves), lds, s, (const T*)dy, (const T*)x, g, (T*)dx, dg, db, M, H, eps, ids, tt, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, rms, (const T*)add, (T*)dx_drop, drop_p, drop_seed, dy32, x32)
   if (H <= 1024) LNB(4); else LNB(8);
 #undef LNB
   OM_LAUNCH_CHECK();
@@ -406,13 +411,14 @@ int omk_ln_bwd(int dtype, const void* dy, const void* x, const float* g, void* d
 }
 
 int omk_ln_bwd_drop(int dtype, const void* dy, const void* x, const float* g, void* dx, void* dx_drop, float drop_p,
-                    uint64_t drop_seed, float* dg, float* db, int64_t M, int H, float eps, hipStream_t s) {
+                    uint64_t drop_seed, float* dg, float* db, int64_t M, int H, float eps, hipStream_t s, const float* dy32,
+                    const float* x32) {
   if (M <= 0) return 0;
   if (H % 4 || H > 2048) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
   if (drop_p <= 0.f) dx_drop = nullptr;
   if (dtype == OM_BF16)
-    return launch_ln_bwd<bf16_t, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, 0, nullptr, dx_drop, drop_p, drop_seed);
-  return launch_ln_bwd<float, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, 0, nullptr, dx_drop, drop_p, drop_seed);
+    return launch_ln_bwd<bf16_t, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, 0, nullptr, dx_drop, drop_p, drop_seed, dy32, x32);
+  return launch_ln_bwd<float, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, 0, nullptr, dx_drop, drop_p, drop_seed, dy32, x32);
 }
 
 int omk_norm_bwd(int dtype, const void* dy, const void* x, const float* g, void* dx, float* dg,
