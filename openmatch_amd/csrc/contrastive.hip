@@ -71,6 +71,25 @@ __global__ void ce_reduce_kernel(const float* __restrict__ row_loss, int Qg, flo
   if (threadIdx.x == 0) *loss = reduction == OM_CE_MEAN ? acc / (valid ? *valid : (float)Qg) * scale : acc * scale;   // all rows ignored: nan, as torch
 }
 
+// S[i,j] = <q_i, p_j> for a training batch's score matrix (8 x 64 per GPU, 64 x 512 with cross-device negatives): one wave per
+// dot product.  The exact-f32 MFMA GEMM took 58 us for this one 128 x 128 tile (a k-ordered chain of 384 dependent MFMAs on one CU,
+// profiles/r05_train_timeline_v1.txt); this is ~5 us.  f32 fmaf chains per lane + a wave reduction.
+__global__ __launch_bounds__(256) void scores_small_kernel(const float* __restrict__ q, const float* __restrict__ p,
+                                                            float* __restrict__ S, int Qg, int Pg, int d) {
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= (int64_t)Qg * Pg) return;
+  const int i = (int)(w / Pg), j = (int)(w % Pg), lane = threadIdx.x & 63;
+  const float4* a = (const float4*)(q + (int64_t)i * d);
+  const float4* b = (const float4*)(p + (int64_t)j * d);
+  float acc = 0.f;
+  for (int c = lane; c < d / 4; c += 64) {
+    const float4 x = a[c], y = b[c];
+    acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) S[w] = acc;
+}
+
 // d_q[i,c] = sum_j dS[q_row0+i, j] * p[j,c]
 __global__ void dq_kernel(const float* __restrict__ dS, const float* __restrict__ p,
                           float* __restrict__ dq, int Pg, int d, int q_row0) {
@@ -111,8 +130,12 @@ extern "C" int om_contrastive_fwd_bwd_ex(const float* q, const float* p, int Qg,
   float* row_loss = dS + (size_t)Qg * Pg;
   float* valid = row_loss + Qg;
   const bool bwd = d_q || d_p;
-  if (om_gemm_nt(OM_F32, q, d, p, d, OM_F32, S, Pg, Qg, Pg, d, nullptr, nullptr, 0, OM_ACT_NONE, s))
+  if ((int64_t)Qg * Pg <= 65536 && d % 4 == 0 && !(((uintptr_t)q | (uintptr_t)p) & 15)) {
+    hipLaunchKernelGGL(scores_small_kernel, dim3((unsigned)(((int64_t)Qg * Pg + 3) / 4)), dim3(256), 0, s, q, p, S, Qg, Pg, d);
+    OM_LAUNCH_CHECK();
+  } else if (om_gemm_nt(OM_F32, q, d, p, d, OM_F32, S, Pg, Qg, Pg, d, nullptr, nullptr, 0, OM_ACT_NONE, s)) {
     return 1;
+  }
   if (target) {
     hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(64), 0, s, target, Qg, valid);
     OM_LAUNCH_CHECK();

@@ -292,6 +292,13 @@ struct WgradLane {
   int device = -1;
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> ready, done, mark;
+  // Early weight transposes (round 5, OM_OPT_TRAIN_WGRAD_STREAM bit 1): the backward's data gradients need every W^T (170 us of
+  // memory-bound transposes at the head of each backward, profiles/r05_train_timeline_v1.txt).  They depend on the weights only,
+  // so the training FORWARD launches them on this side stream, under its own contractions; the backward waits for wt_done instead
+  // of transposing -- when the workspace and the weights are still the ones the transposes were made from.
+  hipEvent_t wt_start = nullptr, wt_done = nullptr;
+  const void *wt_ws = nullptr /* the ws.wt they were written to */, *wt_w0 = nullptr, *wt_w1 = nullptr;
+  int wt_nl = 0;
 };
 static thread_local WgradLane g_lane;
 static int lane_get(int n_layers, WgradLane** out) {
@@ -313,6 +320,10 @@ static int lane_get(int n_layers, WgradLane** out) {
   RUN(grow(g_lane.ready, (size_t)n_layers * 4));
   RUN(grow(g_lane.done, (size_t)n_layers * 4));
   RUN(grow(g_lane.mark, (size_t)n_layers + 1));
+  if (!g_lane.wt_start) {
+    OM_HIP(hipEventCreateWithFlags(&g_lane.wt_start, hipEventDisableTiming));
+    OM_HIP(hipEventCreateWithFlags(&g_lane.wt_done, hipEventDisableTiming));
+  }
   *out = &g_lane;
   return 0;
 }
@@ -450,6 +461,16 @@ static int train_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* 
   if (L > c->max_pos) OM_FAIL("sequence longer than the position table");
 
   tape_flags_set(tape_mem, flags_of(d));
+  if ((om_option(OM_OPT_TRAIN_WGRAD_STREAM) & 2) && d.es == 2 && d.nl > 0) {
+    WgradLane* lane = nullptr;
+    RUN(lane_get(d.nl, &lane));
+    OM_HIP(hipEventRecord(lane->wt_start, s));                       // everything queued so far (the optimizer's update of the
+    OM_HIP(hipStreamWaitEvent(lane->side, lane->wt_start, 0));       // weights, the last reader of ws.wt) comes first
+    lane->wt_ws = nullptr;
+    RUN(transpose_weights(dt, Ls, d, ws, lane->side));
+    OM_HIP(hipEventRecord(lane->wt_done, lane->side));
+    lane->wt_ws = ws.wt; lane->wt_w0 = Ls[0].qkv_w; lane->wt_w1 = Ls[d.nl - 1].ffn2_w; lane->wt_nl = d.nl;
+  }
   RUN(omk_embed(dt, input_ids, token_type_ids, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g,
                 w->emb_ln_b, t.x, M, (int)L, H, c->vocab, c->type_vocab, c->ln_eps, 1, s));
   if (hidden_dropout > 0.f) RUN(omk_dropout(dt, t.x, t.x, M * H, hidden_dropout, site_seed(seed, 0, 0), s));
@@ -649,7 +670,15 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
   } while (0)
   // before the main stream rewrites a buffer that weight gradient I_ of layer L_ reads
 #define WGRAD_DONE(L_, I_) do { if (lane && !wbatch && (L_) < d.nl) OM_HIP(hipStreamWaitEvent(s, lane->done[(L_) * 4 + (I_)], 0)); } while (0)
-  RUN(transpose_weights(dt, Ls, d, ws, s));
+  if (g_lane.wt_ws == ws.wt && g_lane.wt_w0 == Ls[0].qkv_w && g_lane.wt_w1 == Ls[d.nl - 1].ffn2_w && g_lane.wt_nl == d.nl &&
+      g_lane.wt_done && (om_option(OM_OPT_TRAIN_WGRAD_STREAM) & 2)) {
+    OM_HIP(hipStreamWaitEvent(s, g_lane.wt_done, 0));               // the forward's side-stream transposes of these very weights
+  } else {
+    // (a forward's transposes of OTHER weights / another shape may still be writing an overlapping part of the workspace)
+    if (g_lane.wt_done && g_lane.wt_ws) OM_HIP(hipStreamWaitEvent(s, g_lane.wt_done, 0));
+    RUN(transpose_weights(dt, Ls, d, ws, s));
+    g_lane.wt_ws = nullptr;                                          // ws.wt now holds what THIS call made: not the forward's
+  }
 
   for (int l = d.nl - 1; l >= 0; --l) {
     const OmLayerWeights& lw = Ls[l];
