@@ -92,9 +92,11 @@ void om_debug_gemm_gen(int gen);
 #define OM_OPT_GEMM_GROUP_M 6     /* row tiles per group of the persistent GEMM's tile walk (default 8): the group's A panels stay in an
                                    * XCD's L2 while its column tiles are swept */
 #define OM_OPT_SCAN_QGROUP 7      /* query tiles (256 queries each) an XCD keeps resident in its L2 during the index scan (default 8) */
-#define OM_OPT_TRAIN_WGRAD_STREAM 8 /* bit 0 (default 3 = both): the BERT backward's weight-gradient GEMMs run on a second stream beside the data-gradient
-                                    * chain (neither fills the GPU alone at training batch sizes); bit 1 (round 5): the weight transposes the backward
-                                    * needs are launched by the training FORWARD on that stream; 0: everything on the caller's stream */
+#define OM_OPT_TRAIN_WGRAD_STREAM 8 /* bit 0 (default 1): the BERT backward's weight-gradient GEMMs run on a second stream beside the data-gradient
+                                    * chain (neither fills the GPU alone at training batch sizes); bit 1 (round 5, A/B, off): the weight transposes the
+                                    * backward needs are launched by the training FORWARD on that stream -- measured 3 % SLOWER (the memory-bound transposes
+                                    * take more from the forward's contractions than the 170 us they save: profiles/r05_train_ab_v2_*.jsonl);
+                                    * 0: everything on the caller's stream */
 #define OM_OPT_ATTENTION_DEBUG 9  /* 0 (default); timing experiments on the bf16 attention kernel at L in (64, 128]: bit 0 no K / V fetch,
                                    * bit 1 no arithmetic, bit 2 no stores (results are garbage) */
 #define OM_OPT_ENCODER_PINGPONG 10 /* 1 (default): the fused bf16 encoder's kernels alternate their walk direction over the token rows so

@@ -91,7 +91,7 @@ void opt_init() {
   e = getenv("OM_ENCODER_PINGPONG");
   g_opt[OM_OPT_ENCODER_PINGPONG] = e ? atoi(e) : 1;
   e = getenv("OM_TRAIN_WGRAD_STREAM");
-  g_opt[OM_OPT_TRAIN_WGRAD_STREAM] = e ? atoi(e) : 3;
+  g_opt[OM_OPT_TRAIN_WGRAD_STREAM] = e ? atoi(e) : 1;
   e = getenv("OM_SCAN_QGROUP");
   g_opt[OM_OPT_SCAN_QGROUP] = e ? atoi(e) : 8;
   e = getenv("OM_GEMM_GROUP_M");

@@ -292,7 +292,8 @@ struct WgradLane {
   int device = -1;
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> ready, done, mark;
-  // Early weight transposes (round 5, OM_OPT_TRAIN_WGRAD_STREAM bit 1): the backward's data gradients need every W^T (170 us of
+  // Early weight transposes (round 5, OM_OPT_TRAIN_WGRAD_STREAM bit 1, OFF by default: measured 102.4-103.0 steps/s with them against
+  // 105.4-105.8 without on one box, profiles/r05_train_ab_v2_*.jsonl): the backward's data gradients need every W^T (170 us of
   // memory-bound transposes at the head of each backward, profiles/r05_train_timeline_v1.txt).  They depend on the weights only,
   // so the training FORWARD launches them on this side stream, under its own contractions; the backward waits for wt_done instead
   // of transposing -- when the workspace and the weights are still the ones the transposes were made from.
