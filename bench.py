@@ -464,10 +464,11 @@ def main():
         except Exception:
             traffic = None
     roofline = {
-        "kernel": (("gemm_nt_kernel7c16 / 7r16<%s> (persistent 256x256 tiles on a continuous five-unit LDS ring, 128-byte K steps, "
-                    "16x16x32 MFMAs; encoder QKV / out-proj / FFN contractions, plain / GELU / LayerNorm-residual epilogues"
-                    "%s)" % (a.precision, "; bf16: the two-plane residual epilogue runs on gemm_nt_kernel7" if a.precision == "bf16" else ""))
-                   if half else "gemm_nt_kernel6<f32> (exact-f32 MFMA)"),
+        "kernel": ("gemm_nt_kernel7c16 / gemm_nt_kernel7r16<%s>" % a.precision) if half else "gemm_nt_kernel6<f32>",
+        "kernel_note": (("persistent 256x256 tiles on a continuous five-unit LDS ring, 128-byte K steps, 16x16x32 MFMAs; the encoder's QKV / "
+                         "out-proj / FFN contractions with plain / GELU / LayerNorm-residual epilogues%s"
+                         % ("; bf16: the two-plane residual epilogue runs on gemm_nt_kernel7" if a.precision == "bf16" else ""))
+                        if half else "exact-f32 MFMA (32x32x2), k-ordered fmaf chain"),
         "bound": "mfma", "achieved": round(gemm_tflops, 1), "peak": peak, "unit": "TFLOP/s",
         "frac": round(gemm_tflops / peak, 4), "traffic": traffic,
         "traffic_source": tsrc,
@@ -616,6 +617,15 @@ def main():
                        "passages_per_step_per_gpu": a.batch, "seq_len": L, "global_batch": a.batch * world,
                        "index_rows": a.index_rows, "queries": a.queries, "topk": a.topk,
                        "weights": "random-init BertConfig() seed 0", "parallelism": f"shard{world}"},
+            # what every rank did (round 5: so that the first real 8-GPU run needs no edits): encode is WEAK scaling (each rank its own
+            # `passages_per_step_per_gpu` batches, no collective), search is STRONG scaling (the 8.84 M rows split by rank, queries
+            # all-gathered, candidates exchanged by query range with one all-to-all + per-slice merge)
+            "ranks": {"world": world, "rccl_ranks": rccl_ranks,
+                      "encode": {"scaling": "weak", "passages_per_step": [a.batch] * world},
+                      "search": (None if a.no_search else
+                                 {"scaling": "strong" if world > 1 else "single shard",
+                                  "index_rows": [shard_range(a.index_rows, world, r)[0] for r in range(world)],
+                                  "query_slices": [shard_range(a.queries, world, r)[0] for r in range(world)]})},
             "roofline": roofline, "search": search, "parity": parity, other16: f16_mode, "packed": packed_mode, "f32": f32_mode, "train": train, "cpu_baseline": cpu,
         }
         print(json.dumps(line), file=json_out, flush=True)
