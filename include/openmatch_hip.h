@@ -263,6 +263,9 @@ int om_encoder_forward(const OmEncoderConfig* cfg, const OmEncoderWeights* w,
  * rounded up to a multiple of 256, >= 512.  The bound is checked on the device: a batch that holds more tokens returns
  * NaN in every representation (no host synchronisation, never a truncated batch).
  * Workspace: om_encoder_workspace_bytes_packed(cfg, B, L, packed_rows). */
+/* 1 when om_encoder_forward_packed takes (cfg, B, L, packed_rows) under the current run-time switches (OM_OPT_*), else 0:
+ * the host layer asks before choosing the packed entry and falls back to om_encoder_forward.  gated_ffn: T5 v1.1 layers (ffn1g_w). */
+int om_encoder_packed_supported(const OmEncoderConfig* cfg, int gated_ffn, int64_t B, int64_t L, int64_t packed_rows);
 size_t om_encoder_workspace_bytes_packed(const OmEncoderConfig* cfg, int64_t B, int64_t L, int64_t packed_rows);
 int om_encoder_forward_packed(const OmEncoderConfig* cfg, const OmEncoderWeights* w,
                               const int64_t* input_ids, const int64_t* attention_mask,

@@ -31,13 +31,18 @@ def _newest(paths):
     return max(os.path.getmtime(p) for p in paths if os.path.exists(p))
 
 
-def build_native(force=False, verbose=False):
-    """Compile every translation unit for gfx950 and link the shared library. Returns its path."""
+def build_native(force=False, verbose=False, probe=False):
+    """Compile every translation unit for gfx950 and link the shared library. Returns its path.
+    probe=True (`--probe`): also compile the timing variants of the attention / small-batch scan kernels that skip part of their
+    work (-DOM_PROBE_KERNELS; selectable with OM_ATTENTION_DEBUG / OM_SEARCH_DEBUG bits 3-4, results WRONG) -- never shipped."""
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
     flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-x", "hip", "-Wno-unused-result"]
+    if probe:
+        flags.append("-DOM_PROBE_KERNELS")
+        force = True
     hdr_time = _newest(hdrs)
 
     def compile_one(src):
@@ -66,4 +71,4 @@ def build_native(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build_native(force="--force" in sys.argv, verbose=True))
+    print(build_native(force="--force" in sys.argv, verbose=True, probe="--probe" in sys.argv))

@@ -390,8 +390,15 @@ static int launch_attn16_(const void* qkv, void* ctx, const int64_t* mask, const
     OM_HIP(hipFuncSetAttribute((const void*)attention_fwd16_kernel<T, KT, BIAS, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
+  // The timing variants (parts of the kernel compiled out: their results are WRONG) exist in probe builds only
+  // (-DOM_PROBE_KERNELS: python -m openmatch_amd._build --probe); the product library ignores OM_OPT_ATTENTION_DEBUG.
+#ifdef OM_PROBE_KERNELS
   const int dbg = (sizeof(T) == 2 && std::is_same<T, bf16_t>::value && KT == 4 && !BIAS && !DROP) ? om_option(OM_OPT_ATTENTION_DEBUG) : 0;
+#else
+  const int dbg = 0;
+#endif
   if (dbg) {
+#ifdef OM_PROBE_KERNELS
 #define OM_ATTN_DBG(D)                                                                                                        \
   case D:                                                                                                                     \
     hipLaunchKernelGGL((attention_fwd16_kernel<bf16_t, 4, false, false, D>), dim3((unsigned)(heads * B)), dim3(256), lds, s,          \
@@ -399,6 +406,7 @@ static int launch_attn16_(const void* qkv, void* ctx, const int64_t* mask, const
     break;
     switch (dbg) { OM_ATTN_DBG(1) OM_ATTN_DBG(2) OM_ATTN_DBG(3) OM_ATTN_DBG(4) OM_ATTN_DBG(5) OM_ATTN_DBG(6) OM_ATTN_DBG(7) default: break; }
 #undef OM_ATTN_DBG
+#endif
     OM_LAUNCH_CHECK();
     return 0;
   }

@@ -162,6 +162,25 @@ extern "C" size_t om_encoder_workspace_bytes(const OmEncoderConfig* cfg, int64_t
   return carve(cfg, B, L, nullptr).total;
 }
 
+// Whether om_encoder_forward_packed would take (cfg, B, L, packed_rows) under the CURRENT run-time switches: the same tests the
+// forward makes (fused 16-bit path for these widths and this row count, the 16-bit inference attention kernel).  The host layer
+// asks before it chooses the packed entry, so that an A/B switch (OM_GEMM_VARIANT, OM_ENCODER_FUSED_LN = 0, OM_ATTENTION_FAST = 0,
+// om_debug_gemm_gen) degrades a compact batch to the padded entry instead of failing the call.
+extern "C" int om_encoder_packed_supported(const OmEncoderConfig* c, int gated_ffn, int64_t B, int64_t L, int64_t packed_rows) {
+  if (!c || B <= 0 || L <= 0 || L > 256 || packed_rows <= 0) return 0;
+  if (packed_rows % 256 || packed_rows < 512 || packed_rows > B * L + 255) return 0;
+  const int dt = c->dtype;
+  if (dt != OM_BF16 && dt != OM_F16) return 0;
+  if (dt == OM_BF16 && !om_option(OM_OPT_ATTENTION_FAST)) return 0;
+  if (om_option(OM_OPT_ENCODER_FUSED_LN) == 0 || c->n_layers <= 0 || c->hidden % 8) return 0;
+  const int H = c->hidden, F = c->ffn;
+  if (c->arch == OM_ARCH_BERT) { if (c->act != OM_ACT_GELU_ERF) return 0; }
+  else if (c->arch == OM_ARCH_T5) { if (gated_ffn || dt != OM_BF16) return 0; }
+  else return 0;
+  return omk_gemm_ln_fusable(dt, packed_rows, H, H) && omk_gemm_ln_fusable(dt, packed_rows, F, H) &&
+         omk_gemm_ln_fusable(dt, packed_rows, 3 * H, H) && omk_gemm_ln_fusable(dt, packed_rows, H, F) ? 1 : 0;
+}
+
 extern "C" size_t om_encoder_workspace_bytes_packed(const OmEncoderConfig* cfg, int64_t B, int64_t L, int64_t packed_rows) {
   if (!cfg || B <= 0 || L <= 0 || packed_rows <= 0) return 0;
   return carve(cfg, B, L, nullptr, packed_rows).total;

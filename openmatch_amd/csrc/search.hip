@@ -1239,7 +1239,11 @@ struct Scan {
           if (whole / SR_UROWS < ncu) ncu = (int)(whole / SR_UROWS);
 #define STREAM_(NB_, DBG_) hipLaunchKernelGGL((sim_stream_reg_kernel<f16_t, NB_, DBG_>), dim3((unsigned)ncu), dim3(G6_THREADS), SR_LDS, s, idx16 + r0 * d, whole, \
                                        (uint32_t)r0, ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, (om_option(OM_OPT_SEARCH_DEBUG) & 4) ? 0 : 1)
+#ifdef OM_PROBE_KERNELS      // timing variants with MFMAs compiled out (WRONG results): probe builds only (python -m openmatch_amd._build --probe)
 #define STREAM(NB_) do { const int dbg_ = (om_option(OM_OPT_SEARCH_DEBUG) >> 3) & 3; if (dbg_ == 1) STREAM_(NB_, 1); else if (dbg_ == 2) STREAM_(NB_, 2); else STREAM_(NB_, 0); } while (0)
+#else
+#define STREAM(NB_) STREAM_(NB_, 0)
+#endif
           if (nq <= 32) STREAM(1); else if (nq <= 64) STREAM(2); else STREAM(4);
 #undef STREAM
 #undef STREAM_

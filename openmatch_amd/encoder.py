@@ -385,7 +385,13 @@ def packed_rows_apply(cfg, B, L, rows, want_hidden, pooling, gated=False):
         return False
     if cfg.arch == N.ARCH_T5 and gated:
         return False
-    return rows % 256 == 0 and 512 <= rows <= (B * L) // 256 * 256 - 256
+    if not (rows % 256 == 0 and 512 <= rows <= (B * L) // 256 * 256 - 256):
+        return False
+    # the library's own view under the current run-time switches (an A/B switch that takes the fused path away degrades the batch to
+    # the padded entry instead of failing the call)
+    if not isinstance(cfg, N.OmEncoderConfig):
+        cfg = N.OmEncoderConfig(**{f: getattr(cfg, f) for f, _ in N.OmEncoderConfig._fields_ if hasattr(cfg, f)})
+    return bool(N.lib().om_encoder_packed_supported(C.byref(cfg), int(bool(gated)), B, L, rows))
 
 
 def hip_encode(model, items, pooling, head, normalize, code, want_hidden=True, packed_rows=None):

@@ -117,6 +117,7 @@ _SIGNATURES = {
     "om_encoder_forward": (c_int, [C.POINTER(OmEncoderConfig), C.POINTER(OmEncoderWeights), c_void_p,
                                    c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                    c_void_p, c_size_t, c_void_p]),
+    "om_encoder_packed_supported": (c_int, [C.POINTER(OmEncoderConfig), c_int, c_int64, c_int64, c_int64]),
     "om_encoder_workspace_bytes_packed": (c_size_t, [C.POINTER(OmEncoderConfig), c_int64, c_int64, c_int64]),
     "om_encoder_forward_packed": (c_int, [C.POINTER(OmEncoderConfig), C.POINTER(OmEncoderWeights), c_void_p,
                                           c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,

@@ -46,15 +46,24 @@ def parameter_groups(model, weight_decay: float):
     return [{"params": decay, "weight_decay": weight_decay}, {"params": no_decay, "weight_decay": 0.0}]
 
 
-_ctl = {"group": None, "made": False}
+_ctl = {"group": None, "made_for": None}
 
 
 def _control_group():
-    """A host-side (gloo) process group for tiny control collectives that must not touch the GPU stream.  Created on the
-    first gradient averaging, which every rank reaches together; the default group itself when that is already gloo."""
-    if not _ctl["made"]:
-        _ctl["made"] = True
-        _ctl["group"] = None if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+    """A host-side (gloo) process group for tiny control collectives that must not touch the GPU stream; the default group itself
+    when that is already gloo.  Cached per DEFAULT process group: after destroy_process_group() + a new init (tests, several trainers
+    in one process) a fresh one is made.  `DRTrainer.train` calls this once up front, where every rank is at the same point
+    (new_group is itself a collective); a lazy first call from allreduce_mean_ is safe only because every rank makes it in step."""
+    from torch.distributed import distributed_c10d as c10d
+    default = c10d._get_default_group()
+    if _ctl["made_for"] is not default:
+        grp = None
+        if dist.get_backend() != "gloo":
+            try:
+                grp = dist.new_group(backend="gloo")
+            except Exception as e:            # noqa: BLE001  (no gloo in this build: the check runs over the default group instead)
+                logger.warning("no gloo control group (%s): gradient-pattern check runs over the default group", e)
+        _ctl["group"], _ctl["made_for"] = grp, default
     return _ctl["group"]
 
 
@@ -101,8 +110,9 @@ def allreduce_mean_(params: List[torch.nn.Parameter], world_size: int, bucket_by
     if world_size > 1 and dist.is_initialized():
         import hashlib
         h = int.from_bytes(hashlib.blake2b(repr(sig).encode(), digest_size=7).digest(), "little")
-        t = torch.tensor([h, -h], dtype=torch.int64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_control_group())
+        grp = _control_group()
+        t = torch.tensor([h, -h], dtype=torch.int64, device=grads[0].device if (grp is None and dist.get_backend() == "nccl" and grads) else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
         if int(t[0]) != -int(t[1]):
             raise RuntimeError("allreduce_mean_: the ranks hold different gradient patterns (a parameter that received "
                                f"no gradient on some ranks only?); this rank: {sig}")
@@ -350,6 +360,8 @@ class DRTrainer:
         sync = GradSync(W, getattr(a, "grad_bucket_layers", 4)) if (
             W > 1 and accum == 1 and type(self).training_step is DRTrainer.training_step
             and getattr(a, "overlap_grad_allreduce", True)) else None
+        if W > 1 and dist.is_initialized():
+            _control_group()                  # made here, where every rank is at the same point
         if resume_from_checkpoint:
             logger.warning("resume_from_checkpoint=%r is not supported by this trainer (optimizer state is not "
                            "checkpointed): training starts from the model's current weights", resume_from_checkpoint)

@@ -545,6 +545,17 @@ def test_model_batch_and_packed_rows_apply_conditions():
     assert ok(cfg={"arch": N.ARCH_T5, "act": N.ACT_RELU, "dtype": N.OM_BF16}) and not ok(cfg={"arch": N.ARCH_T5, "act": N.ACT_RELU}, gated=True)
     assert not ok(rows=256) and not ok(rows=4100) and not ok(rows=B * Lp) and ok(rows=B * Lp - 256)
     assert not ok(L=512, rows=4096)
+    # the library's run-time switches are part of the answer (om_encoder_packed_supported): with the fused path switched off for an
+    # A/B run the compact batch goes to the padded entry instead of failing inside the call
+    lib = N.lib()
+    for opt, off in ((0, 0), (12, 2)):                       # OM_OPT_ENCODER_FUSED_LN = 0; OM_OPT_GEMM_VARIANT = 2
+        default = 1 if opt == 0 else 0
+        N.check(lib.om_debug_option(opt, off))
+        try:
+            assert not ok()
+        finally:
+            N.check(lib.om_debug_option(opt, default))
+    assert ok()
     os.environ["OM_ENCODER_PACKED"] = "0"
     try:
         assert not ok()
