@@ -162,6 +162,45 @@ def config1(rng):
     print("wrote config1_bert_base.npz")
 
 
+def config1_ac16():
+    """Adds the reference's float16-autocast run (its real `--fp16` mode, retriever/dense_retriever.py:76) to an existing
+    config1_bert_base.npz: embeddings rounded to f16 (P_ac16, Q_ac16), its top-100 ranking and its MRR@10 on the fixture's judgments
+    -- the yardstick a float16 path's MRR deviation belongs next to (round 5).  The stored fp32 / bf16-autocast arrays stay as they
+    are (bf16 autocast on the CPU is not bit-reproducible across runs; the fp32 embeddings are, and are re-checked here)."""
+    path = os.path.join(OUT, "config1_bert_base.npz")
+    g = np.load(path, allow_pickle=False)
+    out = {k: g[k] for k in g.files}
+    torch.manual_seed(0)
+    cfg = BertConfig()
+    lm = BertModel(cfg).eval()
+    assert np.allclose(checksum(lm), out["weight_checksum"], rtol=1e-12)
+    ref = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False))
+    L = lambda ids, lens, n: (ids.astype(np.int64), (np.arange(n)[None, :] < lens.astype(np.int64)[:, None]).astype(np.int64))
+    p_ids, p_mask = L(out["p_input_ids"], out["p_len"], 128)
+    q_ids, q_mask = L(out["q_input_ids"], out["q_len"], 32)
+    doc_ids, qry_ids = [str(x) for x in out["doc_ids"]], [str(x) for x in out["qry_ids"]]
+    Qf = encode_all(ref, "query", q_ids, q_mask, 50, False)
+    assert np.array_equal(Qf, out["Q_f32"]), "the fp32 query embeddings of this run differ from the stored ones"
+    P16 = encode_all(ref, "passage", p_ids, p_mask, 50, True, ac_dtype=torch.float16)
+    Q16 = encode_all(ref, "query", q_ids, q_mask, 50, True, ac_dtype=torch.float16)
+    run16, _ = reference_search(P16, Q16, doc_ids, qry_ids, 100)
+    I16, D16 = run_to_arrays(run16, qry_ids, doc_ids)
+    qrel = {q: {str(d): 1} for q, d in zip(qry_ids, out["qrel_docs"])}
+    out["P_ac16"], out["Q_ac16"], out["I100_ac16"] = P16.astype(np.float16), Q16.astype(np.float16), I16
+    out["mrr10_ac16"] = np.array(mg.reference_eval_mrr()(qrel, run16, cutoff=10)["all"])
+    Pf, Pa = torch.from_numpy(out["P_f32"]).double(), torch.from_numpy(P16).double()
+    Qd, Qa = torch.from_numpy(out["Q_f32"]).double(), torch.from_numpy(Q16).double()
+    cos = torch.nn.functional.cosine_similarity(Pf, Pa, dim=1)
+    dd = ((Qa @ Pa.t()) - (Qd @ Pf.t())).abs()
+    ov = [len(set(a.tolist()) & set(b.tolist())) for a, b in zip(out["I100_f32"], I16)]
+    out["ac16_vs_f32"] = np.array([float(cos.min()), float(cos.mean()), float(dd.max()), float(np.mean(ov)), float(np.min(ov))])
+    print("  config 1, reference float16 autocast vs its fp32: min cos %.8f mean cos %.8f max|ddot| %.4f top-100 overlap %.1f (min %d); MRR@10 fp32 %.4f, "
+          "float16 autocast %.4f (|d| %.4f; bf16 autocast: %.4f)" % (*out["ac16_vs_f32"], float(out["mrr10_f32"]), float(out["mrr10_ac16"]),
+                                                                      abs(float(out["mrr10_ac16"]) - float(out["mrr10_f32"])), abs(float(out["mrr10_ac"]) - float(out["mrr10_f32"]))))
+    np.savez_compressed(path, **out)
+    print("updated config1_bert_base.npz")
+
+
 def config1_spread(rng):
     torch.manual_seed(0)
     cfg = BertConfig(initializer_range=0.1)
@@ -446,6 +485,8 @@ def main():
         config1_spread(np.random.default_rng(SEED + 14))
     if "spread_qrels" in what:
         spread_qrels()
+    if "config1_ac16" in what:
+        config1_ac16()
     if "gtr" in what:
         gtr_base(np.random.default_rng(SEED + 12))
     if "large" in what:
