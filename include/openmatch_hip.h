@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OM_ABI_VERSION 5   /* 5 (round 5): om_grad_sqnorm, om_adamw_step */
+#define OM_ABI_VERSION 5   /* 5 (round 5): om_grad_sqnorm, om_adamw_step, om_loss_scale_update, om_encoder_packed_supported; OM_F16 training */
 
 /* element types */
 #define OM_F32 0
@@ -423,7 +423,7 @@ int om_encoder_train_set_layer_events(void* const* events, int n);
  *   om_adamw_step    torch.optim.AdamW's update with bias corrections for `step` (counted from 1) on
  *                    g' = g * grad_scale * min(1, max_norm / (|g * grad_scale|_2 + 1e-6))   (max_norm <= 0: no clipping);
  *                    gnorm_sq = om_grad_sqnorm's out_sq (required when clipping).  skip_nonfinite != 0: an inf / nan norm
- *                    leaves every buffer untouched (the skipped step of a float16 GradScaler); the caller reads out_sq to learn of it.
+ *                    leaves every buffer untouched (the skipped step of a float16 GradScaler); om_loss_scale_update reads the same scalar.
  * ------------------------------------------------------------------------ */
 #define OM_ADAM_CHUNK 16384
 typedef struct OmAdamTensor {
@@ -435,7 +435,12 @@ typedef struct OmAdamTensor {
 } OmAdamTensor;
 int om_grad_sqnorm(const OmAdamTensor* tensors, const int32_t* chunks, int n_chunks, float* partial, float* out_sq, void* stream);
 int om_adamw_step(const OmAdamTensor* tensors, const int32_t* chunks, int n_chunks, float lr, float beta1, float beta2, float eps,
-                  int64_t step, const float* gnorm_sq, float max_norm, float grad_scale, int skip_nonfinite, void* stream);
+                  int64_t step, const float* gnorm_sq, float max_norm, float grad_scale, int skip_nonfinite,
+                  const float* inv_scale /* device scalar multiplied into grad_scale, or NULL: state4[1] of om_loss_scale_update */, void* stream);
+/* Dynamic loss scale of float16 training (torch.cuda.amp.GradScaler.update; the reference's --fp16 through HF Trainer,
+ * trainer/dense_trainer.py:141-149) on the device: state4 = {scale, 1 / scale, clean steps, skipped steps}; a non-finite
+ * gnorm_sq[0] (om_grad_sqnorm of the SCALED gradients) halves the scale, `growth_interval` finite steps in a row double it. */
+int om_loss_scale_update(const float* gnorm_sq, float* state4, int growth_interval, void* stream);
 
 /* ------------------------------------------------------------------------
  * Exact inner-product search.  Replaces faiss.IndexFlatIP.add / .search

@@ -35,21 +35,31 @@ __device__ __forceinline__ v4s trd(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p));
 }
 __device__ __forceinline__ frag_t frag_of(v4s a, v4s b) { return (frag_t){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
-__device__ __forceinline__ uint32_t pk2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
-__device__ __forceinline__ frag_t pack8(const f32x16_t& v, int u) {
-  const uint4 w = make_uint4(pk2(v[8 * u + 0], v[8 * u + 1]), pk2(v[8 * u + 2], v[8 * u + 3]), pk2(v[8 * u + 4], v[8 * u + 5]), pk2(v[8 * u + 6], v[8 * u + 7]));
+// T = bf16_t or f16_t (round 5: float16 training): the kernel moves raw 16-bit words; only the packing of f32 values and the MFMA opcode
+// depend on the format
+template <typename T> __device__ __forceinline__ uint32_t pk2(float a, float b) { return Half16<T>::pack2(a, b); }
+template <typename T> __device__ __forceinline__ frag_t pack8(const f32x16_t& v, int u) {
+  const uint4 w = make_uint4(pk2<T>(v[8 * u + 0], v[8 * u + 1]), pk2<T>(v[8 * u + 2], v[8 * u + 3]), pk2<T>(v[8 * u + 4], v[8 * u + 5]), pk2<T>(v[8 * u + 6], v[8 * u + 7]));
   return __builtin_bit_cast(frag_t, w);
+}
+template <typename T> __device__ __forceinline__ f32x16_t mma16(const frag_t& a, const frag_t& b, const f32x16_t& c);
+template <> __device__ __forceinline__ f32x16_t mma16<bf16_t>(const frag_t& a, const frag_t& b, const f32x16_t& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16_t mma16<f16_t>(const frag_t& a, const frag_t& b, const f32x16_t& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
 constexpr int PITCH = 192;            // bytes per row of the [L][64] images
 
 // o[dt][r] = OUT[row l31 of this wave][d = 32 dt + (r&3) + 8 (r>>2) + 4 half]  ->  16-byte stores, one row per lane
+template <typename T>
 __device__ __forceinline__ void store_rows(const f32x16_t (&o)[2], char* out, int half, bool valid) {
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int gp = 0; gp < 2; ++gp) {
-      const uint32_t a0 = pk2(o[dt][8 * gp + 0], o[dt][8 * gp + 1]), a1 = pk2(o[dt][8 * gp + 2], o[dt][8 * gp + 3]);
-      const uint32_t b0 = pk2(o[dt][8 * gp + 4], o[dt][8 * gp + 5]), b1 = pk2(o[dt][8 * gp + 6], o[dt][8 * gp + 7]);
+      const uint32_t a0 = pk2<T>(o[dt][8 * gp + 0], o[dt][8 * gp + 1]), a1 = pk2<T>(o[dt][8 * gp + 2], o[dt][8 * gp + 3]);
+      const uint32_t b0 = pk2<T>(o[dt][8 * gp + 4], o[dt][8 * gp + 5]), b1 = pk2<T>(o[dt][8 * gp + 6], o[dt][8 * gp + 7]);
       // (a: d group 2 gp, b: d group 2 gp + 1) -- lanes 32-63 of a swap with lanes 0-31 of b
       const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
       const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
@@ -57,7 +67,7 @@ __device__ __forceinline__ void store_rows(const f32x16_t (&o)[2], char* out, in
     }
 }
 
-template <int KT>
+template <typename T, int KT>
 __global__ __launch_bounds__(64 * KT) void attention_bwd16_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx, bf16_t* __restrict__ dqkv,
     const int64_t* __restrict__ mask, int L, int H, int heads, float scale, float drop_p, uint64_t seed) {
@@ -123,8 +133,8 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd16_kernel(
       for (int kk = 0; kk < 4; ++kk) {
         const frag_t ka = *(const frag_t*)(krow + (kk * 2 + half) * 16);
         const frag_t va = *(const frag_t*)(vrow + (kk * 2 + half) * 16);
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[kk], s[t], 0, 0, 0);       // S^T[key][query]
-        dp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[kk], dp[t], 0, 0, 0);    // dPd^T[key][query]
+        s[t] = mma16<T>(ka, qf[kk], s[t]);       // S^T[key][query]
+        dp[t] = mma16<T>(va, dof[kk], dp[t]);    // dPd^T[key][query]
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -192,8 +202,8 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd16_kernel(
           dp[t][4 * g + e] = ds[e];
         }
         const int koff = (t * 32 + 8 * g + 4 * half) * 2;
-        *(uint2*)(prow + koff) = make_uint2(pk2(pd[0], pd[1]), pk2(pd[2], pd[3]));
-        *(uint2*)(drow + koff) = make_uint2(pk2(ds[0], ds[1]), pk2(ds[2], ds[3]));
+        *(uint2*)(prow + koff) = make_uint2(pk2<T>(pd[0], pd[1]), pk2<T>(pd[2], pd[3]));
+        *(uint2*)(drow + koff) = make_uint2(pk2<T>(ds[0], ds[1]), pk2<T>(ds[2], ds[3]));
       }
     // dQ^T[d][query] = sum_key K^T[d][key] dS[query][key] : K^T by transposing reads, dS from the registers
     f32x16_t o[2];
@@ -206,16 +216,16 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd16_kernel(
     for (int t = 0; t < KT; ++t)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const frag_t dsf = pack8(dp[t], u);
+        const frag_t dsf = pack8<T>(dp[t], u);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const char* p = kt0 + (t * 32 + 16 * u) * PITCH + dt * 64;
           const frag_t kf = frag_of(trd(p), trd(p + 8 * PITCH));
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, dsf, o[dt], 0, 0, 0);
+          o[dt] = mma16<T>(kf, dsf, o[dt]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-    store_rows(o, dbase + (int64_t)qrow * ld2, half, qvalid);
+    store_rows<T>(o, dbase + (int64_t)qrow * ld2, half, qvalid);
   }
   __syncthreads();                                       // Pd, dS complete; K, V no longer needed
 #define BW_PUT(I)                                                                                     \
@@ -251,29 +261,29 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd16_kernel(
       for (int dt = 0; dt < 2; ++dt) {
         const frag_t of = frag_of(trd(xo + 16 * v * PITCH + dt * 64), trd(xo + (16 * v + 8) * PITCH + dt * 64));
         const frag_t qf2 = frag_of(trd(xq + 16 * v * PITCH + dt * 64), trd(xq + (16 * v + 8) * PITCH + dt * 64));
-        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, pf, dv[dt], 0, 0, 0);     // dV^T[d][key]
-        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf2, df, dk[dt], 0, 0, 0);    // dK^T[d][key]
+        dv[dt] = mma16<T>(of, pf, dv[dt]);     // dV^T[d][key]
+        dk[dt] = mma16<T>(qf2, df, dk[dt]);    // dK^T[d][key]
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     const bool kvalid = k0 + l31 < L;
     const int krow = kvalid ? k0 + l31 : L - 1;
-    store_rows(dk, dbase + (int64_t)krow * ld2 + 2 * H, half, kvalid);
-    store_rows(dv, dbase + (int64_t)krow * ld2 + 4 * H, half, kvalid);
+    store_rows<T>(dk, dbase + (int64_t)krow * ld2 + 2 * H, half, kvalid);
+    store_rows<T>(dv, dbase + (int64_t)krow * ld2 + 4 * H, half, kvalid);
   }
 }
 
-template <int KT>
+template <typename T, int KT>
 int launch_bwd16(const void* qkv, const void* dctx, void* dqkv, const int64_t* mask, int64_t B, int L, int H, int heads,
                  float scale, float drop_p, uint64_t seed, hipStream_t s) {
   constexpr int LT = KT * 32;
   const int lds = 2 * LT * PITCH + 2 * LT * (LT * 2 + 8) + LT * 4;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
-    OM_HIP(hipFuncSetAttribute((const void*)attention_bwd16_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    OM_HIP(hipFuncSetAttribute((const void*)attention_bwd16_kernel<T, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((attention_bwd16_kernel<KT>), dim3((unsigned)(heads * B)), dim3(64 * KT), lds, s, (const bf16_t*)qkv,
+  hipLaunchKernelGGL((attention_bwd16_kernel<T, KT>), dim3((unsigned)(heads * B)), dim3(64 * KT), lds, s, (const bf16_t*)qkv,
                      (const bf16_t*)dctx, (bf16_t*)dqkv, mask, L, H, heads, scale, drop_p, seed);
   OM_LAUNCH_CHECK();
   return 0;
@@ -281,13 +291,19 @@ int launch_bwd16(const void* qkv, const void* dctx, void* dqkv, const int64_t* m
 }  // namespace
 
 bool omk_attention_bwd16_ok(int dtype, int L, int H, int heads) {
-  return dtype == OM_BF16 && L >= 1 && L <= 128 && H == heads * 64 && om_option(OM_OPT_ATTENTION_FAST);
+  return (dtype == OM_BF16 || dtype == OM_F16) && L >= 1 && L <= 128 && H == heads * 64 && om_option(OM_OPT_ATTENTION_FAST);
 }
 
-int omk_attention_bwd16(const void* qkv, const void* dctx, void* dqkv, const int64_t* mask, int64_t B, int L, int H,
+int omk_attention_bwd16(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask, int64_t B, int L, int H,
                         int heads, float scale, float drop_p, uint64_t seed, hipStream_t s) {
   if (B <= 0) return 0;
-  if (L <= 32) return launch_bwd16<1>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s);
-  if (L <= 64) return launch_bwd16<2>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s);
-  return launch_bwd16<4>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s);
+#define BWD16(TT)                                                                                            \
+  do {                                                                                                       \
+    if (L <= 32) return launch_bwd16<TT, 1>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s);    \
+    if (L <= 64) return launch_bwd16<TT, 2>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s);    \
+    return launch_bwd16<TT, 4>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s);                 \
+  } while (0)
+  if (dtype == OM_F16) BWD16(f16_t);
+  BWD16(bf16_t);
+#undef BWD16
 }

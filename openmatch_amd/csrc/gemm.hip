@@ -133,7 +133,7 @@ int omk_gemm_wide7(bool persist, const void* A, int64_t lda, const void* B, int6
                    int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s);
 
 bool omk_gemm_wide7_train_ok(int64_t M, int64_t N, int64_t K, int64_t ldc, const GemmEpilogue& ep);
-int omk_gemm_wide7_train(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+int omk_gemm_wide7_train(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                          int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s);
 
 int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int out_dtype,
@@ -181,20 +181,20 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
   }
   const bool ln_fused = ep.ln_stats || ep.rln_stats || ep.stats_out;
   // the training forward's FFN1 (gelu + gelu' to the tape): the continuous 256 x 256 kernel with its two-output epilogue
-  if (wide && in_dtype == OM_BF16 && out_dtype == OM_BF16 && gemm_variant() == 0 && g_debug_gen != 6 &&
+  if (wide && (in_dtype == OM_BF16 || in_dtype == OM_F16) && out_dtype == in_dtype && gemm_variant() == 0 && g_debug_gen != 6 &&
       omk_gemm_wide7_train_ok(M, N, K, ldc, ep))
-    return omk_gemm_wide7_train(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    return omk_gemm_wide7_train(in_dtype, A, lda, B, ldb, C, ldc, M, N, K, ep, s);
   if (in_dtype == OM_F16 && out_dtype == OM_F16) {
     // float16 -> float16 (the inference encoder's float16 mode): the persistent 256 x 256 kernel where the problem is
-    // made of whole tiles, else the generic 128 / 256-row tiles; no training epilogues
+    // made of whole tiles, else the generic 128 / 256-row tiles (which also take the training epilogues of float16 training)
     const int act = ep.act & 0xff;
     const bool resid = ep.resid != nullptr;
-    if (ep.pre_act != nullptr || ep.drop_p > 0.f) OM_FAIL("float16 is an inference format: no training epilogue");
+    const bool train16 = ep.pre_act != nullptr || ep.drop_p > 0.f || act == OM_ACT_GELU_ERF_GRAD;      // float16 training (round 5): the generic tiles
     const int lnf = ep.ln_stats ? 1 : ((ep.rln_stats || ep.stats_out) ? 2 : 0);
     if (ep.out_lo || ep.resid_lo) OM_FAIL("float16: the two-plane residual stream is a bfloat16 feature");
-    const bool g7 = wide && gemm_variant() == 0 && M % 256 == 0 && N % 256 == 0 && (K * 2) % 128 == 0 &&
+    const bool g7 = wide && !train16 && gemm_variant() == 0 && M % 256 == 0 && N % 256 == 0 && (K * 2) % 128 == 0 &&
                     (((uintptr_t)ep.bias & 15) == 0) && !(ep.ln_stats && (ep.rln_stats || ep.stats_out)) &&
-                    !(lnf == 2 && !ep.stats_out) && (!resid || (ep.ldr * 2) % 128 == 0) && !(ep.act & OM_ACT_MUL_RESID) &&
+                    !(lnf == 2 && !ep.stats_out) && (!resid || (ep.ldr * 2) % 128 == 0) && !((ep.act & OM_ACT_MUL_RESID) && (lnf != 0 || !resid)) &&
                     omk_gemm_wide7_f16_has(act, resid, lnf);
     if (g7) return omk_gemm_wide7_f16(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
     if (ln_fused) OM_FAIL("float16: the fused LayerNorm epilogues need whole 256 x 256 tiles");
@@ -257,6 +257,11 @@ int omk_gemm_splitk(int in_dtype, const void* A, int64_t lda, const void* B, int
     if (!attr_bf16) { OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_splitk_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES)); attr_bf16 = true; }
     hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16_t>), dim3((unsigned)tiles, slices), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s,
                        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, per);
+  } else if (in_dtype == OM_F16) {
+    static std::atomic<bool> attr_f16{false};
+    if (!attr_f16) { OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_splitk_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES)); attr_f16 = true; }
+    hipLaunchKernelGGL((gemm_nt_splitk_kernel<f16_t>), dim3((unsigned)tiles, slices), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s,
+                       (const f16_t*)A, lda, (const f16_t*)B, ldb, C, ldc, M, N, K, per);
   } else if (in_dtype == OM_F32) {
     if (!attr_f32) { OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_splitk_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES)); attr_f32 = true; }
     hipLaunchKernelGGL((gemm_nt_splitk_kernel<float>), dim3((unsigned)tiles, slices), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s,

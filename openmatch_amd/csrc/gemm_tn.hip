@@ -42,6 +42,19 @@ __device__ __forceinline__ v4s tn_read(const char* p) {
 //  * a 256 x 256 tile (one workgroup per CU, 65 536 atomics each) was slower than 128 x 128 at every shape;
 //  * with one step of prefetch the token loop ran at ~30 % of the MFMA rate, parked on the global loads (SQ_WAIT_ANY
 //    42 %, no LDS bank conflicts): the loads of step t + 2 are now issued before step t is computed (two register sets).
+// T = bf16_t | f16_t (round 5: float16 training).  The kernels move raw 16-bit words (bf16x8_t = eight shorts); only the MFMA opcode
+// and the value of a word (the bias column sums) depend on the format.
+template <typename T> __device__ __forceinline__ void tn_mma(const bf16x8_t& a, const bf16x8_t& b, f32x16_t& c);
+template <> __device__ __forceinline__ void tn_mma<bf16_t>(const bf16x8_t& a, const bf16x8_t& b, f32x16_t& c) { MmaOps<bf16_t>::mma(a, b, c); }
+template <> __device__ __forceinline__ void tn_mma<f16_t>(const bf16x8_t& a, const bf16x8_t& b, f32x16_t& c) {
+  MmaOps<f16_t>::mma(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c);
+}
+// sum of the eight values of a fragment
+template <typename T> __device__ __forceinline__ float tn_sum8(const uint4& w) {
+  return (Half16<T>::lo(w.x) + Half16<T>::hi(w.x)) + (Half16<T>::lo(w.y) + Half16<T>::hi(w.y)) +
+         (Half16<T>::lo(w.z) + Half16<T>::hi(w.z)) + (Half16<T>::lo(w.w) + Half16<T>::hi(w.w));
+}
+template <typename T>
 __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, float* __restrict__ C,
     int64_t ldc, float* __restrict__ bias, int64_t M, int N, int K, int rows_per_slice, int dbg) {
@@ -128,11 +141,10 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(
       __builtin_amdgcn_sched_barrier(0);                                                               \
       if (ks + 1 < TN_BM / 16) { TN_READ(ks + 1, (ks + 1) & 1) }                                       \
       _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                  \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) MmaOps<bf16_t>::mma(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]); \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) tn_mma<T>(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]); \
         if (do_bias) {      /* the fragment holds 8 tokens of column (lane & 31): add them up under the MFMAs */ \
           const uint4 w = __builtin_bit_cast(uint4, fa[ks & 1][i]);                                    \
-          bsum[i] += (__uint_as_float(w.x << 16) + __uint_as_float(w.x & 0xffff0000u)) + (__uint_as_float(w.y << 16) + __uint_as_float(w.y & 0xffff0000u)) + \
-                     (__uint_as_float(w.z << 16) + __uint_as_float(w.z & 0xffff0000u)) + (__uint_as_float(w.w << 16) + __uint_as_float(w.w & 0xffff0000u)); \
+          bsum[i] += tn_sum8<T>(w); \
         }                                                                                              \
       }                                                                                                \
     }                                                                                                  \
@@ -186,6 +198,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(
 // Two stages of 32 KiB (A + B), two workgroups per CU; whole 64-token steps only (the launcher gives a ragged tail to
 // the register-staged kernel, which can zero-fill).  vmcnt is counted by hand: the DMA is inline assembly.
 constexpr int TD_STAGE = 32768;
+template <typename T>
 __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_dma_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, float* __restrict__ C,
     int64_t ldc, float* __restrict__ bias, int N, int K, int steps_per_slice, int total_steps, int dbg) {
@@ -253,12 +266,10 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_dma_kernel(
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) MmaOps<bf16_t>::mma(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+        for (int j = 0; j < 2; ++j) tn_mma<T>(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
         if (do_bias) {
           const uint4 w = __builtin_bit_cast(uint4, fa[ks & 1][i]);
-          bsum[i] += (__uint_as_float(w.x << 16) + __uint_as_float(w.x & 0xffff0000u)) + (__uint_as_float(w.y << 16) + __uint_as_float(w.y & 0xffff0000u)) +
-                     (__uint_as_float(w.z << 16) + __uint_as_float(w.z & 0xffff0000u)) + (__uint_as_float(w.w << 16) + __uint_as_float(w.w & 0xffff0000u));
-        }
+          bsum[i] += tn_sum8<T>(w);}
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -320,8 +331,13 @@ struct TwBatch { int n, chunk, total, steps; int tile_start[TW_MAXP + 1]; TwProb
 
 // acc + lo + hi of a packed bf16 pair (v_dot2c_f32_bf16 with a pair of ones)
 typedef __bf16 tw_bf2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float tw_sum2(uint32_t pair, float acc) {
+typedef _Float16 tw_h2 __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ float tw_sum2(uint32_t pair, float acc);
+template <> __device__ __forceinline__ float tw_sum2<bf16_t>(uint32_t pair, float acc) {
   return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tw_bf2, pair), __builtin_bit_cast(tw_bf2, 0x3f803f80u), acc, false);
+}
+template <> __device__ __forceinline__ float tw_sum2<f16_t>(uint32_t pair, float acc) {      // v_dot2_f32_f16 with (1, 1)
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(tw_h2, pair), __builtin_bit_cast(tw_h2, 0x3c003c00u), acc, false);
 }
 #define TW_WAIT(K_)                                                                                    \
   do {                                                                                                 \
@@ -331,6 +347,7 @@ __device__ __forceinline__ float tw_sum2(uint32_t pair, float acc) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                              \
   } while (0)
 
+template <typename T>
 __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_wide_kernel(const TwBatch bt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -399,7 +416,7 @@ __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_wide_kernel(const TwBat
   // count (15) every MFMA of a half waited for reads issued just before it (2 200 cycles per step for 1 024 of MFMA).
 #define TW_HALF(FA, FB, NA, NB, NST, NKS, DMA_COND, DMA_STAGE)                                         \
   _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                     \
-    MmaOps<bf16_t>::mma(FA[q >> 2], FB[q & 3], acc[q >> 2][q & 3]);                                    \
+    tn_mma<T>(FA[q >> 2], FB[q & 3], acc[q >> 2][q & 3]);                                    \
     if (q == 0) TW_FRAG_A(NA, NST, NKS, 0)                                                             \
     else if (q <= 4) TW_FRAG_B(NB, NST, NKS, q - 1)                                                    \
     else if (q <= 7) TW_FRAG_A(NA, NST, NKS, q - 4)                                                    \
@@ -412,7 +429,7 @@ __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_wide_kernel(const TwBat
                                            four v_dot2c_f32_bf16 against (1, 1) instead of 14 shift / mask / add instructions: the \
                                            two waves that carry the bias sums reach the step's barrier with the other two */ \
       const uint4 w = __builtin_bit_cast(uint4, FA[q >> 2]);                                           \
-      bsum[q >> 2] = tw_sum2(w.x, tw_sum2(w.y, bsum[q >> 2])) + tw_sum2(w.z, tw_sum2(w.w, 0.f));       \
+      bsum[q >> 2] = tw_sum2<T>(w.x, tw_sum2<T>(w.y, bsum[q >> 2])) + tw_sum2<T>(w.z, tw_sum2<T>(w.w, 0.f));       \
     }                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
   }
@@ -483,10 +500,11 @@ __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_wide_kernel(const TwBat
 }  // namespace
 
 bool omk_gemm_tn_ok(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {
-  return dtype == OM_BF16 && M > 0 && N % 128 == 0 && K % 128 == 0 && lda % 8 == 0 && ldb % 8 == 0 && N <= (1 << 20) && K <= (1 << 20);
+  return (dtype == OM_BF16 || dtype == OM_F16) && M > 0 && N % 128 == 0 && K % 128 == 0 && lda % 8 == 0 && ldb % 8 == 0 && N <= (1 << 20) && K <= (1 << 20);
 }
 
-static int launch_tn_regs(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* bias, int64_t M,
+template <typename T>
+static int launch_tn_regs_t(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* bias, int64_t M,
                           int64_t N, int64_t K, int dbg, hipStream_t s) {
   const int64_t tiles = (N / 128) * (K / 128);
   const int64_t steps = (M + TN_BM - 1) / TN_BM;
@@ -497,18 +515,24 @@ static int launch_tn_regs(const void* A, int64_t lda, const void* B, int64_t ldb
   slices = (steps + per - 1) / per;
   static std::atomic<bool> attr{false};
   if (!attr) {
-    OM_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS));
+    OM_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS));
     attr = true;
   }
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)tiles, (unsigned)slices), dim3(TN_THREADS), TN_LDS, s, (const bf16_t*)A, lda,
+  hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3((unsigned)tiles, (unsigned)slices), dim3(TN_THREADS), TN_LDS, s, (const bf16_t*)A, lda,
                      (const bf16_t*)B, ldb, C, ldc, bias, M, (int)N, (int)K, (int)(per * TN_BM), dbg);
   OM_LAUNCH_CHECK();
   return 0;
 }
 
+static int launch_tn_regs(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* bias, int64_t M,
+                          int64_t N, int64_t K, int dbg, hipStream_t s) {
+  if (dtype == OM_F16) return launch_tn_regs_t<f16_t>(A, lda, B, ldb, C, ldc, bias, M, N, K, dbg, s);
+  return launch_tn_regs_t<bf16_t>(A, lda, B, ldb, C, ldc, bias, M, N, K, dbg, s);
+}
+
 int omk_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* bias,
                 int64_t M, int64_t N, int64_t K, hipStream_t s) {
-  if (!omk_gemm_tn_ok(dtype, M, N, K, lda, ldb)) OM_FAIL("gemm_tn: bf16 operands with N and K multiples of 128 only");
+  if (!omk_gemm_tn_ok(dtype, M, N, K, lda, ldb)) OM_FAIL("gemm_tn: 16-bit operands with N and K multiples of 128 only");
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) OM_FAIL("gemm_tn: operands must be 16-byte aligned");
   const int dbg = om_option(OM_OPT_WGRAD_DEBUG);
   const bool timing = om_timing_on();
@@ -523,15 +547,20 @@ int omk_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, int64_t ld
     slices = (whole + per - 1) / per;
     static std::atomic<bool> attr{false};
     if (!attr) {
-      OM_HIP(hipFuncSetAttribute((const void*)gemm_tn_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TD_STAGE));
+      OM_HIP(hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TD_STAGE));
+      OM_HIP(hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TD_STAGE));
       attr = true;
     }
-    hipLaunchKernelGGL(gemm_tn_dma_kernel, dim3((unsigned)tiles, (unsigned)slices), dim3(TN_THREADS), 2 * TD_STAGE, s, (const bf16_t*)A, lda,
-                       (const bf16_t*)B, ldb, C, ldc, bias, (int)N, (int)K, (int)per, (int)whole, dbg);
+    if (dtype == OM_F16)
+      hipLaunchKernelGGL(gemm_tn_dma_kernel<f16_t>, dim3((unsigned)tiles, (unsigned)slices), dim3(TN_THREADS), 2 * TD_STAGE, s, (const bf16_t*)A, lda,
+                         (const bf16_t*)B, ldb, C, ldc, bias, (int)N, (int)K, (int)per, (int)whole, dbg);
+    else
+      hipLaunchKernelGGL(gemm_tn_dma_kernel<bf16_t>, dim3((unsigned)tiles, (unsigned)slices), dim3(TN_THREADS), 2 * TD_STAGE, s, (const bf16_t*)A, lda,
+                         (const bf16_t*)B, ldb, C, ldc, bias, (int)N, (int)K, (int)per, (int)whole, dbg);
     OM_LAUNCH_CHECK();
     const int64_t done = whole * TN_BM;
-    if (M > done && launch_tn_regs((const bf16_t*)A + done * lda, lda, (const bf16_t*)B + done * ldb, ldb, C, ldc, bias, M - done, N, K, dbg, s)) return 1;
-  } else if (launch_tn_regs(A, lda, B, ldb, C, ldc, bias, M, N, K, dbg, s)) {
+    if (M > done && launch_tn_regs(dtype, (const bf16_t*)A + done * lda, lda, (const bf16_t*)B + done * ldb, ldb, C, ldc, bias, M - done, N, K, dbg, s)) return 1;
+  } else if (launch_tn_regs(dtype, A, lda, B, ldb, C, ldc, bias, M, N, K, dbg, s)) {
     return 1;
   }
   if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, 2.0 * (double)M * (double)N * (double)K);
@@ -547,7 +576,7 @@ extern "C" int om_gemm_tn_acc(int in_dtype, const void* A, int64_t lda, const vo
 
 // ---- batched launch ----------------------------------------------------------------------------------------------------------
 bool omk_gemm_tn_batch_ok(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {
-  return dtype == OM_BF16 && M >= TW_TOK && N % 256 == 0 && K % 256 == 0 && lda % 8 == 0 && ldb % 8 == 0 && N <= (1 << 20) &&
+  return (dtype == OM_BF16 || dtype == OM_F16) && M >= TW_TOK && N % 256 == 0 && K % 256 == 0 && lda % 8 == 0 && ldb % 8 == 0 && N <= (1 << 20) &&
          K <= (1 << 20) && (int64_t)TW_TOK * lda * 2 < (1ll << 31) && (int64_t)TW_TOK * ldb * 2 < (1ll << 31);
 }
 
@@ -558,12 +587,13 @@ int omk_gemm_tn_batch(int dtype, const OmTnProblem* probs, int n, int64_t M, hip
     const OmTnProblem& q = probs[i];
     if (!q.A || !q.B || !q.C) OM_FAIL("gemm_tn_batch: null operand");
     if (!omk_gemm_tn_batch_ok(dtype, M, q.N, q.K, q.lda, q.ldb) || q.ldc > 0x7fffffffLL)
-      OM_FAIL("gemm_tn_batch: bf16 operands with N and K multiples of 256 and at least 32 tokens only");
+      OM_FAIL("gemm_tn_batch: 16-bit operands with N and K multiples of 256 and at least 32 tokens only");
     if (((uintptr_t)q.A & 15) || ((uintptr_t)q.B & 15)) OM_FAIL("gemm_tn_batch: operands must be 16-byte aligned");
   }
   static std::atomic<bool> attr{false};
   if (!attr) {
-    OM_HIP(hipFuncSetAttribute((const void*)gemm_tn_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TW_STAGES * TW_STAGE));
+    OM_HIP(hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, TW_STAGES * TW_STAGE));
+    OM_HIP(hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, TW_STAGES * TW_STAGE));
     attr = true;
   }
   const bool timing = om_timing_on();
@@ -588,7 +618,8 @@ int omk_gemm_tn_batch(int dtype, const OmTnProblem* probs, int n, int64_t M, hip
     bt.total = (int)total;
     bt.chunk = (int)((total + 7) / 8);
     if (timing) om_timing_begin(OM_TIMING_GEMM_BF16, s);
-    hipLaunchKernelGGL(gemm_tn_wide_kernel, dim3((unsigned)(bt.chunk * 8)), dim3(TN_THREADS), TW_STAGES * TW_STAGE, s, bt);
+    if (dtype == OM_F16) hipLaunchKernelGGL(gemm_tn_wide_kernel<f16_t>, dim3((unsigned)(bt.chunk * 8)), dim3(TN_THREADS), TW_STAGES * TW_STAGE, s, bt);
+    else hipLaunchKernelGGL(gemm_tn_wide_kernel<bf16_t>, dim3((unsigned)(bt.chunk * 8)), dim3(TN_THREADS), TW_STAGES * TW_STAGE, s, bt);
     OM_LAUNCH_CHECK();
     if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, flops * (double)(whole * TW_TOK) / (double)M);
   }
@@ -597,7 +628,7 @@ int omk_gemm_tn_batch(int dtype, const OmTnProblem* probs, int n, int64_t M, hip
   if (M > done) {
     for (int i = 0; i < n; ++i) {
       const OmTnProblem& q = probs[i];
-      if (launch_tn_regs((const bf16_t*)q.A + done * q.lda, q.lda, (const bf16_t*)q.B + done * q.ldb, q.ldb, q.C, q.ldc, q.bias,
+      if (launch_tn_regs(dtype, (const bf16_t*)q.A + done * q.lda, q.lda, (const bf16_t*)q.B + done * q.ldb, q.ldb, q.C, q.ldc, q.bias,
                          M - done, q.N, q.K, 0, s)) return 1;
     }
   }

@@ -61,7 +61,10 @@ bool omk_gemm_wide7_train_ok(int64_t M, int64_t N, int64_t K, int64_t ldc, const
          (ep.act & 0xff) == OM_ACT_GELU_ERF && (ep.act & OM_ACT_PRE_GRAD) && !(ep.act & OM_ACT_MUL_RESID) && ep.pre_act && ep.ldp == ldc &&
          !ep.resid && ep.drop_p == 0.f && (((uintptr_t)ep.pre_act | (uintptr_t)ep.bias) & 15) == 0 && !ep.ln_stats && !ep.rln_stats && !ep.stats_out;
 }
-int omk_gemm_wide7_train(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+int omk_gemm_wide7_train_f16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                             int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s);      // gemm_wide7_f16.hip
+int omk_gemm_wide7_train(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                          int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
+  if (dtype == OM_F16) return omk_gemm_wide7_train_f16(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
   return launch7c<bf16_t, OM_ACT_GELU_ERF, 0, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
 }

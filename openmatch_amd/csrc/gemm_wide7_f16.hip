@@ -32,3 +32,9 @@ int omk_gemm_wide7_f16(const void* A, int64_t lda, const void* B, int64_t ldb, v
 #undef OM_L7
   OM_FAIL("no generation-7 float16 kernel for this epilogue");
 }
+
+// float16 training (round 5): FFN1 with gelu and gelu' in one epilogue (kernel 7c16, TRAIN)
+int omk_gemm_wide7_train_f16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                             int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
+  return launch7c<f16_t, OM_ACT_GELU_ERF, 0, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+}

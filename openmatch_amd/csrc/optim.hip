@@ -64,7 +64,7 @@ __global__ __launch_bounds__(1024) void sqnorm_reduce_kernel(const float* __rest
   }
 }
 
-struct AdamArgs { float lr_wd_unused, step_size, beta1, beta2, eps, bc2_sqrt_inv, max_norm, grad_scale, lr; int clip, skip_nonfinite; };
+struct AdamArgs { float lr_wd_unused, step_size, beta1, beta2, eps, bc2_sqrt_inv, max_norm, grad_scale, lr; int clip, skip_nonfinite; const float* inv_scale; };
 
 // torch.optim.AdamW's update (torch/optim/adamw.py, single-tensor form), element by element:
 //   p *= 1 - lr wd;  m += (g - m)(1 - b1);  v = v b2 + (1 - b2) g g;  p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)
@@ -76,8 +76,9 @@ __global__ __launch_bounds__(THREADS) void adamw_kernel(const OmAdamTensor* __re
   const int64_t base = (int64_t)chunks[2 * blockIdx.x + 1] * CHUNK;
   const int64_t n = t.n - base < CHUNK ? t.n - base : CHUNK;
   float gs = a.grad_scale;
+  if (a.inv_scale) gs *= a.inv_scale[0];                            // 1 / (dynamic loss scale), kept on the device (om_loss_scale_update)
   if (gnorm_sq) {
-    const float nrm = sqrtf(gnorm_sq[0]) * fabsf(a.grad_scale);
+    const float nrm = sqrtf(gnorm_sq[0]) * fabsf(gs);
     if (a.skip_nonfinite && !(nrm <= 3.0e38f)) return;           // inf / nan gradients: the step is skipped (GradScaler semantics)
     if (a.clip) gs *= fminf(1.0f, a.max_norm / (nrm + 1e-6f));
   }
@@ -130,9 +131,28 @@ extern "C" int om_grad_sqnorm(const OmAdamTensor* tensors, const int32_t* chunks
   return 0;
 }
 
+// The dynamic loss scale of float16 training (torch.cuda.amp.GradScaler.update, which HF Trainer drives for the reference's --fp16:
+// trainer/dense_trainer.py:141-149), as one thread on the device: a non-finite gradient norm halves the scale (the optimizer
+// skipped that step by itself: om_adamw_step skip_nonfinite) and restarts the count of clean steps; `growth_interval` clean
+// steps double it.  state = {scale, 1 / scale, clean steps, steps skipped so far}.
+__global__ void loss_scale_update_kernel(const float* __restrict__ gnorm_sq, float* __restrict__ state, int growth_interval) {
+  if (threadIdx.x || blockIdx.x) return;
+  float scale = state[0], good = state[2];
+  const bool finite = gnorm_sq[0] <= 3.0e38f;
+  if (!finite) { scale = fmaxf(scale * 0.5f, 1.0f); good = 0.f; state[3] += 1.f; }
+  else if (++good >= (float)growth_interval) { scale = fminf(scale * 2.0f, 16777216.0f); good = 0.f; }
+  state[0] = scale; state[1] = 1.0f / scale; state[2] = good;
+}
+extern "C" int om_loss_scale_update(const float* gnorm_sq, float* state4, int growth_interval, void* stream) {
+  if (!gnorm_sq || !state4 || growth_interval < 1) OM_FAIL("bad argument");
+  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gnorm_sq, state4, growth_interval);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int om_adamw_step(const OmAdamTensor* tensors, const int32_t* chunks, int n_chunks, float lr, float beta1, float beta2,
                              float eps, int64_t step, const float* gnorm_sq, float max_norm, float grad_scale, int skip_nonfinite,
-                             void* stream) {
+                             const float* inv_scale, void* stream) {
   if (n_chunks < 0 || (n_chunks > 0 && (!tensors || !chunks))) OM_FAIL("null argument");
   if (step < 1) OM_FAIL("step counts from 1");
   if (!(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f)) OM_FAIL("betas must lie in [0, 1)");
@@ -148,6 +168,7 @@ extern "C" int om_adamw_step(const OmAdamTensor* tensors, const int32_t* chunks,
   a.max_norm = max_norm; a.grad_scale = grad_scale;
   a.clip = max_norm > 0.f ? 1 : 0;
   a.skip_nonfinite = skip_nonfinite;
+  a.inv_scale = inv_scale;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)n_chunks), dim3(THREADS), 0, (hipStream_t)stream, tensors, chunks, gnorm_sq, a);
   OM_LAUNCH_CHECK();
   return 0;

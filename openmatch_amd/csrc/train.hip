@@ -32,12 +32,12 @@ Dims dims_of(const OmEncoderConfig* c, int64_t B, int64_t L) {
   d.B = B; d.L = L; d.M = B * L; d.Mp = (d.M + 63) / 64 * 64;
   d.H = c->hidden; d.F = c->ffn; d.nl = c->n_layers; d.nh = c->n_heads;
   d.D = c->head_in > 0 ? c->head_out : c->hidden;
-  d.es = c->dtype == OM_BF16 ? 2 : 4;
+  d.es = (c->dtype == OM_BF16 || c->dtype == OM_F16) ? 2 : 4;
   d.t5 = c->arch == OM_ARCH_T5;
   d.gated = d.t5 && (c->act & 0xff) == OM_ACT_GELU_TANH;      // T5 v1.1: gated gelu_new (wi_0, wi_1)
-  d.bert16 = !d.t5 && c->dtype == OM_BF16 && (size_t)d.F * d.es >= (size_t)d.H * 4;
+  d.bert16 = !d.t5 && d.es == 2 && (size_t)d.F * d.es >= (size_t)d.H * 4;
   d.res32 = d.bert16 && om_option(OM_OPT_TRAIN_RES32) != 0;
-  d.pre_grad = c->dtype == OM_BF16 && om_option(OM_OPT_TRAIN_TAPE_GRAD) != 0;
+  d.pre_grad = d.es == 2 && om_option(OM_OPT_TRAIN_TAPE_GRAD) != 0;
   return d;
 }
 Dims dims_with_flags(Dims d, int flags) { d.res32 = (flags & TAPE_RES32) != 0; d.pre_grad = (flags & TAPE_PRE_GRAD) != 0; return d; }
@@ -166,14 +166,15 @@ int wgrad(int dt, const void* dY, int N, const void* X, int K, float* dW, float*
 
 int check_train_cfg(const OmEncoderConfig* c, int64_t L) {
   if (c->arch != OM_ARCH_BERT && c->arch != OM_ARCH_T5) OM_FAIL("unknown arch");
-  if (c->dtype != OM_F32 && c->dtype != OM_BF16) OM_FAIL("dtype must be OM_F32 or OM_BF16");
+  if (c->dtype != OM_F32 && c->dtype != OM_BF16 && c->dtype != OM_F16) OM_FAIL("dtype must be OM_F32, OM_BF16 or OM_F16");
+  if (c->dtype == OM_F16 && c->arch != OM_ARCH_BERT) OM_FAIL("float16 training: BERT-family encoders (T5 activations leave the float16 range: bfloat16)");
   if (c->head_dim != 64 || c->n_heads * 64 != c->hidden) OM_FAIL("head_dim must be 64");
   if (L < 1 || L > 256) OM_FAIL("training supports sequence lengths up to 256");
-  if (c->dtype != OM_BF16 && L > 192) OM_FAIL("float32 training supports sequence lengths up to 192 (bfloat16: 256)");
+  if (c->dtype == OM_F32 && L > 192) OM_FAIL("float32 training supports sequence lengths up to 192 (16-bit formats: 256)");
   if (c->arch == OM_ARCH_BERT && c->act != OM_ACT_GELU_ERF) OM_FAIL("BERT training supports the erf-GELU FFN");
   if (c->arch == OM_ARCH_T5 && (c->act & 0xff) != OM_ACT_RELU && (c->act & 0xff) != OM_ACT_GELU_TANH)
     OM_FAIL("T5 training supports relu and gated gelu_new feed-forward layers");
-  const int es = c->dtype == OM_BF16 ? 2 : 4;
+  const int es = c->dtype == OM_F32 ? 4 : 2;
   if ((c->hidden * es) % 128 || (c->ffn * es) % 128) OM_FAIL("hidden/ffn rows must be multiples of 128 bytes");
   if (c->pooling != OM_POOL_FIRST && c->pooling != OM_POOL_MEAN) OM_FAIL("pooling must be first or mean");
   return 0;

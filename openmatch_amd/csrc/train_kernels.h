@@ -35,7 +35,7 @@ int omk_attention_bwd_bias(int dtype, const void* qkv, const void* dctx, void* d
                            const float* pos_bias, float* drel, hipStream_t s);
 // bf16, L <= 128, no position bias: the transposing-read kernel of attention_bwd16.hip
 bool omk_attention_bwd16_ok(int dtype, int L, int H, int heads);
-int omk_attention_bwd16(const void* qkv, const void* dctx, void* dqkv, const int64_t* mask, int64_t B, int L, int H,
+int omk_attention_bwd16(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask, int64_t B, int L, int H,
                         int heads, float scale, float drop_p, uint64_t seed, hipStream_t s);
 // T5 feed-forward activation (kind 0 relu, 1 gated gelu_new) forward / backward, embedding and bias backward
 int omk_t5_act_fwd(int dtype, const void* f, const void* f2, void* g, int64_t n, int kind, hipStream_t s);

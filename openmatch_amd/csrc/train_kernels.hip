@@ -43,6 +43,7 @@ int omk_transpose(int dtype, const void* in, int64_t ldi, int64_t R, int C, void
   dim3 grid((unsigned)((Rp + 63) / 64), (unsigned)((C + 63) / 64));
 #define TR(TT, OPV) hipLaunchKernelGGL((transpose_kernel<TT, OPV>), grid, dim3(256), 0, s, (const TT*)in, ldi, R, C, (TT*)out, ldo, Rp)
   if (dtype == OM_BF16) { if (op) TR(bf16_t, 1); else TR(bf16_t, 0); }
+  else if (dtype == OM_F16) { if (op) TR(f16_t, 1); else TR(f16_t, 0); }
   else { if (op) TR(float, 1); else TR(float, 0); }
 #undef TR
   OM_LAUNCH_CHECK();
@@ -89,6 +90,7 @@ int omk_transpose_batch(int dtype, const void* const* in, void* const* out, cons
     }
     if (!tiles) continue;
     if (dtype == OM_BF16) hipLaunchKernelGGL((transpose_batch_kernel<bf16_t>), dim3((unsigned)tiles), dim3(256), 0, s, b);
+    else if (dtype == OM_F16) hipLaunchKernelGGL((transpose_batch_kernel<f16_t>), dim3((unsigned)tiles), dim3(256), 0, s, b);
     else hipLaunchKernelGGL((transpose_batch_kernel<float>), dim3((unsigned)tiles), dim3(256), 0, s, b);
     OM_LAUNCH_CHECK();
   }
@@ -117,6 +119,7 @@ int omk_colsum(int dtype, const void* x, int64_t ld, int64_t M, int N, float* ou
   if (M <= 0 || N <= 0) return 0;
   dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 255) / 256 > 64 ? 64 : (M + 255) / 256));
   if (dtype == OM_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, ld, M, N, out);
+  else if (dtype == OM_F16) hipLaunchKernelGGL((colsum_kernel<f16_t>), grid, dim3(256), 0, s, (const f16_t*)x, ld, M, N, out);
   else hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)x, ld, M, N, out);
   OM_LAUNCH_CHECK();
   return 0;
@@ -137,6 +140,7 @@ int omk_dropout(int dtype, const void* x, void* y, int64_t n, float p, uint64_t 
   if (n <= 0) return 0;
   const unsigned grid = (unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
   if (dtype == OM_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, n, p, seed);
+  else if (dtype == OM_F16) hipLaunchKernelGGL((dropout_kernel<f16_t>), dim3(grid), dim3(256), 0, s, (const f16_t*)x, (f16_t*)y, n, p, seed);
   else hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, n, p, seed);
   OM_LAUNCH_CHECK();
   return 0;
@@ -149,6 +153,10 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
   v[0] = __uint_as_float(w.x << 16); v[1] = __uint_as_float(w.x & 0xffff0000u);
   v[2] = __uint_as_float(w.y << 16); v[3] = __uint_as_float(w.y & 0xffff0000u);
 }
+template <> __device__ __forceinline__ void load4<f16_t>(const f16_t* p, float (&v)[4]) {
+  const uint2 w = *(const uint2*)p;
+  v[0] = Half16<f16_t>::lo(w.x); v[1] = Half16<f16_t>::hi(w.x); v[2] = Half16<f16_t>::lo(w.y); v[3] = Half16<f16_t>::hi(w.y);
+}
 template <> __device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
   const float4 w = *(const float4*)p;
   v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w;
@@ -157,6 +165,9 @@ template <typename T> __device__ __forceinline__ void store4(T* p, const float (
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4]) {
   *(uint2*)p = make_uint2((uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16),
                           (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16));
+}
+template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, const float (&v)[4]) {
+  *(uint2*)p = make_uint2(Half16<f16_t>::pack2(v[0], v[1]), Half16<f16_t>::pack2(v[2], v[3]));
 }
 template <> __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4]) {
   *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
@@ -299,7 +310,7 @@ __global__ __launch_bounds__((NV == 8 || MODE == 1) ? 256 : 512) void ln_bwd_ker
             const uint64_t bits = dropout_bits(drop_seed, (uint64_t)(row * H + c) >> 2);   // H % 4 == 0: one group
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float vb = sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(out[e])) : out[e];
+              const float vb = sizeof(T) == 2 ? Half16<T>::value(Half16<T>::bits(out[e])) : out[e];
               dr[e] = dropout_field(bits, e, drop_thresh) ? vb * drop_scale : 0.f;
             }
             store4<T>(dx_drop + row * H + c, dr);
@@ -418,6 +429,8 @@ int omk_ln_bwd_drop(int dtype, const void* dy, const void* x, const float* g, vo
   if (drop_p <= 0.f) dx_drop = nullptr;
   if (dtype == OM_BF16)
     return launch_ln_bwd<bf16_t, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, 0, nullptr, dx_drop, drop_p, drop_seed, dy32, x32);
+  if (dtype == OM_F16)
+    return launch_ln_bwd<f16_t, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, 0, nullptr, dx_drop, drop_p, drop_seed, dy32, x32);
   return launch_ln_bwd<float, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, 0, nullptr, dx_drop, drop_p, drop_seed, dy32, x32);
 }
 
@@ -427,6 +440,8 @@ int omk_norm_bwd(int dtype, const void* dy, const void* x, const float* g, void*
   if (H % 4 || H > 2048) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
   if (dtype == OM_BF16)
     return launch_ln_bwd<bf16_t, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, rms, add);
+  if (dtype == OM_F16)
+    return launch_ln_bwd<f16_t, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, rms, add);
   return launch_ln_bwd<float, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, rms, add);
 }
 
@@ -438,6 +453,8 @@ int omk_embed_bwd(int dtype, const void* dy, const int64_t* ids, const int64_t* 
   if (H % 4 || H > 2048) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
   if (dtype == OM_BF16)
     return launch_ln_bwd<bf16_t, 1>(dy, nullptr, g, nullptr, dg, db, M, H, eps, ids, type_ids, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, s);
+  if (dtype == OM_F16)
+    return launch_ln_bwd<f16_t, 1>(dy, nullptr, g, nullptr, dg, db, M, H, eps, ids, type_ids, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, s);
   return launch_ln_bwd<float, 1>(dy, nullptr, g, nullptr, dg, db, M, H, eps, ids, type_ids, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, s);
 }
 
@@ -483,6 +500,7 @@ int omk_pool_bwd(int dtype, const float* dp, const int64_t* mask, void* dh, int6
   parts = parts < 1 ? 1 : (parts > L ? L : parts);
   const dim3 grid((unsigned)B, (unsigned)parts);
   if (dtype == OM_BF16) hipLaunchKernelGGL((pool_bwd_kernel<bf16_t>), grid, dim3(256), 0, s, dp, mask, (bf16_t*)dh, L, H, mode);
+  else if (dtype == OM_F16) hipLaunchKernelGGL((pool_bwd_kernel<f16_t>), grid, dim3(256), 0, s, dp, mask, (f16_t*)dh, L, H, mode);
   else hipLaunchKernelGGL((pool_bwd_kernel<float>), grid, dim3(256), 0, s, dp, mask, (float*)dh, L, H, mode);
   OM_LAUNCH_CHECK();
   return 0;
@@ -816,10 +834,10 @@ int omk_attention_bwd_bias(int dtype, const void* qkv, const void* dctx, void* d
                            const float* pos_bias, float* drel, hipStream_t s) {
   if (B <= 0) return 0;
   if (!pos_bias && omk_attention_bwd16_ok(dtype, L, H, heads))
-    return omk_attention_bwd16(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s);
+    return omk_attention_bwd16(dtype, qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s);
   if (L < 1 || L > 256) OM_FAIL("training supports sequence lengths up to 256");
   // the three transposed [64][L + 4] images of the backward kernel must fit the 160 KiB of LDS: 256 keys in 16 bits, 192 in f32
-  if (dtype != OM_BF16 && L > 192) OM_FAIL("float32 training supports sequence lengths up to 192 (bfloat16: 256)");
+  if (dtype == OM_F32 && L > 192) OM_FAIL("float32 training supports sequence lengths up to 192 (16-bit formats: 256)");
   if (H != heads * 64) OM_FAIL("head_dim must be 64");
 #define AB(TT)                                                                                       \
   do {                                                                                               \
@@ -830,6 +848,7 @@ int omk_attention_bwd_bias(int dtype, const void* qkv, const void* dctx, void* d
     return launch_attn_bwd<TT, 8>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s);    \
   } while (0)
   if (dtype == OM_BF16) AB(bf16_t);
+  if (dtype == OM_F16) AB(f16_t);
   AB(float);
 #undef AB
 }

@@ -47,9 +47,16 @@ def inference_code(model, code, seq_len):
     return code
 
 
-def training_code(code):
-    """Training runs in bfloat16 or float32 (float16 would need loss scaling; the backward kernels are bfloat16)."""
-    return N.OM_BF16 if code == N.OM_F16 else code
+def training_code(code, model=None):
+    """The compute format of a TRAINING step.  float16 (the reference's `--fp16` training: HF Trainer's torch.cuda.amp autocast +
+    GradScaler, trainer/dense_trainer.py:141-149) is served for BERT-family erf-GELU encoders (round 5; the trainer scales the
+    loss, openmatch_amd/trainer/dense_trainer.py); T5 (activations leave the float16 range) and other activations train in
+    bfloat16.  Without a model (callers that only name a format): the conservative bfloat16."""
+    if code != N.OM_F16:
+        return code
+    if model is None or os.environ.get("OM_TRAIN_F16", "1") == "0":
+        return N.OM_BF16
+    return inference_code(model, code, 0)
 
 
 class _Packed:

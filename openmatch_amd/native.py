@@ -167,7 +167,8 @@ _SIGNATURES = {
     "om_exchange_topk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "om_grad_sqnorm": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "om_adamw_step": (c_int, [c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_int64, c_void_p, c_float, c_float,
-                              c_int, c_void_p]),
+                              c_int, c_void_p, c_void_p]),
+    "om_loss_scale_update": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "om_contrastive_fwd_bwd_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
                                           c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p]),

@@ -26,7 +26,8 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError("invalid AdamW hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.max_grad_norm = float(max_grad_norm or 0.0)
-        self.grad_scale = 1.0                # gradients are multiplied by it (1 / loss scale of float16 training)
+        self.grad_scale = 1.0                # gradients are multiplied by it (a static 1 / loss scale)
+        self.inv_scale = None                # device scalar multiplied in as well (1 / dynamic loss scale: LossScaler.state[1:2])
         self.skip_nonfinite = False          # True: an inf / nan gradient norm skips the step (GradScaler semantics)
         self._plan = None
         self._norm_sq = None                 # device scalar of the last step: sum of squares of the raw gradients (before grad_scale and clipping)
@@ -117,7 +118,8 @@ class FusedAdamW(torch.optim.Optimizer):
                     self.state[p]["step"] = step_no
                 N.check(lib.om_adamw_step(N.ptr(pl["tab"]), N.ptr(pl["chunks"]), pl["n_chunks"], lr, b1, b2, eps, step_no,
                                           N.ptr(self._norm_sq) if need_norm else None, self.max_grad_norm,
-                                          float(self.grad_scale), int(self.skip_nonfinite), stream))
+                                          float(self.grad_scale), int(self.skip_nonfinite),
+                                          N.ptr(self.inv_scale) if self.inv_scale is not None else None, stream))
                 enc.after_inplace_update(pl["refreshed"], pl["stale"])
         return loss
 
@@ -125,4 +127,37 @@ class FusedAdamW(torch.optim.Optimizer):
         """|g * grad_scale|_2 of the last step (before clipping), as a device scalar -- what clip_grad_norm_ returns."""
         if self._norm_sq is None:
             return None
-        return self._norm_sq[0].sqrt() * abs(self.grad_scale)
+        n = self._norm_sq[0].sqrt() * abs(self.grad_scale)
+        return n * self.inv_scale[0] if self.inv_scale is not None else n
+
+
+class LossScaler:
+    """The dynamic loss scale of float16 training, on the device (what torch.cuda.amp.GradScaler is to HF Trainer's --fp16, which
+    the reference inherits: trainer/dense_trainer.py:141-149): `scale` multiplies the loss before backward; FusedAdamW divides
+    it out of the gradients (`inv_scale`), skips a step whose gradients are not finite, and `update()` halves the scale after
+    such a step / doubles it after `growth_interval` clean ones -- without a host synchronisation."""
+
+    def __init__(self, device, init_scale=65536.0, growth_interval=2000):
+        self.state = torch.tensor([init_scale, 1.0 / init_scale, 0.0, 0.0], dtype=torch.float32, device=device)
+        self.growth_interval = int(growth_interval)
+
+    @property
+    def scale(self):                 # device scalar (view)
+        return self.state[0]
+
+    @property
+    def inv_scale(self):
+        return self.state[1:2]
+
+    def attach(self, optimizer):
+        optimizer.inv_scale = self.inv_scale
+        optimizer.skip_nonfinite = True
+
+    def update(self, optimizer):
+        """after optimizer.step(): reads the step's squared gradient norm where the optimizer left it"""
+        with torch.cuda.device(self.state.device):
+            N.check(N.lib().om_loss_scale_update(N.ptr(optimizer._norm_sq), N.ptr(self.state), self.growth_interval,
+                                                 N.stream_ptr(self.state.device)))
+
+    def skipped_steps(self):
+        return int(self.state[3].item())

@@ -191,7 +191,7 @@ class _EncoderTrain(torch.autograd.Function):
 def encode_train(model, head, items, pooling, normalize, code, training):
     """(None, reps) with an autograd edge from `reps` to every encoder / head parameter.
     Dropout follows the HF config only in training mode (model.train())."""
-    code = training_code(code)
+    code = training_code(code, model)
     ids = items["input_ids"].to(torch.int64).contiguous()
     mask = items["attention_mask"].to(device=ids.device, dtype=torch.int64).contiguous()
     tti = items.get("token_type_ids") if hasattr(items, "get") else None

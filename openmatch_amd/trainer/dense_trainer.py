@@ -264,10 +264,29 @@ class DRTrainer:
         return (outputs.loss, outputs) if return_outputs else outputs.loss
 
     def _autocast(self):
+        """--fp16: float16 autocast, as HF Trainer's torch.cuda.amp (trainer/dense_trainer.py:141-149 hands `fp16=`, `scaler=` on):
+        BERT-family encoders then train on the float16 kernels with a dynamic loss scale (round 5), T5 on the bfloat16 ones
+        (openmatch_amd/encoder.py:training_code).  --bf16: the bfloat16 kernels."""
         from contextlib import nullcontext
-        if getattr(self.args, "fp16", False) or getattr(self.args, "bf16", False):
-            return torch.autocast("cuda", dtype=torch.bfloat16)     # selects the bf16 MFMA path
+        if getattr(self.args, "fp16", False):
+            return torch.autocast("cuda", dtype=torch.float16)
+        if getattr(self.args, "bf16", False):
+            return torch.autocast("cuda", dtype=torch.bfloat16)
         return nullcontext()
+
+    def _loss_scaler(self):
+        """The dynamic loss scale of --fp16 runs (None otherwise): created on first use, on the model's device."""
+        if not getattr(self.args, "fp16", False) or str(getattr(self.args, "device", "cpu")).startswith("cpu"):
+            return None
+        if getattr(self, "_scaler", None) is None:
+            from ..optim import LossScaler
+            self._scaler = LossScaler(self.args.device, init_scale=float(getattr(self.args, "fp16_init_scale", 65536.0)),
+                                      growth_interval=int(getattr(self.args, "fp16_growth_interval", 2000)))
+        return self._scaler
+
+    def _scaled(self, loss):
+        sc = self._loss_scaler()
+        return loss if sc is None else loss * sc.scale
 
     def training_step(self, model, inputs, *_unused) -> torch.Tensor:
         model.train()
@@ -275,7 +294,7 @@ class DRTrainer:
         with self._autocast():
             loss = self.compute_loss(model, inputs)
         accum = max(1, getattr(self.args, "gradient_accumulation_steps", 1))
-        (loss / accum).backward()
+        self._scaled(loss / accum).backward()
         return loss.detach() / self._dist_loss_scale_factor
 
     # ------------------------------------------------------------------ loop
@@ -311,13 +330,33 @@ class DRTrainer:
             allreduce_mean_(params, W, skip_storages=skip_storages)
         from ..optim import FusedAdamW
         max_norm = getattr(a, "max_grad_norm", 0.0)
+        scaler = self._loss_scaler()
         if isinstance(self.optimizer, FusedAdamW):
             self.optimizer.max_grad_norm = float(max_norm or 0.0)
+            if scaler is not None:               # unscale, skip a non-finite step, update the scale: all on the device
+                scaler.attach(self.optimizer)
             self.optimizer.step()
+            if scaler is not None:
+                scaler.update(self.optimizer)
         else:
-            if max_norm and max_norm > 0:
-                torch.nn.utils.clip_grad_norm_(params, max_norm)
-            self.optimizer.step()
+            skip = False
+            if scaler is not None:               # a foreign optimizer under --fp16: unscale in place, skip on inf / nan (one host read)
+                grads = [p.grad for p in params if p.grad is not None]
+                torch._foreach_mul_(grads, scaler.inv_scale[0])
+                total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g_) for g_ in grads]))
+                skip = not bool(torch.isfinite(total))
+                st = scaler.state
+                if skip:
+                    st[0] = torch.clamp(st[0] * 0.5, min=1.0); st[2] = 0; st[3] += 1
+                else:
+                    st[2] += 1
+                    if float(st[2]) >= scaler.growth_interval:
+                        st[0] = torch.clamp(st[0] * 2.0, max=16777216.0); st[2] = 0
+                st[1] = 1.0 / st[0]
+            if not skip:
+                if max_norm and max_norm > 0:
+                    torch.nn.utils.clip_grad_norm_(params, max_norm)
+                self.optimizer.step()
             from ..encoder import invalidate_packed
             invalidate_packed(self.model)
         if self.lr_scheduler is not None:
@@ -466,7 +505,7 @@ class GCDenseTrainer(DRTrainer):
                 q_all, p_all, q0, p0, scale = q_reps, p_reps, 0, 0, 1.0
             n_psg = p_all.shape[0] // q_all.shape[0]
             loss, _ = contrastive_loss(q_all, p_all, n_psg, scale, q_reps, q0, p_reps, p0)
-            loss.backward()
+            self._scaled(loss).backward()          # --fp16: the cached representation gradients carry the loss scale into every chunk's backward
             grads = list(q_reps.grad.split(a.gc_q_chunk_size)) + list(p_reps.grad.split(a.gc_p_chunk_size))
             for ch, st, gr in zip(q_chunks + p_chunks, states, grads):
                 torch.random.set_rng_state(st)

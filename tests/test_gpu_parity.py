@@ -1797,3 +1797,59 @@ def test_optimizer_step_refreshes_the_packed_weights(golden, dtype):
             assert off == H * at.key.weight.shape[1]
             want = torch.cat([at.query.weight, at.key.weight, at.value.weight], 0).detach().to(buf.dtype)
             assert torch.equal(buf.view(3 * H, -1), want)
+
+
+def test_float16_training_step_tracks_f32_and_scaler_skips_overflow(golden, tmp_path):
+    """float16 training (round 5): (1) the float16 kernels' gradients on the tiny fixture against the reference's fp32 gradients --
+    direction and size per tensor, closer than the bfloat16 path's; dropout runs; (2) DRTrainer --fp16: the dynamic loss scale on
+    the device -- an absurd initial scale overflows float16, those steps are skipped (parameters untouched) and the scale halves
+    until the step goes through, then the loss falls as in the other formats."""
+    from openmatch.trainer import DRTrainer
+    from openmatch_amd import native as N
+    g = golden("train_bert_tiny")
+    q, p = _train_batch(g)
+    errs = {}
+    for dtype in ("float16", "bfloat16"):
+        model = _train_model(g, dtype=dtype)
+        out = model(query=q, passage=p)
+        assert abs(out.loss.item() - float(g["loss"])) < (5e-3 if dtype == "float16" else 2e-2)
+        (out.loss * 1024.0).backward()
+        names = dict(model.lm_q.named_parameters())
+        rels = []
+        for key in g.files:
+            if not key.startswith("g::") or key[3:] == "head_w":
+                continue
+            ref = torch.from_numpy(g[key]).flatten().double()
+            if ref.norm() < 1e-7:
+                continue
+            got = names[key[3:]].grad.cpu().flatten().double() / 1024.0
+            rels.append(float((got - ref).norm() / ref.norm()))
+            if dtype == "float16":
+                cos = torch.dot(ref, got) / (ref.norm() * got.norm())
+                assert cos > 0.999, (key, cos.item())
+        errs[dtype] = float(np.median(rels))
+    print("median rel-L2 gradient error on the tiny fixture: float16 %.2e, bfloat16 %.2e" % (errs["float16"], errs["bfloat16"]))
+    assert errs["float16"] < errs["bfloat16"]
+    model = _train_model(g, dtype="float16", p_drop=0.1)
+    l1 = model(query=q, passage=p).loss
+    l1.backward()
+    assert torch.isfinite(l1) and all(torch.isfinite(p_.grad).all() for p_ in model.lm_q.parameters() if p_.grad is not None)
+
+    # (2) the trainer's loss scaler
+    model = _train_model(g)                                           # dtype comes from autocast under --fp16
+    args = _trainer_args(tmp_path, fp16=True, fp16_init_scale=float(2 ** 40), fp16_growth_interval=4, max_steps=60, learning_rate=1e-3)
+    trainer = DRTrainer(model=model, args=args)
+    trainer.create_optimizer_and_scheduler(num_training_steps=60)
+    w0 = model.lm_q.encoder.layer[0].output.dense.weight.detach().clone()
+    first = float(trainer.training_step(model, (q, p)))
+    trainer.optimizer_step()
+    sc = trainer._loss_scaler()
+    assert sc is not None and sc.skipped_steps() == 1 and float(sc.state[0]) == float(2 ** 39)      # 2^40 overflowed: skipped, halved
+    assert torch.equal(model.lm_q.encoder.layer[0].output.dense.weight.detach(), w0)                  # nothing moved
+    last = first
+    for _ in range(59):
+        last = float(trainer.training_step(model, (q, p)))
+        trainer.optimizer_step()
+    assert 1 <= sc.skipped_steps() < 40 and float(sc.state[0]) < 2 ** 30 and math.isfinite(last)
+    assert last < first - 0.05, (first, last)
+    assert not torch.equal(model.lm_q.encoder.layer[0].output.dense.weight.detach(), w0)

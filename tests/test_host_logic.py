@@ -354,6 +354,9 @@ def test_compute_format_resolution():
     assert inference_code(relu, N.OM_F16, 128) == N.OM_BF16 and inference_code(t5, N.OM_F16, 128) == N.OM_BF16
     assert inference_code(t5, N.OM_BF16, 128) == N.OM_BF16 and inference_code(bert, N.OM_F32, 512) == N.OM_F32
     assert training_code(N.OM_F16) == N.OM_BF16 and training_code(N.OM_F32) == N.OM_F32
+    # round 5: float16 training is served for BERT-family erf-GELU encoders, bfloat16 elsewhere
+    assert training_code(N.OM_F16, bert) == N.OM_F16 and training_code(N.OM_F16, t5) == N.OM_BF16 and training_code(N.OM_F16, relu) == N.OM_BF16
+    assert training_code(N.OM_BF16, bert) == N.OM_BF16
     assert torch_dtype_of(N.OM_F16) == torch.float16 and torch_dtype_of(N.OM_BF16) == torch.bfloat16 and torch_dtype_of(N.OM_F32) == torch.float32
 
 

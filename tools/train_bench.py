@@ -28,7 +28,7 @@ def main():
     cfg = BertConfig(hidden_dropout_prob=a.dropout, attention_probs_dropout_prob=a.dropout)
     lm = BertModel(cfg)
     model = DRModel(lm_q=lm, lm_p=lm, pooling="first",
-                    model_args=NS(encoder_only=False, dtype="bfloat16" if a.precision == "bf16" else "float32"),
+                    model_args=NS(encoder_only=False, dtype={"bf16": "bfloat16", "f16": "float16"}.get(a.precision, "float32")),
                     data_args=NS(train_n_passages=8),
                     train_args=NS(negatives_x_device=False, per_device_train_batch_size=8)).to(dev)
     g = torch.Generator().manual_seed(1)
@@ -39,7 +39,7 @@ def main():
         batch = tuple({k: v.to(dev) for k, v in b.items()} for b in batch)
     args = NS(device=dev, world_size=1, process_index=0, per_device_train_batch_size=8, negatives_x_device=False,
               learning_rate=5e-6, weight_decay=0.0, adam_beta1=0.9, adam_beta2=0.999, adam_epsilon=1e-8,
-              gradient_accumulation_steps=1, max_grad_norm=1.0, fp16=False, bf16=False)
+              gradient_accumulation_steps=1, max_grad_norm=1.0, fp16=a.precision == "f16", bf16=False)      # f16: float16 kernels + the dynamic loss scale
     trainer = DRTrainer(model=model, args=args)
     if a.optimizer == "torch":
         trainer.optimizer = torch.optim.AdamW(model.parameters(), lr=5e-6, weight_decay=0.0, fused=True)
