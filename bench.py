@@ -264,48 +264,64 @@ def parity_leg(model_16, lm, batches, device, index=None, queries=None, topk=100
 
 
 def train_leg(device, steps=8):
-    """BASELINE config 3 per GPU: one contrastive training step (8 queries x 32 tok + 64 passages x 128 tok, bert-base,
-    dropout 0.1, forward + backward + AdamW) -- steps/s and algorithmic TFLOP/s (3 x forward FLOPs)."""
+    """BASELINE config 3 per GPU: one contrastive training step (8 queries x 32 tok + 64 passages x 128 tok, bert-base, dropout 0.1,
+    forward + backward + clip + AdamW) through the product's own loop (DRTrainer.training_step + DRTrainer.optimizer_step).
+    `value` is the reference's documented mode: `--fp16` (docs/dr-msmarco-passage.md:74) = float16 kernels + dynamic loss scale, with
+    the forward's residual stream in f32 as autocast keeps it.  Beside it: the same step in bfloat16, and in bfloat16 with the 16-bit
+    residual stream of rounds 1-4 (OM_TRAIN_RES32 = 0) for continuity with earlier rounds' numbers."""
     from transformers import BertConfig, BertModel
     from openmatch.modeling import DRModel
     from openmatch.trainer import DRTrainer
+    from openmatch_amd import native as N
     from types import SimpleNamespace as NS
-    torch.manual_seed(0)
-    lm = BertModel(BertConfig(hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1))
-    model = DRModel(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype="bfloat16"),
-                    data_args=NS(train_n_passages=8),
-                    train_args=NS(negatives_x_device=False, per_device_train_batch_size=8)).to(device)
     g = torch.Generator().manual_seed(1)
     mk = lambda n, L: {"input_ids": torch.randint(1000, 30000, (n, L), generator=g), "attention_mask": torch.ones(n, L, dtype=torch.long)}
     # the batch is resident in HBM before the timed region (the bench contract; a training run gets there through the DataLoader's
     # pinned buffers and non-blocking copies -- a pageable host tensor would make every step's copy a stream synchronisation)
     batch = tuple({k: v.to(device) for k, v in b.items()} for b in (mk(8, 32), mk(64, 128)))
-    args = NS(device=device, world_size=1, process_index=0, per_device_train_batch_size=8, negatives_x_device=False,
-              learning_rate=5e-6, weight_decay=0.0, max_grad_norm=1.0, gradient_accumulation_steps=1, fp16=False, bf16=False)
-    trainer = DRTrainer(model=model, args=args)
-    # the product's own step: DRTrainer.training_step (forward + loss + backward) and DRTrainer.optimizer_step (what
-    # DRTrainer.train runs between two batches: clip_grad_norm_(1.0) + AdamW + the refresh of the packed bf16 weights, on
-    # openmatch_amd.optim.FusedAdamW -- HF Trainer's defaults of the reference's command line, docs/dr-msmarco-passage.md:62-80)
-    trainer.create_optimizer_and_scheduler(num_training_steps=10 ** 6)
-
-    def step():
-        loss = trainer.training_step(model, batch)
-        trainer.optimizer_step()
-        return loss
-    for _ in range(3):
-        step()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
     flop = 3 * (8 * 5.474e9 + 64 * GFLOP_PER_PASSAGE * 1e9)
-    out = {"metric": "contrastive training steps/s per GPU (8 q x 32 tok + 64 p x 128 tok, bert-base, fwd + bwd + AdamW, dropout 0.1)",
-           "value": round(1 / dt, 2), "unit": "steps/s", "ms_per_step": round(dt * 1e3, 2), "dtype": "bf16",
-           "algorithmic_tflops": round(flop / dt / 1e12, 1), "frac_of_mfma_peak": round(flop / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
-           "loss": float(loss)}
-    out["optimizer"] = type(trainer.optimizer).__name__
-    del model, trainer
-    torch.cuda.empty_cache()
+
+    def run(fp16, dtype, res32):
+        torch.manual_seed(0)
+        lm = BertModel(BertConfig(hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1))
+        model = DRModel(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype=dtype),
+                        data_args=NS(train_n_passages=8),
+                        train_args=NS(negatives_x_device=False, per_device_train_batch_size=8)).to(device)
+        args = NS(device=device, world_size=1, process_index=0, per_device_train_batch_size=8, negatives_x_device=False,
+                  learning_rate=5e-6, weight_decay=0.0, max_grad_norm=1.0, gradient_accumulation_steps=1, fp16=fp16, bf16=False)
+        trainer = DRTrainer(model=model, args=args)
+        # HF Trainer's defaults of the reference's command line (docs/dr-msmarco-passage.md:62-80): AdamW, clip_grad_norm_(1.0) -- here
+        # openmatch_amd.optim.FusedAdamW: clip + AdamW + the refresh of the packed 16-bit weights in one pass
+        trainer.create_optimizer_and_scheduler(num_training_steps=10 ** 6)
+        N.check(N.lib().om_debug_option(18, int(res32)))              # OM_OPT_TRAIN_RES32
+        try:
+            def step():
+                loss = trainer.training_step(model, batch)
+                trainer.optimizer_step()
+                return loss
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = step()
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+        finally:
+            N.check(N.lib().om_debug_option(18, 1))
+        out = {"value": round(1 / dt, 2), "unit": "steps/s", "ms_per_step": round(dt * 1e3, 2),
+               "algorithmic_tflops": round(flop / dt / 1e12, 1), "frac_of_mfma_peak": round(flop / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
+               "loss": float(loss), "optimizer": type(trainer.optimizer).__name__}
+        sc = trainer._loss_scaler()
+        if sc is not None:
+            out["loss_scale"] = float(sc.state[0]); out["skipped_steps"] = sc.skipped_steps()
+        del model, trainer
+        torch.cuda.empty_cache()
+        return out
+
+    out = {"metric": "contrastive training steps/s per GPU (8 q x 32 tok + 64 p x 128 tok, bert-base, fwd + bwd + clip + AdamW, dropout 0.1)",
+           "dtype": "f16", "mode": "--fp16: float16 kernels + dynamic loss scale (the reference's documented training mode), f32 residual stream"}
+    out.update(run(True, "float16", 1))
+    out["bf16"] = dict(run(False, "bfloat16", 1), mode="bfloat16 kernels, f32 residual stream")
+    out["bf16_res16"] = dict(run(False, "bfloat16", 0), mode="bfloat16 kernels, 16-bit residual stream (OM_TRAIN_RES32=0): the data flow of rounds 1-4")
     return out
 
 

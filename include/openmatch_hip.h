@@ -436,7 +436,9 @@ typedef struct OmAdamTensor {
 int om_grad_sqnorm(const OmAdamTensor* tensors, const int32_t* chunks, int n_chunks, float* partial, float* out_sq, void* stream);
 int om_adamw_step(const OmAdamTensor* tensors, const int32_t* chunks, int n_chunks, float lr, float beta1, float beta2, float eps,
                   int64_t step, const float* gnorm_sq, float max_norm, float grad_scale, int skip_nonfinite,
-                  const float* inv_scale /* device scalar multiplied into grad_scale, or NULL: state4[1] of om_loss_scale_update */, void* stream);
+                  const float* scale_state /* NULL, or state4 of om_loss_scale_update: gradients are multiplied by state4[1] as well, and the
+                                              bias corrections use step - state4[3] (GradScaler does not call step() on a skipped step) */,
+                  void* stream);
 /* Dynamic loss scale of float16 training (torch.cuda.amp.GradScaler.update; the reference's --fp16 through HF Trainer,
  * trainer/dense_trainer.py:141-149) on the device: state4 = {scale, 1 / scale, clean steps, skipped steps}; a non-finite
  * gnorm_sq[0] (om_grad_sqnorm of the SCALED gradients) halves the scale, `growth_interval` finite steps in a row double it. */

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(1024) void sqnorm_reduce_kernel(const float* __rest
   }
 }
 
-struct AdamArgs { float lr_wd_unused, step_size, beta1, beta2, eps, bc2_sqrt_inv, max_norm, grad_scale, lr; int clip, skip_nonfinite; const float* inv_scale; };
+struct AdamArgs { float lr_wd_unused, step_size, beta1, beta2, eps, bc2_sqrt_inv, max_norm, grad_scale, lr; int clip, skip_nonfinite; const float* scale_state; long long step; };
 
 // torch.optim.AdamW's update (torch/optim/adamw.py, single-tensor form), element by element:
 //   p *= 1 - lr wd;  m += (g - m)(1 - b1);  v = v b2 + (1 - b2) g g;  p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)
@@ -76,7 +76,20 @@ __global__ __launch_bounds__(THREADS) void adamw_kernel(const OmAdamTensor* __re
   const int64_t base = (int64_t)chunks[2 * blockIdx.x + 1] * CHUNK;
   const int64_t n = t.n - base < CHUNK ? t.n - base : CHUNK;
   float gs = a.grad_scale;
-  if (a.inv_scale) gs *= a.inv_scale[0];                            // 1 / (dynamic loss scale), kept on the device (om_loss_scale_update)
+  if (a.scale_state) {                                                // the dynamic loss scale's state, kept on the device (om_loss_scale_update)
+    gs *= a.scale_state[1];                                           // 1 / scale
+    const float skipped = a.scale_state[3];
+    if (skipped > 0.f) {       // GradScaler never calls optimizer.step() on a skipped step: the bias corrections count the steps TAKEN
+      __shared__ float bc[2];
+      if (threadIdx.x == 0) {
+        const double n = (double)a.step - (double)skipped;
+        bc[0] = (float)((double)a.lr / (1.0 - pow((double)a.beta1, n)));
+        bc[1] = (float)(1.0 / sqrt(1.0 - pow((double)a.beta2, n)));
+      }
+      __syncthreads();
+      a.step_size = bc[0]; a.bc2_sqrt_inv = bc[1];
+    }
+  }
   if (gnorm_sq) {
     const float nrm = sqrtf(gnorm_sq[0]) * fabsf(gs);
     if (a.skip_nonfinite && !(nrm <= 3.0e38f)) return;           // inf / nan gradients: the step is skipped (GradScaler semantics)
@@ -152,7 +165,7 @@ extern "C" int om_loss_scale_update(const float* gnorm_sq, float* state4, int gr
 
 extern "C" int om_adamw_step(const OmAdamTensor* tensors, const int32_t* chunks, int n_chunks, float lr, float beta1, float beta2,
                              float eps, int64_t step, const float* gnorm_sq, float max_norm, float grad_scale, int skip_nonfinite,
-                             const float* inv_scale, void* stream) {
+                             const float* scale_state, void* stream) {
   if (n_chunks < 0 || (n_chunks > 0 && (!tensors || !chunks))) OM_FAIL("null argument");
   if (step < 1) OM_FAIL("step counts from 1");
   if (!(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f)) OM_FAIL("betas must lie in [0, 1)");
@@ -168,7 +181,7 @@ extern "C" int om_adamw_step(const OmAdamTensor* tensors, const int32_t* chunks,
   a.max_norm = max_norm; a.grad_scale = grad_scale;
   a.clip = max_norm > 0.f ? 1 : 0;
   a.skip_nonfinite = skip_nonfinite;
-  a.inv_scale = inv_scale;
+  a.scale_state = scale_state; a.step = (long long)step;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)n_chunks), dim3(THREADS), 0, (hipStream_t)stream, tensors, chunks, gnorm_sq, a);
   OM_LAUNCH_CHECK();
   return 0;

@@ -27,7 +27,7 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.max_grad_norm = float(max_grad_norm or 0.0)
         self.grad_scale = 1.0                # gradients are multiplied by it (a static 1 / loss scale)
-        self.inv_scale = None                # device scalar multiplied in as well (1 / dynamic loss scale: LossScaler.state[1:2])
+        self.scale_state = None              # LossScaler.state: gradients are divided by the dynamic loss scale, skipped steps are not counted
         self.skip_nonfinite = False          # True: an inf / nan gradient norm skips the step (GradScaler semantics)
         self._plan = None
         self._norm_sq = None                 # device scalar of the last step: sum of squares of the raw gradients (before grad_scale and clipping)
@@ -119,7 +119,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 N.check(lib.om_adamw_step(N.ptr(pl["tab"]), N.ptr(pl["chunks"]), pl["n_chunks"], lr, b1, b2, eps, step_no,
                                           N.ptr(self._norm_sq) if need_norm else None, self.max_grad_norm,
                                           float(self.grad_scale), int(self.skip_nonfinite),
-                                          N.ptr(self.inv_scale) if self.inv_scale is not None else None, stream))
+                                          N.ptr(self.scale_state) if self.scale_state is not None else None, stream))
                 enc.after_inplace_update(pl["refreshed"], pl["stale"])
         return loss
 
@@ -128,13 +128,13 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._norm_sq is None:
             return None
         n = self._norm_sq[0].sqrt() * abs(self.grad_scale)
-        return n * self.inv_scale[0] if self.inv_scale is not None else n
+        return n * self.scale_state[1] if self.scale_state is not None else n
 
 
 class LossScaler:
     """The dynamic loss scale of float16 training, on the device (what torch.cuda.amp.GradScaler is to HF Trainer's --fp16, which
     the reference inherits: trainer/dense_trainer.py:141-149): `scale` multiplies the loss before backward; FusedAdamW divides
-    it out of the gradients (`inv_scale`), skips a step whose gradients are not finite, and `update()` halves the scale after
+    it out of the gradients (`scale_state`), skips a step whose gradients are not finite, and `update()` halves the scale after
     such a step / doubles it after `growth_interval` clean ones -- without a host synchronisation."""
 
     def __init__(self, device, init_scale=65536.0, growth_interval=2000):
@@ -150,7 +150,7 @@ class LossScaler:
         return self.state[1:2]
 
     def attach(self, optimizer):
-        optimizer.inv_scale = self.inv_scale
+        optimizer.scale_state = self.state
         optimizer.skip_nonfinite = True
 
     def update(self, optimizer):

@@ -1756,6 +1756,40 @@ def test_fused_adamw_matches_torch_adamw(max_norm):
     assert all(torch.equal(a, b) for a, b in zip(mine, before))
 
 
+def test_fused_adamw_does_not_count_the_steps_the_loss_scaler_skipped():
+    """torch.cuda.amp.GradScaler does not call optimizer.step() when the scaled gradients overflow, so AdamW's bias corrections
+    count the steps TAKEN.  FusedAdamW + LossScaler keep the skip on the device (no host read): two overflowing steps, then
+    two clean ones, must leave the parameters and both moments where torch.optim.AdamW's first two steps on the same (unscaled)
+    gradients leave them, and the scale halved twice."""
+    from openmatch_amd.optim import FusedAdamW, LossScaler
+    gen = torch.Generator().manual_seed(5)
+    sizes = [(33,), (16385,), (64, 96)]
+    mine = [torch.nn.Parameter(torch.randn(*s, generator=gen).to(DEV)) for s in sizes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    fo = FusedAdamW(mine, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_grad_norm=1.0)
+    to = torch.optim.AdamW(ref, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, foreach=False, fused=False)
+    sc = LossScaler(DEV, init_scale=1024.0, growth_interval=1000)
+    sc.attach(fo)
+    start = [p.detach().clone() for p in mine]
+    for _ in range(2):                                             # overflow: skipped, scale halves
+        for p in mine:
+            p.grad = torch.full_like(p, float("inf"))
+        fo.step(); sc.update(fo)
+    assert all(torch.equal(a, b) for a, b in zip(mine, start))
+    assert sc.skipped_steps() == 2 and float(sc.state[0]) == 256.0
+    for _ in range(2):
+        for a, b in zip(mine, ref):
+            gr = torch.randn(*a.shape, generator=gen).to(DEV)
+            a.grad, b.grad = gr * sc.scale, gr.clone()             # what backward of (loss * scale) leaves
+        torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        fo.step(); sc.update(fo); to.step()
+        for a, b in zip(mine, ref):
+            assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item())
+            for k in ("exp_avg", "exp_avg_sq"):
+                assert (fo.state[a][k] - to.state[b][k]).abs().max().item() <= 2e-6 * max(1.0, to.state[b][k].abs().max().item()), k
+    assert sc.skipped_steps() == 2 and float(sc.state[2]) == 2.0
+
+
 @pytest.mark.parametrize("dtype", ["bfloat16", "float32"])
 def test_optimizer_step_refreshes_the_packed_weights(golden, dtype):
     """The forward reads PACKED copies of the weights (Q|K|V fused, matrices in the compute dtype).  After DRTrainer.optimizer_step
