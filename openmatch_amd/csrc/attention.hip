@@ -694,7 +694,7 @@ int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
   if (B * heads > 0x7fffffffLL) OM_FAIL("batch too large for one launch");
   if (dtype == OM_F16) {                                      // float16 inference mode: the fast kernel only
     if (L > 256) {
-      if (drop_p > 0.f || pos_bias) OM_FAIL("float16 attention: inference without a position-bias table only");
+      if (drop_p > 0.f) OM_FAIL("float16 attention beyond 256 tokens: inference only");
       return launch_attn_long<f16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
     }
     if (L <= 32) return launch_attn16<f16_t, 1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);

@@ -175,7 +175,7 @@ extern "C" int om_encoder_packed_supported(const OmEncoderConfig* c, int gated_f
   if (om_option(OM_OPT_ENCODER_FUSED_LN) == 0 || c->n_layers <= 0 || c->hidden % 8) return 0;
   const int H = c->hidden, F = c->ffn;
   if (c->arch == OM_ARCH_BERT) { if (c->act != OM_ACT_GELU_ERF) return 0; }
-  else if (c->arch == OM_ARCH_T5) { if (gated_ffn || dt != OM_BF16) return 0; }
+  else if (c->arch == OM_ARCH_T5) { if (gated_ffn || (dt == OM_F16 && c->act != OM_ACT_RELU)) return 0; }
   else return 0;
   return omk_gemm_ln_fusable(dt, packed_rows, H, H) && omk_gemm_ln_fusable(dt, packed_rows, F, H) &&
          omk_gemm_ln_fusable(dt, packed_rows, 3 * H, H) && omk_gemm_ln_fusable(dt, packed_rows, H, F) ? 1 : 0;
@@ -201,9 +201,12 @@ extern "C" int om_t5_relative_bucket(int relative_position, int num_buckets, int
 
 static int check_cfg(const OmEncoderConfig* c) {
   if (c->dtype != OM_F32 && c->dtype != OM_BF16 && c->dtype != OM_F16) OM_FAIL("dtype must be OM_F32, OM_BF16 or OM_F16");
-  if (c->dtype == OM_F16 && c->arch != OM_ARCH_BERT)
-    OM_FAIL("float16 mode serves BERT-family encoders (T5 activations leave the float16 range; use OM_BF16)");
-  if (c->dtype == OM_F16 && c->act != OM_ACT_GELU_ERF) OM_FAIL("float16 mode: erf-GELU encoders only");
+  // float16 (the reference's --fp16 = torch.cuda.amp float16, retriever/dense_retriever.py:76): BERT-family erf-GELU encoders, and
+  // (round 5) T5 encoder stacks with ReLU / tanh-GELU feed-forwards.  As under the reference's autocast, nothing clamps: a checkpoint
+  // whose feed-forward activations leave the float16 range overflows here as it does there (the caller picks OM_BF16 for those).
+  if (c->dtype == OM_F16 && c->arch == OM_ARCH_BERT && c->act != OM_ACT_GELU_ERF) OM_FAIL("float16 mode: erf-GELU BERT-family encoders only");
+  if (c->dtype == OM_F16 && c->arch == OM_ARCH_T5 && c->act != OM_ACT_RELU && c->act != OM_ACT_GELU_TANH)
+    OM_FAIL("float16 mode: T5 feed-forwards with ReLU or tanh-GELU only");
   if (c->arch != OM_ARCH_BERT && c->arch != OM_ARCH_T5) OM_FAIL("unknown arch");
   if (c->head_dim != 64 || c->n_heads * 64 != c->hidden)
     OM_FAIL("only head_dim 64 with n_heads*64 == hidden is supported");

@@ -6,8 +6,8 @@
 
 bool omk_gemm_wide7_f16_has(int act, bool resid, int lnf) {
   if (lnf == 2) return act == OM_ACT_NONE && resid;
-  if (lnf == 1) return !resid && (act == OM_ACT_NONE || act == OM_ACT_GELU_ERF);
-  return (act == OM_ACT_NONE) || (act == OM_ACT_GELU_ERF && !resid);
+  if (lnf == 1) return !resid && (act == OM_ACT_NONE || act == OM_ACT_GELU_ERF || act == OM_ACT_RELU);
+  return (act == OM_ACT_NONE) || ((act == OM_ACT_GELU_ERF || act == OM_ACT_RELU) && !resid);      // (T5's gated tanh-GELU layers: the generic tiles)
 }
 
 int omk_gemm_wide7_f16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
@@ -24,10 +24,12 @@ int omk_gemm_wide7_f16(const void* A, int64_t lda, const void* B, int64_t ldb, v
   } else if (lnf == 1) {
     if (act == OM_ACT_NONE && !resid) OM_L7(OM_ACT_NONE, false, 1);
     if (act == OM_ACT_GELU_ERF && !resid) OM_L7(OM_ACT_GELU_ERF, false, 1);
+    if (act == OM_ACT_RELU && !resid) OM_L7(OM_ACT_RELU, false, 1);                  // T5 (round 5): RMSNorm-folded wi + ReLU
   } else {
     if (act == OM_ACT_NONE && resid) OM_L7(OM_ACT_NONE, true, 0);
     if (act == OM_ACT_NONE && !resid) OM_L7(OM_ACT_NONE, false, 0);
     if (act == OM_ACT_GELU_ERF && !resid) OM_L7(OM_ACT_GELU_ERF, false, 0);
+    if (act == OM_ACT_RELU && !resid) OM_L7(OM_ACT_RELU, false, 0);
   }
 #undef OM_L7
   OM_FAIL("no generation-7 float16 kernel for this epilogue");

@@ -36,13 +36,18 @@ def torch_dtype_of(code):
 
 
 def inference_code(model, code, seq_len):
-    """float16 is served where it is safe and built: BERT-family encoders with erf-GELU (three more mantissa bits than
-    bfloat16 in every stored activation, same speed).  Everywhere else -- T5 (activations leave the float16 range),
-    other activations -- a 16-bit request means bfloat16."""
+    """float16 is served where it is built: BERT-family encoders with erf-GELU (three more mantissa bits than bfloat16 in every
+    stored activation, same speed) and (round 5) T5 ENCODER stacks with ReLU / tanh-GELU feed-forwards -- the reference's `--fp16`
+    is float16 autocast for every backbone (retriever/dense_retriever.py:76).  As there, nothing clamps: a T5 checkpoint whose
+    feed-forward activations leave the float16 range overflows in the reference and here alike; OM_T5_F16=0 (or `--bf16` /
+    dtype="bfloat16") serves such a checkpoint with the bfloat16 kernels.  Other activations: a 16-bit request means bfloat16."""
     if code != N.OM_F16:
         return code
     cfg = getattr(model, "config", None)
-    if _arch_of(model) != "bert" or _ACT.get(getattr(cfg, "hidden_act", None)) != N.ACT_GELU_ERF:
+    if _arch_of(model) == "t5":
+        ok = _ACT.get(getattr(cfg, "dense_act_fn", None)) in (N.ACT_RELU, N.ACT_GELU_TANH) and os.environ.get("OM_T5_F16", "1") != "0"
+        return code if ok else N.OM_BF16
+    if _ACT.get(getattr(cfg, "hidden_act", None)) != N.ACT_GELU_ERF:
         return N.OM_BF16
     return code
 
@@ -50,11 +55,11 @@ def inference_code(model, code, seq_len):
 def training_code(code, model=None):
     """The compute format of a TRAINING step.  float16 (the reference's `--fp16` training: HF Trainer's torch.cuda.amp autocast +
     GradScaler, trainer/dense_trainer.py:141-149) is served for BERT-family erf-GELU encoders (round 5; the trainer scales the
-    loss, openmatch_amd/trainer/dense_trainer.py); T5 (activations leave the float16 range) and other activations train in
-    bfloat16.  Without a model (callers that only name a format): the conservative bfloat16."""
+    loss, openmatch_amd/trainer/dense_trainer.py); T5 and other activations train in bfloat16 (the T5 training kernels and the T5
+    decoder position exist in bfloat16 and float32).  Without a model (callers that only name a format): the conservative bfloat16."""
     if code != N.OM_F16:
         return code
-    if model is None or os.environ.get("OM_TRAIN_F16", "1") == "0":
+    if model is None or os.environ.get("OM_TRAIN_F16", "1") == "0" or _arch_of(model) != "bert":
         return N.OM_BF16
     return inference_code(model, code, 0)
 

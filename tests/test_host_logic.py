@@ -336,9 +336,9 @@ def test_one_pass_rule_for_tied_training_batches():
     assert not DRModel(lm_q=lm, lm_p=other, tied=False, **args).train()._one_pass_ok(mk(8, 32), mk(64, 128))
 
 
-def test_compute_format_resolution():
-    """float16 requests: served as float16 for BERT-family erf-GELU encoders, as bfloat16 elsewhere (T5, other
-    activations, every training path)."""
+def test_compute_format_resolution(monkeypatch):
+    """float16 requests: served as float16 for BERT-family erf-GELU encoders and (round 5) T5 encoder stacks, as bfloat16 elsewhere
+    (other activations, OM_T5_F16=0, T5 training)."""
     from types import SimpleNamespace as NS
     from transformers import BertConfig, BertModel, T5Config, T5EncoderModel
     from openmatch_amd import native as N
@@ -351,7 +351,10 @@ def test_compute_format_resolution():
     t5 = T5EncoderModel(T5Config(d_model=64, d_ff=128, num_layers=1, num_heads=1, d_kv=64))
     assert inference_code(bert, N.OM_F16, 128) == N.OM_F16 and inference_code(bert, N.OM_F16, 256) == N.OM_F16
     assert inference_code(bert, N.OM_F16, 512) == N.OM_F16
-    assert inference_code(relu, N.OM_F16, 128) == N.OM_BF16 and inference_code(t5, N.OM_F16, 128) == N.OM_BF16
+    assert inference_code(relu, N.OM_F16, 128) == N.OM_BF16 and inference_code(t5, N.OM_F16, 128) == N.OM_F16
+    monkeypatch.setenv("OM_T5_F16", "0")
+    assert inference_code(t5, N.OM_F16, 128) == N.OM_BF16 and inference_code(bert, N.OM_F16, 128) == N.OM_F16
+    monkeypatch.delenv("OM_T5_F16")
     assert inference_code(t5, N.OM_BF16, 128) == N.OM_BF16 and inference_code(bert, N.OM_F32, 512) == N.OM_F32
     assert training_code(N.OM_F16) == N.OM_BF16 and training_code(N.OM_F32) == N.OM_F32
     # round 5: float16 training is served for BERT-family erf-GELU encoders, bfloat16 elsewhere
