@@ -332,7 +332,7 @@ def test_config1_spread_scores_mrr_and_topk_gate(golden, tmp_path, dtype):
         assert ddot <= 10.0 * r_ddot and n_bad == 0 and d_mrr < 1e-4, (ddot, detail, mrr)
 
 
-T5_F16_FACTOR = (4.0, 3.0)      # (1 - cos, max|ddot|) of the float16 T5 path over the reference's float16 autocast; measured: see the test's print
+T5_F16_FACTOR = (1.0, 1.0)      # (1 - cos, max|ddot|) of the float16 T5 path over the reference's float16 autocast; measured 0.9x x / 0.27 x (the test prints them)
 
 
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
@@ -357,7 +357,7 @@ def test_gtr_base_sized_t5_matches_reference(golden, dtype):
     h_cmin, _, h_ddot = (float(x) for x in g["ac16_vs_f32"])          # the reference's REAL 16-bit mode: float16 autocast
     print(f"\n[GTR-base, {dtype}] max|emb err| {np.abs(P - g['P_f32']).max():.2e}; min cos {cmin:.8f} (reference bf16 autocast {r_cmin:.6f}, "
           f"float16 autocast {h_cmin:.8f}); max|ddot| {ddot:.2e} ({r_ddot:.2e}, {h_ddot:.2e}); against the float16 yardstick: "
-          f"1 - cos {(1 - cmin) / (1 - h_cmin):.1f} x, max|ddot| {ddot / h_ddot:.2f} x")
+          f"1 - cos {(1 - cmin) / (1 - h_cmin):.3f} x, max|ddot| {ddot / h_ddot:.2f} x")
     if dtype == "float32":
         assert np.abs(P - g["P_f32"]).max() < 1e-4 and np.abs(Q - g["Q_f32"]).max() < 1e-4 and ddot < 1e-4
         assert 1.0 - cmin <= 1.0 * (1.0 - h_cmin) and ddot <= 1.0 * h_ddot
