@@ -125,7 +125,9 @@ void om_debug_gemm_gen(int gen);
                                     * runs and returns fp32): pre-LayerNorm sums in f32 on the tape, every LayerNorm output also unrounded for the next
                                     * residual add; 0: 16-bit residual stream as in rounds 1-4 (env OM_TRAIN_RES32; ~3 % faster, 2.4 x further from the
                                     * reference's fp32 gradients on tests/golden/train_base.npz) */
-#define OM_OPT_COUNT 19
+#define OM_OPT_GEMM_SKINNY_M 19    /* 16-bit contractions of at most this many rows run on the weight-streaming kernel (gemm_skinny.hip: one workgroup per
+                                      16 output columns, K split over its waves) instead of the 128-column tiles; env OM_GEMM_SKINNY_M, default 256, 0: off */
+#define OM_OPT_COUNT 20
 int om_debug_option(int opt, int value);
 /* the attention kernel alone (bf16 qkv [B*L, 3H] -> ctx [B*L, H]; mask [B, L] int64), for timing: csrc/kernels.h omk_attention */
 int om_debug_attention(const void* qkv, void* ctx, const int64_t* mask, int64_t B, int L, int H, int heads, void* stream);

@@ -16,7 +16,7 @@ OBJ_DIR = os.path.join(REPO, "build", "obj")
 LIB_PATH = os.path.join(CSRC, "libopenmatch_hip.so")
 ARCH = "gfx950"
 SOURCES = ["abi.cpp", "comm.cpp", "gemm.hip", "gemm_wide6_bf16.hip", "gemm_wide6_f32.hip", "gemm_wide7.hip", "gemm_wide7_ln.hip", "gemm_wide7_f16.hip", "gemm_tn.hip", "elementwise.hip", "attention.hip", "attention_bwd16.hip", "encoder.hip", "decoder.hip",
-           "search.hip", "contrastive.hip", "train_kernels.hip", "train.hip", "optim.hip"]
+           "search.hip", "contrastive.hip", "train_kernels.hip", "train.hip", "optim.hip", "gemm_skinny.hip"]
 HEADERS = ["common.h", "gemm_core.h", "gemm_core2.h", "gemm_core6.h", "gemm_core7.h", "gemm_wide7.h", "gemm_wide6.h", "gemm_epilogue.h", "gemm_epilogue6.h", "attn_common.h", "train_kernels.h", "kernels.h", os.path.join("..", "..", "include", "openmatch_hip.h")]
 
 

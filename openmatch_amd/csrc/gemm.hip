@@ -132,6 +132,9 @@ int omk_gemm_wide7_f16(const void* A, int64_t lda, const void* B, int64_t ldb, v
 int omk_gemm_wide7(bool persist, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                    int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s);
 
+bool omk_gemm_skinny_ok(int in_dtype, int out_dtype, int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep);      // gemm_skinny.hip
+int omk_gemm_skinny(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
+                    int64_t K, const GemmEpilogue& ep, hipStream_t s);
 bool omk_gemm_wide7_train_ok(int64_t M, int64_t N, int64_t K, int64_t ldc, const GemmEpilogue& ep);
 int omk_gemm_wide7_train(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                          int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s);
@@ -148,6 +151,9 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
   if ((lda * es) % 16 != 0 || (ldb * es) % 16 != 0) OM_FAIL("lda/ldb must keep rows 16-byte aligned");
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) OM_FAIL("A/B must be 16-byte aligned");
   if ((ep.act & 0xff) == OM_ACT_GELU_ERF_GRAD && !ep.resid) OM_FAIL("gelu-grad epilogue needs resid");
+  // few rows (a query, a handful of sequences): the weight-streaming kernel, N / 16 workgroups instead of N / 128
+  if (gemm_variant() == 0 && g_debug_gen == 0 && omk_gemm_skinny_ok(in_dtype, out_dtype, M, N, K, ep))
+    return omk_gemm_skinny(in_dtype, A, lda, B, ldb, C, ldc, M, N, K, ep, s);
   const bool wide = wide_ok(out_dtype, C, ldc, M, N, ep);
   // Pick the tile generation that finishes first: whole rounds of (256 CUs x resident workgroups)
   // times the tile's work over its measured relative efficiency (profiles/r01_selftest_gemm_v4.log).

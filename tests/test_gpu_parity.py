@@ -356,8 +356,9 @@ def test_encode_and_forward_return_the_same_representations(dtype, pooling):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("pooling", ["first", "mean"])
-def test_packed_rows_t5_encoder_is_bit_identical_to_padded(pooling):
-    """The packed-rows entry on the fused T5 path (GTR shape in miniature: bfloat16, RMSNorm folded into the GEMMs, the
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_packed_rows_t5_encoder_is_bit_identical_to_padded(pooling, dtype):
+    """The packed-rows entry on the fused T5 path (GTR shape in miniature: both 16-bit formats, RMSNorm folded into the GEMMs, the
     relative-position bias table read at the sequence's own positions): same bits as the padded entry."""
     from transformers import T5Config, T5EncoderModel
     from openmatch.modeling import DRModelForInference
@@ -366,7 +367,7 @@ def test_packed_rows_t5_encoder_is_bit_identical_to_padded(pooling):
     torch.manual_seed(8)
     cfg = T5Config(d_model=256, d_ff=1024, num_layers=3, num_heads=4, d_kv=64, vocab_size=600, feed_forward_proj="relu")
     lm = T5EncoderModel(cfg).eval()
-    model = DRModelForInference(lm_q=lm, lm_p=lm, pooling=pooling, model_args=NS(encoder_only=True, dtype="bfloat16")).to(DEV).eval()
+    model = DRModelForInference(lm_q=lm, lm_p=lm, pooling=pooling, model_args=NS(encoder_only=True, dtype=dtype)).to(DEV).eval()
     code = compute_dtype_code(model.model_args)
     rng = np.random.default_rng(4)
     B, L = 40, 128
@@ -1796,6 +1797,59 @@ def test_fused_adamw_matches_torch_adamw(max_norm):
     fo.step()
     assert not math.isfinite(fo.grad_norm().item())
     assert all(torch.equal(a, b) for a, b in zip(mine, before))
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_few_row_contractions_on_the_weight_streaming_kernel(dtype):
+    """gemm_skinny.hip (om_gemm_nt with M <= OM_OPT_GEMM_SKINNY_M rows, 16-bit): every epilogue the small forwards use -- bias,
+    erf-GELU / ReLU / tanh-GELU, residual added or multiplied (in place too) -- against torch in f32 on the same 16-bit operands;
+    a row's bits do not depend on how many rows ride along; switched off, the tile kernels give the same numbers."""
+    from openmatch_amd import native as N_
+    td = getattr(torch, dtype)
+    code = N_.OM_BF16 if dtype == "bfloat16" else N_.OM_F16
+    lib = N_.lib()
+    gen = torch.Generator().manual_seed(17)
+    tol = 2e-2 if dtype == "bfloat16" else 3e-3
+
+    def run(A, W, bias, resid, act, M=None, inplace=False):
+        M = A.shape[0] if M is None else M
+        C = resid.clone() if inplace else torch.empty(A.shape[0], W.shape[0], device=DEV, dtype=td)
+        r = C if inplace else resid
+        with torch.cuda.device(DEV):
+            N_.check(lib.om_gemm_nt(code, N_.ptr(A), A.shape[1], N_.ptr(W), W.shape[1], code, N_.ptr(C), W.shape[0], M, W.shape[0], A.shape[1],
+                                    N_.ptr(bias) if bias is not None else None, N_.ptr(r) if r is not None else None, W.shape[0], act,
+                                    N_.stream_ptr(torch.device(DEV))))
+        return C
+
+    acts = {N_.ACT_NONE: lambda v: v, N_.ACT_GELU_ERF: torch.nn.functional.gelu, N_.ACT_RELU: torch.relu,
+            N_.ACT_GELU_TANH: lambda v: torch.nn.functional.gelu(v, approximate="tanh")}
+    for (M, Nn, K) in [(1, 768, 768), (5, 2304, 768), (32, 3072, 768), (33, 768, 3072), (64, 256, 256), (100, 768, 1024), (256, 3072, 768)]:
+        A = (torch.randn(M, K, generator=gen) * 0.5).to(DEV, td)
+        W = (torch.randn(Nn, K, generator=gen) * 0.05).to(DEV, td)
+        bias = torch.randn(Nn, generator=gen).to(DEV)
+        resid = torch.randn(M, Nn, generator=gen).to(DEV, td)
+        base = A.float() @ W.float().t()
+        for act, fn in acts.items():
+            for mode in ("plain", "add", "mul", "inplace"):
+                if mode == "mul" and act != N_.ACT_GELU_TANH:
+                    continue
+                want = fn(base + bias)
+                if mode in ("add", "inplace"):
+                    want = want + resid.float()
+                elif mode == "mul":
+                    want = want * resid.float()
+                got = run(A, W, bias, None if mode == "plain" else resid, act | (N_.ACT_MUL_RESID if mode == "mul" else 0), inplace=mode == "inplace")
+                err = (got.float() - want).abs().max().item() / max(1.0, want.abs().max().item())
+                assert err < tol, (M, Nn, K, act, mode, err)
+        full = run(A, W, bias, resid, N_.ACT_GELU_ERF)
+        one = run(A, W, bias, resid, N_.ACT_GELU_ERF, M=1)
+        assert torch.equal(one[:1], full[:1])                      # row 0 alone == row 0 of the batch, bit for bit
+        N_.check(lib.om_debug_option(19, 0))                        # OM_OPT_GEMM_SKINNY_M = 0: the tile kernels
+        try:
+            tiles = run(A, W, bias, resid, N_.ACT_GELU_ERF)
+        finally:
+            N_.check(lib.om_debug_option(19, 256))
+        assert (tiles.float() - full.float()).abs().max().item() <= 2 * tol * max(1.0, full.float().abs().max().item())
 
 
 def test_fused_adamw_does_not_count_the_steps_the_loss_scaler_skipped():

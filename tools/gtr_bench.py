@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """GTR-base-shaped encode throughput (BASELINE config 4: T5 encoder 12 x 768, relu FFN 3072, mean pooling,
-768 -> 768 head, normalise; 128 tokens, bf16).   python tools/gtr_bench.py [--batch 1024] [--gated]"""
+768 -> 768 head, normalise; 128 tokens).   python tools/gtr_bench.py [--batch 1024] [--gated] [--dtype bfloat16|float16]"""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--gated", action="store_true")
+    ap.add_argument("--dtype", default="bfloat16")
     a = ap.parse_args()
     from transformers import T5Config, T5EncoderModel
     from openmatch.modeling import DRModelForInference, LinearHead
@@ -23,7 +24,7 @@ def main():
     lm = T5EncoderModel(cfg).eval()
     head = LinearHead(768, 768)
     model = DRModelForInference(lm_q=lm, lm_p=lm, pooling="mean", normalize=True, head_q=head, head_p=head,
-                                model_args=NS(encoder_only=True, dtype="bfloat16")).to(dev).eval()
+                                model_args=NS(encoder_only=True, dtype=a.dtype)).to(dev).eval()
     ids = torch.randint(3, 32000, (a.batch, 128), device=dev)
     items = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
     out = {}
@@ -55,7 +56,7 @@ def main():
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
             out[name] = {"passages_per_s": round(a.batch / dt, 1), "ms_per_step": round(dt * 1e3, 2)}
         out["ragged_packed"].update(rows=rows, padded_rows=a.batch * 128, identical_to_padded=same)
-    print(json.dumps({"metric": "GTR-base-shaped encode passages/s (T5 encoder, 128 tokens, bf16)", "batch": a.batch,
+    print(json.dumps({"metric": "GTR-base-shaped encode passages/s (T5 encoder, 128 tokens)", "dtype": a.dtype, "batch": a.batch,
                       "gated": a.gated, **out}))
 
 
