@@ -325,6 +325,33 @@ def train_leg(device, steps=8):
     return out
 
 
+def few_rows_leg(model, device):
+    """Latency of SMALL forwards through the product path (a served query: 1 x 32 tokens; a few sequences), ids resident in HBM: the
+    few-rows path of round 5 (gemm_skinny.hip: weight-streaming contractions, <= OM_OPT_GEMM_SKINNY_M token rows) against the tile
+    kernels (the path switched off).  Roofline of such a forward: one pass over the 16-bit weights (170 MB for bert-base)."""
+    from openmatch_amd import native as N
+    out = {"metric": "ms per forward (bert-base, representations out, ids resident in HBM)", "weights_MB": 170.3, "rows": {}}
+    for (B, L) in ((1, 32), (8, 32), (16, 32), (1, 128), (8, 128)):
+        ids = torch.randint(1000, 30000, (B, L), device=device, generator=torch.Generator(device=device).manual_seed(B * L))
+        items = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
+        row = {}
+        for name, lim in (("few_rows_path", 1024), ("tile_kernels", 0)):
+            N.check(N.lib().om_debug_option(19, lim))           # OM_OPT_GEMM_SKINNY_M
+            try:
+                for _ in range(5):
+                    model(query=items)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(30):
+                    model(query=items)
+                torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 30
+            finally:
+                N.check(N.lib().om_debug_option(19, 1024))
+            row[name + "_ms"] = round(dt * 1e3, 3)
+        row["weight_stream_TBps"] = round(170.3e6 / (row["few_rows_path_ms"] * 1e-3) / 1e12, 3)
+        out["rows"]["%dx%d" % (B, L)] = row
+    return out
+
+
 def packed_leg(model, batches, a, L):
     """The SAME timed batches through om_encoder_forward_packed: only the rows up to each sequence's last token (lengths
     ~ U{16..128}) enter the embedding, the contractions and the normalisations; attention runs per sequence.  The
@@ -575,7 +602,7 @@ def main():
         parity = parity_leg(model, lm, batches, device, headline=a.precision)
 
     # ---------------- exact-f32 mode and the training step (sub-objects; N = 1 only) ----------
-    f32_mode, train, f16_mode, packed_mode = None, None, None, None
+    f32_mode, train, f16_mode, packed_mode, few_rows = None, None, None, None, None
     other16 = "bf16" if a.precision == "f16" else "f16"
     if rank == 0 and not dist_on and not a.no_extra and half:
         # the OTHER 16-bit format on the SAME timed batches (same kernels and MFMA rate): bfloat16 carries its pre-LayerNorm
@@ -597,6 +624,7 @@ def main():
         del m16
         torch.cuda.empty_cache()
         packed_mode = packed_leg(model, batches, a, L)
+        few_rows = few_rows_leg(model, device)
         m32 = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first",
                                   model_args=NS(encoder_only=False, dtype="float32")).to(device).eval()
         sub = {k: v[:256] for k, v in batches[0].items()}
@@ -642,7 +670,7 @@ def main():
                                  {"scaling": "strong" if world > 1 else "single shard",
                                   "index_rows": [shard_range(a.index_rows, world, r)[0] for r in range(world)],
                                   "query_slices": [shard_range(a.queries, world, r)[0] for r in range(world)]})},
-            "roofline": roofline, "search": search, "parity": parity, other16: f16_mode, "packed": packed_mode, "f32": f32_mode, "train": train, "cpu_baseline": cpu,
+            "roofline": roofline, "search": search, "parity": parity, other16: f16_mode, "packed": packed_mode, "few_rows": few_rows, "f32": f32_mode, "train": train, "cpu_baseline": cpu,
         }
         print(json.dumps(line), file=json_out, flush=True)
     if dist_on:

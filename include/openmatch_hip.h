@@ -126,8 +126,10 @@ void om_debug_gemm_gen(int gen);
                                     * residual add; 0: 16-bit residual stream as in rounds 1-4 (env OM_TRAIN_RES32; ~3 % faster, 2.4 x further from the
                                     * reference's fp32 gradients on tests/golden/train_base.npz) */
 #define OM_OPT_GEMM_SKINNY_M 19    /* 16-bit contractions of at most this many rows run on the weight-streaming kernel (gemm_skinny.hip: one workgroup per
-                                      16 output columns, K split over its waves) instead of the 128-column tiles; env OM_GEMM_SKINNY_M, default 256, 0: off */
-#define OM_OPT_COUNT 20
+                                      16 output columns, K split over its waves) instead of the 128- / 256-column tiles, and the encoder forward takes its unfused path
+                                      (normalisations as kernels) up to that many token rows; env OM_GEMM_SKINNY_M, default 1024, 0: off */
+#define OM_OPT_GEMM_SKINNY_CFG 20  /* A/B: 0 (default) the kernel's own choice; MT * 10000 + NT * 100 + NW pins the tiles per wave and the K split (gemm_skinny.hip) */
+#define OM_OPT_COUNT 21
 int om_debug_option(int opt, int value);
 /* the attention kernel alone (bf16 qkv [B*L, 3H] -> ctx [B*L, H]; mask [B, L] int64), for timing: csrc/kernels.h omk_attention */
 int om_debug_attention(const void* qkv, void* ctx, const int64_t* mask, int64_t B, int L, int H, int heads, void* stream);

@@ -113,7 +113,7 @@ void opt_init() {
   e = getenv("OM_GEMM_CONT");
   g_opt[OM_OPT_GEMM_CONT] = e ? atoi(e) : 111;
   e = getenv("OM_GEMM_SKINNY_M");
-  g_opt[OM_OPT_GEMM_SKINNY_M] = e ? atoi(e) : 256;
+  g_opt[OM_OPT_GEMM_SKINNY_M] = e ? atoi(e) : 1024;
   g_opt_init.store(true);
 }
 }  // namespace

@@ -169,6 +169,7 @@ extern "C" size_t om_encoder_workspace_bytes(const OmEncoderConfig* cfg, int64_t
 extern "C" int om_encoder_packed_supported(const OmEncoderConfig* c, int gated_ffn, int64_t B, int64_t L, int64_t packed_rows) {
   if (!c || B <= 0 || L <= 0 || L > 256 || packed_rows <= 0) return 0;
   if (packed_rows % 256 || packed_rows < 512 || packed_rows > B * L + 255) return 0;
+  if (packed_rows <= (int64_t)om_option(OM_OPT_GEMM_SKINNY_M)) return 0;      // few rows: the padded entry (its contractions take the weight-streaming kernel)
   const int dt = c->dtype;
   if (dt != OM_BF16 && dt != OM_F16) return 0;
   if (dt == OM_BF16 && !om_option(OM_OPT_ATTENTION_FAST)) return 0;
@@ -241,7 +242,14 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
   const int dt = c->dtype, H = c->hidden, F = c->ffn, nh = c->n_heads;
   const int64_t M = packed ? packed_rows : B * L;
   const int* const cu = packed ? ws.cu : nullptr;
-  const int64_t Mg = ws.Mp;          // rows of the contractions (M padded to whole tiles for large 16-bit batches)
+  // Few rows (a served query, a handful of sequences; round 5): up to OM_OPT_GEMM_SKINNY_M rows the contractions run on the
+  // weight-streaming kernel (gemm_skinny.hip) with the normalisations as kernels -- the persistent 256 x 256 tiles of the fused path
+  // put 6 ... 24 workgroups on 256 CUs there and take ~150 us per layer whatever the batch (profiles/r05_small_forward_*.txt).
+  // (bfloat16 BERT from 512 rows on stays on the fused path: its two-plane residual stream is what holds bfloat16 inside the
+  // reference's own autocast deviation, and the unfused path keeps one plane)
+  const bool few_rows = !packed && dt != OM_F32 && M <= (int64_t)om_option(OM_OPT_GEMM_SKINNY_M) &&
+                        !(dt == OM_BF16 && c->arch == OM_ARCH_BERT && M >= 512 && om_option(OM_OPT_ENCODER_TWO_PLANE) != 0);
+  const int64_t Mg = few_rows ? M : ws.Mp;          // rows of the contractions (M padded to whole tiles for large 16-bit batches)
   const bool bert = c->arch == OM_ARCH_BERT;
   const OmLayerWeights* Ls = w->layers_host;
   if (!Ls) OM_FAIL("layers_host is null");
@@ -271,7 +279,7 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
     // (kernels.h: GemmEpilogue::ln_*, rln_*, stats_out).  23 of the 25 LayerNorm passes over
     // [M,H] disappear (the embedding LayerNorm and the last one stay).
     const bool no_fuse = om_option(OM_OPT_ENCODER_FUSED_LN) == 0;   // A/B switch (om_debug_option)
-    const bool fuse = !no_fuse && c->act == OM_ACT_GELU_ERF && c->n_layers > 0 && H % 8 == 0 &&
+    const bool fuse = !no_fuse && !few_rows && c->act == OM_ACT_GELU_ERF && c->n_layers > 0 && H % 8 == 0 &&
                       omk_gemm_ln_fusable(dt, Mg, H, H) && omk_gemm_ln_fusable(dt, Mg, F, H) &&
                       omk_gemm_ln_fusable(dt, Mg, 3 * H, H) && omk_gemm_ln_fusable(dt, Mg, H, F);
     if (om_option(OM_OPT_ENCODER_DEBUG)) fprintf(stderr, "om_encoder_forward: M=%ld fused_ln=%d packed=%d\n", (long)M, (int)fuse, (int)packed);
@@ -407,7 +415,7 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
     // rsqrt(mean(x^2) + eps) in the epilogue.  Only the first and the final norm run as kernels.
     const bool no_fuse_t5 = om_option(OM_OPT_ENCODER_FUSED_LN) == 0;
     // (gated feed-forward layers keep the kernels: two folded GEMMs per norm measured 1 % slower, tools/gtr_bench.py)
-    const bool fuse_t5 = !no_fuse_t5 && c->n_layers > 0 && !Ls[0].ffn1g_w && H % 8 == 0 && omk_gemm_ln_fusable(dt, Mg, H, H) &&
+    const bool fuse_t5 = !no_fuse_t5 && !few_rows && c->n_layers > 0 && !Ls[0].ffn1g_w && H % 8 == 0 && omk_gemm_ln_fusable(dt, Mg, H, H) &&
                          omk_gemm_ln_fusable(dt, Mg, F, H) && omk_gemm_ln_fusable(dt, Mg, 3 * H, H) &&
                          omk_gemm_ln_fusable(dt, Mg, H, F);
     if (om_option(OM_OPT_ENCODER_DEBUG)) fprintf(stderr, "om_encoder_forward (t5): M=%ld fused_norm=%d packed=%d\n", (long)M, (int)fuse_t5, (int)packed);

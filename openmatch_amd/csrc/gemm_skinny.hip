@@ -6,18 +6,19 @@
 // [768 x 3072] weight is read by SIX workgroups, 786 KB each, one K step after another: ~20 us per launch whatever the batch,
 // x 84 launches = the 1.9 ms floor under every small forward (docs/history.md: "a captured graph changes nothing: the floor is
 // the GPU-side chain").  The operation is a weight STREAM: 2 K N bytes once from HBM, M x that in flops, nothing to reuse.
-// So: one workgroup per 16 output columns (N / 16 workgroups: 48 ... 192 on 256 CUs), its four waves split K four ways, every
-// lane loads its MFMA fragment straight from global memory (16 bytes per lane: W row n0 + lane % 16, 8 consecutive k) -- no LDS
-// staging, up to SK_UNR steps of loads in flight per wave before the first MFMA -- and the four partial tiles meet in LDS in a
-// fixed order.  A row's result does not depend on M or on the rows beside it.
+// So: workgroups of MT x NT output tiles of 16 x 16 (about one workgroup per CU: 48 ... 192 of them where the tile kernels had
+// 6 ... 24), their 4 or 8 waves split K, every lane loads its MFMA fragments straight from global memory (16 bytes per lane:
+// row l % 16, 8 consecutive k) -- no LDS staging, up to 12 K steps of loads in flight per wave before the first MFMA -- and the
+// partial tiles meet in LDS in a fixed order.  A row's result does not depend on M or on the rows beside it.
+// Measured (profiles/r05_skinny_sweep_*.txt, kernel durations): 3.1 - 8 us per launch up to 64 rows, 5.7 - 14 us at 256, 7.6 - 21 us
+// at 512, where the tile kernels take 18 - 56 us whatever the row count; past ~1 000 rows the re-reads of A (N / (16 NT) times,
+// from L2) cost more than the tiles' idle CUs and the tile kernels take over (OM_OPT_GEMM_SKINNY_M).
 //
 // Roofline: HBM; algorithmic bytes per launch = 2 N K (the weight) + 2 M (K + N) (activations in, out).
 #include "kernels.h"
 #include "gemm_epilogue.h"
 
 namespace {
-constexpr int SK_THREADS = 256;
-constexpr int SK_UNR = 8;          // K steps (32 elements each) a wave has in flight
 typedef uint32_t sk_u32x4_t __attribute__((ext_vector_type(4)));
 
 template <typename T> struct SkMma;
@@ -41,18 +42,23 @@ __device__ __forceinline__ float sk_act(float v, int act) {
   return v;
 }
 
-// grid (N / 16, ceil(M / (16 MT))); MFMA operand 1 = 16 rows of A, operand 2 = 16 rows of W (the output columns):
-// lane l holds k = 8 (l >> 4) .. + 7 of row l & 15 of either; D[row 4 (l >> 4) + i][column l & 15].
-template <typename T, int MT>
-__global__ __launch_bounds__(SK_THREADS) void gemm_nt_skinny_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ W, int64_t ldw,
-                                                                   T* C, int64_t ldc, int M, int N, int K, const float* __restrict__ bias,
-                                                                   const T* resid, int64_t ldr, int act, int mul) {
-  __shared__ float red[4][MT][4][64];
+// grid (N / (16 NT), ceil(M / (16 MT))), NW waves that split K; MFMA operand 1 = 16 rows of A, operand 2 = 16 rows of W (the output
+// columns): lane l holds k = 8 (l >> 4) .. + 7 of row l & 15 of either; D[row 4 (l >> 4) + i][column l & 15].
+// MT x NT tiles per wave: (MT + NT) loads feed MT NT MFMAs per K step -- NT > 1 cuts the re-reads of A (every workgroup of a row
+// block reads all of A's K slice: N / (16 NT) times per launch, from L2), NW sets the length of a wave's dependent load chain.
+template <typename T, int MT, int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ W, int64_t ldw,
+                                                                T* C, int64_t ldc, int M, int N, int K, const float* __restrict__ bias,
+                                                                const T* resid, int64_t ldr, int act, int mul) {
+  constexpr int UNR = (MT + NT) <= 3 ? 12 : ((MT + NT) <= 5 ? 8 : 4);      // K steps in flight per wave: (MT + NT) UNR x 4 VGPRs
+  __shared__ float red[NW][MT * NT][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, kg = lane >> 4;
-  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * MT);
-  const int ksl = K >> 2;                                   // this wave's K slice
-  const T* wp = W + (int64_t)(n0 + r) * ldw + wave * ksl + kg * 8;
+  const int n0 = blockIdx.x * (16 * NT), m0 = blockIdx.y * (16 * MT);
+  const int ksl = K / NW;                                   // this wave's K slice
+  const T* wp[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wp[t] = W + (int64_t)(n0 + 16 * t + r) * ldw + wave * ksl + kg * 8;
   const T* ap[MT];
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
@@ -60,40 +66,47 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_nt_skinny_kernel(const T* __r
     m = m < M ? m : M - 1;                                  // rows past M: computed from a valid row, never stored
     ap[j] = A + (int64_t)m * lda + wave * ksl + kg * 8;
   }
-  f32x4_t acc[MT];
+  f32x4_t acc[MT][NT];
 #pragma unroll
-  for (int j = 0; j < MT; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < MT; ++j)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[j][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int steps = ksl >> 5;
-  for (int s0 = 0; s0 < steps; s0 += SK_UNR) {
-    sk_u32x4_t wq[SK_UNR], aq[MT][SK_UNR];
+  for (int s0 = 0; s0 < steps; s0 += UNR) {
+    sk_u32x4_t wq[NT][UNR], aq[MT][UNR];
 #pragma unroll
-    for (int u = 0; u < SK_UNR; ++u)
+    for (int u = 0; u < UNR; ++u)
       if (s0 + u < steps) {
-        wq[u] = __builtin_nontemporal_load((const sk_u32x4_t*)(wp + (s0 + u) * 32));      // the weight passes once
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wq[t][u] = __builtin_nontemporal_load((const sk_u32x4_t*)(wp[t] + (s0 + u) * 32));      // the weight passes once
 #pragma unroll
         for (int j = 0; j < MT; ++j) aq[j][u] = *(const sk_u32x4_t*)(ap[j] + (s0 + u) * 32);
       }
 #pragma unroll
-    for (int u = 0; u < SK_UNR; ++u)
+    for (int u = 0; u < UNR; ++u)
       if (s0 + u < steps) {
 #pragma unroll
-        for (int j = 0; j < MT; ++j) acc[j] = SkMma<T>::mma(aq[j][u], wq[u], acc[j]);
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[j][t] = SkMma<T>::mma(aq[j][u], wq[t][u], acc[j][t]);
       }
   }
 #pragma unroll
   for (int j = 0; j < MT; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) red[wave][j][i][lane] = acc[j][i];
-  __syncthreads();
-  const int i = wave;                                        // each wave finishes one accumulator register of every tile
-  const int n = n0 + r;
-  const float b = bias ? bias[n] : 0.f;
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-  for (int j = 0; j < MT; ++j) {
-    const int m = m0 + 16 * j + 4 * kg + i;
+      for (int i = 0; i < 4; ++i) red[wave][j * NT + t][i][lane] = acc[j][t][i];
+  __syncthreads();
+  // MT NT 4 accumulator registers x 64 lanes to finish, one (tile, register) per wave at a time; partials added in wave order
+  for (int q = wave; q < MT * NT * 4; q += NW) {
+    const int tile = q >> 2, i = q & 3, j = tile / NT, t = tile % NT;
+    const int m = m0 + 16 * j + 4 * kg + i, n = n0 + 16 * t + r;
     if (m >= M) continue;
-    float v = ((red[0][j][i][lane] + red[1][j][i][lane]) + red[2][j][i][lane]) + red[3][j][i][lane];
-    v = sk_act(v + b, act);
+    float v = red[0][tile][i][lane];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += red[w][tile][i][lane];
+    v = sk_act(v + (bias ? bias[n] : 0.f), act);
     if (resid) {
       const float rv = ElemOps<T>::load(resid + (int64_t)m * ldr + n);      // may alias C: read and written by this lane only
       v = mul ? v * rv : v + rv;
@@ -102,20 +115,40 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_nt_skinny_kernel(const T* __r
   }
 }
 
+// (MT, NT, NW) per shape, from the sweep over the four contractions of a bert-base layer at 16 ... 1024 rows
+// (profiles/r05_skinny_sweep_*.txt): about one workgroup per CU -- the 16 x 16 output tiles of the problem over 256, as tiles per
+// workgroup (rows first: a second row tile re-uses the weight fragment, a second column tile the activation fragment).
+struct SkCfg { int mt, nt, nw; };
+static SkCfg sk_choose(int64_t M, int64_t N, int64_t K) {
+  const int forced = om_option(OM_OPT_GEMM_SKINNY_CFG);            // A/B: MT * 10000 + NT * 100 + NW
+  if (forced > 0) return SkCfg{forced / 10000, forced / 100 % 100, forced % 100};
+  const int64_t rt = (M + 15) / 16, tiles = rt * (N / 16);
+  int p = 1;
+  while (p < 8 && tiles > 256 * p) p <<= 1;
+  SkCfg c{1, 1, 4};
+  if (p >= 2) { if (rt >= 2) c.mt = 2; else c.nt = 2; }
+  if (p >= 4) { if (c.nt == 1 && N % 32 == 0) c.nt = 2; else if (rt >= 4) c.mt = 4; }
+  if (p >= 8) { if (rt >= 4 && c.mt < 4) c.mt = 4; else if (N % 64 == 0) c.nt = 4; }
+  while (c.nt > 1 && N % (16 * c.nt)) c.nt >>= 1;
+  // The K split is a function of (N, K) ONLY: the order in which a row's products are added then does not depend on the rows
+  // that ride along -- a query encoded alone and in a batch gives the same bits.  Eight slices where N is narrow (few workgroups,
+  // long K chains: out-proj, FFN2), four where N is wide (within 15 % of the best split at every row count of the sweep).
+  c.nw = (K % 256 == 0 && N <= 1024) ? 8 : 4;
+  return c;
+}
+
 template <typename T>
 int launch_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                   const GemmEpilogue& ep, hipStream_t s) {
   const int act = ep.act & 0xff, mul = (ep.act & OM_ACT_MUL_RESID) ? 1 : 0;
-#define SK_GO(MT_)                                                                                                          \
-  hipLaunchKernelGGL((gemm_nt_skinny_kernel<T, MT_>), dim3((unsigned)(N / 16), (unsigned)((M + 16 * MT_ - 1) / (16 * MT_))), \
-                     dim3(SK_THREADS), 0, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, (int)M, (int)N, (int)K, ep.bias, \
-                     (const T*)ep.resid, ep.ldr, act, mul)
-  if (M <= 16) SK_GO(1);
-  else if (M <= 32) SK_GO(2);
-  else SK_GO(4);
+  const SkCfg c = sk_choose(M, N, K);
+  if (N % (16 * c.nt) || K % (32 * c.nw)) OM_FAIL("gemm_skinny: (NT, NW) does not divide the problem");
+#define SK_GO(MT_, NT_, NW_)                                                                                                           if (c.mt == MT_ && c.nt == NT_ && c.nw == NW_) {                                                                                       hipLaunchKernelGGL((gemm_nt_skinny_kernel<T, MT_, NT_, NW_>), dim3((unsigned)(N / (16 * NT_)), (unsigned)((M + 16 * MT_ - 1) / (16 * MT_))),                        dim3(64 * NW_), 0, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, (int)M, (int)N, (int)K, ep.bias,                                (const T*)ep.resid, ep.ldr, act, mul);                                                                            OM_LAUNCH_CHECK();                                                                                                                   return 0;                                                                                                                          }
+  SK_GO(1, 1, 4) SK_GO(1, 1, 8) SK_GO(1, 2, 4) SK_GO(1, 2, 8) SK_GO(1, 4, 4) SK_GO(1, 4, 8)
+  SK_GO(2, 1, 4) SK_GO(2, 1, 8) SK_GO(2, 2, 4) SK_GO(2, 2, 8) SK_GO(2, 4, 4) SK_GO(2, 4, 8)
+  SK_GO(4, 1, 4) SK_GO(4, 1, 8) SK_GO(4, 2, 4) SK_GO(4, 2, 8) SK_GO(4, 4, 4)
 #undef SK_GO
-  OM_LAUNCH_CHECK();
-  return 0;
+  OM_FAIL("gemm_skinny: no kernel for this (MT, NT, NW)");
 }
 }  // namespace
 
@@ -124,7 +157,7 @@ bool omk_gemm_skinny_ok(int in_dtype, int out_dtype, int64_t M, int64_t N, int64
   const int max_m = om_option(OM_OPT_GEMM_SKINNY_M);
   if (max_m <= 0 || M > max_m || M < 1) return false;
   if (in_dtype != out_dtype || (in_dtype != OM_BF16 && in_dtype != OM_F16)) return false;
-  if (N % 16 || K % 128 || N > (int64_t)65535 * 16) return false;
+  if (N % 16 || K % 128 || N > (int64_t)65535 * 16 || M > (int64_t)65535 * 16) return false;
   const int act = ep.act & 0xff;
   if (act != OM_ACT_NONE && act != OM_ACT_GELU_ERF && act != OM_ACT_RELU && act != OM_ACT_GELU_TANH) return false;
   if (ep.pre_act || ep.drop_p > 0.f || ep.ln_stats || ep.rln_stats || ep.stats_out || ep.resid_lo || ep.out_lo) return false;

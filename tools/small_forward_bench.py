@@ -13,6 +13,8 @@ def main():
     ap.add_argument("--dtype", default="float16")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--limits", default="0,64,256,1024,4096")
+    ap.add_argument("--fused", type=int, default=1, help="OM_OPT_ENCODER_FUSED_LN")
+    ap.add_argument("--shapes", default="1x32,4x32,16x32,64x32,1x128,8x128,16x128,32x128")
     a = ap.parse_args()
     from transformers import BertConfig, BertModel
     from openmatch.modeling import DRModelForInference
@@ -20,8 +22,9 @@ def main():
     torch.manual_seed(0)
     lm = BertModel(BertConfig()).eval()
     model = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype=a.dtype)).to(dev).eval()
-    shapes = [(1, 32), (4, 32), (16, 32), (64, 32), (1, 128), (8, 128), (16, 128), (32, 128)]
-    out = {"metric": "ms per forward (bert-base, ids resident in HBM, representations out)", "dtype": a.dtype, "rows": {}}
+    shapes = [tuple(int(v) for v in x.split("x")) for x in a.shapes.split(",")]
+    N.check(N.lib().om_debug_option(0, a.fused))
+    out = {"metric": "ms per forward (bert-base, ids resident in HBM, representations out)", "dtype": a.dtype, "fused_ln": a.fused, "rows": {}}
     ref = {}
     for lim in [int(x) for x in a.limits.split(",")]:
         N.check(N.lib().om_debug_option(19, lim))
@@ -35,7 +38,7 @@ def main():
                 reps = model(query=items).q_reps
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.iters
             out["rows"].setdefault(f"{B}x{L}", {})[str(lim)] = round(dt * 1e3, 3)
-    N.check(N.lib().om_debug_option(19, 256))
+    N.check(N.lib().om_debug_option(19, 1024)); N.check(N.lib().om_debug_option(0, 1))
     print(json.dumps(out))
 
 
