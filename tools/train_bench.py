@@ -45,7 +45,12 @@ def main():
         trainer.optimizer = torch.optim.AdamW(model.parameters(), lr=5e-6, weight_decay=0.0, fused=True)
     else:
         trainer.create_optimizer_and_scheduler(num_training_steps=10 ** 6)
+    nap = float(os.environ.get("TRAIN_BENCH_HOST_SLEEP_US", "0")) * 1e-6      # probe: does the host have slack? (a busy wait per step)
     def step():
+        if nap > 0:
+            t_end = time.perf_counter() + nap
+            while time.perf_counter() < t_end:
+                pass
         loss = trainer.training_step(model, batch)
         trainer.optimizer_step()
         return loss
