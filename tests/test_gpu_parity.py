@@ -1989,11 +1989,12 @@ def test_optimizer_step_refreshes_the_packed_weights(golden, dtype):
             assert torch.equal(buf.view(3 * H, -1), want)
 
 
-def test_float16_training_step_tracks_f32_and_scaler_skips_overflow(golden, tmp_path):
+def test_float16_training_step_tracks_f32_and_scaler_skips_overflow(golden, tmp_path, monkeypatch):
     """float16 training (round 5): (1) the float16 kernels' gradients on the tiny fixture against the reference's fp32 gradients --
     direction and size per tensor, closer than the bfloat16 path's; dropout runs; (2) DRTrainer --fp16: the dynamic loss scale on
     the device -- an absurd initial scale overflows float16, those steps are skipped (parameters untouched) and the scale halves
     until the step goes through, then the loss falls as in the other formats."""
+    monkeypatch.delenv("OM_TRAIN_F16", raising=False)          # the A/B switch that sends float16 training to the bfloat16 kernels
     from openmatch.trainer import DRTrainer
     from openmatch_amd import native as N
     g = golden("train_bert_tiny")

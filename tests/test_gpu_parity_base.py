@@ -503,11 +503,12 @@ TRAIN_BF16_TIGHT_FACTOR = {1: 3.0, 0: 5.0}      # measured 2.59 (median 1.11) / 
 
 
 @pytest.mark.gpu
-def test_training_step_float16_at_bert_base_width_inside_reference_float16_autocast_envelope(golden):
+def test_training_step_float16_at_bert_base_width_inside_reference_float16_autocast_envelope(golden, monkeypatch):
     """float16 TRAINING (round 5; the reference's documented mode: `--fp16` in docs/dr-msmarco-passage.md:74 = HF Trainer's
     torch.cuda.amp autocast + GradScaler, trainer/dense_trainer.py:141-149): the float16 kernels with a loss scale of 4096 (what the
     fixture's reference run used), per gradient tensor against the reference's own float16-autocast deviation from its fp32
     gradients -- whole-forward autocast at factor 1.0, the tight encoder-only yardstick printed and bounded."""
+    monkeypatch.delenv("OM_TRAIN_F16", raising=False)          # the A/B switch that sends float16 training to the bfloat16 kernels
     g = golden("train_base")
     loss, grads = _train_base_step(g, "float16", loss_scale=4096.0)
     assert abs(loss - float(g["loss_f32"])) <= max(abs(float(g["loss_ac16"]) - float(g["loss_f32"])), 1e-3)
