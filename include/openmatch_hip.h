@@ -96,7 +96,9 @@ void om_debug_gemm_gen(int gen);
                                     * chain (neither fills the GPU alone at training batch sizes); bit 1 (round 5, A/B, off): the weight transposes the
                                     * backward needs are launched by the training FORWARD on that stream -- measured 3 % SLOWER (the memory-bound transposes
                                     * take more from the forward's contractions than the 170 us they save: profiles/r05_train_ab_v2_*.jsonl);
-                                    * 0: everything on the caller's stream */
+                                    * bit 2 (A/B): the LayerNorm backward adds its d_gamma / d_beta sums with atomics, as before round 5 (default:
+                                    * per-block partial sums + one reduce per layer group, a fixed order); bit 3 (A/B): that kernel without the
+                                    * prefetch of the next row; bits 1-3 clear and bit 0 clear: everything on the caller's stream */
 #define OM_OPT_ATTENTION_DEBUG 9  /* 0 (default); timing experiments on the bf16 attention kernel at L in (64, 128]: bit 0 no K / V fetch,
                                    * bit 1 no arithmetic, bit 2 no stores (results are garbage) */
 #define OM_OPT_ENCODER_PINGPONG 10 /* 1 (default): the fused bf16 encoder's kernels alternate their walk direction over the token rows so

@@ -95,6 +95,10 @@ struct Ws {
   // | [M,3H] (QKV): 127 MB per bert-base layer at 9 216 tokens, 1.5 GB per backward of 288 GB
   char* keep;
   size_t skeep;                     // bytes per layer (0: not available for this configuration)
+  // BERT: the LayerNorm backward's per-block column sums of d_gamma / d_beta, one area per site (2 per layer), added up by
+  // omk_ln_param_reduce when the layer group's gradients are published (round 5: no same-address atomics, a fixed order)
+  float* lnpart;
+  size_t slnpart;                   // floats per site
   size_t total;
 };
 inline bool keep_ok(const Dims& d) { return !d.t5 && d.es == 2 && d.H % 256 == 0 && d.F % 256 == 0 && d.M >= 32; }
@@ -122,6 +126,8 @@ Ws carve_ws(const Dims& d, char* base) {
   w.lut = (int*)take(d.t5 ? (size_t)(2 * d.L) * 4 : 0);
   w.skeep = keep_ok(d) ? align_up(5 * mh + mf, 256) : 0;
   w.keep = take(w.skeep * d.nl);
+  w.slnpart = d.t5 ? 0 : (size_t)OM_LNB_MAX_BLOCKS * 2 * d.H;
+  w.lnpart = (float*)take(w.slnpart * 4 * 2 * d.nl);
   w.total = off;
   return w;
 }
@@ -653,6 +659,8 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
                   omk_gemm_tn_batch_ok(dt, M, H, H, H, H) && omk_gemm_tn_batch_ok(dt, M, 3 * H, H, 3 * H, H)))
     wbatch = 0;
   std::vector<OmTnProblem> pend;
+  const bool ln_atomics = (om_option(OM_OPT_TRAIN_WGRAD_STREAM) & 4) != 0;      // A/B: the LayerNorm parameter sums by atomics, as before round 5
+  std::vector<OmLnSite> ln_pend;                                    // LayerNorm sites whose parameter sums wait for the group's reduce
   int group_top = d.nl - 1;                                         // highest layer of the group being collected
   const size_t mh_b = (size_t)M * H * d.es, mf_b = (size_t)M * F * d.es;
 #define WGRAD(I_, dY_, N_, X_, K_, dW_, db_)                                                        \
@@ -707,8 +715,12 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
     // LN2 backward: dy2 = d(loss)/d(y2)
     // (+ the FFN output branch's dropout, which sits after the dense and before the residual add, in the same pass)
     WGRAD_DONE(l + 1, 2);                                           // ws.dy / ws.dd: last read by dWo of the layer above
-    RUN(omk_ln_bwd_drop(dt, dx, y2, lw.ln2_g, dy2, dd2, hidden_dropout, site_seed(seed, l, 4), lg.ln2_g, lg.ln2_b, M, H, c->ln_eps, s,
-                        l == d.nl - 1 ? dpool32 : nullptr, d.res32 ? (const float*)y2 : nullptr));
+    {
+      OmLnSite st = {ln_atomics ? nullptr : ws.lnpart + ws.slnpart * (2 * l + 1), lg.ln2_g, lg.ln2_b, 0};
+      RUN(omk_ln_bwd_drop(dt, dx, y2, lw.ln2_g, dy2, dd2, hidden_dropout, site_seed(seed, l, 4), lg.ln2_g, lg.ln2_b, M, H, c->ln_eps, s,
+                          l == d.nl - 1 ? dpool32 : nullptr, d.res32 ? (const float*)y2 : nullptr, (float*)st.partial, &st.blocks));
+      if (st.partial) ln_pend.push_back(st);
+    }
     const char* dO = hidden_dropout > 0.f ? dd2 : dy2;
     WGRAD(0, dO, H, gl, F, lg.ffn2_w, lg.ffn2_b);                   // dW2 [H,F], db2
     {
@@ -726,8 +738,12 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
     }
     // LN1 backward (ws.dctx holds d/d(x1) for now)
     WGRAD_DONE(l, 0);                                               // ws.dy / ws.dd: read by dW2 of this layer
-    RUN(omk_ln_bwd_drop(dt, ws.dctx, y1, lw.ln1_g, dy1, dd1, hidden_dropout, site_seed(seed, l, 3), lg.ln1_g, lg.ln1_b, M, H, c->ln_eps, s,
-                        nullptr, d.res32 ? (const float*)y1 : nullptr));
+    {
+      OmLnSite st = {ln_atomics ? nullptr : ws.lnpart + ws.slnpart * (2 * l), lg.ln1_g, lg.ln1_b, 0};
+      RUN(omk_ln_bwd_drop(dt, ws.dctx, y1, lw.ln1_g, dy1, dd1, hidden_dropout, site_seed(seed, l, 3), lg.ln1_g, lg.ln1_b, M, H, c->ln_eps, s,
+                          nullptr, d.res32 ? (const float*)y1 : nullptr, (float*)st.partial, &st.blocks));
+      if (st.partial) ln_pend.push_back(st);
+    }
     const char* dA = hidden_dropout > 0.f ? dd1 : dy1;
     WGRAD(2, dA, H, ctx, H, lg.o_w, lg.o_b);                        // dWo [H,H], dbo
     {
@@ -756,18 +772,25 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
         }
         RUN(omk_gemm_tn_batch(dt, pend.data(), (int)pend.size(), M, ws_stream));
         pend.clear();
+        RUN(omk_ln_param_reduce(ln_pend.data(), (int)ln_pend.size(), H, ws_stream));      // the group's LayerNorm parameter gradients
+        ln_pend.clear();
         for (int ll = group_top; ll >= l; --ll) RUN(record_layer_event(ll, ws_stream));
         if (lane && l == 0) OM_HIP(hipEventRecord(lane->done[3], lane->side));       // the join below waits for it
         group_top = l - 1;
       }
     } else if (lane && g_bwd_events) {                              // the layer's gradients are complete when BOTH streams got here
+      RUN(omk_ln_param_reduce(ln_pend.data(), (int)ln_pend.size(), H, s));
+      ln_pend.clear();
       OM_HIP(hipEventRecord(lane->mark[l], s));
       OM_HIP(hipStreamWaitEvent(lane->side, lane->mark[l], 0));
       RUN(record_layer_event(l, lane->side));
     } else {
+      RUN(omk_ln_param_reduce(ln_pend.data(), (int)ln_pend.size(), H, s));
+      ln_pend.clear();
       RUN(record_layer_event(l, s));
     }
   }
+  if (!ln_pend.empty()) OM_FAIL("internal: LayerNorm parameter sums left unreduced");
   if (lane) OM_HIP(hipStreamWaitEvent(s, lane->done[3], 0));        // join: the side stream is in order, layer 0's dWqkv is its last launch
   // ---- embeddings: dropout bwd -> LayerNorm bwd -> scatter into the three tables -------------
   const char* de = dx;

@@ -14,7 +14,15 @@ int omk_ln_bwd(int dtype, const void* dy, const void* x, const float* g, void* d
 int omk_ln_bwd_drop(int dtype, const void* dy, const void* x, const float* g, void* dx, void* dx_drop, float drop_p,
                     uint64_t drop_seed, float* dg, float* db, int64_t M, int H, float eps, hipStream_t s,
                     const float* dy32 = nullptr /* the incoming gradient as f32 [M,H] instead of dy */,
-                    const float* x32 = nullptr /* the normalisation's input as f32 [M,H] instead of x */);
+                    const float* x32 = nullptr /* the normalisation's input as f32 [M,H] instead of x */,
+                    float* partial = nullptr /* [OM_LNB_MAX_BLOCKS][2][H] f32: the blocks' column sums of d_gamma / d_beta go here (plain
+                                                stores) instead of into dg / db (atomics); omk_ln_param_reduce adds them up */,
+                    int* partial_blocks = nullptr /* out: how many blocks wrote */);
+// the second half of that: dg[c] += sum_b partial[b][0][c], db likewise, for n sites in one launch, in a fixed order
+#define OM_LNB_MAX_BLOCKS 512
+#define OM_LN_SITES_MAX 32
+struct OmLnSite { const float* partial; float* dg; float* db; int blocks; };
+int omk_ln_param_reduce(const OmLnSite* sites, int n, int H, hipStream_t s);
 // LayerNorm (rms = 0) or T5 RMSNorm (rms = 1) backward; `add` (optional, same shape) is added to dx
 int omk_norm_bwd(int dtype, const void* dy, const void* x, const float* g, void* dx, float* dg,
                  float* db, int64_t M, int H, float eps, int rms, const void* add, hipStream_t s);

@@ -147,16 +147,18 @@ int omk_dropout(int dtype, const void* x, void* y, int64_t n, float p, uint64_t 
 }
 
 // four consecutive elements as one 8-byte (bf16) / 16-byte (f32) access: p must be that aligned
-template <typename T> __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
-template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float (&v)[4]) {
-  const uint2 w = *(const uint2*)p;
+template <typename T> __device__ __forceinline__ void unpack4(const uint2& w, float (&v)[4]);      // four 16-bit values of a loaded dword pair
+template <> __device__ __forceinline__ void unpack4<bf16_t>(const uint2& w, float (&v)[4]) {
   v[0] = __uint_as_float(w.x << 16); v[1] = __uint_as_float(w.x & 0xffff0000u);
   v[2] = __uint_as_float(w.y << 16); v[3] = __uint_as_float(w.y & 0xffff0000u);
 }
-template <> __device__ __forceinline__ void load4<f16_t>(const f16_t* p, float (&v)[4]) {
-  const uint2 w = *(const uint2*)p;
+template <> __device__ __forceinline__ void unpack4<f16_t>(const uint2& w, float (&v)[4]) {
   v[0] = Half16<f16_t>::lo(w.x); v[1] = Half16<f16_t>::hi(w.x); v[2] = Half16<f16_t>::lo(w.y); v[3] = Half16<f16_t>::hi(w.y);
 }
+template <> __device__ __forceinline__ void unpack4<float>(const uint2&, float (&)[4]) {}          // (never used: PF is a 16-bit path)
+template <typename T> __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float (&v)[4]) { unpack4<bf16_t>(*(const uint2*)p, v); }
+template <> __device__ __forceinline__ void load4<f16_t>(const f16_t* p, float (&v)[4]) { unpack4<f16_t>(*(const uint2*)p, v); }
 template <> __device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
   const float4 w = *(const float4*)p;
   v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w;
@@ -185,15 +187,21 @@ template <> __device__ __forceinline__ void store4<float>(float* p, const float 
 // d_beta, and 1024 blocks adding into the same 96 cache lines serialised at the memory side (41 us per call at
 // 9216 x 768, profiles/r02_train_kernel_stats_v3.csv) -- the block count, not the bytes, set the time.
 // (Four waves for hidden sizes above 1024: the wider per-lane state needs the 256-register budget.)
-template <typename T, int NV, int MODE>
-__global__ __launch_bounds__((NV == 8 || MODE == 1) ? 256 : 512) void ln_bwd_kernel(
+// PF (MODE 0, 16-bit T, x32 given, no dy32): the NEXT row's x32 / dy are loaded (raw) while this row is reduced -- two rows of loads in
+// flight per wave; with the 128-register budget that holds two blocks on a CU (round 5: 130 registers had left room for one block of
+// eight waves, eight rows in flight per CU: 33 us per call at 9 216 x 768 where the bytes need 13)
+template <typename T, int NV, int MODE, bool PF = false>
+__global__ __launch_bounds__((NV == 8 || MODE == 1) ? 256 : 512, (NV == 8 || MODE == 1) ? 1 : 4) void ln_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ g,
     T* __restrict__ dx, float* __restrict__ dg, float* __restrict__ db, int64_t M, int H, float eps,
     const int64_t* __restrict__ ids, const int64_t* __restrict__ type_ids,
     const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
     float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype_, int L, int vocab,
     int type_vocab, int rms, const T* __restrict__ add, T* __restrict__ dx_drop, float drop_p, uint64_t drop_seed,
-    const float* __restrict__ dy32, const float* __restrict__ x32) {
+    const float* __restrict__ dy32, const float* __restrict__ x32, float* __restrict__ partial) {
+  // partial != NULL (MODE 0): the block's column sums of d_gamma / d_beta go to partial[blockIdx.x][2][H] as plain stores and
+  // omk_ln_param_reduce adds them up in block order -- instead of gridDim.x same-address atomics per column, which cost ~7 us of a
+  // 27 us call at 9 216 x 768 and made the sums depend on the arrival order (round 5)
   // dy32 / x32 != NULL (MODE 0): the incoming gradient / the normalisation's input are read from these f32 tensors instead of dy / x
   // (round 5: the gradient of the pooled rows enters the last LayerNorm unrounded; the pre-LayerNorm sums of the 16-bit training
   // forward are kept in f32 -- tools/emulate_train_dataflow.py)
@@ -235,6 +243,17 @@ __global__ __launch_bounds__((NV == 8 || MODE == 1) ? 256 : 512) void ln_bwd_ker
     row_step = (int64_t)parts * LNB_WAVES * L;
     if (part >= parts) row_end = 0;
   }
+  float4 rx[PF ? NV : 1];
+  uint2 rd[PF ? NV : 1];
+#define LNB_FETCH(R_)                                                                   \
+  _Pragma("unroll") for (int j = 0; j < NV; ++j) {                                      \
+    const int c = (lane + 64 * j) * 4;                                                  \
+    if (c < H) {                                                                        \
+      rx[PF ? j : 0] = *(const float4*)(x32 + (R_) * H + c);                            \
+      rd[PF ? j : 0] = *(const uint2*)(dy + (R_) * H + c);                              \
+    }                                                                                   \
+  }
+  if (PF && row_first < row_end) { LNB_FETCH(row_first) }
   for (int64_t row = row_first; row < row_end; row += row_step) {
     float xv[NV][4], dv[NV][4];
     int64_t id = 0, tt = 0;
@@ -245,6 +264,23 @@ __global__ __launch_bounds__((NV == 8 || MODE == 1) ? 256 : 512) void ln_bwd_ker
       t = (int)(row % L);
     }
     float s1 = 0.f;
+    if (PF) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        if ((lane + 64 * j) * 4 < H) {
+          const float4 q = rx[PF ? j : 0];
+          xv[j][0] = q.x; xv[j][1] = q.y; xv[j][2] = q.z; xv[j][3] = q.w;
+          unpack4<T>(rd[PF ? j : 0], dv[j]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s1 += xv[j][e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { xv[j][e] = 0.f; dv[j][e] = 0.f; }
+        }
+      }
+      const int64_t nr = row + row_step;
+      if (nr < row_end) { LNB_FETCH(nr) }
+    } else
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int c = (lane + 64 * j) * 4;
@@ -351,8 +387,13 @@ __global__ __launch_bounds__((NV == 8 || MODE == 1) ? 256 : 512) void ln_bwd_ker
     float sg = 0.f, sb = 0.f;
 #pragma unroll
     for (int k = 0; k < LNB_WAVES; ++k) { sg += red[k * H + c]; sb += red[(LNB_WAVES + k) * H + c]; }
-    atomicAdd(dg + c, sg);
-    if (db) atomicAdd(db + c, sb);
+    if (MODE == 0 && partial) {
+      partial[((size_t)blockIdx.x * 2 + 0) * H + c] = sg;
+      partial[((size_t)blockIdx.x * 2 + 1) * H + c] = sb;
+    } else {
+      atomicAdd(dg + c, sg);
+      if (db) atomicAdd(db + c, sb);
+    }
   }
   if (MODE == 1) {                     // token-type rows 0 and 1: same block reduction, then one atomic per column
     __syncthreads();
@@ -397,21 +438,29 @@ static int launch_ln_bwd(const void* dy, const void* x, const float* g, void* dx
                          const float* word, const float* pos, const float* type, float* dword,
                          float* dpos, float* dtype_, int L, int vocab, int type_vocab, hipStream_t s,
                          int rms = 0, const void* add = nullptr, void* dx_drop = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0,
-                         const float* dy32 = nullptr, const float* x32 = nullptr) {
+                         const float* dy32 = nullptr, const float* x32 = nullptr, float* partial = nullptr, int* partial_blocks = nullptr) {
   const int waves = (H <= 1024 && MODE == 0) ? 8 : 4;
   const int64_t want = (M + waves - 1) / waves;
   // two blocks per CU: ~12 MB of loads in flight (one row per wave at a time), what ~5 TB/s x ~2 us of latency needs;
   // more blocks only add same-address atomics on d_gamma / d_beta (1024 blocks: 41 us, 256: 30 us per call)
-  unsigned grid = (unsigned)(want > 512 ? 512 : want);
+  unsigned grid = (unsigned)(want > OM_LNB_MAX_BLOCKS ? OM_LNB_MAX_BLOCKS : want);
+  if (partial_blocks) *partial_blocks = (int)grid;
   if (MODE == 1) {                     // one position per block, 256 / L blocks per position (kernel comment)
     if (L < 1 || M % L) OM_FAIL("embedding backward: M must be B * L");
     const int parts = 256 / L > 0 ? 256 / L : 1;
     grid = (unsigned)(L * parts);
   }
   const size_t lds = (size_t)2 * waves * H * sizeof(float);       // <= 64 KiB for both shapes
-#define LNB(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, MODE>), dim3(grid), dim3(64 * waves), lds, s, (const T*)dy, (const T*)x, g, (T*)dx, dg, db, M, H, eps, ids, tt, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, rms, (const T*)add, (T*)dx_drop, drop_p, drop_seed, dy32, x32)
-  if (H <= 1024) LNB(4); else LNB(8);
+#define LNB_(NV, PF_) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, MODE, PF_>), dim3(grid), dim3(64 * waves), lds, s, (const T*)dy, (const T*)x, g, (T*)dx, dg, db, M, H, eps, ids, tt, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, rms, (const T*)add, (T*)dx_drop, drop_p, drop_seed, dy32, x32, partial)
+#define LNB(NV) LNB_(NV, false)
+  constexpr bool can_pf = MODE == 0 && sizeof(T) == 2;
+  if (can_pf && x32 && !dy32 && H <= 768 && (om_option(OM_OPT_TRAIN_WGRAD_STREAM) & 8) == 0) {        // (bit 3, A/B: no prefetch;
+    LNB_(3, can_pf);                                                                                   //  wider rows: the prefetch spills)
+  } else if (H <= 768 && MODE == 0) LNB(3);
+  else if (H <= 1024) LNB(4);
+  else LNB(8);
 #undef LNB
+#undef LNB_
   OM_LAUNCH_CHECK();
   return 0;
 }
@@ -423,15 +472,49 @@ int omk_ln_bwd(int dtype, const void* dy, const void* x, const float* g, void* d
 
 int omk_ln_bwd_drop(int dtype, const void* dy, const void* x, const float* g, void* dx, void* dx_drop, float drop_p,
                     uint64_t drop_seed, float* dg, float* db, int64_t M, int H, float eps, hipStream_t s, const float* dy32,
-                    const float* x32) {
-  if (M <= 0) return 0;
+                    const float* x32, float* partial, int* partial_blocks) {
+  if (M <= 0) { if (partial_blocks) *partial_blocks = 0; return 0; }
   if (H % 4 || H > 2048) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
   if (drop_p <= 0.f) dx_drop = nullptr;
-  if (dtype == OM_BF16)
-    return launch_ln_bwd<bf16_t, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, 0, nullptr, dx_drop, drop_p, drop_seed, dy32, x32);
-  if (dtype == OM_F16)
-    return launch_ln_bwd<f16_t, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, 0, nullptr, dx_drop, drop_p, drop_seed, dy32, x32);
-  return launch_ln_bwd<float, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, 0, nullptr, dx_drop, drop_p, drop_seed, dy32, x32);
+#define OM_LNBD(TT) return launch_ln_bwd<TT, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, 0, nullptr, dx_drop, drop_p, drop_seed, dy32, x32, partial, partial_blocks)
+  if (dtype == OM_BF16) OM_LNBD(bf16_t);
+  if (dtype == OM_F16) OM_LNBD(f16_t);
+  OM_LNBD(float);
+#undef OM_LNBD
+}
+
+// d_gamma[c] += sum over blocks of partial[b][0][c], d_beta likewise, for n LayerNorm sites in one launch (the partial sums that
+// omk_ln_bwd_drop left): grid (ceil(H / 64), n), 16 groups of blocks per column, added in a fixed order -- deterministic.
+struct LnSiteTable { OmLnSite site[OM_LN_SITES_MAX]; };
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(LnSiteTable tab, int H) {
+  __shared__ float red[2][16][64];
+  const OmLnSite st = tab.site[blockIdx.y];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6, c = blockIdx.x * 64 + col;
+  float sg = 0.f, sb = 0.f;
+  if (c < H)
+    for (int b = grp; b < st.blocks; b += 16) {
+      sg += st.partial[((size_t)b * 2 + 0) * H + c];
+      sb += st.partial[((size_t)b * 2 + 1) * H + c];
+    }
+  red[0][grp][col] = sg; red[1][grp][col] = sb;
+  __syncthreads();
+  if (grp < 2 && c < H) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += red[grp][k][col];
+    float* dst = grp == 0 ? st.dg : st.db;
+    if (dst) dst[c] += v;
+  }
+}
+int omk_ln_param_reduce(const OmLnSite* sites, int n, int H, hipStream_t s) {
+  for (int i = 0; i < n; i += OM_LN_SITES_MAX) {
+    LnSiteTable tab;
+    const int m = n - i < OM_LN_SITES_MAX ? n - i : OM_LN_SITES_MAX;
+    for (int k = 0; k < m; ++k) tab.site[k] = sites[i + k];
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((unsigned)((H + 63) / 64), (unsigned)m), dim3(1024), 0, s, tab, H);
+    OM_LAUNCH_CHECK();
+  }
+  return 0;
 }
 
 int omk_norm_bwd(int dtype, const void* dy, const void* x, const float* g, void* dx, float* dg,
