@@ -25,7 +25,7 @@ QUIET="--no-cpu-baseline --no-extra --no-parity"
 case $sub in
 validate)
   timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2>$O/bench.err; echo "bench rc=$?"; cut -c1-400 $O/bench.json
-  timeout 1500 python -m pytest tests -m gpu -q -x -s > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log; grep -E " passed| failed| error" $O/pytest.log | tail -3
+  timeout 1500 python -m pytest tests -m gpu -q -s > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log; grep -E " passed| failed| error" $O/pytest.log | tail -3
   timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
   [ -x build/selftest ] && { timeout 300 build/selftest full > $O/selftest_full.log 2>&1; echo "selftest rc=$?"; tail -1 $O/selftest_full.log; }
   ;;
