@@ -391,6 +391,29 @@ int om_encoder_train_backward(const OmEncoderConfig* cfg, const OmEncoderWeights
                               const void* tape, const float* d_reps, const OmEncoderGrads* grads,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* Packed rows in TRAINING (round 5; the training-side counterpart of om_encoder_forward_packed).  The reference's train collator pads
+ * every query to q_max_len and every passage to p_max_len (dataset/data_collator.py:13-24) and the model computes over the padding;
+ * here the contractions, normalisations, the tape and the weight gradients run over `packed_rows` rows -- each sequence's tokens up
+ * to its last unmasked one, back to back.  ids / mask / token types keep their [B, L] layout; packed_rows is a multiple of 256 that
+ * is >= the token count (computed on the host from the collator's lengths) and < B * L.  16-bit BERT-family configurations with
+ * widths of 256, L <= 128, pooling first / mean: ask om_encoder_train_packed_supported.  Same representations and gradients as the
+ * padded pair up to the order of the sums over rows; a bound below the token count turns out_reps into NaN. */
+int om_encoder_train_packed_supported(const OmEncoderConfig* cfg, int64_t B, int64_t L, int64_t packed_rows);
+size_t om_encoder_tape_bytes_packed(const OmEncoderConfig* cfg, int64_t B, int64_t L, int64_t packed_rows);
+size_t om_encoder_train_workspace_bytes_packed(const OmEncoderConfig* cfg, int64_t B, int64_t L, int64_t packed_rows);
+int om_encoder_train_forward_packed(const OmEncoderConfig* cfg, const OmEncoderWeights* w,
+                                    const int64_t* input_ids, const int64_t* attention_mask,
+                                    const int64_t* token_type_ids, int64_t B, int64_t L, int64_t packed_rows,
+                                    float hidden_dropout, float attn_dropout, uint64_t seed,
+                                    void* tape, size_t tape_bytes, float* out_reps,
+                                    void* workspace, size_t workspace_bytes, void* stream);
+int om_encoder_train_backward_packed(const OmEncoderConfig* cfg, const OmEncoderWeights* w,
+                                     const int64_t* input_ids, const int64_t* attention_mask,
+                                     const int64_t* token_type_ids, int64_t B, int64_t L, int64_t packed_rows,
+                                     float hidden_dropout, float attn_dropout, uint64_t seed,
+                                     const void* tape, const float* d_reps, const OmEncoderGrads* grads,
+                                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same pair with the stack's output / its gradient at the boundary instead of pooled representations: out_hidden
  * and d_hidden are [B,L,H] in cfg->dtype (T5: after the final RMSNorm and its dropout).  cfg->pooling / head / normalize
  * are ignored.  What the T5 decoder position (om_t5_decoder_train_*) sits on. */

@@ -687,8 +687,8 @@ int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
                   const float* pos_bias, int64_t B, int L, int H, int heads, float scale,
                   float drop_p, uint64_t seed, hipStream_t s, int reverse, const int* kmax, const int* cu) {
   if (B <= 0) return 0;
-  if (cu && !((dtype == OM_F16 || (dtype == OM_BF16 && om_option(OM_OPT_ATTENTION_FAST))) && L <= 256 && drop_p == 0.f))
-    OM_FAIL("packed rows: 16-bit inference attention, L <= 256");
+  if (cu && !((dtype == OM_F16 || (dtype == OM_BF16 && om_option(OM_OPT_ATTENTION_FAST))) && L <= 256))
+    OM_FAIL("packed rows: the 16-bit attention kernels, L <= 256");      // (with dropout too: the packed training forward, round 5)
   if (L < 1 || L > 1024) OM_FAIL("sequence length must be in [1,1024]");
   if (L > 256 && drop_p > 0.f) OM_FAIL("training supports sequence lengths up to 256");
   if (H != heads * 64) OM_FAIL("head_dim must be 64");

@@ -70,7 +70,9 @@ __device__ __forceinline__ void store_rows(const f32x16_t (&o)[2], char* out, in
 template <typename T, int KT>
 __global__ __launch_bounds__(64 * KT) void attention_bwd16_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx, bf16_t* __restrict__ dqkv,
-    const int64_t* __restrict__ mask, int L, int H, int heads, float scale, float drop_p, uint64_t seed) {
+    const int64_t* __restrict__ mask, int Lm, int H, int heads, float scale, float drop_p, uint64_t seed, const int* __restrict__ cu) {
+  // cu != NULL (packed rows, round 5): sequence b is rows cu[b] .. cu[b + 1] - 1 of qkv / dctx / dqkv, L its own row count; the
+  // mask keeps its pitch Lm.  Rows past L are neither read (clamped) nor written, as for a padded sequence shorter than the tile.
   constexpr int LT = KT * 32;
   constexpr int PP = LT * 2 + 8;                       // bytes per row of the Pd / dS images
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -81,12 +83,19 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd16_kernel(
   float* const sM = (float*)(sD + LT * PP);            // additive key mask (log2 domain)
   const int h = blockIdx.x % heads;
   const int64_t b = blockIdx.x / heads;
+  int64_t row0 = b * Lm;
+  int L = Lm;
+  if (cu) {
+    const int c0 = __builtin_amdgcn_readfirstlane(cu[b]), c1 = __builtin_amdgcn_readfirstlane(cu[b + 1]);
+    row0 = c0; L = c1 - c0;
+    if (L <= 0) return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t ld2 = 6 * (int64_t)H;                  // row pitch of qkv / dqkv in bytes
-  const char* const base = (const char*)(qkv + b * L * 3 * (int64_t)H + h * 64);
-  const char* const dob = (const char*)(dctx + b * L * (int64_t)H + h * 64);
-  char* const dbase = (char*)(dqkv + b * L * 3 * (int64_t)H + h * 64);
+  const char* const base = (const char*)(qkv + row0 * 3 * (int64_t)H + h * 64);
+  const char* const dob = (const char*)(dctx + row0 * (int64_t)H + h * 64);
+  char* const dbase = (char*)(dqkv + row0 * 3 * (int64_t)H + h * 64);
   const AttnDrop dr(drop_p);
 
   // ---- stage K, V (now) and fetch Q, dO (for phase B) : thread -> 16-byte chunk c of row r, four rows apart per pass
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd16_kernel(
   BW_STAGE(0) BW_STAGE(1) BW_STAGE(2) BW_STAGE(3)
 #undef BW_STAGE
   const float LOG2E = 1.4426950408889634f;
-  for (int k = tid; k < LT; k += 64 * KT) sM[k] = k < L ? (mask[b * L + k] != 0 ? 0.f : -1e30f) : -INFINITY;
+  for (int k = tid; k < LT; k += 64 * KT) sM[k] = k < L ? (mask[b * Lm + k] != 0 ? 0.f : -1e30f) : -INFINITY;
 
   const int q0 = wave * 32;
   const int qrow = (q0 + l31) < L ? (q0 + l31) : (L - 1);
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd16_kernel(
 
 template <typename T, int KT>
 int launch_bwd16(const void* qkv, const void* dctx, void* dqkv, const int64_t* mask, int64_t B, int L, int H, int heads,
-                 float scale, float drop_p, uint64_t seed, hipStream_t s) {
+                 float scale, float drop_p, uint64_t seed, hipStream_t s, const int* cu) {
   constexpr int LT = KT * 32;
   const int lds = 2 * LT * PITCH + 2 * LT * (LT * 2 + 8) + LT * 4;
   static std::atomic<bool> attr_set{false};
@@ -284,7 +293,7 @@ int launch_bwd16(const void* qkv, const void* dctx, void* dqkv, const int64_t* m
     attr_set = true;
   }
   hipLaunchKernelGGL((attention_bwd16_kernel<T, KT>), dim3((unsigned)(heads * B)), dim3(64 * KT), lds, s, (const bf16_t*)qkv,
-                     (const bf16_t*)dctx, (bf16_t*)dqkv, mask, L, H, heads, scale, drop_p, seed);
+                     (const bf16_t*)dctx, (bf16_t*)dqkv, mask, L, H, heads, scale, drop_p, seed, cu);
   OM_LAUNCH_CHECK();
   return 0;
 }
@@ -295,13 +304,13 @@ bool omk_attention_bwd16_ok(int dtype, int L, int H, int heads) {
 }
 
 int omk_attention_bwd16(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask, int64_t B, int L, int H,
-                        int heads, float scale, float drop_p, uint64_t seed, hipStream_t s) {
+                        int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, const int* cu) {
   if (B <= 0) return 0;
 #define BWD16(TT)                                                                                            \
   do {                                                                                                       \
-    if (L <= 32) return launch_bwd16<TT, 1>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s);    \
-    if (L <= 64) return launch_bwd16<TT, 2>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s);    \
-    return launch_bwd16<TT, 4>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s);                 \
+    if (L <= 32) return launch_bwd16<TT, 1>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s, cu);    \
+    if (L <= 64) return launch_bwd16<TT, 2>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s, cu);    \
+    return launch_bwd16<TT, 4>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s, cu);                 \
   } while (0)
   if (dtype == OM_F16) BWD16(f16_t);
   BWD16(bf16_t);

@@ -20,6 +20,7 @@
 namespace {
 struct Dims {
   int64_t M, Mp, B, L; int H, F, nl, nh, D; size_t es; bool t5, gated;
+  bool packed;       // packed rows (round 5): M = the caller's row bound; sequence b lives in rows cu[b] .. cu[b + 1] - 1 of every [M, .] tensor
   // what a 16-bit BERT tape holds (fixed by the FORWARD, remembered per tape: tape_flags below):
   bool bert16;       // 16-bit BERT: the configurations the two flags below apply to
   bool res32;        // the pre-LayerNorm sums y1 / y2 in f32 (the forward's residual stream stays in f32: OM_OPT_TRAIN_RES32)
@@ -27,9 +28,10 @@ struct Dims {
 };
 constexpr int TAPE_RES32 = 1, TAPE_PRE_GRAD = 2;
 
-Dims dims_of(const OmEncoderConfig* c, int64_t B, int64_t L) {
+Dims dims_of(const OmEncoderConfig* c, int64_t B, int64_t L, int64_t packed_rows = 0) {
   Dims d;
-  d.B = B; d.L = L; d.M = B * L; d.Mp = (d.M + 63) / 64 * 64;
+  d.packed = packed_rows > 0;
+  d.B = B; d.L = L; d.M = d.packed ? packed_rows : B * L; d.Mp = (d.M + 63) / 64 * 64;
   d.H = c->hidden; d.F = c->ffn; d.nl = c->n_layers; d.nh = c->n_heads;
   d.D = c->head_in > 0 ? c->head_out : c->hidden;
   d.es = (c->dtype == OM_BF16 || c->dtype == OM_F16) ? 2 : 4;
@@ -99,6 +101,7 @@ struct Ws {
   // omk_ln_param_reduce when the layer group's gradients are published (round 5: no same-address atomics, a fixed order)
   float* lnpart;
   size_t slnpart;                   // floats per site
+  int *kmax, *cu, *cls_rows, *row_map;      // packed rows: per-sequence extents, row offsets (+ total, true total), CLS rows, token of every row
   size_t total;
 };
 inline bool keep_ok(const Dims& d) { return !d.t5 && d.es == 2 && d.H % 256 == 0 && d.F % 256 == 0 && d.M >= 32; }
@@ -128,6 +131,10 @@ Ws carve_ws(const Dims& d, char* base) {
   w.keep = take(w.skeep * d.nl);
   w.slnpart = d.t5 ? 0 : (size_t)OM_LNB_MAX_BLOCKS * 2 * d.H;
   w.lnpart = (float*)take(w.slnpart * 4 * 2 * d.nl);
+  w.kmax = (int*)take(d.packed ? (size_t)d.B * 4 : 0);
+  w.cu = (int*)take(d.packed ? (size_t)(d.B + 2) * 4 : 0);
+  w.cls_rows = (int*)take(d.packed ? (size_t)d.B * 4 : 0);
+  w.row_map = (int*)take(d.packed ? (size_t)d.M * 4 : 0);
   w.total = off;
   return w;
 }
@@ -423,6 +430,28 @@ extern "C" size_t om_encoder_train_workspace_bytes(const OmEncoderConfig* cfg, i
   if (!cfg || B <= 0 || L <= 0) return 0;
   return carve_ws(dims_of(cfg, B, L), nullptr).total;
 }
+// Packed rows in training (round 5): the contractions, normalisations and the tape run over `packed_rows` rows -- the tokens up to
+// each sequence's last unmasked one, back to back -- instead of B * L (the reference pads every sequence of a batch to one length,
+// dataset/data_collator.py:13-24, and computes over the padding).  16-bit BERT-family configurations with widths of 256, L <= 128,
+// packed_rows a multiple of 256 that is >= the token count (a bound that is too small turns the representations into NaN).
+extern "C" int om_encoder_train_packed_supported(const OmEncoderConfig* c, int64_t B, int64_t L, int64_t packed_rows) {
+  if (!c || B <= 0 || L <= 0 || packed_rows <= 0) return 0;
+  if (c->arch != OM_ARCH_BERT || (c->dtype != OM_BF16 && c->dtype != OM_F16) || c->n_layers <= 0) return 0;
+  if (packed_rows % 256 || packed_rows < 512 || packed_rows > B * L + 255 || packed_rows >= B * L) return 0;
+  if (c->hidden % 256 || c->ffn % 256 || c->n_heads * 64 != c->hidden) return 0;
+  if (c->pooling != OM_POOL_FIRST && c->pooling != OM_POOL_MEAN) return 0;
+  if (!om_option(OM_OPT_ATTENTION_FAST) || !omk_attention_bwd16_ok(c->dtype, (int)L, c->hidden, c->n_heads)) return 0;
+  if ((size_t)c->ffn < (size_t)2 * c->hidden) return 0;                 // (the f32 pooled tail borrows the [M, F] scratch)
+  return 1;
+}
+extern "C" size_t om_encoder_tape_bytes_packed(const OmEncoderConfig* cfg, int64_t B, int64_t L, int64_t packed_rows) {
+  if (!om_encoder_train_packed_supported(cfg, B, L, packed_rows)) return 0;
+  return carve_tape(dims_of(cfg, B, L, packed_rows), nullptr).total;
+}
+extern "C" size_t om_encoder_train_workspace_bytes_packed(const OmEncoderConfig* cfg, int64_t B, int64_t L, int64_t packed_rows) {
+  if (!om_encoder_train_packed_supported(cfg, B, L, packed_rows)) return 0;
+  return carve_ws(dims_of(cfg, B, L, packed_rows), nullptr).total;
+}
 
 #define RUN(expr) do { if (expr) return 1; } while (0)
 
@@ -433,12 +462,15 @@ static int train_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* 
                               const int64_t* token_type_ids, int64_t B, int64_t L,
                               float hidden_dropout, float attn_dropout, uint64_t seed,
                               void* tape_mem, size_t tape_bytes, float* out_reps, void* out_hidden,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+                              void* workspace, size_t workspace_bytes, void* stream, int64_t packed_rows = 0) {
   if (!c || !w || !input_ids || !attention_mask || !tape_mem || !workspace || (!out_reps && !out_hidden)) OM_FAIL("null argument");
   if (check_train_cfg(c, L)) return 1;
   if (B <= 0) return 0;
   if (((uintptr_t)tape_mem & 255) || ((uintptr_t)workspace & 255)) OM_FAIL("tape/workspace must be 256-byte aligned");
-  const Dims d = dims_of(c, B, L);
+  if (packed_rows > 0 && (out_hidden || !om_encoder_train_packed_supported(c, B, L, packed_rows)))
+    OM_FAIL("packed rows in training: 16-bit BERT-family, widths of 256, L <= 128, rows a multiple of 256 in [512, B * L) (om_encoder_train_packed_supported)");
+  const Dims d = dims_of(c, B, L, packed_rows);
+  const bool packed = d.packed;
   Tape t = carve_tape(d, (char*)tape_mem);
   Ws ws = carve_ws(d, (char*)workspace);
   if (t.total > tape_bytes || ws.total > workspace_bytes) OM_FAIL("tape or workspace too small");
@@ -479,8 +511,19 @@ static int train_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* 
     OM_HIP(hipEventRecord(lane->wt_done, lane->side));
     lane->wt_ws = ws.wt; lane->wt_w0 = Ls[0].qkv_w; lane->wt_w1 = Ls[d.nl - 1].ffn2_w; lane->wt_nl = d.nl;
   }
+  const int* cu = nullptr;
+  const int* row_map = nullptr;
+  if (packed) {
+    // rows of sequence b: cu[b] .. cu[b + 1] - 1 (up to its last unmasked token); row_map names the token of every row (-1: a zero
+    // row behind the last sequence).  The pad rows stay finite through the forward (a zero embedding row, normalised, projected ...)
+    // except where no kernel writes them -- the attention output -- which is zeroed: the weight gradients sum over all M rows, and
+    // 0 (their dY) x anything finite is 0.
+    RUN(omk_mask_extent(attention_mask, B, (int)L, ws.kmax, s));
+    RUN(omk_pack_rows(ws.kmax, B, (int)L, M, ws.cu, ws.cls_rows, ws.row_map, s));
+    cu = ws.cu; row_map = ws.row_map;
+  }
   RUN(omk_embed(dt, input_ids, token_type_ids, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g,
-                w->emb_ln_b, t.x, M, (int)L, H, c->vocab, c->type_vocab, c->ln_eps, 1, s));
+                w->emb_ln_b, t.x, M, (int)L, H, c->vocab, c->type_vocab, c->ln_eps, 1, s, row_map));
   if (hidden_dropout > 0.f) RUN(omk_dropout(dt, t.x, t.x, M * H, hidden_dropout, site_seed(seed, 0, 0), s));
   // res32 (16-bit BERT, default): the residual stream of the FORWARD stays in f32, as the reference's autocast keeps it (layer_norm
   // runs and returns fp32; the residual add of a 16-bit dense output and an fp32 LayerNorm output is fp32).  The pre-LayerNorm sums
@@ -491,7 +534,7 @@ static int train_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* 
   float* xres = nullptr;        // f32 copy of the current layer input
   if (d.res32) {
     RUN(omk_embed(OM_F32, input_ids, token_type_ids, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g,
-                  w->emb_ln_b, ws.x32a, M, (int)L, H, c->vocab, c->type_vocab, c->ln_eps, 1, s));
+                  w->emb_ln_b, ws.x32a, M, (int)L, H, c->vocab, c->type_vocab, c->ln_eps, 1, s, row_map));
     if (hidden_dropout > 0.f) RUN(omk_dropout(OM_F32, ws.x32a, ws.x32a, M * H, hidden_dropout, site_seed(seed, 0, 0), s));
     xres = ws.x32a;
   }
@@ -510,7 +553,8 @@ static int train_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* 
     ep.bias = lw.qkv_b;
     RUN(omk_gemm(dt, x, H, lw.qkv_w, H, dt, qkv, 3 * H, M, 3 * H, H, ep, s));
     RUN(omk_attention(dt, qkv, ctx, attention_mask, nullptr, B, (int)L, H, d.nh, scale, attn_dropout,
-                      site_seed(seed, l, 2), s));
+                      site_seed(seed, l, 2), s, 0, packed ? ws.kmax : nullptr, cu));
+    if (packed) RUN(omk_zero_rows_from(ctx, (int64_t)H * d.es, ws.cu + B, M, s));      // the rows no sequence owns
     ep = GemmEpilogue{};
     ep.bias = lw.o_b; ep.resid = d.res32 ? (const void*)xres : (const void*)x; ep.ldr = H; ep.drop_p = hidden_dropout; ep.seed = site_seed(seed, l, 3);
     RUN(omk_gemm(dt, ctx, H, lw.o_w, H, ydt, y1, H, M, H, H, ep, s));
@@ -543,13 +587,15 @@ static int train_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* 
     const char* y2_last = t.y2 + t.sy * (d.nl - 1);
     const int ydt_last = d.res32 ? OM_F32 : dt;
     if (c->pooling == OM_POOL_FIRST) {
-      RUN(omk_layernorm_f32out(ydt_last, y2_last, L * H, t.pooled, H, last.ln2_g, last.ln2_b, B, H, c->ln_eps, 0, s));
+      if (packed) RUN(omk_layernorm_f32out(ydt_last, y2_last, H, t.pooled, H, last.ln2_g, last.ln2_b, B, H, c->ln_eps, 0, s, nullptr, ws.cls_rows));
+      else RUN(omk_layernorm_f32out(ydt_last, y2_last, L * H, t.pooled, H, last.ln2_g, last.ln2_b, B, H, c->ln_eps, 0, s));
     } else {
       float* x32 = (float*)ws.df;                        // [M, H] f32 fits the [M, F] 16-bit scratch of the backward (bert16: F >= 2 H)
       RUN(omk_layernorm_f32out(ydt_last, y2_last, H, x32, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, 0, s));
-      RUN(omk_pool(OM_F32, x32, attention_mask, t.pooled, B, (int)L, H, c->pooling, s));
+      RUN(omk_pool(OM_F32, x32, attention_mask, t.pooled, B, (int)L, H, c->pooling, s, cu));
     }
   } else {
+    if (packed) OM_FAIL("packed rows in training: the 16-bit pooled tail only");
     RUN(omk_pool(dt, xf, attention_mask, t.pooled, B, (int)L, H, c->pooling, s));
   }
   float* pre = c->normalize ? t.headout : out_reps;      // value before F.normalize
@@ -560,7 +606,19 @@ static int train_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* 
     OM_HIP(hipMemcpyAsync(pre, t.pooled, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));
   }
   if (c->normalize) RUN(omk_l2norm(t.headout, out_reps, B, d.D, s));
+  if (packed) RUN(omk_pack_overflow_poison(ws.cu, B, M, out_reps, B * (int64_t)d.D, s));      // a row bound below the token count: NaN, never a truncated batch
   return 0;
+}
+
+extern "C" int om_encoder_train_forward_packed(const OmEncoderConfig* c, const OmEncoderWeights* w,
+                                               const int64_t* input_ids, const int64_t* attention_mask,
+                                               const int64_t* token_type_ids, int64_t B, int64_t L, int64_t packed_rows,
+                                               float hidden_dropout, float attn_dropout, uint64_t seed,
+                                               void* tape_mem, size_t tape_bytes, float* out_reps,
+                                               void* workspace, size_t workspace_bytes, void* stream) {
+  if (!out_reps || packed_rows <= 0) OM_FAIL("null argument / packed_rows must be positive");
+  return train_forward_impl(c, w, input_ids, attention_mask, token_type_ids, B, L, hidden_dropout, attn_dropout, seed,
+                            tape_mem, tape_bytes, out_reps, nullptr, workspace, workspace_bytes, stream, packed_rows);
 }
 
 extern "C" int om_encoder_train_forward(const OmEncoderConfig* c, const OmEncoderWeights* w,
@@ -591,12 +649,14 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
                                float hidden_dropout, float attn_dropout, uint64_t seed,
                                const void* tape_mem, const float* d_reps, const void* d_hidden,
                                const OmEncoderGrads* g, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+                               size_t workspace_bytes, void* stream, int64_t packed_rows = 0) {
   BwdEventsScope events_scope;
   if (!c || !w || !g || !tape_mem || (!d_reps && !d_hidden) || !workspace) OM_FAIL("null argument");
   if (check_train_cfg(c, L)) return 1;
   if (B <= 0) return 0;
-  const Dims d0 = dims_of(c, B, L);
+  if (packed_rows > 0 && (d_hidden || !om_encoder_train_packed_supported(c, B, L, packed_rows)))
+    OM_FAIL("packed rows in training: not for this configuration (om_encoder_train_packed_supported)");
+  const Dims d0 = dims_of(c, B, L, packed_rows);
   const Dims d = dims_with_flags(d0, tape_flags_get(tape_mem, flags_of(d0)));      // the tape as its forward wrote it
   Tape t = carve_tape(d, (char*)tape_mem);
   Ws ws = carve_ws(d, (char*)workspace);
@@ -609,6 +669,12 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
   if (!Ls || !Gs) OM_FAIL("layers_host is null");
   const float scale = 1.0f / sqrtf((float)c->head_dim);
 
+  const int* cu = nullptr;
+  if (d.packed) {            // the forward's row tables again (the workspace is not the tape: nothing of it survives between the calls)
+    RUN(omk_mask_extent(attention_mask, B, (int)L, ws.kmax, s));
+    RUN(omk_pack_rows(ws.kmax, B, (int)L, M, ws.cu, ws.cls_rows, ws.row_map, s));
+    cu = ws.cu;
+  }
   char* dx = ws.dxa;       // gradient w.r.t. the current layer's OUTPUT
   char* dx_prev = ws.dxb;  // gradient w.r.t. its input (next iteration's dx)
   const float* dpool32 = nullptr;      // the same for the top layer as f32 (16-bit BERT, pooled tail)
@@ -634,8 +700,12 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
     // step from 2.4 x to 3.9 x (worst tensor 8.9 x) the reference's encoder-only bf16 autocast (tools/emulate_train_dataflow.py).
     if (d.bert16) {
       dpool32 = (const float*)ws.df;
-      RUN(omk_pool_bwd(OM_F32, dpooled, attention_mask, ws.df, B, (int)L, H, c->pooling, s));
+      RUN(omk_pool_bwd(OM_F32, dpooled, attention_mask, ws.df, B, (int)L, H, c->pooling, s, cu));
+      // packed rows: the rows behind the last sequence carry a ZERO gradient from here down (LayerNorm backward, dropout and the
+      // contractions map zero rows to zero rows), so they add nothing to the weight gradients that sum over all M rows
+      if (d.packed) RUN(omk_zero_rows_from(ws.df, (int64_t)H * 4, ws.cu + B, M, s));
     } else {
+      if (d.packed) OM_FAIL("packed rows in training: the 16-bit pooled tail only");
       RUN(omk_pool_bwd(dt, dpooled, attention_mask, dx, B, (int)L, H, c->pooling, s));
     }
   }
@@ -752,7 +822,8 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
     }
     WGRAD_DONE(l + 1, 3);                                           // ws.dqkv: last read by dWqkv of the layer above
     RUN(omk_attention_bwd(dt, qkv, ws.dctx, dqkvl, attention_mask, B, (int)L, H, d.nh, scale,
-                          attn_dropout, site_seed(seed, l, 2), s));
+                          attn_dropout, site_seed(seed, l, 2), s, cu));
+    if (d.packed) RUN(omk_zero_rows_from(dqkvl, (int64_t)3 * H * d.es, ws.cu + B, M, s));      // rows the kernel does not own: zero, not stale
     WGRAD(3, dqkvl, 3 * H, x, H, lg.qkv_w, lg.qkv_b);               // dWqkv [3H,H], dbqkv
     {
       GemmEpilogue e4 = {};
@@ -796,8 +867,8 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
   const char* de = dx;
   if (hidden_dropout > 0.f) { RUN(omk_dropout(dt, dx, ws.dd, M * H, hidden_dropout, site_seed(seed, 0, 0), s)); de = ws.dd; }
   RUN(omk_embed_bwd(dt, de, input_ids, token_type_ids, w->word_emb, w->pos_emb, w->type_emb,
-                    w->emb_ln_g, g->word_emb, g->pos_emb, g->type_emb, g->emb_ln_g, g->emb_ln_b, M,
-                    (int)L, H, c->vocab, c->type_vocab, c->ln_eps, s));
+                    w->emb_ln_g, g->word_emb, g->pos_emb, g->type_emb, g->emb_ln_g, g->emb_ln_b, B * L,
+                    (int)L, H, c->vocab, c->type_vocab, c->ln_eps, s, cu));
 #undef WGRAD
 #undef WGRAD_DONE
   RUN(record_layer_event(d.nl, s));
@@ -815,6 +886,17 @@ extern "C" int om_encoder_train_backward(const OmEncoderConfig* c, const OmEncod
   if (!d_reps) OM_FAIL("null argument");
   return train_backward_impl(c, w, input_ids, attention_mask, token_type_ids, B, L, hidden_dropout, attn_dropout, seed,
                              tape_mem, d_reps, nullptr, g, workspace, workspace_bytes, stream);
+}
+extern "C" int om_encoder_train_backward_packed(const OmEncoderConfig* c, const OmEncoderWeights* w,
+                                                const int64_t* input_ids, const int64_t* attention_mask,
+                                                const int64_t* token_type_ids, int64_t B, int64_t L, int64_t packed_rows,
+                                                float hidden_dropout, float attn_dropout, uint64_t seed,
+                                                const void* tape_mem, const float* d_reps,
+                                                const OmEncoderGrads* g, void* workspace,
+                                                size_t workspace_bytes, void* stream) {
+  if (!d_reps || packed_rows <= 0) OM_FAIL("null argument / packed_rows must be positive");
+  return train_backward_impl(c, w, input_ids, attention_mask, token_type_ids, B, L, hidden_dropout, attn_dropout, seed,
+                             tape_mem, d_reps, nullptr, g, workspace, workspace_bytes, stream, packed_rows);
 }
 extern "C" int om_encoder_train_backward_hidden(const OmEncoderConfig* c, const OmEncoderWeights* w,
                                                 const int64_t* input_ids, const int64_t* attention_mask,

@@ -29,22 +29,25 @@ int omk_norm_bwd(int dtype, const void* dy, const void* x, const float* g, void*
 int omk_embed_bwd(int dtype, const void* dy, const int64_t* ids, const int64_t* type_ids,
                   const float* word, const float* pos, const float* type, const float* g,
                   float* dword, float* dpos, float* dtype_, float* dg, float* db, int64_t M, int L,
-                  int H, int vocab, int type_vocab, float eps, hipStream_t s);
+                  int H, int vocab, int type_vocab, float eps, hipStream_t s,
+                  const int* cu = nullptr /* packed rows: dy holds sequence b at rows cu[b] .. cu[b + 1] - 1 (M stays B * L) */);
 int omk_pool_bwd(int dtype, const float* dp, const int64_t* mask, void* dh, int64_t B, int L, int H,
-                 int mode, hipStream_t s);
+                 int mode, hipStream_t s, const int* cu = nullptr /* packed rows: sequence b is rows cu[b] .. of dh */);
+// rows [first[0], M) of a row-major tensor <- 0; `first` is on the device (packed rows: the pad rows behind the last sequence)
+int omk_zero_rows_from(void* p, int64_t row_bytes, const int* first, int64_t M, hipStream_t s);
 int omk_l2norm_bwd(const float* x, const float* dy, float* dx, int64_t M, int D, hipStream_t s);
 int omk_small_nn(const float* A, const float* Bm, float* C, int I, int J, int Cc, hipStream_t s);
 int omk_small_tn(const float* A, const float* Bm, float* C, int I, int J, int Cc, hipStream_t s);
 int omk_attention_bwd(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask,
                       int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
-                      hipStream_t s);
+                      hipStream_t s, const int* cu = nullptr /* packed rows (16-bit, L <= 128): sequence b is rows cu[b] .. cu[b + 1] - 1 */);
 int omk_attention_bwd_bias(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask,
                            int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
                            const float* pos_bias, float* drel, hipStream_t s);
 // bf16, L <= 128, no position bias: the transposing-read kernel of attention_bwd16.hip
 bool omk_attention_bwd16_ok(int dtype, int L, int H, int heads);
 int omk_attention_bwd16(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask, int64_t B, int L, int H,
-                        int heads, float scale, float drop_p, uint64_t seed, hipStream_t s);
+                        int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, const int* cu = nullptr);
 // T5 feed-forward activation (kind 0 relu, 1 gated gelu_new) forward / backward, embedding and bias backward
 int omk_t5_act_fwd(int dtype, const void* f, const void* f2, void* g, int64_t n, int kind, hipStream_t s);
 int omk_t5_act_bwd(int dtype, const void* dg, const void* f, const void* f2, void* df, void* df2, int64_t n, int kind, hipStream_t s);

@@ -191,14 +191,15 @@ template <> __device__ __forceinline__ void store4<float>(float* p, const float 
 // flight per wave; with the 128-register budget that holds two blocks on a CU (round 5: 130 registers had left room for one block of
 // eight waves, eight rows in flight per CU: 33 us per call at 9 216 x 768 where the bytes need 13)
 template <typename T, int NV, int MODE, bool PF = false>
-__global__ __launch_bounds__((NV == 8 || MODE == 1) ? 256 : 512, (NV == 8 || MODE == 1) ? 1 : 4) void ln_bwd_kernel(
+__global__ __launch_bounds__((NV == 8 || MODE == 1) ? 256 : 512, (NV == 8 || MODE == 1) ? 1 : (NV == 3 ? 4 : 3)) void ln_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ g,
     T* __restrict__ dx, float* __restrict__ dg, float* __restrict__ db, int64_t M, int H, float eps,
     const int64_t* __restrict__ ids, const int64_t* __restrict__ type_ids,
     const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
     float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype_, int L, int vocab,
     int type_vocab, int rms, const T* __restrict__ add, T* __restrict__ dx_drop, float drop_p, uint64_t drop_seed,
-    const float* __restrict__ dy32, const float* __restrict__ x32, float* __restrict__ partial) {
+    const float* __restrict__ dy32, const float* __restrict__ x32, float* __restrict__ partial, const int* __restrict__ cu) {
+  // cu != NULL (MODE 1, packed rows): dy holds sequence b's rows at cu[b] .. cu[b + 1] - 1; ids / type_ids keep the [B, L] layout
   // partial != NULL (MODE 0): the block's column sums of d_gamma / d_beta go to partial[blockIdx.x][2][H] as plain stores and
   // omk_ln_param_reduce adds them up in block order -- instead of gridDim.x same-address atomics per column, which cost ~7 us of a
   // 27 us call at 9 216 x 768 and made the sums depend on the arrival order (round 5)
@@ -258,6 +259,13 @@ __global__ __launch_bounds__((NV == 8 || MODE == 1) ? 256 : 512, (NV == 8 || MOD
     float xv[NV][4], dv[NV][4];
     int64_t id = 0, tt = 0;
     int t = 0;
+    int64_t drow = row;                      // the row of dy
+    if (MODE == 1 && cu) {
+      const int64_t sq = row / L;
+      const int c0 = cu[sq], c1 = cu[sq + 1];
+      if (my_t >= c1 - c0) continue;         // (wave-uniform) this sequence has no row at position my_t
+      drow = c0 + my_t;
+    }
     if (MODE == 1) {
       id = ids[row]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
       tt = type_ids ? type_ids[row] : 0; tt = tt < 0 ? 0 : (tt >= type_vocab ? type_vocab - 1 : tt);
@@ -291,7 +299,7 @@ __global__ __launch_bounds__((NV == 8 || MODE == 1) ? 256 : 512, (NV == 8 || MOD
 #pragma unroll
           for (int e = 0; e < 4; ++e) xv[j][e] = (word[id * H + c + e] + type[tt * H + c + e]) + pos[(int64_t)t * H + c + e];
         }
-        if (MODE == 0 && dy32) load4<float>(dy32 + row * H + c, dv[j]); else load4<T>(dy + row * H + c, dv[j]);
+        if (MODE == 0 && dy32) load4<float>(dy32 + row * H + c, dv[j]); else load4<T>(dy + drow * H + c, dv[j]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) s1 += xv[j][e];
       } else {
@@ -438,7 +446,8 @@ static int launch_ln_bwd(const void* dy, const void* x, const float* g, void* dx
                          const float* word, const float* pos, const float* type, float* dword,
                          float* dpos, float* dtype_, int L, int vocab, int type_vocab, hipStream_t s,
                          int rms = 0, const void* add = nullptr, void* dx_drop = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0,
-                         const float* dy32 = nullptr, const float* x32 = nullptr, float* partial = nullptr, int* partial_blocks = nullptr) {
+                         const float* dy32 = nullptr, const float* x32 = nullptr, float* partial = nullptr, int* partial_blocks = nullptr,
+                         const int* cu = nullptr) {
   const int waves = (H <= 1024 && MODE == 0) ? 8 : 4;
   const int64_t want = (M + waves - 1) / waves;
   // two blocks per CU: ~12 MB of loads in flight (one row per wave at a time), what ~5 TB/s x ~2 us of latency needs;
@@ -451,7 +460,7 @@ static int launch_ln_bwd(const void* dy, const void* x, const float* g, void* dx
     grid = (unsigned)(L * parts);
   }
   const size_t lds = (size_t)2 * waves * H * sizeof(float);       // <= 64 KiB for both shapes
-#define LNB_(NV, PF_) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, MODE, PF_>), dim3(grid), dim3(64 * waves), lds, s, (const T*)dy, (const T*)x, g, (T*)dx, dg, db, M, H, eps, ids, tt, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, rms, (const T*)add, (T*)dx_drop, drop_p, drop_seed, dy32, x32, partial)
+#define LNB_(NV, PF_) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, MODE, PF_>), dim3(grid), dim3(64 * waves), lds, s, (const T*)dy, (const T*)x, g, (T*)dx, dg, db, M, H, eps, ids, tt, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, rms, (const T*)add, (T*)dx_drop, drop_p, drop_seed, dy32, x32, partial, cu)
 #define LNB(NV) LNB_(NV, false)
   constexpr bool can_pf = MODE == 0 && sizeof(T) == 2;
   if (can_pf && x32 && !dy32 && H <= 768 && (om_option(OM_OPT_TRAIN_WGRAD_STREAM) & 8) == 0) {        // (bit 3, A/B: no prefetch;
@@ -531,14 +540,28 @@ int omk_norm_bwd(int dtype, const void* dy, const void* x, const float* g, void*
 int omk_embed_bwd(int dtype, const void* dy, const int64_t* ids, const int64_t* type_ids,
                   const float* word, const float* pos, const float* type, const float* g,
                   float* dword, float* dpos, float* dtype_, float* dg, float* db, int64_t M, int L,
-                  int H, int vocab, int type_vocab, float eps, hipStream_t s) {
+                  int H, int vocab, int type_vocab, float eps, hipStream_t s, const int* cu) {
   if (M <= 0) return 0;
   if (H % 4 || H > 2048) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
-  if (dtype == OM_BF16)
-    return launch_ln_bwd<bf16_t, 1>(dy, nullptr, g, nullptr, dg, db, M, H, eps, ids, type_ids, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, s);
-  if (dtype == OM_F16)
-    return launch_ln_bwd<f16_t, 1>(dy, nullptr, g, nullptr, dg, db, M, H, eps, ids, type_ids, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, s);
-  return launch_ln_bwd<float, 1>(dy, nullptr, g, nullptr, dg, db, M, H, eps, ids, type_ids, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, s);
+#define OM_EB(TT) return launch_ln_bwd<TT, 1>(dy, nullptr, g, nullptr, dg, db, M, H, eps, ids, type_ids, word, pos, type, dword, dpos, dtype_, L, vocab, type_vocab, s, 0, nullptr, nullptr, 0.f, 0, nullptr, nullptr, nullptr, nullptr, cu)
+  if (dtype == OM_BF16) OM_EB(bf16_t);
+  if (dtype == OM_F16) OM_EB(f16_t);
+  OM_EB(float);
+#undef OM_EB
+}
+
+// rows [*first, M) of a row-major tensor <- 0 (packed rows: the pad rows behind the last sequence; `first` lives on the device)
+__global__ __launch_bounds__(256) void zero_rows_from_kernel(char* __restrict__ p, int64_t row_bytes, const int* __restrict__ first, int64_t M) {
+  const int64_t vecs = row_bytes >> 4;
+  for (int64_t row = (int64_t)first[0] + blockIdx.x; row < M; row += gridDim.x)
+    for (int64_t v = threadIdx.x; v < vecs; v += 256) *(uint4*)(p + row * row_bytes + v * 16) = make_uint4(0, 0, 0, 0);
+}
+int omk_zero_rows_from(void* p, int64_t row_bytes, const int* first, int64_t M, hipStream_t s) {
+  if (M <= 0) return 0;
+  if (row_bytes % 16 || ((uintptr_t)p & 15)) OM_FAIL("zero_rows_from: rows of whole 16-byte vectors");
+  hipLaunchKernelGGL(zero_rows_from_kernel, dim3((unsigned)(M < 512 ? M : 512)), dim3(256), 0, s, (char*)p, row_bytes, first, M);
+  OM_LAUNCH_CHECK();
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -547,8 +570,11 @@ int omk_embed_bwd(int dtype, const void* dy, const int64_t* ids, const int64_t* 
 // (one block per sequence took 97 us for 72 x 128 x 768 outputs; H % 4 == 0 is checked by the callers of the encoder)
 template <typename T>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dp, const int64_t* __restrict__ mask,
-                                                       T* __restrict__ dh, int L, int H, int mode) {
+                                                       T* __restrict__ dh, int L, int H, int mode, const int* __restrict__ cu) {
+  // cu != NULL (packed rows): sequence b's rows are cu[b] .. cu[b + 1] - 1 of dh; the mask keeps its [B, L] layout
   const int64_t b = blockIdx.x;
+  const int64_t row0 = cu ? cu[b] : b * L;
+  const int Lb = cu ? cu[b + 1] - cu[b] : L;
   __shared__ float cnt_s;
   if (mode == OM_POOL_MEAN) {
     if (threadIdx.x < 64) {
@@ -561,7 +587,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
   }
   const float cnt = mode == OM_POOL_MEAN ? cnt_s : 1.f;
   const int h4 = H >> 2;
-  for (int t = blockIdx.y; t < L; t += gridDim.y) {
+  for (int t = blockIdx.y; t < Lb; t += gridDim.y) {
     const float wgt = mode == OM_POOL_FIRST ? (t == 0 ? 1.f : 0.f) : (float)mask[b * L + t] / cnt;
     for (int c4 = threadIdx.x; c4 < h4; c4 += 256) {
       float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -570,21 +596,21 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
         if (mode == OM_POOL_FIRST) { v[0] = d.x; v[1] = d.y; v[2] = d.z; v[3] = d.w; }
         else { v[0] = d.x * (float)mask[b * L + t] / cnt; v[1] = d.y * (float)mask[b * L + t] / cnt; v[2] = d.z * (float)mask[b * L + t] / cnt; v[3] = d.w * (float)mask[b * L + t] / cnt; }
       }
-      store4<T>(dh + (b * L + t) * H + c4 * 4, v);
+      store4<T>(dh + (row0 + t) * H + c4 * 4, v);
     }
   }
 }
 
 int omk_pool_bwd(int dtype, const float* dp, const int64_t* mask, void* dh, int64_t B, int L, int H,
-                 int mode, hipStream_t s) {
+                 int mode, hipStream_t s, const int* cu) {
   if (B <= 0) return 0;
   if (H % 4) OM_FAIL("hidden size must be a multiple of 4");
   int parts = (int)(2048 / B);
   parts = parts < 1 ? 1 : (parts > L ? L : parts);
   const dim3 grid((unsigned)B, (unsigned)parts);
-  if (dtype == OM_BF16) hipLaunchKernelGGL((pool_bwd_kernel<bf16_t>), grid, dim3(256), 0, s, dp, mask, (bf16_t*)dh, L, H, mode);
-  else if (dtype == OM_F16) hipLaunchKernelGGL((pool_bwd_kernel<f16_t>), grid, dim3(256), 0, s, dp, mask, (f16_t*)dh, L, H, mode);
-  else hipLaunchKernelGGL((pool_bwd_kernel<float>), grid, dim3(256), 0, s, dp, mask, (float*)dh, L, H, mode);
+  if (dtype == OM_BF16) hipLaunchKernelGGL((pool_bwd_kernel<bf16_t>), grid, dim3(256), 0, s, dp, mask, (bf16_t*)dh, L, H, mode, cu);
+  else if (dtype == OM_F16) hipLaunchKernelGGL((pool_bwd_kernel<f16_t>), grid, dim3(256), 0, s, dp, mask, (f16_t*)dh, L, H, mode, cu);
+  else hipLaunchKernelGGL((pool_bwd_kernel<float>), grid, dim3(256), 0, s, dp, mask, (float*)dh, L, H, mode, cu);
   OM_LAUNCH_CHECK();
   return 0;
 }
@@ -908,7 +934,12 @@ static int launch_attn_bwd(const void* qkv, const void* dctx, void* dqkv, const 
 
 int omk_attention_bwd(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask,
                       int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
-                      hipStream_t s) {
+                      hipStream_t s, const int* cu) {
+  if (cu) {           // packed rows: the transposing-read kernel only (16-bit, L <= 128)
+    if (!omk_attention_bwd16_ok(dtype, L, H, heads)) OM_FAIL("packed rows: attention backward for 16-bit formats, L <= 128");
+    if (B <= 0) return 0;
+    return omk_attention_bwd16(dtype, qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s, cu);
+  }
   return omk_attention_bwd_bias(dtype, qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, nullptr, nullptr, s);
 }
 
@@ -917,7 +948,7 @@ int omk_attention_bwd_bias(int dtype, const void* qkv, const void* dctx, void* d
                            const float* pos_bias, float* drel, hipStream_t s) {
   if (B <= 0) return 0;
   if (!pos_bias && omk_attention_bwd16_ok(dtype, L, H, heads))
-    return omk_attention_bwd16(dtype, qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s);
+    return omk_attention_bwd16(dtype, qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s, nullptr);
   if (L < 1 || L > 256) OM_FAIL("training supports sequence lengths up to 256");
   // the three transposed [64][L + 4] images of the backward kernel must fit the 160 KiB of LDS: 256 keys in 16 bits, 192 in f32
   if (dtype == OM_F32 && L > 192) OM_FAIL("float32 training supports sequence lengths up to 192 (16-bit formats: 256)");

@@ -381,6 +381,28 @@ def packed_rows_bound(mask):
     return rows if rows >= 512 else None
 
 
+TOKEN_ROWS_KEY = "om_token_rows"      # batch-dict entry (a Python int): the batch's token count as the HOST knows it -- see token_rows_of
+
+
+def token_rows_of(mask):
+    """Sum over sequences of (1 + index of the last unmasked token; L for an all-masked row) for an attention mask that still lives on
+    the HOST -- what the packed-rows entries need to size their row bound without a device synchronisation.  None for a device tensor."""
+    if not torch.is_tensor(mask) or mask.is_cuda or mask.dim() != 2:
+        return None
+    m = mask != 0
+    L = m.shape[1]
+    last = torch.where(m.any(1), L - m.flip(1).to(torch.int8).argmax(1), torch.full((m.shape[0],), L))
+    return int(last.sum())
+
+
+def rows_bound_of(tokens):
+    """Row bound of the packed entries for a token count: whole 256-row tiles, None below 512 rows."""
+    if tokens is None:
+        return None
+    rows = (int(tokens) + 255) // 256 * 256
+    return rows if rows >= 512 else None
+
+
 LAST_CALL = {}       # what the most recent hip_encode ran on: {"rows": token rows of the contractions, "packed": bool} (tests, bench)
 
 

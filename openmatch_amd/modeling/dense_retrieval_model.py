@@ -26,6 +26,7 @@ from ..arguments import DataArguments, ModelArguments
 from ..arguments import DRTrainingArguments as TrainingArguments
 from ..encoder import compute_dtype_code, hip_encode
 from ..feed import is_packed, token_rows_bound, unpack_token_batch
+from ..encoder import TOKEN_ROWS_KEY, rows_bound_of
 from ..ops import contrastive_loss, encode_with_grad
 from .linear import LinearHead
 
@@ -111,6 +112,9 @@ class DRModel(nn.Module):
         if is_packed(items):            # a batch straight from DRInferenceCollator (16-bit ids + lengths, feed.py): widen it here,
             rows = None if want_hidden else token_rows_bound(items)     # (its lengths are on the host: the bound of the packed-rows encoder)
             items = unpack_token_batch(items, next(model.parameters()).device)     # so `model(passage=batch)` works as with the reference's collator
+        token_rows = items.get(TOKEN_ROWS_KEY) if hasattr(items, "get") else None
+        if token_rows is not None:
+            items = {k: v for k, v in items.items() if k != TOKEN_ROWS_KEY}
         items = BatchEncoding(items)
         if "T5" in type(model).__name__ and not self.model_args.encoder_only:
             return self._encode_t5_decoder(items, model, head)
@@ -126,7 +130,9 @@ class DRModel(nn.Module):
                                          or getattr(cfg, "dropout_rate", 0.0) > 0)       # T5
         if needs_grad or has_dropout:      # train-mode forward (dropout), also under no_grad (GradCache)
             return encode_with_grad(model, head, items, self.pooling, self.normalize, code,
-                                    self.training)
+                                    self.training, packed_rows=rows_bound_of(token_rows))
+        if rows is None and not want_hidden:
+            rows = rows_bound_of(token_rows)        # (a mask that was still on the host when the trainer moved the batch)
         return hip_encode(model, items, self.pooling, head, self.normalize, code, want_hidden=want_hidden, packed_rows=rows)
 
     def _encode_t5_decoder(self, items, model, head):
@@ -190,6 +196,9 @@ class DRModel(nn.Module):
         merged = {}
         for key, q in query.items():
             p_ = passage[key]
+            if key == TOKEN_ROWS_KEY:          # (host-side token counts, DRTrainer._prepare_inputs): the merged batch has both
+                merged[key] = int(q) + int(p_)
+                continue
             q = q.to(p_.device)
             if q.dim() == 2 and q.shape[1] == lq and lq < lp:
                 fill = pad_id if key == "input_ids" else 0

@@ -17,7 +17,7 @@ from torch import Tensor, nn
 from transformers import AutoModel, BatchEncoding, PreTrainedModel, T5EncoderModel
 from transformers.modeling_outputs import ModelOutput
 
-from ..encoder import compute_dtype_code, hip_encode
+from ..encoder import TOKEN_ROWS_KEY, compute_dtype_code, hip_encode, rows_bound_of
 from ..feed import is_packed, token_rows_bound, unpack_token_batch
 from ..loss import rr_loss_functions
 from ..ops import encode_with_grad
@@ -74,7 +74,8 @@ class RRModel(nn.Module):
             raise ValueError("Unknown pooling type: {}".format(self.pooling))
         code = compute_dtype_code(self.model_args)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.lm.parameters()):
-            return encode_with_grad(self.lm, self.head, items, self.pooling, False, code, self.training)[1]
+            tokens = items.get(TOKEN_ROWS_KEY) if hasattr(items, "get") else None      # (host-side token count: packed rows in training)
+            return encode_with_grad(self.lm, self.head, items, self.pooling, False, code, self.training, packed_rows=rows_bound_of(tokens))[1]
         return hip_encode(self.lm, items, self.pooling, self.head, False, code, want_hidden=False, packed_rows=rows)[1]   # [B,1]
 
     def _encode_mono_t5(self, items):

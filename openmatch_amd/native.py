@@ -131,6 +131,16 @@ _SIGNATURES = {
                                           c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, C.c_uint64,
                                           c_void_p, c_void_p, C.POINTER(OmEncoderGrads), c_void_p, c_size_t,
                                           c_void_p]),
+    "om_encoder_train_packed_supported": (c_int, [C.POINTER(OmEncoderConfig), c_int64, c_int64, c_int64]),
+    "om_encoder_tape_bytes_packed": (c_size_t, [C.POINTER(OmEncoderConfig), c_int64, c_int64, c_int64]),
+    "om_encoder_train_workspace_bytes_packed": (c_size_t, [C.POINTER(OmEncoderConfig), c_int64, c_int64, c_int64]),
+    "om_encoder_train_forward_packed": (c_int, [C.POINTER(OmEncoderConfig), C.POINTER(OmEncoderWeights), c_void_p,
+                                                c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_float, C.c_uint64,
+                                                c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "om_encoder_train_backward_packed": (c_int, [C.POINTER(OmEncoderConfig), C.POINTER(OmEncoderWeights), c_void_p,
+                                                 c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_float, C.c_uint64,
+                                                 c_void_p, c_void_p, C.POINTER(OmEncoderGrads), c_void_p, c_size_t,
+                                                 c_void_p]),
     "om_encoder_train_forward_hidden": (c_int, [C.POINTER(OmEncoderConfig), C.POINTER(OmEncoderWeights), c_void_p,
                                                 c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, C.c_uint64,
                                                 c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p]),

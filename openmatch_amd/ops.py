@@ -79,6 +79,6 @@ def contrastive_loss(q_all, p_all, n_psg, scale, q_local, q_row0, p_local, p_row
     return _ContrastiveLoss.apply(q_local, p_local, q_all, p_all, n_psg, scale, q_row0, p_row0, target, REDUCTIONS[reduction])
 
 
-def encode_with_grad(model, head, items, pooling, normalize, code, training):
+def encode_with_grad(model, head, items, pooling, normalize, code, training, packed_rows=None):
     from .train import encode_train  # HIP forward-with-saves + backward (train.hip)
-    return encode_train(model, head, items, pooling, normalize, code, training)
+    return encode_train(model, head, items, pooling, normalize, code, training, packed_rows=packed_rows)

@@ -4,6 +4,7 @@ module's parameters exactly as autograd through HF's own forward would (referenc
 modeling/dense_retrieval_model.py:89-131, trainer/dense_trainer.py:102-108), without ever
 running that forward."""
 import ctypes as C
+import os
 
 import torch
 
@@ -132,26 +133,40 @@ def _encoder_grad_arena(model, head, cfg, device, extra=0):
 
 class _EncoderTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, head, ids, mask, tti, pooling, normalize, code, p_hidden, p_attn, seed, *params):
+    def forward(ctx, model, head, ids, mask, tti, pooling, normalize, code, p_hidden, p_attn, seed, rows, *params):
+        """rows > 0: the packed-rows pair (om_encoder_train_forward_packed / _backward_packed) over that many rows."""
         device = ids.device
         pk = packed_weights(model, head, code, device)
         cfg = N.OmEncoderConfig(pooling=_POOL[pooling], normalize=int(bool(normalize)), **pk.cfg)
         B, L = ids.shape
         D = cfg.head_out if cfg.head_in > 0 else cfg.hidden
         lib = N.lib()
+        rows = int(rows or 0)
+        if rows and not lib.om_encoder_train_packed_supported(C.byref(cfg), B, L, rows):
+            rows = 0                     # (a configuration or a switch the packed pair does not take: the padded pair, same results)
+        LAST_CALL.update(rows=rows if rows else B * L, packed=bool(rows))
         with torch.cuda.device(device):
-            tape = torch.empty(lib.om_encoder_tape_bytes(C.byref(cfg), B, L) + 256, dtype=torch.uint8, device=device)
+            ntape = lib.om_encoder_tape_bytes_packed(C.byref(cfg), B, L, rows) if rows else lib.om_encoder_tape_bytes(C.byref(cfg), B, L)
+            tape = torch.empty(ntape + 256, dtype=torch.uint8, device=device)
             tape_ptr = tape.data_ptr() + (-tape.data_ptr()) % 256
-            nws = lib.om_encoder_train_workspace_bytes(C.byref(cfg), B, L)
+            nws = (lib.om_encoder_train_workspace_bytes_packed(C.byref(cfg), B, L, rows) if rows
+                   else lib.om_encoder_train_workspace_bytes(C.byref(cfg), B, L))
             _buf, ws_ptr = N.Workspace.get(device, nws, "train")
             reps = torch.empty(B, D, device=device, dtype=torch.float32)
-            N.check(lib.om_encoder_train_forward(
-                C.byref(cfg), C.byref(pk.weights), N.ptr(ids), N.ptr(mask), N.ptr(tti), B, L,
-                float(p_hidden), float(p_attn), int(seed), C.c_void_p(tape_ptr), tape.numel() - 256,
-                N.ptr(reps), C.c_void_p(ws_ptr), nws, N.stream_ptr(device)))
+            if rows:
+                N.check(lib.om_encoder_train_forward_packed(
+                    C.byref(cfg), C.byref(pk.weights), N.ptr(ids), N.ptr(mask), N.ptr(tti), B, L, rows,
+                    float(p_hidden), float(p_attn), int(seed), C.c_void_p(tape_ptr), tape.numel() - 256,
+                    N.ptr(reps), C.c_void_p(ws_ptr), nws, N.stream_ptr(device)))
+            else:
+                N.check(lib.om_encoder_train_forward(
+                    C.byref(cfg), C.byref(pk.weights), N.ptr(ids), N.ptr(mask), N.ptr(tti), B, L,
+                    float(p_hidden), float(p_attn), int(seed), C.c_void_p(tape_ptr), tape.numel() - 256,
+                    N.ptr(reps), C.c_void_p(ws_ptr), nws, N.stream_ptr(device)))
         ctx.model, ctx.head, ctx.cfg, ctx.pk = model, head, cfg, pk
         ctx.ids, ctx.mask, ctx.tti, ctx.tape, ctx.tape_ptr = ids, mask, tti, tape, tape_ptr
         ctx.drop = (float(p_hidden), float(p_attn), int(seed))
+        ctx.rows = rows
         ctx.n_params = len(params)
         return reps
 
@@ -161,6 +176,7 @@ class _EncoderTrain(torch.autograd.Function):
         device = ctx.ids.device
         B, L = ctx.ids.shape
         nl = cfg.n_layers
+        rows = ctx.rows
         arena, g, grads, layer_bounds, _cursor, _buf_fn, _keep = _encoder_grad_arena(model, head, cfg, device)
         d_reps = d_reps.to(torch.float32).contiguous()
         lib = N.lib()
@@ -176,21 +192,33 @@ class _EncoderTrain(torch.autograd.Function):
                     e.record(torch.cuda.current_stream(device))           # materialises the hipEvent_t handle
                 handles = (C.c_void_p * (nl + 1))(*[e.cuda_event for e in events])
                 N.check(lib.om_encoder_train_set_layer_events(handles, nl + 1))
-            nws = lib.om_encoder_train_workspace_bytes(C.byref(cfg), B, L)
+            nws = (lib.om_encoder_train_workspace_bytes_packed(C.byref(cfg), B, L, rows) if rows
+                   else lib.om_encoder_train_workspace_bytes(C.byref(cfg), B, L))
             _buf, ws_ptr = N.Workspace.get(device, nws, "train")
-            N.check(lib.om_encoder_train_backward(
-                C.byref(cfg), C.byref(pk.weights), N.ptr(ctx.ids), N.ptr(ctx.mask), N.ptr(ctx.tti), B, L,
-                ctx.drop[0], ctx.drop[1], ctx.drop[2], C.c_void_p(ctx.tape_ptr), N.ptr(d_reps), C.byref(g),
-                C.c_void_p(ws_ptr), nws, N.stream_ptr(device)))
+            if rows:
+                N.check(lib.om_encoder_train_backward_packed(
+                    C.byref(cfg), C.byref(pk.weights), N.ptr(ctx.ids), N.ptr(ctx.mask), N.ptr(ctx.tti), B, L, rows,
+                    ctx.drop[0], ctx.drop[1], ctx.drop[2], C.c_void_p(ctx.tape_ptr), N.ptr(d_reps), C.byref(g),
+                    C.c_void_p(ws_ptr), nws, N.stream_ptr(device)))
+            else:
+                N.check(lib.om_encoder_train_backward(
+                    C.byref(cfg), C.byref(pk.weights), N.ptr(ctx.ids), N.ptr(ctx.mask), N.ptr(ctx.tti), B, L,
+                    ctx.drop[0], ctx.drop[1], ctx.drop[2], C.c_void_p(ctx.tape_ptr), N.ptr(d_reps), C.byref(g),
+                    C.c_void_p(ws_ptr), nws, N.stream_ptr(device)))
         if sync is not None:
             sync.reduce_arena(arena, layer_bounds, events)
         ctx.tape = None
-        return (None,) * 11 + tuple(grads)
+        return (None,) * 12 + tuple(grads)
 
 
-def encode_train(model, head, items, pooling, normalize, code, training):
+LAST_CALL = {"rows": 0, "packed": False}       # what the last training forward ran over (tests, tools)
+
+
+def encode_train(model, head, items, pooling, normalize, code, training, packed_rows=None):
     """(None, reps) with an autograd edge from `reps` to every encoder / head parameter.
-    Dropout follows the HF config only in training mode (model.train())."""
+    Dropout follows the HF config only in training mode (model.train()).
+    packed_rows: a bound on the batch's token count known on the HOST (encoder.packed_rows_bound of the collator's lengths) --
+    the step then runs over that many rows instead of B x L where the packed pair takes the configuration (OM_TRAIN_PACKED=0: never)."""
     code = training_code(code, model)
     ids = items["input_ids"].to(torch.int64).contiguous()
     mask = items["attention_mask"].to(device=ids.device, dtype=torch.int64).contiguous()
@@ -208,7 +236,8 @@ def encode_train(model, head, items, pooling, normalize, code, training):
         p_hidden = p_attn = float(cfg.dropout_rate) if training else 0.0
     seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p_hidden > 0 or p_attn > 0) else 0
     params = _bert_params(model, head) if bert else _t5_params(model, head)
-    reps = _EncoderTrain.apply(model, head, ids, mask, tti, pooling, normalize, code, p_hidden, p_attn, seed,
+    rows = int(packed_rows) if (packed_rows and bert and os.environ.get("OM_TRAIN_PACKED", "1") != "0") else 0
+    reps = _EncoderTrain.apply(model, head, ids, mask, tti, pooling, normalize, code, p_hidden, p_attn, seed, rows,
                                *params)
     return None, reps
 

@@ -175,13 +175,21 @@ class DRTrainer:
             self._save(output_dir)
 
     def _prepare_inputs(self, inputs: Tuple[Dict[str, Union[torch.Tensor, Any]], ...]) -> List[Dict[str, Any]]:
+        from ..encoder import TOKEN_ROWS_KEY, token_rows_of
         dev = self.args.device
         out = []
         for x in inputs:
             if isinstance(x, torch.Tensor):
                 out.append(x.to(dev, non_blocking=True))
             else:
-                out.append({k: (v.to(dev, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in x.items()})
+                moved = {k: (v.to(dev, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in x.items()}
+                # packed rows in training (round 5): while the collator's mask is still on the HOST, note how many token rows the
+                # batch really has -- the training forward then runs over those instead of B x L (openmatch_amd/train.py)
+                if hasattr(x, "keys") and TOKEN_ROWS_KEY not in x and "attention_mask" in x:
+                    tokens = token_rows_of(x["attention_mask"])
+                    if tokens is not None:
+                        moved[TOKEN_ROWS_KEY] = tokens
+                out.append(moved)
         return out
 
     def get_train_dataloader(self) -> DataLoader:
@@ -462,7 +470,7 @@ def split_dense_inputs(model_input: dict, chunk_size: int):
     """{"query": {k: [B,...]}} -> list of {"query": {k: [chunk,...]}} (reference :111-120)."""
     assert len(model_input) == 1
     (arg_key, arg_val), = model_input.items()
-    keys = list(arg_val.keys())
+    keys = [k for k in arg_val.keys() if torch.is_tensor(arg_val[k])]     # (host-side notes such as the token count do not split)
     pieces = zip(*[arg_val[k].split(chunk_size, dim=0) for k in keys])
     return [{arg_key: dict(zip(keys, piece))} for piece in pieces]
 

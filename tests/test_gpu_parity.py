@@ -1709,6 +1709,112 @@ def test_cross_device_negatives_over_a_one_rank_rccl_group_equal_the_local_step(
             assert a.grad is not None and torch.allclose(a.grad, b.grad, rtol=1e-4, atol=1e-6), n
 
 
+def _ragged_train_batch(rng, B, L, vocab=600):
+    ids, mask = synth_tokens(rng, B, L, vocab=vocab, lo_len=3, lo_id=300)
+    ids[0, :], mask[0, :] = rng.integers(300, vocab, L), 1        # a full-length row
+    mask[1, :] = 0; mask[1, ::3] = 1                              # holes
+    mask[2, :] = 0                                                # a row without any token
+    return torch.from_numpy(ids), torch.from_numpy(mask)
+
+
+@pytest.mark.parametrize("pooling", ["first", "mean"])
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_packed_rows_training_step_matches_the_padded_step(dtype, pooling):
+    """Round 5: om_encoder_train_forward_packed / _backward_packed run the training step over the tokens up to each sequence's last
+    unmasked one instead of B x L (the reference pads and computes over the padding, dataset/data_collator.py:13-24).  Same
+    representations and the same gradient for EVERY parameter as the padded pair, up to the order of 16-bit-sized sums: ragged
+    lengths, a full row, a mask with holes, an empty row; a row bound below the token count poisons the step (NaN) instead of
+    truncating it; with dropout the step runs and stays finite."""
+    from transformers import BertConfig, BertModel
+    from openmatch_amd import train as T
+    from openmatch_amd.encoder import compute_dtype_code, rows_bound_of, token_rows_of
+    torch.manual_seed(41)
+    cfg = BertConfig(hidden_size=256, num_hidden_layers=3, num_attention_heads=4, intermediate_size=1024, vocab_size=600,
+                     max_position_embeddings=128, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    lm = BertModel(cfg).to(DEV).train()
+    rng = np.random.default_rng(6)
+    B, L = 24, 128
+    ids, mask = _ragged_train_batch(rng, B, L)
+    tokens = token_rows_of(mask)
+    rows = rows_bound_of(tokens)
+    assert rows is not None and rows < B * L
+    items = {"input_ids": ids.to(DEV), "attention_mask": mask.to(DEV)}
+    code = compute_dtype_code(NS(dtype=dtype))
+    wgt = torch.randn(B, 256, generator=torch.Generator().manual_seed(2)).to(DEV)
+    wgt[2] = 0                       # (the empty row's representation is whatever a softmax over no keys gives: out of the loss)
+
+    def step(packed_rows):
+        lm.zero_grad(set_to_none=True)
+        reps = T.encode_train(lm, None, items, pooling, False, code, True, packed_rows=packed_rows)[1]
+        (reps * wgt).sum().backward()
+        return reps.detach().clone(), {n: p.grad.detach().clone() for n, p in lm.named_parameters() if p.grad is not None}
+
+    reps0, g0 = step(None)
+    assert T.LAST_CALL == {"rows": B * L, "packed": False}
+    reps1, g1 = step(rows)
+    assert T.LAST_CALL == {"rows": rows, "packed": True}
+    keep = torch.ones(B, dtype=torch.bool); keep[2] = False
+    err = (reps1[keep] - reps0[keep]).abs().max().item() / reps0[keep].abs().max().item()
+    assert torch.isfinite(reps1).all() and err < 2e-3, err
+    assert set(g0) == set(g1)
+    worst = ("", 0.0)
+    for n in g0:
+        a, b = g0[n].float(), g1[n].float()
+        assert torch.isfinite(b).all(), n
+        rel = ((a - b).norm() / a.norm().clamp_min(1e-12)).item()
+        if a.norm().item() > 1e-6 and rel > worst[1]:
+            worst = (n, rel)
+    print(f"\n[packed training step, {dtype}, {pooling}] {tokens} tokens -> {rows} of {B * L} rows; reps max rel err {err:.2e}; worst gradient rel-L2 vs padded {worst[1]:.2e} ({worst[0]})")
+    assert worst[1] < 2e-2, worst
+    # a bound below the token count: NaN representations, never a truncated batch
+    small = (tokens // 256) * 256 - 256
+    if small >= 512:
+        reps_bad, _ = step(small)
+        assert T.LAST_CALL["packed"] and torch.isnan(reps_bad).all()
+    # dropout: runs, finite, different from the deterministic step
+    lm.config.hidden_dropout_prob = lm.config.attention_probs_dropout_prob = 0.1
+    try:
+        reps2, g2 = step(rows)
+    finally:
+        lm.config.hidden_dropout_prob = lm.config.attention_probs_dropout_prob = 0.0
+    assert T.LAST_CALL["packed"] and torch.isfinite(reps2[keep]).all() and all(torch.isfinite(v).all() for v in g2.values())
+    assert not torch.equal(reps2, reps1)
+
+
+def test_trainer_takes_packed_rows_when_the_mask_is_still_on_the_host(golden, tmp_path, monkeypatch):
+    """DRTrainer._prepare_inputs notes the batch's token count while the collator's mask is on the host; the one-pass training
+    forward (queries padded to the passage length and encoded with the passages) then runs over the packed rows.  Same loss and
+    gradients as with the switch off (OM_TRAIN_PACKED=0), to 16-bit noise; a batch that is already on the device keeps the padded pair."""
+    from transformers import BertConfig, BertModel
+    from openmatch.modeling import DRModel
+    from openmatch.trainer import DRTrainer
+    from openmatch_amd import train as T
+    torch.manual_seed(43)
+    cfg = BertConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024, vocab_size=600,
+                     max_position_embeddings=128, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    lm = BertModel(cfg)
+    rng = np.random.default_rng(8)
+    q_ids, q_mask = synth_tokens(rng, 4, 32, vocab=600, lo_len=4, lo_id=300)
+    p_ids, p_mask = synth_tokens(rng, 32, 128, vocab=600, lo_len=10, lo_id=300)
+    host = ({"input_ids": torch.from_numpy(q_ids), "attention_mask": torch.from_numpy(q_mask)},
+            {"input_ids": torch.from_numpy(p_ids), "attention_mask": torch.from_numpy(p_mask)})
+    res = {}
+    for mode in ("packed", "off", "device"):
+        model = DRModel(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype="bfloat16"),
+                        data_args=NS(train_n_passages=8), train_args=NS(negatives_x_device=False, per_device_train_batch_size=4)).to(DEV)
+        model.zero_grad(set_to_none=True)
+        monkeypatch.setenv("OM_TRAIN_PACKED", "0" if mode == "off" else "1")
+        t = DRTrainer(model=model, args=_trainer_args(tmp_path), train_dataset=None)
+        batch = host if mode != "device" else tuple({k: v.to(DEV) for k, v in b.items()} for b in host)
+        loss = float(t.training_step(model, batch))
+        assert T.LAST_CALL["packed"] == (mode == "packed"), (mode, T.LAST_CALL)
+        res[mode] = (loss, {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert res["packed"][0] == pytest.approx(res["off"][0], rel=2e-3, abs=2e-3) and res["device"][0] == pytest.approx(res["off"][0], rel=1e-6, abs=1e-6)
+    for n, a in res["off"][1].items():
+        b = res["packed"][1][n]
+        assert ((a - b).norm() / a.norm().clamp_min(1e-12)).item() < 3e-2 or a.norm().item() < 1e-6, n
+
+
 @pytest.mark.parametrize("fp16", [False, True])
 def test_gradient_cache_step_equals_full_batch_step(golden, tmp_path, fp16):
     """GCDenseTrainer (chunked, re-encoded) must give the SAME gradients as one full-batch step; under --fp16 (float16 kernels, the
