@@ -281,7 +281,19 @@ def train_leg(device, steps=8):
     batch = tuple({k: v.to(device) for k, v in b.items()} for b in (mk(8, 32), mk(64, 128)))
     flop = 3 * (8 * 5.474e9 + 64 * GFLOP_PER_PASSAGE * 1e9)
 
-    def run(fp16, dtype, res32):
+    # the same step on RAGGED lengths (queries U{4..32}, passages U{16..128} tokens, right-padded: what a collator hands over) --
+    # padded pair vs the packed-rows pair of round 5 (om_encoder_train_forward_packed: the step runs over the tokens, not over B x L)
+    from openmatch_amd.encoder import TOKEN_ROWS_KEY, token_rows_of
+    from openmatch_amd import train as T
+    gl = torch.Generator().manual_seed(3)
+    def ragged_of(b, lo):
+        L = b["input_ids"].shape[1]
+        lens = torch.randint(lo, L + 1, (b["input_ids"].shape[0],), generator=gl)
+        m = (torch.arange(L)[None, :] < lens[:, None]).long()
+        return {"input_ids": b["input_ids"], "attention_mask": m.to(device)}, token_rows_of(m)
+    ragged = [ragged_of(batch[0], 4), ragged_of(batch[1], 16)]
+
+    def run(fp16, dtype, res32, rag=None):
         torch.manual_seed(0)
         lm = BertModel(BertConfig(hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1))
         model = DRModel(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype=dtype),
@@ -294,9 +306,12 @@ def train_leg(device, steps=8):
         # openmatch_amd.optim.FusedAdamW: clip + AdamW + the refresh of the packed 16-bit weights in one pass
         trainer.create_optimizer_and_scheduler(num_training_steps=10 ** 6)
         N.check(N.lib().om_debug_option(18, int(res32)))              # OM_OPT_TRAIN_RES32
+        use = batch
+        if rag is not None:         # "packed": the token counts ride along, as DRTrainer._prepare_inputs notes them for a host-side batch
+            use = tuple(dict(b, **({TOKEN_ROWS_KEY: n} if rag == "packed" else {})) for b, n in ragged)
         try:
             def step():
-                loss = trainer.training_step(model, batch)
+                loss = trainer.training_step(model, use)
                 trainer.optimizer_step()
                 return loss
             for _ in range(3):
@@ -313,6 +328,9 @@ def train_leg(device, steps=8):
         sc = trainer._loss_scaler()
         if sc is not None:
             out["loss_scale"] = float(sc.state[0]); out["skipped_steps"] = sc.skipped_steps()
+        if rag is not None:
+            out["rows"] = dict(T.LAST_CALL); out["tokens"] = [n for _, n in ragged]
+            out.pop("algorithmic_tflops"); out.pop("frac_of_mfma_peak")          # (priced for full-length rows)
         del model, trainer
         torch.cuda.empty_cache()
         return out
@@ -322,6 +340,10 @@ def train_leg(device, steps=8):
     out.update(run(True, "float16", 1))
     out["bf16"] = dict(run(False, "bfloat16", 1), mode="bfloat16 kernels, f32 residual stream")
     out["bf16_res16"] = dict(run(False, "bfloat16", 0), mode="bfloat16 kernels, 16-bit residual stream (OM_TRAIN_RES32=0): the data flow of rounds 1-4")
+    out["ragged"] = {"note": "the --fp16 step on ragged lengths (queries U{4..32}, passages U{16..128} tokens): the padded pair computes over B x L rows as the "
+                             "reference does, the packed pair (round 5) over the tokens up to each sequence's last unmasked one -- same gradients (tests)",
+                     "padded": run(True, "float16", 1, "padded"), "packed": run(True, "float16", 1, "packed")}
+    out["ragged"]["speedup"] = round(out["ragged"]["packed"]["value"] / out["ragged"]["padded"]["value"], 3)
     return out
 
 

@@ -11,6 +11,8 @@ from types import SimpleNamespace as NS
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--ragged", action="store_true", help="ragged sequence lengths instead of full-length rows")
+    ap.add_argument("--packed", type=int, default=1, help="with --ragged: 1 = the packed-rows training pair, 0 = the padded pair")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--optimizer", default="fused", help="fused: the product's FusedAdamW (clip + AdamW + weight refresh in one pass); "
@@ -33,10 +35,25 @@ def main():
                     train_args=NS(negatives_x_device=False, per_device_train_batch_size=8)).to(dev)
     g = torch.Generator().manual_seed(1)
     mk = lambda n, L: {"input_ids": torch.randint(1000, 30000, (n, L), generator=g), "attention_mask": torch.ones(n, L, dtype=torch.long)}
+    if a.ragged:            # lengths ~ U{8..32} / U{16..128} (as bench.py's ragged encode batches), right-padded: what a collator hands over
+        gl = torch.Generator().manual_seed(3)
+        def rag(b, lo):
+            L = b["input_ids"].shape[1]
+            lens = torch.randint(lo, L + 1, (b["input_ids"].shape[0],), generator=gl)
+            b["attention_mask"] = (torch.arange(L)[None, :] < lens[:, None]).long()
+            return b
+        mk_r = mk
+        mk = lambda n, L: rag(mk_r(n, L), max(2, L // 8))
     ap_host = os.environ.get("TRAIN_BENCH_HOST_BATCH") == "1"       # 1: pageable host tensors, copied (synchronously) every step as before round 5
     batch = (mk(8, 32), mk(64, 128))
+    tokens = None
     if not ap_host:
+        from openmatch_amd.encoder import TOKEN_ROWS_KEY, token_rows_of
+        tokens = [token_rows_of(b["attention_mask"]) for b in batch]
         batch = tuple({k: v.to(dev) for k, v in b.items()} for b in batch)
+        if a.ragged and a.packed:      # the token counts a trainer notes while the collator's batch is still on the host
+            for b, n in zip(batch, tokens):
+                b[TOKEN_ROWS_KEY] = n
     args = NS(device=dev, world_size=1, process_index=0, per_device_train_batch_size=8, negatives_x_device=False,
               learning_rate=5e-6, weight_decay=0.0, adam_beta1=0.9, adam_beta2=0.999, adam_epsilon=1e-8,
               gradient_accumulation_steps=1, max_grad_norm=1.0, fp16=a.precision == "f16", bf16=False)      # f16: float16 kernels + the dynamic loss scale
@@ -63,7 +80,8 @@ def main():
     flop = 3 * (8 * 5.474e9 + 64 * 22.347e9)
     print(json.dumps({"metric": "contrastive train steps/s (8 q x 32 + 64 p x 128, bert-base, fwd+bwd+AdamW)", "steps_per_s": round(1 / dt, 2),
                       "ms_per_step": round(dt * 1e3, 2), "precision": a.precision, "dropout": a.dropout, "wgrad_wgs": a.wgrad_wgs, "optimizer": a.optimizer,
-                      "algorithmic_tflops": round(flop / dt / 1e12, 1), "loss": float(loss)}))
+                      "algorithmic_tflops": round(flop / dt / 1e12, 1), "loss": float(loss), "ragged": bool(a.ragged),
+                      "tokens": tokens, "rows": __import__("openmatch_amd.train", fromlist=["LAST_CALL"]).LAST_CALL}))
 
 
 if __name__ == "__main__":
