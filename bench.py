@@ -329,7 +329,7 @@ def train_leg(device, steps=8):
         if sc is not None:
             out["loss_scale"] = float(sc.state[0]); out["skipped_steps"] = sc.skipped_steps()
         if rag is not None:
-            out["rows"] = dict(T.LAST_CALL); out["tokens"] = [n for _, n in ragged]
+            out["rows"] = dict(T.LAST_CALL); out["tokens"] = [int(n.sum()) for _, n in ragged]
             out.pop("algorithmic_tflops"); out.pop("frac_of_mfma_peak")          # (priced for full-length rows)
         del model, trainer
         torch.cuda.empty_cache()

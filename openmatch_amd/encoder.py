@@ -385,21 +385,24 @@ TOKEN_ROWS_KEY = "om_token_rows"      # batch-dict entry (a Python int): the bat
 
 
 def token_rows_of(mask):
-    """Sum over sequences of (1 + index of the last unmasked token; L for an all-masked row) for an attention mask that still lives on
-    the HOST -- what the packed-rows entries need to size their row bound without a device synchronisation.  None for a device tensor."""
+    """Per sequence: 1 + index of the last unmasked token (L for an all-masked row), as a HOST int64 tensor [B], for an attention mask
+    that still lives on the host -- what the packed-rows entries need to size their row bound without a device synchronisation (the
+    sum is the batch's token count; per sequence so that a batch that is split into chunks or merged keeps its counts).  None for a
+    device tensor."""
     if not torch.is_tensor(mask) or mask.is_cuda or mask.dim() != 2:
         return None
     m = mask != 0
     L = m.shape[1]
-    last = torch.where(m.any(1), L - m.flip(1).to(torch.int8).argmax(1), torch.full((m.shape[0],), L))
-    return int(last.sum())
+    return torch.where(m.any(1), L - m.flip(1).to(torch.int8).argmax(1), torch.full((m.shape[0],), L)).to(torch.int64)
 
 
 def rows_bound_of(tokens):
-    """Row bound of the packed entries for a token count: whole 256-row tiles, None below 512 rows."""
+    """Row bound of the packed entries for a token count (an int, or token_rows_of's per-sequence tensor): whole 256-row tiles, None
+    below 512 rows."""
     if tokens is None:
         return None
-    rows = (int(tokens) + 255) // 256 * 256
+    total = int(tokens.sum()) if torch.is_tensor(tokens) else int(tokens)
+    rows = (total + 255) // 256 * 256
     return rows if rows >= 512 else None
 
 

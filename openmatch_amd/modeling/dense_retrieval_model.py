@@ -197,7 +197,8 @@ class DRModel(nn.Module):
         for key, q in query.items():
             p_ = passage[key]
             if key == TOKEN_ROWS_KEY:          # (host-side token counts, DRTrainer._prepare_inputs): the merged batch has both
-                merged[key] = int(q) + int(p_)
+                as_t = lambda v: v if torch.is_tensor(v) else torch.tensor([int(v)])
+                merged[key] = torch.cat([as_t(q), as_t(p_)])
                 continue
             q = q.to(p_.device)
             if q.dim() == 2 and q.shape[1] == lq and lq < lp:

@@ -470,7 +470,7 @@ def split_dense_inputs(model_input: dict, chunk_size: int):
     """{"query": {k: [B,...]}} -> list of {"query": {k: [chunk,...]}} (reference :111-120)."""
     assert len(model_input) == 1
     (arg_key, arg_val), = model_input.items()
-    keys = [k for k in arg_val.keys() if torch.is_tensor(arg_val[k])]     # (host-side notes such as the token count do not split)
+    keys = [k for k in arg_val.keys() if torch.is_tensor(arg_val[k])]     # (the host-side per-sequence token counts split with the rows)
     pieces = zip(*[arg_val[k].split(chunk_size, dim=0) for k in keys])
     return [{arg_key: dict(zip(keys, piece))} for piece in pieces]
 

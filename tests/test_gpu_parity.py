@@ -1735,9 +1735,9 @@ def test_packed_rows_training_step_matches_the_padded_step(dtype, pooling):
     rng = np.random.default_rng(6)
     B, L = 24, 128
     ids, mask = _ragged_train_batch(rng, B, L)
-    tokens = token_rows_of(mask)
-    rows = rows_bound_of(tokens)
-    assert rows is not None and rows < B * L
+    tokens = int(token_rows_of(mask).sum())
+    rows = rows_bound_of(token_rows_of(mask))
+    assert rows is not None and rows == rows_bound_of(tokens) and rows < B * L
     items = {"input_ids": ids.to(DEV), "attention_mask": mask.to(DEV)}
     code = compute_dtype_code(NS(dtype=dtype))
     wgt = torch.randn(B, 256, generator=torch.Generator().manual_seed(2)).to(DEV)
@@ -1812,6 +1812,19 @@ def test_trainer_takes_packed_rows_when_the_mask_is_still_on_the_host(golden, tm
     assert res["packed"][0] == pytest.approx(res["off"][0], rel=2e-3, abs=2e-3) and res["device"][0] == pytest.approx(res["off"][0], rel=1e-6, abs=1e-6)
     for n, a in res["off"][1].items():
         b = res["packed"][1][n]
+        assert ((a - b).norm() / a.norm().clamp_min(1e-12)).item() < 3e-2 or a.norm().item() < 1e-6, n
+    # the gradient-cache trainer: the per-sequence token counts split with the chunks, so a chunk of 16 passages runs packed too
+    from openmatch.trainer import GCDenseTrainer
+    monkeypatch.setenv("OM_TRAIN_PACKED", "1")
+    model = DRModel(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype="bfloat16"),
+                    data_args=NS(train_n_passages=8), train_args=NS(negatives_x_device=False, per_device_train_batch_size=4)).to(DEV)
+    model.zero_grad(set_to_none=True)
+    t = GCDenseTrainer(model=model, args=_trainer_args(tmp_path, gc_q_chunk_size=4, gc_p_chunk_size=16), train_dataset=None)
+    loss = float(t.training_step(model, host))
+    assert T.LAST_CALL["packed"] and T.LAST_CALL["rows"] < 16 * 128
+    assert loss == pytest.approx(res["off"][0], rel=2e-3, abs=2e-3)
+    for n, a in res["off"][1].items():
+        b = dict(model.named_parameters())[n].grad
         assert ((a - b).norm() / a.norm().clamp_min(1e-12)).item() < 3e-2 or a.norm().item() < 1e-6, n
 
 

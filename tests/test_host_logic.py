@@ -567,3 +567,22 @@ def test_model_batch_and_packed_rows_apply_conditions():
         assert not ok()
     finally:
         del os.environ["OM_ENCODER_PACKED"]
+
+
+def test_host_side_token_counts_split_and_merge():
+    """openmatch_amd.encoder.token_rows_of / rows_bound_of (packed rows in training): per-sequence extents of a host-side mask -- last
+    unmasked token + 1, L for an all-masked row, holes counted -- their bound in whole 256-row tiles (None below 512 rows), and the
+    gradient-cache chunking keeps them per chunk (trainer/dense_trainer.py:split_dense_inputs)."""
+    import torch
+    from openmatch_amd.encoder import TOKEN_ROWS_KEY, rows_bound_of, token_rows_of
+    from openmatch_amd.trainer.dense_trainer import split_dense_inputs
+    m = torch.zeros(6, 128, dtype=torch.long)
+    m[0, :128] = 1; m[1, :5] = 1; m[2, ::7] = 1; m[4, :64] = 1; m[5, 100] = 1          # row 3: nothing unmasked
+    ext = token_rows_of(m)
+    assert ext.tolist() == [128, 5, 127, 128, 64, 101] and ext.dtype == torch.int64 and not ext.is_cuda
+    assert rows_bound_of(ext) == 768 and rows_bound_of(553) == 768 and rows_bound_of(512) == 512 and rows_bound_of(511) == 512
+    assert rows_bound_of(100) is None and rows_bound_of(None) is None and rows_bound_of(ext[1:3]) is None
+    assert token_rows_of(m[0]) is None and token_rows_of("x") is None
+    chunks = split_dense_inputs({"passage": {"input_ids": m.clone(), "attention_mask": m, TOKEN_ROWS_KEY: ext, "note": 3}}, 4)
+    assert [c["passage"][TOKEN_ROWS_KEY].tolist() for c in chunks] == [[128, 5, 127, 128], [64, 101]]
+    assert all("note" not in c["passage"] and c["passage"]["attention_mask"].shape[0] == len(c["passage"][TOKEN_ROWS_KEY]) for c in chunks)

@@ -81,7 +81,7 @@ def main():
     print(json.dumps({"metric": "contrastive train steps/s (8 q x 32 + 64 p x 128, bert-base, fwd+bwd+AdamW)", "steps_per_s": round(1 / dt, 2),
                       "ms_per_step": round(dt * 1e3, 2), "precision": a.precision, "dropout": a.dropout, "wgrad_wgs": a.wgrad_wgs, "optimizer": a.optimizer,
                       "algorithmic_tflops": round(flop / dt / 1e12, 1), "loss": float(loss), "ragged": bool(a.ragged),
-                      "tokens": tokens, "rows": __import__("openmatch_amd.train", fromlist=["LAST_CALL"]).LAST_CALL}))
+                      "tokens": None if tokens is None else [int(n.sum()) for n in tokens], "rows": __import__("openmatch_amd.train", fromlist=["LAST_CALL"]).LAST_CALL}))
 
 
 if __name__ == "__main__":
