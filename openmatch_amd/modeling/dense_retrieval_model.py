@@ -128,7 +128,10 @@ class DRModel(nn.Module):
         has_dropout = self.training and (getattr(cfg, "hidden_dropout_prob", 0.0) > 0
                                          or getattr(cfg, "attention_probs_dropout_prob", 0.0) > 0
                                          or getattr(cfg, "dropout_rate", 0.0) > 0)       # T5
-        if needs_grad or has_dropout:      # train-mode forward (dropout), also under no_grad (GradCache)
+        # train-mode forward: with autograd on, with dropout, and for ANY forward of a model in training mode -- the gradient-cache
+        # trainer's first, tape-less pass must produce the representations its second pass differentiates (the inference kernels'
+        # differ from the training forward's in the last 16-bit digits, which a contrastive loss over near-equal scores amplifies)
+        if needs_grad or has_dropout or (self.training and any(p.requires_grad for p in model.parameters())):
             return encode_with_grad(model, head, items, self.pooling, self.normalize, code,
                                     self.training, packed_rows=rows_bound_of(token_rows))
         if rows is None and not want_hidden:

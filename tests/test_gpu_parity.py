@@ -1813,19 +1813,26 @@ def test_trainer_takes_packed_rows_when_the_mask_is_still_on_the_host(golden, tm
     for n, a in res["off"][1].items():
         b = res["packed"][1][n]
         assert ((a - b).norm() / a.norm().clamp_min(1e-12)).item() < 3e-2 or a.norm().item() < 1e-6, n
-    # the gradient-cache trainer: the per-sequence token counts split with the chunks, so a chunk of 16 passages runs packed too
+    # the gradient-cache trainer: the per-sequence token counts split with the chunks, so a chunk of 16 passages runs packed too;
+    # its first, tape-less pass runs the TRAINING forward (a model in training mode always does), so the step differentiates the
+    # representations the loss saw and lands on the full-batch step's gradients
     from openmatch.trainer import GCDenseTrainer
-    monkeypatch.setenv("OM_TRAIN_PACKED", "1")
-    model = DRModel(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype="bfloat16"),
-                    data_args=NS(train_n_passages=8), train_args=NS(negatives_x_device=False, per_device_train_batch_size=4)).to(DEV)
-    model.zero_grad(set_to_none=True)
-    t = GCDenseTrainer(model=model, args=_trainer_args(tmp_path, gc_q_chunk_size=4, gc_p_chunk_size=16), train_dataset=None)
-    loss = float(t.training_step(model, host))
-    assert T.LAST_CALL["packed"] and T.LAST_CALL["rows"] < 16 * 128
-    assert loss == pytest.approx(res["off"][0], rel=2e-3, abs=2e-3)
-    for n, a in res["off"][1].items():
-        b = dict(model.named_parameters())[n].grad
-        assert ((a - b).norm() / a.norm().clamp_min(1e-12)).item() < 3e-2 or a.norm().item() < 1e-6, n
+    gc = {}
+    for mode in ("packed", "off"):
+        monkeypatch.setenv("OM_TRAIN_PACKED", "0" if mode == "off" else "1")
+        model = DRModel(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype="bfloat16"),
+                        data_args=NS(train_n_passages=8), train_args=NS(negatives_x_device=False, per_device_train_batch_size=4)).to(DEV)
+        model.zero_grad(set_to_none=True)
+        t = GCDenseTrainer(model=model, args=_trainer_args(tmp_path, gc_q_chunk_size=4, gc_p_chunk_size=16), train_dataset=None)
+        loss = float(t.training_step(model, host))
+        assert T.LAST_CALL["packed"] == (mode == "packed") and (mode == "off" or T.LAST_CALL["rows"] < 16 * 128)
+        gc[mode] = (loss, {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert gc["packed"][0] == pytest.approx(gc["off"][0], rel=1e-6, abs=1e-6) and gc["off"][0] == pytest.approx(res["off"][0], rel=2e-3, abs=2e-3)
+    for n, a in gc["off"][1].items():
+        b = gc["packed"][1][n]
+        assert ((a - b).norm() / a.norm().clamp_min(1e-12)).item() < 1e-3 or a.norm().item() < 1e-6, n
+        full = res["off"][1][n]
+        assert ((a - full).norm() / full.norm().clamp_min(1e-12)).item() < 3e-2 or full.norm().item() < 1e-6, n
 
 
 @pytest.mark.parametrize("fp16", [False, True])
