@@ -40,7 +40,7 @@ int omk_small_nn(const float* A, const float* Bm, float* C, int I, int J, int Cc
 int omk_small_tn(const float* A, const float* Bm, float* C, int I, int J, int Cc, hipStream_t s);
 int omk_attention_bwd(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask,
                       int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
-                      hipStream_t s, const int* cu = nullptr /* packed rows (16-bit, L <= 128): sequence b is rows cu[b] .. cu[b + 1] - 1 */);
+                      hipStream_t s, const int* cu = nullptr /* packed rows (16-bit, L <= 256): sequence b is rows cu[b] .. cu[b + 1] - 1 */);
 int omk_attention_bwd_bias(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask,
                            int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
                            const float* pos_bias, float* drel, hipStream_t s);

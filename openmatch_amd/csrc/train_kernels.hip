@@ -693,8 +693,9 @@ int omk_small_tn(const float* A, const float* Bm, float* C, int I, int J, int Cc
 template <typename T, int KT>
 __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
     const T* __restrict__ qkv, const T* __restrict__ dctx, T* __restrict__ dqkv,
-    const int64_t* __restrict__ mask, int L, int H, int heads, float scale, float drop_p,
-    uint64_t seed, const float* __restrict__ pos_bias, float* __restrict__ drel) {
+    const int64_t* __restrict__ mask, int Lm, int H, int heads, float scale, float drop_p,
+    uint64_t seed, const float* __restrict__ pos_bias, float* __restrict__ drel, const int* __restrict__ cu) {
+  // cu != NULL (packed rows, no pos_bias): sequence b is rows cu[b] .. cu[b + 1] - 1, L its own row count; the mask's pitch stays Lm
   // pos_bias [heads][L][L] (T5): added to the scaled scores; drel [heads][2L-1] accumulates the
   // gradient of that bias per relative position key - query (+ L-1), summed over the batch.
   typedef AttnGeom<T> G;
@@ -712,11 +713,14 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
 
   const int h = blockIdx.x % heads;
   const int64_t b = blockIdx.x / heads;
+  int64_t row0 = b * Lm;
+  int L = Lm;
+  if (cu) { row0 = cu[b]; L = cu[b + 1] - cu[b]; if (L <= 0) return; }
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int64_t ld = 3 * (int64_t)H;
-  const T* base = qkv + b * L * ld + h * 64;
-  const T* dob = dctx + b * L * H + h * 64;
-  T* dbase = dqkv + b * L * ld + h * 64;
+  const T* base = qkv + row0 * ld + h * 64;
+  const T* dob = dctx + row0 * H + h * 64;
+  T* dbase = dqkv + row0 * ld + h * 64;
   const AttnDrop dr_(drop_p);
   const uint32_t thresh = dr_.thresh;
   const float keep_scale = dr_.keep_scale;
@@ -738,7 +742,7 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
     }
   }
   for (int k = tid; k < KT * 32; k += nthr)
-    sM[k] = k < L ? (mask[b * L + k] != 0 ? 0.f : -3.4028235e38f) : -INFINITY;
+    sM[k] = k < L ? (mask[b * Lm + k] != 0 ? 0.f : -3.4028235e38f) : -INFINITY;
   if (drel)
     for (int k = tid; k < 2 * KT * 32; k += nthr) sRel[k] = 0.f;
   __syncthreads();
@@ -916,7 +920,7 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
 template <typename T, int KT>
 static int launch_attn_bwd(const void* qkv, const void* dctx, void* dqkv, const int64_t* mask,
                            int64_t B, int L, int H, int heads, float scale, float drop_p,
-                           uint64_t seed, const float* pos_bias, float* drel, hipStream_t s) {
+                           uint64_t seed, const float* pos_bias, float* drel, hipStream_t s, const int* cu = nullptr) {
   constexpr int LP = KT * 32 + 4;
   const int lds = 3 * 64 * LP * (int)sizeof(T) + 6 * KT * 32 * 4;
   static std::atomic<bool> attr_set{false};
@@ -927,7 +931,7 @@ static int launch_attn_bwd(const void* qkv, const void* dctx, void* dqkv, const 
   }
   const int waves = (L + 31) / 32;
   hipLaunchKernelGGL((attention_bwd_kernel<T, KT>), dim3((unsigned)(heads * B)), dim3(64 * waves), lds, s,
-                     (const T*)qkv, (const T*)dctx, (T*)dqkv, mask, L, H, heads, scale, drop_p, seed, pos_bias, drel);
+                     (const T*)qkv, (const T*)dctx, (T*)dqkv, mask, L, H, heads, scale, drop_p, seed, pos_bias, drel, cu);
   OM_LAUNCH_CHECK();
   return 0;
 }
@@ -935,10 +939,23 @@ static int launch_attn_bwd(const void* qkv, const void* dctx, void* dqkv, const 
 int omk_attention_bwd(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask,
                       int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
                       hipStream_t s, const int* cu) {
-  if (cu) {           // packed rows: the transposing-read kernel only (16-bit, L <= 128)
-    if (!omk_attention_bwd16_ok(dtype, L, H, heads)) OM_FAIL("packed rows: attention backward for 16-bit formats, L <= 128");
+  if (cu) {           // packed rows (16-bit formats): the transposing-read kernel up to 128 tokens, the generic one up to 256
+    if (dtype != OM_BF16 && dtype != OM_F16) OM_FAIL("packed rows: attention backward for 16-bit formats");
     if (B <= 0) return 0;
-    return omk_attention_bwd16(dtype, qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s, cu);
+    if (omk_attention_bwd16_ok(dtype, L, H, heads))
+      return omk_attention_bwd16(dtype, qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s, cu);
+    if (L < 1 || L > 256 || H != heads * 64) OM_FAIL("packed rows: attention backward up to 256 tokens, head_dim 64");
+#define ABP(TT)                                                                                      \
+  do {                                                                                               \
+    if (L <= 32) return launch_attn_bwd<TT, 1>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, nullptr, nullptr, s, cu); \
+    if (L <= 64) return launch_attn_bwd<TT, 2>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, nullptr, nullptr, s, cu); \
+    if (L <= 128) return launch_attn_bwd<TT, 4>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, nullptr, nullptr, s, cu); \
+    if (L <= 192) return launch_attn_bwd<TT, 6>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, nullptr, nullptr, s, cu); \
+    return launch_attn_bwd<TT, 8>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, nullptr, nullptr, s, cu);    \
+  } while (0)
+    if (dtype == OM_BF16) ABP(bf16_t);
+    ABP(f16_t);
+#undef ABP
   }
   return omk_attention_bwd_bias(dtype, qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, nullptr, nullptr, s);
 }

@@ -1717,9 +1717,10 @@ def _ragged_train_batch(rng, B, L, vocab=600):
     return torch.from_numpy(ids), torch.from_numpy(mask)
 
 
+@pytest.mark.parametrize("L", [128, 200])
 @pytest.mark.parametrize("pooling", ["first", "mean"])
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
-def test_packed_rows_training_step_matches_the_padded_step(dtype, pooling):
+def test_packed_rows_training_step_matches_the_padded_step(dtype, pooling, L):
     """Round 5: om_encoder_train_forward_packed / _backward_packed run the training step over the tokens up to each sequence's last
     unmasked one instead of B x L (the reference pads and computes over the padding, dataset/data_collator.py:13-24).  Same
     representations and the same gradient for EVERY parameter as the padded pair, up to the order of 16-bit-sized sums: ragged
@@ -1730,10 +1731,10 @@ def test_packed_rows_training_step_matches_the_padded_step(dtype, pooling):
     from openmatch_amd.encoder import compute_dtype_code, rows_bound_of, token_rows_of
     torch.manual_seed(41)
     cfg = BertConfig(hidden_size=256, num_hidden_layers=3, num_attention_heads=4, intermediate_size=1024, vocab_size=600,
-                     max_position_embeddings=128, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+                     max_position_embeddings=256, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     lm = BertModel(cfg).to(DEV).train()
     rng = np.random.default_rng(6)
-    B, L = 24, 128
+    B = 24                       # (L = 200: the attention backward's generic kernel; 128: the transposing-read one)
     ids, mask = _ragged_train_batch(rng, B, L)
     tokens = int(token_rows_of(mask).sum())
     rows = rows_bound_of(token_rows_of(mask))
