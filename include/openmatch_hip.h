@@ -114,14 +114,15 @@ void om_debug_gemm_gen(int gen);
                                      * launch per group of layers computes their weight gradients (env OM_TRAIN_WGRAD_BATCH) */
 #define OM_OPT_GEMM_MAX_GRID 15    /* 0 (default): the persistent 16-bit GEMM takes every CU; > 0: at most this many workgroups (one per CU) --
                                     * two half-batch encoder forwards on two streams share the chip with 128 each */
-#define OM_OPT_GEMM_CONT 16        /* bit mask (env OM_GEMM_CONT, default 111 = bits 0-3, 5, 6) of the persistent 16-bit GEMM's continuous ring (the K loop of a tile
+#define OM_OPT_GEMM_CONT 16        /* bit mask (env OM_GEMM_CONT, default 239 = bits 0-3, 5, 6, 7) of the persistent 16-bit GEMM's continuous ring (the K loop of a tile
                                     * prefetches the next tile's first two steps; epilogue and accumulator initialisation of the next tile interleaved).
                                     * bit 0: the variants without a residual; bit 1: the one-plane residual variants; bit 2: the f16 index scan of wide
                                     * query batches; bit 3: (no effect since round 5: the continuous GEMM kernels exist on 16 x 16 x 32 MFMAs only);
                                     * bit 4 (A/B, off): plain whole-tile bf16 shapes prefer the continuous kernels even when they leave CUs idle;
                                     * bit 5: the training forward's FFN1 (gelu + gelu' to the tape) on the continuous kernel with a two-output
                                     * epilogue; bit 6: generation 2 priced at its measured 0.55 of a 256 x 256 tile's rate when choosing between it and the
-                                    * continuous kernel for plain whole-tile bf16 shapes; a cleared bit 0 / 1: the ring restarts per tile as in round 3 */
+                                    * continuous kernel for plain whole-tile 16-bit shapes; bit 7 (round 5): plain float16 contractions follow the tile-choice model as
+                                    * bfloat16 does (cleared: every whole-tile float16 shape on the persistent kernel); a cleared bit 0 / 1: the ring restarts per tile as in round 3 */
 #define OM_OPT_TRAIN_TAPE_GRAD 17  /* 1 (default): the bf16 BERT training forward keeps gelu'(f) on its tape instead of f (env OM_TRAIN_TAPE_GRAD) */
 #define OM_OPT_TRAIN_RES32 18      /* 1 (default): the bf16 BERT training FORWARD keeps its residual stream in f32, as the reference's autocast does (layer_norm
                                     * runs and returns fp32): pre-LayerNorm sums in f32 on the tape, every LayerNorm output also unrounded for the next

@@ -111,7 +111,7 @@ void opt_init() {
   e = getenv("OM_TRAIN_RES32");
   g_opt[OM_OPT_TRAIN_RES32] = e ? atoi(e) : 1;
   e = getenv("OM_GEMM_CONT");
-  g_opt[OM_OPT_GEMM_CONT] = e ? atoi(e) : 111;
+  g_opt[OM_OPT_GEMM_CONT] = e ? atoi(e) : 239;
   e = getenv("OM_GEMM_SKINNY_M");
   g_opt[OM_OPT_GEMM_SKINNY_M] = e ? atoi(e) : 1024;
   g_opt_init.store(true);

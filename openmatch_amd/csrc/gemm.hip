@@ -173,7 +173,8 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
     // A/B (OM_OPT_GEMM_CONT bit 4): plain 16-bit shapes of whole 256 x 256 tiles go to the continuous-ring kernels even when
     // those leave CUs idle (training: N = 768 at 9 216 token rows is 108 tiles -- the cost model above prefers 216 tiles of
     // 256 x 128 on generation 2; the idle CUs are not idle in a training step, the weight-gradient lane runs beside)
-    const bool plain16 = in_dtype == OM_BF16 && out_dtype == OM_BF16 && !ep.pre_act && ep.drop_p == 0.f && M % 256 == 0 && N % 256 == 0 &&
+    const bool f16_model = in_dtype == OM_F16 && (om_option(OM_OPT_GEMM_CONT) & 128);      // bit 7 (round 5): float16 follows the same rules
+    const bool plain16 = (in_dtype == OM_BF16 || f16_model) && out_dtype == in_dtype && !ep.pre_act && ep.drop_p == 0.f && M % 256 == 0 && N % 256 == 0 &&
                          K * 2 >= 3 * 128;
     if ((om_option(OM_OPT_GEMM_CONT) & 16) && plain16) gen = 6;
     // Round 5 (bit 6, default on): the model above prices generation 2 at 0.92 of a 256 x 256 tile's rate; measured in the training
@@ -202,7 +203,12 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
                     (((uintptr_t)ep.bias & 15) == 0) && !(ep.ln_stats && (ep.rln_stats || ep.stats_out)) &&
                     !(lnf == 2 && !ep.stats_out) && (!resid || (ep.ldr * 2) % 128 == 0) && !((ep.act & OM_ACT_MUL_RESID) && (lnf != 0 || !resid)) &&
                     omk_gemm_wide7_f16_has(act, resid, lnf);
-    if (g7) return omk_gemm_wide7_f16(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    // Round 5 (OM_OPT_GEMM_CONT bit 7, default on): a PLAIN float16 contraction goes to the persistent kernel only where the tile-choice
+    // model above says so, as bfloat16 does.  Before, every whole-tile float16 shape went there: the N = 768 data gradients of a training
+    // step (108 tiles on 256 CUs) took 66 / 51 us where generation 2 takes 62 / 47, and 60 / 48 against 50 / 40 at the 5 120 rows of a
+    // packed batch (profiles/r05_gemm_variant_probe.json).  The fused-LayerNorm variants exist in generation 7 only.
+    const bool want7 = lnf != 0 || gen == 6 || !(om_option(OM_OPT_GEMM_CONT) & 128);
+    if (g7 && want7) return omk_gemm_wide7_f16(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
     if (ln_fused) OM_FAIL("float16: the fused LayerNorm epilogues need whole 256 x 256 tiles");
     if (wide && gen != 1) return launch_gemm2<f16_t, f16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
     return launch_gemm<f16_t, f16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
