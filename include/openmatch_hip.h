@@ -103,9 +103,10 @@ void om_debug_gemm_gen(int gen);
                                    * bit 1 no arithmetic, bit 2 no stores (results are garbage) */
 #define OM_OPT_ENCODER_PINGPONG 10 /* 1 (default): the fused bf16 encoder's kernels alternate their walk direction over the token rows so
                                    * each starts on the rows its producer wrote last (memory-side cache hits); 0: always first to last */
-#define OM_OPT_ENCODER_TWO_PLANE 11 /* 1 (default): the fused bfloat16 BERT encoder keeps its pre-LayerNorm residual stream in TWO 16-bit
-                                   * planes (value = hi + lo; the reference's autocast keeps it in f32) -- 1 - cos against the fp32 chain
-                                   * 1e-5 instead of 4.8e-5 for +2 bytes per element at the two residual sites of a layer; 0: one plane */
+#define OM_OPT_ENCODER_TWO_PLANE 11 /* bit mask (env OM_ENCODER_TWO_PLANE, default 3): the fused BERT encoder keeps its pre-LayerNorm residual stream in TWO
+                                   * 16-bit planes (value = hi + lo; the reference's autocast keeps it in f32) for +2 bytes per element at the two
+                                   * residual sites of a layer -- bit 0 bfloat16 (round 3: 1 - cos against the fp32 chain 1e-5 instead of 4.8e-5),
+                                   * bit 1 float16 (round 6: the headline format inside the reference's own float16 autocast); 0: one plane */
 #define OM_OPT_GEMM_VARIANT 12     /* 0 (default): automatic tile-generation choice; 1 | 2 | 6 pin a generation (A/B measurements) */
 #define OM_OPT_SEARCH_DEBUG 13     /* bit 0: om_sim_topk logs every round (rows done, chunk, list lengths) to stderr; bit 2 (A/B): the small-batch scan
                                     * fetches the index with the default cache policy instead of non-temporal loads (env OM_SEARCH_DEBUG) */
@@ -114,7 +115,7 @@ void om_debug_gemm_gen(int gen);
                                      * launch per group of layers computes their weight gradients (env OM_TRAIN_WGRAD_BATCH) */
 #define OM_OPT_GEMM_MAX_GRID 15    /* 0 (default): the persistent 16-bit GEMM takes every CU; > 0: at most this many workgroups (one per CU) --
                                     * two half-batch encoder forwards on two streams share the chip with 128 each */
-#define OM_OPT_GEMM_CONT 16        /* bit mask (env OM_GEMM_CONT, default 239 = bits 0-3, 5, 6, 7) of the persistent 16-bit GEMM's continuous ring (the K loop of a tile
+#define OM_OPT_GEMM_CONT 16        /* bit mask (env OM_GEMM_CONT, default 495 = bits 0-3, 5, 6, 7, 8) of the persistent 16-bit GEMM's continuous ring (the K loop of a tile
                                     * prefetches the next tile's first two steps; epilogue and accumulator initialisation of the next tile interleaved).
                                     * bit 0: the variants without a residual; bit 1: the one-plane residual variants; bit 2: the f16 index scan of wide
                                     * query batches; bit 3: (no effect since round 5: the continuous GEMM kernels exist on 16 x 16 x 32 MFMAs only);
@@ -122,7 +123,8 @@ void om_debug_gemm_gen(int gen);
                                     * bit 5: the training forward's FFN1 (gelu + gelu' to the tape) on the continuous kernel with a two-output
                                     * epilogue; bit 6: generation 2 priced at its measured 0.55 of a 256 x 256 tile's rate when choosing between it and the
                                     * continuous kernel for plain whole-tile 16-bit shapes; bit 7 (round 5): plain float16 contractions follow the tile-choice model as
-                                    * bfloat16 does (cleared: every whole-tile float16 shape on the persistent kernel); a cleared bit 0 / 1: the ring restarts per tile as in round 3 */
+                                    * bfloat16 does (cleared: every whole-tile float16 shape on the persistent kernel); bits 8 / 9 (round 6): the float16 / bfloat16 TWO-plane residual variants on the continuous
+                                    * ring (cleared -- bit 9 by default -- : the restart-per-tile kernel of round 3); a cleared bit 0 / 1: the ring restarts per tile as in round 3 */
 #define OM_OPT_TRAIN_TAPE_GRAD 17  /* 1 (default): the bf16 BERT training forward keeps gelu'(f) on its tape instead of f (env OM_TRAIN_TAPE_GRAD) */
 #define OM_OPT_TRAIN_RES32 18      /* 1 (default): the bf16 BERT training FORWARD keeps its residual stream in f32, as the reference's autocast does (layer_norm
                                     * runs and returns fp32): pre-LayerNorm sums in f32 on the tape, every LayerNorm output also unrounded for the next

@@ -97,7 +97,7 @@ void opt_init() {
   e = getenv("OM_GEMM_GROUP_M");
   g_opt[OM_OPT_GEMM_GROUP_M] = e ? atoi(e) : 8;
   e = getenv("OM_ENCODER_TWO_PLANE");
-  g_opt[OM_OPT_ENCODER_TWO_PLANE] = e ? atoi(e) : 1;
+  g_opt[OM_OPT_ENCODER_TWO_PLANE] = e ? atoi(e) : 3;
   e = getenv("OM_GEMM_VARIANT");
   g_opt[OM_OPT_GEMM_VARIANT] = e ? atoi(e) : 0;
   e = getenv("OM_SEARCH_DEBUG");
@@ -111,7 +111,7 @@ void opt_init() {
   e = getenv("OM_TRAIN_RES32");
   g_opt[OM_OPT_TRAIN_RES32] = e ? atoi(e) : 1;
   e = getenv("OM_GEMM_CONT");
-  g_opt[OM_OPT_GEMM_CONT] = e ? atoi(e) : 239;
+  g_opt[OM_OPT_GEMM_CONT] = e ? atoi(e) : 495;
   e = getenv("OM_GEMM_SKINNY_M");
   g_opt[OM_OPT_GEMM_SKINNY_M] = e ? atoi(e) : 1024;
   g_opt_init.store(true);

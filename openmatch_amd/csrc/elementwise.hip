@@ -108,11 +108,11 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_kernel(
 // bf16 rows with 16-byte accesses: 32 lanes own one row (two rows per wave), every lane holds NV
 // vectors of 8 elements.  The 8-byte accesses of the generic kernel reach ~4.1 TB/s on
 // [131072, 768]; 16-byte ones are what the memory path is built for (MI355X_MICROARCH.md).
-template <int NV, typename TOut = bf16_t>      // TOut = float: the LAST normalisation before pooling (the reference's autocast
-__global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(     // runs layer_norm in fp32 and returns fp32)
-    const bf16_t* __restrict__ x, int64_t ldx, TOut* __restrict__ y, int64_t ldy,
+template <int NV, typename TOut = bf16_t, typename TIn = bf16_t>      // TOut = float: the LAST normalisation before pooling (the reference's
+__global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(     // autocast runs layer_norm in fp32 and returns fp32); TIn: bf16_t or f16_t (round 6)
+    const TIn* __restrict__ x, int64_t ldx, TOut* __restrict__ y, int64_t ldy,
     const float* __restrict__ g, const float* __restrict__ b, int64_t M, int H, float eps, int rms,
-    const bf16_t* __restrict__ x_lo,          // x_lo: second plane of a two-plane residual stream (value = x + x_lo), or NULL
+    const TIn* __restrict__ x_lo,             // x_lo: second plane of a two-plane residual stream (value = x + x_lo), or NULL
     const int* __restrict__ rows = nullptr) { // gather: output row r normalises input row rows[r]
   const int lane = threadIdx.x & 31;
   const int64_t orow = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
@@ -127,12 +127,12 @@ __global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(     // runs laye
       const uint4 t = *(const uint4*)(x + row * ldx + c * 8);
       const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[j][2 * e] = bf16_to_f32((bf16_t)(w[e] & 0xffff)); v[j][2 * e + 1] = bf16_to_f32((bf16_t)(w[e] >> 16)); }
+      for (int e = 0; e < 4; ++e) { v[j][2 * e] = Half16<TIn>::lo(w[e]); v[j][2 * e + 1] = Half16<TIn>::hi(w[e]); }
       if (x_lo) {
         const uint4 t2 = *(const uint4*)(x_lo + row * ldx + c * 8);
         const uint32_t w2[4] = {t2.x, t2.y, t2.z, t2.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[j][2 * e] += bf16_to_f32((bf16_t)(w2[e] & 0xffff)); v[j][2 * e + 1] += bf16_to_f32((bf16_t)(w2[e] >> 16)); }
+        for (int e = 0; e < 4; ++e) { v[j][2 * e] += Half16<TIn>::lo(w2[e]); v[j][2 * e + 1] += Half16<TIn>::hi(w2[e]); }
       }
     } else {
 #pragma unroll
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(     // runs laye
         float y0 = (v[j][2 * e] - mean) * rstd * gv[2 * e], y1 = (v[j][2 * e + 1] - mean) * rstd * gv[2 * e + 1];
         if (b) { y0 += bv[2 * e]; y1 += bv[2 * e + 1]; }
         o[2 * e] = y0; o[2 * e + 1] = y1;
-        w[e] = (uint32_t)f32_to_bf16(y0) | ((uint32_t)f32_to_bf16(y1) << 16);
+        w[e] = Half16<TIn>::pack2(y0, y1);
       }
       if (sizeof(TOut) == 4) {
         Vec4<float>::store((float*)y + orow * ldy + c * 8, *(float(*)[4])&o[0]);
@@ -397,18 +397,20 @@ int omk_layernorm_f32out(int dtype, const void* x, int64_t ldx, float* y, int64_
                          int64_t M, int H, float eps, int rms, hipStream_t s, const void* x_lo, const int* rows) {
   if (H % 4 != 0 || H > 64 * 4 * MAX_VEC_LIMIT) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
   if (M <= 0) return 0;
-  if (dtype == OM_BF16 && H % 8 == 0 && H <= 1024 && ldx % 8 == 0 && ldy % 4 == 0 &&
+  if ((dtype == OM_BF16 || (dtype == OM_F16 && x_lo)) && H % 8 == 0 && H <= 1024 && ldx % 8 == 0 && ldy % 4 == 0 &&
       !(((uintptr_t)x | (uintptr_t)y | (uintptr_t)x_lo) & 15) && !(((uintptr_t)g | (uintptr_t)b) & 15)) {
     const unsigned grid = (unsigned)((M + 7) / 8);
     const int nv = (H / 8 + 31) / 32;
-#define LN8F(NV) hipLaunchKernelGGL((layernorm_bf16x8_kernel<NV, float>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ldx, \
-                                    y, ldy, g, b, M, H, eps, rms, (const bf16_t*)x_lo, rows)
+#define LN8F_(NV, TI) hipLaunchKernelGGL((layernorm_bf16x8_kernel<NV, float, TI>), dim3(grid), dim3(256), 0, s, (const TI*)x, ldx, \
+                                    y, ldy, g, b, M, H, eps, rms, (const TI*)x_lo, rows)
+#define LN8F(NV) do { if (dtype == OM_BF16) LN8F_(NV, bf16_t); else LN8F_(NV, f16_t); } while (0)
     if (nv <= 1) LN8F(1); else if (nv == 2) LN8F(2); else if (nv == 3) LN8F(3); else LN8F(4);
 #undef LN8F
+#undef LN8F_
     OM_LAUNCH_CHECK();
     return 0;
   }
-  if (x_lo) OM_FAIL("two-plane LayerNorm input: bf16 rows of whole 16-byte vectors only");
+  if (x_lo) OM_FAIL("two-plane LayerNorm input: 16-bit rows of whole 16-byte vectors only");
   if (dtype == OM_BF16) return launch_ln<bf16_t, float>(x, ldx, y, ldy, g, b, M, H, eps, rms, s, rows);
   if (dtype == OM_F16) return launch_ln<f16_t, float>(x, ldx, y, ldy, g, b, M, H, eps, rms, s, rows);
   return launch_ln<float, float>(x, ldx, y, ldy, g, b, M, H, eps, rms, s, rows);
@@ -447,17 +449,19 @@ int omk_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, c
                   const float* b, int64_t M, int H, float eps, int rms, hipStream_t s, const void* x_lo) {
   if (H % 4 != 0 || H > 64 * 4 * MAX_VEC_LIMIT) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
   if (M <= 0) return 0;
-  if (x_lo && !(dtype == OM_BF16 && H % 8 == 0 && H <= 1024 && ldx % 8 == 0 && ldy % 8 == 0 &&
+  if (x_lo && !((dtype == OM_BF16 || dtype == OM_F16) && H % 8 == 0 && H <= 1024 && ldx % 8 == 0 && ldy % 8 == 0 &&
                 !(((uintptr_t)x | (uintptr_t)y | (uintptr_t)x_lo) & 15) && !(((uintptr_t)g | (uintptr_t)b) & 15)))
-    OM_FAIL("two-plane LayerNorm input: bf16 rows of whole 16-byte vectors only");
-  if (dtype == OM_BF16 && H % 8 == 0 && H <= 1024 && ldx % 8 == 0 && ldy % 8 == 0 &&
+    OM_FAIL("two-plane LayerNorm input: 16-bit rows of whole 16-byte vectors only");
+  if ((dtype == OM_BF16 || (dtype == OM_F16 && x_lo)) && H % 8 == 0 && H <= 1024 && ldx % 8 == 0 && ldy % 8 == 0 &&
       !(((uintptr_t)x | (uintptr_t)y) & 15) && !(((uintptr_t)g | (uintptr_t)b) & 15)) {
     const unsigned grid = (unsigned)((M + 7) / 8);
     const int nv = (H / 8 + 31) / 32;
-#define LN8(NV) hipLaunchKernelGGL((layernorm_bf16x8_kernel<NV>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ldx, \
-                                   (bf16_t*)y, ldy, g, b, M, H, eps, rms, (const bf16_t*)x_lo)
+#define LN8_(NV, TI) hipLaunchKernelGGL((layernorm_bf16x8_kernel<NV, TI, TI>), dim3(grid), dim3(256), 0, s, (const TI*)x, ldx, \
+                                   (TI*)y, ldy, g, b, M, H, eps, rms, (const TI*)x_lo)
+#define LN8(NV) do { if (dtype == OM_BF16) LN8_(NV, bf16_t); else LN8_(NV, f16_t); } while (0)
     if (nv <= 1) LN8(1); else if (nv == 2) LN8(2); else if (nv == 3) LN8(3); else LN8(4);
 #undef LN8
+#undef LN8_
     OM_LAUNCH_CHECK();
     return 0;
   }

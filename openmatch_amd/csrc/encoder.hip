@@ -149,7 +149,7 @@ static EncWs carve(const OmEncoderConfig* c, int64_t B, int64_t L, char* base, i
   w.stats1 = (float*)take(fuse ? (size_t)2 * c->n_layers * M * 8 : 0);
   w.stats2 = w.stats1 ? w.stats1 + (size_t)c->n_layers * M * 2 : nullptr;
   w.slots = (float*)take(fuse ? (size_t)2 * ((H + 255) / 256) * M * 8 : 0);
-  const bool two = fuse && c->dtype == OM_BF16 && c->arch == OM_ARCH_BERT;
+  const bool two = fuse && c->arch == OM_ARCH_BERT;      // both 16-bit formats (round 6): the planes exist whether or not the switch uses them
   w.y_lo = take(two ? M * H * es : 0);
   w.x1_lo = take(two ? M * H * es : 0);
   w.Mp = (int64_t)M;
@@ -169,7 +169,10 @@ extern "C" size_t om_encoder_workspace_bytes(const OmEncoderConfig* cfg, int64_t
 extern "C" int om_encoder_packed_supported(const OmEncoderConfig* c, int gated_ffn, int64_t B, int64_t L, int64_t packed_rows) {
   if (!c || B <= 0 || L <= 0 || L > 256 || packed_rows <= 0) return 0;
   if (packed_rows % 256 || packed_rows < 512 || packed_rows > B * L + 255) return 0;
-  if (packed_rows <= (int64_t)om_option(OM_OPT_GEMM_SKINNY_M)) return 0;      // few rows: the padded entry (its contractions take the weight-streaming kernel)
+  // few rows: the padded entry's contractions take the weight-streaming kernel -- decided there on ITS row count B * L, so only a
+  // batch whose PADDED form is that small is sent back (B = 64, L = 128 with 1 024 real tokens would otherwise run the tile kernels
+  // over all 8 192 padded rows: ADVICE r5)
+  if (B * L <= (int64_t)om_option(OM_OPT_GEMM_SKINNY_M)) return 0;
   const int dt = c->dtype;
   if (dt != OM_BF16 && dt != OM_F16) return 0;
   if (dt == OM_BF16 && !om_option(OM_OPT_ATTENTION_FAST)) return 0;
@@ -248,7 +251,7 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
   // (bfloat16 BERT from 512 rows on stays on the fused path: its two-plane residual stream is what holds bfloat16 inside the
   // reference's own autocast deviation, and the unfused path keeps one plane)
   const bool few_rows = !packed && dt != OM_F32 && M <= (int64_t)om_option(OM_OPT_GEMM_SKINNY_M) &&
-                        !(dt == OM_BF16 && c->arch == OM_ARCH_BERT && M >= 512 && om_option(OM_OPT_ENCODER_TWO_PLANE) != 0);
+                        !(dt == OM_BF16 && c->arch == OM_ARCH_BERT && M >= 512 && (om_option(OM_OPT_ENCODER_TWO_PLANE) & 1) != 0);
   const int64_t Mg = few_rows ? M : ws.Mp;          // rows of the contractions (M padded to whole tiles for large 16-bit batches)
   const bool bert = c->arch == OM_ARCH_BERT;
   const OmLayerWeights* Ls = w->layers_host;
@@ -288,7 +291,9 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
       const float inv_h = 1.0f / (float)H;
       // Two-plane residual stream (bfloat16): y1 = ws.y + ws.y_lo, y2 = ws.x1 + ws.x1_lo; the GEMMs that consume LN(y)
       // as their A operand read the first plane, the residual adds and the final LayerNorm read both.
-      const bool two = dt == OM_BF16 && om_option(OM_OPT_ENCODER_TWO_PLANE) != 0;
+      // (OM_OPT_ENCODER_TWO_PLANE: bit 0 bfloat16 (round 3), bit 1 float16 (round 6) -- the headline format, whose single plane was
+      // what kept it outside the reference's own float16 autocast on small-weight models: DESIGN.md section 2)
+      const bool two = (om_option(OM_OPT_ENCODER_TWO_PLANE) & (dt == OM_BF16 ? 1 : 2)) != 0;
       const int nslots = 2 * (H / 256);
       // y1 lives in ws.y, y2 in ws.x1; ws.x is the embedding output (layer 0's input)
       // Ping-pong walk: every kernel of the chain starts on the rows its producer wrote last (reverse = 1 on every second

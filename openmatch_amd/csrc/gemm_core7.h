@@ -285,12 +285,13 @@ __device__ __forceinline__ void g7_ring_reset(G7Ring& r) {
   r.ac = 0; r.bc = G7_UNIT_BYTES; r.an = 2 * G7_UNIT_BYTES; r.bn = 3 * G7_UNIT_BYTES; r.sp = 4 * G7_UNIT_BYTES;
 }
 // TAIL (residual variants, gemm_wide7.h kernel 7r): the LAST step of a tile gives its twelve issue slots behind sub-steps
-// 1, 2, 3 -- A(nk + 1) and the first half of B(nk + 1) in the plain ring -- to tail(slot 0..11, spare unit, the unit A(nk - 1) leaves): the epilogue's tables and
+// 1, 2, 3 -- A(nk + 1) and the first half of B(nk + 1) in the plain ring -- to tail(slot 0..11, spare unit, the unit A(nk - 1) leaves, the unit
+// B(nk - 1) leaves -- free behind the step's barrier like A's: the fragment reads behind it are the NEXT step's): the epilogue's tables and
 // its first residual patches go into the units that step frees (the spare during sub-steps 1-2, the unit A(nk - 1) leaves
 // behind the barrier), so that the epilogue starts on landed data.  The tile after then starts with step 0 resident only and
 // issues A(1) / the first half of B(1) itself.  The eight issues of sub-steps 1-2 are the step's youngest at its barrier
 // either way (vmcnt(8)).  TAIL_EMPTY: a tail that issues nothing (the index scan: its filter needs the three units for staging).
-struct G7NoTail { __device__ __forceinline__ void operator()(int, int, int) const {} };
+struct G7NoTail { __device__ __forceinline__ void operator()(int, int, int, int) const {} };
 // ZERO_FIRST (the index scan): the tile starts from zero -- the first sixteen MFMAs of its first step take the constant 0 as
 // their C operand and `acc` need not be initialised (one more copy of the step body instead of sixteen initialising MFMAs).
 template <typename T, bool TAIL = false, typename TailFn = G7NoTail, bool TAIL_EMPTY = false, bool ZERO_FIRST = false>
@@ -336,7 +337,7 @@ __device__ __forceinline__ void gemm_mainloop7_cont(const G7SrcU& src, const cha
       if (q < 4) AN[q] = *(const frag_t*)(smem + (UA) + rowa + q * 32 * G7_ROW_BYTES + (SLOT));          \
       else BN[q - 4] = *(const frag_t*)(smem + (UB) + rowb + (q - 4) * 32 * G7_ROW_BYTES + (SLOT));      \
     } else if (!(q & 1)) {                                                                               \
-      if ((LASTSTEP) && (TSLOT) >= 0) tail((TSLOT) + ((q - 8) >> 1), u_sp, u_ac);                        \
+      if ((LASTSTEP) && (TSLOT) >= 0) tail((TSLOT) + ((q - 8) >> 1), u_sp, u_ac, u_bc);                        \
       else g7_issue_##P(src, PTR, (DBASE) + ((q - 8) >> 1), lds0 + (UNIT) + (((DBASE) + ((q - 8) >> 1)) * 4 + wave) * 1024); \
     }                                                                                                    \
     G7_FENCE();                                                                                          \
@@ -379,7 +380,7 @@ __device__ __forceinline__ void gemm_mainloop7_cont(const G7SrcU& src, const cha
 //     barrier      vmcnt(8): everything but A(t+2) has landed (B(t+1) is a step and a half old)
 //     sub-step 1   k 32-63;  reads step t+1, k 0-31;  B(t+2) -> the unit A(t) leaves
 // On entry: step 0 landed and published, A(1) and ALL of B(1) issued (the 32 x 32 x 16 loop above enters with half of B(1)).
-// TAIL: the last step's sixteen issue slots go to tail(slot 0..15, spare unit, the unit A(nk - 1) leaves) -- slots 0-7 behind
+// TAIL: the last step's sixteen issue slots go to tail(slot 0..15, spare unit, the unit A(nk - 1) leaves, the unit B(nk - 1) leaves) -- slots 0-7 behind
 // sub-step 0 (the step's youngest at its barrier), 8-15 behind sub-step 1.
 template <typename T> struct Mma16c;
 template <> struct Mma16c<bf16_t> {
@@ -425,7 +426,7 @@ __device__ __forceinline__ void gemm_mainloop7_cont16(const G7SrcU& src, const c
       else AN[(q >> 2) - 8] = *(const frag_t*)(smem + (UA) + rowa + ((q >> 2) - 8) * 16 * G7_ROW_BYTES + (SLOT)); \
     }                                                                                                    \
     if ((q & 7) == 5) {                                                                                  \
-      if (LASTSTEP) tail((TBASE) + (q >> 3), u_sp, u_ac);                                                \
+      if (LASTSTEP) tail((TBASE) + (q >> 3), u_sp, u_ac, u_bc);                                                \
       else g7_issue_##P(src, PTR, q >> 3, lds0 + (UNIT) + ((q >> 3) * 4 + wave) * 1024);                 \
     }                                                                                                    \
     G7_FENCE();                                                                                          \

@@ -332,10 +332,15 @@ def _ensure_folded(pk, device):
     nfold = lib.om_encoder_fold_bytes(C.byref(cfg))
     if nfold:
         with torch.cuda.device(device):
-            blob = torch.empty(nfold + 256, dtype=torch.uint8, device=device)
+            # ONE blob per packed object for its whole life: an optimizer that refreshes the packed copies in place
+            # (after_inplace_update) invalidates the fold, and the next inference use folds again INTO THE SAME BUFFER
+            # (a fresh blob per step/eval cycle appended to pk.keep grew by ~170 MB per cycle at bert-base)
+            blob = getattr(pk, "fold_blob", None)
+            if blob is None or blob.numel() < nfold + 256 or blob.device != torch.device(device):
+                blob = torch.empty(nfold + 256, dtype=torch.uint8, device=device)
+                pk.fold_blob = blob
             ptr = blob.data_ptr() + (-blob.data_ptr()) % 256
             N.check(lib.om_encoder_fold_weights(C.byref(cfg), C.byref(pk.weights), C.c_void_p(ptr), nfold, N.stream_ptr(device)))
-        pk.keep.append(blob)
         pk.weights.folded = ptr
 
 

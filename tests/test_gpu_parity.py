@@ -1845,6 +1845,61 @@ def test_trainer_takes_packed_rows_when_the_mask_is_still_on_the_host(golden, tm
     assert cosine > 0.97, cosine
 
 
+def test_step_eval_cycles_keep_one_fold_buffer(tmp_path):
+    """FusedAdamW refreshes the packed 16-bit weights in place and drops what was derived from them (the
+    LayerNorm-folded inference weights); an evaluation between two steps folds again.  The fold must go back into the SAME device
+    buffer: step / eval cycles keep the packed object's buffer list and the allocated device memory constant, and every
+    evaluation sees the updated weights."""
+    from transformers import BertConfig, BertModel
+    from openmatch.modeling import DRModel
+    from openmatch.trainer import DRTrainer
+    from openmatch_amd import encoder as enc
+    torch.manual_seed(47)
+    cfg = BertConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024, vocab_size=600,
+                     max_position_embeddings=128, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    lm = BertModel(cfg)
+    rng = np.random.default_rng(9)
+    q_ids, q_mask = synth_tokens(rng, 4, 32, vocab=600, lo_len=4, lo_id=300)
+    p_ids, p_mask = synth_tokens(rng, 32, 128, vocab=600, lo_len=10, lo_id=300)
+    dev = lambda i, m: {"input_ids": torch.from_numpy(i).to(DEV), "attention_mask": torch.from_numpy(m).to(DEV)}
+    q, p = dev(q_ids, q_mask), dev(p_ids, p_mask)
+    model = DRModel(lm_q=lm, lm_p=lm, pooling="first", model_args=NS(encoder_only=False, dtype="bfloat16"),
+                    data_args=NS(train_n_passages=8), train_args=NS(negatives_x_device=False, per_device_train_batch_size=4)).to(DEV)
+    t = DRTrainer(model=model, args=_trainer_args(tmp_path, learning_rate=1e-2), train_dataset=None)
+    t.create_optimizer_and_scheduler(num_training_steps=100)
+    assert type(t.optimizer).__name__ == "FusedAdamW"
+
+    def evaluate():
+        model.eval()
+        with torch.no_grad():
+            reps = model(passage=p).p_reps.float().clone()       # 32 x 128 = 4096 tokens: the fused (LayerNorm-folded) path
+        model.train()
+        return reps
+
+    def inference_pk():
+        cache = lm.__dict__[enc._PACK_CACHE_ATTR]
+        pks = [v[1] for v in cache.values() if getattr(v[1], "fold_blob", None) is not None]
+        assert len(pks) == 1, len(pks)
+        return pks[0]
+
+    state, prev = [], None
+    for cycle in range(5):
+        model.zero_grad(set_to_none=True)
+        t.training_step(model, (q, p))
+        t.optimizer_step()
+        reps = evaluate()
+        assert torch.isfinite(reps).all()
+        if prev is not None:
+            assert not torch.equal(reps, prev), "the evaluation must see the step's weights"
+        prev = reps
+        pk = inference_pk()
+        torch.cuda.synchronize()
+        state.append((len(pk.keep), pk.fold_blob.data_ptr(), torch.cuda.memory_allocated(DEV)))
+    print(f"\n[step/eval cycles] (len(keep), fold buffer, bytes allocated) per cycle: {state}")
+    assert len({s[0] for s in state[1:]}) == 1 and len({s[1] for s in state[1:]}) == 1, state
+    assert state[-1][2] <= state[1][2] + (1 << 20), state
+
+
 @pytest.mark.parametrize("fp16", [False, True])
 def test_gradient_cache_step_equals_full_batch_step(golden, tmp_path, fp16):
     """GCDenseTrainer (chunked, re-encoded) must give the SAME gradients as one full-batch step; under --fp16 (float16 kernels, the

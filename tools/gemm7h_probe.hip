@@ -78,7 +78,7 @@ __device__ __forceinline__ void gemm_mainloop7_cont16h(const G7SrcU& src, const 
     }                                                                                                    \
     if (!(G7H_ABL & 1) && (G7_DMA_EARLY_ ? (q < (NISS) * G7_DMA_EARLY_ && q % G7_DMA_EARLY_ == G7_DMA_EARLY_ - 1) : (q % ISTR == (ISTR == 8 ? 5 : 1)))) { \
       const int di_ = G7_DMA_EARLY_ ? q / (G7_DMA_EARLY_ ? G7_DMA_EARLY_ : 1) : q / ISTR;                \
-      if (LASTSTEP) tail((TBASE) + di_, u_sp, u_ac);                                                     \
+      if (LASTSTEP) tail((TBASE) + di_, u_sp, u_ac, u_bc);                                                   \
       else g7_issue_##P(src, PTR, di_, lds0 + (UNIT) + (di_ * 4 + wave) * 1024);                         \
     }                                                                                                    \
     G7_FENCE();                                                                                          \
