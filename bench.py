@@ -341,7 +341,8 @@ def train_leg(device, steps=8):
     out["bf16"] = dict(run(False, "bfloat16", 1), mode="bfloat16 kernels, f32 residual stream")
     out["bf16_res16"] = dict(run(False, "bfloat16", 0), mode="bfloat16 kernels, 16-bit residual stream (OM_TRAIN_RES32=0): the data flow of rounds 1-4")
     out["ragged"] = {"note": "the --fp16 step on ragged lengths (queries U{4..32}, passages U{16..128} tokens): the padded pair computes over B x L rows as the "
-                             "reference does, the packed pair (round 5) over the tokens up to each sequence's last unmasked one -- same gradients (tests)",
+                             "reference does, the packed pair (round 5) over the tokens up to each sequence's last unmasked one -- same gradients (tests), and since "
+                             "round 6 the same dropout masks (keyed on the token, not on the packed row): the two `loss` values below agree to 16-bit noise",
                      "padded": run(True, "float16", 1, "padded"), "packed": run(True, "float16", 1, "packed")}
     out["ragged"]["speedup"] = round(out["ragged"]["packed"]["value"] / out["ragged"]["padded"]["value"], 3)
     return out

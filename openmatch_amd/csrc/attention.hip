@@ -286,7 +286,8 @@ __device__ __forceinline__ void attention_fwd16_body(
     for (int t = 0; t < KTC; ++t)
   #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const uint64_t bits = attn_drop_bits(seed, b, h, heads, L, q0 + l31, (t * 32 + 8 * g + 4 * half) >> 2);
+        // (keyed with the mask's row pitch Lm, not the sequence's own length: a packed and a padded step draw the same mask)
+        const uint64_t bits = attn_drop_bits(seed, b, h, heads, Lm, q0 + l31, (t * 32 + 8 * g + 4 * half) >> 2);
 #pragma unroll
         for (int e = 0; e < 4; ++e) s[t][4 * g + e] = attn_drop_keep(bits, e, dr.thresh) ? s[t][4 * g + e] : 0.f;
         __builtin_amdgcn_sched_barrier(0);

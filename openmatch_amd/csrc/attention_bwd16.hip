@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd16_kernel(
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         uint64_t bits = ~0ull;
-        if (dr.thresh) bits = attn_drop_bits(seed, b, h, heads, L, q0 + l31, (t * 32 + 8 * g + 4 * half) >> 2);
+        if (dr.thresh) bits = attn_drop_bits(seed, b, h, heads, Lm, q0 + l31, (t * 32 + 8 * g + 4 * half) >> 2);      // (the forward's key: mask pitch)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float p = s[t][4 * g + e] * inv;

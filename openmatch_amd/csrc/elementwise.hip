@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(     // autocast 
     const TIn* __restrict__ x, int64_t ldx, TOut* __restrict__ y, int64_t ldy,
     const float* __restrict__ g, const float* __restrict__ b, int64_t M, int H, float eps, int rms,
     const TIn* __restrict__ x_lo,             // x_lo: second plane of a two-plane residual stream (value = x + x_lo), or NULL
-    const int* __restrict__ rows = nullptr) { // gather: output row r normalises input row rows[r]
+    const int* __restrict__ rows = nullptr,   // gather: output row r normalises input row rows[r]
+    int lo8 = 0) {                            // 1: x_lo is the eight-bit plane (kernels.h omk_lo8_offset) of the [.., H] tensor x points into
   const int lane = threadIdx.x & 31;
   const int64_t orow = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
   if (orow >= M) return;
@@ -128,7 +129,16 @@ __global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(     // autocast 
       const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[j][2 * e] = Half16<TIn>::lo(w[e]); v[j][2 * e + 1] = Half16<TIn>::hi(w[e]); }
-      if (x_lo) {
+      if (x_lo && lo8) {       // the row's index in the [M, H] tensor the plane belongs to: row * ldx / H (ldx = L * H gathers the CLS rows)
+        const int64_t trow = row * (ldx / H);
+        const unsigned char* p8 = (const unsigned char*)x_lo;
+        const uint32_t wa = *(const uint32_t*)(p8 + omk_lo8_offset(trow, c * 8, H)), wb = *(const uint32_t*)(p8 + omk_lo8_offset(trow, c * 8 + 4, H));
+        const om_f32x2_t a01 = __builtin_amdgcn_cvt_pk_f32_bf8((int)wa, false), a23 = __builtin_amdgcn_cvt_pk_f32_bf8((int)wa, true);
+        const om_f32x2_t b01 = __builtin_amdgcn_cvt_pk_f32_bf8((int)wb, false), b23 = __builtin_amdgcn_cvt_pk_f32_bf8((int)wb, true);
+        const float l8[8] = {a01[0], a01[1], a23[0], a23[1], b01[0], b01[1], b23[0], b23[1]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] = fmaf(l8[e], 0.0009765625f, v[j][e]);
+      } else if (x_lo) {
         const uint4 t2 = *(const uint4*)(x_lo + row * ldx + c * 8);
         const uint32_t w2[4] = {t2.x, t2.y, t2.z, t2.w};
 #pragma unroll
@@ -394,7 +404,8 @@ int omk_ln_stats_reduce(const float* slots, int nslots, int64_t M, float* out, h
 
 // x in the compute format (optionally two planes, bf16) -> y in f32
 int omk_layernorm_f32out(int dtype, const void* x, int64_t ldx, float* y, int64_t ldy, const float* g, const float* b,
-                         int64_t M, int H, float eps, int rms, hipStream_t s, const void* x_lo, const int* rows) {
+                         int64_t M, int H, float eps, int rms, hipStream_t s, const void* x_lo, const int* rows, int lo8) {
+  if (lo8 && !(x_lo && dtype == OM_F16 && H % 256 == 0 && ldx % H == 0)) OM_FAIL("eight-bit second plane: float16 rows of a whole-tile [M, H] tensor");
   if (H % 4 != 0 || H > 64 * 4 * MAX_VEC_LIMIT) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
   if (M <= 0) return 0;
   if ((dtype == OM_BF16 || (dtype == OM_F16 && x_lo)) && H % 8 == 0 && H <= 1024 && ldx % 8 == 0 && ldy % 4 == 0 &&
@@ -402,7 +413,7 @@ int omk_layernorm_f32out(int dtype, const void* x, int64_t ldx, float* y, int64_
     const unsigned grid = (unsigned)((M + 7) / 8);
     const int nv = (H / 8 + 31) / 32;
 #define LN8F_(NV, TI) hipLaunchKernelGGL((layernorm_bf16x8_kernel<NV, float, TI>), dim3(grid), dim3(256), 0, s, (const TI*)x, ldx, \
-                                    y, ldy, g, b, M, H, eps, rms, (const TI*)x_lo, rows)
+                                    y, ldy, g, b, M, H, eps, rms, (const TI*)x_lo, rows, lo8)
 #define LN8F(NV) do { if (dtype == OM_BF16) LN8F_(NV, bf16_t); else LN8F_(NV, f16_t); } while (0)
     if (nv <= 1) LN8F(1); else if (nv == 2) LN8F(2); else if (nv == 3) LN8F(3); else LN8F(4);
 #undef LN8F
@@ -446,7 +457,8 @@ int omk_layernorm_dual(int dtype, const float* x, int64_t ldx, void* y, float* y
 }
 
 int omk_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* g,
-                  const float* b, int64_t M, int H, float eps, int rms, hipStream_t s, const void* x_lo) {
+                  const float* b, int64_t M, int H, float eps, int rms, hipStream_t s, const void* x_lo, int lo8) {
+  if (lo8 && !(x_lo && dtype == OM_F16 && H % 256 == 0 && ldx % H == 0)) OM_FAIL("eight-bit second plane: float16 rows of a whole-tile [M, H] tensor");
   if (H % 4 != 0 || H > 64 * 4 * MAX_VEC_LIMIT) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
   if (M <= 0) return 0;
   if (x_lo && !((dtype == OM_BF16 || dtype == OM_F16) && H % 8 == 0 && H <= 1024 && ldx % 8 == 0 && ldy % 8 == 0 &&
@@ -457,7 +469,7 @@ int omk_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, c
     const unsigned grid = (unsigned)((M + 7) / 8);
     const int nv = (H / 8 + 31) / 32;
 #define LN8_(NV, TI) hipLaunchKernelGGL((layernorm_bf16x8_kernel<NV, TI, TI>), dim3(grid), dim3(256), 0, s, (const TI*)x, ldx, \
-                                   (TI*)y, ldy, g, b, M, H, eps, rms, (const TI*)x_lo)
+                                   (TI*)y, ldy, g, b, M, H, eps, rms, (const TI*)x_lo, (const int*)nullptr, lo8)
 #define LN8(NV) do { if (dtype == OM_BF16) LN8_(NV, bf16_t); else LN8_(NV, f16_t); } while (0)
     if (nv <= 1) LN8(1); else if (nv == 2) LN8(2); else if (nv == 3) LN8(3); else LN8(4);
 #undef LN8

@@ -353,26 +353,27 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
 #undef OM_WALK
       const OmLayerWeights& last = Ls[c->n_layers - 1];
       const void* lo = two ? ws.x1_lo : nullptr;
+      const int lo8 = two && dt == OM_F16 ? 1 : 0;       // float16: the second plane is the eight-bit blob of gemm_wide7.h kernel 7r16
       if (packed && c->pooling == OM_POOL_FIRST) {         // the [CLS] row of sequence b is packed row cu[b]
-        RUN(omk_layernorm_f32out(dt, ws.x1, H, ws.final32, H, last.ln2_g, last.ln2_b, B, H, c->ln_eps, 0, s, lo, ws.cls_rows));
+        RUN(omk_layernorm_f32out(dt, ws.x1, H, ws.final32, H, last.ln2_g, last.ln2_b, B, H, c->ln_eps, 0, s, lo, ws.cls_rows, lo8));
         final32_rows = B;
       } else if (!out_hidden && c->pooling == OM_POOL_FIRST) {    // only the [CLS] rows are ever read: normalised straight into f32
-        RUN(omk_layernorm_f32out(dt, ws.x1, L * H, ws.final32, H, last.ln2_g, last.ln2_b, B, H, c->ln_eps, 0, s, lo));
+        RUN(omk_layernorm_f32out(dt, ws.x1, L * H, ws.final32, H, last.ln2_g, last.ln2_b, B, H, c->ln_eps, 0, s, lo, nullptr, lo8));
         final32_rows = B;
       } else if (!out_hidden && c->pooling != OM_POOL_NONE) {
-        RUN(omk_layernorm_f32out(dt, ws.x1, H, ws.final32, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, 0, s, lo));
+        RUN(omk_layernorm_f32out(dt, ws.x1, H, ws.final32, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, 0, s, lo, nullptr, lo8));
         final32_rows = M;
       } else {
         void* dst = out_hidden ? out_hidden : (void*)ws.x;
-        RUN(omk_layernorm(dt, ws.x1, H, dst, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, 0, s, lo));
+        RUN(omk_layernorm(dt, ws.x1, H, dst, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, 0, s, lo, lo8));
         final_hidden = (char*)dst;
         // hidden states AND representations: the pooled rows still come from an f32 normalisation (the reference's autocast
         // returns fp32 from layer_norm), so encode() and forward() give the same representations
         if (c->pooling == OM_POOL_FIRST) {
-          RUN(omk_layernorm_f32out(dt, ws.x1, L * H, ws.final32, H, last.ln2_g, last.ln2_b, B, H, c->ln_eps, 0, s, lo));
+          RUN(omk_layernorm_f32out(dt, ws.x1, L * H, ws.final32, H, last.ln2_g, last.ln2_b, B, H, c->ln_eps, 0, s, lo, nullptr, lo8));
           final32_rows = B;
         } else if (c->pooling != OM_POOL_NONE) {
-          RUN(omk_layernorm_f32out(dt, ws.x1, H, ws.final32, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, 0, s, lo));
+          RUN(omk_layernorm_f32out(dt, ws.x1, H, ws.final32, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, 0, s, lo, nullptr, lo8));
           final32_rows = M;
         }
       }

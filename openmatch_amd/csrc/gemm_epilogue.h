@@ -70,8 +70,10 @@ __device__ __forceinline__ float epi_value(float v, int64_t m, int64_t n, int64_
   }
   v = act_apply<ACT, sizeof(OutT) == 2>(v);
   if (TRAIN) {
-    if (drop_thresh)
-      v = dropout_keep(ep.seed, (uint64_t)m * (uint64_t)N + (uint64_t)n, drop_thresh) ? v * drop_scale : 0.f;
+    if (drop_thresh) {
+      const uint64_t mr = (ep.drop_rows && m < M) ? (uint64_t)(int64_t)ep.drop_rows[m] : (uint64_t)m;      // the row's token (packed rows)
+      v = dropout_keep(ep.seed, mr * (uint64_t)N + (uint64_t)n, drop_thresh) ? v * drop_scale : 0.f;
+    }
   }
   return v;
 }

@@ -216,7 +216,7 @@ __device__ __forceinline__ void store_wave_tile6(f32x16_t (&acc)[4][4], int64_t 
         f32x2_t a_lo = {acc[MI][ni][4 * j], acc[MI][ni][4 * j + 1]}, a_hi = {acc[MI][ni][4 * j + 2], acc[MI][ni][4 * j + 3]};  \
         if (ln_in) { a_lo *= rs[MI]; a_hi *= rs[MI]; }                                                     \
         uint64_t dbits = 0;            /* n % 4 == 0, N % 8 == 0: one hash for the four columns */        \
-        if (TRAIN) { if (es.drop_thresh) dbits = dropout_bits(ep.seed, ((uint64_t)m * (uint64_t)N + (uint64_t)n) >> 2); } \
+        if (TRAIN) { if (es.drop_thresh) dbits = dropout_bits(ep.seed, (((ep.drop_rows && m < M) ? (uint64_t)(int64_t)ep.drop_rows[m] : (uint64_t)m) * (uint64_t)N + (uint64_t)n) >> 2); } \
         const f32x2_t lo = epi_pair<ACT, TRAIN, OutT>(a_lo, m, n, M, N, ep, es, dbits, 0);                 \
         const f32x2_t hi = epi_pair<ACT, TRAIN, OutT>(a_hi, m, n + 2, M, N, ep, es, dbits, 2);             \
         f32x2_t lo_ = lo, hi_ = hi;                                                                        \

@@ -863,6 +863,18 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c16(
 //                                      ring.sp (the unit B(nk - 1) left)      slices 0-3 staging patch
 // (slice i of a unit = this wave's i-th own KiB, at unit + (4 i + wave) KiB: no wave touches another wave's slices.)
 // =========================================================================================================================
+// LNF == 3, float16 (round 6, second step): the second plane in EIGHT bits.  The first version (two float16 planes, kept for bfloat16)
+// paid 44 k cycles per tile epilogue against 24 k with one plane (tools/epilogue_trace.py, profiles/r06_epilogue_trace_*.json): the
+// epilogue's time is its count of 1 KiB vector-memory operations (~300 cycles each per wave with four waves issuing), and two planes
+// double them.  The remainder y - hi is at most half an ulp of hi, so e5m2 of (remainder * 2^10) carries y to ~2^-14 |y| -- eight times
+// finer than one float16 plane, where the reference's autocast keeps f32 -- in ONE byte.  Nobody but this kernel (as producer and, two
+// launches later, as the consumer of the residual) and the final LayerNorm reads that plane, so it is not a row-major matrix but a
+// wave-native blob: tile (m0, n0) of an [M, N] output -> 4 waves x 8 patches x (64 lanes x 32 bytes), lane l holding quarter G's eight
+// bytes at (G >> 1) KiB + 16 l + 8 (G & 1): the producer stores two 16-byte registers per patch straight from the conversion (no LDS
+// transposition), the consumer fetches them by two lane-linear LDS-DMA instructions and reads its own bytes back.  Per patch 6 fetches
+// + 6 stores (16 with two 16-bit planes, 8 with one).  LDS: entry e = hi 4 KiB + lo 2 KiB (slices 0-5 of ring.an / ring.bn), tables in
+// slices 6-7 of ring.an and slice 6 of ring.bn, staging in ring.sp; all sixteen tail slots of the last K step are fetches of patches 0 / 1
+// and the tables.  kernels.h: omk_lo8_offset is the blob's index function (the final LayerNorm kernels decode through it).
 // LNF == 3 (round 6): the same on the TWO-PLANE residual stream of gemm_nt_kernel7 above (y = y_hi + y_lo; the residual is read as
 // r_hi + r_lo, the output written as C = round16(y), ep.out_lo = round16(y - C)) -- both 16-bit formats; float16 is the headline
 // format since round 4 and kept its stream in ONE plane until now, which put it 2.6 x (1 - cos) / 1.8 x (max |ddot|) outside the
@@ -890,7 +902,9 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
   static_assert(LNF == 0 || LNF == 2 || LNF == 3, "residual variants: plain, or output-side LayerNorm on a one- / two-plane residual stream");
   constexpr bool LNO = LNF >= 2;
   constexpr bool TWO = LNF == 3;               // two-plane residual stream (round 6): see the layout note above the kernel
-  constexpr int NPF = TWO ? 8 : 4;             // DMA instructions per residual patch, stores per output patch
+  // float16: the second plane is EIGHT bits per element (e5m2 of remainder * 2^10) in a wave-native blob -- see the note above the kernel
+  constexpr bool LO8 = TWO && std::is_same<T, f16_t>::value;
+  constexpr bool TWO16 = TWO && !LO8;          // bfloat16 (opt-in, OM_GEMM_CONT bit 9): a second 16-bit row-major plane
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -922,7 +936,8 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
   size_t ldc2 = (size_t)ldc * sizeof(OutT), ldr2 = (size_t)ep.ldr * sizeof(OutT);
   asm volatile("" : "+s"(ldc2), "+s"(ldr2));
   // second plane of the residual; absent (layer 0 adds the one-plane embedding output): fetched from the first plane and scaled by 0
-  const float rlo_scale = (TWO && ep.resid_lo) ? 1.f : 0.f;
+  const float rlo_scale = (TWO16 && ep.resid_lo) ? 1.f : 0.f;
+  const bool has_lo8 = LO8 && ep.resid_lo != nullptr;
 
   for (;;) {
     int lane = lane0;
@@ -933,12 +948,19 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
     char* const bn0 = smem + ring.bn + wave * 1024;
     char* const sp0 = smem + ring.sp + wave * 1024;
     // tables: one plane -- behind the first residual slot in the spare of the last step; two planes -- in the unit B(nk - 1) left
-    const char* const etab0 = (TWO ? sp0 : an0) + 4 * 4096;   // gamma | beta
-    const char* const etab1 = (TWO ? sp0 : an0) + 5 * 4096;   // (sum, sum of squares) of my 128 residual rows
-    const char* const tab0 = ((live && !TWO) ? an0 : sp0) + 6 * 4096;   // s_n | b_n of the tile about to start
+    // tables: one plane -- behind the first residual slot in the spare of the last step; two 16-bit planes -- in the unit B(nk - 1) left;
+    // 16 + 8 bits -- gamma | beta and the statistics behind entry 0 (slices 6, 7), the next tile's bias behind entry 1 (slice 6)
+    const char* const etab0 = LO8 ? an0 + 6 * 4096 : (TWO ? sp0 : an0) + 4 * 4096;   // gamma | beta
+    const char* const etab1 = LO8 ? an0 + 7 * 4096 : (TWO ? sp0 : an0) + 5 * 4096;   // (sum, sum of squares) of my 128 residual rows
+    const char* const tab0 = (live ? (LO8 ? bn0 : (TWO ? sp0 : an0)) : sp0) + 6 * 4096;   // s_n | b_n of the tile about to start
     const bool res_ln = LNO && ep.rln_stats != nullptr;
     const char* const rbase = (const char*)((const OutT*)ep.resid + pmc * ep.ldr + pnc);
-    const char* const rlo_base = (TWO && ep.resid_lo) ? (const char*)((const OutT*)ep.resid_lo + pmc * ep.ldr + pnc) : rbase;
+    const char* const rlo_base = (TWO16 && ep.resid_lo) ? (const char*)((const OutT*)ep.resid_lo + pmc * ep.ldr + pnc) : rbase;
+    // the 8-bit plane of the finished tile (pm, pn): 16 KiB per wave tile = 8 patches of 64 lanes x 32 bytes, wave-uniform base
+    const size_t blob8 = LO8 ? ((size_t)(((pm >> 8) * ntn + (pn >> 8)) * 4 + wave) * 8) * 2048 : 0;
+    const char* const rl8_base = LO8 ? (const char*)(ep.resid_lo ? ep.resid_lo : ep.out_lo) + blob8 : nullptr;
+    char* const cl8_base = LO8 ? (char*)ep.out_lo + blob8 : nullptr;
+    const uint32_t lane16 = (uint32_t)lane * 16;
     uint32_t roff[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) roff[k] = (uint32_t)((lane >> 3) * ldr2) + (((lane & 7) ^ ((4 * k + (lane >> 4)) & 7)) << 4);
@@ -947,12 +969,13 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
     frag_t fb[8];
     const char* const st_rd = sp0 + (lane >> 3) * 128;
     char* const cbase = (char*)(C + pmc * ldc + pnc);
-    char* const cbase_lo = TWO ? (char*)((OutT*)ep.out_lo + pmc * ldc + pnc) : cbase;
+    char* const cbase_lo = TWO16 ? (char*)((OutT*)ep.out_lo + pmc * ldc + pnc) : cbase;
     const uint32_t coff = (uint32_t)((lane >> 3) * ldc2) + (lane & 7) * 16;
     float2* const stat_slot = LNO ? (float2*)ep.stats_out + ((pn >> 8) * 2 + wn) * M : nullptr;
     uint4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
     uint4 la0, la1, la2, la3, lb0, lb1, lb2, lb3;            // two planes: the read-back of the remainder plane
-    uint2 plo[8];                                             // two planes: the patch's remainder words until the hi plane is read back
+    uint2 plo[8];                                             // two 16-bit planes: the patch's remainder words until the hi plane is read back
+    uint2 plo8[4];                                            // 16 + 8 bits: the patch's remainder bytes, quarter G at plo8[G]
 
     // residual slot of patch P_: one plane -- a ring of three 4 KiB slots; two planes -- a ring of two 8 KiB entries (hi 0-3, lo 4-7)
 #define G7R_SLOT(P_) (TWO ? (((P_) & 1) == 0 ? an0 : bn0) : (((P_) % 3) == 0 ? an0 : (((P_) % 3) == 1 ? bn0 : bn0 + 4 * 4096)))
@@ -961,7 +984,8 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
     const size_t poff = (size_t)(((P_) >> 1) * 32) * ldr2 + ((P_) & 1) * 128;                                  \
     const uint32_t buf = g7_lds_addr(G7R_SLOT(P_));                                                            \
     _Pragma("unroll") for (int k = 0; k < 4; ++k) g7_dma(rbase + poff + (size_t)(8 * k) * ldr2, roff[k], buf + k * 4096); \
-    if (TWO) { _Pragma("unroll") for (int k = 0; k < 4; ++k) g7_dma(rlo_base + poff + (size_t)(8 * k) * ldr2, roff[k], buf + (4 + k) * 4096); } \
+    if (TWO16) { _Pragma("unroll") for (int k = 0; k < 4; ++k) g7_dma(rlo_base + poff + (size_t)(8 * k) * ldr2, roff[k], buf + (4 + k) * 4096); } \
+    if (LO8) { _Pragma("unroll") for (int k = 0; k < 2; ++k) g7_dma(rl8_base + (P_) * 2048 + k * 1024, lane16, buf + (4 + k) * 4096); } \
   } while (0)
     // quarter G_ of patch P_ = (mi, nh): row block ti2 = G_ >> 1, column blocks 2 (G_ & 1) + {0, 1} -- eight values per lane
 #define G7R_WRITE_Q(P_, G_)                                                                                    \
@@ -978,7 +1002,14 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
     _Pragma("unroll") for (int e = 0; e < 8; ++e) v8[e] = acc[TI][FJ0 + (e >> 2)][e & 3];                      \
     f32x8_t r8 = {Half16<OutT>::lo(ra_.x), Half16<OutT>::hi(ra_.x), Half16<OutT>::lo(ra_.y), Half16<OutT>::hi(ra_.y), \
                   Half16<OutT>::lo(rb_.x), Half16<OutT>::hi(rb_.x), Half16<OutT>::lo(rb_.y), Half16<OutT>::hi(rb_.y)}; \
-    if (TWO) {                                                                                                 \
+    if (LO8) {           /* my own eight bytes of the quarter, as the producing lane stored them (same tile / wave / patch / lane map) */ \
+      const uint2 lw_ = *(const uint2*)(G7R_SLOT(P_) + (4 + ((G_) >> 1)) * 4096 + lane * 16 + ((G_) & 1) * 8);   \
+      const f32x2_t l01 = __builtin_amdgcn_cvt_pk_f32_bf8((int)lw_.x, false), l23 = __builtin_amdgcn_cvt_pk_f32_bf8((int)lw_.x, true); \
+      const f32x2_t l45 = __builtin_amdgcn_cvt_pk_f32_bf8((int)lw_.y, false), l67 = __builtin_amdgcn_cvt_pk_f32_bf8((int)lw_.y, true); \
+      const f32x8_t l8 = {l01[0], l01[1], l23[0], l23[1], l45[0], l45[1], l67[0], l67[1]};                     \
+      if (has_lo8) r8 = __builtin_elementwise_fma(l8, (f32x8_t)(0.0009765625f), r8);       /* (select, not a product by 0: the dummy bytes may decode to inf) */ \
+    }                                                                                                          \
+    if (TWO16) {                                                                                               \
       const uint2 la_ = *(const uint2*)(buf + 4 * 4096 + ((c0_ ^ ((rr >> 1) & 7)) << 4));                      \
       const uint2 lb_ = *(const uint2*)(buf + 4 * 4096 + ((c1_ ^ ((rr >> 1) & 7)) << 4));                      \
       const f32x8_t l8 = {Half16<OutT>::lo(la_.x), Half16<OutT>::hi(la_.x), Half16<OutT>::lo(la_.y), Half16<OutT>::hi(la_.y), \
@@ -1018,8 +1049,15 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
       const f32x8_t h8 = {Half16<OutT>::lo(pa_.x), Half16<OutT>::hi(pa_.x), Half16<OutT>::lo(pa_.y), Half16<OutT>::hi(pa_.y), \
                           Half16<OutT>::lo(pb_.x), Half16<OutT>::hi(pb_.x), Half16<OutT>::lo(pb_.y), Half16<OutT>::hi(pb_.y)}; \
       const f32x8_t d8 = v8 - h8;                                                                              \
+      if (LO8) {       /* e5m2 of the remainder * 2^10 (|remainder| <= half an ulp of the float16 word: <= 2^-11 |y|): y = hi + lo to ~2^-14 |y| */ \
+        const f32x8_t s8_ = d8 * (f32x8_t)(1024.f);                                                            \
+        int w0_ = __builtin_amdgcn_cvt_pk_bf8_f32(s8_[0], s8_[1], 0, false); w0_ = __builtin_amdgcn_cvt_pk_bf8_f32(s8_[2], s8_[3], w0_, true); \
+        int w1_ = __builtin_amdgcn_cvt_pk_bf8_f32(s8_[4], s8_[5], 0, false); w1_ = __builtin_amdgcn_cvt_pk_bf8_f32(s8_[6], s8_[7], w1_, true); \
+        plo8[(G_)] = make_uint2((uint32_t)w0_, (uint32_t)w1_);                                                 \
+      } else {                                                                                                 \
       plo[2 * (G_)] = make_uint2(Half16<OutT>::pack2(d8[0], d8[1]), Half16<OutT>::pack2(d8[2], d8[3]));        \
       plo[2 * (G_) + 1] = make_uint2(Half16<OutT>::pack2(d8[4], d8[5]), Half16<OutT>::pack2(d8[6], d8[7]));    \
+      }                                                                                                        \
     }                                                                                                          \
     *(uint2*)(sp0 + G7E_ROW(rr) + ((c0_ ^ (rr & 7)) << 4) + 8 * (q4 & 1)) = pa_;                               \
     *(uint2*)(sp0 + G7E_ROW(rr) + ((c1_ ^ (rr & 7)) << 4) + 8 * (q4 & 1)) = pb_;                               \
@@ -1066,6 +1104,32 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
       G7R_ST(P_, 0, C0); G7R_ST(P_, 1, C1); G7R_ST(P_, 2, C2); G7R_ST(P_, 3, C3); G7_FENCE_();                 \
     }                                                                                                          \
   } while (0)
+    // 16 + 8 bits: half K_ (quarters 2 K_, 2 K_ + 1) of patch PP's remainder bytes straight from the registers -- one 16-byte store per lane,
+    // 1 KiB per wave, no LDS round trip (the consumer reads them back with the same lane map)
+#ifdef G7E_STORE16U
+#define G7R_ST_LO8(PP, K_) do { const uint4 v_ = make_uint4(plo8[2 * (K_)].x, plo8[2 * (K_)].y, plo8[2 * (K_) + 1].x, plo8[2 * (K_) + 1].y); \
+                                G7E_STORE16U(cl8_base + (PP) * 2048 + (K_) * 1024, lane16, v_); } while (0)
+#else
+#define G7R_ST_LO8(PP, K_) do { const uint4 v_ = make_uint4(plo8[2 * (K_)].x, plo8[2 * (K_)].y, plo8[2 * (K_) + 1].x, plo8[2 * (K_) + 1].y); \
+                                G7E_STORE16(cl8_base + (PP) * 2048 + (K_) * 1024 + lane16, v_); } while (0)
+#endif
+    // ... and its pipeline: the one-plane iteration with a ring of TWO entries (hi 4 KiB + lo 2 KiB), six fetches and 4 + 2 stores per patch
+#define G7R_ITER8(P_, YWAIT, C0, C1, C2, C3, N0, N1, N2, N3)                                                   \
+  do {                                                                                                         \
+    if (tr_prev && threadIdx.x == 0) tr_prev[17 + (P_)] = clock64();                                           \
+    if ((P_) + 1 < 8) {                                                                                        \
+      if ((P_) + 2 < 8) G7R_RES_DMA((P_) + 2);                                                                 \
+      G7_WAIT_VM(YWAIT);                                                                                       \
+      G7R_WRITE_Q((P_) + 1, 0); G7_FENCE_(); G7R_ST(P_, 0, C0); G7_FENCE_();                                   \
+      G7R_WRITE_Q((P_) + 1, 1); G7_FENCE_(); G7R_ST_LO8((P_) + 1, 0); G7R_ST(P_, 1, C1); G7_FENCE_();          \
+      G7R_WRITE_Q((P_) + 1, 2); G7_FENCE_(); G7R_ST(P_, 2, C2); G7_FENCE_();                                   \
+      G7R_WRITE_Q((P_) + 1, 3); G7_FENCE_();                                                                   \
+      N0 = G7R_RB(0); N1 = G7R_RB(1); N2 = G7R_RB(2); N3 = G7R_RB(3);                                          \
+      G7_FENCE_(); G7R_ST_LO8((P_) + 1, 1); G7R_ST(P_, 3, C3); G7_FENCE_();                                    \
+    } else {                                                                                                   \
+      G7R_ST(P_, 0, C0); G7R_ST(P_, 1, C1); G7R_ST(P_, 2, C2); G7R_ST(P_, 3, C3); G7_FENCE_();                 \
+    }                                                                                                          \
+  } while (0)
     // Two planes: the same pipeline with a ring of TWO residual entries (patch p + 2 is fetched into the entry patch p was read
     // from one iteration ago) and eight stores per patch -- the hi and the lo line of a row quarter behind each quarter of the next
     // patch's conversion.  Per iteration: fetch of p + 2 -> wait for p + 1 -> [convert a quarter of p + 1 (hi staged, lo words kept)
@@ -1096,7 +1160,7 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
 #define G7R_B sb0, sb1, sb2, sb3, lb0, lb1, lb2, lb3
 
     if (live) {
-      if (TWO) {
+      if (TWO16) {
         // the second plane of patch 1 (the tail's sixteen slots hold tables, both planes of patch 0 and the first of patch 1)
         const uint32_t buf = g7_lds_addr(bn0);
 #pragma unroll
@@ -1113,11 +1177,24 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
         }
       }
       if (tr_prev && threadIdx.x == 0) tr_prev[16] = clock64();
-      G7R_WRITE_Q(0, 0); G7R_WRITE_Q(0, 1); G7R_WRITE_Q(0, 2); G7R_WRITE_Q(0, 3);
+      G7R_WRITE_Q(0, 0); G7R_WRITE_Q(0, 1);
+      if (LO8) G7R_ST_LO8(0, 0);
+      G7R_WRITE_Q(0, 2); G7R_WRITE_Q(0, 3);
       G7_FENCE_();
       sa0 = G7R_RB(0); sa1 = G7R_RB(1); sa2 = G7R_RB(2); sa3 = G7R_RB(3);
       G7_FENCE_();
-      if (TWO) {
+      if (LO8) {
+        G7R_ST_LO8(0, 1);
+        G7_FENCE_();
+        // younger than the awaited patch's fetch: [p = 0] the next tile's bias table (2), patch 0's two lo stores, the fetch of patch 2 (6);
+        // [p = 1 .. 5] 4 + 2 stores + the next fetch (6); [p = 6] 4 + 2 stores
+        G7R_ITER8(0, 10, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
+        G7R_ITER8(1, 12, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+        G7R_ITER8(2, 12, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
+        G7R_ITER8(3, 12, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+        G7R_ITER8(4, 12, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
+        G7R_ITER8(5, 12, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+      } else if (TWO) {
         G7R_WRITE_LO();
         G7_FENCE_();
         la0 = G7R_RB(0); la1 = G7R_RB(1); la2 = G7R_RB(2); la3 = G7R_RB(3);
@@ -1156,7 +1233,8 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
       }
     }
     if (live) {
-      if (TWO) G7R_ITER2_(6, 8, G7R_A, G7R_B);
+      if (LO8) G7R_ITER8(6, 6, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
+      else if (TWO) G7R_ITER2_(6, 8, G7R_A, G7R_B);
       else G7R_ITER(6, 8, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3);
       if (have) {                              // every ring slot and table of this epilogue has been read: A(1) and B(1) of the next tile
         g7_fill_a(src, cur_a + G7_ROW_BYTES, smem + ring.an, wave);
@@ -1182,7 +1260,8 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
 #pragma unroll
     for (int q = 0; q < 64; ++q) asm volatile("" : "+a"(acc[q >> 3][q & 7]));
     if (live) {
-      if (TWO) G7R_ITER2_(7, 0, G7R_B, G7R_A);
+      if (LO8) G7R_ITER8(7, 0, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+      else if (TWO) G7R_ITER2_(7, 0, G7R_B, G7R_A);
       else G7R_ITER(7, 0, sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
       if (tr_prev && threadIdx.x == 0) { tr_prev[28] = clock64(); tr_prev[29] = blockIdx.x; tr_prev[31] = wall_clock64(); }
     }
@@ -1190,6 +1269,8 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
 #undef G7R_B
 #undef G7R_ITER2_
 #undef G7R_ITER2
+#undef G7R_ITER8
+#undef G7R_ST_LO8
 #undef G7R_ITER
 #undef G7R_ST
 #undef G7R_ST_
@@ -1215,7 +1296,9 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
     {
       const int64_t mc = m0 + wm * 128, nc = n0 + wn * 128;
       const char* const rb_ = (const char*)((const OutT*)ep.resid + mc * ep.ldr + nc);
-      const char* const rl_ = (TWO && ep.resid_lo) ? (const char*)((const OutT*)ep.resid_lo + mc * ep.ldr + nc) : rb_;
+      const char* const rl_ = (TWO16 && ep.resid_lo) ? (const char*)((const OutT*)ep.resid_lo + mc * ep.ldr + nc) : rb_;
+      const char* const rl8_ = LO8 ? (const char*)(ep.resid_lo ? ep.resid_lo : ep.out_lo) + ((size_t)(((m0 >> 8) * ntn + (n0 >> 8)) * 4 + wave) * 8) * 2048 : nullptr;
+      const uint32_t l16_ = (uint32_t)lane0 * 16;
       const bool rln = LNO && ep.rln_stats != nullptr;
       const float* const dummy = (const float*)A;
       const float* const t_g = rln ? ep.rln_g + nc : dummy;
@@ -1229,7 +1312,18 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
       auto tail = [&](int slot, int u_spare, int u_olda, int u_oldb) __attribute__((always_inline)) {
         char* const s0 = smem + u_spare + w1k;
         const uint32_t o0 = lds_base + u_olda + w1k;
-        if (TWO) {
+        if (LO8) {
+          // slots 0-7 (behind sub-step 0: the spare only): patch 0 (hi 0-3, lo 4-5), gamma | beta (6), statistics (7); 8-15 (behind the step's
+          // barrier, into the unit A(nk - 1) leaves): patch 1 (hi 0-3, lo 4-5), the next tile's bias table (6; twice: the count is fixed)
+          (void)u_oldb;
+          if (slot < 4) g7_dma(rb_ + (size_t)(8 * slot) * ldr2, ro[slot], g7_lds_addr(s0) + slot * 4096);
+          else if (slot < 6) g7_dma(rl8_ + (slot - 4) * 1024, l16_, g7_lds_addr(s0) + slot * 4096);
+          else if (slot == 6) g7_table2(t_g, t_b, s0 + 6 * 4096, lane0);
+          else if (slot == 7) g7_table1(t_s, s0 + 7 * 4096, lane0);
+          else if (slot < 12) g7_dma(rb_ + 128 + (size_t)(8 * (slot - 8)) * ldr2, ro[slot - 8], o0 + (slot - 8) * 4096);
+          else if (slot < 14) g7_dma(rl8_ + 2048 + (slot - 12) * 1024, l16_, o0 + (slot - 8) * 4096);
+          else g7_table2(dummy, t_bias, smem + u_olda + w1k + 6 * 4096, lane0);
+        } else if (TWO) {
           // slots 0-7 (behind sub-step 0: the spare only) both planes of patch 0; 8-11 (behind the step's barrier) the tables into the
           // unit B(nk - 1) left; 12-15 the first plane of patch 1 into the unit A(nk - 1) left
           char* const b0 = smem + u_oldb + w1k;

@@ -7,12 +7,14 @@ int omk_ln_fold(int dtype /* OM_BF16 | OM_F16 */, const void* W, const float* ga
                 float* colsum, float* bf, int N, int K, hipStream_t s);
 int omk_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* g,
                   const float* b, int64_t M, int H, float eps, int rms, hipStream_t s,
-                  const void* x_lo = nullptr /* second plane of a two-plane input: normalises x + x_lo */);
+                  const void* x_lo = nullptr /* second plane of a two-plane input: normalises x + x_lo */,
+                  int lo8 = 0 /* 1: x_lo is the eight-bit plane of omk_lo8_offset (float16; ldx == H, H % 256 == 0) */);
 int omk_layernorm_dual(int dtype, const float* x, int64_t ldx, void* y, float* y32, int64_t ldy, const float* g, const float* b,
                        int64_t M, int H, float eps, hipStream_t s);
 int omk_layernorm_f32out(int dtype, const void* x, int64_t ldx, float* y, int64_t ldy, const float* g, const float* b,
                          int64_t M, int H, float eps, int rms, hipStream_t s, const void* x_lo = nullptr,
-                         const int* rows = nullptr /* gather: output row r normalises input row rows[r] */);
+                         const int* rows = nullptr /* gather: output row r normalises input row rows[r] */,
+                         int lo8 = 0 /* 1: x_lo is the eight-bit plane of omk_lo8_offset; ldx = H or a multiple of it (the CLS-row gather) */);
 int omk_embed(int dtype, const int64_t* ids, const int64_t* type_ids, const float* word,
               const float* pos, const float* type, const float* g, const float* b, void* out,
               int64_t M, int L, int H, int vocab, int type_vocab, float eps, int bert,
@@ -48,6 +50,8 @@ struct GemmEpilogue {
   int64_t ldp;
   float drop_p;        // 0 = no dropout
   uint64_t seed;
+  const int* drop_rows;  // packed rows (training): drop_rows[m] = the token (b * L + position) output row m holds -- the dropout mask is keyed on
+                         //   (token, column), so a packed step and the padded step of the same batch draw the SAME mask; NULL: the row itself
   unsigned long long* trace;  // debug: per-block phase timestamps (om_debug_gemm_trace), else NULL
   // ---- LayerNorm fused across GEMMs (16-bit inference path of the BERT encoder, v6 kernel only) ----
   // stats = [M][2] f32 (sum, sum of squares) of a row over `1 / ln_inv_h` columns.
@@ -67,6 +71,18 @@ struct GemmEpilogue {
                              //   A consumer that starts where its producer finished finds those rows in the memory-side cache
                              //   (256 MB; the encoder's activations are 200-800 MB per tensor) -- encoder.hip alternates.
 };
+// Byte offset of element (m, n) of an [M, N] tensor's EIGHT-BIT second plane (float16 two-plane residual stream, round 6: gemm_wide7.h kernel
+// 7r16 with LNF == 3 writes and reads it in its own lane order -- tile (256 x 256) -> wave (128 x 128) -> patch (32 rows x 64 columns) ->
+// 64 lanes x 32 bytes; value = e5m2 of (y - hi) * 2^10).  M, N multiples of 256.
+__host__ __device__ inline size_t omk_lo8_offset(int64_t m, int64_t n, int64_t N) {
+  const int64_t tile = (m >> 8) * (N >> 8) + (n >> 8);
+  const int wave = (int)(((m >> 7) & 1) * 2 + ((n >> 7) & 1));
+  const int r = (int)(m & 127), c = (int)(n & 127);
+  const int P = 2 * (r >> 5) + (c >> 6);
+  const int G = 2 * ((r >> 4) & 1) + ((c >> 5) & 1);
+  const int lane = ((c >> 2) & 3) * 16 + (r & 15);
+  return ((size_t)((tile * 4 + wave) * 8 + P)) * 2048 + (size_t)((G >> 1) * 1024 + lane * 16 + (G & 1) * 8 + ((c >> 4) & 1) * 4 + (c & 3));
+}
 // (sum, sum of squares) per row from the slot partials a GEMM with stats_out left: out[m] = sum over slots, in slot order
 int omk_ln_stats_reduce(const float* slots, int nslots, int64_t M, float* out, hipStream_t s);
 // true when omk_gemm will run [M,N] x K (16-bit) on the kernel that implements the ln_* / rln_* / stats_out fields

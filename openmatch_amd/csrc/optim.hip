@@ -32,7 +32,7 @@ __global__ __launch_bounds__(THREADS) void grad_sqnorm_kernel(const OmAdamTensor
   const OmAdamTensor t = T[chunks[2 * blockIdx.x]];
   const int64_t base = (int64_t)chunks[2 * blockIdx.x + 1] * CHUNK;
   const int64_t n = t.n - base < CHUNK ? t.n - base : CHUNK;
-  const float* g = t.g + base;
+  const float* g = t.g ? t.g + base : nullptr;        // (an absent gradient stays NULL whatever the chunk's offset: ADVICE r5)
   float s = 0.f;
   if (g) {
     const bool vec = ((uintptr_t)g & 15) == 0;

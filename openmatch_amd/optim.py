@@ -92,6 +92,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     raise N.NativeError("FusedAdamW updates contiguous float32 parameters on an MI355X device; there is no CPU fallback")
                 key = (float(group["lr"]), tuple(group["betas"]), float(group["eps"]), self._state_of(p)["step"] + 1)
                 launches.setdefault(key, []).append((p, g, float(group["weight_decay"])))
+        self._last_step_ran = False              # LossScaler.update judges a step only if one ran
         if not launches:
             return loss
         all_entries = [e for es in launches.values() for e in es]
@@ -121,6 +122,7 @@ class FusedAdamW(torch.optim.Optimizer):
                                           float(self.grad_scale), int(self.skip_nonfinite),
                                           N.ptr(self.scale_state) if self.scale_state is not None else None, stream))
                 enc.after_inplace_update(pl["refreshed"], pl["stale"])
+        self._last_step_ran = True
         return loss
 
     def grad_norm(self):
@@ -150,14 +152,24 @@ class LossScaler:
         return self.state[1:2]
 
     def attach(self, optimizer):
+        """The skipped-step count (state[3]) corrects the ATTACHED optimizer's bias corrections (its `state[p]['step']` counts
+        attempted steps, the kernel subtracts the skipped ones): a different optimizer starts from a count of zero."""
+        import weakref
+        prev = getattr(self, "_attached", None)
+        if prev is not None and prev() is not None and prev() is not optimizer:
+            self._skipped_before = getattr(self, "_skipped_before", 0) + int(self.state[3].item())
+            self.state[3].zero_()
+        self._attached = weakref.ref(optimizer)
         optimizer.scale_state = self.state
         optimizer.skip_nonfinite = True
 
     def update(self, optimizer):
         """after optimizer.step(): reads the step's squared gradient norm where the optimizer left it"""
+        if optimizer._norm_sq is None or not getattr(optimizer, "_last_step_ran", True):
+            return                           # step() returned early (no parameter had a gradient): nothing to judge, the scale stands
         with torch.cuda.device(self.state.device):
             N.check(N.lib().om_loss_scale_update(N.ptr(optimizer._norm_sq), N.ptr(self.state), self.growth_interval,
                                                  N.stream_ptr(self.state.device)))
 
     def skipped_steps(self):
-        return int(self.state[3].item())
+        return int(self.state[3].item()) + getattr(self, "_skipped_before", 0)

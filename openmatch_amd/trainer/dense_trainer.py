@@ -371,6 +371,21 @@ class DRTrainer:
             self.lr_scheduler.step()
         self.optimizer.zero_grad(set_to_none=True)
 
+    def _rewind_scheduler_for_skipped_steps(self):
+        """--fp16: HF Trainer steps the LR scheduler only when GradScaler let the optimizer step run.  Here the skip happens on the
+        device (no host read per step), so `optimizer_step` always steps the scheduler; at every log line -- where the host reads the
+        running loss anyway -- the scheduler is set back by the steps the scaler skipped since the last look, so the schedule lags
+        the reference's by at most `logging_steps` steps after an overflow."""
+        scaler = getattr(self, "_scaler", None)
+        if scaler is None or self.lr_scheduler is None:
+            return
+        skipped = scaler.skipped_steps()
+        new = skipped - getattr(self, "_skipped_seen", 0)
+        self._skipped_seen = skipped
+        if new > 0 and hasattr(self.lr_scheduler, "last_epoch"):
+            self.lr_scheduler.last_epoch = max(-1, self.lr_scheduler.last_epoch - new - 1)
+            self.lr_scheduler.step()               # recomputes the groups' lr at the rewound position
+
     def _num_steps(self, loader):
         a = self.args
         accum = max(1, getattr(a, "gradient_accumulation_steps", 1))
@@ -446,6 +461,7 @@ class DRTrainer:
                 if per_epoch:                 # HF: epoch + (steps done in this epoch) / (steps per epoch)
                     self.state.epoch = epoch + min(1.0, in_epoch / per_epoch)
                 if self.state.global_step % log_every == 0:
+                    self._rewind_scheduler_for_skipped_steps()
                     entry = {"loss": float(running) / (log_every * accum), "learning_rate": self.lr_scheduler.get_last_lr()[0],
                              "epoch": self.state.epoch, "step": self.state.global_step}
                     self.state.log_history.append(entry)

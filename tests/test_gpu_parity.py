@@ -1725,7 +1725,7 @@ def test_packed_rows_training_step_matches_the_padded_step(dtype, pooling, L):
     unmasked one instead of B x L (the reference pads and computes over the padding, dataset/data_collator.py:13-24).  Same
     representations and the same gradient for EVERY parameter as the padded pair, up to the order of 16-bit-sized sums: ragged
     lengths, a full row, a mask with holes, an empty row; a row bound below the token count poisons the step (NaN) instead of
-    truncating it; with dropout the step runs and stays finite."""
+    truncating it; with dropout (same seed) the packed step equals the padded step as well: the masks are keyed on the token."""
     from transformers import BertConfig, BertModel
     from openmatch_amd import train as T
     from openmatch_amd.encoder import compute_dtype_code, rows_bound_of, token_rows_of
@@ -1775,14 +1775,33 @@ def test_packed_rows_training_step_matches_the_padded_step(dtype, pooling, L):
     if small >= 512:
         reps_bad, _ = step(small)
         assert T.LAST_CALL["packed"] and torch.isnan(reps_bad).all()
-    # dropout: runs, finite, different from the deterministic step
+    # dropout (p = 0.1, both sites): every mask is keyed on (token, column) / (sequence, head, query, key), never on the packed row
+    # (round 6; round 5 keyed the hidden-dropout masks on the row index, so the two entries drew different masks and the bench's
+    # `train.ragged` printed two different losses for one batch): the packed step equals the padded step of the same seed exactly as
+    # it does without dropout -- and differs from the deterministic step
     lm.config.hidden_dropout_prob = lm.config.attention_probs_dropout_prob = 0.1
     try:
-        reps2, g2 = step(rows)
+        torch.manual_seed(1234)
+        reps_d0, gd0 = step(None)
+        assert T.LAST_CALL == {"rows": B * L, "packed": False}
+        torch.manual_seed(1234)
+        reps_d1, gd1 = step(rows)
+        assert T.LAST_CALL == {"rows": rows, "packed": True}
     finally:
         lm.config.hidden_dropout_prob = lm.config.attention_probs_dropout_prob = 0.0
-    assert T.LAST_CALL["packed"] and torch.isfinite(reps2[keep]).all() and all(torch.isfinite(v).all() for v in g2.values())
-    assert not torch.equal(reps2, reps1)
+    assert torch.isfinite(reps_d1[keep]).all() and all(torch.isfinite(v).all() for v in gd1.values())
+    assert not torch.equal(reps_d1, reps1)
+    err_d = (reps_d1[keep] - reps_d0[keep]).abs().max().item() / reps_d0[keep].abs().max().item()
+    worst_d = ("", 0.0)
+    for n in gd0:
+        if "key.bias" in n:
+            continue
+        a, b = gd0[n].float(), gd1[n].float()
+        rel = ((a - b).norm() / a.norm().clamp_min(1e-12)).item()
+        if a.norm().item() > 1e-6 and rel > worst_d[1]:
+            worst_d = (n, rel)
+    print(f"[packed training step, {dtype}, {pooling}, dropout 0.1] reps max rel err vs padded {err_d:.2e}; worst gradient rel-L2 vs padded {worst_d[1]:.2e} ({worst_d[0]})")
+    assert err_d < 2e-3 and worst_d[1] < 2e-2, (err_d, worst_d)
 
 
 def test_trainer_takes_packed_rows_when_the_mask_is_still_on_the_host(golden, tmp_path, monkeypatch):

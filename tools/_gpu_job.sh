@@ -1,9 +1,6 @@
 set -u
-O=gpurun_out/r06_a; mkdir -p $O
+O=gpurun_out/r06_d; mkdir -p $O
 export LD_LIBRARY_PATH=$PWD/openmatch_amd/csrc:${LD_LIBRARY_PATH:-}
-timeout 1500 python -m pytest tests/test_gpu_parity_base.py -m gpu -q -s -x -k "config1 or bit_identical or bert_large" > $O/pytest_base.log 2>&1; echo "base rc=$?"
-grep -E "config 1|bert-large|passed|failed|xfail|Error|error" $O/pytest_base.log | cut -c1-400 | tail -30
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -x -k "fold_buffer or encoder_f32_matches or packed_rows_encoder or fused or two_plane or few_rows" > $O/pytest_enc.log 2>&1; echo "enc rc=$?"
-grep -E "passed|failed|Error|step/eval" $O/pytest_enc.log | cut -c1-300 | tail -10
-timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-search > $O/bench.json 2>$O/bench.err; echo "bench rc=$?"; cut -c1-1500 $O/bench.json
-OM_ENCODER_TWO_PLANE=1 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-search --no-extra --no-parity > $O/bench_oneplane.json 2>$O/bench1.err; echo "bench(one plane f16) rc=$?"; cut -c1-600 $O/bench_oneplane.json
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "packed_rows_training or scaler or float16_training or dropout or trainer_takes or training_step or gradient_cache" > $O/pytest.log 2>&1; echo "pytest rc=$?"
+grep -E "passed|failed|Error|packed training step" $O/pytest.log | cut -c1-300 | tail -14
+timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-search --no-parity 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); t=d.get('train') or {}; print(json.dumps({k:t.get(k) for k in ('value','loss')})); r=t.get('ragged') or {}; print({k:(r[k]['value'], r[k]['loss']) for k in ('padded','packed') if k in r})" | tee $O/train.txt
