@@ -106,7 +106,9 @@ void om_debug_gemm_gen(int gen);
 #define OM_OPT_ENCODER_TWO_PLANE 11 /* bit mask (env OM_ENCODER_TWO_PLANE, default 3): the fused BERT encoder keeps its pre-LayerNorm residual stream in TWO
                                    * 16-bit planes (value = hi + lo; the reference's autocast keeps it in f32) for +2 bytes per element at the two
                                    * residual sites of a layer -- bit 0 bfloat16 (round 3: 1 - cos against the fp32 chain 1e-5 instead of 4.8e-5),
-                                   * bit 1 float16 (round 6: the headline format inside the reference's own float16 autocast); 0: one plane */
+                                   * bit 1 float16 (round 6: the headline format inside the reference's own float16 autocast); bit 2 (opt-in, float16): the
+                                   * second plane in EIGHT bits (e5m2 of the remainder * 2^10, a kernel-private layout) -- + 2.6 % passages/s at the same cosine / dot
+                                   * ratios, one more swapped tie on the config-1 fixture's MRR@10; 0: one plane */
 #define OM_OPT_GEMM_VARIANT 12     /* 0 (default): automatic tile-generation choice; 1 | 2 | 6 pin a generation (A/B measurements) */
 #define OM_OPT_SEARCH_DEBUG 13     /* bit 0: om_sim_topk logs every round (rows done, chunk, list lengths) to stderr; bit 2 (A/B): the small-batch scan
                                     * fetches the index with the default cache policy instead of non-temporal loads (env OM_SEARCH_DEBUG) */

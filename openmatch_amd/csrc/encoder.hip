@@ -294,6 +294,9 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
       // (OM_OPT_ENCODER_TWO_PLANE: bit 0 bfloat16 (round 3), bit 1 float16 (round 6) -- the headline format, whose single plane was
       // what kept it outside the reference's own float16 autocast on small-weight models: DESIGN.md section 2)
       const bool two = (om_option(OM_OPT_ENCODER_TWO_PLANE) & (dt == OM_BF16 ? 1 : 2)) != 0;
+      // bit 2 (float16, opt-in): the second plane in eight bits -- + 2.6 % passages/s, the same cosine / dot ratios, one more swapped tie on
+      // the config-1 fixture's MRR@10 (gemm_wide7.h kernel 7r16, LNF == 4)
+      const int lo8 = two && dt == OM_F16 && (om_option(OM_OPT_ENCODER_TWO_PLANE) & 4) ? 1 : 0;
       const int nslots = 2 * (H / 256);
       // y1 lives in ws.y, y2 in ws.x1; ws.x is the embedding output (layer 0's input)
       // Ping-pong walk: every kernel of the chain starts on the rows its producer wrote last (reverse = 1 on every second
@@ -323,7 +326,7 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
         // ---- attention output + residual -> y1, statistics of LN1
         e = GemmEpilogue{};
         e.bias = lw.o_b; e.ldr = H; e.stats_out = ws.slots; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
-        if (two) e.out_lo = ws.y_lo;
+        if (two) { e.out_lo = ws.y_lo; e.lo8 = lo8; }
         if (l == 0) {
           e.resid = ws.x;                    // the embedding output: one plane
         } else {
@@ -345,7 +348,7 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
         e = GemmEpilogue{};
         e.bias = lw.ffn2_b; e.resid = ws.y; e.ldr = H; e.rln_stats = st1; e.rln_g = lw.ln1_g; e.rln_b = lw.ln1_b;
         e.stats_out = ws.slots; e.ln_inv_h = inv_h; e.ln_eps = c->ln_eps;
-        if (two) { e.resid_lo = ws.y_lo; e.out_lo = ws.x1_lo; }
+        if (two) { e.resid_lo = ws.y_lo; e.out_lo = ws.x1_lo; e.lo8 = lo8; }
         e.reverse = OM_WALK();
         RUN(omk_gemm(dt, ws.ff, F, lw.ffn2_w, F, dt, ws.x1, H, Mg, H, F, e, s));
         RUN(omk_ln_stats_reduce(ws.slots, nslots, Mg, st2, s));
@@ -353,7 +356,6 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
 #undef OM_WALK
       const OmLayerWeights& last = Ls[c->n_layers - 1];
       const void* lo = two ? ws.x1_lo : nullptr;
-      const int lo8 = two && dt == OM_F16 ? 1 : 0;       // float16: the second plane is the eight-bit blob of gemm_wide7.h kernel 7r16
       if (packed && c->pooling == OM_POOL_FIRST) {         // the [CLS] row of sequence b is packed row cu[b]
         RUN(omk_layernorm_f32out(dt, ws.x1, H, ws.final32, H, last.ln2_g, last.ln2_b, B, H, c->ln_eps, 0, s, lo, ws.cls_rows, lo8));
         final32_rows = B;

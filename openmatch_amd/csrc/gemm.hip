@@ -197,7 +197,7 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
     const int act = ep.act & 0xff;
     const bool resid = ep.resid != nullptr;
     const bool train16 = ep.pre_act != nullptr || ep.drop_p > 0.f || act == OM_ACT_GELU_ERF_GRAD;      // float16 training (round 5): the generic tiles
-    const int lnf = ep.ln_stats ? 1 : ((ep.rln_stats || ep.stats_out) ? (ep.out_lo ? 3 : 2) : 0);
+    const int lnf = ep.ln_stats ? 1 : ((ep.rln_stats || ep.stats_out) ? (ep.out_lo ? (ep.lo8 ? 4 : 3) : 2) : 0);
     const bool g7 = wide && !train16 && gemm_variant() == 0 && M % 256 == 0 && N % 256 == 0 && (K * 2) % 128 == 0 &&
                     (((uintptr_t)ep.bias & 15) == 0) && !(ep.ln_stats && (ep.rln_stats || ep.stats_out)) &&
                     !(lnf >= 2 && !ep.stats_out) && (!resid || (ep.ldr * 2) % 128 == 0) && !((ep.act & OM_ACT_MUL_RESID) && (lnf != 0 || !resid)) &&

@@ -863,7 +863,7 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c16(
 //                                      ring.sp (the unit B(nk - 1) left)      slices 0-3 staging patch
 // (slice i of a unit = this wave's i-th own KiB, at unit + (4 i + wave) KiB: no wave touches another wave's slices.)
 // =========================================================================================================================
-// LNF == 3, float16 (round 6, second step): the second plane in EIGHT bits.  The first version (two float16 planes, kept for bfloat16)
+// LNF == 4, float16 only (round 6, second step; OPT-IN: OM_ENCODER_TWO_PLANE bit 2): the second plane in EIGHT bits.  The first version (two 16-bit planes, LNF == 3)
 // paid 44 k cycles per tile epilogue against 24 k with one plane (tools/epilogue_trace.py, profiles/r06_epilogue_trace_*.json): the
 // epilogue's time is its count of 1 KiB vector-memory operations (~300 cycles each per wave with four waves issuing), and two planes
 // double them.  The remainder y - hi is at most half an ulp of hi, so e5m2 of (remainder * 2^10) carries y to ~2^-14 |y| -- eight times
@@ -875,6 +875,10 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c16(
 // + 6 stores (16 with two 16-bit planes, 8 with one).  LDS: entry e = hi 4 KiB + lo 2 KiB (slices 0-5 of ring.an / ring.bn), tables in
 // slices 6-7 of ring.an and slice 6 of ring.bn, staging in ring.sp; all sixteen tail slots of the last K step are fetches of patches 0 / 1
 // and the tables.  kernels.h: omk_lo8_offset is the blob's index function (the final LayerNorm kernels decode through it).
+// Measured (profiles/r06_*): epilogue 33.5 k cycles per tile against 44.0 k (two 16-bit planes) and 23.8 k (one plane); encode 42.6 k
+// passages/s against 41.5 k / 44.2 k; 1 - cos and max |ddot| on the config-1 fixture 0.73 x / 0.74 x of the reference's float16 autocast,
+// the same as with two 16-bit planes -- but the fixture's tie-broken MRR@10 moves by one swapped pair (0.0048; 0.0000 with 16 bits, the
+// reference's own float16 run 0.0007), so the default stays LNF == 3.
 // LNF == 3 (round 6): the same on the TWO-PLANE residual stream of gemm_nt_kernel7 above (y = y_hi + y_lo; the residual is read as
 // r_hi + r_lo, the output written as C = round16(y), ep.out_lo = round16(y - C)) -- both 16-bit formats; float16 is the headline
 // format since round 4 and kept its stream in ONE plane until now, which put it 2.6 x (1 - cos) / 1.8 x (max |ddot|) outside the
@@ -899,12 +903,12 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
   typedef T OutT;
   typedef typename MmaOps<T>::frag_t frag_t;
   static_assert(sizeof(T) == 2, "16-bit in, 16-bit out");
-  static_assert(LNF == 0 || LNF == 2 || LNF == 3, "residual variants: plain, or output-side LayerNorm on a one- / two-plane residual stream");
+  static_assert(LNF == 0 || LNF == 2 || LNF == 3 || LNF == 4, "residual variants: plain, or output-side LayerNorm on a one- / two-plane residual stream");
+  static_assert(LNF != 4 || std::is_same<T, f16_t>::value, "the eight-bit second plane is a float16 format (half an ulp of float16 * 2^10 fits e5m2)");
   constexpr bool LNO = LNF >= 2;
-  constexpr bool TWO = LNF == 3;               // two-plane residual stream (round 6): see the layout note above the kernel
-  // float16: the second plane is EIGHT bits per element (e5m2 of remainder * 2^10) in a wave-native blob -- see the note above the kernel
-  constexpr bool LO8 = TWO && std::is_same<T, f16_t>::value;
-  constexpr bool TWO16 = TWO && !LO8;          // bfloat16 (opt-in, OM_GEMM_CONT bit 9): a second 16-bit row-major plane
+  constexpr bool TWO = LNF >= 3;               // two-plane residual stream (round 6): see the layout notes above the kernel
+  constexpr bool LO8 = LNF == 4;               // ... whose second plane is EIGHT bits per element (e5m2 of remainder * 2^10) in a wave-native blob
+  constexpr bool TWO16 = LNF == 3;             // ... or a second 16-bit row-major plane
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1395,7 +1399,7 @@ static int launch7r(const void* A, int64_t lda, const void* B, int64_t ldb, void
                     int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
   const int64_t ntiles = (M / 256) * (N / 256);
   if (ntiles >= 0x7fff0000LL) OM_FAIL("gemm: more than 2^31 output tiles");
-  if (LNF == 3 && (!ep.out_lo || ((uintptr_t)ep.out_lo & 15) || ((uintptr_t)ep.resid_lo & 15))) OM_FAIL("two-plane residual epilogue: out_lo (and resid_lo) 16-byte aligned planes");
+  if (LNF >= 3 && (!ep.out_lo || ((uintptr_t)ep.out_lo & 15) || ((uintptr_t)ep.resid_lo & 15))) OM_FAIL("two-plane residual epilogue: out_lo (and resid_lo) 16-byte aligned planes");
   int grid = g7_num_cus();
   const int cap = om_option(OM_OPT_GEMM_MAX_GRID);
   if (cap > 0 && cap < grid) grid = cap;
@@ -1424,6 +1428,10 @@ static int launch7(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   if constexpr (RESID && (LNF == 0 || LNF == 2)) {      // one-plane residual variants on the continuous ring (bit 1 of the option)
     if (K * 2 >= 3 * G7_ROW_BYTES && (om_option(OM_OPT_GEMM_CONT) & 2) != 0) return launch7r<T, ACT, LNF>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
   }
+  if constexpr (LNF == 4) {                              // float16 with the eight-bit second plane: the continuous kernel only
+    if (K * 2 < 3 * G7_ROW_BYTES) OM_FAIL("two-plane residual epilogue with the eight-bit plane: K >= 192");
+    return launch7r<T, ACT, LNF>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+  } else {
   if constexpr (RESID && LNF == 3) {                     // two-plane residual variant on the continuous ring (round 6): bit 8 float16, bit 9 bfloat16
     // (bfloat16 stays on the restart-per-tile kernel by default: the continuous kernel is 1.3 % faster end to end, but its 16 x 16 x 32 summation
     // order moves the config-1 fixture's tie-broken MRR@10 from 0.0025 to 0.0037 against the reference's own 0.0035 -- one swapped pair)
@@ -1449,4 +1457,5 @@ static int launch7(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, 2.0 * (double)M * (double)N * (double)K);
   OM_LAUNCH_CHECK();
   return 0;
+  }
 }

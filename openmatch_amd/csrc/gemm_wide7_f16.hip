@@ -5,7 +5,7 @@
 #include "gemm_wide7.h"
 
 bool omk_gemm_wide7_f16_has(int act, bool resid, int lnf) {
-  if (lnf == 2 || lnf == 3) return act == OM_ACT_NONE && resid;
+  if (lnf == 2 || lnf == 3 || lnf == 4) return act == OM_ACT_NONE && resid;
   if (lnf == 1) return !resid && (act == OM_ACT_NONE || act == OM_ACT_GELU_ERF || act == OM_ACT_RELU);
   return (act == OM_ACT_NONE) || ((act == OM_ACT_GELU_ERF || act == OM_ACT_RELU) && !resid);      // (T5's gated tanh-GELU layers: the generic tiles)
 }
@@ -14,16 +14,18 @@ int omk_gemm_wide7_f16(const void* A, int64_t lda, const void* B, int64_t ldb, v
                        int64_t N, int64_t K, const GemmEpilogue& ep, hipStream_t s) {
   const int act = ep.act & 0xff;
   const bool resid = ep.resid != nullptr;
-  const int lnf = ep.ln_stats ? 1 : ((ep.rln_stats || ep.stats_out) ? (ep.out_lo ? 3 : 2) : 0);
+  const int lnf = ep.ln_stats ? 1 : ((ep.rln_stats || ep.stats_out) ? (ep.out_lo ? (ep.lo8 ? 4 : 3) : 2) : 0);
   if (M % 256 || N % 256 || (K * 2) % G7_ROW_BYTES) OM_FAIL("generation 7 takes whole 256 x 256 tiles and 128-byte K steps");
   if (lnf >= 2 && !ep.stats_out) OM_FAIL("the output-side LayerNorm variant accumulates row statistics: stats_out is null");
-  if ((ep.out_lo || ep.resid_lo) && lnf != 3) OM_FAIL("two-plane residual stream: only with the output-side LayerNorm epilogue");
+  if ((ep.out_lo || ep.resid_lo) && lnf < 3) OM_FAIL("two-plane residual stream: only with the output-side LayerNorm epilogue");
   if (ep.ln_stats && (ep.rln_stats || ep.stats_out)) OM_FAIL("fused LayerNorm: either the A side or the output side");
 #define OM_L7(A_, R_, F_) return launch7<f16_t, A_, R_, F_>(A, lda, B, ldb, C, ldc, M, N, K, ep, s)
   if (lnf == 2) {
     if (act == OM_ACT_NONE && resid) OM_L7(OM_ACT_NONE, true, 2);
   } else if (lnf == 3) {                     // two-plane residual stream (round 6: GemmEpilogue::out_lo / resid_lo)
     if (act == OM_ACT_NONE && resid) OM_L7(OM_ACT_NONE, true, 3);
+  } else if (lnf == 4) {                     // ... with the eight-bit second plane (GemmEpilogue::lo8)
+    if (act == OM_ACT_NONE && resid) OM_L7(OM_ACT_NONE, true, 4);
   } else if (lnf == 1) {
     if (act == OM_ACT_NONE && !resid) OM_L7(OM_ACT_NONE, false, 1);
     if (act == OM_ACT_GELU_ERF && !resid) OM_L7(OM_ACT_GELU_ERF, false, 1);

@@ -65,6 +65,7 @@ struct GemmEpilogue {
                              //   omk_ln_stats_reduce adds the slots in a fixed order into the [M][2] array the consumers read
   const void* resid_lo;      // two-plane residual stream (bf16 BERT inference): the residual is resid + resid_lo (NULL: one plane)
   void* out_lo;              //   and the output is written as C = round16(y), out_lo = round16(y - C); selects the LNF == 3 kernel
+  int lo8;                   //   1 (float16): both second planes are EIGHT-bit blobs (omk_lo8_offset below; the LNF == 4 kernel) instead of 16-bit matrices
   float ln_inv_h, ln_eps;
   int ln_rms;                // 1: the statistics describe a T5 RMSNorm (no mean, no shift): only sum of squares is used
   int reverse;               // 1: walk the output tiles from the last row block to the first (persistent 16-bit kernel only).

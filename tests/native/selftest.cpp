@@ -263,6 +263,43 @@ static void test_contrastive() {
   report("contrastive loss", e, 1e-5); report("contrastive scores", es, 1e-5); report("contrastive d_q (local rows)", eq, 1e-6); report("contrastive d_p (local rows)", ep, 1e-6);
 }
 
+// The C-ABI collectives on a ONE-rank communicator (every box so far had one GPU): om_comm_unique_id -> om_comm_init -> om_allgather_rows ->
+// om_allreduce_grads -> om_exchange_topk -> om_topk_merge, the call sequence of a sharded search and of cross-device negatives, with no
+// Python in between (include/openmatch_hip.h:561-573; reference: modeling/dense_retrieval_model.py:247-258, retriever/dense_retriever.py:43-58).
+static void test_collectives_one_rank() {
+  unsigned char id[OM_COMM_ID_BYTES];
+  if (om_comm_unique_id(id)) { printf("%-64s SKIPPED (RCCL not loadable: %s)\n", "collectives on a one-rank communicator", om_last_error()); return; }
+  void* comm = nullptr;
+  OMCK(om_comm_init(id, 1, 0, &comm));
+  int count = 0; OMCK(om_comm_count(comm, &count));
+  report("comm: one rank as RCCL counts them", count == 1 ? 0 : 1, 0);
+  const int rows = 37, d = 96;
+  auto x = randn((size_t)rows * d);
+  float* dx = upload(x); float* dg = dalloc<float>((size_t)rows * d);
+  OMCK(om_allgather_rows(comm, dx, dg, rows, (int64_t)d * 4, nullptr)); CK(hipDeviceSynchronize());
+  auto g = download(dg, (size_t)rows * d);
+  double e = 0; for (size_t i = 0; i < g.size(); ++i) e = std::max(e, (double)fabs(g[i] - x[i]));
+  report("allgather_rows (world 1: the rows themselves)", e, 0);
+  OMCK(om_allreduce_grads(comm, dg, (int64_t)rows * d, 1, nullptr)); CK(hipDeviceSynchronize());
+  g = download(dg, (size_t)rows * d);
+  e = 0; for (size_t i = 0; i < g.size(); ++i) e = std::max(e, (double)fabs(g[i] - x[i]));
+  report("allreduce_grads average (world 1: unchanged)", e, 0);
+  // a shard's candidates [world = 1][q_block][k] -> the owner of the query block, then the merge
+  const int Q = 6, k = 16;
+  std::vector<float> D((size_t)Q * k); std::vector<int64_t> I(D.size());
+  for (int q = 0; q < Q; ++q) { std::vector<float> v(k); for (auto& t : v) t = (float)(rng() % 1000) * 0.01f; std::sort(v.begin(), v.end(), std::greater<float>());
+    for (int j = 0; j < k; ++j) { D[q * k + j] = v[j]; I[q * k + j] = 1000 * q + j; } }
+  float* dD = upload(D); int64_t* dI = upload(I); float* rD = dalloc<float>(D.size()); int64_t* rI = dalloc<int64_t>(I.size());
+  OMCK(om_exchange_topk(comm, 1, dD, dI, Q, k, rD, rI, nullptr));
+  float* mD = dalloc<float>((size_t)Q * k); int64_t* mI = dalloc<int64_t>((size_t)Q * k);
+  OMCK(om_topk_merge(rD, rI, 1, Q, k, k, mD, mI, nullptr)); CK(hipDeviceSynchronize());
+  auto oD = download(mD, D.size()); auto oI = download(mI, I.size());
+  int bad = 0; for (size_t i = 0; i < D.size(); ++i) bad += (oD[i] != D[i]) || (oI[i] != I[i]);
+  report("exchange_topk + topk_merge (world 1: the shard's own lists)", bad, 0);
+  OMCK(om_comm_destroy(comm));
+  hipFree(dx); hipFree(dg); hipFree(dD); hipFree(dI); hipFree(rD); hipFree(rI); hipFree(mD); hipFree(mI);
+}
+
 // ---------------------------------------------------------------- micro-benchmarks
 static void bench_gemm(int dtype, int64_t M, int64_t N, int64_t K, int act) {
   size_t es = dtype == OM_BF16 ? 2 : 4;
@@ -386,6 +423,7 @@ int main(int argc, char** argv) {
     }
     test_merge();
     test_contrastive();
+    test_collectives_one_rank();
   }
   if (what == "trace") {
     const int64_t N = argc > 2 ? atoi(argv[2]) : 768, K = argc > 3 ? atoi(argv[3]) : 768, M = argc > 4 ? atoll(argv[4]) : 32768;

@@ -473,6 +473,63 @@ def test_fused_layernorm_path_matches_unfused_and_oracle(hidden, heads, ffn):
         assert not torch.equal(fused, plain)          # the two paths really are different code
 
 
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_residual_stream_variants_of_the_fused_path(dtype):
+    """The pre-LayerNorm residual stream of the fused 16-bit path (OM_OPT_ENCODER_TWO_PLANE, include/openmatch_hip.h): one 16-bit plane,
+    two 16-bit planes (default; the continuous-ring kernel 7r16 with LNF == 3 for float16 and -- OM_GEMM_CONT bit 9 -- for bfloat16, whose
+    default is the restart-per-tile kernel), and float16's 16 + 8-bit form (LNF == 4: e5m2 remainders in the kernel's own lane order,
+    decoded by the final LayerNorm through omk_lo8_offset).  Every variant tracks the f32 oracle; the two-plane forms are closer to it
+    than the one-plane form, and the eight-bit plane lands where the sixteen-bit one does (first and mean pooling: the CLS-row gather and
+    the all-rows read of the final LayerNorm; a ragged batch and a row count that is not a multiple of 256)."""
+    from transformers import BertConfig, BertModel
+    from openmatch.modeling import DRModelForInference
+    from openmatch_amd import native as N
+    torch.manual_seed(13)
+    cfg = BertConfig(hidden_size=512, num_hidden_layers=4, num_attention_heads=8, intermediate_size=1024, vocab_size=600,
+                     max_position_embeddings=128)
+    lm = BertModel(cfg).eval()
+    with torch.no_grad():
+        for name, p in lm.named_parameters():
+            if "LayerNorm.weight" in name:
+                p.copy_(1.0 + 0.3 * torch.randn_like(p))
+            elif "LayerNorm.bias" in name:
+                p.copy_(0.2 * torch.randn_like(p))
+    sd = {k: v.clone() for k, v in lm.state_dict().items()}
+    rng = np.random.default_rng(21)
+    bit = 2 if dtype == "float16" else 1
+    variants = [("one", 0, 495), ("two16", bit, 495)]
+    variants += [("two8", 2 | 4, 495)] if dtype == "float16" else [("two16_cont", 1, 495 | 512)]
+    err = {}
+    for pooling in ("first", "mean"):
+        model = DRModelForInference(lm_q=lm, lm_p=lm, pooling=pooling, normalize=False,
+                                    model_args=NS(encoder_only=False, dtype=dtype)).to(DEV).eval()
+        for B, L in ((40, 128), (21, 100)):
+            ids, mask = synth_tokens(rng, B, L, vocab=600, lo_len=5, lo_id=300)
+            items = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
+            dev_items = {k: v.to(DEV) for k, v in items.items()}
+            _, ref = encoder_ref.encode(sd, cfg, "bert", items, pooling, None, False)
+            ref = ref.double()
+            for name, planes, cont in variants:
+                N.check(N.lib().om_debug_option(11, planes)); N.check(N.lib().om_debug_option(16, cont)); N.check(N.lib().om_debug_option(19, 0))
+                try:
+                    _, reps = model.encode_passage(dev_items)
+                    _, again = model.encode_passage(dev_items)
+                finally:
+                    N.check(N.lib().om_debug_option(11, 3)); N.check(N.lib().om_debug_option(16, 495)); N.check(N.lib().om_debug_option(19, 1024))
+                assert torch.isfinite(reps).all() and torch.equal(reps, again), (name, pooling, B, L)
+                e = ((reps.double().cpu() - ref).norm(dim=1) / ref.norm(dim=1)).max().item()
+                err.setdefault(name, []).append(e)
+    worst = {k: max(v) for k, v in err.items()}
+    print(f"\n[residual stream, {dtype}] worst relative row error vs the f32 oracle: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+    tol = 2e-3 if dtype == "float16" else 2e-2
+    assert all(v < tol for v in worst.values()), worst
+    assert worst["two16"] < worst["one"], worst
+    if dtype == "float16":
+        assert worst["two8"] < worst["one"] and worst["two8"] < 1.25 * worst["two16"], worst
+    else:
+        assert worst["two16_cont"] < worst["one"], worst
+
+
 @pytest.mark.parametrize("gated", [False, True])
 def test_fused_rmsnorm_path_matches_unfused_and_oracle(gated):
     """The T5 counterpart: RMSNorm folded into the GEMMs (bf16, >= 512 tokens), GTR-style tail."""
