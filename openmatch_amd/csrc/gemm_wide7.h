@@ -722,6 +722,7 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c16(
   } while (0)
 #define G7C_ITER(P_, C0, C1, C2, C3, N0, N1, N2, N3)                                                           \
   do {                                                                                                         \
+    if constexpr ((P_) < 8) { if (tr_prev && threadIdx.x == 0) tr_prev[17 + (P_)] = clock64(); }               \
     if constexpr ((P_) + 1 < NVP) {                                                                            \
       G7C_WRITE_V((P_) + 1, 0); G7_FENCE_(); G7C_ST(P_, 0, C0); G7_FENCE_();                                   \
       G7C_WRITE_V((P_) + 1, 1); G7_FENCE_(); G7C_ST(P_, 1, C1); G7_FENCE_();                                   \
@@ -738,6 +739,7 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c16(
 #define G7C_ITER_(...) G7C_ITER(__VA_ARGS__)
 
     if (live) {
+      if (tr_prev && threadIdx.x == 0) tr_prev[16] = clock64();
       G7C_WRITE_V(0, 0); G7C_WRITE_V(0, 1); G7C_WRITE_V(0, 2); G7C_WRITE_V(0, 3);
       G7_FENCE_();
       sa0 = G7C_RB(0); sa1 = G7C_RB(1); sa2 = G7C_RB(2); sa3 = G7C_RB(3);
@@ -761,32 +763,53 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c16(
     // ---- the next tile's initialising fragments: u_m b_n + v_m s_n as ONE 16 x 16 x 32 MFMA per tile, factors split into
     // 16-bit hi + lo in k slots 0-5 of k block 0 (lanes 0-15); the other k blocks are zero
     if (have) {
-      if (live) G7_WAIT_VM(8); else G7_WAIT_VM(0);
+      // The next tile's tables (fetched at the top of this epilogue) have landed once nothing OLDER than the stores issued since is
+      // outstanding: 6 (TRAIN: 13) patch iterations of four stores.  Rounds 4-5 waited vmcnt(8) here -- for the ACKNOWLEDGEMENT of all but
+      // the last two patches' stores, 2.5 k of the 47.6 k cycles of an FFN1 tile (tools/epilogue_trace.py: the iteration in front of this
+      // block took 5.0 k cycles where its neighbours take 1.5-1.6 k).
+      if (live) { if constexpr (TRAIN) G7_WAIT_VM(52); else G7_WAIT_VM(24); } else G7_WAIT_VM(0);
       const bool ln_in = LNF == 1 && ep.ln_stats != nullptr;
       const bool has_cs = LNF == 1 && ep.ln_colsum != nullptr, has_b = ep.bias != nullptr;
       auto split = [](float x, uint32_t& hi, uint32_t& lo) {
         hi = Half16<T>::bits(x); lo = Half16<T>::bits(x - Half16<T>::value(hi));
       };
+      // Round 6: the eight row blocks' statistics are read first and their chains kept free of branches and of libm's correctly rounded
+      // sqrtf (u = sqrt(var) only feeds a 16-bit hi + lo split: var * rsq(var) is exact enough, and var >= eps is never subnormal, so the
+      // bare v_rsq_f32 is what rsqrtf would return) -- the form of rounds 4-5 was eight DEPENDENT chains of ~40 instructions behind one
+      // LDS read each, a branch between them: 3.4 k cycles per tile on the only wave of the SIMD (tools/epilogue_trace.py, FFN1: the
+      // iteration in front of this block 4.9-5.0 k cycles, its neighbours 1.5-1.6 k).
+      float uu[8], vv[8];
+      {
+        float2 st[8];
+#pragma unroll
+        for (int ti = 0; ti < 8; ++ti) {       // unconditional reads (eight in flight, one wait): without statistics the values are never selected
+          if constexpr (LNF == 1) st[ti] = *(const float2*)(tab1 + (ti * 16 + l15) * 8); else st[ti] = make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int ti = 0; ti < 8; ++ti) {
+          const float mu = ep.ln_rms ? 0.f : st[ti].x * ep.ln_inv_h;
+          const float var = fmaxf(st[ti].y * ep.ln_inv_h - mu * mu, 0.f) + ep.ln_eps;
+          const float rstd = __builtin_amdgcn_rsqf(var);
+          rsn[ti] = ln_in ? rstd : 1.f;
+          uu[ti] = ln_in ? var * rstd : 1.f;
+          vv[ti] = ln_in ? -mu : 0.f;
+        }
+      }
 #pragma unroll
       for (int ti = 0; ti < 8; ++ti) {
-        float u = 1.f, v = 0.f;
-        if (ln_in) {
-          const float2 st = *(const float2*)(tab1 + (ti * 16 + l15) * 8);
-          const float mu = ep.ln_rms ? 0.f : st.x * ep.ln_inv_h;
-          const float var = fmaxf(st.y * ep.ln_inv_h - mu * mu, 0.f) + ep.ln_eps;
-          rsn[ti] = rsqrtf(var);
-          u = sqrtf(var); v = -mu;
-        }
         uint32_t uh, ul, vh, vl;
-        split(u, uh, ul); split(v, vh, vl);
+        split(uu[ti], uh, ul); split(vv[ti], vh, vl);
         uint4 w = make_uint4(uh | (ul << 16), uh | (vh << 16), vl | (vh << 16), 0u);     // k: u_hi u_lo u_hi v_hi v_lo v_hi 0 0
         if (q4) w = make_uint4(0u, 0u, 0u, 0u);
         asm volatile("" : "+v"(w.x), "+v"(w.y), "+v"(w.z));       // opaque per row block: one MFMA per tile, no accumulator copies
         fa[ti] = __builtin_bit_cast(frag_t, w);
       }
+      float bb[8], ss[8];
+#pragma unroll
+      for (int fj = 0; fj < 8; ++fj) { bb[fj] = *(const float*)(tab0 + 512 + (fj * 16 + l15) * 4); ss[fj] = *(const float*)(tab0 + (fj * 16 + l15) * 4); }
 #pragma unroll
       for (int fj = 0; fj < 8; ++fj) {
-        float b = *(const float*)(tab0 + 512 + (fj * 16 + l15) * 4), sc = *(const float*)(tab0 + (fj * 16 + l15) * 4);
+        float b = bb[fj], sc = ss[fj];
         if (!has_b) b = 0.f;
         if (!(ln_in && has_cs)) sc = 0.f;
         uint32_t bh, bl, sh, sl;
@@ -1225,9 +1248,12 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
       auto split = [](float x, uint32_t& hi, uint32_t& lo) {
         hi = Half16<T>::bits(x); lo = Half16<T>::bits(x - Half16<T>::value(hi));
       };
+      float bb[8];
+#pragma unroll
+      for (int fj = 0; fj < 8; ++fj) bb[fj] = *(const float*)(tab0 + 512 + (fj * 16 + l15) * 4);      // (eight reads in flight, one wait)
 #pragma unroll
       for (int fj = 0; fj < 8; ++fj) {
-        float b = *(const float*)(tab0 + 512 + (fj * 16 + l15) * 4);
+        float b = bb[fj];
         if (!has_b) b = 0.f;
         uint32_t bh, bl;
         split(b, bh, bl);

@@ -925,6 +925,8 @@ __global__ __launch_bounds__(256) void select_radix_kernel(
   for (int shift = 24; shift >= 0; shift -= 8) {
     hist[tid] = 0;
     __syncthreads();
+    // (round 6 probe: one LDS atomic per DISTINCT bin of a wave for the two high bytes -- where nearly every lane names the same bin -- ran
+    // 170 us per launch against 152: the same-address atomics are not what this kernel waits for; it is 3 % of a search)
     for (unsigned i = tid; i < n; i += 256) {
       const uint32_t v = (uint32_t)(src[i] >> 32);
       if ((v & mask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
@@ -1322,7 +1324,10 @@ struct Scan {
       // Few queries: the exact re-score and the final sort are queued BEHIND the last round before the flags are read, so
       // the host's wake-up overlaps them instead of idling the device (a 34 us hole per search at one query).  They
       // cover lists up to twice the estimate; a longer list (never seen) counts as a failed fast schedule.
-      const bool spec = bf16 && nq <= 32;
+      // (round 6: up to 128 queries, the whole small-batch regime of the register-resident stream kernel -- a search of 2.6-3.3 ms; at
+      // thousands of queries the one wake-up per 90 ms search is nothing, and a re-score grid sized for twice the estimate would launch
+      // millions of empty workgroups.  om_sim_topk has exactly ONE host synchronisation per search on this schedule: this read)
+      const bool spec = bf16 && nq <= 128;
       const unsigned spec_cover = (unsigned)std::min<int64_t>(2 * list, SORT_CAP);
       if (spec) {
         if (rescore(spec_cover)) return 1;

@@ -357,8 +357,11 @@ __global__ __launch_bounds__((NV == 8 || MODE == 1) ? 256 : 512, (NV == 8 || MOD
           store4<T>(dx + row * H + c, out);
           if (dx_drop) {               // dropout of the value as stored (rounded to T), like the separate pass it replaces
             float dr[4];
-            const int64_t krow = (MODE == 0 && cu) ? (int64_t)cu[row] : row;              // MODE 0: `cu` carries the packed rows' token map
-            const uint64_t bits = dropout_bits(drop_seed, (uint64_t)(krow * H + c) >> 2);  // H % 4 == 0: one group
+            // MODE 0: `cu` carries the packed rows' token map; a wave works on ONE row, so the look-up is a scalar load (a per-lane
+            // load cost the three registers this 128-register kernel does not have)
+            int krow = __builtin_amdgcn_readfirstlane((int)row);
+            if (MODE == 0 && cu) krow = cu[krow];
+            const uint64_t bits = dropout_bits(drop_seed, (uint64_t)((int64_t)krow * H + c) >> 2);  // H % 4 == 0: one group
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float vb = sizeof(T) == 2 ? Half16<T>::value(Half16<T>::bits(out[e])) : out[e];

@@ -61,6 +61,25 @@ def main():
         rows.sort(key=lambda r: r[0])
         gaps += [int(b[0] - a[0]) for a, b in zip(rows, rows[1:])]
     out["tile_period"] = med(np.array(gaps)) if gaps else None
+    # FFN1 + GELU of the last layer (kernel 7c16): tile ids [nt, 4 nt) survive the later FFN2 launch; stamps [16] epilogue start,
+    # [17 + p] start of patch iteration p (p < 8), [28] last store issued
+    t1 = buf.cpu().numpy().reshape(ntile, 32).astype(np.int64)[nt:4 * nt]
+    ok1 = (t1[:, 28] > t1[:, 15]) & (t1[:, 15] > t1[:, 0]) & (t1[:, 0] > 0)
+    t1 = t1[ok1]
+    if len(t1):
+        f1 = {"tiles": int(ok1.sum()), "k_loop": med(t1[:, 15] - t1[:, 0]), "epilogue_total": med(t1[:, 28] - t1[:, 15]),
+              "k_end_to_epilogue_start": med(t1[:, 16] - t1[:, 15]),
+              "patch_iter": [med(t1[:, 18 + p] - t1[:, 17 + p]) for p in range(7)], "last_iter_to_end": med(t1[:, 28] - t1[:, 24])}
+        by = {}
+        for row in t1:
+            by.setdefault(int(row[29]), []).append(row)
+        g1 = []
+        for rows in by.values():
+            rows.sort(key=lambda r: r[0])
+            g1 += [int(b[0] - a[0]) for a, b in zip(rows, rows[1:])]
+        f1["tile_period"] = med(np.array(g1)) if g1 else None
+        out["ffn1_gelu"] = f1
+    out["epi_skew"] = os.environ.get("OM_GEMM_EPI_SKEW", "0")
     print(json.dumps(out))
 
 
