@@ -420,7 +420,7 @@ template <typename T, int KT>
 static int launch_attn16(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias, int64_t B, int L, int H,
                          int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, int rev, const int* kmax, const int* cu = nullptr) {
   if (std::is_same<T, f16_t>::value) {            // float16: BERT-family encoders; dropout for float16 training, T5's bias table for inference (round 5)
-    if (pos_bias && drop_p > 0.f) OM_FAIL("float16 attention: a position-bias table in inference only (T5 trains in bfloat16)");
+    if (pos_bias && drop_p > 0.f) return launch_attn16_<f16_t, KT, true, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, rev, kmax, cu);   // float16 T5 training (round 6)
     if (pos_bias) return launch_attn16_<f16_t, KT, true, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev, kmax, cu);
     if (drop_p > 0.f) return launch_attn16_<f16_t, KT, false, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, rev, kmax, cu);
     return launch_attn16_<T, KT, false, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, rev, kmax, cu);

@@ -91,7 +91,7 @@ struct DecWs { char *x, *n, *t, *ctx, *ff, *ff2, *kv; size_t total; };
 DecWs carve(const OmEncoderConfig* c, int64_t B, int64_t L, char* base) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return base + o; };
-  const size_t es = c->dtype == OM_BF16 ? 2 : 4;
+  const size_t es = (c->dtype == OM_BF16 || c->dtype == OM_F16) ? 2 : 4;
   DecWs w;
   w.x = take((size_t)B * c->hidden * es); w.n = take((size_t)B * c->hidden * es);
   w.t = take((size_t)B * c->hidden * es); w.ctx = take((size_t)B * c->hidden * es);
@@ -113,7 +113,7 @@ extern "C" int om_t5_decoder_step(const OmEncoderConfig* c, const OmT5DecoderWei
   if (!c || !w || !enc_hidden || !attention_mask || !out_hidden) OM_FAIL("null argument");
   if (B <= 0) return 0;
   if (c->arch != OM_ARCH_T5) OM_FAIL("decoder step: T5 only");
-  if (c->dtype != OM_F32 && c->dtype != OM_BF16) OM_FAIL("dtype must be OM_F32 or OM_BF16");
+  if (c->dtype != OM_F32 && c->dtype != OM_BF16 && c->dtype != OM_F16) OM_FAIL("dtype must be OM_F32, OM_BF16 or OM_F16");
   if (c->head_dim != 64 || c->n_heads * 64 != c->hidden) OM_FAIL("head_dim must be 64 (inner dim == d_model)");
   if (L < 1 || L > 256) OM_FAIL("sequence length must be in [1,256]");
   if (!w->layers_host || w->n_layers < 1 || !w->start_emb || !w->final_ln_g) OM_FAIL("incomplete decoder weights");
@@ -130,6 +130,7 @@ extern "C" int om_t5_decoder_step(const OmEncoderConfig* c, const OmT5DecoderWei
     if (om_gemm_nt(dt, A_, lda_, W_, ldw_, dt, C_, ldc_, M_, N_, K_, nullptr, res_, ldr_, act_, s)) return 1; \
   } while (0)
   if (dt == OM_BF16) hipLaunchKernelGGL((dec_start_kernel<bf16_t>), dim3((unsigned)((B * H + 255) / 256)), dim3(256), 0, s, w->start_emb, (bf16_t*)ws.x, B, H);
+  else if (dt == OM_F16) hipLaunchKernelGGL((dec_start_kernel<f16_t>), dim3((unsigned)((B * H + 255) / 256)), dim3(256), 0, s, w->start_emb, (f16_t*)ws.x, B, H);
   else hipLaunchKernelGGL((dec_start_kernel<float>), dim3((unsigned)((B * H + 255) / 256)), dim3(256), 0, s, w->start_emb, (float*)ws.x, B, H);
   OM_LAUNCH_CHECK();
   for (int l = 0; l < w->n_layers; ++l) {
@@ -145,6 +146,7 @@ extern "C" int om_t5_decoder_step(const OmEncoderConfig* c, const OmT5DecoderWei
     GEMM(ws.n, H, lw.ca_q_w, H, ws.t, H, B, H, H, nullptr, 0, OM_ACT_NONE);
     GEMM(enc_hidden, H, lw.ca_kv_w, H, ws.kv, 2 * H, M, 2 * H, H, nullptr, 0, OM_ACT_NONE);
     if (dt == OM_BF16) hipLaunchKernelGGL((dec_cross_kernel<bf16_t>), dim3((unsigned)(B * nh)), dim3(256), 0, s, (const bf16_t*)ws.t, (const bf16_t*)ws.kv, attention_mask, (bf16_t*)ws.ctx, (int)L, H, nh, 0.f, 0ull);
+    else if (dt == OM_F16) hipLaunchKernelGGL((dec_cross_kernel<f16_t>), dim3((unsigned)(B * nh)), dim3(256), 0, s, (const f16_t*)ws.t, (const f16_t*)ws.kv, attention_mask, (f16_t*)ws.ctx, (int)L, H, nh, 0.f, 0ull);
     else hipLaunchKernelGGL((dec_cross_kernel<float>), dim3((unsigned)(B * nh)), dim3(256), 0, s, (const float*)ws.t, (const float*)ws.kv, attention_mask, (float*)ws.ctx, (int)L, H, nh, 0.f, 0ull);
     OM_LAUNCH_CHECK();
     GEMM(ws.ctx, H, lw.ca_o_w, H, ws.x, H, B, H, H, ws.x, H, OM_ACT_NONE);
@@ -159,6 +161,7 @@ extern "C" int om_t5_decoder_step(const OmEncoderConfig* c, const OmT5DecoderWei
     GEMM(ws.ff, F, lw.ffn2_w, F, ws.x, H, B, H, F, ws.x, H, OM_ACT_NONE);
   }
   if (dt == OM_BF16) hipLaunchKernelGGL((dec_final_kernel<bf16_t>), dim3((unsigned)B), dim3(256), 0, s, (const bf16_t*)ws.x, w->final_ln_g, out_hidden, H, c->ln_eps);
+  else if (dt == OM_F16) hipLaunchKernelGGL((dec_final_kernel<f16_t>), dim3((unsigned)B), dim3(256), 0, s, (const f16_t*)ws.x, w->final_ln_g, out_hidden, H, c->ln_eps);
   else hipLaunchKernelGGL((dec_final_kernel<float>), dim3((unsigned)B), dim3(256), 0, s, (const float*)ws.x, w->final_ln_g, out_hidden, H, c->ln_eps);
   OM_LAUNCH_CHECK();
 #undef GEMM
@@ -270,7 +273,7 @@ struct DecTape {
   char* at(int l, size_t off) const { return base + sl * l + off; }
 };
 DecTape dec_tape(const OmEncoderConfig* c, int nl, int64_t B, int64_t L, char* base) {
-  const size_t es = c->dtype == OM_BF16 ? 2 : 4;
+  const size_t es = (c->dtype == OM_BF16 || c->dtype == OM_F16) ? 2 : 4;
   const size_t bh = align_up((size_t)B * c->hidden * es, 256), bf = align_up((size_t)B * c->ffn * es, 256);
   DecTape t;
   t.base = base;
@@ -291,7 +294,7 @@ struct DecTrainWs {
 DecTrainWs dec_train_ws(const OmEncoderConfig* c, int nl, int64_t B, int64_t L, char* base) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return base + o; };
-  const size_t es = c->dtype == OM_BF16 ? 2 : 4;
+  const size_t es = (c->dtype == OM_BF16 || c->dtype == OM_F16) ? 2 : 4;
   const size_t H = c->hidden, F = c->ffn, M = (size_t)B * L, Mp = (M + 63) / 64 * 64;
   const size_t bh = (size_t)B * H * es, bf = (size_t)B * F * es;
   DecTrainWs w;
@@ -310,7 +313,7 @@ DecTrainWs dec_train_ws(const OmEncoderConfig* c, int nl, int64_t B, int64_t L, 
 // transposed weights of decoder layer l (the data-gradient GEMMs' B operands)
 struct DecWt { char *sa_v, *sa_o, *ca_q, *ca_kv, *ca_o, *f1, *f1g, *f2; };
 DecWt dec_wt(const OmEncoderConfig* c, const DecTrainWs& ws, int l) {
-  const size_t es = c->dtype == OM_BF16 ? 2 : 4, H = c->hidden, F = c->ffn;
+  const size_t es = (c->dtype == OM_BF16 || c->dtype == OM_F16) ? 2 : 4, H = c->hidden, F = c->ffn;
   char* p = ws.wt + ws.swt * l;
   DecWt v;
   v.sa_v = p; p += H * H * es; v.sa_o = p; p += H * H * es; v.ca_q = p; p += H * H * es;
@@ -320,7 +323,7 @@ DecWt dec_wt(const OmEncoderConfig* c, const DecTrainWs& ws, int l) {
 }
 int dec_check(const OmEncoderConfig* c, const OmT5DecoderWeights* w, int64_t L) {
   if (c->arch != OM_ARCH_T5) OM_FAIL("decoder step: T5 only");
-  if (c->dtype != OM_F32 && c->dtype != OM_BF16) OM_FAIL("dtype must be OM_F32 or OM_BF16");
+  if (c->dtype != OM_F32 && c->dtype != OM_BF16 && c->dtype != OM_F16) OM_FAIL("dtype must be OM_F32, OM_BF16 or OM_F16");
   if (c->head_dim != 64 || c->n_heads * 64 != c->hidden) OM_FAIL("head_dim must be 64 (inner dim == d_model)");
   if (L < 1 || L > 256) OM_FAIL("sequence length must be in [1,256]");
   if (!w->layers_host || w->n_layers < 1 || !w->start_emb || !w->final_ln_g) OM_FAIL("incomplete decoder weights");
@@ -516,6 +519,8 @@ extern "C" int om_t5_decoder_train_forward(const OmEncoderConfig* c, const OmT5D
   if (t.total > tape_bytes || ws.total > workspace_bytes) OM_FAIL("tape or workspace too small");
   if (c->dtype == OM_BF16)
     return dec_train_forward_t<bf16_t>(c, w, enc_hidden, attention_mask, B, L, dropout, seed, t, ws, out_hidden, (hipStream_t)stream);
+  if (c->dtype == OM_F16)
+    return dec_train_forward_t<f16_t>(c, w, enc_hidden, attention_mask, B, L, dropout, seed, t, ws, out_hidden, (hipStream_t)stream);
   return dec_train_forward_t<float>(c, w, enc_hidden, attention_mask, B, L, dropout, seed, t, ws, out_hidden, (hipStream_t)stream);
 }
 
@@ -533,6 +538,8 @@ extern "C" int om_t5_decoder_train_backward(const OmEncoderConfig* c, const OmT5
   if (ws.total > workspace_bytes) OM_FAIL("workspace too small");
   if (c->dtype == OM_BF16)
     return dec_train_backward_t<bf16_t>(c, w, enc_hidden, attention_mask, B, L, dropout, seed, t, ws, d_out, g, d_enc_hidden, (hipStream_t)stream);
+  if (c->dtype == OM_F16)
+    return dec_train_backward_t<f16_t>(c, w, enc_hidden, attention_mask, B, L, dropout, seed, t, ws, d_out, g, d_enc_hidden, (hipStream_t)stream);
   return dec_train_backward_t<float>(c, w, enc_hidden, attention_mask, B, L, dropout, seed, t, ws, d_out, g, d_enc_hidden, (hipStream_t)stream);
 }
 

@@ -92,6 +92,14 @@ __device__ __forceinline__ bool g7_tile(int it, int64_t ntm, int64_t ntn, int gr
   return true;
 }
 
+// v summed over the four lanes {l, l ^ 16, l ^ 32, l ^ 48}: (own + lane ^ 16) + the same of the other half, in every lane -- v_permlane16_swap
+// (odd 16-lane rows of one operand <-> even rows of the other) and v_permlane32_swap (upper half <-> lower half) with both operands = v
+__device__ __forceinline__ float g7_quad_row_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float t = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+  return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+}
 // one 1 KiB table by LDS-DMA: lanes 0-31 fetch 512 B from `lo`, lanes 32-63 from `hi` (16 bytes per lane)
 __device__ __forceinline__ void g7_table2(const float* lo, const float* hi, char* dst, int lane) {
   g7_dma_v((lane < 32 ? lo : hi) + (lane & 31) * 4, g7_lds_addr(dst));
@@ -1089,9 +1097,9 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
     *(uint2*)(sp0 + G7E_ROW(rr) + ((c0_ ^ (rr & 7)) << 4) + 8 * (q4 & 1)) = pa_;                               \
     *(uint2*)(sp0 + G7E_ROW(rr) + ((c1_ ^ (rr & 7)) << 4) + 8 * (q4 & 1)) = pb_;                               \
     if (LNO && NH == 1 && ((G_) & 1) == 1) {   /* row block T2 of this 32-row pair has all its 128 columns: partial sums of the row */ \
-      float s1 = ssum[T2], s2 = ssq[T2];                                                                       \
-      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);                                              \
-      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);                                              \
+      /* the four lanes l15 + 16 {0, 1, 2, 3} hold the row's partial sums: the same tree as own + lane ^ 16, then + lane ^ 32 (bit-identical to \
+         the shuffles of rounds 4-5) on the two VALU row / half swaps of gfx950 instead of four ds_bpermute round trips through the LDS */ \
+      const float s1 = g7_quad_row_sum(ssum[T2]), s2 = g7_quad_row_sum(ssq[T2]);                               \
       if (q4 == 0) stat_slot[m] = make_float2(s1, s2);                                                         \
       ssum[T2] = 0.f; ssq[T2] = 0.f;                                                                           \
     }                                                                                                          \

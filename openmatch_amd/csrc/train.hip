@@ -180,7 +180,10 @@ int wgrad(int dt, const void* dY, int N, const void* X, int K, float* dW, float*
 int check_train_cfg(const OmEncoderConfig* c, int64_t L) {
   if (c->arch != OM_ARCH_BERT && c->arch != OM_ARCH_T5) OM_FAIL("unknown arch");
   if (c->dtype != OM_F32 && c->dtype != OM_BF16 && c->dtype != OM_F16) OM_FAIL("dtype must be OM_F32, OM_BF16 or OM_F16");
-  if (c->dtype == OM_F16 && c->arch != OM_ARCH_BERT) OM_FAIL("float16 training: BERT-family encoders (T5 activations leave the float16 range: bfloat16)");
+  // float16 training (the reference's --fp16 = torch.cuda.amp float16 + GradScaler for every backbone): BERT-family since round 5, T5 stacks
+  // since round 6 (ReLU / gated tanh-GELU feed-forwards; as under the reference's autocast nothing clamps -- a checkpoint whose feed-forward
+  // activations leave the float16 range overflows there and here alike, the loss scaler skips such steps)
+  if (c->dtype == OM_F16 && c->arch != OM_ARCH_BERT && c->arch != OM_ARCH_T5) OM_FAIL("float16 training: BERT-family and T5 encoders");
   if (c->head_dim != 64 || c->n_heads * 64 != c->hidden) OM_FAIL("head_dim must be 64");
   if (L < 1 || L > 256) OM_FAIL("training supports sequence lengths up to 256");
   if (c->dtype == OM_F32 && L > 192) OM_FAIL("float32 training supports sequence lengths up to 192 (16-bit formats: 256)");

@@ -1033,6 +1033,7 @@ int omk_t5_act_fwd(int dtype, const void* f, const void* f2, void* g, int64_t n,
   if (n <= 0) return 0;
   const unsigned grid = (unsigned)((n + 255) / 256);
   if (dtype == OM_BF16) hipLaunchKernelGGL(t5_act_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)f, (const bf16_t*)f2, (bf16_t*)g, n, kind);
+  else if (dtype == OM_F16) hipLaunchKernelGGL(t5_act_fwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, (const f16_t*)f, (const f16_t*)f2, (f16_t*)g, n, kind);
   else hipLaunchKernelGGL(t5_act_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)f, (const float*)f2, (float*)g, n, kind);
   OM_LAUNCH_CHECK();
   return 0;
@@ -1041,6 +1042,7 @@ int omk_t5_act_bwd(int dtype, const void* dg, const void* f, const void* f2, voi
   if (n <= 0) return 0;
   const unsigned grid = (unsigned)((n + 255) / 256);
   if (dtype == OM_BF16) hipLaunchKernelGGL(t5_act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dg, (const bf16_t*)f, (const bf16_t*)f2, (bf16_t*)df, (bf16_t*)df2, n, kind);
+  else if (dtype == OM_F16) hipLaunchKernelGGL(t5_act_bwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, (const f16_t*)dg, (const f16_t*)f, (const f16_t*)f2, (f16_t*)df, (f16_t*)df2, n, kind);
   else hipLaunchKernelGGL(t5_act_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dg, (const float*)f, (const float*)f2, (float*)df, (float*)df2, n, kind);
   OM_LAUNCH_CHECK();
   return 0;
@@ -1057,6 +1059,7 @@ __global__ void t5_embed_bwd_kernel(const T* __restrict__ dy, const int64_t* __r
 int omk_t5_embed_bwd(int dtype, const void* dy, const int64_t* ids, float* dword, int64_t M, int H, int vocab, hipStream_t s) {
   if (M <= 0) return 0;
   if (dtype == OM_BF16) hipLaunchKernelGGL(t5_embed_bwd_kernel<bf16_t>, dim3((unsigned)M), dim3(256), 0, s, (const bf16_t*)dy, ids, dword, M, H, vocab);
+  else if (dtype == OM_F16) hipLaunchKernelGGL(t5_embed_bwd_kernel<f16_t>, dim3((unsigned)M), dim3(256), 0, s, (const f16_t*)dy, ids, dword, M, H, vocab);
   else hipLaunchKernelGGL(t5_embed_bwd_kernel<float>, dim3((unsigned)M), dim3(256), 0, s, (const float*)dy, ids, dword, M, H, vocab);
   OM_LAUNCH_CHECK();
   return 0;

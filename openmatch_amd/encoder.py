@@ -55,11 +55,13 @@ def inference_code(model, code, seq_len):
 def training_code(code, model=None):
     """The compute format of a TRAINING step.  float16 (the reference's `--fp16` training: HF Trainer's torch.cuda.amp autocast +
     GradScaler, trainer/dense_trainer.py:141-149) is served for BERT-family erf-GELU encoders (round 5; the trainer scales the
-    loss, openmatch_amd/trainer/dense_trainer.py); T5 and other activations train in bfloat16 (the T5 training kernels and the T5
-    decoder position exist in bfloat16 and float32).  Without a model (callers that only name a format): the conservative bfloat16."""
+    loss, openmatch_amd/trainer/dense_trainer.py) and (round 6) for T5 stacks with ReLU / tanh-GELU feed-forwards, encoder and
+    decoder position alike -- under the same conditions as float16 inference (inference_code: as under the reference's autocast nothing
+    clamps, OM_T5_F16=0 keeps T5 in bfloat16).  Other activations train in bfloat16; OM_TRAIN_F16=0 sends every float16 request
+    there.  Without a model (callers that only name a format): the conservative bfloat16."""
     if code != N.OM_F16:
         return code
-    if model is None or os.environ.get("OM_TRAIN_F16", "1") == "0" or _arch_of(model) != "bert":
+    if model is None or os.environ.get("OM_TRAIN_F16", "1") == "0":
         return N.OM_BF16
     return inference_code(model, code, 0)
 
@@ -510,7 +512,7 @@ def hip_t5_decoder_step(model, items, code):
     (modeling/dense_retrieval_model.py:137-141).  Encoder through om_encoder_forward, decoder through om_t5_decoder_step."""
     if not hasattr(model, "decoder") or not hasattr(model, "encoder"):
         raise ValueError("an encoder-decoder T5 model is required")
-    code = training_code(code)             # T5: a 16-bit request means bfloat16 (inference_code)
+    code = inference_code(model, code, 0)  # float16 where the T5 stack takes it (round 6: the decoder position too), else bfloat16
     enc_hidden, _ = hip_encode(model, items, None, None, False, code, want_hidden=True)
     device = enc_hidden.device
     mask = items["attention_mask"].to(device=device, dtype=torch.int64).contiguous()

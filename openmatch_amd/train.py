@@ -212,6 +212,7 @@ class _EncoderTrain(torch.autograd.Function):
 
 
 LAST_CALL = {"rows": 0, "packed": False}       # what the last training forward ran over (tests, tools)
+LAST_TRAIN_CODE = None                          # the compute format (native.OM_*) the last encode_train / t5_decoder_state_train ran in
 
 
 def encode_train(model, head, items, pooling, normalize, code, training, packed_rows=None):
@@ -219,7 +220,8 @@ def encode_train(model, head, items, pooling, normalize, code, training, packed_
     Dropout follows the HF config only in training mode (model.train()).
     packed_rows: a bound on the batch's token count known on the HOST (encoder.packed_rows_bound of the collator's lengths) --
     the step then runs over that many rows instead of B x L where the packed pair takes the configuration (OM_TRAIN_PACKED=0: never)."""
-    code = training_code(code, model)
+    global LAST_TRAIN_CODE
+    code = LAST_TRAIN_CODE = training_code(code, model)
     ids = items["input_ids"].to(torch.int64).contiguous()
     mask = items["attention_mask"].to(device=ids.device, dtype=torch.int64).contiguous()
     tti = items.get("token_type_ids") if hasattr(items, "get") else None
@@ -355,7 +357,8 @@ def t5_decoder_state_train(model, items, code, training):
     and decoder parameter -- the training-mode counterpart of encoder.hip_t5_decoder_step."""
     if not hasattr(model, "decoder") or not hasattr(model, "encoder"):
         raise ValueError("an encoder-decoder T5 model is required")
-    code = training_code(code)
+    global LAST_TRAIN_CODE
+    code = LAST_TRAIN_CODE = training_code(code, model)
     ids = items["input_ids"].to(torch.int64).contiguous()
     mask = items["attention_mask"].to(device=ids.device, dtype=torch.int64).contiguous()
     N.require_device(ids, mask, None)

@@ -3,6 +3,7 @@
 LinearHead, normalise; `encoder_only=True`), loss.backward(), every parameter gradient.
 Run:  cd /tmp && python /root/repo/oracle/make_golden_t5_train.py     (needs /root/reference)
 Kept apart from make_golden.py so the committed fixtures of the other cases are not regenerated.
+`--add-f16` (round 6): adds the reference's float16-autocast yardsticks to the committed fixtures (add_f16_yardsticks).
 """
 import os
 import sys
@@ -85,7 +86,62 @@ def case(tag, gated, rng):
     print("wrote", tag, "loss", float(o.loss), "grads", sum(k.startswith("g::") for k in out))
 
 
+def add_f16_yardsticks(tag, gated):
+    """Round 6: the reference's OWN float16 mode on the committed fixture -- its training step under torch.autocast(float16) with
+    a static loss scale of 1024 (what `--fp16` = torch.cuda.amp + GradScaler does between two scale updates,
+    trainer/dense_trainer.py:141-149) -- recorded as per-tensor relative L2 deviations of its gradients from its fp32 gradients:
+    the yardstick a float16 kernel path's gradients are held to (tests/test_gpu_parity.py).  The stored fp32 arrays are not
+    regenerated: the model is rebuilt from the fixture's weights and its fp32 step re-checked against them first."""
+    path = os.path.join(OUT, tag + ".npz")
+    g = dict(np.load(path))
+    cfg = T5Config(d_model=128, d_ff=256, num_layers=2, num_heads=2, d_kv=64, vocab_size=600, dropout_rate=0.0,
+                   feed_forward_proj="gated-gelu" if gated else "relu")
+
+    def build():
+        lm = T5EncoderModel(cfg)
+        lm.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w::")})
+        head = LinearHead(128, 128)
+        head.linear.weight.data.copy_(torch.from_numpy(g["head_w"]))
+        m = DRModel(lm_q=lm, lm_p=lm, pooling="mean", head_q=head, head_p=head, normalize=True,
+                    model_args=NS(encoder_only=True), data_args=NS(train_n_passages=int(g["n_psg"])),
+                    train_args=NS(negatives_x_device=False, per_device_train_batch_size=4))
+        return m.train(), lm, head
+    q = {"input_ids": torch.from_numpy(g["q_input_ids"]), "attention_mask": torch.from_numpy(g["q_attention_mask"])}
+    p = {"input_ids": torch.from_numpy(g["p_input_ids"]), "attention_mask": torch.from_numpy(g["p_attention_mask"])}
+
+    def grads_of(lm, head):
+        out, seen = {"head_w": head.linear.weight.grad.detach().clone()}, set()
+        for k, v in lm.named_parameters():
+            if v.grad is not None and id(v) not in seen:
+                seen.add(id(v)); out[k] = v.grad.detach().clone()
+        return out
+    m, lm, head = build()
+    o = m(query=q, passage=p); o.loss.backward()
+    g32 = grads_of(lm, head)
+    for k, v in g32.items():
+        ref = g["g::" + k]
+        assert np.allclose(v.numpy(), ref, rtol=1e-5, atol=1e-7), k
+    scale = 1024.0
+    m, lm, head = build()
+    with torch.autocast("cpu", dtype=torch.float16):
+        o16 = m(query=q, passage=p)
+    (o16.loss.float() * scale).backward()
+    g16 = {k: v / scale for k, v in grads_of(lm, head).items()}
+    rel = {k: float((g16[k].double() - g32[k].double()).norm() / g32[k].double().norm().clamp_min(1e-30)) for k in g32}
+    for k, r in rel.items():
+        g["ac16rel::" + k] = np.array(r)
+    g["ac16_loss"] = np.array(float(o16.loss))
+    vals = sorted(rel.values())
+    print(f"{tag}: reference float16-autocast gradients vs its fp32: rel-L2 median {vals[len(vals) // 2]:.2e} max {vals[-1]:.2e} "
+          f"({max(rel, key=rel.get)}); loss {float(o16.loss):.5f} vs {float(g['loss']):.5f}")
+    np.savez_compressed(path, **g)
+
+
 if __name__ == "__main__":
+    if "--add-f16" in sys.argv:
+        add_f16_yardsticks("train_t5_tiny_relu", False)
+        add_f16_yardsticks("train_t5_tiny_gated", True)
+        sys.exit(0)
     rng = np.random.default_rng(SEED + 99)
     case("train_t5_tiny_relu", False, rng)
     case("train_t5_tiny_gated", True, rng)

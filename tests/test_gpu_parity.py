@@ -989,6 +989,98 @@ def test_t5_training_bf16_and_dropout_are_sane(golden):
     assert after < before, (before, after)
 
 
+@pytest.mark.parametrize("fixture,gated", [("train_t5_tiny_relu", False), ("train_t5_tiny_gated", True)])
+def test_t5_training_float16_inside_reference_float16_autocast(golden, fixture, gated, monkeypatch):
+    """float16 T5 training (round 6; the reference's `--fp16` is float16 autocast + GradScaler for every backbone,
+    trainer/dense_trainer.py:141-149): the float16 kernels' step on the reference-executed fixtures, loss scaled by 1024 as under a
+    GradScaler.  Yardstick: the reference's OWN float16-autocast gradients on the same fixture (oracle/make_golden_t5_train.py
+    --add-f16: per-tensor relative L2 from its fp32 gradients) -- every tensor within 3 x its yardstick (or 3 x the median
+    yardstick where a tensor's own is tiny), the loss within 3 x the reference's own loss deviation; bfloat16 on the same fixture
+    is printed beside it."""
+    monkeypatch.delenv("OM_TRAIN_F16", raising=False); monkeypatch.delenv("OM_T5_F16", raising=False)
+    from openmatch.modeling import DRModel, LinearHead
+    from openmatch_amd import native as N
+    from openmatch_amd import train as T
+    g = golden(fixture)
+    yard = {k[len("ac16rel::"):]: float(g[k]) for k in g.files if k.startswith("ac16rel::")}
+    assert yard, "fixture without float16-autocast yardsticks (oracle/make_golden_t5_train.py --add-f16)"
+    med = float(np.median(list(yard.values())))
+
+    def step(dtype):
+        cfg, lm = model_from_golden(g, "t5", gated=gated)
+        lm.config.dropout_rate = 0.0
+        head = LinearHead(128, 128)
+        head.linear.weight.data.copy_(torch.from_numpy(g["head_w"]))
+        model = DRModel(lm_q=lm, lm_p=lm, pooling="mean", head_q=head, head_p=head, normalize=True,
+                        model_args=NS(encoder_only=True, dtype=dtype), data_args=NS(train_n_passages=int(g["n_psg"])),
+                        train_args=NS(negatives_x_device=False, per_device_train_batch_size=4)).to(DEV).train()
+        mk = lambda k: {"input_ids": torch.from_numpy(g[k + "_input_ids"]).to(DEV),
+                        "attention_mask": torch.from_numpy(g[k + "_attention_mask"]).to(DEV)}
+        out = model(query=mk("q"), passage=mk("p"))
+        (out.loss * 1024.0).backward()
+        names = dict(lm.named_parameters())
+        rel = {}
+        for key in yard:
+            got = (head.linear.weight.grad if key == "head_w" else names[key].grad).float().cpu().double() / 1024.0
+            ref = torch.from_numpy(g["g::" + key]).double()
+            rel[key] = ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+        return out.loss.item(), rel
+    loss16, rel16 = step("float16")
+    assert T.LAST_TRAIN_CODE == N.OM_F16, "the float16 request must run the float16 kernels"
+    lossb, relb = step("bfloat16")
+    worst = max(rel16, key=lambda k: rel16[k] / max(yard[k], med))
+    print(f"\n[T5 {'gated-gelu' if gated else 'relu'} float16 training] rel-L2 vs the reference's fp32 gradients: median {np.median(list(rel16.values())):.2e} "
+          f"(reference float16 autocast {med:.2e}; bfloat16 kernels {np.median(list(relb.values())):.2e}); worst tensor {rel16[worst] / max(yard[worst], med):.2f} x "
+          f"its yardstick ({worst}); loss {loss16:.5f} vs fp32 {float(g['loss']):.5f} (reference float16 autocast {float(g['ac16_loss']):.5f})")
+    for k in yard:
+        assert rel16[k] <= 3.0 * max(yard[k], med), (k, rel16[k], yard[k], med)
+    assert abs(loss16 - float(g["loss"])) <= max(3.0 * abs(float(g["ac16_loss"]) - float(g["loss"])), 1e-3)
+    assert np.median(list(rel16.values())) < np.median(list(relb.values()))       # three more mantissa bits than bfloat16
+
+
+def test_t5_decoder_position_float16_training_and_inference_track_f32():
+    """The T5 decoder position (DRModel with encoder_only=False, monoT5) in float16 (round 6): the inference step and the training
+    pair on the float16 kernels against the same model in float32 -- representations within 2e-3 relative, every gradient's cosine
+    > 0.999 (bfloat16: > 0.99 in the test above), closer than bfloat16 on the median."""
+    import copy
+    from transformers import T5Config, T5ForConditionalGeneration
+    from openmatch.modeling import DRModel
+    torch.manual_seed(123)
+    cfg = T5Config(d_model=128, d_ff=256, num_layers=2, num_decoder_layers=2, num_heads=2, d_kv=64, vocab_size=600,
+                   feed_forward_proj="gated-gelu", tie_word_embeddings=False, decoder_start_token_id=0, dropout_rate=0.0)
+    lm = T5ForConditionalGeneration(cfg)
+    rng = np.random.default_rng(23)
+    ids, mask = synth_tokens(rng, 8, 64, vocab=600, lo_len=10, lo_id=300)
+    items = {"input_ids": torch.from_numpy(ids).to(DEV), "attention_mask": torch.from_numpy(mask).to(DEV)}
+    R = torch.randn(8, 128, generator=torch.Generator().manual_seed(8)).to(DEV)
+
+    def run(dtype):
+        m = copy.deepcopy(lm)
+        dr = DRModel(lm_q=m, lm_p=m, model_args=NS(encoder_only=False, dtype=dtype), data_args=NS(train_n_passages=1),
+                     train_args=NS(negatives_x_device=False)).to(DEV).train()
+        _h, reps = dr.encode_passage(items)
+        (reps * R * 256.0).sum().backward()
+        grads = {n: p.grad.float().cpu() / 256.0 for n, p in m.named_parameters() if p.grad is not None}
+        dr.eval()
+        with torch.no_grad():
+            _h, inf = dr.encode_passage(items)
+        return reps.detach().float().cpu(), inf.float().cpu(), grads
+    r32, i32, g32 = run("float32")
+    r16, i16, g16 = run("float16")
+    rb, ib, gb = run("bfloat16")
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    print(f"\n[T5 decoder position] training reps rel err float16 {rel(r16, r32):.2e} (bfloat16 {rel(rb, r32):.2e}); inference float16 {rel(i16, i32):.2e} (bfloat16 {rel(ib, i32):.2e})")
+    assert rel(r16, r32) < 2e-3 and rel(i16, i32) < 2e-3 and rel(r16, r32) < rel(rb, r32) and rel(i16, i32) < rel(ib, i32)
+    cos16, cosb = [], []
+    for key, a in g32.items():
+        if float(a.abs().max()) == 0.0:
+            continue
+        c = lambda x: (torch.dot(a.flatten().double(), x.flatten().double()) / (a.norm().double() * x.norm().double())).item()
+        cos16.append(c(g16[key])); cosb.append(c(gb[key]))
+        assert cos16[-1] > 0.999, (key, cos16[-1])
+    assert np.median(cos16) >= np.median(cosb)
+
+
 def test_training_gradients_match_oracle_autograd_at_bert_width():
     """One bert-base-WIDTH layer (H=768, F=3072, 12 heads), 8 x 128-token passages + 4 x 32-token
     queries: exercises the 256-row GEMM tiles, the fused GELU' epilogue and the wgrad path at real
