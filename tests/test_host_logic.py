@@ -337,8 +337,8 @@ def test_one_pass_rule_for_tied_training_batches():
 
 
 def test_compute_format_resolution(monkeypatch):
-    """float16 requests: served as float16 for BERT-family erf-GELU encoders and (round 5) T5 encoder stacks, as bfloat16 elsewhere
-    (other activations, OM_T5_F16=0, T5 training)."""
+    """float16 requests: served as float16 for BERT-family erf-GELU encoders and T5 stacks (inference: round 5; training: round 6),
+    as bfloat16 elsewhere (other activations, OM_T5_F16=0, OM_TRAIN_F16=0, a format named without a model)."""
     from types import SimpleNamespace as NS
     from transformers import BertConfig, BertModel, T5Config, T5EncoderModel
     from openmatch_amd import native as N
@@ -357,9 +357,15 @@ def test_compute_format_resolution(monkeypatch):
     monkeypatch.delenv("OM_T5_F16")
     assert inference_code(t5, N.OM_BF16, 128) == N.OM_BF16 and inference_code(bert, N.OM_F32, 512) == N.OM_F32
     assert training_code(N.OM_F16) == N.OM_BF16 and training_code(N.OM_F32) == N.OM_F32
-    # round 5: float16 training is served for BERT-family erf-GELU encoders, bfloat16 elsewhere
-    assert training_code(N.OM_F16, bert) == N.OM_F16 and training_code(N.OM_F16, t5) == N.OM_BF16 and training_code(N.OM_F16, relu) == N.OM_BF16
+    # float16 training is served for BERT-family erf-GELU encoders (round 5) and T5 stacks (round 6), bfloat16 elsewhere
+    assert training_code(N.OM_F16, bert) == N.OM_F16 and training_code(N.OM_F16, t5) == N.OM_F16 and training_code(N.OM_F16, relu) == N.OM_BF16
     assert training_code(N.OM_BF16, bert) == N.OM_BF16
+    monkeypatch.setenv("OM_T5_F16", "0")
+    assert training_code(N.OM_F16, t5) == N.OM_BF16 and training_code(N.OM_F16, bert) == N.OM_F16
+    monkeypatch.delenv("OM_T5_F16")
+    monkeypatch.setenv("OM_TRAIN_F16", "0")
+    assert training_code(N.OM_F16, t5) == N.OM_BF16 and training_code(N.OM_F16, bert) == N.OM_BF16
+    monkeypatch.delenv("OM_TRAIN_F16")
     assert torch_dtype_of(N.OM_F16) == torch.float16 and torch_dtype_of(N.OM_BF16) == torch.bfloat16 and torch_dtype_of(N.OM_F32) == torch.float32
 
 
