@@ -38,7 +38,7 @@ GEMM_GFLOP_PER_PASSAGE = 12 * 24 * 128 * 768 ** 2 / 1e9
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 # rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md) of this command, committed per round and per format
-TRAFFIC_FILES = {"f16": "r05_hbm_traffic_f16.json", "bf16": "r03_hbm_traffic.json"}
+TRAFFIC_FILES = {"f16": "r06_hbm_traffic_f16.json", "bf16": "r03_hbm_traffic.json"}
 
 
 def parse():

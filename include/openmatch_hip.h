@@ -87,8 +87,9 @@ void om_debug_gemm_gen(int gen);
 #define OM_OPT_SCAN_GEN7 3        /* 1 (default): f16 index scan of wide query batches on the persistent generation-7 kernel; 0: generation 6 */
 #define OM_OPT_SCAN_GROWTH 4      /* fast schedule of the index scan: rows scanned per round grow by this many percent of the rows already
                                     * scanned (default 60; smaller = more rounds, tighter thresholds, fewer appends per tile) */
-#define OM_OPT_WGRAD_DEBUG 5     /* 0 (default); timing experiments on the weight-gradient kernel: bit 1 plain stores, bit 2 one step
-                                   * (both break the result), value >> 4 = workgroups aimed at / 64 */
+#define OM_OPT_WGRAD_DEBUG 5     /* 0 (default); A/B switches of the weight-gradient kernel: bit 3 the register-staged kernel for everything, value >> 4 =
+                                   * workgroups aimed at / 64.  Bits 1 (plain stores) and 2 (one step of the token loop) break the result: they are timing
+                                   * probes and act only in a probe build (-DOM_PROBE_KERNELS); the shipped library ignores them (round 6) */
 #define OM_OPT_GEMM_GROUP_M 6     /* row tiles per group of the persistent GEMM's tile walk (default 8): the group's A panels stay in an
                                    * XCD's L2 while its column tiles are swept */
 #define OM_OPT_SCAN_QGROUP 7      /* query tiles (256 queries each) an XCD keeps resident in its L2 during the index scan (default 8) */

@@ -534,7 +534,13 @@ int omk_gemm_tn(int dtype, const void* A, int64_t lda, const void* B, int64_t ld
                 int64_t M, int64_t N, int64_t K, hipStream_t s) {
   if (!omk_gemm_tn_ok(dtype, M, N, K, lda, ldb)) OM_FAIL("gemm_tn: 16-bit operands with N and K multiples of 128 only");
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) OM_FAIL("gemm_tn: operands must be 16-byte aligned");
+  // bits 1 and 2 (plain stores instead of atomics, one step of the token loop) BREAK the result: timing probes, honoured only in a probe
+  // build (python -m openmatch_amd._build --probe); the shipped library keeps the selection bits (3: register-staged kernel, >> 4: grid aim)
+#ifdef OM_PROBE_KERNELS
   const int dbg = om_option(OM_OPT_WGRAD_DEBUG);
+#else
+  const int dbg = om_option(OM_OPT_WGRAD_DEBUG) & ~6;
+#endif
   const bool timing = om_timing_on();
   if (timing) om_timing_begin(OM_TIMING_GEMM_BF16, s);
   const int64_t whole = (dbg & 8) ? 0 : M / TN_BM;             // (dbg 8: the register-staged kernel for everything)
