@@ -109,6 +109,7 @@ struct EncWs {
   char* wfold;
   float *colsum, *bfold, *stats1, *stats2, *slots;
   char *y_lo, *x1_lo;
+  float *r32a, *r32b, *y32;   // few-rows 16-bit BERT (round 6): the f32 residual stream -- LayerNorm outputs and pre-LayerNorm sums as autocast keeps them
   int64_t Mp;       // row count the GEMMs run on: M rounded up to whole 256-row tiles (the buffers are that tall)
   size_t total;
 };
@@ -152,6 +153,10 @@ static EncWs carve(const OmEncoderConfig* c, int64_t B, int64_t L, char* base, i
   const bool two = fuse && c->arch == OM_ARCH_BERT;      // both 16-bit formats (round 6): the planes exist whether or not the switch uses them
   w.y_lo = take(two ? M * H * es : 0);
   w.x1_lo = take(two ? M * H * es : 0);
+  const bool few32 = half && c->arch == OM_ARCH_BERT && packed_rows == 0 && Mreal <= (size_t)std::max(0, om_option(OM_OPT_GEMM_SKINNY_M));
+  w.r32a = (float*)take(few32 ? Mreal * H * 4 : 0);
+  w.r32b = (float*)take(few32 ? Mreal * H * 4 : 0);
+  w.y32 = (float*)take(few32 ? Mreal * H * 4 : 0);
   w.Mp = (int64_t)M;
   w.total = off;
   return w;
@@ -270,6 +275,7 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
   // 16-bit runs that only return representations: the LAST normalisation writes f32 (the reference's autocast runs
   // layer_norm in fp32), into ws.final32 -- B CLS rows (pooling "first": already the pooled vectors) or all M rows
   int64_t final32_rows = 0;
+  const float* f32_rows = ws.final32;       // where those rows are (the few-rows path leaves them in its f32 residual buffer)
   if (bert) {
     if (L > c->max_pos) OM_FAIL("sequence longer than the position table");
     RUN(omk_embed(dt, input_ids, token_type_ids, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g,
@@ -378,6 +384,35 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
           RUN(omk_layernorm_f32out(dt, ws.x1, H, ws.final32, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, 0, s, lo, nullptr, lo8));
           final32_rows = M;
         }
+      }
+    } else if (few_rows && ws.y32 && c->n_layers > 0 && (om_option(OM_OPT_ENCODER_TWO_PLANE) & (dt == OM_BF16 ? 1 : 2)) != 0) {
+      // Few rows (a served query, a handful of sequences), 16-bit (round 6): the residual stream in f32, as the reference's autocast keeps
+      // it (layer_norm runs and returns fp32; a 16-bit dense output + an fp32 LayerNorm output is an fp32 sum: HF:models/bert/modeling_bert.py
+      // :289-293,347-351 under retriever/dense_retriever.py:76) -- what the two-plane stream is to the fused path.  Every LayerNorm writes
+      // its output twice (16-bit: the next contraction's operand; f32: what the next residual add reads), the residual contractions add
+      // the f32 copy and leave their sum in f32 (gemm_skinny.hip: resid32 / out32).  Rounds 4-5 kept one 16-bit plane here.
+      RUN(omk_embed(OM_F32, input_ids, token_type_ids, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, ws.r32a, M, (int)L, H,
+                    c->vocab, c->type_vocab, c->ln_eps, 1, s, nullptr));
+      for (int l = 0; l < c->n_layers; ++l) {
+        const OmLayerWeights& lw = Ls[l];
+        const bool last = l == c->n_layers - 1;
+        GEMM(ws.x, H, lw.qkv_w, H, ws.qkv, 3 * H, 3 * H, H, lw.qkv_b, nullptr, 0, OM_ACT_NONE);
+        RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, nullptr, B, (int)L, H, nh, scale, 0.f, 0, s, 0, ws.kmax));
+        GemmEpilogue e = {};
+        e.bias = lw.o_b; e.resid32 = ws.r32a; e.ldr = H; e.out32 = ws.y32;
+        RUN(omk_gemm(dt, ws.ctx, H, lw.o_w, H, dt, ws.y, H, Mg, H, H, e, s));                  // y32 = ctx Wo^T + b + x (f32)
+        RUN(omk_layernorm_dual(dt, ws.y32, H, ws.x1, ws.r32b, H, lw.ln1_g, lw.ln1_b, M, H, c->ln_eps, s));
+        GEMM(ws.x1, H, lw.ffn1_w, H, ws.ff, F, F, H, lw.ffn1_b, nullptr, 0, c->act);
+        e = GemmEpilogue{};
+        e.bias = lw.ffn2_b; e.resid32 = ws.r32b; e.ldr = H; e.out32 = ws.y32;
+        RUN(omk_gemm(dt, ws.ff, F, lw.ffn2_w, F, dt, ws.y, H, Mg, H, F, e, s));                // y32 = ff W2^T + b + x1 (f32)
+        void* dst = (last && out_hidden) ? out_hidden : (void*)ws.x;
+        RUN(omk_layernorm_dual(dt, ws.y32, H, dst, ws.r32a, H, lw.ln2_g, lw.ln2_b, M, H, c->ln_eps, s));
+        final_hidden = (char*)dst;
+      }
+      if (c->pooling != OM_POOL_NONE) {       // the pooled rows come from the f32 copy of the last normalisation (the reference's autocast returns fp32)
+        f32_rows = ws.r32a;
+        final32_rows = M;
       }
     } else
     for (int l = 0; l < c->n_layers; ++l) {
@@ -505,10 +540,10 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
   if (c->pooling != OM_POOL_NONE) {
     const bool head = c->head_in > 0 && w->head_w;
     float* pooled = head ? ws.pooled : out_reps;
-    if (final32_rows == B && c->pooling == OM_POOL_FIRST)
-      OM_HIP(hipMemcpyAsync(pooled, ws.final32, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));
+    if (final32_rows == B && c->pooling == OM_POOL_FIRST && (f32_rows == ws.final32 || L == 1))
+      OM_HIP(hipMemcpyAsync(pooled, f32_rows, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));
     else if (final32_rows == M)
-      RUN(omk_pool(OM_F32, ws.final32, attention_mask, pooled, B, (int)L, H, c->pooling, s, cu));
+      RUN(omk_pool(OM_F32, f32_rows, attention_mask, pooled, B, (int)L, H, c->pooling, s, cu));
     else
       RUN(omk_pool(dt, final_hidden, attention_mask, pooled, B, (int)L, H, c->pooling, s));
     int D = H;

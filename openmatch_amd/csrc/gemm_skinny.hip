@@ -49,7 +49,7 @@ __device__ __forceinline__ float sk_act(float v, int act) {
 template <typename T, int MT, int NT, int NW>
 __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ W, int64_t ldw,
                                                                 T* C, int64_t ldc, int M, int N, int K, const float* __restrict__ bias,
-                                                                const T* resid, int64_t ldr, int act, int mul) {
+                                                                const T* resid, int64_t ldr, int act, int mul, const float* resid32, float* out32) {
   constexpr int UNR = (MT + NT) <= 3 ? 12 : ((MT + NT) <= 5 ? 8 : 4);      // K steps in flight per wave: (MT + NT) UNR x 4 VGPRs
   __shared__ float red[NW][MT * NT][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -107,11 +107,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const T* __rest
 #pragma unroll
     for (int w = 1; w < NW; ++w) v += red[w][tile][i][lane];
     v = sk_act(v + (bias ? bias[n] : 0.f), act);
-    if (resid) {
+    if (resid32) {
+      v += resid32[(int64_t)m * ldr + n];                                  // the f32 residual stream of the few-rows path (may alias out32)
+    } else if (resid) {
       const float rv = ElemOps<T>::load(resid + (int64_t)m * ldr + n);      // may alias C: read and written by this lane only
       v = mul ? v * rv : v + rv;
     }
-    ElemOps<T>::store(C + (int64_t)m * ldc + n, v);
+    if (out32) out32[(int64_t)m * ldc + n] = v;
+    else ElemOps<T>::store(C + (int64_t)m * ldc + n, v);
   }
 }
 
@@ -143,7 +146,7 @@ int launch_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* 
   const int act = ep.act & 0xff, mul = (ep.act & OM_ACT_MUL_RESID) ? 1 : 0;
   const SkCfg c = sk_choose(M, N, K);
   if (N % (16 * c.nt) || K % (32 * c.nw)) OM_FAIL("gemm_skinny: (NT, NW) does not divide the problem");
-#define SK_GO(MT_, NT_, NW_)                                                                                                           if (c.mt == MT_ && c.nt == NT_ && c.nw == NW_) {                                                                                       hipLaunchKernelGGL((gemm_nt_skinny_kernel<T, MT_, NT_, NW_>), dim3((unsigned)(N / (16 * NT_)), (unsigned)((M + 16 * MT_ - 1) / (16 * MT_))),                        dim3(64 * NW_), 0, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, (int)M, (int)N, (int)K, ep.bias,                                (const T*)ep.resid, ep.ldr, act, mul);                                                                            OM_LAUNCH_CHECK();                                                                                                                   return 0;                                                                                                                          }
+#define SK_GO(MT_, NT_, NW_)                                                                                                           if (c.mt == MT_ && c.nt == NT_ && c.nw == NW_) {                                                                                       hipLaunchKernelGGL((gemm_nt_skinny_kernel<T, MT_, NT_, NW_>), dim3((unsigned)(N / (16 * NT_)), (unsigned)((M + 16 * MT_ - 1) / (16 * MT_))),                        dim3(64 * NW_), 0, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, (int)M, (int)N, (int)K, ep.bias,                                (const T*)ep.resid, ep.ldr, act, mul, ep.resid32, ep.out32);                                                                            OM_LAUNCH_CHECK();                                                                                                                   return 0;                                                                                                                          }
   SK_GO(1, 1, 4) SK_GO(1, 1, 8) SK_GO(1, 2, 4) SK_GO(1, 2, 8) SK_GO(1, 4, 4) SK_GO(1, 4, 8)
   SK_GO(2, 1, 4) SK_GO(2, 1, 8) SK_GO(2, 2, 4) SK_GO(2, 2, 8) SK_GO(2, 4, 4) SK_GO(2, 4, 8)
   SK_GO(4, 1, 4) SK_GO(4, 1, 8) SK_GO(4, 2, 4) SK_GO(4, 2, 8) SK_GO(4, 4, 4)
@@ -161,7 +164,7 @@ bool omk_gemm_skinny_ok(int in_dtype, int out_dtype, int64_t M, int64_t N, int64
   const int act = ep.act & 0xff;
   if (act != OM_ACT_NONE && act != OM_ACT_GELU_ERF && act != OM_ACT_RELU && act != OM_ACT_GELU_TANH) return false;
   if (ep.pre_act || ep.drop_p > 0.f || ep.ln_stats || ep.rln_stats || ep.stats_out || ep.resid_lo || ep.out_lo) return false;
-  if ((ep.act & OM_ACT_MUL_RESID) && !ep.resid) return false;
+  if ((ep.act & OM_ACT_MUL_RESID) && (!ep.resid || ep.resid32)) return false;
   return true;
 }
 

@@ -65,6 +65,8 @@ struct GemmEpilogue {
                              //   omk_ln_stats_reduce adds the slots in a fixed order into the [M][2] array the consumers read
   const void* resid_lo;      // two-plane residual stream (bf16 BERT inference): the residual is resid + resid_lo (NULL: one plane)
   void* out_lo;              //   and the output is written as C = round16(y), out_lo = round16(y - C); selects the LNF == 3 kernel
+  const float* resid32;      // few-rows path (gemm_skinny.hip, round 6): the residual as f32 [M, ldr] instead of `resid` -- the reference's autocast keeps the
+  float* out32;              //   LayerNorm outputs it adds in fp32 -- and the sum written as f32 [M, ldc] here instead of into C
   int lo8;                   //   1 (float16): both second planes are EIGHT-bit blobs (omk_lo8_offset below; the LNF == 4 kernel) instead of 16-bit matrices
   float ln_inv_h, ln_eps;
   int ln_rms;                // 1: the statistics describe a T5 RMSNorm (no mean, no shift): only sum of squares is used

@@ -2197,6 +2197,7 @@ def test_few_rows_forward_tracks_f32_path_and_is_batch_invariant(dtype, arch):
     m16, m32 = mk(dtype), mk("float32")
     rng = np.random.default_rng(12)
     tol = 5e-6 if dtype == "float16" else 2e-4
+    worse = []
     for B, L in ((1, 32), (1, 7), (3, 32), (8, 32), (5, 128), (8, 128), (31, 33)):
         ids, mask = synth_tokens(rng, B, L, vocab=600, lo_len=max(2, L // 3), lo_id=300)
         ids[0, :], mask[0, :] = rng.integers(300, 600, L), 1
@@ -2211,11 +2212,19 @@ def test_few_rows_forward_tracks_f32_path_and_is_batch_invariant(dtype, arch):
         cos = lambda a, b: torch.nn.functional.cosine_similarity(a, b, dim=1).min().item()
         assert 1 - cos(few, ref) < tol and 1 - cos(tiles, ref) < tol, (B, L, cos(few, ref), cos(tiles, ref))
         assert 1 - cos(few, ref) <= 2.0 * (1 - cos(tiles, ref)) + 1e-7, (B, L, cos(few, ref), cos(tiles, ref))
+        # BERT (round 6): the few-rows path keeps its residual stream in f32 as the reference's autocast does (the tile kernels below
+        # 512 rows keep ONE 16-bit plane): measured by the relative row error, it is the closer of the two at every batch of the list
+        rel = lambda a: ((a - ref).norm(dim=1) / ref.norm(dim=1)).max().item()
+        worse.append((B, L, rel(few), rel(tiles)))
         if dtype == "bfloat16" and arch == "bert" and B * L >= 512:
             continue            # bfloat16 BERT from 512 rows on keeps the fused path (two-plane residual stream): another code path than L rows alone
         alone = m16.encode_passage({k: v[:1] for k, v in items.items()})[1]
         batch = m16.encode_passage(items)[1]
         assert torch.equal(alone[0], batch[0]), (B, L)
+    print(f"\n[few rows, {arch}, {dtype}] max relative row error vs f32 (few-rows path / tile kernels): " + ", ".join(f"{b}x{l}: {a:.1e} / {t:.1e}" for b, l, a, t in worse))
+    if arch == "bert":
+        few_sum, tile_sum = sum(a for _, _, a, _ in worse), sum(t for _, _, _, t in worse)
+        assert few_sum < tile_sum, (few_sum, tile_sum)
 
 
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])

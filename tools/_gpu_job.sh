@@ -1,4 +1,6 @@
 set -u
-bash tools/gpu.sh prof r06_prof --no-search --no-extra
-bash tools/gpu.sh pmc r06_pmc_hbm hbm --no-search
-bash tools/gpu.sh pmc r06_pmc_sq sq --no-search
+O=gpurun_out/r06_n; mkdir -p $O
+export LD_LIBRARY_PATH=$PWD/openmatch_amd/csrc:${LD_LIBRARY_PATH:-}
+for tp in 3 0 3 0; do
+OM_ENCODER_TWO_PLANE=$tp timeout 600 python tools/small_forward_bench.py --limits 1024 --iters 200 --shapes 1x32,4x32,16x32,1x128,8x128 2>/dev/null | tail -1 | cut -c1-400
+done
