@@ -92,6 +92,26 @@ __device__ __forceinline__ bool g7_tile(int it, int64_t ntm, int64_t ntn, int gr
   return true;
 }
 
+// Probe (round 6, OM_GEMM_STAGGER): workgroups on alternate CUs of an XCD start late by a fraction of a tile period, so that the chip's
+// epilogues (all HBM traffic, no MFMA) and K loops (the reverse) stop coinciding across CUs.  group_m bits 17-27: delay in units of
+// 1 024 cycles per phase; bits 28-29: log2 of the number of phases.
+__device__ __forceinline__ void g7_stagger(int group_m) {
+  const int unit = (group_m >> 17) & 0x7ff;
+  if (unit == 0) return;
+  const int nph = 1 << ((group_m >> 28) & 3);
+  const int n = ((blockIdx.x >> 3) & (nph - 1)) * unit;
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+}
+static int g7_stagger_bits() {
+  static const int v = [] {
+    const char* e = getenv("OM_GEMM_STAGGER");
+    const char* p = getenv("OM_GEMM_STAGGER_PH");
+    const int unit = e ? atoi(e) & 0x7ff : 0, ph = p ? atoi(p) : 2;
+    return (unit << 17) | ((ph >= 8 ? 3 : ph >= 4 ? 2 : ph >= 2 ? 1 : 0) << 28);
+  }();
+  return v;
+}
+
 // v summed over the four lanes {l, l ^ 16, l ^ 32, l ^ 48}: (own + lane ^ 16) + the same of the other half, in every lane -- v_permlane16_swap
 // (odd 16-lane rows of one operand <-> even rows of the other) and v_permlane32_swap (upper half <-> lower half) with both operands = v
 __device__ __forceinline__ float g7_quad_row_sum(float v) {
@@ -646,6 +666,7 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7c16(
   g7_fill_b(src, cur_b, smem + ring.bc, wave);
   g7_fill_a(src, cur_a + G7_ROW_BYTES, smem + ring.an, wave);
   g7_fill_b(src, cur_b + G7_ROW_BYTES, smem + ring.bn, wave);
+  g7_stagger(group_m);
 
   bool live = false, have = true;
   int64_t pm = m0, pn = n0;
@@ -963,6 +984,7 @@ __global__ __launch_bounds__(G6_THREADS) void gemm_nt_kernel7r16(
   g7_fill_a(src, cur_a + G7_ROW_BYTES, smem + ring.an, wave);
   g7_fill_b(src, cur_b + G7_ROW_BYTES, smem + ring.bn, wave);
   g7_table2((const float*)A, ep.bias ? ep.bias + n0 + wn * 128 : (const float*)A, smem + ring.sp + (6 * 4 + wave) * 1024, lane0);
+  g7_stagger(group_m);
 
   bool live = false, have = true;
   int64_t pm = m0, pn = n0;
@@ -1420,7 +1442,7 @@ static int launch7c(const void* A, int64_t lda, const void* B, int64_t ldb, void
   }
   const bool timing = om_timing_on();
   if (timing) om_timing_begin(OM_TIMING_GEMM_BF16, s);
-  const int gm_arg = (std::max(1, om_option(OM_OPT_GEMM_GROUP_M)) & 0xffff) | (ep.reverse ? 1 << 16 : 0);
+  const int gm_arg = (std::max(1, om_option(OM_OPT_GEMM_GROUP_M)) & 0xffff) | (ep.reverse ? 1 << 16 : 0) | g7_stagger_bits();
   hipLaunchKernelGGL((gemm_nt_kernel7c16<T, ACT, LNF, TRAIN>), dim3((unsigned)grid), dim3(G6_THREADS), G7_LDS_BYTES, s,
                      (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, gm_arg);
   if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, 2.0 * (double)M * (double)N * (double)K);
@@ -1445,7 +1467,7 @@ static int launch7r(const void* A, int64_t lda, const void* B, int64_t ldb, void
   }
   const bool timing = om_timing_on();
   if (timing) om_timing_begin(OM_TIMING_GEMM_BF16, s);
-  const int gm_arg = (std::max(1, om_option(OM_OPT_GEMM_GROUP_M)) & 0xffff) | (ep.reverse ? 1 << 16 : 0);
+  const int gm_arg = (std::max(1, om_option(OM_OPT_GEMM_GROUP_M)) & 0xffff) | (ep.reverse ? 1 << 16 : 0) | g7_stagger_bits();
   hipLaunchKernelGGL((gemm_nt_kernel7r16<T, ACT, LNF>), dim3((unsigned)grid), dim3(G6_THREADS), G7_LDS_BYTES, s,
                      (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, ep, gm_arg);
   if (timing) om_timing_end(OM_TIMING_GEMM_BF16, s, 2.0 * (double)M * (double)N * (double)K);
