@@ -119,7 +119,10 @@ class DRModel(nn.Module):
         if "T5" in type(model).__name__ and not self.model_args.encoder_only:
             return self._encode_t5_decoder(items, model, head)
         if self.feature != "last_hidden_state":
-            raise NotImplementedError("only feature='last_hidden_state' is produced by the HIP encoder")
+            # the reference cannot run any other feature either: it indexes hidden[:, 0, :] / mean-pools over a sequence axis
+            # (modeling/dense_retrieval_model.py:143-149), which fails on HF's 2-D pooler_output
+            raise NotImplementedError("only feature='last_hidden_state' is produced by the HIP encoder (the reference's own "
+                                      "encode() fails on 2-D features such as pooler_output)")
         if self.pooling not in ("first", "mean"):
             raise ValueError("Unknown pooling type: {}".format(self.pooling))
         code = compute_dtype_code(self.model_args)
