@@ -137,10 +137,16 @@ void om_debug_gemm_gen(int gen);
                                       16 output columns, K split over its waves) instead of the 128- / 256-column tiles, and the encoder forward takes its unfused path
                                       (normalisations as kernels) up to that many token rows; env OM_GEMM_SKINNY_M, default 1024, 0: off */
 #define OM_OPT_GEMM_SKINNY_CFG 20  /* A/B: 0 (default) the kernel's own choice; MT * 10000 + NT * 100 + NW pins the tiles per wave and the K split (gemm_skinny.hip) */
-#define OM_OPT_COUNT 21
+#define OM_OPT_FEW_ROWS_LN_FUSE 21 /* round 6: 16-bit BERT forwards of at most this many token rows (default 64; env OM_FEW_ROWS_LN_FUSE; 0: off) launch no
+                                      LayerNorm kernels between the embedding and the last layer: the contraction that consumes a LayerNorm's output
+                                      normalises its operand rows itself, the one that adds it re-derives the element (gemm_skinny.hip; same bits) */
+#define OM_OPT_COUNT 22
 int om_debug_option(int opt, int value);
 /* the attention kernel alone (bf16 qkv [B*L, 3H] -> ctx [B*L, H]; mask [B, L] int64), for timing: csrc/kernels.h omk_attention */
 int om_debug_attention(const void* qkv, void* ctx, const int64_t* mask, int64_t B, int L, int H, int heads, void* stream);
+/* self-check of the LayerNorm row reduction (csrc/ln_row.h): every group of 64 consecutive floats of `in` summed by the __shfl_xor butterfly
+ * (out_shuffle[g]) and by its DPP / permlane form (out_dpp[g]); the two must agree bit for bit (tests/test_gpu_parity.py) */
+int om_debug_wave_sum_check(const float* in, float* out_shuffle, float* out_dpp, int64_t groups, void* stream);
 int om_kernel_timing_enable(int enable);
 int om_kernel_timing_read(int kernel_class, double* total_ms, int64_t* launches, double* flops);
 

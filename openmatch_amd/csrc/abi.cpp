@@ -114,6 +114,8 @@ void opt_init() {
   g_opt[OM_OPT_GEMM_CONT] = e ? atoi(e) : 495;
   e = getenv("OM_GEMM_SKINNY_M");
   g_opt[OM_OPT_GEMM_SKINNY_M] = e ? atoi(e) : 1024;
+  e = getenv("OM_FEW_ROWS_LN_FUSE");
+  g_opt[OM_OPT_FEW_ROWS_LN_FUSE] = e ? atoi(e) : 64;
   g_opt_init.store(true);
 }
 }  // namespace

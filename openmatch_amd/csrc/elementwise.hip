@@ -3,44 +3,10 @@
 // f32 -> f16 index shadow copy.  One wavefront (64 lanes) owns one row; 4 rows per block.
 #include "common.h"
 #include "kernels.h"
+#include "ln_row.h"
 
 #define ROWS_PER_BLOCK 4
 #define MAX_VEC_LIMIT 8  // 4-element vectors per lane -> H <= 2048 (NV = 4 covers H <= 1024)
-
-template <typename T> struct Vec4;
-template <> struct Vec4<float> {
-  __device__ static inline void load(const float* p, float (&v)[4]) {
-    const float4 t = *(const float4*)p;
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-  }
-  __device__ static inline void store(float* p, const float (&v)[4]) {
-    *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
-  }
-};
-template <> struct Vec4<bf16_t> {
-  __device__ static inline void load(const bf16_t* p, float (&v)[4]) {
-    const uint2 t = *(const uint2*)p;
-    v[0] = bf16_to_f32((bf16_t)(t.x & 0xffff)); v[1] = bf16_to_f32((bf16_t)(t.x >> 16));
-    v[2] = bf16_to_f32((bf16_t)(t.y & 0xffff)); v[3] = bf16_to_f32((bf16_t)(t.y >> 16));
-  }
-  __device__ static inline void store(bf16_t* p, const float (&v)[4]) {
-    uint2 t;
-    t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-    *(uint2*)p = t;
-  }
-};
-
-template <> struct Vec4<f16_t> {
-  __device__ static inline void load(const f16_t* p, float (&v)[4]) {
-    const uint2 t = *(const uint2*)p;
-    v[0] = Half16<f16_t>::lo(t.x); v[1] = Half16<f16_t>::hi(t.x);
-    v[2] = Half16<f16_t>::lo(t.y); v[3] = Half16<f16_t>::hi(t.y);
-  }
-  __device__ static inline void store(f16_t* p, const float (&v)[4]) {
-    *(uint2*)p = make_uint2(Half16<f16_t>::pack2(v[0], v[1]), Half16<f16_t>::pack2(v[2], v[3]));
-  }
-};
 
 // Normalise the row held in x[][] (nv vectors per lane) and write it out.
 // LayerNorm: two-pass mean / biased variance in f32 (torch.nn.LayerNorm);
@@ -49,22 +15,8 @@ template <typename TOut, int MAX_VEC>
 __device__ inline void norm_and_store(float (&x)[MAX_VEC][4], int nvec, int lane, int H,
                                       const float* __restrict__ g, const float* __restrict__ b,
                                       float eps, int rms, TOut* __restrict__ out, float* __restrict__ out32 = nullptr) {
-  float mean = 0.f;
-  if (!rms) {
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < MAX_VEC; ++j)
-      if (j < nvec && (lane + 64 * j) * 4 < H) s += (x[j][0] + x[j][1]) + (x[j][2] + x[j][3]);
-    mean = wave_sum(s) / (float)H;
-  }
-  float ss = 0.f;
-#pragma unroll
-  for (int j = 0; j < MAX_VEC; ++j)
-    if (j < nvec && (lane + 64 * j) * 4 < H) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { const float d = x[j][e] - mean; ss += d * d; }
-    }
-  const float rstd = rsqrtf(wave_sum(ss) / (float)H + eps);
+  float mean, rstd;
+  ln_row_stats<MAX_VEC>(x, nvec, lane, H, eps, rms, mean, rstd);
 #pragma unroll
   for (int j = 0; j < MAX_VEC; ++j) {
     const int c = (lane + 64 * j) * 4;
@@ -75,7 +27,7 @@ __device__ inline void norm_and_store(float (&x)[MAX_VEC][4], int nvec, int lane
         float bv[4];
         Vec4<float>::load(b + c, bv);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = (x[j][e] - mean) * rstd * gv[e] + bv[e];
+        for (int e = 0; e < 4; ++e) y[e] = ln_affine(x[j][e], mean, rstd, gv[e], bv[e]);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = (x[j][e] - mean) * rstd * gv[e];
@@ -247,7 +199,7 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void embed_kernel(
     const int64_t* __restrict__ ids, const int64_t* __restrict__ type_ids,
     const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
     const float* __restrict__ g, const float* __restrict__ b, TOut* __restrict__ out, int64_t M,
-    int L, int H, int vocab, int type_vocab, float eps, int bert, const int* __restrict__ row_map) {
+    int L, int H, int vocab, int type_vocab, float eps, int bert, const int* __restrict__ row_map, float* __restrict__ out32) {
   const int lane = threadIdx.x & 63;
   const int64_t orow = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (orow >= M) return;
@@ -279,7 +231,7 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void embed_kernel(
         for (int e = 0; e < 4; ++e) v[j][e] = (w[e] + ty[e]) + p[e];
       }
     }
-    norm_and_store<TOut, MAX_VEC>(v, nvec, lane, H, g, b, eps, 0, out + orow * H);
+    norm_and_store<TOut, MAX_VEC>(v, nvec, lane, H, g, b, eps, 0, out + orow * H, out32 ? out32 + orow * H : nullptr);
   } else {
 #pragma unroll
     for (int j = 0; j < MAX_VEC; ++j) {
@@ -485,13 +437,14 @@ int omk_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, c
 int omk_embed(int dtype, const int64_t* ids, const int64_t* type_ids, const float* word,
               const float* pos, const float* type, const float* g, const float* b, void* out,
               int64_t M, int L, int H, int vocab, int type_vocab, float eps, int bert,
-              hipStream_t s, const int* row_map) {
+              hipStream_t s, const int* row_map, float* out32) {
   if (H % 4 != 0 || H > 64 * 4 * MAX_VEC_LIMIT) OM_FAIL("hidden size must be a multiple of 4 and <= 2048");
   if (M <= 0) return 0;
+  if (out32 && (!bert || row_map)) OM_FAIL("embedding: the f32 copy goes with the BERT LayerNorm on unpacked rows");
   const unsigned grid = (unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
 #define EMBED_LAUNCH(TT, NV)                                                                   \
   hipLaunchKernelGGL((embed_kernel<TT, NV>), dim3(grid), dim3(64 * ROWS_PER_BLOCK), 0, s, ids, \
-                     type_ids, word, pos, type, g, b, (TT*)out, M, L, H, vocab, type_vocab, eps, bert, row_map)
+                     type_ids, word, pos, type, g, b, (TT*)out, M, L, H, vocab, type_vocab, eps, bert, row_map, out32)
   if (dtype == OM_BF16) {
     if (H <= 1024) EMBED_LAUNCH(bf16_t, 4); else EMBED_LAUNCH(bf16_t, 8);
   } else if (dtype == OM_F16) {
@@ -541,6 +494,23 @@ extern "C" int om_index_to_f16(const float* rows_f32, int64_t N, int d, void* ro
   const unsigned grid = (unsigned)((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
   hipLaunchKernelGGL(index_to_f16_kernel, dim3(grid), dim3(64 * ROWS_PER_BLOCK), 0,
                      (hipStream_t)stream, rows_f32, (f16_t*)rows_f16, N, d, (unsigned*)stats);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- self-check of ln_row.h's row reduction against the __shfl_xor butterfly (om_debug_wave_sum_check) ----
+__global__ __launch_bounds__(256) void wave_sum_check_kernel(const float* __restrict__ in, float* __restrict__ a, float* __restrict__ b, int64_t groups) {
+  const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= groups) return;
+  const float v = in[g * 64 + (threadIdx.x & 63)];
+  const float s0 = wave_sum(v);
+  float s1[1] = {v};
+  ln_wave_sums<1>(s1);
+  if ((threadIdx.x & 63) == (int)(g % 64)) { a[g] = s0; b[g] = s1[0]; }      // a different lane reports for every group: all lanes hold the sum
+}
+extern "C" int om_debug_wave_sum_check(const float* in, float* out_shuffle, float* out_dpp, int64_t groups, void* stream) {
+  if (!in || !out_shuffle || !out_dpp || groups <= 0) OM_FAIL("om_debug_wave_sum_check: null argument");
+  hipLaunchKernelGGL(wave_sum_check_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, out_shuffle, out_dpp, groups);
   OM_LAUNCH_CHECK();
   return 0;
 }

@@ -227,6 +227,19 @@ static int check_cfg(const OmEncoderConfig* c) {
 
 // packed_rows > 0: the token axis holds only the rows up to each sequence's last unmasked token, back to back
 // (om_encoder_forward_packed); every per-token kernel and contraction then runs over packed_rows rows instead of B * L.
+bool omk_gemm_skinny_ok(int in_dtype, int out_dtype, int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep);      // gemm_skinny.hip
+// whether the four contractions of a BERT layer take their pending-LayerNorm forms on the few-rows kernel at this shape
+static bool pending_ln_ok(int dt, int64_t M, int H, int F, int act) {
+  static const float one = 1.f;
+  GemmEpilogue a = {}, r = {};
+  a.a_ln32 = &one; a.a_ln_g = &one; a.a_ln_b = &one;
+  r.rln32 = &one; r.rln32_stats = &one; r.rln_g = &one; r.rln_b = &one; r.out32 = const_cast<float*>(&one);
+  GemmEpilogue f = a;
+  f.act = act;
+  return omk_gemm_skinny_ok(dt, dt, M, 3 * (int64_t)H, H, a) && omk_gemm_skinny_ok(dt, dt, M, F, H, f) &&
+         omk_gemm_skinny_ok(dt, dt, M, H, H, r) && omk_gemm_skinny_ok(dt, dt, M, H, F, r);
+}
+
 static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* w,
                                 const int64_t* input_ids, const int64_t* attention_mask,
                                 const int64_t* token_type_ids, int64_t B, int64_t L,
@@ -278,8 +291,10 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
   const float* f32_rows = ws.final32;       // where those rows are (the few-rows path leaves them in its f32 residual buffer)
   if (bert) {
     if (L > c->max_pos) OM_FAIL("sequence longer than the position table");
+    // few rows, 16-bit (round 6): the residual stream in f32 -- the embedding leaves its LayerNorm output in both forms
+    const bool few32 = few_rows && ws.y32 && c->n_layers > 0 && (om_option(OM_OPT_ENCODER_TWO_PLANE) & (dt == OM_BF16 ? 1 : 2)) != 0;
     RUN(omk_embed(dt, input_ids, token_type_ids, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g,
-                  w->emb_ln_b, ws.x, M, (int)L, H, c->vocab, c->type_vocab, c->ln_eps, 1, s, packed ? ws.row_map : nullptr));
+                  w->emb_ln_b, ws.x, M, (int)L, H, c->vocab, c->type_vocab, c->ln_eps, 1, s, packed ? ws.row_map : nullptr, few32 ? ws.r32a : nullptr));
     const float scale = 1.0f / sqrtf((float)c->head_dim);
     // LayerNorm fused across the GEMMs (bf16, large batches): the LayerNorm outputs are never
     // written.  The GEMM that produces a pre-LayerNorm sum y also accumulates its row statistics; the
@@ -385,14 +400,49 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
           final32_rows = M;
         }
       }
-    } else if (few_rows && ws.y32 && c->n_layers > 0 && (om_option(OM_OPT_ENCODER_TWO_PLANE) & (dt == OM_BF16 ? 1 : 2)) != 0) {
+    } else if (few32 && M <= (int64_t)om_option(OM_OPT_FEW_ROWS_LN_FUSE) && pending_ln_ok(dt, Mg, H, F, c->act)) {
+      // A handful of rows (<= 64: a served query), 16-bit (round 6): the f32 residual stream of the branch below with its LayerNorms PENDING --
+      // no normalisation launches between the embedding and the last layer (86 -> 63 dependent launches for bert-base; a launch costs
+      // 5.3 us here whatever it does, profiles/r06_few_rows_graph_probe.json).  y_a / y_b hold the pre-LayerNorm sums in f32; the
+      // contraction that consumes LN(y) normalises its operand rows itself and leaves (mean, rstd) per row, the one that adds LN(y)
+      // re-derives the element from them (gemm_skinny.hip: a_ln32 / rln32; ln_row.h is the one definition of the arithmetic, so
+      // the bits are those of the branch below -- test_few_rows_forward_*).
+      float* const y_a = ws.y32;      // attention block's sum: ctx Wo^T + b + x
+      float* const y_b = ws.r32b;     // feed-forward block's sum: ff W2^T + b + x1
+      for (int l = 0; l < c->n_layers; ++l) {
+        const OmLayerWeights& lw = Ls[l];
+        float* const st1 = ws.stats1 + (size_t)l * M * 2;                          // (mean, rstd) of LN1 of this layer
+        float* const st2p = l ? ws.stats2 + (size_t)(l - 1) * M * 2 : nullptr;     // ... of LN2 of the previous one
+        GemmEpilogue e = {};
+        e.bias = lw.qkv_b; e.ln_eps = c->ln_eps;
+        if (l) { e.a_ln32 = y_b; e.a_ln_g = Ls[l - 1].ln2_g; e.a_ln_b = Ls[l - 1].ln2_b; e.a_ln_stats_out = st2p; }
+        RUN(omk_gemm(dt, ws.x, H, lw.qkv_w, H, dt, ws.qkv, 3 * H, Mg, 3 * H, H, e, s));
+        RUN(omk_attention(dt, ws.qkv, ws.ctx, attention_mask, nullptr, B, (int)L, H, nh, scale, 0.f, 0, s, 0, ws.kmax));
+        e = GemmEpilogue{};
+        e.bias = lw.o_b; e.ldr = H; e.out32 = y_a; e.ln_eps = c->ln_eps;
+        if (l) { e.rln32 = y_b; e.rln32_stats = st2p; e.rln_g = Ls[l - 1].ln2_g; e.rln_b = Ls[l - 1].ln2_b; }
+        else e.resid32 = ws.r32a;
+        RUN(omk_gemm(dt, ws.ctx, H, lw.o_w, H, dt, ws.y, H, Mg, H, H, e, s));
+        e = GemmEpilogue{};
+        e.bias = lw.ffn1_b; e.act = c->act; e.ln_eps = c->ln_eps;
+        e.a_ln32 = y_a; e.a_ln_g = lw.ln1_g; e.a_ln_b = lw.ln1_b; e.a_ln_stats_out = st1;
+        RUN(omk_gemm(dt, ws.x1, H, lw.ffn1_w, H, dt, ws.ff, F, Mg, F, H, e, s));
+        e = GemmEpilogue{};
+        e.bias = lw.ffn2_b; e.ldr = H; e.out32 = y_b; e.ln_eps = c->ln_eps;
+        e.rln32 = y_a; e.rln32_stats = st1; e.rln_g = lw.ln1_g; e.rln_b = lw.ln1_b;
+        RUN(omk_gemm(dt, ws.ff, F, lw.ffn2_w, F, dt, ws.y, H, Mg, H, F, e, s));
+      }
+      const OmLayerWeights& last = Ls[c->n_layers - 1];
+      void* dst = out_hidden ? out_hidden : (void*)ws.x;
+      RUN(omk_layernorm_dual(dt, y_b, H, dst, ws.r32a, H, last.ln2_g, last.ln2_b, M, H, c->ln_eps, s));
+      final_hidden = (char*)dst;
+      if (c->pooling != OM_POOL_NONE) { f32_rows = ws.r32a; final32_rows = M; }
+    } else if (few32) {
       // Few rows (a served query, a handful of sequences), 16-bit (round 6): the residual stream in f32, as the reference's autocast keeps
       // it (layer_norm runs and returns fp32; a 16-bit dense output + an fp32 LayerNorm output is an fp32 sum: HF:models/bert/modeling_bert.py
       // :289-293,347-351 under retriever/dense_retriever.py:76) -- what the two-plane stream is to the fused path.  Every LayerNorm writes
       // its output twice (16-bit: the next contraction's operand; f32: what the next residual add reads), the residual contractions add
       // the f32 copy and leave their sum in f32 (gemm_skinny.hip: resid32 / out32).  Rounds 4-5 kept one 16-bit plane here.
-      RUN(omk_embed(OM_F32, input_ids, token_type_ids, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, ws.r32a, M, (int)L, H,
-                    c->vocab, c->type_vocab, c->ln_eps, 1, s, nullptr));
       for (int l = 0; l < c->n_layers; ++l) {
         const OmLayerWeights& lw = Ls[l];
         const bool last = l == c->n_layers - 1;

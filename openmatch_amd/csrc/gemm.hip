@@ -154,7 +154,7 @@ int omk_gemm(int in_dtype, const void* A, int64_t lda, const void* B, int64_t ld
   // few rows (a query, a handful of sequences): the weight-streaming kernel, N / 16 workgroups instead of N / 128
   if (gemm_variant() == 0 && g_debug_gen == 0 && omk_gemm_skinny_ok(in_dtype, out_dtype, M, N, K, ep))
     return omk_gemm_skinny(in_dtype, A, lda, B, ldb, C, ldc, M, N, K, ep, s);
-  if (ep.resid32 || ep.out32) OM_FAIL("f32 residual / f32 sum epilogue: the few-rows kernel only (gemm_skinny.hip)");
+  if (ep.resid32 || ep.out32 || ep.a_ln32 || ep.rln32) OM_FAIL("f32 residual / f32 sum / pending-LayerNorm epilogue: the few-rows kernel only (gemm_skinny.hip)");
   const bool wide = wide_ok(out_dtype, C, ldc, M, N, ep);
   // Pick the tile generation that finishes first: whole rounds of (256 CUs x resident workgroups)
   // times the tile's work over its measured relative efficiency (profiles/r01_selftest_gemm_v4.log).

@@ -15,8 +15,11 @@
 // from L2) cost more than the tiles' idle CUs and the tile kernels take over (OM_OPT_GEMM_SKINNY_M).
 //
 // Roofline: HBM; algorithmic bytes per launch = 2 N K (the weight) + 2 M (K + N) (activations in, out).
+#include <algorithm>
+#include <atomic>
 #include "kernels.h"
 #include "gemm_epilogue.h"
+#include "ln_row.h"
 
 namespace {
 typedef uint32_t sk_u32x4_t __attribute__((ext_vector_type(4)));
@@ -42,16 +45,35 @@ __device__ __forceinline__ float sk_act(float v, int act) {
   return v;
 }
 
+// pending LayerNorms of a launch (GemmEpilogue a_ln32 ... rln32_stats)
+struct SkLn {
+  const float *a32, *a_g, *a_b;
+  float* stats_out;
+  const float *r32, *r_stats, *r_g, *r_b;
+  float eps;
+};
+
 // grid (N / (16 NT), ceil(M / (16 MT))), NW waves that split K; MFMA operand 1 = 16 rows of A, operand 2 = 16 rows of W (the output
 // columns): lane l holds k = 8 (l >> 4) .. + 7 of row l & 15 of either; D[row 4 (l >> 4) + i][column l & 15].
 // MT x NT tiles per wave: (MT + NT) loads feed MT NT MFMAs per K step -- NT > 1 cuts the re-reads of A (every workgroup of a row
 // block reads all of A's K slice: N / (16 NT) times per launch, from L2), NW sets the length of a wave's dependent load chain.
-template <typename T, int MT, int NT, int NW>
+//
+// LNA (round 6): the A operand is a PENDING LayerNorm -- f32 rows a_ln32 [M, K] to be normalised with (gamma, beta).  The weight
+// fragments of the first batch are requested first; under their flight the workgroup's 16 MT rows are normalised by its waves exactly as
+// layernorm_kernel would (ln_row.h: one wave per row, the same reductions, the same fused multiply-add, the same rounding to T) into
+// LDS, from where every wave takes its K slice of all rows as fragments.  The first column block leaves (mean, rstd) per row for the
+// contraction that later adds the same LayerNorm's output as its residual (rln32: the element is re-derived, bit for bit, from the
+// row's statistics).  A forward over <= 64 token rows then has no normalisation launches at all (encoder.hip).
+template <typename T, int MT, int NT, int NW, bool LNA>
 __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ W, int64_t ldw,
                                                                 T* C, int64_t ldc, int M, int N, int K, const float* __restrict__ bias,
-                                                                const T* resid, int64_t ldr, int act, int mul, const float* resid32, float* out32) {
-  constexpr int UNR = (MT + NT) <= 3 ? 12 : ((MT + NT) <= 5 ? 8 : 4);      // K steps in flight per wave: (MT + NT) UNR x 4 VGPRs
-  __shared__ float red[NW][MT * NT][4][64];
+                                                                const T* resid, int64_t ldr, int act, int mul, const float* resid32, float* out32,
+                                                                SkLn ln) {
+  constexpr int UNR = LNA ? ((MT + NT) <= 4 ? 6 : 2)
+                          : ((MT + NT) <= 3 ? 12 : ((MT + NT) <= 5 ? 8 : 4));      // K steps in flight per wave: (MT + NT) UNR x 4 VGPRs
+  constexpr int RED_BYTES = NW * MT * NT * 4 * 64 * 4;
+  extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+  float (*red)[MT * NT][4][64] = (float (*)[MT * NT][4][64])sk_smem;     // [NW][MT * NT][4][64], after the K loop
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, kg = lane >> 4;
   const int n0 = blockIdx.x * (16 * NT), m0 = blockIdx.y * (16 * MT);
@@ -59,19 +81,20 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const T* __rest
   const T* wp[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) wp[t] = W + (int64_t)(n0 + 16 * t + r) * ldw + wave * ksl + kg * 8;
+  const int steps = ksl >> 5;
+  const int xs_pitch = 2 * K + 16;                          // LNA: the normalised rows in LDS; + 16 bytes: the 16 rows of a fragment read on distinct banks
   const T* ap[MT];
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
     int m = m0 + 16 * j + r;
     m = m < M ? m : M - 1;                                  // rows past M: computed from a valid row, never stored
-    ap[j] = A + (int64_t)m * lda + wave * ksl + kg * 8;
+    ap[j] = LNA ? (const T*)(sk_smem + (size_t)(16 * j + r) * xs_pitch) + wave * ksl + kg * 8 : A + (int64_t)m * lda + wave * ksl + kg * 8;
   }
   f32x4_t acc[MT][NT];
 #pragma unroll
   for (int j = 0; j < MT; ++j)
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[j][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const int steps = ksl >> 5;
   for (int s0 = 0; s0 < steps; s0 += UNR) {
     sk_u32x4_t wq[NT][UNR], aq[MT][UNR];
 #pragma unroll
@@ -79,9 +102,69 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const T* __rest
       if (s0 + u < steps) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) wq[t][u] = __builtin_nontemporal_load((const sk_u32x4_t*)(wp[t] + (s0 + u) * 32));      // the weight passes once
+        if (!LNA) {
 #pragma unroll
-        for (int j = 0; j < MT; ++j) aq[j][u] = *(const sk_u32x4_t*)(ap[j] + (s0 + u) * 32);
+          for (int j = 0; j < MT; ++j) aq[j][u] = *(const sk_u32x4_t*)(ap[j] + (s0 + u) * 32);
+        }
       }
+    if (LNA && s0 == 0) {
+      // the workgroup's rows, normalised: wave w takes rows w, w + NW, ... (all their loads first: one trip to memory)
+      constexpr int RPW = (16 * MT + NW - 1) / NW;
+      const int nvec = (K / 4 + 63) / 64;
+      float x[RPW][4][4];
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        const int rr = wave + q * NW;
+        int m = m0 + rr;
+        m = m < M ? m : M - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = (lane + 64 * j) * 4;
+          if (rr < 16 * MT && j < nvec && c < K) {
+            const float4 t4 = *(const float4*)(ln.a32 + (int64_t)m * K + c);
+            x[q][j][0] = t4.x; x[q][j][1] = t4.y; x[q][j][2] = t4.z; x[q][j][3] = t4.w;
+          }
+        }
+      }
+      float gv[4][4], bv[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (j < nvec && c < K) {
+          const float4 g4 = *(const float4*)(ln.a_g + c), b4 = *(const float4*)(ln.a_b + c);
+          gv[j][0] = g4.x; gv[j][1] = g4.y; gv[j][2] = g4.z; gv[j][3] = g4.w;
+          bv[j][0] = b4.x; bv[j][1] = b4.y; bv[j][2] = b4.z; bv[j][3] = b4.w;
+        }
+      }
+      float mean[RPW], rstd[RPW];
+      ln_rows_stats<RPW, 4>(x, nvec, lane, K, ln.eps, 0, mean, rstd);
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        const int rr = wave + q * NW;
+        if (rr < 16 * MT) {
+          if (ln.stats_out && blockIdx.x == 0 && lane == 0 && m0 + rr < M) *(float2*)(ln.stats_out + (int64_t)(m0 + rr) * 2) = make_float2(mean[q], rstd[q]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            if (j < nvec && c < K) {
+              float y[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) y[e] = ln_affine(x[q][j][e], mean[q], rstd[q], gv[j][e], bv[j][e]);
+              Vec4<T>::store((T*)(sk_smem + (size_t)rr * xs_pitch) + c, y);
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (LNA) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+        if (s0 + u < steps) {
+#pragma unroll
+          for (int j = 0; j < MT; ++j) aq[j][u] = *(const sk_u32x4_t*)(ap[j] + (s0 + u) * 32);
+        }
+    }
 #pragma unroll
     for (int u = 0; u < UNR; ++u)
       if (s0 + u < steps) {
@@ -91,6 +174,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const T* __rest
           for (int t = 0; t < NT; ++t) acc[j][t] = SkMma<T>::mma(aq[j][u], wq[t][u], acc[j][t]);
       }
   }
+  if (LNA) __syncthreads();                                 // the partials below reuse the rows' LDS
 #pragma unroll
   for (int j = 0; j < MT; ++j)
 #pragma unroll
@@ -107,7 +191,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const T* __rest
 #pragma unroll
     for (int w = 1; w < NW; ++w) v += red[w][tile][i][lane];
     v = sk_act(v + (bias ? bias[n] : 0.f), act);
-    if (resid32) {
+    if (ln.r32) {
+      const float2 st = *(const float2*)(ln.r_stats + (int64_t)m * 2);      // the residual is a pending LayerNorm: this element of its output
+      v += ln_affine(ln.r32[(int64_t)m * ldr + n], st.x, st.y, ln.r_g[n], ln.r_b[n]);
+    } else if (resid32) {
       v += resid32[(int64_t)m * ldr + n];                                  // the f32 residual stream of the few-rows path (may alias out32)
     } else if (resid) {
       const float rv = ElemOps<T>::load(resid + (int64_t)m * ldr + n);      // may alias C: read and written by this lane only
@@ -140,15 +227,44 @@ static SkCfg sk_choose(int64_t M, int64_t N, int64_t K) {
   return c;
 }
 
+template <typename T, int MT, int NT, int NW, bool LNA>
+int launch_skinny_cfg(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                      const GemmEpilogue& ep, hipStream_t s) {
+  const int act = ep.act & 0xff, mul = (ep.act & OM_ACT_MUL_RESID) ? 1 : 0;
+  const SkLn ln = {ep.a_ln32, ep.a_ln_g, ep.a_ln_b, ep.a_ln_stats_out, ep.rln32, ep.rln32_stats, ep.rln_g, ep.rln_b, ep.ln_eps};
+  size_t lds = (size_t)NW * MT * NT * 4 * 64 * 4;                                   // the partial tiles
+  if (LNA) lds = std::max(lds, (size_t)16 * MT * (2 * (size_t)K + 16));              // ... or the normalised rows
+  if (lds > 64 * 1024) {
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set) {
+      OM_HIP(hipFuncSetAttribute((const void*)gemm_nt_skinny_kernel<T, MT, NT, NW, LNA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL((gemm_nt_skinny_kernel<T, MT, NT, NW, LNA>), dim3((unsigned)(N / (16 * NT)), (unsigned)((M + 16 * MT - 1) / (16 * MT))),
+                     dim3(64 * NW), lds, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, (int)M, (int)N, (int)K, ep.bias,
+                     (const T*)ep.resid, ep.ldr, act, mul, ep.resid32, ep.out32, ln);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T>
 int launch_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                   const GemmEpilogue& ep, hipStream_t s) {
-  const int act = ep.act & 0xff, mul = (ep.act & OM_ACT_MUL_RESID) ? 1 : 0;
   const SkCfg c = sk_choose(M, N, K);
   if (N % (16 * c.nt) || K % (32 * c.nw)) OM_FAIL("gemm_skinny: (NT, NW) does not divide the problem");
-#define SK_GO(MT_, NT_, NW_)                                                                                                           if (c.mt == MT_ && c.nt == NT_ && c.nw == NW_) {                                                                                       hipLaunchKernelGGL((gemm_nt_skinny_kernel<T, MT_, NT_, NW_>), dim3((unsigned)(N / (16 * NT_)), (unsigned)((M + 16 * MT_ - 1) / (16 * MT_))),                        dim3(64 * NW_), 0, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, (int)M, (int)N, (int)K, ep.bias,                                (const T*)ep.resid, ep.ldr, act, mul, ep.resid32, ep.out32);                                                                            OM_LAUNCH_CHECK();                                                                                                                   return 0;                                                                                                                          }
+  const bool lna = ep.a_ln32 != nullptr;
+  if (lna && (size_t)16 * c.mt * (2 * (size_t)K + 16) > 160 * 1024) OM_FAIL("gemm_skinny: pending-LayerNorm operand rows do not fit in LDS");
+#define SK_GO(MT_, NT_, NW_)                                                                                              \
+  if (c.mt == MT_ && c.nt == NT_ && c.nw == NW_)                                                                          \
+    return lna ? launch_skinny_cfg<T, MT_, NT_, NW_, true>(A, lda, W, ldw, C, ldc, M, N, K, ep, s)                          \
+               : launch_skinny_cfg<T, MT_, NT_, NW_, false>(A, lda, W, ldw, C, ldc, M, N, K, ep, s);
   SK_GO(1, 1, 4) SK_GO(1, 1, 8) SK_GO(1, 2, 4) SK_GO(1, 2, 8) SK_GO(1, 4, 4) SK_GO(1, 4, 8)
   SK_GO(2, 1, 4) SK_GO(2, 1, 8) SK_GO(2, 2, 4) SK_GO(2, 2, 8) SK_GO(2, 4, 4) SK_GO(2, 4, 8)
+#undef SK_GO
+  if (lna) OM_FAIL("gemm_skinny: a pending-LayerNorm operand takes at most 32 rows per workgroup (omk_gemm_skinny_ok)");      // 64 rows of f32 per workgroup spill
+#define SK_GO(MT_, NT_, NW_) \
+  if (c.mt == MT_ && c.nt == NT_ && c.nw == NW_) return launch_skinny_cfg<T, MT_, NT_, NW_, false>(A, lda, W, ldw, C, ldc, M, N, K, ep, s);
   SK_GO(4, 1, 4) SK_GO(4, 1, 8) SK_GO(4, 2, 4) SK_GO(4, 2, 8) SK_GO(4, 4, 4)
 #undef SK_GO
   OM_FAIL("gemm_skinny: no kernel for this (MT, NT, NW)");
@@ -164,7 +280,9 @@ bool omk_gemm_skinny_ok(int in_dtype, int out_dtype, int64_t M, int64_t N, int64
   const int act = ep.act & 0xff;
   if (act != OM_ACT_NONE && act != OM_ACT_GELU_ERF && act != OM_ACT_RELU && act != OM_ACT_GELU_TANH) return false;
   if (ep.pre_act || ep.drop_p > 0.f || ep.ln_stats || ep.rln_stats || ep.stats_out || ep.resid_lo || ep.out_lo) return false;
-  if ((ep.act & OM_ACT_MUL_RESID) && (!ep.resid || ep.resid32)) return false;
+  if ((ep.act & OM_ACT_MUL_RESID) && (!ep.resid || ep.resid32 || ep.rln32)) return false;
+  if (ep.a_ln32 && (!ep.a_ln_g || !ep.a_ln_b || K % 4 || K > 1024 || sk_choose(M, N, K).mt > 2)) return false;   // LayerNorm (with shift), rows of <= 1024 elements, <= 32 rows per workgroup
+  if (ep.rln32 && (!ep.rln32_stats || !ep.rln_g || !ep.rln_b)) return false;
   return true;
 }
 

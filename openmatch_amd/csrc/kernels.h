@@ -18,7 +18,8 @@ int omk_layernorm_f32out(int dtype, const void* x, int64_t ldx, float* y, int64_
 int omk_embed(int dtype, const int64_t* ids, const int64_t* type_ids, const float* word,
               const float* pos, const float* type, const float* g, const float* b, void* out,
               int64_t M, int L, int H, int vocab, int type_vocab, float eps, int bert,
-              hipStream_t s, const int* row_map = nullptr /* packed rows: output row t embeds token row_map[t] of ids (-1: a zero row) */);
+              hipStream_t s, const int* row_map = nullptr /* packed rows: output row t embeds token row_map[t] of ids (-1: a zero row) */,
+              float* out32 = nullptr /* BERT: the unrounded f32 copy of the normalised rows as well (few-rows path) */);
 int omk_pool(int dtype, const void* x, const int64_t* mask, float* out, int64_t B, int L, int H,
              int mode, hipStream_t s, const int* cu = nullptr /* packed rows: sequence b is rows cu[b] .. of x */);
 int omk_l2norm(const float* x, float* y, int64_t M, int D, hipStream_t s);
@@ -67,6 +68,15 @@ struct GemmEpilogue {
   void* out_lo;              //   and the output is written as C = round16(y), out_lo = round16(y - C); selects the LNF == 3 kernel
   const float* resid32;      // few-rows path (gemm_skinny.hip, round 6): the residual as f32 [M, ldr] instead of `resid` -- the reference's autocast keeps the
   float* out32;              //   LayerNorm outputs it adds in fp32 -- and the sum written as f32 [M, ldc] here instead of into C
+  // few rows with PENDING LayerNorms (gemm_skinny.hip, round 6): the normalisations of a forward over a handful of rows are not launches of
+  // their own -- the contraction that consumes a LayerNorm's output normalises its operand rows itself, the one that adds it as a residual
+  // re-derives the element from the row's (mean, rstd)
+  const float* a_ln32;       // the A operand is LN(a_ln32 [M, K] f32, row pitch K) with a_ln_g / a_ln_b and ln_eps (A itself is ignored); K = hidden size
+  const float* a_ln_g;
+  const float* a_ln_b;
+  float* a_ln_stats_out;     //   (mean, rstd) per row [M][2], written by the first column block of every row block: what a later rln32 reads
+  const float* rln32;        // the residual is LN(rln32 [M, ldr] f32) with rln32_stats [M][2] = (mean, rstd) and rln_g / rln_b (per output column)
+  const float* rln32_stats;
   int lo8;                   //   1 (float16): both second planes are EIGHT-bit blobs (omk_lo8_offset below; the LNF == 4 kernel) instead of 16-bit matrices
   float ln_inv_h, ln_eps;
   int ln_rms;                // 1: the statistics describe a T5 RMSNorm (no mean, no shift): only sum of squares is used

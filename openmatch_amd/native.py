@@ -100,6 +100,7 @@ _SIGNATURES = {
     "om_debug_gemm_gen": (None, [c_int]),
     "om_debug_option": (c_int, [c_int, c_int]),
     "om_debug_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "om_debug_wave_sum_check": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "om_encoder_fold_bytes": (c_size_t, [C.POINTER(OmEncoderConfig)]),
     "om_encoder_fold_weights": (c_int, [C.POINTER(OmEncoderConfig), C.POINTER(OmEncoderWeights), c_void_p, c_size_t, c_void_p]),
     "om_kernel_timing_enable": (c_int, [c_int]),

@@ -2221,10 +2221,62 @@ def test_few_rows_forward_tracks_f32_path_and_is_batch_invariant(dtype, arch):
         alone = m16.encode_passage({k: v[:1] for k, v in items.items()})[1]
         batch = m16.encode_passage(items)[1]
         assert torch.equal(alone[0], batch[0]), (B, L)
+        if arch == "bert" and B * L <= 64:      # pending LayerNorms (round 6, <= OM_OPT_FEW_ROWS_LN_FUSE rows) == the LayerNorm kernels, bit for bit
+            N_.check(N_.lib().om_debug_option(21, 0))
+            try:
+                with_kernels = m16.encode_passage(items)[1]
+            finally:
+                N_.check(N_.lib().om_debug_option(21, 64))
+            assert torch.equal(with_kernels, batch), (B, L)
     print(f"\n[few rows, {arch}, {dtype}] max relative row error vs f32 (few-rows path / tile kernels): " + ", ".join(f"{b}x{l}: {a:.1e} / {t:.1e}" for b, l, a, t in worse))
     if arch == "bert":
         few_sum, tile_sum = sum(a for _, _, a, _ in worse), sum(t for _, _, _, t in worse)
         assert few_sum < tile_sum, (few_sum, tile_sum)
+
+
+def test_layernorm_row_reduction_without_the_lds_crossbar_equals_the_shuffle_butterfly():
+    """ln_row.h sums a row over the 64 lanes with v_permlane32/16_swap, DPP row rotation, ds_swizzle and DPP quad permutations in the
+    pairing of the __shfl_xor butterfly (common.h wave_sum): the same bits, on values of mixed sign and magnitude, in every lane."""
+    from openmatch_amd import native as N_
+    g = torch.Generator().manual_seed(3)
+    groups = 4099
+    x = (torch.randn(groups * 64, generator=g) * torch.exp(torch.randn(groups * 64, generator=g) * 3)).to(DEV)
+    a, b = torch.zeros(groups, device=DEV), torch.zeros(groups, device=DEV)
+    N_.check(N_.lib().om_debug_wave_sum_check(x.data_ptr(), a.data_ptr(), b.data_ptr(), groups, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert torch.allclose(a.double(), x.view(groups, 64).double().sum(1), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_pending_layernorms_of_a_handful_of_rows_give_the_bits_of_the_layernorm_kernels(dtype):
+    """Round 6: a 16-bit BERT forward over <= OM_OPT_FEW_ROWS_LN_FUSE (64) token rows launches no LayerNorm kernel between the embedding and
+    the last layer -- the contraction that consumes LN(y) normalises its operand rows itself, the one that adds LN(y) re-derives the element
+    from (mean, rstd) (gemm_skinny.hip; ln_row.h holds the one definition of the arithmetic).  At bert-base width (three 4-element vectors
+    per lane and row), pooled representations AND the hidden states equal the path with the normalisations as kernels bit for bit; mean
+    and first pooling; 1 ... 64 rows."""
+    from transformers import BertConfig, BertModel
+    from openmatch.modeling import DRModelForInference
+    from openmatch_amd import native as N_
+    torch.manual_seed(33)
+    lm = BertModel(BertConfig(num_hidden_layers=3, vocab_size=2000, max_position_embeddings=128)).eval()
+    rng = np.random.default_rng(5)
+    for pooling in ("first", "mean"):
+        m16 = DRModelForInference(lm_q=lm, lm_p=lm, pooling=pooling, model_args=NS(encoder_only=False, dtype=dtype)).to(DEV).eval()
+        m32 = DRModelForInference(lm_q=lm, lm_p=lm, pooling=pooling, model_args=NS(encoder_only=False, dtype="float32")).to(DEV).eval()
+        for B, L in ((1, 32), (1, 5), (2, 32), (3, 17), (1, 64), (4, 16)):
+            ids, mask = synth_tokens(rng, B, L, vocab=2000, lo_len=max(2, L // 2), lo_id=1000)
+            items = {"input_ids": torch.from_numpy(ids).to(DEV), "attention_mask": torch.from_numpy(mask).to(DEV)}
+            hid, reps = m16.encode_passage(items)
+            N_.check(N_.lib().om_debug_option(21, 0))
+            try:
+                hid_k, reps_k = m16.encode_passage(items)
+            finally:
+                N_.check(N_.lib().om_debug_option(21, 64))
+            assert torch.equal(reps, reps_k), (pooling, B, L, (reps - reps_k).abs().max().item())
+            assert torch.equal(hid, hid_k), (pooling, B, L)
+            ref = m32.encode_passage(items)[1]
+            assert 1 - torch.nn.functional.cosine_similarity(reps.double(), ref.double(), dim=1).min().item() < (5e-6 if dtype == "float16" else 2e-4)
 
 
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])

@@ -1,11 +1,9 @@
 set -u
-O=gpurun_out/r06_stagger; mkdir -p $O
+O=gpurun_out/r06_p; mkdir -p $O
 export LD_LIBRARY_PATH=$PWD/openmatch_amd/csrc:${LD_LIBRARY_PATH:-}
-Q="--no-cpu-baseline --no-extra --no-parity --no-search"
-for round in 1 2; do for cfg in "0 2" "16 2" "32 2" "12 4" "48 2"; do set -- $cfg
-  OM_GEMM_STAGGER=$1 OM_GEMM_STAGGER_PH=$2 timeout 300 python bench.py --steps 10 --warmup 3 $Q > $O/b_$1_$2_$round.json 2>$O/err.log
-  echo "stagger=$1 ph=$2 $(grep -o '"value": [0-9.]*' $O/b_$1_$2_$round.json | head -1) $(grep -o '"frac": [0-9.]*' $O/b_$1_$2_$round.json | head -1)"
-done; done
-for cfg in "0 2" "32 2"; do set -- $cfg
-  OM_GEMM_STAGGER=$1 OM_GEMM_STAGGER_PH=$2 timeout 300 python tools/epilogue_trace.py 2>/dev/null | tail -1 | cut -c1-900
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "few_row or pending or small or bert_tiny or retriever_end_to_end or weight_streaming or layernorm or row_reduction or rmsnorm" > $O/pytest.log 2>&1; echo "rc=$?"
+grep -E "passed|failed|Error|^E  " $O/pytest.log | cut -c1-400 | tail -8
+for v in 64 0 64 0; do
+OM_FEW_ROWS_LN_FUSE=$v timeout 600 python tools/small_forward_bench.py --limits 1024 --iters 300 --shapes 1x32,2x32,1x64,4x32,1x128 2>/dev/null | tail -1 | cut -c90-400
 done
+timeout 300 python tools/few_rows_graph_probe.py --shapes 1x32 2>/dev/null | tail -1
