@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const T* __rest
                                                                 T* C, int64_t ldc, int M, int N, int K, const float* __restrict__ bias,
                                                                 const T* resid, int64_t ldr, int act, int mul, const float* resid32, float* out32,
                                                                 SkLn ln) {
-  constexpr int UNR = LNA ? ((MT + NT) <= 4 ? 6 : 2)
+  constexpr int UNR = LNA ? (NW == 8 ? ((MT + NT) <= 3 ? 4 : 2) : ((MT + NT) <= 4 ? 6 : 2))      // (eight waves: 256 registers per lane, and the rows' f32 copies live beside the weight fragments)
                           : ((MT + NT) <= 3 ? 12 : ((MT + NT) <= 5 ? 8 : 4));      // K steps in flight per wave: (MT + NT) UNR x 4 VGPRs
   constexpr int RED_BYTES = NW * MT * NT * 4 * 64 * 4;
   extern __shared__ __attribute__((aligned(16))) char sk_smem[];

@@ -23,10 +23,8 @@ template <> struct Vec4<bf16_t> {
     v[2] = bf16_to_f32((bf16_t)(t.y & 0xffff)); v[3] = bf16_to_f32((bf16_t)(t.y >> 16));
   }
   __device__ static inline void store(bf16_t* p, const float (&v)[4]) {
-    uint2 t;
-    t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-    *(uint2*)p = t;
+    // v_cvt_pk_bf16_f32 (gfx950): round to nearest even like f32_to_bf16, which it equals on every non-NaN input (the two give different NaNs)
+    *(uint2*)p = make_uint2(Half16<bf16_t>::pack2(v[0], v[1]), Half16<bf16_t>::pack2(v[2], v[3]));
   }
 };
 
