@@ -407,8 +407,8 @@ int om_encoder_train_backward(const OmEncoderConfig* cfg, const OmEncoderWeights
  * every query to q_max_len and every passage to p_max_len (dataset/data_collator.py:13-24) and the model computes over the padding;
  * here the contractions, normalisations, the tape and the weight gradients run over `packed_rows` rows -- each sequence's tokens up
  * to its last unmasked one, back to back.  ids / mask / token types keep their [B, L] layout; packed_rows is a multiple of 256 that
- * is >= the token count (computed on the host from the collator's lengths) and < B * L.  16-bit BERT-family configurations with
- * widths of 256, L <= 256, pooling first / mean: ask om_encoder_train_packed_supported.  Same representations and gradients as the
+ * is >= the token count (computed on the host from the collator's lengths) and < B * L.  16-bit BERT-family and (round 6) T5 encoder
+ * configurations with widths of 256, L <= 256, pooling first / mean: ask om_encoder_train_packed_supported.  Same representations and gradients as the
  * padded pair up to the order of the sums over rows; a bound below the token count turns out_reps into NaN. */
 int om_encoder_train_packed_supported(const OmEncoderConfig* cfg, int64_t B, int64_t L, int64_t packed_rows);
 size_t om_encoder_tape_bytes_packed(const OmEncoderConfig* cfg, int64_t B, int64_t L, int64_t packed_rows);

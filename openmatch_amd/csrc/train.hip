@@ -221,8 +221,11 @@ int t5_train_forward(const OmEncoderConfig* c, const OmEncoderWeights* w, const 
   const int64_t M = d.M;
   const OmLayerWeights* Ls = w->layers_host;
   RUN(t5_bias_setup(c, w, d, ws, s));
-  RUN(omk_embed(dt, input_ids, nullptr, w->word_emb, nullptr, nullptr, nullptr, nullptr, t.x, M, (int)d.L, H, c->vocab, 1, c->ln_eps, 0, s));
-  if (hd > 0.f) RUN(omk_dropout(dt, t.x, t.x, M * H, hd, site_seed(seed, 0, 0), s));
+  // packed rows (round 6): the tables are in ws (train_forward_impl); every dropout mask is keyed on the token through row_map
+  const int* const cu = d.packed ? ws.cu : nullptr;
+  const int* const row_map = d.packed ? ws.row_map : nullptr;
+  RUN(omk_embed(dt, input_ids, nullptr, w->word_emb, nullptr, nullptr, nullptr, nullptr, t.x, M, (int)d.L, H, c->vocab, 1, c->ln_eps, 0, s, row_map));
+  if (hd > 0.f) RUN(omk_dropout(dt, t.x, t.x, M * H, hd, site_seed(seed, 0, 0), s, row_map, H));
   for (int l = 0; l < d.nl; ++l) {
     const OmLayerWeights& lw = Ls[l];
     char* x = t.x + t.sx * l;
@@ -233,13 +236,14 @@ int t5_train_forward(const OmEncoderConfig* c, const OmEncoderWeights* w, const 
     RUN(omk_layernorm(dt, x, H, ws.nbuf, H, lw.ln1_g, nullptr, M, H, c->ln_eps, 1, s));
     GemmEpilogue ep = {};
     RUN(omk_gemm(dt, ws.nbuf, H, lw.qkv_w, H, dt, qkv, 3 * H, M, 3 * H, H, ep, s));
-    RUN(omk_attention(dt, qkv, ctx, attention_mask, ws.posbias, d.B, (int)d.L, H, d.nh, 1.0f, ad, site_seed(seed, l, 2), s));
+    RUN(omk_attention(dt, qkv, ctx, attention_mask, ws.posbias, d.B, (int)d.L, H, d.nh, 1.0f, ad, site_seed(seed, l, 2), s, 0, d.packed ? ws.kmax : nullptr, cu));
+    if (d.packed) RUN(omk_zero_rows_from(ctx, (int64_t)H * d.es, ws.cu + d.B, M, s));      // the rows no sequence owns
     ep = GemmEpilogue{};
-    ep.resid = x; ep.ldr = H; ep.drop_p = hd; ep.seed = site_seed(seed, l, 3);
+    ep.resid = x; ep.ldr = H; ep.drop_p = hd; ep.seed = site_seed(seed, l, 3); ep.drop_rows = row_map;
     RUN(omk_gemm(dt, ctx, H, lw.o_w, H, dt, x1, H, M, H, H, ep, s));
     RUN(omk_layernorm(dt, x1, H, ws.nbuf, H, lw.ln2_g, nullptr, M, H, c->ln_eps, 1, s));
     ep = GemmEpilogue{};
-    ep.pre_act = f; ep.ldp = F; ep.drop_p = hd; ep.seed = site_seed(seed, l, 5);
+    ep.pre_act = f; ep.ldp = F; ep.drop_p = hd; ep.seed = site_seed(seed, l, 5); ep.drop_rows = row_map;
     if (d.gated) {
       if (!lw.ffn1g_w) OM_FAIL("gated T5 feed-forward needs ffn1g_w");
       char* f2 = t.f2 + t.sf * l;
@@ -251,11 +255,11 @@ int t5_train_forward(const OmEncoderConfig* c, const OmEncoderWeights* w, const 
     }
     RUN(omk_gemm(dt, ws.nbuf, H, lw.ffn1_w, H, dt, ws.g, F, M, F, H, ep, s));
     ep = GemmEpilogue{};
-    ep.resid = x1; ep.ldr = H; ep.drop_p = hd; ep.seed = site_seed(seed, l, 4);
+    ep.resid = x1; ep.ldr = H; ep.drop_p = hd; ep.seed = site_seed(seed, l, 4); ep.drop_rows = row_map;
     RUN(omk_gemm(dt, ws.g, F, lw.ffn2_w, F, dt, t.x + t.sx * (l + 1), H, M, H, F, ep, s));
   }
   RUN(omk_layernorm(dt, t.x + t.sx * d.nl, H, ws.dxa, H, w->final_ln_g, nullptr, M, H, c->ln_eps, 1, s));
-  if (hd > 0.f) RUN(omk_dropout(dt, ws.dxa, ws.dxa, M * H, hd, site_seed(seed, d.nl, 1), s));
+  if (hd > 0.f) RUN(omk_dropout(dt, ws.dxa, ws.dxa, M * H, hd, site_seed(seed, d.nl, 1), s, row_map, H));
   *final_hidden = ws.dxa;
   return 0;
 }
@@ -367,7 +371,9 @@ int t5_train_backward(const OmEncoderConfig* c, const OmEncoderWeights* w, const
 #define WGRAD(dY_, N_, X_, K_, dW_) RUN(wgrad(dt, dY_, N_, X_, K_, dW_, nullptr, d, ws, s))
   RUN(transpose_weights(dt, Ls, d, ws, s));
   // final dropout + RMSNorm
-  if (hd > 0.f) RUN(omk_dropout(dt, dx, dx, M * H, hd, site_seed(seed, d.nl, 1), s));
+  const int* const cu = d.packed ? ws.cu : nullptr;                 // packed rows (round 6): the tables train_backward_impl rebuilt
+  const int* const row_map = d.packed ? ws.row_map : nullptr;
+  if (hd > 0.f) RUN(omk_dropout(dt, dx, dx, M * H, hd, site_seed(seed, d.nl, 1), s, row_map, H));
   RUN(omk_norm_bwd(dt, dx, t.x + t.sx * d.nl, w->final_ln_g, dx_other, g->final_ln_g, nullptr, M, H, c->ln_eps, 1, nullptr, s));
   { char* tmp = dx; dx = dx_other; dx_other = tmp; }
   const int kind = d.gated ? 1 : 0;
@@ -383,13 +389,13 @@ int t5_train_backward(const OmEncoderConfig* c, const OmEncoderWeights* w, const
     const WtView wt = wt_of(d, ws, l);
     // ---- feed-forward branch
     const char* dO = dx;
-    if (hd > 0.f) { RUN(omk_dropout(dt, dx, ws.dd, M * H, hd, site_seed(seed, l, 4), s)); dO = ws.dd; }
+    if (hd > 0.f) { RUN(omk_dropout(dt, dx, ws.dd, M * H, hd, site_seed(seed, l, 4), s, row_map, H)); dO = ws.dd; }
     RUN(omk_t5_act_fwd(dt, f, f2, ws.g, M * F, kind, s));                     // g = act(f) [* f2]
-    if (hd > 0.f) RUN(omk_dropout(dt, ws.g, ws.g, M * F, hd, site_seed(seed, l, 5), s));
+    if (hd > 0.f) RUN(omk_dropout(dt, ws.g, ws.g, M * F, hd, site_seed(seed, l, 5), s, row_map, F));
     WGRAD(dO, H, ws.g, F, lg.ffn2_w);                                         // dWo2 [H,F]
     GemmEpilogue e = {};
     RUN(omk_gemm(dt, dO, H, wt.f2, H, dt, ws.df, F, M, F, H, e, s));          // dg = dO Wo2;  Wo2^T [F,H]
-    if (hd > 0.f) RUN(omk_dropout(dt, ws.df, ws.df, M * F, hd, site_seed(seed, l, 5), s));
+    if (hd > 0.f) RUN(omk_dropout(dt, ws.df, ws.df, M * F, hd, site_seed(seed, l, 5), s, row_map, F));
     RUN(omk_t5_act_bwd(dt, ws.df, f, f2, ws.df, ws.df2, M * F, kind, s));     // df (in place), df2
     RUN(omk_layernorm(dt, x1, H, ws.nbuf, H, lw.ln2_g, nullptr, M, H, c->ln_eps, 1, s));   // n2 again
     WGRAD(ws.df, F, ws.nbuf, H, lg.ffn1_w);                                   // dWi (wi / wi_0) [F,H]
@@ -407,12 +413,13 @@ int t5_train_backward(const OmEncoderConfig* c, const OmEncoderWeights* w, const
     RUN(omk_norm_bwd(dt, ws.dy, x1, lw.ln2_g, dx_other, lg.ln2_g, nullptr, M, H, c->ln_eps, 1, dx, s));   // dx1
     // ---- attention branch (dx_other now holds d/d x1)
     const char* dA = dx_other;
-    if (hd > 0.f) { RUN(omk_dropout(dt, dx_other, ws.dd, M * H, hd, site_seed(seed, l, 3), s)); dA = ws.dd; }
+    if (hd > 0.f) { RUN(omk_dropout(dt, dx_other, ws.dd, M * H, hd, site_seed(seed, l, 3), s, row_map, H)); dA = ws.dd; }
     WGRAD(dA, H, ctx, H, lg.o_w);
     e = GemmEpilogue{};
     RUN(omk_gemm(dt, dA, H, wt.o, H, dt, ws.dctx, H, M, H, H, e, s));         // dctx = dA Wo
     RUN(omk_attention_bwd_bias(dt, qkv, ws.dctx, ws.dqkv, attention_mask, d.B, (int)d.L, H, d.nh, 1.0f, ad,
-                               site_seed(seed, l, 2), ws.posbias, ws.drel, s));
+                               site_seed(seed, l, 2), ws.posbias, ws.drel, s, cu));
+    if (d.packed) RUN(omk_zero_rows_from(ws.dqkv, (int64_t)3 * H * d.es, ws.cu + d.B, M, s));      // rows the kernel does not own: zero, not stale
     RUN(omk_layernorm(dt, x, H, ws.nbuf, H, lw.ln1_g, nullptr, M, H, c->ln_eps, 1, s));    // n1 again
     WGRAD(ws.dqkv, 3 * H, ws.nbuf, H, lg.qkv_w);
     e = GemmEpilogue{};
@@ -422,8 +429,8 @@ int t5_train_backward(const OmEncoderConfig* c, const OmEncoderWeights* w, const
   }
 #undef WGRAD
   const char* de = dx;
-  if (hd > 0.f) { RUN(omk_dropout(dt, dx, ws.dd, M * H, hd, site_seed(seed, 0, 0), s)); de = ws.dd; }
-  RUN(omk_t5_embed_bwd(dt, de, input_ids, g->word_emb, M, H, c->vocab, s));
+  if (hd > 0.f) { RUN(omk_dropout(dt, dx, ws.dd, M * H, hd, site_seed(seed, 0, 0), s, row_map, H)); de = ws.dd; }
+  RUN(omk_t5_embed_bwd(dt, de, input_ids, g->word_emb, M, H, c->vocab, s, row_map));
   RUN(omk_t5_bias_bwd(ws.drel, ws.lut, g->rel_bias, (int)d.L, d.nh, s));
   RUN(record_layer_event(d.nl, s));
   g_bwd_events = nullptr; g_bwd_nevents = 0;
@@ -442,16 +449,16 @@ extern "C" size_t om_encoder_train_workspace_bytes(const OmEncoderConfig* cfg, i
 }
 // Packed rows in training (round 5): the contractions, normalisations and the tape run over `packed_rows` rows -- the tokens up to
 // each sequence's last unmasked one, back to back -- instead of B * L (the reference pads every sequence of a batch to one length,
-// dataset/data_collator.py:13-24, and computes over the padding).  16-bit BERT-family configurations with widths of 256, L <= 256,
+// dataset/data_collator.py:13-24, and computes over the padding).  16-bit BERT-family and (round 6) T5 configurations with widths of 256, L <= 256,
 // packed_rows a multiple of 256 that is >= the token count (a bound that is too small turns the representations into NaN).
 extern "C" int om_encoder_train_packed_supported(const OmEncoderConfig* c, int64_t B, int64_t L, int64_t packed_rows) {
   if (!c || B <= 0 || L <= 0 || packed_rows <= 0) return 0;
-  if (c->arch != OM_ARCH_BERT || (c->dtype != OM_BF16 && c->dtype != OM_F16) || c->n_layers <= 0) return 0;
+  if ((c->arch != OM_ARCH_BERT && c->arch != OM_ARCH_T5) || (c->dtype != OM_BF16 && c->dtype != OM_F16) || c->n_layers <= 0) return 0;      // (T5: round 6)
   if (packed_rows % 256 || packed_rows < 512 || packed_rows > B * L + 255 || packed_rows >= B * L) return 0;
   if (c->hidden % 256 || c->ffn % 256 || c->n_heads * 64 != c->hidden) return 0;
   if (c->pooling != OM_POOL_FIRST && c->pooling != OM_POOL_MEAN) return 0;
   if (!om_option(OM_OPT_ATTENTION_FAST) || L > 256) return 0;
-  if ((size_t)c->ffn < (size_t)2 * c->hidden) return 0;                 // (the f32 pooled tail borrows the [M, F] scratch)
+  if (c->arch == OM_ARCH_BERT && (size_t)c->ffn < (size_t)2 * c->hidden) return 0;      // (the f32 pooled tail borrows the [M, F] scratch)
   return 1;
 }
 extern "C" size_t om_encoder_tape_bytes_packed(const OmEncoderConfig* cfg, int64_t B, int64_t L, int64_t packed_rows) {
@@ -478,7 +485,7 @@ static int train_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* 
   if (B <= 0) return 0;
   if (((uintptr_t)tape_mem & 255) || ((uintptr_t)workspace & 255)) OM_FAIL("tape/workspace must be 256-byte aligned");
   if (packed_rows > 0 && (out_hidden || !om_encoder_train_packed_supported(c, B, L, packed_rows)))
-    OM_FAIL("packed rows in training: 16-bit BERT-family, widths of 256, L <= 256, rows a multiple of 256 in [512, B * L) (om_encoder_train_packed_supported)");
+    OM_FAIL("packed rows in training: 16-bit BERT-family or T5 encoder, widths of 256, L <= 256, rows a multiple of 256 in [512, B * L) (om_encoder_train_packed_supported)");
   const Dims d = dims_of(c, B, L, packed_rows);
   const bool packed = d.packed;
   Tape t = carve_tape(d, (char*)tape_mem);
@@ -491,13 +498,17 @@ static int train_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* 
   if (!Ls) OM_FAIL("layers_host is null");
   if (d.t5) {
     char* xf_t5 = nullptr;
+    if (packed) {      // (round 6) the row tables of the BERT branch below; a T5 block has no bias anywhere, so the rows no sequence owns stay exact zeros
+      RUN(omk_mask_extent(attention_mask, B, (int)L, ws.kmax, s));
+      RUN(omk_pack_rows(ws.kmax, B, (int)L, M, ws.cu, ws.cls_rows, ws.row_map, s));
+    }
     if (t5_train_forward(c, w, input_ids, attention_mask, d, t, ws, hidden_dropout, attn_dropout, seed, &xf_t5, s)) return 1;
     if (out_hidden) {
       OM_HIP(hipMemcpyAsync(out_hidden, xf_t5, (size_t)M * H * d.es, hipMemcpyDeviceToDevice, s));
       return 0;
     }
     const bool head_t5 = c->head_in > 0 && w->head_w;
-    RUN(omk_pool(dt, xf_t5, attention_mask, t.pooled, B, (int)L, H, c->pooling, s));
+    RUN(omk_pool(dt, xf_t5, attention_mask, t.pooled, B, (int)L, H, c->pooling, s, packed ? ws.cu : nullptr));
     float* pre_t5 = c->normalize ? t.headout : out_reps;
     if (head_t5) {
       if (om_gemm_nt(OM_F32, t.pooled, H, w->head_w, c->head_in, OM_F32, pre_t5, d.D, B, d.D, c->head_in,
@@ -506,6 +517,7 @@ static int train_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights* 
       OM_HIP(hipMemcpyAsync(pre_t5, t.pooled, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));
     }
     if (c->normalize) RUN(omk_l2norm(t.headout, out_reps, B, d.D, s));
+    if (packed) RUN(omk_pack_overflow_poison(ws.cu, B, M, out_reps, B * (int64_t)d.D, s));
     return 0;
   }
   if (L > c->max_pos) OM_FAIL("sequence longer than the position table");
@@ -719,8 +731,9 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
       // contractions map zero rows to zero rows), so they add nothing to the weight gradients that sum over all M rows
       if (d.packed) RUN(omk_zero_rows_from(ws.df, (int64_t)H * 4, ws.cu + B, M, s));
     } else {
-      if (d.packed) OM_FAIL("packed rows in training: the 16-bit pooled tail only");
-      RUN(omk_pool_bwd(dt, dpooled, attention_mask, dx, B, (int)L, H, c->pooling, s));
+      if (d.packed && !d.t5) OM_FAIL("packed rows in training: the 16-bit pooled tail only");
+      RUN(omk_pool_bwd(dt, dpooled, attention_mask, dx, B, (int)L, H, c->pooling, s, cu));
+      if (d.packed) RUN(omk_zero_rows_from(dx, (int64_t)H * d.es, ws.cu + B, M, s));      // zero gradient rows stay zero all the way down (no bias in a T5 block)
     }
   }
   if (d.t5)

@@ -45,7 +45,7 @@ int omk_attention_bwd(int dtype, const void* qkv, const void* dctx, void* dqkv, 
                       hipStream_t s, const int* cu = nullptr /* packed rows (16-bit, L <= 256): sequence b is rows cu[b] .. cu[b + 1] - 1 */);
 int omk_attention_bwd_bias(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask,
                            int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
-                           const float* pos_bias, float* drel, hipStream_t s);
+                           const float* pos_bias, float* drel, hipStream_t s, const int* cu = nullptr /* packed rows, as above (the bias table keeps the pitch L) */);
 // bf16, L <= 128, no position bias: the transposing-read kernel of attention_bwd16.hip
 bool omk_attention_bwd16_ok(int dtype, int L, int H, int heads);
 int omk_attention_bwd16(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask, int64_t B, int L, int H,
@@ -53,5 +53,6 @@ int omk_attention_bwd16(int dtype, const void* qkv, const void* dctx, void* dqkv
 // T5 feed-forward activation (kind 0 relu, 1 gated gelu_new) forward / backward, embedding and bias backward
 int omk_t5_act_fwd(int dtype, const void* f, const void* f2, void* g, int64_t n, int kind, hipStream_t s);
 int omk_t5_act_bwd(int dtype, const void* dg, const void* f, const void* f2, void* df, void* df2, int64_t n, int kind, hipStream_t s);
-int omk_t5_embed_bwd(int dtype, const void* dy, const int64_t* ids, float* dword, int64_t M, int H, int vocab, hipStream_t s);
+int omk_t5_embed_bwd(int dtype, const void* dy, const int64_t* ids, float* dword, int64_t M, int H, int vocab, hipStream_t s,
+                     const int* row_map = nullptr /* packed rows: row r carries token row_map[r] of ids (-1: a row no sequence owns) */);
 int omk_t5_bias_bwd(const float* drel, const int* lut, float* dtable, int L, int heads, hipStream_t s);

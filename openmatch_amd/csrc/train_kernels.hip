@@ -705,7 +705,7 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
     const T* __restrict__ qkv, const T* __restrict__ dctx, T* __restrict__ dqkv,
     const int64_t* __restrict__ mask, int Lm, int H, int heads, float scale, float drop_p,
     uint64_t seed, const float* __restrict__ pos_bias, float* __restrict__ drel, const int* __restrict__ cu) {
-  // cu != NULL (packed rows, no pos_bias): sequence b is rows cu[b] .. cu[b + 1] - 1, L its own row count; the mask's pitch stays Lm
+  // cu != NULL (packed rows; with pos_bias since round 6: T5 training): sequence b is rows cu[b] .. cu[b + 1] - 1, L its own row count; the mask's pitch stays Lm
   // pos_bias [heads][L][L] (T5): added to the scaled scores; drel [heads][2L-1] accumulates the
   // gradient of that bias per relative position key - query (+ L-1), summed over the batch.
   typedef AttnGeom<T> G;
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
           float v = s[t][4 * g + e] * scale + mb[e];
           if (pos_bias) {
             const int kc = (t * 32 + 8 * g + 4 * half + e) < L ? (t * 32 + 8 * g + 4 * half + e) : (L - 1);
-            v += pos_bias[((int64_t)h * L + myrow) * L + kc];
+            v += pos_bias[((int64_t)h * Lm + myrow) * Lm + kc];      // (the table's pitch: the padded length, also for packed rows)
           }
           s[t][4 * g + e] = v; mx = fmaxf(mx, v);
         }
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
         const float dlogit = s[t][r] * (dp[t][r] - delta);          // d loss / d (scaled score + bias)
         if (drel) {
           const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, q = blk0 + l31;
-          if (q < L && key < L) atomicAdd(&sRel[key - q + (L - 1)], dlogit);
+          if (q < L && key < L) atomicAdd(&sRel[key - q + (Lm - 1)], dlogit);
         }
         s[t][r] = dlogit * scale;                                     // dS
       }
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
   }
   __syncthreads();
   if (drel)
-    for (int k = tid; k < 2 * L - 1; k += nthr) atomicAdd(drel + (int64_t)h * (2 * L - 1) + k, sRel[k]);
+    for (int k = tid; k < 2 * Lm - 1; k += nthr) atomicAdd(drel + (int64_t)h * (2 * Lm - 1) + k, sRel[k]);
   if (!active) return;
 
   // ------------------------------------------------------------------ phase B
@@ -898,7 +898,7 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd_kernel(
           float p = 0.f, pd = 0.f, dpp = 0.f;
           if (q < L && kvalid) {
             float lg = sb[4 * g + e] * scale + mbk;
-            if (pos_bias) lg += pos_bias[((int64_t)h * L + q) * L + (blk0 + l31)];
+            if (pos_bias) lg += pos_bias[((int64_t)h * Lm + q) * Lm + (blk0 + l31)];
             p = G::exp_(lg - m4[e]) * i4[e];
             pd = p; dpp = dpb[4 * g + e];
             if (thresh) {
@@ -967,26 +967,27 @@ int omk_attention_bwd(int dtype, const void* qkv, const void* dctx, void* dqkv, 
     ABP(f16_t);
 #undef ABP
   }
-  return omk_attention_bwd_bias(dtype, qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, nullptr, nullptr, s);
+  return omk_attention_bwd_bias(dtype, qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, nullptr, nullptr, s, nullptr);
 }
 
 int omk_attention_bwd_bias(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask,
                            int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
-                           const float* pos_bias, float* drel, hipStream_t s) {
+                           const float* pos_bias, float* drel, hipStream_t s, const int* cu) {
   if (B <= 0) return 0;
+  if (cu && dtype != OM_BF16 && dtype != OM_F16) OM_FAIL("packed rows: attention backward for 16-bit formats");
   if (!pos_bias && omk_attention_bwd16_ok(dtype, L, H, heads))
-    return omk_attention_bwd16(dtype, qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s, nullptr);
+    return omk_attention_bwd16(dtype, qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s, cu);
   if (L < 1 || L > 256) OM_FAIL("training supports sequence lengths up to 256");
   // the three transposed [64][L + 4] images of the backward kernel must fit the 160 KiB of LDS: 256 keys in 16 bits, 192 in f32
   if (dtype == OM_F32 && L > 192) OM_FAIL("float32 training supports sequence lengths up to 192 (16-bit formats: 256)");
   if (H != heads * 64) OM_FAIL("head_dim must be 64");
 #define AB(TT)                                                                                       \
   do {                                                                                               \
-    if (L <= 32) return launch_attn_bwd<TT, 1>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s); \
-    if (L <= 64) return launch_attn_bwd<TT, 2>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s); \
-    if (L <= 128) return launch_attn_bwd<TT, 4>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s); \
-    if (L <= 192) return launch_attn_bwd<TT, 6>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s); \
-    return launch_attn_bwd<TT, 8>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s);    \
+    if (L <= 32) return launch_attn_bwd<TT, 1>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s, cu); \
+    if (L <= 64) return launch_attn_bwd<TT, 2>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s, cu); \
+    if (L <= 128) return launch_attn_bwd<TT, 4>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s, cu); \
+    if (L <= 192) return launch_attn_bwd<TT, 6>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s, cu); \
+    return launch_attn_bwd<TT, 8>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s, cu);    \
   } while (0)
   if (dtype == OM_BF16) AB(bf16_t);
   if (dtype == OM_F16) AB(f16_t);
@@ -1051,16 +1052,18 @@ int omk_t5_act_bwd(int dtype, const void* dg, const void* f, const void* f2, voi
 // T5 embedding backward: d word_emb[id] += dy[row]   (shared embedding, no norm, no positions)
 template <typename T>
 __global__ void t5_embed_bwd_kernel(const T* __restrict__ dy, const int64_t* __restrict__ ids, float* __restrict__ dword,
-                                    int64_t M, int H, int vocab) {
+                                    int64_t M, int H, int vocab, const int* __restrict__ row_map) {
   const int64_t row = blockIdx.x;
-  int64_t id = ids[row]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  int64_t tok = row;
+  if (row_map) { tok = row_map[row]; if (tok < 0) return; }
+  int64_t id = ids[tok]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
   for (int c = threadIdx.x; c < H; c += blockDim.x) atomicAdd(dword + id * H + c, ElemOps<T>::load(dy + row * H + c));
 }
-int omk_t5_embed_bwd(int dtype, const void* dy, const int64_t* ids, float* dword, int64_t M, int H, int vocab, hipStream_t s) {
+int omk_t5_embed_bwd(int dtype, const void* dy, const int64_t* ids, float* dword, int64_t M, int H, int vocab, hipStream_t s, const int* row_map) {
   if (M <= 0) return 0;
-  if (dtype == OM_BF16) hipLaunchKernelGGL(t5_embed_bwd_kernel<bf16_t>, dim3((unsigned)M), dim3(256), 0, s, (const bf16_t*)dy, ids, dword, M, H, vocab);
-  else if (dtype == OM_F16) hipLaunchKernelGGL(t5_embed_bwd_kernel<f16_t>, dim3((unsigned)M), dim3(256), 0, s, (const f16_t*)dy, ids, dword, M, H, vocab);
-  else hipLaunchKernelGGL(t5_embed_bwd_kernel<float>, dim3((unsigned)M), dim3(256), 0, s, (const float*)dy, ids, dword, M, H, vocab);
+  if (dtype == OM_BF16) hipLaunchKernelGGL(t5_embed_bwd_kernel<bf16_t>, dim3((unsigned)M), dim3(256), 0, s, (const bf16_t*)dy, ids, dword, M, H, vocab, row_map);
+  else if (dtype == OM_F16) hipLaunchKernelGGL(t5_embed_bwd_kernel<f16_t>, dim3((unsigned)M), dim3(256), 0, s, (const f16_t*)dy, ids, dword, M, H, vocab, row_map);
+  else hipLaunchKernelGGL(t5_embed_bwd_kernel<float>, dim3((unsigned)M), dim3(256), 0, s, (const float*)dy, ids, dword, M, H, vocab, row_map);
   OM_LAUNCH_CHECK();
   return 0;
 }

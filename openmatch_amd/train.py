@@ -238,7 +238,7 @@ def encode_train(model, head, items, pooling, normalize, code, training, packed_
         p_hidden = p_attn = float(cfg.dropout_rate) if training else 0.0
     seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p_hidden > 0 or p_attn > 0) else 0
     params = _bert_params(model, head) if bert else _t5_params(model, head)
-    rows = int(packed_rows) if (packed_rows and bert and os.environ.get("OM_TRAIN_PACKED", "1") != "0") else 0
+    rows = int(packed_rows) if (packed_rows and os.environ.get("OM_TRAIN_PACKED", "1") != "0") else 0      # (T5 stacks too since round 6; the library has the last word)
     reps = _EncoderTrain.apply(model, head, ids, mask, tti, pooling, normalize, code, p_hidden, p_attn, seed, rows,
                                *params)
     return None, reps

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--optimizer", default="fused", help="fused: the product's FusedAdamW (clip + AdamW + weight refresh in one pass); "
                     "torch: clip_grad_norm_ + torch.optim.AdamW(fused=True) + a re-pack of the 16-bit weights")
+    ap.add_argument("--arch", default="bert", help="bert (bert-base) | t5 (GTR-base-shaped T5 encoder stack: d_model 768, d_ff 3072, 12 layers, ReLU)")
     ap.add_argument("--wgrad-wgs", type=int, default=0, help="weight-gradient workgroups per launch / 64 (0: the kernel's default, 5)")
     a = ap.parse_args()
     from transformers import BertConfig, BertModel
@@ -27,10 +28,14 @@ def main():
         from openmatch_amd import native as N
         N.check(N.lib().om_debug_option(5, a.wgrad_wgs << 4))         # OM_OPT_WGRAD_DEBUG: bits 4.. = workgroups / 64
     torch.manual_seed(0)
-    cfg = BertConfig(hidden_dropout_prob=a.dropout, attention_probs_dropout_prob=a.dropout)
-    lm = BertModel(cfg)
-    model = DRModel(lm_q=lm, lm_p=lm, pooling="first",
-                    model_args=NS(encoder_only=False, dtype={"bf16": "bfloat16", "f16": "float16"}.get(a.precision, "float32")),
+    if a.arch == "t5":
+        from transformers import T5Config, T5EncoderModel
+        lm = T5EncoderModel(T5Config(d_model=768, d_ff=3072, num_layers=12, num_heads=12, d_kv=64, vocab_size=32128, feed_forward_proj="relu", dropout_rate=a.dropout))
+    else:
+        cfg = BertConfig(hidden_dropout_prob=a.dropout, attention_probs_dropout_prob=a.dropout)
+        lm = BertModel(cfg)
+    model = DRModel(lm_q=lm, lm_p=lm, pooling="mean" if a.arch == "t5" else "first",
+                    model_args=NS(encoder_only=a.arch == "t5", dtype={"bf16": "bfloat16", "f16": "float16"}.get(a.precision, "float32")),
                     data_args=NS(train_n_passages=8),
                     train_args=NS(negatives_x_device=False, per_device_train_batch_size=8)).to(dev)
     g = torch.Generator().manual_seed(1)
@@ -78,7 +83,7 @@ def main():
         loss = step()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
     flop = 3 * (8 * 5.474e9 + 64 * 22.347e9)
-    print(json.dumps({"metric": "contrastive train steps/s (8 q x 32 + 64 p x 128, bert-base, fwd+bwd+AdamW)", "steps_per_s": round(1 / dt, 2),
+    print(json.dumps({"metric": "contrastive train steps/s (8 q x 32 + 64 p x 128, %s, fwd+bwd+AdamW)" % ("GTR-base-shaped T5 encoder" if a.arch == "t5" else "bert-base"), "steps_per_s": round(1 / dt, 2),
                       "ms_per_step": round(dt * 1e3, 2), "precision": a.precision, "dropout": a.dropout, "wgrad_wgs": a.wgrad_wgs, "optimizer": a.optimizer,
                       "algorithmic_tflops": round(flop / dt / 1e12, 1), "loss": float(loss), "ragged": bool(a.ragged),
                       "tokens": None if tokens is None else [int(n.sum()) for n in tokens], "rows": __import__("openmatch_amd.train", fromlist=["LAST_CALL"]).LAST_CALL}))
