@@ -21,6 +21,7 @@
 // Per wave and step: 64 MFMA (2048 cycles), 32 ds_read_b128, 16 global_load_lds_dwordx4, one
 // s_waitcnt vmcnt(8) + s_barrier.  Issue order is pinned by hand as in gemm_core6.h.
 #pragma once
+#include <type_traits>
 #include "gemm_core6.h"
 
 #define G7_ROW_BYTES 128
@@ -389,7 +390,9 @@ template <> struct Mma16c<bf16_t> {
 template <> struct Mma16c<f16_t> {
   __device__ static inline void mma(const f16x8_t& a, const f16x8_t& b, f32x4_t& c) { c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
-template <typename T, bool TAIL = false, typename TailFn = G7NoTail>
+// ZERO_FIRST (the index scan, round 6): the tile starts from zero -- the 64 MFMAs of the first sub-step take the constant 0 as their C operand
+// and `acc` need not be initialised (one more copy of the step body instead of 256 accumulator writes).
+template <typename T, bool TAIL = false, typename TailFn = G7NoTail, bool ZERO_FIRST = false>
 __device__ __forceinline__ void gemm_mainloop7_cont16(const G7SrcU& src, const char* cur_a, const char* cur_b,
                                                       const char* next_a, const char* next_b, int nk, char* smem, G7Ring& ring,
                                                       f32x4_t (&acc)[8][8], unsigned long long* tr = nullptr, TailFn tail = TailFn()) {
@@ -418,9 +421,10 @@ __device__ __forceinline__ void gemm_mainloop7_cont16(const G7SrcU& src, const c
 #define G7_FENCE() __builtin_amdgcn_sched_barrier(0)
   // 64 MFMAs from (AF, BF); every fourth covers one fragment read into (BN, then AN) from (UA, UB) chunk SLOT; MFMAs 5, 13, ..
   // each cover one DMA issue of operand P (PTR, instruction q >> 3) into UNIT -- or, in the last step of a TAIL loop, tail(TBASE + (q >> 3))
-#define G7C_SUB16(AF, BF, AN, BN, UA, UB, SLOT, P, PTR, UNIT, TBASE, LASTSTEP)                           \
+#define G7C_SUB16(AF, BF, AN, BN, UA, UB, SLOT, P, PTR, UNIT, TBASE, LASTSTEP, ZERO)                     \
   _Pragma("unroll") for (int q = 0; q < 64; ++q) {                                                       \
-    Mma16c<T>::mma(BF[q & 7], AF[q >> 3], acc[q >> 3][q & 7]);                                           \
+    if (ZERO) { f32x4_t z_ = {0.f, 0.f, 0.f, 0.f}; Mma16c<T>::mma(BF[q & 7], AF[q >> 3], z_); acc[q >> 3][q & 7] = z_; } \
+    else Mma16c<T>::mma(BF[q & 7], AF[q >> 3], acc[q >> 3][q & 7]);                                      \
     if ((q & 3) == 0) {                                                                                  \
       if (q < 32) BN[q >> 2] = *(const frag_t*)(smem + (UB) + rowb + (q >> 2) * 16 * G7_ROW_BYTES + (SLOT)); \
       else AN[(q >> 2) - 8] = *(const frag_t*)(smem + (UA) + rowa + ((q >> 2) - 8) * 16 * G7_ROW_BYTES + (SLOT)); \
@@ -431,22 +435,24 @@ __device__ __forceinline__ void gemm_mainloop7_cont16(const G7SrcU& src, const c
     }                                                                                                    \
     G7_FENCE();                                                                                          \
   }
-#define G7C_STEP16(LASTSTEP)                                                                             \
+#define G7C_STEP16(LASTSTEP, ZERO)                                                                       \
   do {                                                                                                   \
     G7_STEP_STAMP();                                                                                     \
-    G7C_SUB16(a0, b0, a1, b1, u_ac, u_bc, slot[1], a, ka, u_sp, 0, LASTSTEP)                             \
-    __builtin_amdgcn_s_waitcnt(0x0078);                                     /* vmcnt(8) lgkmcnt(0) */     \
+    G7C_SUB16(a0, b0, a1, b1, u_ac, u_bc, slot[1], a, ka, u_sp, 0, LASTSTEP, ZERO)                       \
+    /* vmcnt(8) lgkmcnt(0); a tail that issues nothing (the index scan) leaves the next tile's B(0) as the youngest issues: vmcnt(0) */ \
+    if ((LASTSTEP) && std::is_same<TailFn, G7NoTail>::value) __builtin_amdgcn_s_waitcnt(0x0070); else __builtin_amdgcn_s_waitcnt(0x0078); \
     __builtin_amdgcn_s_barrier();                                                                        \
     G7_FENCE();                                                                                          \
-    G7C_SUB16(a1, b1, a0, b0, u_an, u_bn, slot[0], b, kb, u_ac, 8, LASTSTEP)                             \
+    G7C_SUB16(a1, b1, a0, b0, u_an, u_bn, slot[0], b, kb, u_ac, 8, LASTSTEP, false)                      \
     { const int o_ac = u_ac, o_bc = u_bc; u_ac = u_an; u_bc = u_bn; u_an = u_sp; u_bn = o_ac; u_sp = o_bc; } \
     if (t + 3 == nk) { ka = next_a; kb = next_b; } else { ka += G7_ROW_BYTES; kb += G7_ROW_BYTES; }      \
   } while (0)
   int t = 0;
   G7_LOOP_STAMP();
   const int nplain = TAIL ? nk - 1 : nk;
-  for (; t < nplain; ++t) G7C_STEP16(false);
-  if (TAIL) G7C_STEP16(true);
+  if (ZERO_FIRST) { G7C_STEP16(false, true); ++t; }
+  for (; t < nplain; ++t) G7C_STEP16(false, false);
+  if (TAIL) G7C_STEP16(true, false);
 #undef G7C_STEP16
 #undef G7C_SUB16
 #undef G7_FENCE

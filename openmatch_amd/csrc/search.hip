@@ -560,6 +560,164 @@ __global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7c(
   G7_WAIT_VM(0);
 }
 
+// ---- the continuous-ring scan on 16 x 16 x 32 MFMAs (round 6) -------------------------------------------------------------------
+// The K loop of the encoder's kernels 7c16 / 7r16 (gemm_core7.h gemm_mainloop7_cont16: 28.3 k cycles per K = 768 tile where the
+// 32 x 32 x 16 loop above takes ~30 k) under the same filter.  Accumulator layout: acc[ti][fj][r] = score(query q0 + wm*128 + ti*16 +
+// (lane & 15), row r0 + wn*128 + fj*16 + 4*(lane >> 4) + r): a lane holds EIGHT queries' thresholds and 32 scores per query block.
+// Ring protocol of that loop: it enters with A(1) AND all of B(1) issued (the 32 x 32 loop issues the second half of B(1) itself), so
+// all eight B(1) requests go out behind the filter; its last step issues nothing (empty tail: vmcnt(0) at the last barrier) and the
+// tile starts from zero inside the loop (ZERO_FIRST).  Same staging, same survivor records, same lists as kernel 7c.
+// Measured (profiles/r06_scan_16x16x32_ab.txt): in shader cycles the tile is LONGER (K loop 29.3 k against 26.8 k, filter 6.3 k against
+// 4.7 k: eight query blocks per lane instead of four) and the clock higher (the small MFMA shape draws less); end to end +1.4 % on one
+// box, -0.8 % on another.  A wash: the 32 x 32 x 16 kernel stays the default, this one is OM_GEMM_CONT bit 10.
+// One query block (ti: 16 queries) against the wave's 128 index rows: 32 scores per lane, 11 v_max3, one compare and one branch when
+// none reaches its query's threshold; the survivor path behind it as cold code.  (Tried: ONE branch per four blocks with the survivor
+// path re-reading the accumulators -- 7.7 k cycles per tile against 6.3 k: with 3.4 survivors per wave and tile most groups of four
+// blocks hold one, and then pay the reads and the maxima twice.)
+template <int TI0, int TI1>
+__device__ __forceinline__ void sc7c16_filter(f32x4_t (&acc)[8][8], const float (&th)[8], uint32_t id0, uint32_t ql0, int lane, const Sc7cStage& st,
+                                              unsigned& wcount, int64_t q0, u64* __restrict__ keys, unsigned* __restrict__ cnt) {
+#pragma unroll
+  for (int ti = TI0; ti < TI1; ++ti) {
+    f32x4_t a[8];
+    float bm[8];
+#pragma unroll
+    for (int fj = 0; fj < 8; ++fj) {
+      asm volatile("" : "+a"(acc[ti][fj]));            // stays in its AGPRs until this point
+      a[fj] = acc[ti][fj];
+      bm[fj] = sc7c_max3(sc7c_max3(a[fj][0], a[fj][1], a[fj][2]), a[fj][3], a[fj][3]);
+    }
+    const float mx = sc7c_max3(sc7c_max3(bm[0], bm[1], bm[2]), sc7c_max3(bm[3], bm[4], bm[5]), sc7c_max3(bm[6], bm[7], bm[7]));
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx >= th[ti]) != 0, 0)) {          // wave-uniform: some lane holds a survivor
+#pragma unroll
+      for (int fj = 0; fj < 8; ++fj) {
+        if (__builtin_amdgcn_ballot_w64(bm[fj] >= th[ti]) == 0) continue;
+        if (wcount > SC7C_CAP - 256) { sc7c_flush(st, 0u, wcount, lane, q0, keys, cnt); wcount = 0; }      // a block adds at most 256
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool pass = a[fj][r] >= th[ti];
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+          if (m != 0) {
+            if (pass) {
+              const unsigned pos = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+              *(u64*)sc7c_key_slot(st, pos) = pack_key(a[fj][r], id0 + (uint32_t)(fj * 16 + r));
+              *sc7c_q_slot(st, pos) = (uint16_t)(ql0 + ti * 16);
+            }
+            wcount += (unsigned)__builtin_popcountll(m);
+          }
+        }
+      }
+    }
+    G7_FENCE_();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(G6_THREADS) void sim_filter_kernel7c16(
+    const T* __restrict__ rows, int64_t nrows, uint32_t row_base, const T* __restrict__ queries,
+    int64_t nq, int64_t d, const float* __restrict__ thr, u64* __restrict__ keys,
+    unsigned* __restrict__ cnt, int group_m, unsigned long long* __restrict__ trace) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane0 = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t ntr = (nrows + 255) / 256, ntq = (nq + 255) / 256;
+  const int nk = (int)((d * 2) / G7_ROW_BYTES);
+  unsigned wcount = 0;                     // records in this wave's staging area (wave-uniform)
+  unsigned pend_n = 0;                     // records of the previous tile held in registers, one per lane (wave-uniform)
+  u64 pend_key = 0; uint32_t pend_q = 0;
+  int64_t r0, q0;
+  const int qgroup = group_m >> 8;
+  group_m &= 255;
+  Sc7Walk walk;
+  if (!walk.init(ntr, ntq, group_m, qgroup, r0, q0)) return;
+  G7SrcU src;
+  g7_offsets_u<T>(src, d, d, wave, lane0);         // every row of every tile exists (padded query panel, whole row tiles)
+  G7Ring ring;
+  g7_ring_reset(ring);
+  const uint32_t lds_base = g7_lds_addr(smem);
+  const char* cur_a = (const char*)(queries + q0 * d);
+  const char* cur_b = (const char*)(rows + r0 * d);
+  g7_dma((const char*)(thr + q0 + wm * 128), lane0 * 16, lds_base + ring.sp + (7 * 4 + wave) * 1024);
+  g7_fill_a(src, cur_a, smem + ring.ac, wave);
+  g7_fill_b(src, cur_b, smem + ring.bc, wave);
+  g7_fill_a(src, cur_a + G7_ROW_BYTES, smem + ring.an, wave);
+  g7_fill_b(src, cur_b + G7_ROW_BYTES, smem + ring.bn, wave);
+  G7_WAIT_VM(16);                                  // the thresholds and K step 0 (A(1), B(1) may be outstanding)
+  __builtin_amdgcn_s_barrier();                    // first pair only: K step 0 published
+  int64_t r1 = r0, q1 = q0;
+  bool has_next = walk.next(r1, q1);
+  for (;;) {
+    unsigned long long* tr = nullptr;
+    if (trace) {
+      const int64_t tile_id = (r0 / 256) * ntq + q0 / 256;
+      if (tile_id < 8192) tr = trace + tile_id * 32;
+    }
+    if (tr && threadIdx.x == 0) { tr[0] = tr[1] = clock64(); tr[30] = wall_clock64(); }
+    float th[8];
+    f32x4_t acc[8][8];           // (starts from zero inside the K loop: ZERO_FIRST -- no initialising pass)
+    {
+      int lane_i = lane0;
+      asm volatile("" : "+v"(lane_i));
+      const char* const tab = smem + ring.sp + (7 * 4 + wave) * 1024;      // this pair's thresholds (fetched under the previous filter)
+#pragma unroll
+      for (int ti = 0; ti < 8; ++ti) th[ti] = *(const float*)(tab + (ti * 16 + (lane_i & 15)) * 4);
+    }
+    const char* const next_a = (const char*)(queries + q1 * d);      // (no next pair: this one again -- a harmless prefetch)
+    const char* const next_b = (const char*)(rows + r1 * d);
+    gemm_mainloop7_cont16<T, true, G7NoTail, true>(src, cur_a, cur_b, next_a, next_b, nk, smem, ring, acc, tr);
+    if (tr && threadIdx.x == 0) tr[15] = clock64();
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const Sc7cStage st = {smem + ring.bn + wave * 1024, smem + ring.sp + wave * 1024};
+    // the previous tile's records: list positions requested now, consumed half a filter later
+    unsigned pend_pos = 0;
+    if (pend_n && (unsigned)lane < pend_n) pend_pos = atomicAdd(cnt + pend_q, 1u);
+    // under the filter: A(1) of the next pair (into the unit the filter does not use) and its thresholds
+    g7_fill_a(src, next_a + G7_ROW_BYTES, smem + ring.an, wave);
+    g7_dma((const char*)(thr + q1 + wm * 128), lane0 * 16, g7_lds_addr(st.sp) + 7 * 4096);
+    G7_FENCE_();
+    if (tr && threadIdx.x == 0) tr[16] = clock64();
+    {
+      const uint32_t id0 = row_base + (uint32_t)r0 + (uint32_t)(wn * 128 + 4 * (lane >> 4));    // row id of (fj = 0, r = 0)
+      const uint32_t ql0 = (uint32_t)(wm * 128 + (lane & 15));
+      sc7c16_filter<0, 4>(acc, th, id0, ql0, lane, st, wcount, q0, keys, cnt);
+      if (pend_n) {
+        if ((unsigned)lane < pend_n && pend_pos < SORT_CAP) keys[(int64_t)pend_q * SORT_CAP + pend_pos] = pend_key;
+        pend_n = 0;
+      }
+      G7_FENCE_();
+      if (tr && threadIdx.x == 0) tr[17] = clock64();
+      sc7c16_filter<4, 8>(acc, th, id0, ql0, lane, st, wcount, q0, keys, cnt);
+      if (tr && threadIdx.x == 0) { tr[18] = clock64(); tr[20] = wcount; }
+      if (wcount > 64) sc7c_flush(st, 64u, wcount, lane, q0, keys, cnt);
+      pend_n = wcount < 64u ? wcount : 64u;
+      if ((unsigned)lane < pend_n) {
+        pend_key = *(const u64*)sc7c_key_slot(st, (unsigned)lane);
+        pend_q = (uint32_t)q0 + *sc7c_q_slot(st, (unsigned)lane);
+      }
+      wcount = 0;
+    }
+    // A(1) and the thresholds were fetched a whole filter ago; everything issued since (the key stores of the pending records, half a
+    // filter old; a synchronous flush, rare) is older than any DMA of the next K loop.  The staging area has been read (lgkmcnt): B(1)
+    // may overwrite it -- all eight requests (the 16 x 16 x 32 loop enters with the whole unit issued).
+    if (tr && threadIdx.x == 0) tr[19] = clock64();
+    G7_WAIT_VM(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (tr && threadIdx.x == 0) tr[21] = clock64();
+    g7_fill_b(src, next_b + G7_ROW_BYTES, smem + ring.bn, wave);
+    if (tr && threadIdx.x == 0) { tr[28] = clock64(); tr[29] = blockIdx.x; tr[31] = wall_clock64(); }
+    if (!has_next) break;
+    cur_a = next_a; cur_b = next_b; r0 = r1; q0 = q1;
+    has_next = walk.next(r1, q1);
+  }
+  if (pend_n && (unsigned)lane0 < pend_n) {
+    const unsigned pos = atomicAdd(cnt + pend_q, 1u);
+    if (pos < SORT_CAP) keys[(int64_t)pend_q * SORT_CAP + pos] = pend_key;
+  }
+  G7_WAIT_VM(0);
+}
+
 // Small query batches (<= 128 queries): the scan is a pass over the whole f16 index (13.6 GB at 8.8 M x 768) that has to
 // run at HBM speed.  The generic 128-query tile spends 1.7 PFLOP of matrix-core time on padding at Q = 1 (3.99 ms per
 // search in round 1, profiles/r01_search_shapes.jsonl).  Round 2 kept one or two 32-query blocks resident in LDS beside a
@@ -1221,7 +1379,10 @@ struct Scan {
           int ncu = g7_num_cus();
           const int64_t tiles = (whole / 256) * ntn;
           if (tiles < ncu) ncu = (int)tiles;
-          if ((d * 2) / G7_ROW_BYTES >= 3 && (om_option(OM_OPT_GEMM_CONT) & 4))      // bit 2: the scan on the continuous ring
+          if ((d * 2) / G7_ROW_BYTES >= 3 && (om_option(OM_OPT_GEMM_CONT) & 4) && (om_option(OM_OPT_GEMM_CONT) & 1024))      // bit 10 (round 6): ... on 16 x 16 x 32 MFMAs
+            hipLaunchKernelGGL((sim_filter_kernel7c16<f16_t>), dim3((unsigned)ncu), dim3(G6_THREADS), G7_LDS_BYTES, s, idx16 + r0 * d, whole,
+                               (uint32_t)r0, ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8 | (std::max(1, om_option(OM_OPT_SCAN_QGROUP)) << 8), omk_debug_trace());
+          else if ((d * 2) / G7_ROW_BYTES >= 3 && (om_option(OM_OPT_GEMM_CONT) & 4))      // bit 2: the scan on the continuous ring
             hipLaunchKernelGGL((sim_filter_kernel7c<f16_t>), dim3((unsigned)ncu), dim3(G6_THREADS), G7_LDS_BYTES, s, idx16 + r0 * d, whole,
                                (uint32_t)r0, ws.qb, nq, (int64_t)d, ws.thr, ws.keys, ws.cnt, 8 | (std::max(1, om_option(OM_OPT_SCAN_QGROUP)) << 8), omk_debug_trace());
           else
@@ -1441,6 +1602,8 @@ extern "C" int om_sim_topk(int mode, const float* queries, int64_t n_queries,
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel7<f16_t>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
     OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel7c<f16_t>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
+    OM_HIP(hipFuncSetAttribute((const void*)sim_filter_kernel7c16<f16_t>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS_BYTES));
     OM_HIP(hipFuncSetAttribute((const void*)select_radix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                SORT_CAP * 8 + 1024 + 64));

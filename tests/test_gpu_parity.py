@@ -2302,6 +2302,28 @@ def test_few_rows_forward_tracks_f32_path_and_is_batch_invariant(dtype, arch):
         assert few_sum < tile_sum, (few_sum, tile_sum)
 
 
+def test_index_scan_on_16x16x32_mfmas_returns_the_lists_of_the_default_kernel():
+    """OM_GEMM_CONT bit 10 (round 6, opt-in: a wash end to end, profiles/r06_scan_16x16x32_ab.txt): the wide-batch scan on the encoder's
+    16 x 16 x 32 K loop.  Same scores, same ids as the default 32 x 32 x 16 kernel, k-way ties included, on a ragged row count."""
+    from openmatch_amd import native as N_
+    from openmatch_amd.index import FlatIPIndex
+    g = torch.Generator().manual_seed(9)
+    N, nq, d, k = 70000 + 131, 300, 768, 200
+    rows = torch.randn(N, d, generator=g)
+    rows[1000:1040] = rows[999]                      # a 41-way exact tie
+    q = torch.randn(nq, d, generator=g)
+    q[7] = rows[999] * 3.0                           # ... that one query ranks first
+    idx = FlatIPIndex(d, device=DEV)
+    idx.add(rows.numpy())
+    D0, I0 = idx.search(q.numpy(), k)
+    N_.check(N_.lib().om_debug_option(16, 495 | 1024))
+    try:
+        D1, I1 = idx.search(q.numpy(), k)
+    finally:
+        N_.check(N_.lib().om_debug_option(16, 495))
+    assert np.array_equal(I0, I1) and np.array_equal(D0, D1)
+
+
 def test_layernorm_row_reduction_without_the_lds_crossbar_equals_the_shuffle_butterfly():
     """ln_row.h sums a row over the 64 lanes with v_permlane32/16_swap, DPP row rotation, ds_swizzle and DPP quad permutations in the
     pairing of the __shfl_xor butterfly (common.h wave_sum): the same bits, on values of mixed sign and magnitude, in every lane."""
