@@ -83,7 +83,8 @@ void om_debug_gemm_gen(int gen);
  * shapes allow (default), 0 = one normalisation kernel per site; OM_OPT_ENCODER_DEBUG 1 = log the path taken. */
 #define OM_OPT_ENCODER_FUSED_LN 0
 #define OM_OPT_ENCODER_DEBUG 1
-#define OM_OPT_ATTENTION_FAST 2   /* 1 (default): bf16 inference attention on the low-instruction-count kernel; 0: the generic kernel */
+#define OM_OPT_ATTENTION_FAST 2   /* 1 (default): bf16 inference attention on the low-instruction-count kernel; 0: the generic kernel; bit 1 (tests): the
+                                     tile-at-a-time kernels that serve more than 256 tokens (forward with dropout, backward) at every length */
 #define OM_OPT_SCAN_GEN7 3        /* 1 (default): f16 index scan of wide query batches on the persistent generation-7 kernel; 0: generation 6 */
 #define OM_OPT_SCAN_GROWTH 4      /* fast schedule of the index scan: rows scanned per round grow by this many percent of the rows already
                                     * scanned (default 60; smaller = more rounds, tighter thresholds, fewer appends per tile) */
@@ -386,7 +387,9 @@ size_t om_encoder_tape_bytes(const OmEncoderConfig* cfg, int64_t B, int64_t L);
 size_t om_encoder_train_workspace_bytes(const OmEncoderConfig* cfg, int64_t B, int64_t L);
 
 /* hidden_dropout / attn_dropout: HF config hidden_dropout_prob / attention_probs_dropout_prob
- * (0 disables).  out_reps: f32 [B,D] as om_encoder_forward. */
+ * (0 disables).  out_reps: f32 [B,D] as om_encoder_forward.  Sequence length: up to 512 tokens in the 16-bit formats (round 6: above 256 the
+ * attention runs on kernels that keep one score tile in registers; the reference trains at whatever length its collator pads to,
+ * dataset/data_collator.py:13-24), up to 192 in float32. */
 int om_encoder_train_forward(const OmEncoderConfig* cfg, const OmEncoderWeights* w,
                              const int64_t* input_ids, const int64_t* attention_mask,
                              const int64_t* token_type_ids, int64_t B, int64_t L,

@@ -444,7 +444,9 @@ static int launch_attn16(const void* qkv, void* ctx, const int64_t* mask, const 
 template <typename T>
 __global__ __launch_bounds__(256) void attention_long_kernel(
     const T* __restrict__ qkv, T* __restrict__ ctx, const int64_t* __restrict__ mask,
-    const float* __restrict__ pos_bias, int L, int H, int heads, float scale) {
+    const float* __restrict__ pos_bias, int L, int H, int heads, float scale, float drop_p, uint64_t seed) {
+  // drop_p > 0 (round 6: training beyond 256 tokens): the probabilities that meet V are masked with the (sequence, head, query, key)
+  // hash the backward regenerates (attn_common.h); the normaliser is the sum of the unmasked ones, as in the other kernels
   typedef AttnGeom<T> G;
   typedef typename MmaOps<T>::frag_t frag_t;
   constexpr int LP = 128 + 4;
@@ -467,6 +469,9 @@ __global__ __launch_bounds__(256) void attention_long_kernel(
 #pragma unroll
   for (int kk = 0; kk < G::NKK; ++kk) qf[kk] = *(const frag_t*)(base + (int64_t)qrow * ld + (kk * 2 + half) * G::EPC);
 
+  const AttnDrop dr_(drop_p);
+  const uint32_t thresh = dr_.thresh;
+  const float keep_scale = dr_.keep_scale;
   float m_run = -INFINITY, l_run = 0.f;
   f32x16_t o[2];
 #pragma unroll
@@ -533,8 +538,8 @@ __global__ __launch_bounds__(256) void attention_long_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float e = G::exp_(s[t][r] - mx);
-        s[t][r] = e;
         sum += e;
+        s[t][r] = (thresh && !attn_drop_keep1(seed, b, h, heads, L, q0 + l31, kc + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, thresh)) ? 0.f : (thresh ? e * keep_scale : e);
       }
     sum += __shfl_xor(sum, 32, 64);
     l_run = l_run * alpha + sum;
@@ -581,7 +586,7 @@ __global__ __launch_bounds__(256) void attention_long_kernel(
 
 template <typename T>
 static int launch_attn_long(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias, int64_t B, int L, int H,
-                            int heads, float scale, hipStream_t s) {
+                            int heads, float scale, hipStream_t s, float drop_p = 0.f, uint64_t seed = 0) {
   const int lds = 128 * AttnGeom<T>::ROWB + 64 * 132 * (int)sizeof(T) + 128 * 4 + 128 * 4;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
@@ -589,7 +594,7 @@ static int launch_attn_long(const void* qkv, void* ctx, const int64_t* mask, con
     attr_set = true;
   }
   hipLaunchKernelGGL((attention_long_kernel<T>), dim3((unsigned)(heads * B), (unsigned)((L + 127) / 128)), dim3(256), lds, s,
-                     (const T*)qkv, (T*)ctx, mask, pos_bias, L, H, heads, scale);
+                     (const T*)qkv, (T*)ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed);
   OM_LAUNCH_CHECK();
   return 0;
 }
@@ -691,13 +696,14 @@ int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
   if (cu && !((dtype == OM_F16 || (dtype == OM_BF16 && om_option(OM_OPT_ATTENTION_FAST))) && L <= 256))
     OM_FAIL("packed rows: the 16-bit attention kernels, L <= 256");      // (with dropout too: the packed training forward, round 5)
   if (L < 1 || L > 1024) OM_FAIL("sequence length must be in [1,1024]");
-  if (L > 256 && drop_p > 0.f) OM_FAIL("training supports sequence lengths up to 256");
+  if (L > 256 && drop_p > 0.f && (L > 512 || dtype == OM_F32)) OM_FAIL("attention with dropout: up to 512 tokens in the 16-bit formats (float32: 256)");
   if (H != heads * 64) OM_FAIL("head_dim must be 64");
   if (B * heads > 0x7fffffffLL) OM_FAIL("batch too large for one launch");
+  // OM_OPT_ATTENTION_FAST bit 1 (tests): the tile-at-a-time kernels of L > 256 at every length (their masks and results must agree with the others')
+  const bool force_long = (om_option(OM_OPT_ATTENTION_FAST) & 2) != 0 && !cu && dtype != OM_F32;
   if (dtype == OM_F16) {                                      // float16 inference mode: the fast kernel only
-    if (L > 256) {
-      if (drop_p > 0.f) OM_FAIL("float16 attention beyond 256 tokens: inference only");
-      return launch_attn_long<f16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
+    if (L > 256 || force_long) {
+      return launch_attn_long<f16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s, drop_p, seed);      // (with dropout: training up to 512 tokens, round 6)
     }
     if (L <= 32) return launch_attn16<f16_t, 1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
     if (L <= 64) return launch_attn16<f16_t, 2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
@@ -705,8 +711,8 @@ int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
     if (L <= 192) return launch_attn16<f16_t, 6>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
     return launch_attn16<f16_t, 8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
   }
-  if (L > 256) {                                              // online-softmax kernel, any dtype
-    if (dtype == OM_BF16) return launch_attn_long<bf16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
+  if (L > 256 || force_long) {                                // online-softmax kernel, any dtype
+    if (dtype == OM_BF16) return launch_attn_long<bf16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s, drop_p, seed);
     return launch_attn_long<float>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
   }
   if (dtype == OM_BF16 && om_option(OM_OPT_ATTENTION_FAST)) {        // the low-instruction-count kernel (inference, and training with dropout)

@@ -185,8 +185,8 @@ int check_train_cfg(const OmEncoderConfig* c, int64_t L) {
   // activations leave the float16 range overflows there and here alike, the loss scaler skips such steps)
   if (c->dtype == OM_F16 && c->arch != OM_ARCH_BERT && c->arch != OM_ARCH_T5) OM_FAIL("float16 training: BERT-family and T5 encoders");
   if (c->head_dim != 64 || c->n_heads * 64 != c->hidden) OM_FAIL("head_dim must be 64");
-  if (L < 1 || L > 256) OM_FAIL("training supports sequence lengths up to 256");
-  if (c->dtype == OM_F32 && L > 192) OM_FAIL("float32 training supports sequence lengths up to 192 (16-bit formats: 256)");
+  if (L < 1 || L > 512) OM_FAIL("training supports sequence lengths up to 512");      // (257 .. 512: round 6, the tile-at-a-time attention kernels)
+  if (c->dtype == OM_F32 && L > 192) OM_FAIL("float32 training supports sequence lengths up to 192 (16-bit formats: 512)");
   if (c->arch == OM_ARCH_BERT && c->act != OM_ACT_GELU_ERF) OM_FAIL("BERT training supports the erf-GELU FFN");
   if (c->arch == OM_ARCH_T5 && (c->act & 0xff) != OM_ACT_RELU && (c->act & 0xff) != OM_ACT_GELU_TANH)
     OM_FAIL("T5 training supports relu and gated gelu_new feed-forward layers");
@@ -417,6 +417,10 @@ int t5_train_backward(const OmEncoderConfig* c, const OmEncoderWeights* w, const
     WGRAD(dA, H, ctx, H, lg.o_w);
     e = GemmEpilogue{};
     RUN(omk_gemm(dt, dA, H, wt.o, H, dt, ws.dctx, H, M, H, H, e, s));         // dctx = dA Wo
+    if (d.L > 256 || (!d.packed && dt != OM_F32 && (om_option(OM_OPT_ATTENTION_FAST) & 2)))      // (round 6) beyond 256 tokens: one score tile in registers at a time, delta from the tape's attention output
+      RUN(omk_attention_bwd_long(dt, qkv, ctx, ws.dctx, ws.dqkv, attention_mask, d.B, (int)d.L, H, d.nh, 1.0f, ad,
+                                 site_seed(seed, l, 2), ws.posbias, ws.drel, s));
+    else
     RUN(omk_attention_bwd_bias(dt, qkv, ws.dctx, ws.dqkv, attention_mask, d.B, (int)d.L, H, d.nh, 1.0f, ad,
                                site_seed(seed, l, 2), ws.posbias, ws.drel, s, cu));
     if (d.packed) RUN(omk_zero_rows_from(ws.dqkv, (int64_t)3 * H * d.es, ws.cu + d.B, M, s));      // rows the kernel does not own: zero, not stale
@@ -849,6 +853,10 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
       RUN(omk_gemm(dt, dA, H, wt.o, H, dt, ws.dctx, H, M, H, H, e3, s));    // dctx = dA Wo
     }
     WGRAD_DONE(l + 1, 3);                                           // ws.dqkv: last read by dWqkv of the layer above
+    if (L > 256 || (!d.packed && dt != OM_F32 && (om_option(OM_OPT_ATTENTION_FAST) & 2)))      // (round 6) beyond 256 tokens: one score tile in registers at a time, delta from the tape's attention output
+      RUN(omk_attention_bwd_long(dt, qkv, ctx, ws.dctx, dqkvl, attention_mask, B, (int)L, H, d.nh, scale,
+                                 attn_dropout, site_seed(seed, l, 2), nullptr, nullptr, s));
+    else
     RUN(omk_attention_bwd(dt, qkv, ws.dctx, dqkvl, attention_mask, B, (int)L, H, d.nh, scale,
                           attn_dropout, site_seed(seed, l, 2), s, cu));
     if (d.packed) RUN(omk_zero_rows_from(dqkvl, (int64_t)3 * H * d.es, ws.cu + B, M, s));      // rows the kernel does not own: zero, not stale

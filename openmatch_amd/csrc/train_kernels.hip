@@ -946,6 +946,277 @@ static int launch_attn_bwd(const void* qkv, const void* dctx, void* dqkv, const 
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// Attention backward beyond 256 tokens (round 6: training up to 512), 16-bit formats.  The kernel above keeps a whole row of scores per
+// lane in registers (s[KT], dp[KT]: 32 registers per key tile) and three transposed images in LDS; at 512 tokens neither fits.  Here:
+//  * phase A runs over the key tiles TWICE with one tile in registers -- an online softmax for the row statistics, then the
+//    gradients -- and takes delta = rowsum(P o dP) as dO . O from the forward's output (the identity every flash-attention backward
+//    uses; O is on the tape);
+//  * the LDS holds TWO images at a time: K^T under phase A, then Q^T and dO^T under phase B (which was a loop over query tiles already);
+//  * four waves (one per SIMD: the whole register file), each owning the 32-row blocks w, w + 4, ... of either phase.
+// Same masks (attn_common.h hash on (sequence, head, query, key)), same bias and bias-gradient handling as the kernel above.
+template <typename T>
+__global__ __launch_bounds__(256) void attention_bwd_long_kernel(
+    const T* __restrict__ qkv, const T* __restrict__ ctx, const T* __restrict__ dctx, T* __restrict__ dqkv,
+    const int64_t* __restrict__ mask, int L, int H, int heads, float scale, float drop_p,
+    uint64_t seed, const float* __restrict__ pos_bias, float* __restrict__ drel) {
+  typedef AttnGeom<T> G;
+  typedef typename MmaOps<T>::frag_t frag_t;
+  constexpr int LMAX = 512, LP = LMAX + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* img0 = (T*)smem;                          // K^T (phase A), Q^T (phase B): [64][LP]
+  T* img1 = img0 + 64 * LP;                    // dO^T (phase B)
+  float* sM = (float*)(img1 + 64 * LP);        // additive key mask
+  float* sMax = sM + LMAX;                     // per query: row max, 1/row sum, delta
+  float* sInv = sMax + LMAX;
+  float* sDelta = sInv + LMAX;
+  float* sRel = sDelta + LMAX;                 // [2 * LMAX] bias gradient per relative position
+
+  const int h = blockIdx.x % heads;
+  const int64_t b = blockIdx.x / heads;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int KT = (L + 31) / 32;
+  const int64_t ld = 3 * (int64_t)H;
+  const T* base = qkv + b * L * ld + h * 64;
+  const T* dob = dctx + b * L * H + h * 64;
+  const T* ob = ctx + b * L * H + h * 64;
+  T* dbase = dqkv + b * L * ld + h * 64;
+  const AttnDrop dr_(drop_p);
+  const uint32_t thresh = dr_.thresh;
+  const float keep_scale = dr_.keep_scale;
+
+  // K^T
+  for (int idx = tid; idx < KT * 32 * G::CPR; idx += nthr) {
+    const int row = idx / G::CPR, c = idx % G::CPR;
+    uint4 kv = make_uint4(0, 0, 0, 0);
+    if (row < L) kv = *(const uint4*)(base + (int64_t)row * ld + H + c * G::EPC);
+    const T* ke = (const T*)&kv;
+#pragma unroll
+    for (int e = 0; e < G::EPC; ++e) img0[(c * G::EPC + e) * LP + row] = ke[e];
+  }
+  for (int k = tid; k < KT * 32; k += nthr)
+    sM[k] = k < L ? (mask[b * L + k] != 0 ? 0.f : -3.4028235e38f) : -INFINITY;
+  if (drel)
+    for (int k = tid; k < 2 * LMAX; k += nthr) sRel[k] = 0.f;
+  __syncthreads();
+
+  const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+
+  // ------------------------------------------------------------------ phase A: query blocks wave, wave + 4, ...
+  for (int blk0 = wave * 32; blk0 < L; blk0 += 128) {
+    const int myrow = (blk0 + l31) < L ? (blk0 + l31) : (L - 1);
+    frag_t qf[G::NKK], dof[G::NKK];
+    float delta = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < G::NKK; ++kk) {
+      qf[kk] = *(const frag_t*)(base + (int64_t)myrow * ld + (kk * 2 + half) * G::EPC);
+      dof[kk] = *(const frag_t*)(dob + (int64_t)myrow * H + (kk * 2 + half) * G::EPC);
+      const uint4 dw = *(const uint4*)(dob + (int64_t)myrow * H + (kk * 2 + half) * G::EPC);
+      const uint4 ow = *(const uint4*)(ob + (int64_t)myrow * H + (kk * 2 + half) * G::EPC);
+      const uint32_t dws[4] = {dw.x, dw.y, dw.z, dw.w}, ows[4] = {ow.x, ow.y, ow.z, ow.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) delta += Half16<T>::lo(dws[e]) * Half16<T>::lo(ows[e]) + Half16<T>::hi(dws[e]) * Half16<T>::hi(ows[e]);
+    }
+    delta += __shfl_xor(delta, 32, 64);          // dO . O over the 64 features of the head: = rowsum(P o dP)
+    // one key tile of scaled, masked, biased scores for this lane's query: registers <-> keys t*32 + (r&3) + 8(r>>2) + 4 half
+#define OM_ABL_SCORES(T_, S_)                                                                            \
+    do {                                                                                                 \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) S_[r] = 0.f;                                        \
+      const int krow_ = ((T_) * 32 + l31) < L ? ((T_) * 32 + l31) : (L - 1);                             \
+      const T* kp_ = base + (int64_t)krow_ * ld + H;                                                     \
+      _Pragma("unroll") for (int kk = 0; kk < G::NKK; ++kk) {                                            \
+        const frag_t ka_ = *(const frag_t*)(kp_ + (kk * 2 + half) * G::EPC);                             \
+        MmaOps<T>::mma(ka_, qf[kk], S_);                                                                 \
+      }                                                                                                  \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                    \
+        const f32x4_t mb_ = *(const f32x4_t*)(sM + (T_) * 32 + 8 * g + 4 * half);                        \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                  \
+          float v_ = S_[4 * g + e] * scale + mb_[e];                                                     \
+          if (pos_bias) {                                                                                \
+            const int kc_ = ((T_) * 32 + 8 * g + 4 * half + e) < L ? ((T_) * 32 + 8 * g + 4 * half + e) : (L - 1); \
+            v_ += pos_bias[((int64_t)h * L + myrow) * L + kc_];                                          \
+          }                                                                                              \
+          S_[4 * g + e] = v_;                                                                            \
+        }                                                                                                \
+      }                                                                                                  \
+    } while (0)
+    // pass 1: the row's maximum and normaliser, online over the key tiles
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int t = 0; t < KT; ++t) {
+      f32x16_t sc;
+      OM_ABL_SCORES(t, sc);
+      float mx = m_run;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));      // (tile 0 holds key 0: unmasked or finfo.min, finite -- mx is finite from here on)
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += G::exp_(sc[r] - mx);
+      sum += __shfl_xor(sum, 32, 64);
+      l_run = l_run * G::exp_(m_run - mx) + sum;
+      m_run = mx;
+    }
+    const float inv = 1.0f / l_run;
+    // pass 2: P, dP, dS tile by tile; dQ accumulates
+    f32x16_t o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    for (int t = 0; t < KT; ++t) {
+      f32x16_t sc, dp;
+      OM_ABL_SCORES(t, sc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+      {
+        const int krow = (t * 32 + l31) < L ? (t * 32 + l31) : (L - 1);
+        const T* vp = base + (int64_t)krow * ld + 2 * H;
+#pragma unroll
+        for (int kk = 0; kk < G::NKK; ++kk) {
+          const frag_t va = *(const frag_t*)(vp + (kk * 2 + half) * G::EPC);
+          MmaOps<T>::mma(va, dof[kk], dp);       // dPd^T[key][query]
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float pr = G::exp_(sc[r] - m_run) * inv;
+        float dpp = dp[r];
+        if (thresh) dpp = attn_drop_keep1(seed, b, h, heads, L, blk0 + l31, key, thresh) ? dpp * keep_scale : 0.f;
+        const float dlogit = pr * (dpp - delta);                      // d loss / d (scaled score + bias)
+        if (drel && (blk0 + l31) < L && key < L) atomicAdd(&sRel[key - (blk0 + l31) + (L - 1)], dlogit);
+        sc[r] = dlogit * scale;                                        // dS
+      }
+      SlabMma<T>::run(sc, img0 + l31 * LP + t * 32 + 4 * half, LP, o);   // dQ += dS K
+    }
+#undef OM_ABL_SCORES
+    if (half == 0 && blk0 + l31 < L) { sMax[blk0 + l31] = m_run; sInv[blk0 + l31] = inv; sDelta[blk0 + l31] = delta; }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = blk0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (q < L) ElemOps<T>::store(dbase + (int64_t)q * ld + dt * 32 + l31, o[dt][r]);
+      }
+  }
+  __syncthreads();                                 // K^T has been consumed, the statistics are published
+  if (drel)
+    for (int k = tid; k < 2 * L - 1; k += nthr) atomicAdd(drel + (int64_t)h * (2 * L - 1) + k, sRel[k]);
+  // Q^T and dO^T
+  for (int idx = tid; idx < KT * 32 * G::CPR; idx += nthr) {
+    const int row = idx / G::CPR, c = idx % G::CPR;
+    uint4 qv = make_uint4(0, 0, 0, 0), dv = qv;
+    if (row < L) {
+      qv = *(const uint4*)(base + (int64_t)row * ld + c * G::EPC);
+      dv = *(const uint4*)(dob + (int64_t)row * H + c * G::EPC);
+    }
+    const T* qe = (const T*)&qv; const T* de = (const T*)&dv;
+#pragma unroll
+    for (int e = 0; e < G::EPC; ++e) {
+      img0[(c * G::EPC + e) * LP + row] = qe[e];
+      img1[(c * G::EPC + e) * LP + row] = de[e];
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ phase B: key blocks wave, wave + 4, ...
+  for (int blk0 = wave * 32; blk0 < L; blk0 += 128) {
+    const int myrow = (blk0 + l31) < L ? (blk0 + l31) : (L - 1);
+    const bool kvalid = (blk0 + l31) < L;
+    const float mbk = sM[blk0 + l31];
+    frag_t kf[G::NKK], vf[G::NKK];
+#pragma unroll
+    for (int kk = 0; kk < G::NKK; ++kk) {
+      kf[kk] = *(const frag_t*)(base + (int64_t)myrow * ld + H + (kk * 2 + half) * G::EPC);
+      vf[kk] = *(const frag_t*)(base + (int64_t)myrow * ld + 2 * H + (kk * 2 + half) * G::EPC);
+    }
+    f32x16_t dv[2], dk[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dv[dt][r] = 0.f; dk[dt][r] = 0.f; }
+    for (int tq = 0; tq < KT; ++tq) {
+      const int qr = (tq * 32 + l31) < L ? (tq * 32 + l31) : (L - 1);
+      f32x16_t sb, dpb;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sb[r] = 0.f; dpb[r] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < G::NKK; ++kk) {
+        const frag_t qa = *(const frag_t*)(base + (int64_t)qr * ld + (kk * 2 + half) * G::EPC);
+        const frag_t da = *(const frag_t*)(dob + (int64_t)qr * H + (kk * 2 + half) * G::EPC);
+        MmaOps<T>::mma(qa, kf[kk], sb);        // S[query][key]
+        MmaOps<T>::mma(da, vf[kk], dpb);       // dPd[query][key]
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int q4 = tq * 32 + 8 * g + 4 * half;
+        const f32x4_t m4 = *(const f32x4_t*)(sMax + q4);
+        const f32x4_t i4 = *(const f32x4_t*)(sInv + q4);
+        const f32x4_t d4 = *(const f32x4_t*)(sDelta + q4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int q = q4 + e;
+          float pr = 0.f, pd = 0.f, dpp = 0.f;
+          if (q < L && kvalid) {
+            float lg = sb[4 * g + e] * scale + mbk;
+            if (pos_bias) lg += pos_bias[((int64_t)h * L + q) * L + (blk0 + l31)];
+            pr = G::exp_(lg - m4[e]) * i4[e];
+            pd = pr; dpp = dpb[4 * g + e];
+            if (thresh) {
+              const bool keep = attn_drop_keep1(seed, b, h, heads, L, q, blk0 + l31, thresh);
+              pd = keep ? pr * keep_scale : 0.f;
+              dpp = keep ? dpp * keep_scale : 0.f;
+            }
+          }
+          sb[4 * g + e] = pd;                                   // Pd[q][key]
+          dpb[4 * g + e] = (q < L && kvalid) ? pr * (dpp - d4[e]) * scale : 0.f;   // dS[q][key]
+        }
+      }
+      SlabMma<T>::run(sb, img1 + l31 * LP + tq * 32 + 4 * half, LP, dv);    // dV += Pd^T dO
+      SlabMma<T>::run(dpb, img0 + l31 * LP + tq * 32 + 4 * half, LP, dk);   // dK += dS^T Q
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = blk0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (key < L) {
+          ElemOps<T>::store(dbase + (int64_t)key * ld + H + dt * 32 + l31, dk[dt][r]);
+          ElemOps<T>::store(dbase + (int64_t)key * ld + 2 * H + dt * 32 + l31, dv[dt][r]);
+        }
+      }
+  }
+}
+
+template <typename T>
+static int launch_attn_bwd_long(const void* qkv, const void* ctx, const void* dctx, void* dqkv, const int64_t* mask,
+                                int64_t B, int L, int H, int heads, float scale, float drop_p,
+                                uint64_t seed, const float* pos_bias, float* drel, hipStream_t s) {
+  const int lds = 2 * 64 * 516 * (int)sizeof(T) + 6 * 512 * 4;
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set) {
+    OM_HIP(hipFuncSetAttribute((const void*)attention_bwd_long_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attention_bwd_long_kernel<T>), dim3((unsigned)(heads * B)), dim3(256), lds, s,
+                     (const T*)qkv, (const T*)ctx, (const T*)dctx, (T*)dqkv, mask, L, H, heads, scale, drop_p, seed, pos_bias, drel);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+// 256 < L <= 512, 16-bit formats: needs the forward's output (the tape's ctx)
+int omk_attention_bwd_long(int dtype, const void* qkv, const void* ctx, const void* dctx, void* dqkv, const int64_t* mask,
+                           int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
+                           const float* pos_bias, float* drel, hipStream_t s) {
+  if (B <= 0) return 0;
+  if (L < 1 || L > 512) OM_FAIL("attention backward (tile-at-a-time form): up to 512 tokens");      // (taken from 257 on; below that only when a test forces it)
+  if (H != heads * 64) OM_FAIL("head_dim must be 64");
+  if (!ctx) OM_FAIL("attention backward beyond 256 tokens needs the forward's output");
+  if (dtype == OM_BF16) return launch_attn_bwd_long<bf16_t>(qkv, ctx, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s);
+  if (dtype == OM_F16) return launch_attn_bwd_long<f16_t>(qkv, ctx, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s);
+  OM_FAIL("attention backward beyond 256 tokens: 16-bit formats");
+}
+
 int omk_attention_bwd(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask,
                       int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
                       hipStream_t s, const int* cu) {

