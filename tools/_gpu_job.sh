@@ -1,5 +1,5 @@
 set -u
-O=gpurun_out/r06_l; mkdir -p $O
 export LD_LIBRARY_PATH=$PWD/openmatch_amd/csrc:${LD_LIBRARY_PATH:-}
-timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "tile_at_a_time or beyond_256" > $O/pytest.log 2>&1; echo "rc=$?"
-grep -E "passed|failed|Error|^E  |tile-at-a-time|training at L" $O/pytest.log | cut -c1-330 | tail -40
+for cfg in 64x128 32x256 16x512 24x384; do
+  timeout 300 python tools/train_bench.py --precision f16 --passages $cfg --steps 20 2>&1 | tail -1 | cut -c1-260
+done

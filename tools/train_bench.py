@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--optimizer", default="fused", help="fused: the product's FusedAdamW (clip + AdamW + weight refresh in one pass); "
                     "torch: clip_grad_norm_ + torch.optim.AdamW(fused=True) + a re-pack of the 16-bit weights")
+    ap.add_argument("--passages", default="64x128", help="passages per step x tokens (e.g. 16x512: the same 8 192 passage tokens at 512 per passage, round 6)")
     ap.add_argument("--arch", default="bert", help="bert (bert-base) | t5 (GTR-base-shaped T5 encoder stack: d_model 768, d_ff 3072, 12 layers, ReLU)")
     ap.add_argument("--wgrad-wgs", type=int, default=0, help="weight-gradient workgroups per launch / 64 (0: the kernel's default, 5)")
     a = ap.parse_args()
@@ -32,11 +33,11 @@ def main():
         from transformers import T5Config, T5EncoderModel
         lm = T5EncoderModel(T5Config(d_model=768, d_ff=3072, num_layers=12, num_heads=12, d_kv=64, vocab_size=32128, feed_forward_proj="relu", dropout_rate=a.dropout))
     else:
-        cfg = BertConfig(hidden_dropout_prob=a.dropout, attention_probs_dropout_prob=a.dropout)
+        cfg = BertConfig(hidden_dropout_prob=a.dropout, attention_probs_dropout_prob=a.dropout)      # (max_position_embeddings 512)
         lm = BertModel(cfg)
     model = DRModel(lm_q=lm, lm_p=lm, pooling="mean" if a.arch == "t5" else "first",
                     model_args=NS(encoder_only=a.arch == "t5", dtype={"bf16": "bfloat16", "f16": "float16"}.get(a.precision, "float32")),
-                    data_args=NS(train_n_passages=8),
+                    data_args=NS(train_n_passages=8 if a.passages == "64x128" else int(a.passages.split("x")[0]) // 8),
                     train_args=NS(negatives_x_device=False, per_device_train_batch_size=8)).to(dev)
     g = torch.Generator().manual_seed(1)
     mk = lambda n, L: {"input_ids": torch.randint(1000, 30000, (n, L), generator=g), "attention_mask": torch.ones(n, L, dtype=torch.long)}
@@ -50,7 +51,8 @@ def main():
         mk_r = mk
         mk = lambda n, L: rag(mk_r(n, L), max(2, L // 8))
     ap_host = os.environ.get("TRAIN_BENCH_HOST_BATCH") == "1"       # 1: pageable host tensors, copied (synchronously) every step as before round 5
-    batch = (mk(8, 32), mk(64, 128))
+    pn, pl = (int(v) for v in a.passages.split("x"))
+    batch = (mk(8, 32), mk(pn, pl))
     tokens = None
     if not ap_host:
         from openmatch_amd.encoder import TOKEN_ROWS_KEY, token_rows_of
