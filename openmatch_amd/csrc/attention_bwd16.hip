@@ -67,10 +67,14 @@ __device__ __forceinline__ void store_rows(const f32x16_t (&o)[2], char* out, in
     }
 }
 
-template <typename T, int KT>
+template <typename T, int KT, bool BIAS>
 __global__ __launch_bounds__(64 * KT) void attention_bwd16_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx, bf16_t* __restrict__ dqkv,
-    const int64_t* __restrict__ mask, int Lm, int H, int heads, float scale, float drop_p, uint64_t seed, const int* __restrict__ cu) {
+    const int64_t* __restrict__ mask, int Lm, int H, int heads, float scale, float drop_p, uint64_t seed, const int* __restrict__ cu,
+    const float* __restrict__ pos_bias, float* __restrict__ drel) {
+  // BIAS (round 6: T5 training, which ran the generic kernel at 281 us per layer where this one takes ~50): pos_bias [heads][Lm][Lm] is added
+  // to the scaled scores (phase A recomputes them; phase B reads Pd / dS from LDS and never sees it); drel [heads][2 Lm - 1] accumulates the
+  // gradient of the bias per relative position key - query + (Lm - 1), through an LDS histogram per workgroup.
   // cu != NULL (packed rows, round 5): sequence b is rows cu[b] .. cu[b + 1] - 1 of qkv / dctx / dqkv, L its own row count; the
   // mask keeps its pitch Lm.  Rows past L are neither read (clamped) nor written, as for a padded sequence shorter than the tile.
   constexpr int LT = KT * 32;
@@ -81,6 +85,7 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd16_kernel(
   char* const sP = sB + LT * PITCH;                    // Pd [query][key]
   char* const sD = sP + LT * PP;                       // dS [query][key]
   float* const sM = (float*)(sD + LT * PP);            // additive key mask (log2 domain)
+  float* const sRel = sM + LT;                         // BIAS: [2 LT] bias gradient per relative position
   const int h = blockIdx.x % heads;
   const int64_t b = blockIdx.x / heads;
   int64_t row0 = b * Lm;
@@ -117,6 +122,8 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd16_kernel(
 #undef BW_STAGE
   const float LOG2E = 1.4426950408889634f;
   for (int k = tid; k < LT; k += 64 * KT) sM[k] = k < L ? (mask[b * Lm + k] != 0 ? 0.f : -1e30f) : -INFINITY;
+  if (BIAS)
+    for (int k = tid; k < 2 * LT; k += 64 * KT) sRel[k] = 0.f;
 
   const int q0 = wave * 32;
   const int qrow = (q0 + l31) < L ? (q0 + l31) : (L - 1);
@@ -156,7 +163,11 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd16_kernel(
         const f32x4_t mb = *(const f32x4_t*)(sM + t * 32 + 8 * g + 4 * half);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = fmaf(s[t][4 * g + e], c2, mb[e]);
+          float v = fmaf(s[t][4 * g + e], c2, mb[e]);
+          if (BIAS) {
+            const int kc = (t * 32 + 8 * g + 4 * half + e) < L ? (t * 32 + 8 * g + 4 * half + e) : (L - 1);
+            v = fmaf(pos_bias[((int64_t)h * Lm + qrow) * Lm + kc], LOG2E, v);      // (the table's pitch: the padded length, also for packed rows)
+          }
           s[t][4 * g + e] = v;
           mx = fmaxf(mx, v);
         }
@@ -207,7 +218,12 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd16_kernel(
         for (int e = 0; e < 4; ++e) {
           const float p = qvalid ? s[t][4 * g + e] : 0.f;
           pd[e] = ((kept >> (16 * t + 4 * g + e)) & 1) ? p * dr.keep_scale : 0.f;
-          ds[e] = p * (dp[t][4 * g + e] - delta) * scale;
+          const float dlogit = p * (dp[t][4 * g + e] - delta);          // d loss / d (scaled score + bias)
+          if (BIAS) {
+            const int key = t * 32 + 8 * g + 4 * half + e;
+            if (qvalid && key < L) atomicAdd(&sRel[key - (q0 + l31) + (Lm - 1)], dlogit);
+          }
+          ds[e] = dlogit * scale;
           dp[t][4 * g + e] = ds[e];
         }
         const int koff = (t * 32 + 8 * g + 4 * half) * 2;
@@ -237,6 +253,8 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd16_kernel(
     store_rows<T>(o, dbase + (int64_t)qrow * ld2, half, qvalid);
   }
   __syncthreads();                                       // Pd, dS complete; K, V no longer needed
+  if (BIAS)
+    for (int k = tid; k < 2 * Lm - 1; k += 64 * KT) atomicAdd(drel + (int64_t)h * (2 * Lm - 1) + k, sRel[k]);
 #define BW_PUT(I)                                                                                     \
   {                                                                                                   \
     const int r = sr + (I) * 8 * KT;                                                                  \
@@ -282,18 +300,18 @@ __global__ __launch_bounds__(64 * KT) void attention_bwd16_kernel(
   }
 }
 
-template <typename T, int KT>
+template <typename T, int KT, bool BIAS>
 int launch_bwd16(const void* qkv, const void* dctx, void* dqkv, const int64_t* mask, int64_t B, int L, int H, int heads,
-                 float scale, float drop_p, uint64_t seed, hipStream_t s, const int* cu) {
+                 float scale, float drop_p, uint64_t seed, hipStream_t s, const int* cu, const float* pos_bias, float* drel) {
   constexpr int LT = KT * 32;
-  const int lds = 2 * LT * PITCH + 2 * LT * (LT * 2 + 8) + LT * 4;
+  const int lds = 2 * LT * PITCH + 2 * LT * (LT * 2 + 8) + LT * 4 + (BIAS ? 2 * LT * 4 : 0);
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
-    OM_HIP(hipFuncSetAttribute((const void*)attention_bwd16_kernel<T, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    OM_HIP(hipFuncSetAttribute((const void*)attention_bwd16_kernel<T, KT, BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((attention_bwd16_kernel<T, KT>), dim3((unsigned)(heads * B)), dim3(64 * KT), lds, s, (const bf16_t*)qkv,
-                     (const bf16_t*)dctx, (bf16_t*)dqkv, mask, L, H, heads, scale, drop_p, seed, cu);
+  hipLaunchKernelGGL((attention_bwd16_kernel<T, KT, BIAS>), dim3((unsigned)(heads * B)), dim3(64 * KT), lds, s, (const bf16_t*)qkv,
+                     (const bf16_t*)dctx, (bf16_t*)dqkv, mask, L, H, heads, scale, drop_p, seed, cu, pos_bias, drel);
   OM_LAUNCH_CHECK();
   return 0;
 }
@@ -304,15 +322,18 @@ bool omk_attention_bwd16_ok(int dtype, int L, int H, int heads) {
 }
 
 int omk_attention_bwd16(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask, int64_t B, int L, int H,
-                        int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, const int* cu) {
+                        int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, const int* cu, const float* pos_bias, float* drel) {
   if (B <= 0) return 0;
-#define BWD16(TT)                                                                                            \
-  do {                                                                                                       \
-    if (L <= 32) return launch_bwd16<TT, 1>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s, cu);    \
-    if (L <= 64) return launch_bwd16<TT, 2>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s, cu);    \
-    return launch_bwd16<TT, 4>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s, cu);                 \
+  if ((pos_bias != nullptr) != (drel != nullptr)) OM_FAIL("attention backward: the position bias and its gradient buffer go together");
+#define BWD16_(TT, BB)                                                                                                            \
+  do {                                                                                                                            \
+    if (L <= 32) return launch_bwd16<TT, 1, BB>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s, cu, pos_bias, drel);   \
+    if (L <= 64) return launch_bwd16<TT, 2, BB>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s, cu, pos_bias, drel);   \
+    return launch_bwd16<TT, 4, BB>(qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s, cu, pos_bias, drel);                \
   } while (0)
+#define BWD16(TT) do { if (pos_bias) BWD16_(TT, true); else BWD16_(TT, false); } while (0)
   if (dtype == OM_F16) BWD16(f16_t);
   BWD16(bf16_t);
 #undef BWD16
+#undef BWD16_
 }

@@ -53,7 +53,8 @@ int omk_attention_bwd_long(int dtype, const void* qkv, const void* ctx, const vo
 // bf16, L <= 128, no position bias: the transposing-read kernel of attention_bwd16.hip
 bool omk_attention_bwd16_ok(int dtype, int L, int H, int heads);
 int omk_attention_bwd16(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask, int64_t B, int L, int H,
-                        int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, const int* cu = nullptr);
+                        int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, const int* cu = nullptr,
+                        const float* pos_bias = nullptr, float* drel = nullptr /* T5 (round 6): the bias table [heads][L][L] and its gradient per relative position */);
 // T5 feed-forward activation (kind 0 relu, 1 gated gelu_new) forward / backward, embedding and bias backward
 int omk_t5_act_fwd(int dtype, const void* f, const void* f2, void* g, int64_t n, int kind, hipStream_t s);
 int omk_t5_act_bwd(int dtype, const void* dg, const void* f, const void* f2, void* df, void* df2, int64_t n, int kind, hipStream_t s);

@@ -1246,8 +1246,8 @@ int omk_attention_bwd_bias(int dtype, const void* qkv, const void* dctx, void* d
                            const float* pos_bias, float* drel, hipStream_t s, const int* cu) {
   if (B <= 0) return 0;
   if (cu && dtype != OM_BF16 && dtype != OM_F16) OM_FAIL("packed rows: attention backward for 16-bit formats");
-  if (!pos_bias && omk_attention_bwd16_ok(dtype, L, H, heads))
-    return omk_attention_bwd16(dtype, qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s, cu);
+  if (omk_attention_bwd16_ok(dtype, L, H, heads) && (pos_bias != nullptr) == (drel != nullptr))      // (with the T5 bias too since round 6)
+    return omk_attention_bwd16(dtype, qkv, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, s, cu, pos_bias, drel);
   if (L < 1 || L > 256) OM_FAIL("training supports sequence lengths up to 256");
   // the three transposed [64][L + 4] images of the backward kernel must fit the 160 KiB of LDS: 256 keys in 16 bits, 192 in f32
   if (dtype == OM_F32 && L > 192) OM_FAIL("float32 training supports sequence lengths up to 192 (16-bit formats: 256)");
