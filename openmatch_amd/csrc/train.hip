@@ -84,6 +84,7 @@ Tape carve_tape(const Dims& d, char* base) {
 struct Ws {
   char *g;                          // fwd: GELU output [M,F]
   char *dxa, *dxb, *dy, *dd, *df, *dqkv, *dctx;   // bwd activation gradients
+  float* astats;                    // attention backward beyond 256 tokens: (max, 1 / sum, delta) per (sequence, head, query)
   char *tl, *tr, *wt;               // transposed operands (f32 / odd widths only) / every layer's transposed weights
   size_t swt;                       // bytes of one layer's transposed weights
   float *dhead, *dpooled;
@@ -114,6 +115,7 @@ Ws carve_ws(const Dims& d, char* base) {
   w.g = take(mf);
   w.dxa = take(mh); w.dxb = take(mh); w.dy = take(mh); w.dd = take(mh);
   w.df = take(mf); w.dqkv = take(3 * mh); w.dctx = take(mh);
+  w.astats = (float*)take(d.es == 2 ? omk_attention_bwd_long_stats_bytes(d.B, d.nh) : 0);
   w.tl = take(wide * d.Mp * d.es);
   w.tr = take(wide * d.Mp * d.es);
   w.swt = align_up(((size_t)4 * d.H * d.H + (size_t)(d.gated ? 3 : 2) * d.F * d.H) * d.es, 256);
@@ -419,7 +421,7 @@ int t5_train_backward(const OmEncoderConfig* c, const OmEncoderWeights* w, const
     RUN(omk_gemm(dt, dA, H, wt.o, H, dt, ws.dctx, H, M, H, H, e, s));         // dctx = dA Wo
     if (d.L > 256 || (!d.packed && dt != OM_F32 && (om_option(OM_OPT_ATTENTION_FAST) & 2)))      // (round 6) beyond 256 tokens: one score tile in registers at a time, delta from the tape's attention output
       RUN(omk_attention_bwd_long(dt, qkv, ctx, ws.dctx, ws.dqkv, attention_mask, d.B, (int)d.L, H, d.nh, 1.0f, ad,
-                                 site_seed(seed, l, 2), ws.posbias, ws.drel, s));
+                                 site_seed(seed, l, 2), ws.posbias, ws.drel, ws.astats, s));
     else
     RUN(omk_attention_bwd_bias(dt, qkv, ws.dctx, ws.dqkv, attention_mask, d.B, (int)d.L, H, d.nh, 1.0f, ad,
                                site_seed(seed, l, 2), ws.posbias, ws.drel, s, cu));
@@ -855,7 +857,7 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
     WGRAD_DONE(l + 1, 3);                                           // ws.dqkv: last read by dWqkv of the layer above
     if (L > 256 || (!d.packed && dt != OM_F32 && (om_option(OM_OPT_ATTENTION_FAST) & 2)))      // (round 6) beyond 256 tokens: one score tile in registers at a time, delta from the tape's attention output
       RUN(omk_attention_bwd_long(dt, qkv, ctx, ws.dctx, dqkvl, attention_mask, B, (int)L, H, d.nh, scale,
-                                 attn_dropout, site_seed(seed, l, 2), nullptr, nullptr, s));
+                                 attn_dropout, site_seed(seed, l, 2), nullptr, nullptr, ws.astats, s));
     else
     RUN(omk_attention_bwd(dt, qkv, ws.dctx, dqkvl, attention_mask, B, (int)L, H, d.nh, scale,
                           attn_dropout, site_seed(seed, l, 2), s, cu));

@@ -46,10 +46,11 @@ int omk_attention_bwd(int dtype, const void* qkv, const void* dctx, void* dqkv, 
 int omk_attention_bwd_bias(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask,
                            int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
                            const float* pos_bias, float* drel, hipStream_t s, const int* cu = nullptr /* packed rows, as above (the bias table keeps the pitch L) */);
-// 256 < L <= 512, 16-bit formats (round 6): one key / query tile in registers at a time; ctx = the forward's output (delta = dO . O)
+// 256 < L <= 512, 16-bit formats (round 6): two kernels with one key / query tile in registers at a time; ctx = the forward's output (delta = dO . O)
 int omk_attention_bwd_long(int dtype, const void* qkv, const void* ctx, const void* dctx, void* dqkv, const int64_t* mask,
                            int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
-                           const float* pos_bias, float* drel, hipStream_t s);
+                           const float* pos_bias, float* drel, float* stats /* omk_attention_bwd_long_stats_bytes(B, heads) of scratch */, hipStream_t s);
+size_t omk_attention_bwd_long_stats_bytes(int64_t B, int heads);
 // bf16, L <= 128, no position bias: the transposing-read kernel of attention_bwd16.hip
 bool omk_attention_bwd16_ok(int dtype, int L, int H, int heads);
 int omk_attention_bwd16(int dtype, const void* qkv, const void* dctx, void* dqkv, const int64_t* mask, int64_t B, int L, int H,

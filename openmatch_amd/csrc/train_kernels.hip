@@ -949,28 +949,27 @@ static int launch_attn_bwd(const void* qkv, const void* dctx, void* dqkv, const 
 // ---------------------------------------------------------------------------------------
 // Attention backward beyond 256 tokens (round 6: training up to 512), 16-bit formats.  The kernel above keeps a whole row of scores per
 // lane in registers (s[KT], dp[KT]: 32 registers per key tile) and three transposed images in LDS; at 512 tokens neither fits.  Here:
-//  * phase A runs over the key tiles TWICE with one tile in registers -- an online softmax for the row statistics, then the
-//    gradients -- and takes delta = rowsum(P o dP) as dO . O from the forward's output (the identity every flash-attention backward
-//    uses; O is on the tape);
-//  * the LDS holds TWO images at a time: K^T under phase A, then Q^T and dO^T under phase B (which was a loop over query tiles already);
-//  * four waves (one per SIMD: the whole register file), each owning the 32-row blocks w, w + 4, ... of either phase.
+//  * TWO kernels, each with one wave per 32-row block and four blocks per workgroup (grid: (sequence, head) x ceil(L / 128)):
+//      A  wave <-> query block: over the key tiles TWICE with one tile in registers -- an online softmax for the row statistics, then the
+//         gradients -- with delta = rowsum(P o dP) taken as dO . O from the forward's output (the identity every flash-attention backward
+//         uses; O is on the tape); writes dQ and the statistics (max, 1 / sum, delta per query) to `stats`;
+//      B  wave <-> key block: a loop over the query tiles (as phase B of the kernel above) with the statistics read back;
+//  * LDS holds what each needs: K^T under A; Q^T, dO^T and the statistics under B.
 // Same masks (attn_common.h hash on (sequence, head, query, key)), same bias and bias-gradient handling as the kernel above.
+#define OM_ABL_LMAX 512
+#define OM_ABL_LP (OM_ABL_LMAX + 4)
 template <typename T>
-__global__ __launch_bounds__(256) void attention_bwd_long_kernel(
+__global__ __launch_bounds__(256) void attention_bwd_long_a_kernel(
     const T* __restrict__ qkv, const T* __restrict__ ctx, const T* __restrict__ dctx, T* __restrict__ dqkv,
     const int64_t* __restrict__ mask, int L, int H, int heads, float scale, float drop_p,
-    uint64_t seed, const float* __restrict__ pos_bias, float* __restrict__ drel) {
+    uint64_t seed, const float* __restrict__ pos_bias, float* __restrict__ drel, float* __restrict__ stats) {
   typedef AttnGeom<T> G;
   typedef typename MmaOps<T>::frag_t frag_t;
-  constexpr int LMAX = 512, LP = LMAX + 4;
+  constexpr int LMAX = OM_ABL_LMAX, LP = OM_ABL_LP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* img0 = (T*)smem;                          // K^T (phase A), Q^T (phase B): [64][LP]
-  T* img1 = img0 + 64 * LP;                    // dO^T (phase B)
-  float* sM = (float*)(img1 + 64 * LP);        // additive key mask
-  float* sMax = sM + LMAX;                     // per query: row max, 1/row sum, delta
-  float* sInv = sMax + LMAX;
-  float* sDelta = sInv + LMAX;
-  float* sRel = sDelta + LMAX;                 // [2 * LMAX] bias gradient per relative position
+  T* sKt = (T*)smem;                           // K^T: [64][LP]
+  float* sM = (float*)(sKt + 64 * LP);         // additive key mask
+  float* sRel = sM + LMAX;                     // [2 * LMAX] bias gradient per relative position
 
   const int h = blockIdx.x % heads;
   const int64_t b = blockIdx.x / heads;
@@ -981,18 +980,18 @@ __global__ __launch_bounds__(256) void attention_bwd_long_kernel(
   const T* dob = dctx + b * L * H + h * 64;
   const T* ob = ctx + b * L * H + h * 64;
   T* dbase = dqkv + b * L * ld + h * 64;
+  float* st = stats + (int64_t)blockIdx.x * 3 * LMAX;      // [3][LMAX]: max, 1 / sum, delta
   const AttnDrop dr_(drop_p);
   const uint32_t thresh = dr_.thresh;
   const float keep_scale = dr_.keep_scale;
 
-  // K^T
   for (int idx = tid; idx < KT * 32 * G::CPR; idx += nthr) {
     const int row = idx / G::CPR, c = idx % G::CPR;
     uint4 kv = make_uint4(0, 0, 0, 0);
     if (row < L) kv = *(const uint4*)(base + (int64_t)row * ld + H + c * G::EPC);
     const T* ke = (const T*)&kv;
 #pragma unroll
-    for (int e = 0; e < G::EPC; ++e) img0[(c * G::EPC + e) * LP + row] = ke[e];
+    for (int e = 0; e < G::EPC; ++e) sKt[(c * G::EPC + e) * LP + row] = ke[e];
   }
   for (int k = tid; k < KT * 32; k += nthr)
     sM[k] = k < L ? (mask[b * L + k] != 0 ? 0.f : -3.4028235e38f) : -INFINITY;
@@ -1001,9 +1000,8 @@ __global__ __launch_bounds__(256) void attention_bwd_long_kernel(
   __syncthreads();
 
   const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
-
-  // ------------------------------------------------------------------ phase A: query blocks wave, wave + 4, ...
-  for (int blk0 = wave * 32; blk0 < L; blk0 += 128) {
+  const int blk0 = (blockIdx.y * 4 + wave) * 32;       // this wave's query block
+  if (blk0 < L) {
     const int myrow = (blk0 + l31) < L ? (blk0 + l31) : (L - 1);
     frag_t qf[G::NKK], dof[G::NKK];
     float delta = 0.f;
@@ -1087,10 +1085,10 @@ __global__ __launch_bounds__(256) void attention_bwd_long_kernel(
         if (drel && (blk0 + l31) < L && key < L) atomicAdd(&sRel[key - (blk0 + l31) + (L - 1)], dlogit);
         sc[r] = dlogit * scale;                                        // dS
       }
-      SlabMma<T>::run(sc, img0 + l31 * LP + t * 32 + 4 * half, LP, o);   // dQ += dS K
+      SlabMma<T>::run(sc, sKt + l31 * LP + t * 32 + 4 * half, LP, o);   // dQ += dS K
     }
 #undef OM_ABL_SCORES
-    if (half == 0 && blk0 + l31 < L) { sMax[blk0 + l31] = m_run; sInv[blk0 + l31] = inv; sDelta[blk0 + l31] = delta; }
+    if (half == 0 && blk0 + l31 < L) { st[blk0 + l31] = m_run; st[LMAX + blk0 + l31] = inv; st[2 * LMAX + blk0 + l31] = delta; }
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -1099,10 +1097,40 @@ __global__ __launch_bounds__(256) void attention_bwd_long_kernel(
         if (q < L) ElemOps<T>::store(dbase + (int64_t)q * ld + dt * 32 + l31, o[dt][r]);
       }
   }
-  __syncthreads();                                 // K^T has been consumed, the statistics are published
-  if (drel)
+  if (drel) {
+    __syncthreads();
     for (int k = tid; k < 2 * L - 1; k += nthr) atomicAdd(drel + (int64_t)h * (2 * L - 1) + k, sRel[k]);
-  // Q^T and dO^T
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attention_bwd_long_b_kernel(
+    const T* __restrict__ qkv, const T* __restrict__ dctx, T* __restrict__ dqkv,
+    const int64_t* __restrict__ mask, int L, int H, int heads, float scale, float drop_p,
+    uint64_t seed, const float* __restrict__ pos_bias, const float* __restrict__ stats) {
+  typedef AttnGeom<T> G;
+  typedef typename MmaOps<T>::frag_t frag_t;
+  constexpr int LMAX = OM_ABL_LMAX, LP = OM_ABL_LP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sQt = (T*)smem;                           // Q^T: [64][LP]
+  T* sDOt = sQt + 64 * LP;                     // dO^T
+  float* sMax = (float*)(sDOt + 64 * LP);      // per query: row max, 1 / row sum, delta (kernel A)
+  float* sInv = sMax + LMAX;
+  float* sDelta = sInv + LMAX;
+
+  const int h = blockIdx.x % heads;
+  const int64_t b = blockIdx.x / heads;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int KT = (L + 31) / 32;
+  const int64_t ld = 3 * (int64_t)H;
+  const T* base = qkv + b * L * ld + h * 64;
+  const T* dob = dctx + b * L * H + h * 64;
+  T* dbase = dqkv + b * L * ld + h * 64;
+  const float* st = stats + (int64_t)blockIdx.x * 3 * LMAX;
+  const AttnDrop dr_(drop_p);
+  const uint32_t thresh = dr_.thresh;
+  const float keep_scale = dr_.keep_scale;
+
   for (int idx = tid; idx < KT * 32 * G::CPR; idx += nthr) {
     const int row = idx / G::CPR, c = idx % G::CPR;
     uint4 qv = make_uint4(0, 0, 0, 0), dv = qv;
@@ -1113,107 +1141,117 @@ __global__ __launch_bounds__(256) void attention_bwd_long_kernel(
     const T* qe = (const T*)&qv; const T* de = (const T*)&dv;
 #pragma unroll
     for (int e = 0; e < G::EPC; ++e) {
-      img0[(c * G::EPC + e) * LP + row] = qe[e];
-      img1[(c * G::EPC + e) * LP + row] = de[e];
+      sQt[(c * G::EPC + e) * LP + row] = qe[e];
+      sDOt[(c * G::EPC + e) * LP + row] = de[e];
     }
+  }
+  for (int k = tid; k < KT * 32; k += nthr) {
+    sMax[k] = k < L ? st[k] : 0.f; sInv[k] = k < L ? st[LMAX + k] : 0.f; sDelta[k] = k < L ? st[2 * LMAX + k] : 0.f;
   }
   __syncthreads();
 
-  // ------------------------------------------------------------------ phase B: key blocks wave, wave + 4, ...
-  for (int blk0 = wave * 32; blk0 < L; blk0 += 128) {
-    const int myrow = (blk0 + l31) < L ? (blk0 + l31) : (L - 1);
-    const bool kvalid = (blk0 + l31) < L;
-    const float mbk = sM[blk0 + l31];
-    frag_t kf[G::NKK], vf[G::NKK];
+  const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int blk0 = (blockIdx.y * 4 + wave) * 32;       // this wave's key block
+  if (blk0 >= L) return;
+  const int myrow = (blk0 + l31) < L ? (blk0 + l31) : (L - 1);
+  const bool kvalid = (blk0 + l31) < L;
+  const float mbk = kvalid ? (mask[b * L + blk0 + l31] != 0 ? 0.f : -3.4028235e38f) : -INFINITY;
+  frag_t kf[G::NKK], vf[G::NKK];
+#pragma unroll
+  for (int kk = 0; kk < G::NKK; ++kk) {
+    kf[kk] = *(const frag_t*)(base + (int64_t)myrow * ld + H + (kk * 2 + half) * G::EPC);
+    vf[kk] = *(const frag_t*)(base + (int64_t)myrow * ld + 2 * H + (kk * 2 + half) * G::EPC);
+  }
+  f32x16_t dv[2], dk[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dv[dt][r] = 0.f; dk[dt][r] = 0.f; }
+  for (int tq = 0; tq < KT; ++tq) {
+    const int qr = (tq * 32 + l31) < L ? (tq * 32 + l31) : (L - 1);
+    f32x16_t sb, dpb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sb[r] = 0.f; dpb[r] = 0.f; }
 #pragma unroll
     for (int kk = 0; kk < G::NKK; ++kk) {
-      kf[kk] = *(const frag_t*)(base + (int64_t)myrow * ld + H + (kk * 2 + half) * G::EPC);
-      vf[kk] = *(const frag_t*)(base + (int64_t)myrow * ld + 2 * H + (kk * 2 + half) * G::EPC);
+      const frag_t qa = *(const frag_t*)(base + (int64_t)qr * ld + (kk * 2 + half) * G::EPC);
+      const frag_t da = *(const frag_t*)(dob + (int64_t)qr * H + (kk * 2 + half) * G::EPC);
+      MmaOps<T>::mma(qa, kf[kk], sb);        // S[query][key]
+      MmaOps<T>::mma(da, vf[kk], dpb);       // dPd[query][key]
     }
-    f32x16_t dv[2], dk[2];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int g = 0; g < 4; ++g) {
+      const int q4 = tq * 32 + 8 * g + 4 * half;
+      const f32x4_t m4 = *(const f32x4_t*)(sMax + q4);
+      const f32x4_t i4 = *(const f32x4_t*)(sInv + q4);
+      const f32x4_t d4 = *(const f32x4_t*)(sDelta + q4);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { dv[dt][r] = 0.f; dk[dt][r] = 0.f; }
-    for (int tq = 0; tq < KT; ++tq) {
-      const int qr = (tq * 32 + l31) < L ? (tq * 32 + l31) : (L - 1);
-      f32x16_t sb, dpb;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { sb[r] = 0.f; dpb[r] = 0.f; }
-#pragma unroll
-      for (int kk = 0; kk < G::NKK; ++kk) {
-        const frag_t qa = *(const frag_t*)(base + (int64_t)qr * ld + (kk * 2 + half) * G::EPC);
-        const frag_t da = *(const frag_t*)(dob + (int64_t)qr * H + (kk * 2 + half) * G::EPC);
-        MmaOps<T>::mma(qa, kf[kk], sb);        // S[query][key]
-        MmaOps<T>::mma(da, vf[kk], dpb);       // dPd[query][key]
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int q4 = tq * 32 + 8 * g + 4 * half;
-        const f32x4_t m4 = *(const f32x4_t*)(sMax + q4);
-        const f32x4_t i4 = *(const f32x4_t*)(sInv + q4);
-        const f32x4_t d4 = *(const f32x4_t*)(sDelta + q4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int q = q4 + e;
-          float pr = 0.f, pd = 0.f, dpp = 0.f;
-          if (q < L && kvalid) {
-            float lg = sb[4 * g + e] * scale + mbk;
-            if (pos_bias) lg += pos_bias[((int64_t)h * L + q) * L + (blk0 + l31)];
-            pr = G::exp_(lg - m4[e]) * i4[e];
-            pd = pr; dpp = dpb[4 * g + e];
-            if (thresh) {
-              const bool keep = attn_drop_keep1(seed, b, h, heads, L, q, blk0 + l31, thresh);
-              pd = keep ? pr * keep_scale : 0.f;
-              dpp = keep ? dpp * keep_scale : 0.f;
-            }
+      for (int e = 0; e < 4; ++e) {
+        const int q = q4 + e;
+        float pr = 0.f, pd = 0.f, dpp = 0.f;
+        if (q < L && kvalid) {
+          float lg = sb[4 * g + e] * scale + mbk;
+          if (pos_bias) lg += pos_bias[((int64_t)h * L + q) * L + (blk0 + l31)];
+          pr = G::exp_(lg - m4[e]) * i4[e];
+          pd = pr; dpp = dpb[4 * g + e];
+          if (thresh) {
+            const bool keep = attn_drop_keep1(seed, b, h, heads, L, q, blk0 + l31, thresh);
+            pd = keep ? pr * keep_scale : 0.f;
+            dpp = keep ? dpp * keep_scale : 0.f;
           }
-          sb[4 * g + e] = pd;                                   // Pd[q][key]
-          dpb[4 * g + e] = (q < L && kvalid) ? pr * (dpp - d4[e]) * scale : 0.f;   // dS[q][key]
         }
+        sb[4 * g + e] = pd;                                   // Pd[q][key]
+        dpb[4 * g + e] = (q < L && kvalid) ? pr * (dpp - d4[e]) * scale : 0.f;   // dS[q][key]
       }
-      SlabMma<T>::run(sb, img1 + l31 * LP + tq * 32 + 4 * half, LP, dv);    // dV += Pd^T dO
-      SlabMma<T>::run(dpb, img0 + l31 * LP + tq * 32 + 4 * half, LP, dk);   // dK += dS^T Q
     }
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = blk0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (key < L) {
-          ElemOps<T>::store(dbase + (int64_t)key * ld + H + dt * 32 + l31, dk[dt][r]);
-          ElemOps<T>::store(dbase + (int64_t)key * ld + 2 * H + dt * 32 + l31, dv[dt][r]);
-        }
-      }
+    SlabMma<T>::run(sb, sDOt + l31 * LP + tq * 32 + 4 * half, LP, dv);    // dV += Pd^T dO
+    SlabMma<T>::run(dpb, sQt + l31 * LP + tq * 32 + 4 * half, LP, dk);    // dK += dS^T Q
   }
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = blk0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (key < L) {
+        ElemOps<T>::store(dbase + (int64_t)key * ld + H + dt * 32 + l31, dk[dt][r]);
+        ElemOps<T>::store(dbase + (int64_t)key * ld + 2 * H + dt * 32 + l31, dv[dt][r]);
+      }
+    }
 }
 
 template <typename T>
 static int launch_attn_bwd_long(const void* qkv, const void* ctx, const void* dctx, void* dqkv, const int64_t* mask,
                                 int64_t B, int L, int H, int heads, float scale, float drop_p,
-                                uint64_t seed, const float* pos_bias, float* drel, hipStream_t s) {
-  const int lds = 2 * 64 * 516 * (int)sizeof(T) + 6 * 512 * 4;
+                                uint64_t seed, const float* pos_bias, float* drel, float* stats, hipStream_t s) {
+  const int lds_a = 64 * OM_ABL_LP * (int)sizeof(T) + 3 * OM_ABL_LMAX * 4;
+  const int lds_b = 2 * 64 * OM_ABL_LP * (int)sizeof(T) + 3 * OM_ABL_LMAX * 4;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
-    OM_HIP(hipFuncSetAttribute((const void*)attention_bwd_long_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    OM_HIP(hipFuncSetAttribute((const void*)attention_bwd_long_a_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
+    OM_HIP(hipFuncSetAttribute((const void*)attention_bwd_long_b_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
     attr_set = true;
   }
-  hipLaunchKernelGGL((attention_bwd_long_kernel<T>), dim3((unsigned)(heads * B)), dim3(256), lds, s,
-                     (const T*)qkv, (const T*)ctx, (const T*)dctx, (T*)dqkv, mask, L, H, heads, scale, drop_p, seed, pos_bias, drel);
+  const dim3 grid((unsigned)(heads * B), (unsigned)((L + 127) / 128));
+  hipLaunchKernelGGL((attention_bwd_long_a_kernel<T>), grid, dim3(256), lds_a, s,
+                     (const T*)qkv, (const T*)ctx, (const T*)dctx, (T*)dqkv, mask, L, H, heads, scale, drop_p, seed, pos_bias, drel, stats);
+  OM_LAUNCH_CHECK();
+  hipLaunchKernelGGL((attention_bwd_long_b_kernel<T>), grid, dim3(256), lds_b, s,
+                     (const T*)qkv, (const T*)dctx, (T*)dqkv, mask, L, H, heads, scale, drop_p, seed, pos_bias, (const float*)stats);
   OM_LAUNCH_CHECK();
   return 0;
 }
 
 // 256 < L <= 512, 16-bit formats: needs the forward's output (the tape's ctx)
+size_t omk_attention_bwd_long_stats_bytes(int64_t B, int heads) { return (size_t)B * heads * 3 * OM_ABL_LMAX * 4; }
 int omk_attention_bwd_long(int dtype, const void* qkv, const void* ctx, const void* dctx, void* dqkv, const int64_t* mask,
                            int64_t B, int L, int H, int heads, float scale, float drop_p, uint64_t seed,
-                           const float* pos_bias, float* drel, hipStream_t s) {
+                           const float* pos_bias, float* drel, float* stats, hipStream_t s) {
   if (B <= 0) return 0;
   if (L < 1 || L > 512) OM_FAIL("attention backward (tile-at-a-time form): up to 512 tokens");      // (taken from 257 on; below that only when a test forces it)
   if (H != heads * 64) OM_FAIL("head_dim must be 64");
-  if (!ctx) OM_FAIL("attention backward beyond 256 tokens needs the forward's output");
-  if (dtype == OM_BF16) return launch_attn_bwd_long<bf16_t>(qkv, ctx, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s);
-  if (dtype == OM_F16) return launch_attn_bwd_long<f16_t>(qkv, ctx, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, s);
+  if (!ctx || !stats) OM_FAIL("attention backward beyond 256 tokens needs the forward's output and a statistics buffer (omk_attention_bwd_long_stats_bytes)");
+  if (dtype == OM_BF16) return launch_attn_bwd_long<bf16_t>(qkv, ctx, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, stats, s);
+  if (dtype == OM_F16) return launch_attn_bwd_long<f16_t>(qkv, ctx, dctx, dqkv, mask, B, L, H, heads, scale, drop_p, seed, pos_bias, drel, stats, s);
   OM_FAIL("attention backward beyond 256 tokens: 16-bit formats");
 }
 

@@ -1364,7 +1364,7 @@ def test_bf16_attention_backward_kernels_agree(L, p_drop):
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
 def test_tile_at_a_time_attention_kernels_agree_with_the_others_under_dropout(dtype, arch):
     """Training beyond 256 tokens (round 6) runs its attention on kernels that keep ONE score tile in registers: the online-softmax
-    forward (with dropout now) and attention_bwd_long_kernel (two passes over the key tiles, delta = dO . O).  Forced at L = 200 / 96
+    forward (with dropout now) and attention_bwd_long_a / _b_kernel (two passes over the key tiles, delta = dO . O; dK, dV over the query tiles).  Forced at L = 200 / 96
     (OM_OPT_ATTENTION_FAST bit 1) they must reproduce the step of the kernels that normally serve those lengths: the same dropout masks
     (one hash of (sequence, head, query, key)), loss and gradients up to 16-bit rounding -- BERT and T5 (position bias and its gradient)."""
     from transformers import BertConfig, BertModel, T5Config, T5EncoderModel
