@@ -277,7 +277,7 @@ int om_encoder_forward(const OmEncoderConfig* cfg, const OmEncoderWeights* w,
  * the embedding, all contractions and the normalisations over `packed_rows` rows instead of B * L, attention per
  * sequence over its own rows, and pools from them: the representations om_encoder_forward returns, for
  * sum(lengths) / (B * L) of the work.  16-bit configurations with the fused path (hidden, ffn multiples of 256;
- * BERT-family: erf-GELU, float16 or bfloat16; T5 encoders: bfloat16, no gated feed-forward), L <= 256, pooling set (no out_hidden).
+ * BERT-family: erf-GELU, float16 or bfloat16; T5 encoders: no gated feed-forward), L <= 1024 (round 6; was 256), pooling set (no out_hidden).
  * packed_rows: the caller's bound on the token count -- sum over sequences of (1 + index of the last unmasked token) --
  * rounded up to a multiple of 256, >= 512.  The bound is checked on the device: a batch that holds more tokens returns
  * NaN in every representation (no host synchronisation, never a truncated batch).

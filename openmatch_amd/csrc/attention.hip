@@ -444,7 +444,9 @@ static int launch_attn16(const void* qkv, void* ctx, const int64_t* mask, const 
 template <typename T>
 __global__ __launch_bounds__(256) void attention_long_kernel(
     const T* __restrict__ qkv, T* __restrict__ ctx, const int64_t* __restrict__ mask,
-    const float* __restrict__ pos_bias, int L, int H, int heads, float scale, float drop_p, uint64_t seed) {
+    const float* __restrict__ pos_bias, int Lm, int H, int heads, float scale, float drop_p, uint64_t seed, const int* __restrict__ cu) {
+  // cu != NULL (packed rows beyond 256 tokens, round 6): sequence b is rows cu[b] .. cu[b + 1] - 1 of qkv / ctx, L its own row count; the mask,
+  // the bias table and the dropout hash keep the padded pitch Lm.
   // drop_p > 0 (round 6: training beyond 256 tokens): the probabilities that meet V are masked with the (sequence, head, query, key)
   // hash the backward regenerates (attn_common.h); the normaliser is the sum of the unmasked ones, as in the other kernels
   typedef AttnGeom<T> G;
@@ -461,7 +463,11 @@ __global__ __launch_bounds__(256) void attention_long_kernel(
   const int qb = blockIdx.y * 128;
   const int tid = threadIdx.x;
   const int64_t ld = 3 * (int64_t)H;
-  const T* base = qkv + b * L * ld + h * 64;
+  int64_t row0 = b * Lm;
+  int L = Lm;
+  if (cu) { row0 = cu[b]; L = cu[b + 1] - cu[b]; }
+  if (qb >= L) return;                                       // (whole workgroup: a sequence shorter than this query block)
+  const T* base = qkv + row0 * ld + h * 64;
   const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int q0 = qb + wave * 32;
   const int qrow = (q0 + l31) < L ? (q0 + l31) : (L - 1);
@@ -493,7 +499,7 @@ __global__ __launch_bounds__(256) void attention_long_kernel(
 #pragma unroll
       for (int e = 0; e < G::EPC; ++e) sVt[(c * G::EPC + e) * LP + row] = ve[e];
     }
-    if (tid < 128) sM[tid] = (kc + tid) < L ? (mask[b * L + kc + tid] != 0 ? 0.f : -3.4028235e38f) : -INFINITY;
+    if (tid < 128) sM[tid] = (kc + tid) < L ? (mask[b * Lm + kc + tid] != 0 ? 0.f : -3.4028235e38f) : -INFINITY;
     __syncthreads();
 
     f32x16_t s[4];
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(256) void attention_long_kernel(
           float v = s[t][4 * g + e] * scale;
           if (pos_bias) {
             const int kcol = (kc + k0 + e) < L ? (kc + k0 + e) : (L - 1);
-            v += pos_bias[((int64_t)h * L + qrow) * L + kcol];
+            v += pos_bias[((int64_t)h * Lm + qrow) * Lm + kcol];
           }
           v += mb[e];
           s[t][4 * g + e] = v;
@@ -539,7 +545,7 @@ __global__ __launch_bounds__(256) void attention_long_kernel(
       for (int r = 0; r < 16; ++r) {
         const float e = G::exp_(s[t][r] - mx);
         sum += e;
-        s[t][r] = (thresh && !attn_drop_keep1(seed, b, h, heads, L, q0 + l31, kc + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, thresh)) ? 0.f : (thresh ? e * keep_scale : e);
+        s[t][r] = (thresh && !attn_drop_keep1(seed, b, h, heads, Lm, q0 + l31, kc + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, thresh)) ? 0.f : (thresh ? e * keep_scale : e);
       }
     sum += __shfl_xor(sum, 32, 64);
     l_run = l_run * alpha + sum;
@@ -573,7 +579,7 @@ __global__ __launch_bounds__(256) void attention_long_kernel(
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (q0 < L) {
-    T* out = ctx + (b * L + q0) * H + h * 64;
+    T* out = ctx + (row0 + q0) * H + h * 64;
     constexpr int VPR = G::ROWB / 16;
 #pragma unroll
     for (int it = 0; it < 32 * VPR / 64; ++it) {
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(256) void attention_long_kernel(
 
 template <typename T>
 static int launch_attn_long(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias, int64_t B, int L, int H,
-                            int heads, float scale, hipStream_t s, float drop_p = 0.f, uint64_t seed = 0) {
+                            int heads, float scale, hipStream_t s, float drop_p = 0.f, uint64_t seed = 0, const int* cu = nullptr) {
   const int lds = 128 * AttnGeom<T>::ROWB + 64 * 132 * (int)sizeof(T) + 128 * 4 + 128 * 4;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
@@ -594,7 +600,7 @@ static int launch_attn_long(const void* qkv, void* ctx, const int64_t* mask, con
     attr_set = true;
   }
   hipLaunchKernelGGL((attention_long_kernel<T>), dim3((unsigned)(heads * B), (unsigned)((L + 127) / 128)), dim3(256), lds, s,
-                     (const T*)qkv, (T*)ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed);
+                     (const T*)qkv, (T*)ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed, cu);
   OM_LAUNCH_CHECK();
   return 0;
 }
@@ -693,17 +699,17 @@ int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
                   const float* pos_bias, int64_t B, int L, int H, int heads, float scale,
                   float drop_p, uint64_t seed, hipStream_t s, int reverse, const int* kmax, const int* cu) {
   if (B <= 0) return 0;
-  if (cu && !((dtype == OM_F16 || (dtype == OM_BF16 && om_option(OM_OPT_ATTENTION_FAST))) && L <= 256))
-    OM_FAIL("packed rows: the 16-bit attention kernels, L <= 256");      // (with dropout too: the packed training forward, round 5)
+  if (cu && !(dtype == OM_F16 || (dtype == OM_BF16 && om_option(OM_OPT_ATTENTION_FAST))))
+    OM_FAIL("packed rows: the 16-bit attention kernels");      // (with dropout too: the packed training forward, round 5; beyond 256 tokens: round 6)
   if (L < 1 || L > 1024) OM_FAIL("sequence length must be in [1,1024]");
   if (L > 256 && drop_p > 0.f && (L > 512 || dtype == OM_F32)) OM_FAIL("attention with dropout: up to 512 tokens in the 16-bit formats (float32: 256)");
   if (H != heads * 64) OM_FAIL("head_dim must be 64");
   if (B * heads > 0x7fffffffLL) OM_FAIL("batch too large for one launch");
   // OM_OPT_ATTENTION_FAST bit 1 (tests): the tile-at-a-time kernels of L > 256 at every length (their masks and results must agree with the others')
-  const bool force_long = (om_option(OM_OPT_ATTENTION_FAST) & 2) != 0 && !cu && dtype != OM_F32;
+  const bool force_long = (om_option(OM_OPT_ATTENTION_FAST) & 2) != 0 && dtype != OM_F32;
   if (dtype == OM_F16) {                                      // float16 inference mode: the fast kernel only
     if (L > 256 || force_long) {
-      return launch_attn_long<f16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s, drop_p, seed);      // (with dropout: training up to 512 tokens, round 6)
+      return launch_attn_long<f16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s, drop_p, seed, cu);      // (with dropout: training up to 512 tokens, round 6)
     }
     if (L <= 32) return launch_attn16<f16_t, 1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
     if (L <= 64) return launch_attn16<f16_t, 2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
@@ -712,7 +718,7 @@ int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
     return launch_attn16<f16_t, 8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
   }
   if (L > 256 || force_long) {                                // online-softmax kernel, any dtype
-    if (dtype == OM_BF16) return launch_attn_long<bf16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s, drop_p, seed);
+    if (dtype == OM_BF16) return launch_attn_long<bf16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s, drop_p, seed, cu);
     return launch_attn_long<float>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
   }
   if (dtype == OM_BF16 && om_option(OM_OPT_ATTENTION_FAST)) {        // the low-instruction-count kernel (inference, and training with dropout)

@@ -172,7 +172,7 @@ extern "C" size_t om_encoder_workspace_bytes(const OmEncoderConfig* cfg, int64_t
 // asks before it chooses the packed entry, so that an A/B switch (OM_GEMM_VARIANT, OM_ENCODER_FUSED_LN = 0, OM_ATTENTION_FAST = 0,
 // om_debug_gemm_gen) degrades a compact batch to the padded entry instead of failing the call.
 extern "C" int om_encoder_packed_supported(const OmEncoderConfig* c, int gated_ffn, int64_t B, int64_t L, int64_t packed_rows) {
-  if (!c || B <= 0 || L <= 0 || L > 256 || packed_rows <= 0) return 0;
+  if (!c || B <= 0 || L <= 0 || L > 1024 || packed_rows <= 0) return 0;      // (beyond 256 tokens: round 6, the online-softmax attention kernel takes packed rows)
   if (packed_rows % 256 || packed_rows < 512 || packed_rows > B * L + 255) return 0;
   // few rows: the padded entry's contractions take the weight-streaming kernel -- decided there on ITS row count B * L, so only a
   // batch whose PADDED form is that small is sent back (B = 64, L = 128 with 1 024 real tokens would otherwise run the tile kernels
@@ -252,8 +252,8 @@ static int encoder_forward_impl(const OmEncoderConfig* c, const OmEncoderWeights
   if (!workspace || ((uintptr_t)workspace & 255)) OM_FAIL("workspace must be 256-byte aligned");
   const bool packed = packed_rows > 0;
   if (packed) {
-    if (c->dtype == OM_F32 || out_hidden || c->pooling == OM_POOL_NONE || L > 256 || c->n_layers < 1)
-      OM_FAIL("packed rows: 16-bit inference that returns representations only, L <= 256");
+    if (c->dtype == OM_F32 || out_hidden || c->pooling == OM_POOL_NONE || c->n_layers < 1)
+      OM_FAIL("packed rows: 16-bit inference that returns representations only");
     if (packed_rows % 256 || packed_rows < 512 || packed_rows > B * L + 255) OM_FAIL("packed_rows: a multiple of 256 in [512, B * L + 255]");
   }
   EncWs ws = carve(c, B, L, (char*)workspace, packed_rows);

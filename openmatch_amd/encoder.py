@@ -423,7 +423,7 @@ def packed_rows_apply(cfg, B, L, rows, want_hidden, pooling, gated=False):
     OM_ENCODER_PACKED=0 keeps every batch on the padded entry."""
     if os.environ.get("OM_ENCODER_PACKED", "1") == "0" or want_hidden or pooling is None:
         return False
-    if cfg.dtype not in (N.OM_BF16, N.OM_F16) or cfg.hidden % 256 or cfg.ffn % 256 or cfg.n_layers < 1 or L > 256:
+    if cfg.dtype not in (N.OM_BF16, N.OM_F16) or cfg.hidden % 256 or cfg.ffn % 256 or cfg.n_layers < 1 or L > 1024:
         return False
     if cfg.arch == N.ARCH_BERT and cfg.act != N.ACT_GELU_ERF:
         return False

@@ -365,6 +365,48 @@ def test_encode_and_forward_return_the_same_representations(dtype, pooling):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("arch", ["bert", "t5"])
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_packed_rows_beyond_256_tokens_are_bit_identical_to_padded(dtype, arch):
+    """Round 6: the packed-rows encoder takes sequences of up to 1 024 tokens (was 256): the online-softmax attention kernel reads each
+    sequence's own rows and length, the mask / position-bias table / padded pitch stay.  Same bits as the padded entry at 384 and 520
+    tokens: ragged lengths, a full-length row, a mask with holes, an empty row; BERT and T5 (relative-position bias); both poolings."""
+    from transformers import BertConfig, BertModel, T5Config, T5EncoderModel
+    from openmatch.modeling import DRModelForInference
+    from openmatch_amd import encoder as enc_mod
+    from openmatch_amd.encoder import compute_dtype_code, hip_encode, packed_rows_bound
+    torch.manual_seed(15)
+    if arch == "bert":
+        lm = BertModel(BertConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024, vocab_size=600,
+                                  max_position_embeddings=640)).eval()
+    else:
+        lm = T5EncoderModel(T5Config(d_model=256, d_ff=1024, num_layers=2, num_heads=4, d_kv=64, vocab_size=600, feed_forward_proj="relu")).eval()
+    rng = np.random.default_rng(19)
+    for L, pooling in ((384, "mean"), (520, "first")):
+        model = DRModelForInference(lm_q=lm, lm_p=lm, pooling=pooling, model_args=NS(encoder_only=arch == "t5", dtype=dtype)).to(DEV).eval()
+        code = compute_dtype_code(model.model_args)
+        B = 12
+        ids, mask = synth_tokens(rng, B, L, vocab=600, lo_len=5, lo_id=300)
+        ids[0, :], mask[0, :] = rng.integers(300, 600, L), 1
+        mask[1, :] = 0; mask[1, ::3] = 1
+        mask[2, :] = 0
+        m = torch.from_numpy(mask)
+        rows = packed_rows_bound(m)
+        assert rows is not None and rows < B * L - 256
+        items = {"input_ids": torch.from_numpy(ids).to(DEV), "attention_mask": m.to(DEV)}
+        padded = hip_encode(model.lm_p, items, pooling, None, False, code, want_hidden=False)[1]
+        assert enc_mod.LAST_CALL == {"rows": B * L, "packed": False}
+        packed = hip_encode(model.lm_p, items, pooling, None, False, code, want_hidden=False, packed_rows=rows)[1]
+        assert enc_mod.LAST_CALL == {"rows": rows, "packed": True}, enc_mod.LAST_CALL
+        keep = torch.ones(B, dtype=torch.bool); keep[2] = False          # (the empty row: a softmax over no keys)
+        assert torch.isfinite(padded[keep]).all()
+        assert torch.equal(packed[keep], padded[keep]), (L, (packed[keep] - padded[keep]).abs().max().item())
+        if rows - 512 >= 512:          # a bound below the token count: NaN everywhere
+            small = hip_encode(model.lm_p, items, pooling, None, False, code, want_hidden=False, packed_rows=rows - 512)[1]
+            assert torch.isnan(small).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("pooling", ["first", "mean"])
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
 def test_packed_rows_t5_encoder_is_bit_identical_to_padded(pooling, dtype):

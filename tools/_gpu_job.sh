@@ -1,7 +1,5 @@
 set -u
-O=$PWD/gpurun_out/r06_lp; mkdir -p $O
+O=gpurun_out/r06_pk; mkdir -p $O
 export LD_LIBRARY_PATH=$PWD/openmatch_amd/csrc:${LD_LIBRARY_PATH:-}
-R=$PWD; cd /tmp; export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/st -- python $R/tools/train_bench.py --precision f16 --passages 16x512 --steps 10 > $O/prof.log 2>&1
-f=$(find $O/st -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats.csv
-head -12 $O/kernel_stats.csv | cut -d, -f1-4 | cut -c1-150
+timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "packed or beyond or tile_at" > $O/pytest.log 2>&1; echo "rc=$?"
+grep -E "passed|failed|Error|^E  " $O/pytest.log | cut -c1-300 | tail -8
