@@ -556,7 +556,7 @@ def test_model_batch_and_packed_rows_apply_conditions():
     assert not ok(cfg={"dtype": N.OM_F32}) and not ok(cfg={"hidden": 128}) and not ok(cfg={"act": N.ACT_RELU})
     assert ok(cfg={"arch": N.ARCH_T5, "act": N.ACT_RELU, "dtype": N.OM_BF16}) and not ok(cfg={"arch": N.ARCH_T5, "act": N.ACT_RELU}, gated=True)
     assert not ok(rows=256) and not ok(rows=4100) and not ok(rows=B * Lp) and ok(rows=B * Lp - 256)
-    assert not ok(L=512, rows=4096)
+    assert ok(L=512, rows=4096) and not ok(L=1100, rows=4096)       # (round 6: packed rows at every inference length the encoder takes)
     # the library's run-time switches are part of the answer (om_encoder_packed_supported): with the fused path switched off for an
     # A/B run the compact batch goes to the padded entry instead of failing inside the call
     lib = N.lib()
