@@ -84,7 +84,8 @@ void om_debug_gemm_gen(int gen);
 #define OM_OPT_ENCODER_FUSED_LN 0
 #define OM_OPT_ENCODER_DEBUG 1
 #define OM_OPT_ATTENTION_FAST 2   /* 1 (default): bf16 inference attention on the low-instruction-count kernel; 0: the generic kernel; bit 1 (tests): the
-                                     tile-at-a-time kernels that serve more than 256 tokens (forward with dropout, backward) at every length */
+                                     tile-at-a-time kernels that serve more than 256 tokens (forward with dropout, backward) at every length; bit 2 (A/B):
+                                     beyond 256 tokens the first online-softmax kernel instead of the chunked fast one (round 6) */
 #define OM_OPT_SCAN_GEN7 3        /* 1 (default): f16 index scan of wide query batches on the persistent generation-7 kernel; 0: generation 6 */
 #define OM_OPT_SCAN_GROWTH 4      /* fast schedule of the index scan: rows scanned per round grow by this many percent of the rows already
                                     * scanned (default 60; smaller = more rounds, tighter thresholds, fewer appends per tile) */

@@ -434,6 +434,200 @@ static int launch_attn16(const void* qkv, void* ctx, const int64_t* mask, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Beyond 256 tokens in the 16-bit formats (round 6): the body of the kernel above inside a loop over 128-key chunks with the online
+// softmax.  A workgroup owns 128 queries of one (sequence, head) -- four waves of 32 -- and per chunk: K and V rows by LDS-DMA
+// (row-major, swizzled on the source address), S^T = K Q^T, exp2 softmax against the running maximum, V^T fragments by transposing
+// LDS reads.  O^T keeps a query per LANE, so the rescaling by exp2(m_old - m_new) is one multiply per accumulator register with the
+// lane's own factor (the f32 kernel below keeps queries in registers and sends the factors through an LDS table).  Dropout, the T5
+// bias table and packed rows as in the kernel above.  Measured at 16 x 512 tokens, 12 heads: profiles/r06_train_long_sequences.txt.
+template <typename T, bool BIAS, bool DROP>
+__global__ __launch_bounds__(256, 2) void attention_fwd16c_kernel(
+    const T* __restrict__ qkv, T* __restrict__ ctx, const int64_t* __restrict__ mask,
+    const float* __restrict__ pos_bias, int Lm, int H, int heads, float scale, float drop_p, uint64_t seed, const int* __restrict__ cu) {
+  typedef typename MmaOps<T>::frag_t frag_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sK = smem;
+  char* const sV = smem + 128 * 128;
+  float* const sM = (float*)(smem + 2 * 128 * 128);
+  const int h = blockIdx.x % heads;
+  const int64_t b = blockIdx.x / heads;
+  int64_t row0 = b * Lm;
+  int L = Lm;
+  if (cu) {
+    const int c0 = __builtin_amdgcn_readfirstlane(cu[b]), c1 = __builtin_amdgcn_readfirstlane(cu[b + 1]);
+    row0 = c0; L = c1 - c0;
+  }
+  const int qb = blockIdx.y * 128;
+  if (qb >= L) return;                                      // (whole workgroup)
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t ld2 = 6 * (int64_t)H;                       // row pitch of qkv in bytes
+  const char* const base = (const char*)(qkv + row0 * 3 * (int64_t)H + h * 64);
+  const float LOG2E = 1.4426950408889634f;
+  const int q0 = qb + wave * 32;
+  const bool active = q0 < L;                               // (wave-uniform; an inactive wave still fetches its share of every chunk)
+  const int qrow = (q0 + l31) < L ? (q0 + l31) : (L - 1);
+  frag_t qf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const frag_t*)(base + (int64_t)qrow * ld2 + (kk * 2 + half) * 16);
+  const float c2 = scale * LOG2E;
+  const AttnDrop dr(drop_p);
+  const int key = (l31 >> 1) & 7;
+  const int i16 = lane & 15;
+  const char* const vt0 = sV + (4 * half + (i16 >> 2)) * 128 + 32 * ((lane >> 4) & 1) + 8 * (i16 & 3);
+  const int vsw = (i16 >> 3) & 1;
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16_t o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+
+  for (int kc = 0; kc < L; kc += 128) {
+    __syncthreads();                                         // the previous chunk has been consumed by every wave
+    // K and V rows kc .. kc + 127: instruction i of wave w moves rows (i * 4 + w) * 8 .. + 7, lane -> row (lane >> 3), physical
+    // 16-byte chunk (lane & 7) <- source chunk (lane & 7) ^ ((row >> 1) & 7) for K, ^ 4 ((row >> 1) & 1) for V (the kernel above)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (i * 4 + wave) * 8 + (lane >> 3);
+      const int rr = (kc + r) < L ? (kc + r) : (L - 1);
+      const uint32_t off = (uint32_t)(rr * ld2) + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+      const uint32_t offv = (uint32_t)(rr * ld2) + (((lane & 7) ^ (((r >> 1) & 1) << 2)) << 4);
+      const uint32_t dst = (uint32_t)((i * 4 + wave) * 1024);
+      g7_dma(base + 2 * H, off, g7_lds_addr(sK) + dst);
+      g7_dma(base + 4 * H, offv, g7_lds_addr(sV) + dst);
+    }
+    if (tid < 128) sM[tid] = (kc + tid) < L ? (mask[b * Lm + kc + tid] != 0 ? 0.f : -1e30f) : -INFINITY;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the DMA above is not in hipcc's bookkeeping
+    __syncthreads();
+    if (!active) continue;
+
+    f32x16_t s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+      const char* krow = sK + (t * 32 + l31) * 128;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const frag_t a = *(const frag_t*)(krow + (((kk * 2 + half) ^ key) << 4));
+        MmaOps<T>::mma(a, qf[kk], s[t]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float mx = m_run;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int k0 = t * 32 + 8 * g + 4 * half;
+        const f32x4_t mb = *(const f32x4_t*)(sM + k0);
+        f32x4_t pb = {0.f, 0.f, 0.f, 0.f};
+        if (BIAS) {
+          const float* pr = pos_bias + ((int64_t)h * Lm + qrow) * Lm;      // (the table's pitch: the padded length, also for packed rows)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pb[e] = pr[(kc + k0 + e) < Lm ? (kc + k0 + e) : (Lm - 1)] * LOG2E;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = fmaf(s[t][4 * g + e], c2, mb[e]) + pb[e];
+          s[t][4 * g + e] = v;
+          mx = fmaxf(mx, v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // the first chunk always holds key 0 (unmasked, or -1e30: finite): mx is finite from here on
+    const float alpha = __builtin_amdgcn_exp2f(m_run - mx);   // exp2(-inf) = 0 on the first chunk
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[t][r] - mx);
+        s[t][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    l_run = l_run * alpha + sum;
+    m_run = mx;
+    if (DROP) {       // (keyed with the mask's row pitch Lm: the backward kernels and a packed step regenerate the same mask)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const uint64_t bits = attn_drop_bits(seed, b, h, heads, Lm, q0 + l31, (kc + t * 32 + 8 * g + 4 * half) >> 2);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[t][4 * g + e] = attn_drop_keep(bits, e, dr.thresh) ? s[t][4 * g + e] : 0.f;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;        // O^T: this lane's query in every register
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      uint4 pa[2];      // probabilities of this key tile as two k slabs (k slot e of half h <-> register 8u + e)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        pa[u] = make_uint4(Half16<T>::pack2(s[t][8 * u + 0], s[t][8 * u + 1]), Half16<T>::pack2(s[t][8 * u + 2], s[t][8 * u + 3]),
+                           Half16<T>::pack2(s[t][8 * u + 4], s[t][8 * u + 5]), Half16<T>::pack2(s[t][8 * u + 6], s[t][8 * u + 7]));
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const char* p = vt0 + (t * 32 + 16 * u) * 128 + ((dt ^ vsw) << 6);
+          const frag_t vf = vfrag_of<frag_t>(vtrd(p), vtrd(p + 8 * 128));
+          MmaOps<T>::mma(vf, __builtin_bit_cast(frag_t, pa[u]), o[dt]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // O / l (x the keep scale): through the wave's own K rows, out as whole 128-byte rows (the kernel above)
+  __syncthreads();
+  if (!active) return;
+  const float inv = (DROP ? dr.keep_scale : 1.0f) / l_run;
+  char* const so = sK + (wave * 32) * 128;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      uint32_t a0 = Half16<T>::pack2(o[dt][8 * gp + 0] * inv, o[dt][8 * gp + 1] * inv), a1 = Half16<T>::pack2(o[dt][8 * gp + 2] * inv, o[dt][8 * gp + 3] * inv);
+      uint32_t b0 = Half16<T>::pack2(o[dt][8 * gp + 4] * inv, o[dt][8 * gp + 5] * inv), b1 = Half16<T>::pack2(o[dt][8 * gp + 6] * inv, o[dt][8 * gp + 7] * inv);
+      auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+      auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+      *(uint4*)(so + l31 * 128 + (((4 * dt + 2 * gp + half) ^ (l31 & 7)) << 4)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    }
+  char* const out = (char*)(ctx + (row0 + q0) * (int64_t)H + h * 64);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + (lane >> 3), c = lane & 7;
+    const uint4 v = *(const uint4*)(so + row * 128 + ((c ^ (row & 7)) << 4));
+    if (q0 + row < L) *(uint4*)(out + (int64_t)row * H * 2 + c * 16) = v;
+  }
+}
+
+template <typename T, bool BIAS, bool DROP>
+static int launch_attn16c_(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias, int64_t B, int L, int H,
+                           int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, const int* cu) {
+  const int lds = 2 * 128 * 128 + 128 * 4;
+  hipLaunchKernelGGL((attention_fwd16c_kernel<T, BIAS, DROP>), dim3((unsigned)(heads * B), (unsigned)((L + 127) / 128)), dim3(256), lds, s,
+                     (const T*)qkv, (T*)ctx, mask, pos_bias, L, H, heads, scale, drop_p, seed, cu);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T>
+static int launch_attn16c(const void* qkv, void* ctx, const int64_t* mask, const float* pos_bias, int64_t B, int L, int H,
+                          int heads, float scale, float drop_p, uint64_t seed, hipStream_t s, const int* cu) {
+  if (pos_bias && drop_p > 0.f) return launch_attn16c_<T, true, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, cu);
+  if (pos_bias) return launch_attn16c_<T, true, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, cu);
+  if (drop_p > 0.f) return launch_attn16c_<T, false, true>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, cu);
+  return launch_attn16c_<T, false, false>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, 0.f, 0, s, cu);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Long sequences (256 < L <= 1024, inference): the kernels above keep a whole score row per lane (L / 2 registers) and
 // all of K, V in LDS, which stops at 256 keys.  Document corpora are encoded at 512 tokens (the reference accepts anything
 // up to max_position_embeddings).  Here a workgroup owns 128 QUERIES of one (batch, head) -- four waves of 32 -- and walks
@@ -709,7 +903,8 @@ int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
   const bool force_long = (om_option(OM_OPT_ATTENTION_FAST) & 2) != 0 && dtype != OM_F32;
   if (dtype == OM_F16) {                                      // float16 inference mode: the fast kernel only
     if (L > 256 || force_long) {
-      return launch_attn_long<f16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s, drop_p, seed, cu);      // (with dropout: training up to 512 tokens, round 6)
+      if (!(om_option(OM_OPT_ATTENTION_FAST) & 4)) return launch_attn16c<f16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, cu);
+      return launch_attn_long<f16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s, drop_p, seed, cu);      // (bit 2, A/B: the first online-softmax kernel)
     }
     if (L <= 32) return launch_attn16<f16_t, 1>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
     if (L <= 64) return launch_attn16<f16_t, 2>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
@@ -718,6 +913,8 @@ int omk_attention(int dtype, const void* qkv, void* ctx, const int64_t* mask,
     return launch_attn16<f16_t, 8>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, reverse, kmax, cu);
   }
   if (L > 256 || force_long) {                                // online-softmax kernel, any dtype
+    if (dtype == OM_BF16 && om_option(OM_OPT_ATTENTION_FAST) && !(om_option(OM_OPT_ATTENTION_FAST) & 4))
+      return launch_attn16c<bf16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, drop_p, seed, s, cu);
     if (dtype == OM_BF16) return launch_attn_long<bf16_t>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s, drop_p, seed, cu);
     return launch_attn_long<float>(qkv, ctx, mask, pos_bias, B, L, H, heads, scale, s);
   }
