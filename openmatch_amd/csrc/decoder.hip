@@ -28,7 +28,8 @@ __global__ void dec_start_kernel(const float* __restrict__ emb, T* __restrict__ 
   if (i < B * H) ElemOps<T>::store(x + i, emb[i % H]);
 }
 
-// Single-query cross attention.  Block = (batch b, head h), 256 threads: thread l scores key l (L <= 256), block softmax,
+#define DEC_MAX_L 1024
+// Single-query cross attention.  Block = (batch b, head h), 256 threads: thread l scores keys l, l + 256, ... (L <= 1 024), block softmax,
 // then 64 threads x 4 row groups accumulate ctx[d] = sum_l p[l] V[l][d].  kv: [B, L, 2H] (K | V), q, ctx: [B, H].
 // Training: drop_p > 0 zeroes probabilities by the hash of (seed, (b heads + h) L + l) -- HF drops attention weights after
 // the softmax (modeling_t5.py T5Attention); the backward regenerates the same mask.
@@ -36,8 +37,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void dec_cross_kernel(const T* __restrict__ q, const T* __restrict__ kv,
                                                         const int64_t* __restrict__ mask, T* __restrict__ ctx, int L,
                                                         int H, int heads, float drop_p, uint64_t seed) {
+  constexpr int NJ = DEC_MAX_L / 256;          // keys per thread: l = tid + 256 j (round 6: up to 1 024 encoder positions; was 256)
   __shared__ float sq[64];
-  __shared__ float sp[256];
+  __shared__ float sp[DEC_MAX_L];
   __shared__ float red[8];
   __shared__ float part[4][64];
   const int h = blockIdx.x % heads;
@@ -45,23 +47,36 @@ __global__ __launch_bounds__(256) void dec_cross_kernel(const T* __restrict__ q,
   const int tid = threadIdx.x;
   if (tid < 64) sq[tid] = ElemOps<T>::load(q + b * H + h * 64 + tid);
   __syncthreads();
-  float sc = -INFINITY;
-  if (tid < L) {
-    const T* kr = kv + (b * L + tid) * 2 * (int64_t)H + h * 64;
-    float a = 0.f;
+  float sc[NJ];
+  float mxl = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int l = tid + 256 * j;
+    sc[j] = -INFINITY;
+    if (l < L) {
+      const T* kr = kv + (b * L + l) * 2 * (int64_t)H + h * 64;
+      float a = 0.f;
 #pragma unroll 8
-    for (int d = 0; d < 64; ++d) a = fmaf(sq[d], ElemOps<T>::load(kr + d), a);
-    sc = a + (mask[b * L + tid] != 0 ? 0.f : -3.4028235e38f);        // HF: (1 - mask) * finfo.min
+      for (int d = 0; d < 64; ++d) a = fmaf(sq[d], ElemOps<T>::load(kr + d), a);
+      sc[j] = a + (mask[b * L + l] != 0 ? 0.f : -3.4028235e38f);        // HF: (1 - mask) * finfo.min
+    }
+    mxl = fmaxf(mxl, sc[j]);
   }
-  float mx = wave_max(sc);
+  float mx = wave_max(mxl);
   if ((tid & 63) == 0) red[tid >> 6] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  const float e = tid < L ? expf(sc - mx) : 0.f;
-  float sum = wave_sum(e);
-  if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
   const DropCfg dc(drop_p);
-  sp[tid] = (dc.thresh && tid < L && !dropout_keep(seed, (uint64_t)blockIdx.x * (uint64_t)L + (uint64_t)tid, dc.thresh)) ? 0.f : e * (dc.thresh ? dc.keep_scale : 1.f);
+  float suml = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int l = tid + 256 * j;
+    const float e = l < L ? expf(sc[j] - mx) : 0.f;
+    suml += e;
+    sp[l] = (dc.thresh && l < L && !dropout_keep(seed, (uint64_t)blockIdx.x * (uint64_t)L + (uint64_t)l, dc.thresh)) ? 0.f : e * (dc.thresh ? dc.keep_scale : 1.f);
+  }
+  float sum = wave_sum(suml);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
   __syncthreads();
   const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
   const int d = tid & 63, grp = tid >> 6;
@@ -115,7 +130,7 @@ extern "C" int om_t5_decoder_step(const OmEncoderConfig* c, const OmT5DecoderWei
   if (c->arch != OM_ARCH_T5) OM_FAIL("decoder step: T5 only");
   if (c->dtype != OM_F32 && c->dtype != OM_BF16 && c->dtype != OM_F16) OM_FAIL("dtype must be OM_F32, OM_BF16 or OM_F16");
   if (c->head_dim != 64 || c->n_heads * 64 != c->hidden) OM_FAIL("head_dim must be 64 (inner dim == d_model)");
-  if (L < 1 || L > 256) OM_FAIL("sequence length must be in [1,256]");
+  if (L < 1 || L > DEC_MAX_L) OM_FAIL("sequence length must be in [1,1024]");
   if (!w->layers_host || w->n_layers < 1 || !w->start_emb || !w->final_ln_g) OM_FAIL("incomplete decoder weights");
   const int akind = c->act & 0xff;
   if (akind != OM_ACT_RELU && akind != OM_ACT_GELU_TANH) OM_FAIL("T5 decoder supports relu and gated gelu_new feed-forward layers");
@@ -214,8 +229,9 @@ __global__ __launch_bounds__(256) void dec_cross_bwd_kernel(const T* __restrict_
                                                             const int64_t* __restrict__ mask, const T* __restrict__ dctx,
                                                             T* __restrict__ dq, T* __restrict__ dkv, int L, int H, int heads,
                                                             float drop_p, uint64_t seed) {
+  constexpr int NJ = DEC_MAX_L / 256;          // keys per thread: l = tid + 256 j
   __shared__ float sq[64], sd[64];
-  __shared__ float sp[256];
+  __shared__ float sp[DEC_MAX_L];
   __shared__ float red[12];
   __shared__ float part[4][64];
   const int h = blockIdx.x % heads;
@@ -223,38 +239,61 @@ __global__ __launch_bounds__(256) void dec_cross_bwd_kernel(const T* __restrict_
   const int tid = threadIdx.x;
   if (tid < 64) { sq[tid] = ElemOps<T>::load(q + b * H + h * 64 + tid); sd[tid] = ElemOps<T>::load(dctx + b * H + h * 64 + tid); }
   __syncthreads();
-  float sc = -INFINITY, dpd = 0.f;
-  if (tid < L) {
-    const T* kr = kv + (b * L + tid) * 2 * (int64_t)H + h * 64;
-    float a = 0.f;
+  float sc[NJ], dpd[NJ];
+  float mxl = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int l = tid + 256 * j;
+    sc[j] = -INFINITY; dpd[j] = 0.f;
+    if (l < L) {
+      const T* kr = kv + (b * L + l) * 2 * (int64_t)H + h * 64;
+      float a = 0.f, dd = 0.f;
 #pragma unroll 8
-    for (int d = 0; d < 64; ++d) { a = fmaf(sq[d], ElemOps<T>::load(kr + d), a); dpd = fmaf(sd[d], ElemOps<T>::load(kr + H + d), dpd); }
-    sc = a + (mask[b * L + tid] != 0 ? 0.f : -3.4028235e38f);
+      for (int d = 0; d < 64; ++d) { a = fmaf(sq[d], ElemOps<T>::load(kr + d), a); dd = fmaf(sd[d], ElemOps<T>::load(kr + H + d), dd); }
+      sc[j] = a + (mask[b * L + l] != 0 ? 0.f : -3.4028235e38f);
+      dpd[j] = dd;
+    }
+    mxl = fmaxf(mxl, sc[j]);
   }
-  float mx = wave_max(sc);
+  float mx = wave_max(mxl);
   if ((tid & 63) == 0) red[tid >> 6] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  const float e = tid < L ? expf(sc - mx) : 0.f;
-  float sum = wave_sum(e);
+  float e[NJ];
+  float suml = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) { e[j] = (tid + 256 * j) < L ? expf(sc[j] - mx) : 0.f; suml += e[j]; }
+  float sum = wave_sum(suml);
   if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
   __syncthreads();
-  const float pl = e / ((red[4] + red[5]) + (red[6] + red[7]));
+  const float invs = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
   const DropCfg dc(drop_p);
-  const bool keep = !dc.thresh || (tid < L && dropout_keep(seed, (uint64_t)blockIdx.x * (uint64_t)L + (uint64_t)tid, dc.thresh));
   const float ks = dc.thresh ? dc.keep_scale : 1.f;
-  const float pd = keep ? pl * ks : 0.f;
-  const float dp = keep ? dpd * ks : 0.f;
-  float dot = wave_sum(pl * dp);
+  float pl[NJ], pd[NJ], dp[NJ];
+  float dotl = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int l = tid + 256 * j;
+    pl[j] = e[j] * invs;
+    const bool keep = !dc.thresh || (l < L && dropout_keep(seed, (uint64_t)blockIdx.x * (uint64_t)L + (uint64_t)l, dc.thresh));
+    pd[j] = keep ? pl[j] * ks : 0.f;
+    dp[j] = keep ? dpd[j] * ks : 0.f;
+    dotl += pl[j] * dp[j];
+  }
+  float dot = wave_sum(dotl);
   if ((tid & 63) == 0) red[8 + (tid >> 6)] = dot;
   __syncthreads();
   dot = (red[8] + red[9]) + (red[10] + red[11]);
-  const float ds = pl * (dp - dot);
-  sp[tid] = tid < L ? ds : 0.f;
-  if (tid < L) {
-    T* dr = dkv + (b * L + tid) * 2 * (int64_t)H + h * 64;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int l = tid + 256 * j;
+    const float ds = pl[j] * (dp[j] - dot);
+    sp[l] = l < L ? ds : 0.f;
+    if (l < L) {
+      T* dr = dkv + (b * L + l) * 2 * (int64_t)H + h * 64;
 #pragma unroll 8
-    for (int d = 0; d < 64; ++d) { ElemOps<T>::store(dr + d, ds * sq[d]); ElemOps<T>::store(dr + H + d, pd * sd[d]); }
+      for (int d = 0; d < 64; ++d) { ElemOps<T>::store(dr + d, ds * sq[d]); ElemOps<T>::store(dr + H + d, pd[j] * sd[d]); }
+    }
   }
   __syncthreads();
   const int d = tid & 63, grp = tid >> 6;
@@ -325,7 +364,7 @@ int dec_check(const OmEncoderConfig* c, const OmT5DecoderWeights* w, int64_t L) 
   if (c->arch != OM_ARCH_T5) OM_FAIL("decoder step: T5 only");
   if (c->dtype != OM_F32 && c->dtype != OM_BF16 && c->dtype != OM_F16) OM_FAIL("dtype must be OM_F32, OM_BF16 or OM_F16");
   if (c->head_dim != 64 || c->n_heads * 64 != c->hidden) OM_FAIL("head_dim must be 64 (inner dim == d_model)");
-  if (L < 1 || L > 256) OM_FAIL("sequence length must be in [1,256]");
+  if (L < 1 || L > DEC_MAX_L) OM_FAIL("sequence length must be in [1,1024]");
   if (!w->layers_host || w->n_layers < 1 || !w->start_emb || !w->final_ln_g) OM_FAIL("incomplete decoder weights");
   const int akind = c->act & 0xff;
   if (akind != OM_ACT_RELU && akind != OM_ACT_GELU_TANH) OM_FAIL("T5 decoder supports relu and gated gelu_new feed-forward layers");
