@@ -375,6 +375,34 @@ def few_rows_leg(model, device):
     return out
 
 
+def long_passages_leg(model, device):
+    """Encode at the lengths document corpora use (round 6): 256 x 512-token passages per batch -- the same 131 072 tokens as the headline
+    batch -- full length and ragged through the packed-rows entry.  Beyond 256 tokens attention runs on attention_fwd16c_kernel (the fast
+    kernel's body in an online-softmax loop over 128-key chunks); the contractions are the headline's."""
+    from openmatch_amd import encoder as enc_mod
+    from openmatch_amd.encoder import TOKEN_ROWS_KEY, token_rows_of
+    B, L = 256, 512
+    g = torch.Generator(device=device).manual_seed(512)
+    ids = torch.randint(1000, 30000, (B, L), device=device, generator=g)
+    full = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
+    lens = torch.randint(64, L + 1, (B,), generator=torch.Generator().manual_seed(7))
+    mask = (torch.arange(L)[None, :] < lens[:, None]).long()
+    ragged = {"input_ids": ids, "attention_mask": mask.to(device)}
+    ragged_packed = dict(ragged); ragged_packed[TOKEN_ROWS_KEY] = token_rows_of(mask)      # the token counts a collator's host-side mask gives
+    out = {"metric": "passages/s encode at 512 tokens per passage (bert-base, float16, 256 passages per batch)", "tokens_per_batch": B * L}
+    for name, items in (("full_length", full), ("ragged_padded", ragged), ("ragged_packed", ragged_packed)):
+        for _ in range(2):
+            model(passage=items)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5):
+            model(passage=items)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+        out[name] = {"passages_per_s": round(B / dt, 1), "ms_per_batch": round(dt * 1e3, 2), "rows": dict(enc_mod.LAST_CALL)}
+    out["full_length"]["tokens_per_s"] = round(B * L / (out["full_length"]["ms_per_batch"] * 1e-3))
+    out["ragged_tokens"] = int(lens.sum())
+    return out
+
+
 def packed_leg(model, batches, a, L):
     """The SAME timed batches through om_encoder_forward_packed: only the rows up to each sequence's last token (lengths
     ~ U{16..128}) enter the embedding, the contractions and the normalisations; attention runs per sequence.  The
@@ -625,7 +653,7 @@ def main():
         parity = parity_leg(model, lm, batches, device, headline=a.precision)
 
     # ---------------- exact-f32 mode and the training step (sub-objects; N = 1 only) ----------
-    f32_mode, train, f16_mode, packed_mode, few_rows = None, None, None, None, None
+    f32_mode, train, f16_mode, packed_mode, few_rows, long_passages = None, None, None, None, None, None
     other16 = "bf16" if a.precision == "f16" else "f16"
     if rank == 0 and not dist_on and not a.no_extra and half:
         # the OTHER 16-bit format on the SAME timed batches (same kernels and MFMA rate): bfloat16 carries its pre-LayerNorm
@@ -648,6 +676,7 @@ def main():
         torch.cuda.empty_cache()
         packed_mode = packed_leg(model, batches, a, L)
         few_rows = few_rows_leg(model, device)
+        long_passages = long_passages_leg(model, device)
         m32 = DRModelForInference(lm_q=lm, lm_p=lm, pooling="first",
                                   model_args=NS(encoder_only=False, dtype="float32")).to(device).eval()
         sub = {k: v[:256] for k, v in batches[0].items()}
@@ -693,7 +722,7 @@ def main():
                                  {"scaling": "strong" if world > 1 else "single shard",
                                   "index_rows": [shard_range(a.index_rows, world, r)[0] for r in range(world)],
                                   "query_slices": [shard_range(a.queries, world, r)[0] for r in range(world)]})},
-            "roofline": roofline, "search": search, "parity": parity, other16: f16_mode, "packed": packed_mode, "few_rows": few_rows, "f32": f32_mode, "train": train, "cpu_baseline": cpu,
+            "roofline": roofline, "search": search, "parity": parity, other16: f16_mode, "packed": packed_mode, "few_rows": few_rows, "long_passages": long_passages, "f32": f32_mode, "train": train, "cpu_baseline": cpu,
         }
         print(json.dumps(line), file=json_out, flush=True)
     if dist_on:
