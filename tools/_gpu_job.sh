@@ -1,9 +1,7 @@
 set -u
-O=gpurun_out/r06_lb; mkdir -p $O
+O=gpurun_out/r06_m; mkdir -p $O
 export LD_LIBRARY_PATH=$PWD/openmatch_amd/csrc:${LD_LIBRARY_PATH:-}
-timeout 600 python bench.py --steps 5 --warmup 2 --no-search --no-cpu-baseline --no-parity > $O/bench.json 2>$O/err.log; echo rc=$?
-python -c "
-import json
-d=json.loads([l for l in open('$O/bench.json') if l.startswith('{')][-1])
-print(d['value'], json.dumps(d.get('long_passages')))
-"; tail -3 $O/err.log | cut -c1-300
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity_base.py -m gpu -q -x -k "train or attention or packed or t5 or gradient or grad" > $O/pytest.log 2>&1; echo "rc=$?"
+grep -E "passed|failed|Error|^E  " $O/pytest.log | cut -c1-300 | tail -6
+for cfg in 32x256 40x200 64x128; do echo "$cfg $(timeout 300 python tools/train_bench.py --precision f16 --passages $cfg --steps 20 2>&1 | tail -1 | cut -c90-160)"; done
+echo "t5 32x256 $(timeout 300 python tools/train_bench.py --arch t5 --precision f16 --passages 32x256 --steps 20 2>&1 | tail -1 | cut -c100-175)"
