@@ -419,9 +419,9 @@ int t5_train_backward(const OmEncoderConfig* c, const OmEncoderWeights* w, const
     WGRAD(dA, H, ctx, H, lg.o_w);
     e = GemmEpilogue{};
     RUN(omk_gemm(dt, dA, H, wt.o, H, dt, ws.dctx, H, M, H, H, e, s));         // dctx = dA Wo
-    // (round 6) beyond 256 tokens -- and from 129 on, where the transposing-read kernel stops: the generic kernel keeps a whole score row in
-    // registers and runs 14-20 % of a step slower there (profiles/r06_train_long_sequences.txt) --
-    if (d.L > 256 || (!d.packed && dt != OM_F32 && ((om_option(OM_OPT_ATTENTION_FAST) & 2) || ((om_option(OM_OPT_ATTENTION_FAST) & 1) && d.L > 128))))      // one score tile in registers at a time, delta from the tape's attention output
+    // (round 6) beyond 256 tokens -- and from 193 on: the generic kernel keeps a whole score row in registers, which is fine up to six key tiles
+    // (it wins by 4-7 % of a step at 144 ... 192 tokens) and 20 % of a step slower with eight (profiles/r06_train_long_sequences.txt) --
+    if (d.L > 256 || (!d.packed && dt != OM_F32 && ((om_option(OM_OPT_ATTENTION_FAST) & 2) || ((om_option(OM_OPT_ATTENTION_FAST) & 1) && d.L > 192))))      // one score tile in registers at a time, delta from the tape's attention output
       RUN(omk_attention_bwd_long(dt, qkv, ctx, ws.dctx, ws.dqkv, attention_mask, d.B, (int)d.L, H, d.nh, 1.0f, ad,
                                  site_seed(seed, l, 2), ws.posbias, ws.drel, ws.astats, s));
     else
@@ -857,8 +857,8 @@ static int train_backward_impl(const OmEncoderConfig* c, const OmEncoderWeights*
       RUN(omk_gemm(dt, dA, H, wt.o, H, dt, ws.dctx, H, M, H, H, e3, s));    // dctx = dA Wo
     }
     WGRAD_DONE(l + 1, 3);                                           // ws.dqkv: last read by dWqkv of the layer above
-    // (round 6) beyond 256 tokens -- and from 129 on, where the transposing-read kernel stops (see t5_train_backward) --
-    if (L > 256 || (!d.packed && dt != OM_F32 && ((om_option(OM_OPT_ATTENTION_FAST) & 2) || ((om_option(OM_OPT_ATTENTION_FAST) & 1) && L > 128))))      // one score tile in registers at a time, delta from the tape's attention output
+    // (round 6) beyond 256 tokens -- and from 193 on (see t5_train_backward) --
+    if (L > 256 || (!d.packed && dt != OM_F32 && ((om_option(OM_OPT_ATTENTION_FAST) & 2) || ((om_option(OM_OPT_ATTENTION_FAST) & 1) && L > 192))))      // one score tile in registers at a time, delta from the tape's attention output
       RUN(omk_attention_bwd_long(dt, qkv, ctx, ws.dctx, dqkvl, attention_mask, B, (int)L, H, d.nh, scale,
                                  attn_dropout, site_seed(seed, l, 2), nullptr, nullptr, ws.astats, s));
     else
